@@ -1,0 +1,48 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- see mc_oracle_impl.inc for the contract and
+ * the reference citations.  Builds libmc_oracle.so with the fp32 and fp64
+ * instantiations of the restated Muskingum-Cunge segment step and network
+ * loop.  Compile with:  gcc -O2 -ffp-contract=off -fPIC -shared (Makefile).
+ */
+#include <math.h>
+
+#define REAL float
+#define SFX(x) x##_f32
+#define POW powf
+#define SQRT sqrtf
+#define FABS fabsf
+#define FMAX(a, b) ((a) > (b) ? (a) : (b)) /* Fortran MAX on non-NaN operands */
+#define FMIN(a, b) ((a) < (b) ? (a) : (b))
+#include "mc_oracle_impl.inc"
+#undef REAL
+#undef SFX
+#undef POW
+#undef SQRT
+#undef FABS
+
+#define REAL double
+#define SFX(x) x##_f64
+#define POW pow
+#define SQRT sqrt
+#define FABS fabs
+#include "mc_oracle_impl.inc"
+
+/* Batch driver for the WRF-Hydro original through oracle/wrf_bind.f90
+ * (argument order of MUSKINGCUNGE.f90:8-12).  in[n][15] uses the same column
+ * order as mc_oracle_segments_f32; out[n][3] = qdc velc depthc. */
+typedef void (*wrf_fn)(const float *qup, const float *quc, const float *qdp, const float *ql,
+                       const float *dt, const float *so, const float *dx, const float *n,
+                       const float *cs, const float *bw, const float *tw, const float *twcc,
+                       const float *ncc, const float *depthp, float *qdc, float *velc,
+                       float *depthc);
+void mc_oracle_wrf_segments_f32(wrf_fn f, long n, const float *in, float *out)
+{
+    long i;
+    for (i = 0; i < n; ++i) {
+        const float *a = in + 15 * i;
+        float *o = out + 3 * i;
+        o[0] = o[1] = o[2] = 0.0f;
+        f(&a[1], &a[2], &a[3], &a[4], &a[0], &a[12], &a[5], &a[9], &a[11], &a[6], &a[7],
+          &a[8], &a[10], &a[14], &o[0], &o[1], &o[2]);
+    }
+}

@@ -1,0 +1,154 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front end of the CPU oracle.
+
+Wraps oracle/libmc_oracle.so (the C restatement, mc_oracle_impl.inc) and, when
+present, the oracle/_ref/*.so builds of the reference Fortran
+(oracle/Makefile `make ref`).  Never imported by the product package.
+
+Column order of a segment input row (15): dt qup quc qdp ql dx bw tw twcc n ncc
+cs s0 velp depthp ; output row (6): qdc velc depthc ck cn X  -- the argument
+order of c_muskingcungenwm
+(/root/reference/src/kernel/muskingum/pyMCsingleSegStime_NoLoop.f90:8-21).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+IN_COLS = ("dt", "qup", "quc", "qdp", "ql", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0",
+           "velp", "depthp")
+OUT_COLS = ("qdc", "velc", "depthc", "ck", "cn", "X")
+# column order of the params block handed to network(): column_mapper order,
+# /root/reference/src/troute-routing/troute/routing/fast_reach/mc_reach.pyx:150-162
+PARAM_COLS = ("dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0")
+
+_CT = {np.dtype("float32"): (C.c_float, "f32"), np.dtype("float64"): (C.c_double, "f64")}
+
+
+def build(force=False):
+    """Compile the C restatement (and, if /root/reference exists, oracle/_ref)."""
+    so = os.path.join(_HERE, "libmc_oracle.so")
+    if force or not os.path.exists(so) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
+        for f in ("mc_oracle.c", "mc_oracle_impl.inc")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "libmc_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src/kernel/muskingum"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def segments(inputs, return_iters=False):
+    """Restated kernel over rows of `inputs` [n,15] (float32 or float64)."""
+    inputs = np.ascontiguousarray(inputs)
+    ct, sfx = _CT[inputs.dtype]
+    n = inputs.shape[0]
+    out = np.zeros((n, 6), dtype=inputs.dtype)
+    iters = np.zeros(n, dtype=np.int32)
+    fn = getattr(lib(), f"mc_oracle_segments_{sfx}")
+    fn.restype = None
+    fn(C.c_long(n), _ptr(inputs, ct), _ptr(out, ct), _ptr(iters, C.c_int))
+    return (out, iters) if return_iters else out
+
+
+def ref_path(name):
+    return os.path.join(_HERE, "_ref", name)
+
+
+def have_ref(name="libmc_ref_qj0_f32.so"):
+    return os.path.exists(ref_path(name))
+
+
+_REFS = {}
+
+
+def ref_symbol(name, symbol):
+    """Address of `symbol` in oracle/_ref/<name> as a void pointer."""
+    key = (name, symbol)
+    if key not in _REFS:
+        h = C.CDLL(ref_path(name))
+        _REFS[key] = (h, C.cast(getattr(h, symbol), C.c_void_p))
+    return _REFS[key][1]
+
+
+F32_SYMBOL = "c_muskingcungenwm"
+F64_SYMBOL = "_QMmuskingcunge_modulePmuskingcungenwm"
+
+
+def ref_segments(inputs, name=None):
+    """A reference build (c_muskingcungenwm signature) over rows of `inputs`."""
+    inputs = np.ascontiguousarray(inputs)
+    ct, sfx = _CT[inputs.dtype]
+    if name is None:
+        name = f"libmc_ref_qj0_{sfx}.so"
+    sym = ref_symbol(name, F32_SYMBOL if sfx == "f32" else F64_SYMBOL)
+    n = inputs.shape[0]
+    out = np.zeros((n, 6), dtype=inputs.dtype)
+    fn = getattr(lib(), f"mc_oracle_ref_segments_{sfx}")
+    fn.restype = None
+    fn(sym, C.c_long(n), _ptr(inputs, ct), _ptr(out, ct))
+    return out
+
+
+def wrf_segments(inputs):
+    """Unmodified WRF-Hydro submuskingcunge over rows of `inputs` [n,15] f32 -> [n,3]."""
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+    sym = ref_symbol("libmc_wrf_f32.so", "c_submuskingcunge")
+    n = inputs.shape[0]
+    out = np.zeros((n, 3), dtype=np.float32)
+    fn = lib().mc_oracle_wrf_segments_f32
+    fn.restype = None
+    fn(sym, C.c_long(n), _ptr(inputs, C.c_float), _ptr(out, C.c_float))
+    return out
+
+
+def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assume_short_ts,
+            prefilled=None, fvd_init=None, ref_name=None, return_iters=False):
+    """Reference network loop (mc_reach.pyx:492-750 restated).
+
+    reaches   : list of int arrays (row positions, upstream->downstream), list order
+    upstreams : list of int arrays (row positions summed at the head of each reach)
+    params    : [nseg, 9] in PARAM_COLS order;  q0 [nseg,3];  qlat [nseg,nq]
+    returns   : fvd [nseg, nsteps+1, 3]   (column 0 of axis 1 = initial state)
+    """
+    params = np.ascontiguousarray(params)
+    dt = params.dtype
+    ct, sfx = _CT[dt]
+    q0 = np.ascontiguousarray(q0, dtype=dt)
+    qlat = np.ascontiguousarray(qlat, dtype=dt)
+    nseg = params.shape[0]
+    reach_ptr = np.zeros(len(reaches) + 1, dtype=np.int64)
+    reach_ptr[1:] = np.cumsum([len(r) for r in reaches])
+    reach_seg = (np.concatenate([np.asarray(r, dtype=np.int64) for r in reaches])
+                 if reaches else np.zeros(0, np.int64))
+    up_ptr = np.zeros(len(upstreams) + 1, dtype=np.int64)
+    up_ptr[1:] = np.cumsum([len(u) for u in upstreams])
+    up_idx = (np.concatenate([np.asarray(u, dtype=np.int64) for u in upstreams] + [np.zeros(0, np.int64)]))
+    fvd = np.zeros((nseg, nsteps + 1, 3), dtype=dt) if fvd_init is None else np.ascontiguousarray(fvd_init, dtype=dt)
+    pre = None if prefilled is None else np.ascontiguousarray(prefilled, dtype=np.uint8)
+    ref = C.c_void_p(0)
+    if ref_name is not None:
+        ref = ref_symbol(ref_name, F32_SYMBOL if sfx == "f32" else F64_SYMBOL)
+    iters = C.c_long(0)
+    fn = getattr(lib(), f"mc_oracle_network_{sfx}")
+    fn.restype = None
+    fn(C.c_long(nseg), C.c_int(nsteps), C.c_int(qts_subdivisions), C.c_long(len(reaches)),
+       _ptr(reach_ptr, C.c_long), _ptr(reach_seg, C.c_long), _ptr(up_ptr, C.c_long),
+       _ptr(up_idx, C.c_long), _ptr(params, ct), _ptr(q0, ct), _ptr(qlat, ct),
+       C.c_long(qlat.shape[1]), C.c_int(int(bool(assume_short_ts))),
+       None if pre is None else _ptr(pre, C.c_ubyte), _ptr(fvd, ct), ref, C.byref(iters))
+    return (fvd, iters.value) if return_iters else fvd
