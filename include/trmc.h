@@ -1,0 +1,178 @@
+/*
+ * trmc.h -- C ABI of the MI355X-native Muskingum-Cunge routing engine
+ * (libtrmc.so, built from t-route_amd/csrc/ for gfx950).
+ *
+ * This is the drop-in boundary for ONE reference path:
+ *
+ *   troute.routing.compute.compute_nhd_routing_v02
+ *     -> troute.routing.fast_reach.mc_reach.compute_network_structured
+ *        -> reach.muskingcunge -> c_muskingcungenwm (Fortran)
+ *
+ * Reference interfaces replaced (paths relative to the T-Route tree):
+ *   [R1] src/troute-routing/troute/routing/fast_reach/mc_reach.pyx:164-224
+ *        compute_network_structured(...)  -- whole-network, all timesteps
+ *   [R2] src/troute-routing/troute/routing/fast_reach/reach.pyx:66-103
+ *        compute_reach_kernel(...) -> dict  -- one segment, one timestep
+ *   [R3] src/kernel/muskingum/pyMCsingleSegStime_NoLoop.f90:8-21 and
+ *        src/troute-routing/troute/routing/fast_reach/pyMCsingleSegStime_NoLoop.h:1-21
+ *        c_muskingcungenwm(21 float*)  -- the Fortran bind(c) symbol
+ *   [R4] src/troute-network/troute/network/musking/mc_reach_structs.h:8-17,
+ *        reach_structs.h:11-25  -- AoS _MC_Segment/_MC_Reach/_Reach, replaced
+ *        by the plan's SoA columns + CSR upstream lists
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns 0 on success or a
+ *     negative trmc_status and leaves a message in trmc_last_error()
+ *     (thread-local).  The reference raises ValueError for shape errors
+ *     (mc_reach.pyx:243-250); the Python shim maps TRMC_EINVAL to ValueError
+ *     and everything else to RuntimeError.
+ *   - "row" = position in the caller's segment table (the reference's
+ *     data_idx order: ascending segment id, compute.py:1447-1461).
+ *   - real arrays are float (precision 32) or double (precision 64), chosen at
+ *     plan creation; the reference computes in float
+ *     (src/kernel/muskingum/varPrecision.f90:5).
+ *   - there is no CPU fallback: with no HIP device every entry point that
+ *     computes fails with TRMC_ENODEVICE.
+ */
+#ifndef TRMC_H
+#define TRMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRMC_ABI_VERSION 1
+
+typedef enum trmc_status {
+    TRMC_OK = 0,
+    TRMC_EINVAL = -1,    /* bad argument / shape mismatch  -> ValueError     */
+    TRMC_ECYCLE = -2,    /* upstream graph is not acyclic  -> ValueError     */
+    TRMC_ENODEVICE = -3, /* no usable HIP device           -> RuntimeError   */
+    TRMC_EHIP = -4,      /* HIP runtime error              -> RuntimeError   */
+    TRMC_ENOMEM = -5,    /* allocation failed              -> MemoryError    */
+    TRMC_ESTATE = -6     /* call order violated (e.g. download before route) */
+} trmc_status;
+
+/* Parameter column order of `params` (9 columns, row-major [nseg][9]): the
+ * order column_mapper produces for the reference kernel, mc_reach.pyx:150-162 */
+enum { TRMC_P_DT = 0, TRMC_P_DX, TRMC_P_BW, TRMC_P_TW, TRMC_P_TWCC, TRMC_P_N,
+       TRMC_P_NCC, TRMC_P_CS, TRMC_P_S0, TRMC_NPARAM };
+
+typedef struct trmc_plan trmc_plan;
+
+/* Per-route timing and shape facts, filled by trmc_route_device().  Times are
+ * HIP-event times on the plan's own stream. */
+typedef struct trmc_stats {
+    int64_t nseg;            /* rows in the plan (incl. boundary rows)        */
+    int64_t nseg_routed;     /* rows that are computed                         */
+    int32_t nlevels;         /* topological depth in segments                  */
+    int32_t nsteps;          /* timesteps of the last route                    */
+    int32_t assume_short_ts;
+    int32_t main_launches;   /* launches of the segment-step kernel            */
+    int64_t segment_steps;   /* nseg_routed * nsteps                           */
+    double ms_prep;          /* forcing transpose + initial-state scatter      */
+    double ms_main;          /* all launches of the segment-step kernel        */
+    double ms_emit;          /* [t][seg] -> [row][t][q,v,d] transpose          */
+    double ms_total;         /* prep + main + emit                             */
+} trmc_stats;
+
+const char *trmc_last_error(void);
+int trmc_abi_version(void);
+int trmc_device_count(int *count);
+
+/*
+ * Build a routing plan: topology flattened to segment levels, parameters laid
+ * out as SoA columns in level-major order, everything resident in HBM.
+ * Replaces the MC_Segment/MC_Reach object construction of [R1]
+ * (mc_reach.pyx:283-378) and [R4].
+ *
+ *   nseg      rows
+ *   up_ptr    [nseg+1] CSR offsets; up_idx[up_ptr[r]..up_ptr[r+1]) are the rows
+ *             whose flow enters row r, IN THE ORDER THE REFERENCE SUMS THEM
+ *             (mc_reach.pyx:499-502: upstream_connections[reach[0]] for the
+ *             head of a reach, the previous segment inside a reach)
+ *   params    [nseg][TRMC_NPARAM] float (always float: compute.py:549)
+ *   boundary  [nseg] or NULL; non-zero marks a row that is not routed but
+ *             carries a prescribed hydrograph (the reference's
+ *             upstream_results rows, mc_reach.pyx:451-469)
+ *   precision 32 or 64
+ *   device    HIP device ordinal
+ */
+int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                     const float *params, const uint8_t *boundary, int precision,
+                     int device, trmc_plan **out);
+void trmc_plan_destroy(trmc_plan *plan);
+
+/* Host-only topology flattening (no device needed): the same routine the plan
+ * uses.  level_of_row[nseg] (-1 for boundary rows), plan_pos_of_row[nseg],
+ * *nlevels; any output pointer may be NULL.  TRMC_ECYCLE if the graph is cyclic. */
+int trmc_topology_levels(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                         const uint8_t *boundary, int32_t *level_of_row,
+                         int64_t *plan_pos_of_row, int32_t *nlevels);
+
+/* Facts about the flattened topology (host side, no device work). */
+int trmc_plan_info(const trmc_plan *plan, int64_t *nseg, int64_t *nseg_routed,
+                   int32_t *nlevels, int32_t *precision, int32_t *device);
+/* level_of_row[nseg] (-1 for boundary rows); plan_pos_of_row[nseg] = position in
+ * the level-major device order.  Either pointer may be NULL. */
+int trmc_plan_levels(const trmc_plan *plan, int32_t *level_of_row, int64_t *plan_pos_of_row);
+
+/*
+ * Stage one routing window's forcing into HBM (H2D).  Arrays are in row order,
+ * element type per the plan's precision.
+ *   qlat          [nseg][nq]   lateral inflow per forcing interval
+ *   q0            [nseg][3]    qu0 qd0 h0  (mc_reach.pyx:361: initial q = column
+ *                              0, initial depth = column 2)
+ *   boundary_fvd  [nboundary][nsteps][3] q,v,d hydrographs of the boundary rows
+ *                 in ascending row order, or NULL when the plan has none
+ */
+int trmc_upload_forcing(trmc_plan *plan, int nsteps, const void *qlat, int64_t nq,
+                        const void *q0, const void *boundary_fvd);
+
+/*
+ * Route nsteps timesteps on the device (asynchronous launches on the plan's
+ * stream, then waits for completion).  Replaces the time x reach loop of [R1]
+ * (mc_reach.pyx:492-505, :719-750) and the per-reach chain of
+ * compute_reach_kernel (mc_reach.pyx:70-138).
+ *   qts_subdivisions  timesteps per forcing interval (qlat column = (t-1)/qts)
+ *   assume_short_ts   non-zero: quc := qup (mc_reach.pyx:504-505, :135-136)
+ * Results stay in HBM until downloaded.
+ */
+int trmc_route_device(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_short_ts);
+
+/* Full result, row order: fvd_out[nseg][nsteps][3] = (q, vel, depth) per step,
+ * i.e. flowveldepth[:, 1:, :] of [R1] (mc_reach.pyx:807-813).  D2H. */
+int trmc_download_fvd(trmc_plan *plan, void *fvd_out);
+/* Final state in the reference's q0 layout, new_q0 = fvd[:, [-3,-3,-1]]
+ * (AbstractNetwork.py:182-190): q0_out[nseg][3] = (q_T, q_T, depth_T).  D2H. */
+int trmc_download_final_state(trmc_plan *plan, void *q0_out);
+/* Flow hydrographs of selected rows (e.g. network outlets):
+ * out[nrows][nsteps].  dst_is_device != 0: `out` is a device pointer on the
+ * plan's device (used to hand outlet hydrographs to RCCL without a host trip). */
+int trmc_gather_flow_rows(trmc_plan *plan, const int64_t *rows, int64_t nrows, void *out,
+                          int dst_is_device);
+
+int trmc_get_stats(const trmc_plan *plan, trmc_stats *stats);
+
+/* Convenience: upload + route + download in one call (what the drop-in
+ * compute_network_structured shim uses). */
+int trmc_route(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_short_ts,
+               const void *qlat, int64_t nq, const void *q0, const void *boundary_fvd,
+               void *fvd_out);
+
+/*
+ * Batch of independent single-segment steps on the device: the GPU
+ * counterpart of calling [R3]/[R2] n times.
+ *   in   [n][15]  dt qup quc qdp ql dx bw tw twcc n ncc cs s0 velp depthp
+ *   out  [n][6]   qdc velc depthc ck cn X
+ * precision 32: float arrays; 64: double arrays.  qdc is taken as 0 on entry,
+ * as reach.pyx:55 passes it.
+ */
+int trmc_segments(int device, int precision, int64_t n, const void *in, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRMC_H */

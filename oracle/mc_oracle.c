@@ -20,6 +20,29 @@
 #undef SQRT
 #undef FABS
 
+/* fp32 with the bit-reproducible power the GPU uses (t-route_amd/csrc/det_pow.h):
+ * same restated algorithm, only POW differs.  GPU fp32 results are compared
+ * bit-for-bit with this instantiation; it is itself compared with the libm
+ * instantiation above (which is pinned bit-exactly to the reference Fortran). */
+#include "../t-route_amd/csrc/det_pow.h"
+#define REAL float
+#define SFX(x) x##_f32det
+#define POW trmc_det_powf
+#define SQRT sqrtf
+#define FABS fabsf
+#include "mc_oracle_impl.inc"
+#undef REAL
+#undef SFX
+#undef POW
+#undef SQRT
+#undef FABS
+
+void mc_oracle_det_powf(long n, const float *x, const float *y, float *out)
+{
+    long i;
+    for (i = 0; i < n; ++i) out[i] = trmc_det_powf(x[i], y[i]);
+}
+
 #define REAL double
 #define SFX(x) x##_f64
 #define POW pow

@@ -52,10 +52,31 @@ def _ptr(a, ct):
     return a.ctypes.data_as(C.POINTER(ct))
 
 
-def segments(inputs, return_iters=False):
-    """Restated kernel over rows of `inputs` [n,15] (float32 or float64)."""
+def _sfx(dtype, det):
+    ct, sfx = _CT[np.dtype(dtype)]
+    if det:
+        if sfx != "f32":
+            raise ValueError("the bit-reproducible power exists for float32 only")
+        sfx = "f32det"
+    return ct, sfx
+
+
+def det_powf(x, y):
+    """t-route_amd/csrc/det_pow.h evaluated on the host (elementwise, float32)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(np.broadcast_to(np.asarray(y, dtype=np.float32), x.shape))
+    out = np.empty_like(x)
+    fn = lib().mc_oracle_det_powf
+    fn.restype = None
+    fn(C.c_long(x.size), _ptr(x, C.c_float), _ptr(y, C.c_float), _ptr(out, C.c_float))
+    return out
+
+
+def segments(inputs, return_iters=False, det=False):
+    """Restated kernel over rows of `inputs` [n,15] (float32 or float64).
+    det=True: use the bit-reproducible power of det_pow.h instead of libm powf."""
     inputs = np.ascontiguousarray(inputs)
-    ct, sfx = _CT[inputs.dtype]
+    ct, sfx = _sfx(inputs.dtype, det)
     n = inputs.shape[0]
     out = np.zeros((n, 6), dtype=inputs.dtype)
     iters = np.zeros(n, dtype=np.int32)
@@ -117,7 +138,7 @@ def wrf_segments(inputs):
 
 
 def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assume_short_ts,
-            prefilled=None, fvd_init=None, ref_name=None, return_iters=False):
+            prefilled=None, fvd_init=None, ref_name=None, return_iters=False, det=False):
     """Reference network loop (mc_reach.pyx:492-750 restated).
 
     reaches   : list of int arrays (row positions, upstream->downstream), list order
@@ -127,7 +148,7 @@ def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assu
     """
     params = np.ascontiguousarray(params)
     dt = params.dtype
-    ct, sfx = _CT[dt]
+    ct, sfx = _sfx(dt, det)
     q0 = np.ascontiguousarray(q0, dtype=dt)
     qlat = np.ascontiguousarray(qlat, dtype=dt)
     nseg = params.shape[0]
@@ -142,7 +163,7 @@ def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assu
     pre = None if prefilled is None else np.ascontiguousarray(prefilled, dtype=np.uint8)
     ref = C.c_void_p(0)
     if ref_name is not None:
-        ref = ref_symbol(ref_name, F32_SYMBOL if sfx == "f32" else F64_SYMBOL)
+        ref = ref_symbol(ref_name, F64_SYMBOL if sfx == "f64" else F32_SYMBOL)
     iters = C.c_long(0)
     fn = getattr(lib(), f"mc_oracle_network_{sfx}")
     fn.restype = None

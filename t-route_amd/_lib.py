@@ -1,0 +1,100 @@
+"""ctypes binding of libtrmc.so (include/trmc.h).
+
+The library is the product: if it is missing or does not load, importing this
+module's ``lib()`` raises -- there is no Python or CPU fallback for the
+routing arithmetic.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrmc.so")
+
+TRMC_OK, TRMC_EINVAL, TRMC_ECYCLE, TRMC_ENODEVICE, TRMC_EHIP, TRMC_ENOMEM, TRMC_ESTATE = 0, -1, -2, -3, -4, -5, -6
+NPARAM = 9
+PARAM_COLS = ("dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0")  # trmc.h TRMC_P_*
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("nseg", C.c_int64), ("nseg_routed", C.c_int64), ("nlevels", C.c_int32), ("nsteps", C.c_int32),
+        ("assume_short_ts", C.c_int32), ("main_launches", C.c_int32), ("segment_steps", C.c_int64),
+        ("ms_prep", C.c_double), ("ms_main", C.c_double), ("ms_emit", C.c_double), ("ms_total", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
+_P = C.POINTER
+# name -> (restype, argtypes); must list every symbol include/trmc.h declares
+SIGNATURES = {
+    "trmc_last_error": (C.c_char_p, []),
+    "trmc_abi_version": (_int, []),
+    "trmc_device_count": (_int, [_P(_int)]),
+    "trmc_plan_create": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _int, _P(_vp)]),
+    "trmc_plan_destroy": (None, [_vp]),
+    "trmc_topology_levels": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
+    "trmc_plan_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i32), _P(_i32), _P(_i32)]),
+    "trmc_plan_levels": (_int, [_vp, _vp, _vp]),
+    "trmc_upload_forcing": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
+    "trmc_route_device": (_int, [_vp, _int, _int, _int]),
+    "trmc_download_fvd": (_int, [_vp, _vp]),
+    "trmc_download_final_state": (_int, [_vp, _vp]),
+    "trmc_gather_flow_rows": (_int, [_vp, _vp, _i64, _vp, _int]),
+    "trmc_get_stats": (_int, [_vp, _P(Stats)]),
+    "trmc_route": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp]),
+    "trmc_segments": (_int, [_int, _int, _i64, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libtrmc.so (once).  Raises if the HIP library is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C t-route_amd/csrc).  There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = h
+    return _LIB
+
+
+def check(rc):
+    """Map a trmc_status to the exception the reference would raise."""
+    if rc == TRMC_OK:
+        return
+    msg = lib().trmc_last_error().decode("utf-8", "replace")
+    if rc in (TRMC_EINVAL, TRMC_ECYCLE):
+        raise ValueError(msg)
+    if rc == TRMC_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(f"trmc error {rc}: {msg}")
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().trmc_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def np_dtype(precision):
+    if precision == 32:
+        return np.float32
+    if precision == 64:
+        return np.float64
+    raise ValueError("precision must be 32 or 64")

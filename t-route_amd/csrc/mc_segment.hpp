@@ -1,0 +1,275 @@
+// mc_segment.hpp -- one Muskingum-Cunge segment-timestep, precision-generic.
+//
+// Device arithmetic of the engine.  Semantics follow the reference Fortran
+// (paths relative to the T-Route tree):
+//   src/kernel/muskingum/MCsingleSegStime_f2py_NOLOOP.f90
+//     muskingcungenwm :8-186, secant2_h :198-334, courant :342-367,
+//     hydraulic_geometry :374-444
+// with the canonical initialisation Qj_0 = 0 at label 110 (the shipped routine
+// reads Qj_0 uninitialised at :92-93; its parent sets it,
+// src/kernel/muskingum/MUSKINGCUNGE.f90:100, and
+// src/kernel/muskingum/test_MC_kernel.py:36-40 asserts equality with the parent).
+//
+// Layout of the computation (not of the reference's call tree):
+//   * ChannelConst   everything that depends only on the channel parameters is
+//                    formed once per segment-step (side distance z, bankfull
+//                    depth, sqrt(s0), sqrt(1+z^2), the two Manning factors);
+//   * SecantPoint    one evaluation of the residual  Q_mc(h) - Q_manning(h);
+//   * mc_segment_step the bracketed secant iteration, outflow, velocity, depth.
+// The same operations, in the same order and rounding as the reference, so the
+// fp32 instantiation is bit-comparable with the fp32 Fortran wherever pow()
+// agrees; compile with -ffp-contract=off.
+//
+// Math policy M:  M::sqrt(x); M::pow(x, y); and, so that x**a and x**b can share
+// one logarithm, M::Log, M::log_of(x), M::pow_l(log_of(x), x, y) == M::pow(x, y).
+//
+// The header is host/device neutral on purpose: tests/host_harness.cpp
+// instantiates it with libm on the CPU to check the logic against the oracle
+// without a GPU.  The shipped library only ever instantiates it in device code.
+#pragma once
+
+#if defined(__HIPCC__)
+#define MC_HD __host__ __device__ __forceinline__
+#else
+#define MC_HD inline
+#endif
+
+namespace trmc {
+
+template <class T> MC_HD T mc_max(T a, T b) { return a > b ? a : b; }
+template <class T> MC_HD T mc_min(T a, T b) { return a < b ? a : b; }
+template <class T> MC_HD T mc_abs(T a) { return a < T(0) ? -a : a; }
+
+// Channel parameters of one segment, as the reference names them.
+template <class T> struct ChannelParams {
+    T dt, dx, bw, tw, twcc, n, ncc, cs, s0;
+};
+
+// Segment-invariant quantities.
+template <class T> struct ChannelConst {
+    T z;          // side distance 1/cs (1 when cs == 0)            f90:49-53
+    T bfd;        // bankfull depth                                 f90:55-61
+    T sqrt_s0;    // sqrt(s0)
+    T sq1pz2;     // sqrt(1 + z*z)
+    T s0_n;       // sqrt(s0)/n
+    T s0_ncc;     // sqrt(s0)/ncc
+    T two_sq;     // 2*sqrt(1 + z*z)
+    T half_dt;    // dt/2
+    bool fp_ok;   // twcc > 0 && ncc > 0 : flood-plain terms may activate
+};
+
+template <class T, class M>
+MC_HD ChannelConst<T> make_const(const ChannelParams<T> &p)
+{
+    ChannelConst<T> c;
+    c.z = (p.cs == T(0)) ? T(1) : T(1) / p.cs;
+    if (p.bw > p.tw)
+        c.bfd = p.bw / T(0.00001);
+    else if (p.bw == p.tw)
+        c.bfd = p.bw / (T(2) * c.z);
+    else
+        c.bfd = (p.tw - p.bw) / (T(2) * c.z);
+    c.sqrt_s0 = M::sqrt(p.s0);
+    c.sq1pz2 = M::sqrt(T(1) + c.z * c.z);
+    c.s0_n = c.sqrt_s0 / p.n;
+    c.s0_ncc = c.sqrt_s0 / p.ncc;
+    c.two_sq = T(2) * c.sq1pz2;
+    c.half_dt = p.dt / T(2);
+    c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
+    return c;
+}
+
+// Wetted geometry at depth h (f90:374-444).
+template <class T> struct Section {
+    T twl, area, areac, wp, wpc, R, h_in, h_over;
+};
+
+template <class T, class M>
+MC_HD Section<T> section_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c)
+{
+    Section<T> s;
+    s.twl = p.bw + T(2) * c.z * h;
+    s.h_over = mc_max(h - c.bfd, T(0));
+    s.h_in = mc_min(c.bfd, h);
+    if (s.h_over > T(0) && p.twcc <= T(0)) { // NWM 3.0: no flood plain -> extend trapezoid
+        s.h_over = T(0);
+        s.h_in = h;
+    }
+    s.area = (p.bw + s.h_in * c.z) * s.h_in;
+    s.wp = p.bw + T(2) * s.h_in * c.sq1pz2;
+    s.areac = p.twcc * s.h_over;
+    s.wpc = (s.h_over > T(0)) ? p.twcc + (T(2) * s.h_over) : T(0);
+    s.R = (s.area + s.areac) / (s.wp + s.wpc);
+    return s;
+}
+
+// Muskingum coefficients carried from one residual evaluation to the next
+// (the reference keeps them alive through intent(out) dummies, f90:92-95).
+template <class T> struct MuskCoef {
+    T C1, C2, C3, C4, X;
+};
+
+// Boundary flows of one segment-step.
+template <class T> struct Inflow {
+    T qup, quc, qdp, ql;
+};
+
+// Residual Q_mc(h) - Q_manning(h) at depth h (f90:198-334).
+//   LOWER=false: "interval 1": X from the previous residual `qj_prev`, clamp [0,0.5]
+//   LOWER=true : "interval 2": X from the coefficients just left in `k`, clamp [0.25,0.5]
+template <class T, class M, bool LOWER>
+MC_HD T secant_residual(T h, T qj_prev, const ChannelParams<T> &p, const ChannelConst<T> &c,
+                        const Inflow<T> &f, MuskCoef<T> &k)
+{
+    const T c23 = T(2) / T(3), c53 = T(5) / T(3);
+    const Section<T> s = section_at<T, M>(h, p, c);
+    const bool over = (h > c.bfd) && c.fp_ok;
+
+    // R**(2/3) and R**(5/3) share one logarithm (M::Log), see det_pow.h
+    const typename M::Log lr = M::log_of(s.R);
+    const T r23 = M::pow_l(lr, s.R, c23);
+    T ck;
+    if (over) {
+        ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * M::pow_l(lr, s.R, c53)
+                                                  * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
+                               * s.area
+                           + (c.s0_ncc * c53 * M::pow(h - c.bfd, c23)) * s.areac)
+                              / (s.area + s.areac));
+    } else if (h > T(0)) {
+        ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * M::pow_l(lr, s.R, c53)
+                                                 * (c.two_sq / (p.bw + T(2) * h * c.z)))));
+    } else {
+        ck = T(0);
+    }
+
+    const T km = (ck > T(0)) ? mc_max(p.dt, p.dx / ck) : p.dt;
+
+    T x;
+    if (ck > T(0)) {
+        const T width = over ? p.twcc : s.twl;
+        const T denom = T(2) * width * p.s0 * ck * p.dx;
+        if (!LOWER)
+            x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - (qj_prev / denom))));
+        else
+            x = mc_min(T(0.5),
+                       mc_max(T(0.25),
+                              T(0.5) * (T(1) - (((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4)
+                                                / denom))));
+    } else {
+        x = T(0.5);
+    }
+
+    const T d = (km * (T(1) - x) + c.half_dt);
+    k.C1 = (km * x + c.half_dt) / d;
+    k.C2 = (c.half_dt - km * x) / d;
+    k.C3 = (km * (T(1) - x) - c.half_dt) / d;
+    k.C4 = (f.ql * p.dt) / d;
+    k.X = x;
+    if (LOWER) {
+        const T w = (k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp);
+        if ((k.C4 < T(0)) && (mc_abs(k.C4) > w)) k.C4 = -w;
+    }
+
+    if ((s.wp + s.wpc) > T(0))
+        return ((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4)
+               - ((T(1) / (((s.wp * p.n) + (s.wpc * p.ncc)) / (s.wp + s.wpc))) * (s.area + s.areac) * r23
+                  * c.sqrt_s0);
+    return T(0);
+}
+
+// Kinematic celerity and Courant number at depth h (f90:342-367; unguarded).
+template <class T, class M>
+MC_HD void courant_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, T &ck, T &cn)
+{
+    const T c23 = T(2) / T(3), c53 = T(5) / T(3);
+    const Section<T> s = section_at<T, M>(h, p, c);
+    const typename M::Log lr = M::log_of(s.R);
+    ck = mc_max(T(0), (c.s0_n * (c53 * M::pow_l(lr, s.R, c23)
+                                  - (c23 * M::pow_l(lr, s.R, c53) * (c.two_sq / (p.bw + T(2) * s.h_in * c.z))))
+                           * s.area
+                       + (c.s0_ncc * c53 * M::pow(s.h_over, c23)) * s.areac)
+                          / (s.area + s.areac));
+    cn = ck * (p.dt / p.dx);
+}
+
+template <class T> struct StepResult {
+    T qdc, velc, depthc; // outflow, velocity, depth at the new time level
+    T h;                 // depth the iteration ended on (courant uses it even with no flow)
+    T X;                 // last weighting factor (0 when nothing was routed)
+};
+
+// One segment, one timestep (f90:8-186).
+template <class T, class M>
+MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &f, T depthp)
+{
+    const ChannelConst<T> c = make_const<T, M>(p);
+    const T mindepth = T(0.01);
+    StepResult<T> out;
+
+    const T depth0 = mc_max(depthp, T(0));
+    T h = (depth0 * T(1.33)) + mindepth;
+    T h_0 = (depth0 * T(0.67));
+
+    if (!(f.ql > T(0) || f.qup > T(0) || f.quc > T(0) || f.qdp > T(0))) {
+        out.qdc = T(0); out.velc = T(0); out.depthc = T(0); out.h = h; out.X = T(0);
+        return out;
+    }
+
+    MuskCoef<T> k{T(0), T(0), T(0), T(0), T(0)};
+    T aerror = T(0.01), rerror = T(1);
+    int maxiter = 100, tries = 0;
+    for (;;) {
+        T qj_0 = T(0);
+        int iter = 0;
+        while (rerror > T(0.01) && aerror >= mindepth && iter <= maxiter) {
+            qj_0 = secant_residual<T, M, false>(h_0, qj_0, p, c, f, k);
+            const T qj = secant_residual<T, M, true>(h, T(0), p, c, f, k);
+            T h_1;
+            if (qj_0 - qj != T(0)) {
+                h_1 = h - ((qj * (h_0 - h)) / (qj_0 - qj));
+                if (h_1 < T(0)) h_1 = h;
+            } else {
+                h_1 = h;
+            }
+            if (h > T(0)) {
+                rerror = mc_abs((h_1 - h) / h);
+                aerror = mc_abs(h_1 - h);
+            } else {
+                rerror = T(0);
+                aerror = T(0.9);
+            }
+            h_0 = mc_max(T(0), h);
+            h = mc_max(T(0), h_1);
+            ++iter;
+            if (h < mindepth) break;
+        }
+        if (iter >= maxiter && ++tries <= 4) { // widen the bracket and retry
+            h = h * T(1.33);
+            h_0 = h_0 * T(0.67);
+            maxiter += 25;
+            continue;
+        }
+        break;
+    }
+
+    const T w3 = (k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp);
+    if ((w3 + k.C4) < T(0)) {
+        if ((k.C4 < T(0)) && (mc_abs(k.C4) > w3))
+            out.qdc = T(0);
+        else
+            out.qdc = mc_max(((k.C1 * f.qup) + (k.C2 * f.quc) + k.C4), ((k.C1 * f.qup) + (k.C3 * f.qdp) + k.C4));
+    } else {
+        out.qdc = w3 + k.C4;
+    }
+
+    const T twl = p.bw + T(2) * c.z * h;
+    const T a = (twl - p.bw) / T(2);
+    const T R = (h * (p.bw + twl) / T(2)) / (p.bw + T(2) * M::sqrt(a * a + h * h));
+    out.velc = (T(1) / p.n) * M::pow(R, T(2) / T(3)) * c.sqrt_s0;
+    out.depthc = h;
+    out.h = h;
+    out.X = k.X;
+    return out;
+}
+
+} // namespace trmc

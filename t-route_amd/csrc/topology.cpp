@@ -1,0 +1,168 @@
+// topology.cpp -- see topology.hpp.
+#include "topology.hpp"
+
+#include <algorithm>
+#include <limits>
+
+namespace trmc {
+
+int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                   const uint8_t *boundary, Topology &t, std::string &err)
+{
+    if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
+        err = "nseg out of range";
+        return -1;
+    }
+    if (nseg > 0 && (!up_ptr || up_ptr[0] != 0)) {
+        err = "up_ptr must start at 0";
+        return -1;
+    }
+    const int64_t nnz = nseg ? up_ptr[nseg] : 0;
+    for (int64_t r = 0; r < nseg; ++r)
+        if (up_ptr[r + 1] < up_ptr[r]) {
+            err = "up_ptr is not monotone at row " + std::to_string(r);
+            return -1;
+        }
+    if (nnz >= std::numeric_limits<int32_t>::max()) {
+        err = "too many upstream links";
+        return -1;
+    }
+    for (int64_t k = 0; k < nnz; ++k)
+        if (up_idx[k] < 0 || up_idx[k] >= nseg) {
+            err = "up_idx[" + std::to_string(k) + "] = " + std::to_string(up_idx[k]) + " is not a row";
+            return -1;
+        }
+
+    t = Topology();
+    t.nseg = nseg;
+    auto is_b = [&](int64_t r) { return boundary && boundary[r] != 0; };
+
+    // downstream CSR over routed rows (edges u -> r for routed r)
+    std::vector<int32_t> down_ptr(nseg + 1, 0), indeg(nseg, 0);
+    for (int64_t r = 0; r < nseg; ++r) {
+        if (is_b(r)) continue;
+        for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) {
+            const int64_t u = up_idx[k];
+            if (u == r) {
+                err = "row " + std::to_string(r) + " lists itself as upstream";
+                return -2;
+            }
+            ++down_ptr[u + 1];
+            if (!is_b(u)) ++indeg[r];
+        }
+    }
+    for (int64_t r = 0; r < nseg; ++r) down_ptr[r + 1] += down_ptr[r];
+    std::vector<int32_t> down_idx(down_ptr[nseg]);
+    {
+        std::vector<int32_t> fill(down_ptr.begin(), down_ptr.end() - 1);
+        for (int64_t r = 0; r < nseg; ++r) {
+            if (is_b(r)) continue;
+            for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k)
+                down_idx[fill[up_idx[k]]++] = (int32_t)r;
+        }
+    }
+
+    // levels: longest path from a headwater, Kahn order
+    t.level_of_row.assign(nseg, -1);
+    std::vector<int32_t> queue;
+    queue.reserve(nseg);
+    int64_t nrouted = 0;
+    for (int64_t r = 0; r < nseg; ++r) {
+        if (is_b(r)) {
+            t.boundary_rows.push_back((int32_t)r);
+            continue;
+        }
+        ++nrouted;
+        if (indeg[r] == 0) {
+            t.level_of_row[r] = 0;
+            queue.push_back((int32_t)r);
+        }
+    }
+    t.nboundary = (int64_t)t.boundary_rows.size();
+    int32_t maxlevel = -1;
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const int32_t r = queue[head];
+        const int32_t lr = t.level_of_row[r];
+        maxlevel = std::max(maxlevel, lr);
+        for (int32_t k = down_ptr[r]; k < down_ptr[r + 1]; ++k) {
+            const int32_t dn = down_idx[k];
+            t.level_of_row[dn] = std::max(t.level_of_row[dn], lr + 1);
+            if (--indeg[dn] == 0) queue.push_back(dn);
+        }
+    }
+    if ((int64_t)queue.size() != nrouted) {
+        err = "upstream graph has a cycle (" + std::to_string(nrouted - (int64_t)queue.size())
+              + " rows unreachable from headwaters)";
+        return -2;
+    }
+    t.nlevels = maxlevel + 1;
+
+    // depth-first rank from the outlets, walking upstream in the reference's order
+    std::vector<int32_t> rank_order; // routed rows in preorder
+    rank_order.reserve(nrouted);
+    {
+        std::vector<uint8_t> seen(nseg, 0);
+        std::vector<int32_t> stack;
+        for (int64_t o = 0; o < nseg; ++o) {
+            if (is_b(o) || seen[o]) continue;
+            // outlet: routed row that feeds no routed row
+            if (down_ptr[o + 1] != down_ptr[o]) continue;
+            stack.push_back((int32_t)o);
+            seen[o] = 1;
+            while (!stack.empty()) {
+                const int32_t r = stack.back();
+                stack.pop_back();
+                rank_order.push_back(r);
+                // push in reverse so the first-listed upstream is visited first
+                for (int64_t k = up_ptr[r + 1] - 1; k >= up_ptr[r]; --k) {
+                    const int32_t u = (int32_t)up_idx[k];
+                    if (!is_b(u) && !seen[u]) {
+                        seen[u] = 1;
+                        stack.push_back(u);
+                    }
+                }
+            }
+        }
+    }
+    if ((int64_t)rank_order.size() != nrouted) { // cannot happen in a DAG
+        err = "internal: depth-first walk missed rows";
+        return -2;
+    }
+
+    // stable counting sort of the preorder by level
+    t.lvl_ptr.assign(t.nlevels + 1, 0);
+    for (int32_t r : rank_order) ++t.lvl_ptr[t.level_of_row[r] + 1];
+    t.lvl_ptr[0] = (int32_t)t.nboundary;
+    for (int32_t l = 0; l < t.nlevels; ++l) t.lvl_ptr[l + 1] += t.lvl_ptr[l];
+    t.pos_of_row.assign(nseg, -1);
+    t.row_of_pos.assign(nseg, -1);
+    for (int64_t b = 0; b < t.nboundary; ++b) {
+        t.pos_of_row[t.boundary_rows[b]] = (int32_t)b;
+        t.row_of_pos[b] = t.boundary_rows[b];
+    }
+    {
+        std::vector<int32_t> fill(t.lvl_ptr.begin(), t.lvl_ptr.end() - 1);
+        for (int32_t r : rank_order) {
+            const int32_t p = fill[t.level_of_row[r]]++;
+            t.pos_of_row[r] = p;
+            t.row_of_pos[p] = r;
+        }
+    }
+
+    // upstream CSR over plan positions (boundary rows keep an empty list)
+    t.up_ptr.assign(nseg + 1, 0);
+    for (int64_t p = 0; p < nseg; ++p) {
+        const int32_t r = t.row_of_pos[p];
+        t.up_ptr[p + 1] = t.up_ptr[p] + (is_b(r) ? 0 : (int32_t)(up_ptr[r + 1] - up_ptr[r]));
+    }
+    t.up_idx.resize(t.up_ptr[nseg]);
+    for (int64_t p = 0; p < nseg; ++p) {
+        const int32_t r = t.row_of_pos[p];
+        if (is_b(r)) continue;
+        int32_t w = t.up_ptr[p];
+        for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) t.up_idx[w++] = t.pos_of_row[up_idx[k]];
+    }
+    return 0;
+}
+
+} // namespace trmc

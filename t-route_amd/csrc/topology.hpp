@@ -1,0 +1,40 @@
+// topology.hpp -- host-side flattening of a river network into segment levels.
+//
+// Input is the computational graph the reference builds out of reach lists and
+// upstream_connections (mc_reach.pyx:283-289, :367-378): for every row the
+// ordered list of rows whose flow enters it.  Output is the level-major device
+// order the kernels use:
+//   level(row) = 0 for headwaters, 1 + max(level(upstream rows)) otherwise;
+//   boundary rows (prescribed hydrographs) get level -1 and constrain nothing;
+//   rows are ordered by (level, depth-first rank from the outlets) so that each
+//   level is one contiguous slice and rows that are neighbours inside a level
+//   have neighbouring upstream rows in the slices before it (coalesced gathers).
+// This replaces the reference's reach ordering contract ("every reach's
+// upstream reaches precede it", nhd_network.py:503-557) by an explicit level
+// structure; a reach of n segments simply occupies n consecutive levels.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace trmc {
+
+struct Topology {
+    int64_t nseg = 0;
+    int64_t nboundary = 0;
+    int32_t nlevels = 0;                 // number of routed levels (max level + 1)
+    std::vector<int32_t> level_of_row;   // [nseg], -1 = boundary
+    std::vector<int32_t> pos_of_row;     // [nseg] row -> plan position
+    std::vector<int32_t> row_of_pos;     // [nseg] plan position -> row
+    std::vector<int32_t> lvl_ptr;        // [nlevels+1] plan-position offsets of the routed levels
+                                         // (positions [0, lvl_ptr[0]) hold the boundary rows)
+    std::vector<int32_t> up_ptr;         // [nseg+1] CSR over plan positions
+    std::vector<int32_t> up_idx;         // upstream plan positions, reference summation order
+    std::vector<int32_t> boundary_rows;  // ascending rows flagged as boundary
+};
+
+// Returns 0 on success; -1 bad argument, -2 cycle.  `err` receives a message.
+int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                   const uint8_t *boundary, Topology &topo, std::string &err);
+
+} // namespace trmc

@@ -1,0 +1,760 @@
+// trmc.hip -- HIP kernels and C ABI of the MI355X Muskingum-Cunge engine (gfx950).
+//
+// Data layout in HBM (plan order = level-major, see topology.hpp):
+//   params      8 SoA columns [nseg_pad] (dx bw tw twcc n ncc cs s0) + dt (scalar, or a
+//               9th column when the caller's dt column is not uniform)
+//   up_ptr/idx  CSR of upstream plan positions (int32)
+//   level       int32 [nseg_pad]
+//   qlat_tm     [nq][nseg_pad]           forcing, one coalesced row per forcing interval
+//   q/v/d_tm    [nsteps+1][nseg_pad]     time-major state AND result: step t reads row
+//               t-1 (own previous flow/depth, upstream previous flows) and, without the
+//               short-timestep assumption, row t of upstream levels
+//   out         [nseg][nsteps][3]        caller layout (mc_reach.pyx:807-813), produced
+//               by an LDS-tiled transpose at the end of the route
+// nseg_pad rounds nseg up to 64 so every time row starts on a 256-byte boundary.
+//
+// Launch structure
+//   assume_short_ts = 1 : step t of every segment depends only on step t-1
+//       (mc_reach.pyx:504-505, :135-136) -> one launch per timestep over all
+//       routed segments.
+//   assume_short_ts = 0 : (level l, step t) depends on (<l, t) and (l, t-1)
+//       -> anti-diagonal wavefront d = l + t; the segments of all levels on
+//       one diagonal form ONE contiguous slice of the plan order and run as
+//       one launch; nlevels + nsteps - 1 launches in total.
+// One thread per segment-step; all loads/stores are unit-stride except the
+// upstream gather, which the intra-level ordering keeps near-monotone.
+//
+// No CPU fallback exists in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/trmc.h"
+#include "det_pow.h"
+#include "mc_segment.hpp"
+#include "topology.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? TRMC_ENOMEM : TRMC_EHIP,                   \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+// ---------------------------------------------------------------- device math
+// fp32: the bit-reproducible power of det_pow.h (IEEE double + - * / fma only), so the
+// whole fp32 path is bit-comparable with the host oracle; sqrtf and / are the
+// correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+struct DevMathF {
+    using Log = double;
+    static __device__ __forceinline__ Log log_of(float x) { return trmc_det_log2((double)x); }
+    static __device__ __forceinline__ float pow_l(Log l, float, float y) { return trmc_det_powf_from_log(l, y); }
+    static __device__ __forceinline__ float pow(float x, float y) { return trmc_det_powf(x, y); }
+    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+};
+// fp64: device libm pow (about 1 ulp; not bit-reproducible against glibc)
+struct DevMathD {
+    using Log = double;
+    static __device__ __forceinline__ Log log_of(double x) { return x; }
+    static __device__ __forceinline__ double pow_l(Log, double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+};
+template <class T> struct DevMath;
+template <> struct DevMath<float> { using type = DevMathF; };
+template <> struct DevMath<double> { using type = DevMathD; };
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------- kernels
+template <class T> struct StepArgs {
+    const T *dx, *bw, *tw, *twcc, *n, *ncc, *cs, *s0;
+    const T *dt_col; // nullptr -> uniform dt
+    T dt;
+    const int32_t *up_ptr, *up_idx, *level;
+    const T *qlat_tm;
+    T *q_tm, *v_tm, *d_tm;
+    int64_t nseg_pad;
+    int32_t nsteps, qts;
+};
+
+// One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
+// positions [s_begin, s_end).
+template <class T, bool SHORT>
+__global__ void __launch_bounds__(kBlock)
+k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag)
+{
+    using M = typename DevMath<T>::type;
+    const int32_t s = s_begin + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (s >= s_end) return;
+    const int32_t t = SHORT ? diag : diag - a.level[s];
+    if (t < 1 || t > a.nsteps) return;
+
+    const size_t row_p = (size_t)(t - 1) * (size_t)a.nseg_pad; // previous time level
+    const size_t row_c = (size_t)t * (size_t)a.nseg_pad;       // current time level
+
+    trmc::ChannelParams<T> p;
+    p.dt = a.dt_col ? a.dt_col[s] : a.dt;
+    p.dx = a.dx[s];
+    p.bw = a.bw[s];
+    p.tw = a.tw[s];
+    p.twcc = a.twcc[s];
+    p.n = a.n[s];
+    p.ncc = a.ncc[s];
+    p.cs = a.cs[s];
+    p.s0 = a.s0[s];
+
+    trmc::Inflow<T> f;
+    f.qdp = a.q_tm[row_p + s];
+    const T depthp = a.d_tm[row_p + s];
+    f.ql = a.qlat_tm[(size_t)((t - 1) / a.qts) * (size_t)a.nseg_pad + s];
+
+    // junction sums in the reference's order (mc_reach.pyx:499-502)
+    T qup = T(0), quc = T(0);
+    const int32_t k0 = a.up_ptr[s], k1 = a.up_ptr[s + 1];
+    for (int32_t k = k0; k < k1; ++k) {
+        const int32_t u = a.up_idx[k];
+        qup += a.q_tm[row_p + u];
+        if (!SHORT) quc += a.q_tm[row_c + u];
+    }
+    f.qup = qup;
+    f.quc = SHORT ? qup : quc;
+
+    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp);
+    a.q_tm[row_c + s] = r.qdc;
+    a.v_tm[row_c + s] = r.velc;
+    a.d_tm[row_c + s] = r.depthc;
+}
+
+// forcing: in[row][nq] (caller order) -> qlat_tm[j][pos]; LDS tile of 64 positions x 32 columns
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_prep_qlat(const T *__restrict__ in, const int32_t *__restrict__ row_of_pos, T *__restrict__ qlat_tm,
+            int32_t nseg, int64_t nseg_pad, int32_t nq)
+{
+    __shared__ T tile[32][65];
+    const int32_t p0 = blockIdx.x * 64;
+    const int32_t j0 = blockIdx.y * 32;
+    const int32_t nj = min(32, nq - j0);
+    for (int32_t i = threadIdx.x; i < 64 * 32; i += kBlock) {
+        const int32_t pl = i / 32, jl = i % 32;
+        const int32_t p = p0 + pl;
+        if (p < nseg && jl < nj) tile[jl][pl] = in[(size_t)row_of_pos[p] * nq + j0 + jl];
+    }
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < 64 * 32; i += kBlock) {
+        const int32_t jl = i / 64, pl = i % 64;
+        const int32_t p = p0 + pl;
+        if (p < nseg && jl < nj) qlat_tm[(size_t)(j0 + jl) * nseg_pad + p] = tile[jl][pl];
+    }
+}
+
+// initial state: time row 0 <- q0[row] = (qu0, qd0, h0)   (mc_reach.pyx:361)
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_init_state(const T *__restrict__ q0, const int32_t *__restrict__ row_of_pos, T *q_tm, T *v_tm, T *d_tm,
+             int32_t nseg)
+{
+    const int32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= nseg) return;
+    const size_t r = (size_t)row_of_pos[p] * 3;
+    q_tm[p] = q0[r + 0];
+    v_tm[p] = q0[r + 1];
+    d_tm[p] = q0[r + 2];
+}
+
+// boundary rows: prescribed hydrographs bfvd[b][t-1][c] -> time rows 1..nsteps at position b
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_fill_boundary(const T *__restrict__ bfvd, T *q_tm, T *v_tm, T *d_tm, int32_t nboundary, int32_t nsteps,
+                int64_t nseg_pad)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)nboundary * nsteps) return;
+    const int32_t b = (int32_t)(i / nsteps), t = (int32_t)(i % nsteps) + 1;
+    const size_t src = ((size_t)b * nsteps + (t - 1)) * 3;
+    const size_t dst = (size_t)t * nseg_pad + b;
+    q_tm[dst] = bfvd[src + 0];
+    v_tm[dst] = bfvd[src + 1];
+    d_tm[dst] = bfvd[src + 2];
+}
+
+// result: time-major SoA -> out[row][t-1][3]; tile = 64 positions x 64 steps through LDS
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_emit(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restrict__ d_tm,
+       const int32_t *__restrict__ row_of_pos, T *__restrict__ out, int32_t nseg, int64_t nseg_pad,
+       int32_t nsteps)
+{
+    __shared__ T tile[64][3 * 64 + 1]; // [position][step*3 + c]
+    const int32_t p0 = blockIdx.x * 64;
+    const int32_t t0 = blockIdx.y * 64; // zero-based output step
+    const int32_t nt = min(64, nsteps - t0);
+    for (int32_t i = threadIdx.x; i < 64 * 64; i += kBlock) {
+        const int32_t tl = i / 64, pl = i % 64;
+        const int32_t p = p0 + pl;
+        if (p < nseg && tl < nt) {
+            const size_t src = (size_t)(t0 + tl + 1) * nseg_pad + p;
+            tile[pl][tl * 3 + 0] = q_tm[src];
+            tile[pl][tl * 3 + 1] = v_tm[src];
+            tile[pl][tl * 3 + 2] = d_tm[src];
+        }
+    }
+    __syncthreads();
+    const int32_t wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    for (int32_t pl = wave; pl < 64; pl += kBlock / 64) {
+        const int32_t p = p0 + pl;
+        if (p >= nseg) break;
+        T *dst = out + ((size_t)row_of_pos[p] * nsteps + t0) * 3;
+        for (int32_t e = lane; e < nt * 3; e += 64) dst[e] = tile[pl][e];
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_final_state(const T *__restrict__ q_tm, const T *__restrict__ d_tm, const int32_t *__restrict__ row_of_pos,
+              T *__restrict__ q0_out, int32_t nseg, int64_t nseg_pad, int32_t nsteps)
+{
+    const int32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= nseg) return;
+    const size_t src = (size_t)nsteps * nseg_pad + p;
+    const size_t r = (size_t)row_of_pos[p] * 3;
+    const T q = q_tm[src];
+    q0_out[r + 0] = q;
+    q0_out[r + 1] = q;
+    q0_out[r + 2] = d_tm[src];
+}
+
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_gather_rows(const T *__restrict__ q_tm, const int32_t *__restrict__ pos, T *__restrict__ out, int64_t nrows,
+              int64_t nseg_pad, int32_t nsteps)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrows * nsteps) return;
+    const int64_t r = i / nsteps;
+    const int32_t t = (int32_t)(i % nsteps) + 1;
+    out[i] = q_tm[(size_t)t * nseg_pad + pos[r]];
+}
+
+// independent single-segment steps: in[n][15] -> out[n][6] (with courant), cf. reach.pyx:66-103
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
+{
+    using M = typename DevMath<T>::type;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const T *x = in + i * 15;
+    trmc::ChannelParams<T> p;
+    trmc::Inflow<T> f;
+    p.dt = x[0]; f.qup = x[1]; f.quc = x[2]; f.qdp = x[3]; f.ql = x[4];
+    p.dx = x[5]; p.bw = x[6]; p.tw = x[7]; p.twcc = x[8]; p.n = x[9]; p.ncc = x[10];
+    p.cs = x[11]; p.s0 = x[12];
+    const T depthp = x[14];
+    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp);
+    T ck, cn;
+    const trmc::ChannelConst<T> c = trmc::make_const<T, M>(p);
+    trmc::courant_at<T, M>(r.h, p, c, ck, cn);
+    T *o = out + i * 6;
+    o[0] = r.qdc; o[1] = r.velc; o[2] = r.depthc; o[3] = ck; o[4] = cn; o[5] = r.X;
+}
+
+// ---------------------------------------------------------------- plan
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need ? need : 1);
+        if (e != hipSuccess) return fail(TRMC_ENOMEM, std::string("hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
+        bytes = need;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+} // namespace
+
+struct trmc_plan {
+    int device = 0;
+    int precision = 32;
+    size_t esz = 4;
+    trmc::Topology topo;
+    int64_t nseg = 0, nseg_pad = 0, nrouted = 0;
+    bool dt_uniform = true;
+    double dt = 0.0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // static, plan order
+    DevBuf params; // 9 columns x nseg_pad
+    DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row;
+    // per window
+    DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch;
+    int64_t nq = 0;
+    int32_t staged_nsteps = -1; // nsteps the staged forcing was uploaded for
+    int32_t routed_nsteps = -1; // nsteps of the last completed route
+    trmc_stats stats{};
+};
+
+namespace {
+
+template <class T> T *col(trmc_plan *pl, int c) { return (T *)pl->params.p + (size_t)c * pl->nseg_pad; }
+
+template <class T> int upload_params(trmc_plan *pl, const float *params)
+{
+    const int64_t n = pl->nseg, np = pl->nseg_pad;
+    std::vector<T> host((size_t)TRMC_NPARAM * np, T(0));
+    // a benign channel for the padding lanes (never routed, never read back)
+    for (int64_t p = 0; p < n; ++p) {
+        const float *src = params + (size_t)pl->topo.row_of_pos[p] * TRMC_NPARAM;
+        for (int c = 0; c < TRMC_NPARAM; ++c) host[(size_t)c * np + p] = (T)src[c];
+    }
+    if (int rc = pl->params.ensure(host.size() * sizeof(T))) return rc;
+    HIP_TRY(hipMemcpy(pl->params.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int upload_i32(DevBuf &b, const std::vector<int32_t> &v, size_t min_elems)
+{
+    const size_t n = v.size() > min_elems ? v.size() : min_elems;
+    if (int rc = b.ensure(n * sizeof(int32_t))) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpy(b.p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int use_device(const trmc_plan *pl)
+{
+    HIP_TRY(hipSetDevice(pl->device));
+    return 0;
+}
+
+template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
+{
+    StepArgs<T> a;
+    a.dt_col = pl->dt_uniform ? nullptr : col<T>(pl, TRMC_P_DT);
+    a.dt = (T)pl->dt;
+    a.dx = col<T>(pl, TRMC_P_DX);
+    a.bw = col<T>(pl, TRMC_P_BW);
+    a.tw = col<T>(pl, TRMC_P_TW);
+    a.twcc = col<T>(pl, TRMC_P_TWCC);
+    a.n = col<T>(pl, TRMC_P_N);
+    a.ncc = col<T>(pl, TRMC_P_NCC);
+    a.cs = col<T>(pl, TRMC_P_CS);
+    a.s0 = col<T>(pl, TRMC_P_S0);
+    a.up_ptr = (const int32_t *)pl->up_ptr.p;
+    a.up_idx = (const int32_t *)pl->up_idx.p;
+    a.level = (const int32_t *)pl->level.p;
+    a.qlat_tm = (const T *)pl->qlat_tm.p;
+    const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
+    a.q_tm = (T *)pl->tm.p;
+    a.v_tm = a.q_tm + plane;
+    a.d_tm = a.v_tm + plane;
+    a.nseg_pad = pl->nseg_pad;
+    a.nsteps = nsteps;
+    a.qts = qts;
+    return a;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int short_ts)
+{
+    const trmc::Topology &tp = pl->topo;
+    const int32_t n = (int32_t)pl->nseg;
+    const int64_t np = pl->nseg_pad;
+    hipStream_t st = pl->stream;
+    const size_t plane = (size_t)(nsteps + 1) * np;
+    if (int rc = pl->tm.ensure(3 * plane * sizeof(T))) return rc;
+    if (int rc = pl->qlat_tm.ensure((size_t)pl->nq * np * sizeof(T))) return rc;
+    if (int rc = pl->out.ensure((size_t)pl->nseg * nsteps * 3 * sizeof(T))) return rc;
+    StepArgs<T> a = step_args<T>(pl, nsteps, qts);
+    const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
+
+    HIP_TRY(hipEventRecord(pl->ev[0], st));
+    // the reference allocates flowveldepth as zeros (mc_reach.pyx:253): rows never written
+    // (time rows of padding lanes, velocity of boundary rows) must read as 0
+    HIP_TRY(hipMemsetAsync(pl->tm.p, 0, 3 * plane * sizeof(T), st));
+    if (n > 0) {
+        hipLaunchKernelGGL((k_prep_qlat<T>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
+                           (const T *)pl->in_qlat.p, row_of_pos, (T *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);
+        hipLaunchKernelGGL((k_init_state<T>), dim3(blocks_for(n)), dim3(kBlock), 0, st, (const T *)pl->in_q0.p,
+                           row_of_pos, a.q_tm, a.v_tm, a.d_tm, n);
+    }
+    if (tp.nboundary > 0)
+        hipLaunchKernelGGL((k_fill_boundary<T>), dim3(blocks_for(tp.nboundary * (int64_t)nsteps)), dim3(kBlock), 0, st,
+                           (const T *)pl->in_bfvd.p, a.q_tm, a.v_tm, a.d_tm, (int32_t)tp.nboundary, nsteps, np);
+    HIP_TRY(hipEventRecord(pl->ev[1], st));
+
+    int32_t launches = 0;
+    if (pl->nrouted > 0) {
+        const int32_t L = tp.nlevels;
+        if (short_ts) {
+            const int32_t s0 = tp.lvl_ptr[0], s1 = tp.lvl_ptr[L];
+            for (int32_t t = 1; t <= nsteps; ++t) {
+                hipLaunchKernelGGL((k_mc_step<T, true>), dim3(blocks_for(s1 - s0)), dim3(kBlock), 0, st, a, s0, s1, t);
+                ++launches;
+            }
+        } else {
+            for (int32_t d = 1; d <= L - 1 + nsteps; ++d) {
+                const int32_t lo = d - nsteps > 0 ? d - nsteps : 0;
+                const int32_t hi = d - 1 < L - 1 ? d - 1 : L - 1;
+                const int32_t s0 = tp.lvl_ptr[lo], s1 = tp.lvl_ptr[hi + 1];
+                if (s1 <= s0) continue;
+                hipLaunchKernelGGL((k_mc_step<T, false>), dim3(blocks_for(s1 - s0)), dim3(kBlock), 0, st, a, s0, s1, d);
+                ++launches;
+            }
+        }
+    }
+    HIP_TRY(hipEventRecord(pl->ev[2], st));
+    if (n > 0)
+        hipLaunchKernelGGL((k_emit<T>), dim3((n + 63) / 64, (unsigned)((nsteps + 63) / 64)), dim3(kBlock), 0, st, a.q_tm,
+                           a.v_tm, a.d_tm, row_of_pos, (T *)pl->out.p, n, np, nsteps);
+    HIP_TRY(hipEventRecord(pl->ev[3], st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+
+    float ms01 = 0, ms12 = 0, ms23 = 0;
+    HIP_TRY(hipEventElapsedTime(&ms01, pl->ev[0], pl->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms12, pl->ev[1], pl->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms23, pl->ev[2], pl->ev[3]));
+    trmc_stats &s = pl->stats;
+    s.nseg = pl->nseg;
+    s.nseg_routed = pl->nrouted;
+    s.nlevels = tp.nlevels;
+    s.nsteps = nsteps;
+    s.assume_short_ts = short_ts ? 1 : 0;
+    s.main_launches = launches;
+    s.segment_steps = pl->nrouted * (int64_t)nsteps;
+    s.ms_prep = ms01;
+    s.ms_main = ms12;
+    s.ms_emit = ms23;
+    s.ms_total = (double)ms01 + ms12 + ms23;
+    pl->routed_nsteps = nsteps;
+    return 0;
+}
+
+template <class T> int segments_t(int64_t n, const void *in, void *out)
+{
+    DevBuf din, dout;
+    int rc = din.ensure((size_t)n * 15 * sizeof(T));
+    if (!rc) rc = dout.ensure((size_t)n * 6 * sizeof(T));
+    if (!rc) {
+        hipError_t e = hipMemcpy(din.p, in, (size_t)n * 15 * sizeof(T), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((k_segments<T>), dim3(blocks_for(n)), dim3(kBlock), 0, 0, (const T *)din.p, (T *)dout.p, n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)n * 6 * sizeof(T), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TRMC_EHIP, std::string("trmc_segments: ") + hipGetErrorString(e));
+    }
+    din.release();
+    dout.release();
+    return rc;
+}
+
+int check_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(TRMC_ENODEVICE, std::string("no HIP device available (") + hipGetErrorString(e)
+                                        + "); this library has no CPU fallback");
+    if (device < 0 || device >= count)
+        return fail(TRMC_EINVAL, "device ordinal " + std::to_string(device) + " out of range [0," + std::to_string(count) + ")");
+    return 0;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------- C ABI
+extern "C" {
+
+const char *trmc_last_error(void) { return g_err.c_str(); }
+int trmc_abi_version(void) { return TRMC_ABI_VERSION; }
+
+int trmc_device_count(int *count)
+{
+    if (!count) return fail(TRMC_EINVAL, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(TRMC_ENODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = c;
+    return 0;
+}
+
+int trmc_topology_levels(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
+                         int32_t *level_of_row, int64_t *plan_pos_of_row, int32_t *nlevels)
+{
+    trmc::Topology t;
+    std::string err;
+    const int rc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, t, err);
+    if (rc) return fail(rc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
+    for (int64_t r = 0; r < nseg; ++r) {
+        if (level_of_row) level_of_row[r] = t.level_of_row[r];
+        if (plan_pos_of_row) plan_pos_of_row[r] = t.pos_of_row[r];
+    }
+    if (nlevels) *nlevels = t.nlevels;
+    return 0;
+}
+
+int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
+                     const uint8_t *boundary, int precision, int device, trmc_plan **out)
+{
+    if (!out) return fail(TRMC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (precision != 32 && precision != 64) return fail(TRMC_EINVAL, "precision must be 32 or 64");
+    if (nseg > 0 && !params) return fail(TRMC_EINVAL, "params is NULL");
+    if (int rc = check_device(device)) return rc;
+
+    trmc_plan *pl = new (std::nothrow) trmc_plan();
+    if (!pl) return fail(TRMC_ENOMEM, "out of host memory");
+    std::string err;
+    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err);
+    if (trc) {
+        delete pl;
+        return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
+    }
+    pl->device = device;
+    pl->precision = precision;
+    pl->esz = precision == 32 ? 4 : 8;
+    pl->nseg = nseg;
+    pl->nseg_pad = (nseg + 63) / 64 * 64;
+    if (pl->nseg_pad == 0) pl->nseg_pad = 64;
+    pl->nrouted = nseg - pl->topo.nboundary;
+    pl->dt_uniform = true;
+    pl->dt = nseg ? params[TRMC_P_DT] : 0.0;
+    for (int64_t r = 1; r < nseg; ++r)
+        if (params[(size_t)r * TRMC_NPARAM + TRMC_P_DT] != params[TRMC_P_DT]) {
+            pl->dt_uniform = false;
+            break;
+        }
+
+    auto bail = [&](int rc) {
+        trmc_plan_destroy(pl);
+        return rc;
+    };
+    {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
+        if (e != hipSuccess) return bail(fail(TRMC_EHIP, std::string("stream/event setup: ") + hipGetErrorString(e)));
+    }
+    int rc = precision == 32 ? upload_params<float>(pl, params) : upload_params<double>(pl, params);
+    if (rc) return bail(rc);
+    std::vector<int32_t> level_plan((size_t)pl->nseg_pad, 0);
+    for (int64_t p = 0; p < nseg; ++p) level_plan[p] = pl->topo.level_of_row[pl->topo.row_of_pos[p]];
+    if ((rc = upload_i32(pl->level, level_plan, 1))) return bail(rc);
+    if ((rc = upload_i32(pl->up_ptr, pl->topo.up_ptr, 1))) return bail(rc);
+    if ((rc = upload_i32(pl->up_idx, pl->topo.up_idx, 1))) return bail(rc);
+    if ((rc = upload_i32(pl->row_of_pos, pl->topo.row_of_pos, 1))) return bail(rc);
+    if ((rc = upload_i32(pl->pos_of_row, pl->topo.pos_of_row, 1))) return bail(rc);
+    *out = pl;
+    return 0;
+}
+
+void trmc_plan_destroy(trmc_plan *pl)
+{
+    if (!pl) return;
+    (void)hipSetDevice(pl->device);
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row,
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch})
+        b->release();
+    for (auto &e : pl->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (pl->stream) (void)hipStreamDestroy(pl->stream);
+    delete pl;
+}
+
+int trmc_plan_info(const trmc_plan *pl, int64_t *nseg, int64_t *nseg_routed, int32_t *nlevels, int32_t *precision,
+                   int32_t *device)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (nseg) *nseg = pl->nseg;
+    if (nseg_routed) *nseg_routed = pl->nrouted;
+    if (nlevels) *nlevels = pl->topo.nlevels;
+    if (precision) *precision = pl->precision;
+    if (device) *device = pl->device;
+    return 0;
+}
+
+int trmc_plan_levels(const trmc_plan *pl, int32_t *level_of_row, int64_t *plan_pos_of_row)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    for (int64_t r = 0; r < pl->nseg; ++r) {
+        if (level_of_row) level_of_row[r] = pl->topo.level_of_row[r];
+        if (plan_pos_of_row) plan_pos_of_row[r] = pl->topo.pos_of_row[r];
+    }
+    return 0;
+}
+
+int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq, const void *q0,
+                        const void *boundary_fvd)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
+    if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
+    if (pl->nseg > 0 && (!qlat || !q0)) return fail(TRMC_EINVAL, "qlat/q0 is NULL");
+    if (pl->topo.nboundary > 0 && !boundary_fvd)
+        return fail(TRMC_EINVAL, "plan has boundary rows but boundary_fvd is NULL");
+    if (int rc = use_device(pl)) return rc;
+    const size_t e = pl->esz;
+    if (int rc = pl->in_qlat.ensure((size_t)pl->nseg * nq * e)) return rc;
+    if (int rc = pl->in_q0.ensure((size_t)pl->nseg * 3 * e)) return rc;
+    if (pl->nseg > 0) {
+        HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, (size_t)pl->nseg * nq * e, hipMemcpyHostToDevice, pl->stream));
+        HIP_TRY(hipMemcpyAsync(pl->in_q0.p, q0, (size_t)pl->nseg * 3 * e, hipMemcpyHostToDevice, pl->stream));
+    }
+    if (pl->topo.nboundary > 0) {
+        const size_t b = (size_t)pl->topo.nboundary * nsteps * 3 * e;
+        if (int rc = pl->in_bfvd.ensure(b)) return rc;
+        HIP_TRY(hipMemcpyAsync(pl->in_bfvd.p, boundary_fvd, b, hipMemcpyHostToDevice, pl->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(pl->stream));
+    pl->nq = nq;
+    pl->staged_nsteps = nsteps;
+    pl->routed_nsteps = -1;
+    return 0;
+}
+
+int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->staged_nsteps < 0) return fail(TRMC_ESTATE, "trmc_upload_forcing must precede trmc_route_device");
+    if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
+    if (qts_subdivisions < 1) return fail(TRMC_EINVAL, "qts_subdivisions must be >= 1");
+    if (pl->topo.nboundary > 0 && nsteps != pl->staged_nsteps)
+        return fail(TRMC_EINVAL, "nsteps differs from the staged boundary hydrographs");
+    // the reference's precondition, mc_reach.pyx:246-247
+    if ((int64_t)(nsteps - 1) / qts_subdivisions >= pl->nq)
+        return fail(TRMC_EINVAL, "Number of columns (timesteps) in Qlat is incorrect: need "
+                                     + std::to_string((nsteps - 1) / qts_subdivisions + 1) + ", got " + std::to_string(pl->nq));
+    if (int rc = use_device(pl)) return rc;
+    return pl->precision == 32 ? route_device_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
+                               : route_device_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
+}
+
+int trmc_download_fvd(trmc_plan *pl, void *fvd_out)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (pl->nseg == 0) return 0;
+    if (!fvd_out) return fail(TRMC_EINVAL, "fvd_out is NULL");
+    if (int rc = use_device(pl)) return rc;
+    HIP_TRY(hipMemcpy(fvd_out, pl->out.p, (size_t)pl->nseg * pl->routed_nsteps * 3 * pl->esz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int trmc_download_final_state(trmc_plan *pl, void *q0_out)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (pl->nseg == 0) return 0;
+    if (!q0_out) return fail(TRMC_EINVAL, "q0_out is NULL");
+    if (int rc = use_device(pl)) return rc;
+    const size_t bytes = (size_t)pl->nseg * 3 * pl->esz;
+    if (int rc = pl->scratch.ensure(bytes)) return rc;
+    const int32_t n = (int32_t)pl->nseg, T_ = pl->routed_nsteps;
+    const size_t plane = (size_t)(T_ + 1) * pl->nseg_pad;
+    if (pl->precision == 32) {
+        const float *q = (const float *)pl->tm.p;
+        hipLaunchKernelGGL((k_final_state<float>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
+                           (const int32_t *)pl->row_of_pos.p, (float *)pl->scratch.p, n, pl->nseg_pad, T_);
+    } else {
+        const double *q = (const double *)pl->tm.p;
+        hipLaunchKernelGGL((k_final_state<double>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
+                           (const int32_t *)pl->row_of_pos.p, (double *)pl->scratch.p, n, pl->nseg_pad, T_);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(q0_out, pl->scratch.p, bytes, hipMemcpyDeviceToHost, pl->stream));
+    HIP_TRY(hipStreamSynchronize(pl->stream));
+    return 0;
+}
+
+int trmc_gather_flow_rows(trmc_plan *pl, const int64_t *rows, int64_t nrows, void *out, int dst_is_device)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (nrows == 0) return 0;
+    if (!rows || !out) return fail(TRMC_EINVAL, "rows/out is NULL");
+    if (int rc = use_device(pl)) return rc;
+    std::vector<int32_t> pos((size_t)nrows);
+    for (int64_t i = 0; i < nrows; ++i) {
+        if (rows[i] < 0 || rows[i] >= pl->nseg) return fail(TRMC_EINVAL, "row out of range");
+        pos[i] = pl->topo.pos_of_row[rows[i]];
+    }
+    const int32_t T_ = pl->routed_nsteps;
+    const size_t obytes = (size_t)nrows * T_ * pl->esz;
+    const size_t pbytes = ((size_t)nrows * sizeof(int32_t) + 255) / 256 * 256;
+    if (int rc = pl->scratch.ensure(pbytes + (dst_is_device ? 0 : obytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(pl->scratch.p, pos.data(), (size_t)nrows * sizeof(int32_t), hipMemcpyHostToDevice, pl->stream));
+    void *dst = dst_is_device ? out : (void *)((char *)pl->scratch.p + pbytes);
+    if (pl->precision == 32)
+        hipLaunchKernelGGL((k_gather_rows<float>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream,
+                           (const float *)pl->tm.p, (const int32_t *)pl->scratch.p, (float *)dst, nrows, pl->nseg_pad, T_);
+    else
+        hipLaunchKernelGGL((k_gather_rows<double>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream,
+                           (const double *)pl->tm.p, (const int32_t *)pl->scratch.p, (double *)dst, nrows, pl->nseg_pad, T_);
+    HIP_TRY(hipGetLastError());
+    if (!dst_is_device) HIP_TRY(hipMemcpyAsync(out, dst, obytes, hipMemcpyDeviceToHost, pl->stream));
+    HIP_TRY(hipStreamSynchronize(pl->stream));
+    return 0;
+}
+
+int trmc_get_stats(const trmc_plan *pl, trmc_stats *stats)
+{
+    if (!pl || !stats) return fail(TRMC_EINVAL, "plan/stats is NULL");
+    *stats = pl->stats;
+    return 0;
+}
+
+int trmc_route(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts, const void *qlat, int64_t nq,
+               const void *q0, const void *boundary_fvd, void *fvd_out)
+{
+    if (int rc = trmc_upload_forcing(pl, nsteps, qlat, nq, q0, boundary_fvd)) return rc;
+    if (int rc = trmc_route_device(pl, nsteps, qts_subdivisions, assume_short_ts)) return rc;
+    return trmc_download_fvd(pl, fvd_out);
+}
+
+int trmc_segments(int device, int precision, int64_t n, const void *in, void *out)
+{
+    if (precision != 32 && precision != 64) return fail(TRMC_EINVAL, "precision must be 32 or 64");
+    if (n < 0) return fail(TRMC_EINVAL, "n < 0");
+    if (n == 0) return 0;
+    if (!in || !out) return fail(TRMC_EINVAL, "in/out is NULL");
+    if (int rc = check_device(device)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return precision == 32 ? segments_t<float>(n, in, out) : segments_t<double>(n, in, out);
+}
+
+} // extern "C"

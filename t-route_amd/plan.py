@@ -1,0 +1,165 @@
+"""RoutingPlan -- Python handle of a trmc_plan (include/trmc.h).
+
+A plan owns the flattened topology and the channel parameters in HBM; one plan
+serves any number of routing windows (the reference rebuilds its MC_Segment /
+MC_Reach objects on every compute_network_structured call,
+mc_reach.pyx:283-378).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def csr_from_lists(lists):
+    """[[rows...], ...] -> (ptr int64[n+1], idx int64[nnz])"""
+    ptr = np.zeros(len(lists) + 1, dtype=np.int64)
+    if lists:
+        ptr[1:] = np.cumsum([len(x) for x in lists])
+    idx = np.fromiter((v for x in lists for v in x), dtype=np.int64, count=int(ptr[-1]))
+    return ptr, idx
+
+
+def topology_levels(up_ptr, up_idx, boundary=None):
+    """Host-only level flattening (no GPU).  Returns (level_of_row, plan_pos_of_row, nlevels)."""
+    up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
+    up_idx = np.ascontiguousarray(up_idx, dtype=np.int64)
+    nseg = up_ptr.shape[0] - 1
+    b = None if boundary is None else np.ascontiguousarray(boundary, dtype=np.uint8)
+    lvl = np.empty(nseg, dtype=np.int32)
+    pos = np.empty(nseg, dtype=np.int64)
+    nl = C.c_int32(0)
+    _lib.check(_lib.lib().trmc_topology_levels(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(b),
+                                               _lib.ptr(lvl), _lib.ptr(pos), C.byref(nl)))
+    return lvl, pos, nl.value
+
+
+class RoutingPlan:
+    def __init__(self, up_ptr, up_idx, params, boundary=None, precision=32, device=0):
+        """
+        up_ptr/up_idx : CSR of upstream rows per row, reference summation order
+        params        : float32 [nseg, 9] in _lib.PARAM_COLS order
+        boundary      : optional bool/uint8 [nseg], rows with prescribed hydrographs
+        """
+        self._h = C.c_void_p(0)
+        up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
+        up_idx = np.ascontiguousarray(up_idx, dtype=np.int64)
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        nseg = up_ptr.shape[0] - 1
+        if params.shape != (nseg, _lib.NPARAM):
+            raise ValueError("data_values shape mismatch")
+        b = None if boundary is None else np.ascontiguousarray(boundary, dtype=np.uint8)
+        if b is not None and b.shape != (nseg,):
+            raise ValueError("boundary mask shape mismatch")
+        self.nseg = nseg
+        self.precision = precision
+        self.dtype = _lib.np_dtype(precision)
+        self.nboundary = 0 if b is None else int(np.count_nonzero(b))
+        h = C.c_void_p(0)
+        _lib.check(_lib.lib().trmc_plan_create(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
+                                               _lib.ptr(b), precision, device, C.byref(h)))
+        self._h = h
+        self._nsteps = None
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().trmc_plan_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- facts ------------------------------------------------------------------------
+    def info(self):
+        nseg, nr = C.c_int64(0), C.c_int64(0)
+        nl, pr, dev = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.lib().trmc_plan_info(self._h, C.byref(nseg), C.byref(nr), C.byref(nl), C.byref(pr),
+                                             C.byref(dev)))
+        return {"nseg": nseg.value, "nseg_routed": nr.value, "nlevels": nl.value, "precision": pr.value,
+                "device": dev.value}
+
+    def levels(self):
+        lvl = np.empty(self.nseg, dtype=np.int32)
+        pos = np.empty(self.nseg, dtype=np.int64)
+        _lib.check(_lib.lib().trmc_plan_levels(self._h, _lib.ptr(lvl), _lib.ptr(pos)))
+        return lvl, pos
+
+    def stats(self):
+        s = _lib.Stats()
+        _lib.check(_lib.lib().trmc_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    # -- one routing window -------------------------------------------------------------
+    def upload_forcing(self, nsteps, qlat, q0, boundary_fvd=None):
+        qlat = np.ascontiguousarray(qlat, dtype=self.dtype)
+        q0 = np.ascontiguousarray(q0, dtype=self.dtype)
+        if qlat.ndim != 2 or qlat.shape[0] != self.nseg:
+            raise ValueError(f"Number of rows in Qlat is incorrect: expected ({self.nseg}), got ({qlat.shape[0]})")
+        if q0.shape != (self.nseg, 3):
+            raise ValueError("initial_conditions shape mismatch")
+        bf = None
+        if self.nboundary:
+            bf = np.ascontiguousarray(boundary_fvd, dtype=self.dtype)
+            if bf.shape != (self.nboundary, nsteps, 3):
+                raise ValueError("boundary hydrograph shape mismatch")
+        _lib.check(_lib.lib().trmc_upload_forcing(self._h, nsteps, _lib.ptr(qlat), qlat.shape[1], _lib.ptr(q0),
+                                                  _lib.ptr(bf)))
+        self._nsteps = nsteps
+
+    def route_device(self, nsteps, qts_subdivisions, assume_short_ts):
+        _lib.check(_lib.lib().trmc_route_device(self._h, nsteps, qts_subdivisions, int(bool(assume_short_ts))))
+        self._nsteps = nsteps
+        return self.stats()
+
+    def download_fvd(self):
+        out = np.empty((self.nseg, self._nsteps, 3), dtype=self.dtype)
+        _lib.check(_lib.lib().trmc_download_fvd(self._h, _lib.ptr(out)))
+        return out
+
+    def download_final_state(self):
+        out = np.empty((self.nseg, 3), dtype=self.dtype)
+        _lib.check(_lib.lib().trmc_download_final_state(self._h, _lib.ptr(out)))
+        return out
+
+    def gather_flow_rows(self, rows, device_ptr=None):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        if device_ptr is not None:
+            _lib.check(_lib.lib().trmc_gather_flow_rows(self._h, _lib.ptr(rows), rows.shape[0],
+                                                        C.c_void_p(device_ptr), 1))
+            return None
+        out = np.empty((rows.shape[0], self._nsteps), dtype=self.dtype)
+        _lib.check(_lib.lib().trmc_gather_flow_rows(self._h, _lib.ptr(rows), rows.shape[0], _lib.ptr(out), 0))
+        return out
+
+    def route(self, nsteps, qts_subdivisions, assume_short_ts, qlat, q0, boundary_fvd=None):
+        """upload + route + download: fvd [nseg, nsteps, 3]."""
+        self.upload_forcing(nsteps, qlat, q0, boundary_fvd)
+        self.route_device(nsteps, qts_subdivisions, assume_short_ts)
+        return self.download_fvd()
+
+
+def segments(inputs, device=0):
+    """Batch of independent single-segment steps on the GPU.  inputs [n,15] -> [n,6]."""
+    inputs = np.ascontiguousarray(inputs)
+    if inputs.dtype == np.float32:
+        precision = 32
+    elif inputs.dtype == np.float64:
+        precision = 64
+    else:
+        raise ValueError("inputs must be float32 or float64")
+    if inputs.ndim != 2 or inputs.shape[1] != 15:
+        raise ValueError("inputs must be [n, 15]")
+    out = np.empty((inputs.shape[0], 6), dtype=inputs.dtype)
+    _lib.check(_lib.lib().trmc_segments(device, precision, inputs.shape[0], _lib.ptr(inputs), _lib.ptr(out)))
+    return out

@@ -1,0 +1,286 @@
+"""Drop-in for ``troute.routing.fast_reach.mc_reach`` (Muskingum-Cunge branch).
+
+``compute_network_structured`` has the positional signature and the 10-tuple
+return of the reference's Cython function
+(src/troute-routing/troute/routing/fast_reach/mc_reach.pyx:164-224, return
+:811-845) and can be registered in the reference's ``_compute_func_map``
+(src/troute-routing/troute/routing/compute.py:21-26) -- see INTEGRATION.md.
+
+Only the MC branch is implemented (this project's scope): reservoir reaches
+(reach_type 1) and gage nudging raise NotImplementedError.  All arithmetic
+runs in libtrmc.so on the GPU; there is no Python fallback.
+"""
+import numpy as np
+
+from ... import _lib
+from ...plan import RoutingPlan
+
+# mc_reach.pyx:150-162: the kernel's column order inside data_values
+_KERNEL_COLS = ("dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0")
+
+
+def binary_find(arr, els):
+    """Positions of ``els`` in sorted ``arr`` (mc_reach.pyx:36-66); ValueError if absent."""
+    arr = np.asarray(arr)
+    els = np.asarray(list(els) if not isinstance(els, np.ndarray) else els, dtype=arr.dtype)
+    if els.size == 0:
+        return []
+    idx = np.searchsorted(arr, els)
+    idx_c = np.minimum(idx, arr.shape[0] - 1)
+    bad = arr[idx_c] != els
+    if bad.any():
+        raise ValueError(f"element {els[bad][0]} not found in {arr}")
+    return idx_c.tolist()
+
+
+def column_mapper(src_cols):
+    """Map source columns to the kernel's column order (mc_reach.pyx:150-162)."""
+    index = {label: i for i, label in enumerate(src_cols)}
+    return [index[label] for label in _KERNEL_COLS]
+
+
+def _flatten_network(reaches_wTypes, upstream_connections, data_idx):
+    """Reach lists + upstream dict -> per-row upstream CSR in the reference's summation order.
+
+    Head of a reach: rows of upstream_connections[reach[0]] in dict-list order
+    (mc_reach.pyx:288-289, :499-502).  Inside a reach: the previous segment
+    (mc_reach.pyx:133-138).  Rows that belong to no reach get no upstreams and
+    are reported in ``in_reach``.
+    """
+    nseg = data_idx.shape[0]
+    heads, head_ups = [], []
+    flat = []
+    starts = []
+    for reach, reach_type in reaches_wTypes:
+        if reach_type == 1:
+            raise NotImplementedError(
+                "reservoir reaches (reach_type 1) are outside the Muskingum-Cunge hot path; "
+                "run MC-only (break_network_at_waterbodies: False)")
+        starts.append(len(flat))
+        flat.extend(reach)
+        heads.append(reach[0])
+        head_ups.append(upstream_connections.get(reach[0], ()))
+    flat = np.asarray(flat, dtype=np.int64)
+    rows = np.asarray(binary_find(data_idx, flat), dtype=np.int64)
+    in_reach = np.zeros(nseg, dtype=bool)
+    in_reach[rows] = True
+    if rows.shape[0] != np.count_nonzero(in_reach):
+        raise ValueError("a segment appears in more than one reach")
+
+    counts = np.zeros(nseg, dtype=np.int64)
+    is_head = np.zeros(flat.shape[0], dtype=bool)
+    is_head[np.asarray(starts, dtype=np.int64)] = True
+    counts[rows[~is_head]] = 1
+    head_rows = rows[is_head]
+    up_rows_of_head = [binary_find(data_idx, u) for u in head_ups]
+    counts[head_rows] = [len(u) for u in up_rows_of_head]
+    up_ptr = np.zeros(nseg + 1, dtype=np.int64)
+    up_ptr[1:] = np.cumsum(counts)
+    up_idx = np.empty(up_ptr[-1], dtype=np.int64)
+    # inside a reach: previous element of the flattened reach list
+    prev = np.empty_like(rows)
+    prev[1:] = rows[:-1]
+    up_idx[up_ptr[rows[~is_head]]] = prev[~is_head]
+    for r, ups in zip(head_rows.tolist(), up_rows_of_head):
+        up_idx[up_ptr[r]:up_ptr[r] + len(ups)] = ups
+    return up_ptr, up_idx, in_reach
+
+
+def compute_network_structured(
+    nsteps,
+    dt,
+    qts_subdivisions,
+    reaches_wTypes,
+    upstream_connections,
+    data_idx,
+    data_cols,
+    data_values,
+    initial_conditions,
+    qlat_values,
+    lake_numbers_col,
+    wbody_cols,
+    data_assimilation_parameters,
+    reservoir_types,
+    reservoir_type_specified,
+    model_start_time,
+    usgs_values,
+    usgs_positions,
+    usgs_positions_reach,
+    usgs_positions_gage,
+    lastobs_values_init,
+    time_since_lastobs_init,
+    da_decay_coefficient,
+    reservoir_usgs_obs,
+    reservoir_usgs_wbody_idx,
+    reservoir_usgs_time,
+    reservoir_usgs_update_time,
+    reservoir_usgs_prev_persisted_flow,
+    reservoir_usgs_persistence_update_time,
+    reservoir_usgs_persistence_index,
+    reservoir_usace_obs,
+    reservoir_usace_wbody_idx,
+    reservoir_usace_time,
+    reservoir_usace_update_time,
+    reservoir_usace_prev_persisted_flow,
+    reservoir_usace_persistence_update_time,
+    reservoir_usace_persistence_index,
+    reservoir_rfc_obs,
+    reservoir_rfc_wbody_idx,
+    reservoir_rfc_totalCounts,
+    reservoir_rfc_file,
+    reservoir_rfc_use_forecast,
+    reservoir_rfc_timeseries_idx,
+    reservoir_rfc_update_time,
+    reservoir_rfc_da_timestep,
+    reservoir_rfc_persist_days,
+    great_lakes_idx,
+    great_lakes_times,
+    great_lakes_discharge,
+    great_lakes_param_idx,
+    great_lakes_param_prev_assim_flow,
+    great_lakes_param_prev_assim_times,
+    great_lakes_param_update_times,
+    great_lakes_climatology,
+    upstream_results={},
+    assume_short_ts=False,
+    return_courant=False,
+    da_check_gage=-1,
+    from_files=True,
+    *,
+    precision=32,
+    device=0,
+    return_stats=False,
+):
+    """Route one (sub)network for ``nsteps`` timesteps on the GPU.
+
+    Arguments and return value: see the reference docstring,
+    mc_reach.pyx:225-240, and SURVEY.md 8(b).  Keyword-only extensions:
+    ``precision`` (32 = the reference's arithmetic type, 64 = double),
+    ``device`` (HIP ordinal), ``return_stats`` (append the trmc_stats dict).
+    """
+    data_idx = np.ascontiguousarray(data_idx, dtype=np.int64)
+    data_values = np.asarray(data_values)
+    qlat_values = np.asarray(qlat_values)
+    initial_conditions = np.asarray(initial_conditions)
+    nseg = data_idx.shape[0]
+
+    # preconditions of the reference, same messages (mc_reach.pyx:243-250)
+    if qlat_values.shape[0] != nseg:
+        raise ValueError(
+            f"Number of rows in Qlat is incorrect: expected ({nseg}), got ({qlat_values.shape[0]})")
+    if qlat_values.shape[1] < nsteps / qts_subdivisions:
+        raise ValueError(
+            f"Number of columns (timesteps) in Qlat is incorrect: expected at most ({nseg}), "
+            f"got ({qlat_values.shape[1]}). The number of columns in Qlat must be equal to or less than "
+            "the number of routing timesteps")
+    if data_values.shape[0] != nseg or data_values.shape[1] != len(data_cols):
+        raise ValueError("data_values shape mismatch")
+
+    usgs_positions = np.asarray(usgs_positions)
+    if usgs_positions.shape[0] != 0:
+        raise NotImplementedError("streamflow nudging (usgs gages) is outside the Muskingum-Cunge hot path")
+
+    params = np.ascontiguousarray(np.asarray(data_values, dtype=np.float32)[:, column_mapper(list(data_cols))])
+    up_ptr, up_idx, in_reach = _flatten_network(reaches_wTypes, upstream_connections, data_idx)
+
+    # rows that carry a prescribed hydrograph: upstream_results (mc_reach.pyx:451-469);
+    # rows in no reach at all stay zero in the reference -- prescribed zero hydrograph
+    fill_index_mask = np.ones(nseg, dtype=bool)
+    boundary = ~in_reach
+    dtype = _lib.np_dtype(precision)
+    bvals = {}
+    q0 = np.array(initial_conditions, dtype=dtype, copy=True)
+    q0[boundary] = 0
+    for _tw, tmp in upstream_results.items():
+        fill_index = int(tmp["position_index"])
+        fill_index_mask[fill_index] = False
+        boundary[fill_index] = True
+        res = np.asarray(tmp["results"], dtype=dtype).reshape(-1, 3)
+        if res.shape[0] != nsteps:
+            raise ValueError("upstream_results hydrograph length does not match nsteps")
+        bvals[fill_index] = res
+        q0[fill_index, 0] = initial_conditions[fill_index, 0]
+        q0[fill_index, 2] = initial_conditions[fill_index, 2]
+    brow = np.flatnonzero(boundary)
+    boundary_fvd = None
+    if brow.size:
+        boundary_fvd = np.zeros((brow.size, nsteps, 3), dtype=dtype)
+        for k, r in enumerate(brow.tolist()):
+            if r in bvals:
+                boundary_fvd[k] = bvals[r]
+
+    with RoutingPlan(up_ptr, up_idx, params, boundary if brow.size else None, precision, device) as plan:
+        fvd = plan.route(nsteps, qts_subdivisions, assume_short_ts, qlat_values, q0, boundary_fvd)
+        stats = plan.stats()
+
+    out_dtype = np.float32 if precision == 32 else np.float64
+    flowveldepth = fvd.reshape(nseg, nsteps * 3).astype(out_dtype, copy=False)[fill_index_mask]
+    upstream = np.zeros((nseg, nsteps), dtype="float32")[fill_index_mask]  # np.empty in the reference (:487)
+    t_end = nsteps * dt
+    f32 = lambda a: np.asarray(a, dtype="float32")  # noqa: E731
+    i32 = lambda a: np.asarray(a, dtype="int32")  # noqa: E731
+    result = (
+        np.asarray(data_idx, dtype=np.intp)[fill_index_mask],
+        flowveldepth,
+        0,
+        (
+            np.asarray([], dtype=np.int64),
+            np.full(0, np.nan, dtype="float32"),
+            np.full(0, np.nan, dtype="float32"),
+        ),
+        (
+            i32(reservoir_usgs_wbody_idx),
+            f32(reservoir_usgs_update_time) - t_end,
+            f32(reservoir_usgs_prev_persisted_flow),
+            f32(reservoir_usgs_persistence_index),
+            f32(reservoir_usgs_persistence_update_time) - t_end,
+        ),
+        (
+            i32(reservoir_usace_wbody_idx),
+            f32(reservoir_usace_update_time) - t_end,
+            f32(reservoir_usace_prev_persisted_flow),
+            f32(reservoir_usace_persistence_index),
+            f32(reservoir_usace_persistence_update_time) - t_end,
+        ),
+        upstream,
+        (
+            i32(reservoir_rfc_wbody_idx),
+            f32(reservoir_rfc_update_time) - t_end,
+            i32(reservoir_rfc_timeseries_idx),
+        ),
+        np.zeros((0, nsteps + 1), dtype="float32"),
+        (
+            i32(great_lakes_param_idx),
+            f32(great_lakes_param_prev_assim_flow),
+            i32(great_lakes_param_prev_assim_times),
+            i32(great_lakes_param_update_times),
+        ),
+    )
+    if return_stats:
+        return result + (stats,)
+    return result
+
+
+def mc_only_args(nsteps, dt, qts_subdivisions, reaches, upstream_connections, data_idx, data_cols,
+                 data_values, initial_conditions, qlat_values, upstream_results=None,
+                 assume_short_ts=False):
+    """Positional argument list for an MC-only call: every DA / reservoir array empty, exactly the
+    shapes compute_nhd_routing_v02 passes when those features are off (compute.py:1513-1576)."""
+    e_f2 = np.zeros((0, 0), dtype="float32")
+    e_f1 = np.zeros(0, dtype="float32")
+    e_i1 = np.zeros(0, dtype="int32")
+    reaches_wTypes = [(list(r), 0) for r in reaches]
+    return [
+        nsteps, dt, qts_subdivisions, reaches_wTypes, upstream_connections,
+        np.asarray(data_idx, dtype="int64"), np.asarray(data_cols, dtype=object),
+        np.asarray(data_values, dtype="float32"), np.asarray(initial_conditions, dtype="float32"),
+        np.asarray(qlat_values, dtype="float32"),
+        [], np.zeros((0, 0), dtype="float64"), {}, np.zeros((0, 0), dtype="int32"), False,
+        "2021-08-23_13:00:00",
+        e_f2, e_i1, e_i1, e_i1, e_f1, e_f1, 0.0,
+        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
+        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
+        e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
+        e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
+        upstream_results or {}, assume_short_ts,
+    ]
