@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Muskingum-Cunge routing of a CONUS-scale network on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input: routing the
+whole seeded synthetic CONUS network (2 729 077 segments, 14 713 independent networks,
+troute_amd/synthetic.py) for one forcing window of 288 x 300 s timesteps with the
+reference's configured assume_short_ts=True (test/LowerColorado_TX/test_AnA.yaml:32),
+fp32 (the reference's arithmetic type), cold start -- forcing and topology already
+resident in HBM when the timed region starts, results left in HBM in the reference's
+[segment][timestep][q,v,d] layout.
+
+Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
+  roofline      dominant kernel (k_mc_step) against the 8 TB/s HBM roofline, timed with
+                HIP events on the plan's own stream inside this run
+  cpu_baseline  the reference Fortran kernel (oracle/_ref, amdflang -O2) driven by the
+                restated reference loop on this host's cores, bounded sample
+  full_ts       the same workload without the short-timestep assumption (level wavefront)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_SEGSTEP = 64          # 32 params + 4 qlat + 8 own state + 8 upstream + 12 out
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nseg", type=int, default=None, help="override network size (default CONUS)")
+    ap.add_argument("--nnet", type=int, default=None)
+    ap.add_argument("--nsteps", type=int, default=288)
+    ap.add_argument("--qts", type=int, default=12)
+    ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-ts", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    return ap.parse_args()
+
+
+def cpu_baseline(net, nsteps, qts, short_ts, target_s):
+    """Reference kernel on host cores over a bounded sample of the SAME workload.
+
+    Sample = independent networks other than the dominant basin, smallest-cost subset
+    sized so the run lasts about `target_s` s; one network loop call per worker thread
+    (the reference's by-network parallelism, compute.py:1211-1395; ctypes drops the GIL).
+    """
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+    from troute_amd import sharding
+    from troute_amd.plan import topology_levels
+    from troute_amd.synthetic import upstream_csr
+
+    kind, ref_name = "port", None
+    if O.have_ref("libmc_ref_f32.so"):
+        kind, ref_name = "reference", "libmc_ref_f32.so"
+    cores = os.cpu_count() or 1
+    to = net["to"]
+    nseg = to.shape[0]
+    outlet = sharding.outlet_of(to)
+    uniq, lab = np.unique(outlet, return_inverse=True)
+    sizes = np.bincount(lab)
+    budget = int(1.5e6 * target_s * cores / nsteps)          # ~1.5 M seg-steps/s/core
+    order = np.argsort(sizes, kind="stable")                  # small networks first; dominant basin last
+    take = order[np.cumsum(sizes[order]) <= max(budget, sizes[order][0])]
+    if take.size == 0:
+        take = order[:1]
+    part, _ = sharding.lpt_assign(sizes[take], cores)
+    net_worker = np.full(uniq.shape[0], -1, dtype=np.int64)
+    net_worker[take] = part
+    row_worker = net_worker[lab]
+    up_ptr, up_idx = upstream_csr(to)
+    from troute_amd.distributed import restrict_csr
+
+    jobs = []
+    for w in range(cores):
+        rows = np.flatnonzero(row_worker == w)
+        if rows.size == 0:
+            continue
+        g2l = np.full(nseg, -1, dtype=np.int64)
+        g2l[rows] = np.arange(rows.shape[0])
+        lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)
+        lvl, _, _ = topology_levels(lp, li)
+        jobs.append((lp, li, lvl, np.ascontiguousarray(net["params"][rows]),
+                     np.zeros((rows.shape[0], 3), np.float32), np.ascontiguousarray(net["qlat"][rows])))
+
+    def run(j):
+        lp, li, lvl, par, q0, ql = j
+        O.network_by_segment(nsteps, qts, lp, li, lvl, par, q0, ql, short_ts, ref_name=ref_name)
+        return par.shape[0]
+
+    O.lib()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        done = sum(ex.map(run, jobs))
+    dt = time.perf_counter() - t0
+    return {
+        "value": done * nsteps / dt, "unit": "segment-timesteps/s", "cores": cores, "kind": kind,
+        "sample": f"{int(take.size)} independent networks ({done} segments, dominant basin excluded) x "
+                  f"{nsteps} steps, {dt:.1f} s wall, {len(jobs)} threads, by-network parallelism",
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    from troute_amd import _lib, synthetic
+    from troute_amd.distributed import ShardedRouter
+
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libtrmc.so has no CPU fallback")
+
+    kw = {}
+    if a.nseg:
+        kw["nseg"] = a.nseg
+        kw["nnet"] = a.nnet or max(3, a.nseg // 185)
+    cache = os.environ.get("TRMC_CACHE", "/tmp/trmc_cache")
+    t0 = time.perf_counter()
+    if rank == 0:
+        net = synthetic.generate(cache_dir=cache, **kw)
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        net = synthetic.generate(cache_dir=cache, **kw)
+    t_gen = time.perf_counter() - t0
+    to, params, qlat = net["to"], net["params"], net["qlat"]
+    nseg = to.shape[0]
+    q0 = np.zeros((nseg, 3), dtype=np.float32)
+
+    def all_gather_np(arr):
+        """all_gather of ragged numpy blocks over RCCL (padded to the largest block)."""
+        import torch
+        arr = np.ascontiguousarray(arr)
+        n = torch.tensor([arr.shape[0]], device="cuda", dtype=torch.int64)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        ns = [int(x.item()) for x in ns]
+        tail = arr.shape[1:]
+        buf = torch.zeros((max(ns),) + tail, device="cuda", dtype=torch.from_numpy(arr[:0]).dtype)
+        if arr.shape[0]:
+            buf[:arr.shape[0]] = torch.from_numpy(arr).cuda()
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        return [o[:k].cpu().numpy() for o, k in zip(outs, ns)]
+
+    t0 = time.perf_counter()
+    router = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision)
+    t_plan = time.perf_counter() - t0
+    router.upload(a.nsteps, qlat, q0)
+    ag = all_gather_np if world > 1 else None
+
+    def sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(short_ts, steps, warmup):
+        for _ in range(warmup):
+            router.route(a.qts, short_ts, ag)
+        sync()
+        t0 = time.perf_counter()
+        mains, totals, launches = [], [], 0
+        for _ in range(steps):
+            rows, hyd = router.route(a.qts, short_ts, ag)
+            st = router.last_stats["phase0"]
+            mains.append(st["ms_main"])
+            totals.append(st["ms_total"])
+            launches = st["main_launches"]
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, float(np.mean(mains)), float(np.mean(totals)), launches, router.last_stats, hyd
+
+    el, ms_main, ms_total, launches, stats, hyd = timed(True, a.steps, a.warmup)
+    segsteps_job = nseg * a.nsteps
+    value = segsteps_job * a.steps / el
+    info = router.plan0.info()
+    seg0 = stats["phase0"]["segment_steps"]
+    achieved = seg0 * ALG_BYTES_PER_SEGSTEP * (a.precision // 32) / (ms_main * 1e-3) / 1e9
+
+    full = None
+    if not a.no_full_ts:
+        fsteps = max(1, min(a.steps, 3))
+        el_f, ms_main_f, ms_total_f, launches_f, stats_f, _ = timed(False, fsteps, 1)
+        full = {
+            "value": segsteps_job * fsteps / el_f, "unit": "segment-timesteps/s", "ms_per_step": el_f / fsteps * 1e3,
+            "launches": launches_f, "ms_main": ms_main_f,
+            "roofline_frac": stats_f["phase0"]["segment_steps"] * ALG_BYTES_PER_SEGSTEP * (a.precision // 32)
+            / (ms_main_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(net, a.nsteps, a.qts, True, a.cpu_seconds)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            cpu = {"error": repr(e)}
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "segment-timesteps/sec, CONUS NHD 2.7M-seg MC",
+            "value": value,
+            "unit": "segment-timesteps/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if a.precision == 32 else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic CONUS NHDPlus-shaped network, MC-only, 24 h @ 300 s dt (configs[2])",
+                "segments": int(nseg), "networks": int(len(net["net_sizes"])), "timesteps": a.nsteps,
+                "qts_subdivisions": a.qts, "assume_short_ts": True, "cold_start": True,
+                "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
+                "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
+                "generate_s": round(t_gen, 2), "plan_s": round(t_plan, 2),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_mc_step<float,true>" if a.precision == 32 else "k_mc_step<double,true>",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "launches_per_step": launches, "avg_launch_ms": ms_main / max(launches, 1),
+                "alg_bytes_per_launch": seg0 / max(launches, 1) * ALG_BYTES_PER_SEGSTEP * (a.precision // 32),
+                "ms_main": ms_main, "ms_total_device": ms_total,
+            },
+            "cpu_baseline": cpu,
+            "full_ts": full,
+            "outlet_hydrographs": list(hyd.shape),
+        }
+        print(json.dumps(line))
+    router.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,12 +146,6 @@ def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assu
     params    : [nseg, 9] in PARAM_COLS order;  q0 [nseg,3];  qlat [nseg,nq]
     returns   : fvd [nseg, nsteps+1, 3]   (column 0 of axis 1 = initial state)
     """
-    params = np.ascontiguousarray(params)
-    dt = params.dtype
-    ct, sfx = _sfx(dt, det)
-    q0 = np.ascontiguousarray(q0, dtype=dt)
-    qlat = np.ascontiguousarray(qlat, dtype=dt)
-    nseg = params.shape[0]
     reach_ptr = np.zeros(len(reaches) + 1, dtype=np.int64)
     reach_ptr[1:] = np.cumsum([len(r) for r in reaches])
     reach_seg = (np.concatenate([np.asarray(r, dtype=np.int64) for r in reaches])
@@ -159,6 +153,25 @@ def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assu
     up_ptr = np.zeros(len(upstreams) + 1, dtype=np.int64)
     up_ptr[1:] = np.cumsum([len(u) for u in upstreams])
     up_idx = (np.concatenate([np.asarray(u, dtype=np.int64) for u in upstreams] + [np.zeros(0, np.int64)]))
+    return network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_idx, params, q0, qlat,
+                          assume_short_ts, prefilled, fvd_init, ref_name, return_iters, det)
+
+
+def network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_idx, params, q0, qlat,
+                   assume_short_ts, prefilled=None, fvd_init=None, ref_name=None, return_iters=False,
+                   det=False):
+    """As network(), with the reach lists already flattened to CSR arrays (int64)."""
+    params = np.ascontiguousarray(params)
+    dt = params.dtype
+    ct, sfx = _sfx(dt, det)
+    q0 = np.ascontiguousarray(q0, dtype=dt)
+    qlat = np.ascontiguousarray(qlat, dtype=dt)
+    nseg = params.shape[0]
+    reach_ptr = np.ascontiguousarray(reach_ptr, dtype=np.int64)
+    reach_seg = np.ascontiguousarray(reach_seg, dtype=np.int64)
+    up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
+    up_idx = np.ascontiguousarray(up_idx, dtype=np.int64)
+    nreach = reach_ptr.shape[0] - 1
     fvd = np.zeros((nseg, nsteps + 1, 3), dtype=dt) if fvd_init is None else np.ascontiguousarray(fvd_init, dtype=dt)
     pre = None if prefilled is None else np.ascontiguousarray(prefilled, dtype=np.uint8)
     ref = C.c_void_p(0)
@@ -167,9 +180,28 @@ def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assu
     iters = C.c_long(0)
     fn = getattr(lib(), f"mc_oracle_network_{sfx}")
     fn.restype = None
-    fn(C.c_long(nseg), C.c_int(nsteps), C.c_int(qts_subdivisions), C.c_long(len(reaches)),
+    fn(C.c_long(nseg), C.c_int(nsteps), C.c_int(qts_subdivisions), C.c_long(nreach),
        _ptr(reach_ptr, C.c_long), _ptr(reach_seg, C.c_long), _ptr(up_ptr, C.c_long),
        _ptr(up_idx, C.c_long), _ptr(params, ct), _ptr(q0, ct), _ptr(qlat, ct),
        C.c_long(qlat.shape[1]), C.c_int(int(bool(assume_short_ts))),
        None if pre is None else _ptr(pre, C.c_ubyte), _ptr(fvd, ct), ref, C.byref(iters))
     return (fvd, iters.value) if return_iters else fvd
+
+
+def network_by_segment(nsteps, qts_subdivisions, up_ptr, up_idx, level, params, q0, qlat, assume_short_ts,
+                       **kw):
+    """Drive the loop with every segment as its own one-segment reach, visited in level order.
+    Identical arithmetic to reach-wise execution: inside a reach the reference hands segment i+1
+    exactly (q[i,t-1], q[i,t]) (mc_reach.pyx:133-138), which is what a one-element upstream sum gives."""
+    order = np.argsort(level, kind="stable").astype(np.int64)
+    n = order.shape[0]
+    reach_ptr = np.arange(n + 1, dtype=np.int64)
+    cnt = (up_ptr[1:] - up_ptr[:-1])[order]
+    r_up_ptr = np.zeros(n + 1, dtype=np.int64)
+    r_up_ptr[1:] = np.cumsum(cnt)
+    # gather the upstream lists in visiting order
+    starts = up_ptr[:-1][order]
+    rep = np.repeat(starts - r_up_ptr[:-1], cnt)
+    r_up_idx = up_idx[np.arange(r_up_ptr[-1]) + rep] if r_up_ptr[-1] else np.zeros(0, np.int64)
+    return network_arrays(nsteps, qts_subdivisions, reach_ptr, order, r_up_ptr, r_up_idx, params, q0, qlat,
+                          assume_short_ts, **kw)
