@@ -73,9 +73,10 @@ def cpu_baseline(net, nsteps, qts, short_ts, target_s):
     outlet = sharding.outlet_of(to)
     uniq, lab = np.unique(outlet, return_inverse=True)
     sizes = np.bincount(lab)
-    budget = int(1.5e6 * target_s * cores / nsteps)          # ~1.5 M seg-steps/s/core
-    order = np.argsort(sizes, kind="stable")                  # small networks first; dominant basin last
-    take = order[np.cumsum(sizes[order]) <= max(budget, sizes[order][0])]
+    per_thread = int(1.5e6 * target_s / nsteps)              # ~1.5 M seg-steps/s/core
+    order = np.argsort(sizes, kind="stable")                  # small networks first
+    order = order[sizes[order] <= max(per_thread, int(sizes.min()))]   # a network never exceeds one thread's budget
+    take = order[np.cumsum(sizes[order]) <= per_thread * cores]
     if take.size == 0:
         take = order[:1]
     part, _ = sharding.lpt_assign(sizes[take], cores)
@@ -109,7 +110,8 @@ def cpu_baseline(net, nsteps, qts, short_ts, target_s):
     dt = time.perf_counter() - t0
     return {
         "value": done * nsteps / dt, "unit": "segment-timesteps/s", "cores": cores, "kind": kind,
-        "sample": f"{int(take.size)} independent networks ({done} segments, dominant basin excluded) x "
+        "sample": f"{int(take.size)} of {int(uniq.shape[0])} independent networks ({done} segments; networks larger than "
+                  f"{per_thread} segments, incl. the dominant basin, left out) x "
                   f"{nsteps} steps, {dt:.1f} s wall, {len(jobs)} threads, by-network parallelism",
     }
 

@@ -398,9 +398,9 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
 
     HIP_TRY(hipEventRecord(pl->ev[0], st));
-    // the reference allocates flowveldepth as zeros (mc_reach.pyx:253): rows never written
-    // (time rows of padding lanes, velocity of boundary rows) must read as 0
-    HIP_TRY(hipMemsetAsync(pl->tm.p, 0, 3 * plane * sizeof(T), st));
+    // every element the result reads is written below: time row 0 by k_init_state, rows 1..nsteps
+    // of routed positions by k_mc_step and of boundary positions by k_fill_boundary (the padding
+    // lanes of each row are never read), so the reference's zero fill (mc_reach.pyx:253) is moot
     if (n > 0) {
         hipLaunchKernelGGL((k_prep_qlat<T>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
                            (const T *)pl->in_qlat.p, row_of_pos, (T *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);

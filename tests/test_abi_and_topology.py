@@ -1,0 +1,164 @@
+"""CPU-side checks of the C-ABI library: it loads, exports what include/trmc.h declares, refuses to
+compute without a GPU, and its native topology flattening is right.  No GPU compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+from troute_amd import _lib
+from troute_amd.plan import RoutingPlan, csr_from_lists, segments, topology_levels
+from troute_amd.routing.fast_reach.mc_reach import _flatten_network, binary_find, column_mapper
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "trmc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(trmc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 16
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in trmc.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with trmc.h"
+    assert lib.trmc_abi_version() == 1
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="CPU-only check")
+def test_no_cpu_fallback():
+    """Without a HIP device every computing entry point fails loudly."""
+    up_ptr, up_idx = csr_from_lists([[], [0]])
+    params = np.ones((2, 9), np.float32)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        RoutingPlan(up_ptr, up_idx, params)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        segments(np.ones((1, 15), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "t-route_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{fn} imports the oracle"
+                assert "libmc_oracle" not in src, f"{fn} loads the oracle library"
+                assert not re.search(r'#\s*include\s*"[^"]*oracle', src), f"{fn} includes oracle code"
+    # and the built product library links nothing from it
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
+
+
+# ---- topology flattening (native, host only) ---------------------------------------------------------
+def check_levels(up_ptr, up_idx, lvl, pos, nl, boundary=None):
+    n = up_ptr.shape[0] - 1
+    b = np.zeros(n, bool) if boundary is None else np.asarray(boundary, bool)
+    assert sorted(pos.tolist()) == list(range(n))                      # a permutation
+    assert (lvl[b] == -1).all() and (lvl[~b] >= 0).all()
+    assert lvl.max() + 1 == nl
+    for r in range(n):
+        if b[r]:
+            continue
+        ups = up_idx[up_ptr[r]:up_ptr[r + 1]]
+        ups = ups[~b[ups]]
+        want = 0 if ups.size == 0 else lvl[ups].max() + 1            # longest path from a headwater
+        assert lvl[r] == want
+    # every level is one contiguous slice of the plan order, boundary rows first
+    order = np.argsort(pos)
+    assert (np.diff(lvl[order]) >= 0).all()
+
+
+def test_levels_toy_network():
+    toy = H.load_toy()
+    rconn = {int(k): v for k, v in toy["expected_rconn"].items()}
+    ids = np.array(sorted(rconn), dtype=np.int64)
+    row = {int(s): i for i, s in enumerate(ids)}
+    up_ptr, up_idx = csr_from_lists([[row[u] for u in rconn[int(s)]] for s in ids])
+    lvl, pos, nl = topology_levels(up_ptr, up_idx)
+    check_levels(up_ptr, up_idx, lvl, pos, nl)
+    # the long chain 20->19->18->17->16->...->8 of test_nhd_network.py:2-35
+    assert lvl[row[20]] == 0 and lvl[row[8]] == 12 and nl == 13
+    assert lvl[row[2800]] == 0          # isolated segment
+
+
+def test_levels_lowercolorado_match_survey_probe():
+    lc = H.LowerColorado()
+    up_ptr, up_idx, in_reach = _flatten_network([(r, 0) for r in lc.reaches], lc.rconn, lc.ids)
+    assert in_reach.all()
+    lvl, pos, nl = topology_levels(up_ptr, up_idx)
+    assert nl == 649                                                   # longest segment path
+    fan = np.bincount(np.diff(up_ptr))
+    assert fan[3] == 7                                                 # junction fan-in {2: 3856, 3: 7}
+    lv = lvl.astype(np.int64)
+    has = up_ptr[1:] > up_ptr[:-1]
+    mx = np.maximum.reduceat(lv[up_idx], up_ptr[:-1][has])
+    assert np.array_equal(lv[has], mx + 1) and (lv[~has] == 0).all()
+    order = np.argsort(pos)
+    assert (np.diff(lvl[order]) >= 0).all()
+
+
+def test_levels_with_boundary_rows():
+    ups = [[], [0], [1], [2, 5], [], [4]]
+    up_ptr, up_idx = csr_from_lists(ups)
+    b = np.array([0, 0, 1, 0, 0, 0], np.uint8)                          # row 2 carries a prescribed hydrograph
+    lvl, pos, nl = topology_levels(up_ptr, up_idx, b)
+    check_levels(up_ptr, up_idx, lvl, pos, nl, b)
+    assert lvl.tolist() == [0, 1, -1, 2, 0, 1] and pos[2] == 0
+
+
+def test_cycle_and_bad_input_raise_valueerror():
+    up_ptr, up_idx = csr_from_lists([[1], [0]])
+    with pytest.raises(ValueError, match="cycle"):
+        topology_levels(up_ptr, up_idx)
+    up_ptr, up_idx = csr_from_lists([[0]])
+    with pytest.raises(ValueError):
+        topology_levels(up_ptr, up_idx)
+    with pytest.raises(ValueError, match="not a row"):
+        topology_levels(np.array([0, 1], np.int64), np.array([7], np.int64))
+    lvl, pos, nl = topology_levels(np.array([0], np.int64), np.zeros(0, np.int64))      # empty network
+    assert nl == 0 and lvl.size == 0
+
+
+def test_levels_random_forest_large():
+    rng = np.random.default_rng(3)
+    to = H.random_network(rng, 20000)
+    reaches, heads_up, ups = H.reaches_from_to(to)
+    up_ptr, up_idx = csr_from_lists(ups)
+    lvl, pos, nl = topology_levels(up_ptr, up_idx)
+    lv = lvl.astype(np.int64)
+    has = up_ptr[1:] > up_ptr[:-1]
+    mx = np.maximum.reduceat(lv[up_idx], up_ptr[:-1][has])
+    assert np.array_equal(lv[has], mx + 1) and (lv[~has] == 0).all()
+    assert sorted(pos.tolist()) == list(range(20000))
+
+
+# ---- host shims of the reference's helpers -----------------------------------------------------------
+def test_binary_find_and_column_mapper():
+    arr = np.array([3, 5, 9, 12], np.int64)
+    assert binary_find(arr, [9, 3]) == [2, 0]
+    with pytest.raises(ValueError, match="not found"):
+        binary_find(arr, [4])
+    with pytest.raises(ValueError, match="not found"):
+        binary_find(arr, [99])
+    assert column_mapper(H.DATA_COLS) == [0, 4, 1, 2, 3, 5, 6, 7, 8]   # mc_reach.pyx:150-162
+
+
+def test_flatten_network_matches_reference_structs():
+    """Upstream lists: head of a reach <- upstream_connections[reach[0]] in dict order; inside a reach
+    <- the previous segment (mc_reach.pyx:288-289, :133-138)."""
+    toy = H.load_toy()
+    for tw, reaches in toy["reaches_bytw"].items():
+        net = {int(k): v for k, v in toy["independent_networks"][tw].items()}
+        ids = np.array(sorted(net), dtype=np.int64)
+        row = {int(s): i for i, s in enumerate(ids)}
+        up_ptr, up_idx, in_reach = _flatten_network([(r, 0) for r in reaches], net, ids)
+        assert in_reach.all()
+        for r in reaches:
+            assert up_idx[up_ptr[row[r[0]]]:up_ptr[row[r[0]] + 1]].tolist() == [row[u] for u in net[r[0]]]
+            for a, b in zip(r[:-1], r[1:]):
+                assert up_idx[up_ptr[row[b]]:up_ptr[row[b] + 1]].tolist() == [row[a]]
+    with pytest.raises(NotImplementedError):
+        _flatten_network([([1], 1)], {}, np.array([1], np.int64))

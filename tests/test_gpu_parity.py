@@ -1,0 +1,333 @@
+"""Parity of the HIP path against the oracle and the reference goldens -- needs an MI355X.
+
+All calls go through the C ABI (ctypes -> libtrmc.so).  The fp32 path uses the bit-reproducible
+power of det_pow.h, so it is compared BIT FOR BIT with the oracle's det instantiation (same
+restated algorithm on the CPU); the oracle's libm instantiation is pinned bit-exactly to the
+reference Fortran in test_oracle_pinning.py, and the goldens below are reference-Fortran outputs.
+
+Stated tolerances
+  fp32 vs oracle(det)        : bit-identical (NaN patterns included), every test
+  fp32 vs reference Fortran  : segment step   >= 99.5 % of vectors identical, max rel 1e-5
+                               short-ts net   >= 99 % of values identical, max abs 2e-6 m3/s
+  fp64 vs reference (fp64)   : segment step   rel 1e-9 at p99.9 (device pow is ~1 ulp, not glibc's)
+                               short-ts net   rel 1e-10
+  full-ts from a cold start is chaotic in the reference itself (test_oracle_pinning.py), hence
+  bit-exactness against the det oracle is THE parity statement there.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import oracle as O
+from troute_amd import _lib
+from troute_amd.plan import RoutingPlan, csr_from_lists, segments, topology_levels
+from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+from troute_amd.routing.fast_reach.reach import compute_reach_kernel
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def assert_bit_identical(got, want, what=""):
+    gb, wb = bits(got), bits(want)
+    if not np.array_equal(gb, wb):
+        bad = np.argwhere(gb != wb)
+        raise AssertionError(f"{what}: {bad.shape[0]} of {gb.size} values differ; first at {bad[0].tolist()}: "
+                             f"{got[tuple(bad[0])]!r} vs {want[tuple(bad[0])]!r}")
+
+
+def test_gpu_present_and_native_library_loaded():
+    assert _lib.device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libtrmc.so" in maps
+
+
+# ---- one segment, one timestep (reference: c_muskingcungenwm / compute_reach_kernel) ----------------
+def test_segment_step_fp32_bit_identical_to_det_oracle():
+    x = H.load_kernel_vectors()["inputs_f64"].astype(np.float32)
+    assert_bit_identical(segments(x), O.segments(x, det=True), "12k kernel vectors")
+
+
+def test_segment_step_fp32_vs_reference_fortran():
+    kv = H.load_kernel_vectors()
+    got = segments(kv["inputs_f64"].astype(np.float32))
+    ref = kv["ref_qj0_f32"]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = np.isfinite(ref).all(1)
+    rel = np.abs(got[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30)
+    assert (rel[:, :3].max(1) == 0).mean() >= 0.995
+    assert rel.max() < 1e-5
+
+
+def test_segment_step_fp64_vs_reference_fortran():
+    kv = H.load_kernel_vectors()
+    x = kv["inputs_f64"].astype(np.float32).astype(np.float64)
+    got = segments(x)
+    ref = kv["ref_qj0_f64"]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = np.isfinite(ref).all(1)
+    rel = np.abs(got[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-300)
+    assert np.quantile(rel[:, :3].max(1), 0.999) < 1e-9
+    assert rel[:, :3].max() < 1e-5          # one ill-conditioned vector (secant at its 1 % exit)
+
+
+def test_compute_reach_kernel_dict_entry():
+    """The reference's dict-returning test entry (reach.pyx:66-103) on its low-flow KAT."""
+    r = compute_reach_kernel(60.0, 0.04598825, 0.04598825, 0.21487340, 40.0, 1800.0, 112.0, 448.0,
+                             623.5999755859375, 0.02800000086426735, 0.03136000037193298,
+                             1.399999976158142, 0.0017999999690800905, 0.0704801953, 0.0100334705)
+    assert set(r) == {"qdc", "velc", "depthc", "cn", "ck", "X"}
+    exp = (0.7570106983184814, 0.12373604625463486, 0.02334451675415039)   # mc_sseg_stime_NOLOOP_demo.py:229-231
+    assert np.allclose([r["qdc"], r["velc"], r["depthc"]], exp, rtol=2e-7)
+
+
+# ---- LowerColorado_TX MC-only through the drop-in callable --------------------------------------------
+@pytest.fixture(scope="module")
+def lc():
+    return H.LowerColorado()
+
+
+def route_lc(lc, short, precision=32, **kw):
+    args = mc_only_args(lc.nts, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values,
+                        lc.q0, lc.qlat, assume_short_ts=short)
+    r = compute_network_structured(*args, precision=precision, return_stats=True, **kw)
+    return r, r[1].reshape(lc.nseg, lc.nts, 3)
+
+
+@pytest.mark.parametrize("short", [True, False])
+def test_lowercolorado_fp32_bit_identical_to_det_oracle(lc, short):
+    r, fvd = route_lc(lc, short)
+    reaches, ups = lc.row_lists()
+    want = O.network(lc.nts, lc.qts, reaches, ups, lc.params9, lc.q0, lc.qlat, short, det=True)[:, 1:, :]
+    assert_bit_identical(fvd, want, f"LowerColorado short={short}")
+    st = r[-1]
+    assert st["nlevels"] == 649 and st["nseg_routed"] == 11248
+    assert st["main_launches"] == (288 if short else 649 + 288 - 1)
+
+
+def test_lowercolorado_return_tuple_shape(lc):
+    r, _ = route_lc(lc, True)
+    assert len(r) == 11                                   # 10-tuple + stats
+    ids, fvd = r[0], r[1]
+    assert ids.dtype == np.intp and np.array_equal(ids, lc.ids)
+    assert fvd.shape == (lc.nseg, lc.nts * 3) and fvd.dtype == np.float32
+    assert r[2] == 0 and len(r[3]) == 3 and len(r[4]) == 5 and len(r[5]) == 5
+    assert r[6].shape == (lc.nseg, lc.nts) and len(r[7]) == 3 and r[8].shape == (0, lc.nts + 1) and len(r[9]) == 4
+
+
+def test_lowercolorado_fp32_vs_reference_golden_short_ts(lc):
+    _, fvd = route_lc(lc, True)
+    g = lc.golden()
+    got, want = fvd[:, g["tsel"] - 1, :], g["shortts_f32_tsel"]
+    assert (got == want).mean() >= 0.99
+    assert np.abs(got - want).max() < 2e-6
+    gp, wp = fvd[g["probes"]], g["shortts_f32_probes"][:, 1:, :]
+    assert (gp == wp).mean() >= 0.99 and np.abs(gp - wp).max() < 2e-6
+
+
+def test_lowercolorado_fp32_vs_reference_golden_full_ts(lc):
+    """Chaotic regime: only a distributional statement is meaningful against the libm-pow reference."""
+    _, fvd = route_lc(lc, False)
+    g = lc.golden()
+    got, want = fvd[:, g["tsel"] - 1, :], g["fullts_f32_tsel"]
+    assert (got == want).mean() >= 0.90
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-6)
+    assert np.quantile(rel, 0.99) < 1e-4
+
+
+def test_lowercolorado_fp64_vs_reference_golden(lc):
+    _, fvd = route_lc(lc, True, precision=64)
+    g = lc.golden()
+    assert fvd.dtype == np.float64
+    for got, want in ((fvd[:, -1, :], g["shortts_f64_final"]), (fvd[g["probes"]], g["shortts_f64_probes"][:, 1:, :])):
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-6)
+        assert rel.max() < 1e-10
+
+
+def test_final_state_and_outlet_gather_agree_with_full_result(lc):
+    from troute_amd.routing.fast_reach.mc_reach import _flatten_network
+    up_ptr, up_idx, _ = _flatten_network([(r, 0) for r in lc.reaches], lc.rconn, lc.ids)
+    with RoutingPlan(up_ptr, up_idx, lc.params9) as plan:
+        fvd = plan.route(lc.nts, lc.qts, True, lc.qlat, lc.q0)
+        fs = plan.download_final_state()
+        rows = np.array([0, 17, lc.nseg - 1, 5000], np.int64)
+        hyd = plan.gather_flow_rows(rows)
+    # new_q0 = fvd[:, [-3,-3,-1]] (AbstractNetwork.py:182-190)
+    assert_bit_identical(fs, fvd[:, -1, :][:, [0, 0, 2]], "final state")
+    assert_bit_identical(hyd, fvd[rows, :, 0], "gathered hydrographs")
+
+
+def test_upstream_results_composition_equals_whole_network(lc):
+    """Ordered sub-network execution (compute.py:553-907): route the part above a cut segment first,
+    hand its tailwater hydrograph over as upstream_results (mc_reach.pyx:451-469), route the rest --
+    bit-identical to routing the whole network at once, and the hand-off row is masked from the output."""
+    row = {int(s): i for i, s in enumerate(lc.ids)}
+    # pick the last segment of a mid-network reach with a sizeable sub-tree
+    up_of = lc.rconn
+    def subtree(seg):
+        out, stack = [], [seg]
+        while stack:
+            s = stack.pop()
+            out.append(s)
+            stack.extend(up_of.get(s, []))
+        return out
+    cut = None
+    for r in lc.reaches[::-1]:
+        n = len(subtree(r[-1]))
+        if 800 < n < 4000:
+            cut = r[-1]
+            break
+    assert cut is not None
+    upper = set(subtree(cut))
+    for short in (True, False):
+        _, whole = route_lc(lc, short)
+        # upper part on its own
+        r_up = [r for r in lc.reaches if r[0] in upper]
+        ids_up = np.array(sorted(upper), np.int64)
+        sel = np.array([row[s] for s in ids_up])
+        a = mc_only_args(lc.nts, lc.dt, lc.qts, r_up, lc.rconn, ids_up, lc.data_cols, lc.data_values[sel],
+                         lc.q0[sel], lc.qlat[sel], assume_short_ts=short)
+        ru = compute_network_structured(*a)
+        fu = ru[1].reshape(len(ids_up), lc.nts, 3)
+        assert_bit_identical(fu, whole[sel], "upper part alone")
+        # lower part, fed by the cut segment's hydrograph
+        ids_lo = np.array(sorted((set(lc.ids.tolist()) - upper) | {cut}), np.int64)
+        sel = np.array([row[s] for s in ids_lo])
+        r_lo = [r for r in lc.reaches if r[0] not in upper]
+        pos = int(np.searchsorted(ids_lo, cut))
+        ur = {cut: {"position_index": pos, "results": fu[int(np.searchsorted(ids_up, cut))].reshape(-1)}}
+        a = mc_only_args(lc.nts, lc.dt, lc.qts, r_lo, lc.rconn, ids_lo, lc.data_cols, lc.data_values[sel],
+                         lc.q0[sel], lc.qlat[sel], upstream_results=ur, assume_short_ts=short)
+        rl = compute_network_structured(*a)
+        assert rl[0].shape[0] == len(ids_lo) - 1 and cut not in rl[0]
+        keep = np.array([row[s] for s in rl[0]])
+        assert_bit_identical(rl[1].reshape(-1, lc.nts, 3), whole[keep], f"lower part short={short}")
+
+
+# ---- ragged / edge shapes on random forests ---------------------------------------------------------------
+def synth_inputs(rng, n, nq, dt_uniform=True):
+    p = np.stack([np.full(n, 300.0) if dt_uniform else rng.choice([60.0, 300.0, 600.0], n),
+                  rng.uniform(200, 4000, n), rng.uniform(0.5, 20, n), np.zeros(n), np.zeros(n),
+                  rng.choice([0.04, 0.05, 0.06], n), np.zeros(n), rng.uniform(0.1, 2.0, n),
+                  np.exp(rng.uniform(np.log(1e-4), np.log(0.1), n))], 1)
+    p[:, 3] = p[:, 2] * 5 / 3
+    p[:, 4] = p[:, 3] * 3
+    p[:, 6] = 2 * p[:, 5]
+    ql = (np.exp(rng.normal(np.log(5e-3), 2.0, (n, nq))) * (rng.random((n, nq)) > 0.1)).astype(np.float32)
+    q0 = np.stack([rng.uniform(0, 2, n), rng.uniform(0, 2, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+    q0[rng.random(n) < 0.3] = 0
+    return p.astype(np.float32), ql, q0
+
+
+def run_both(ups, params, qlat, q0, nsteps, qts, short):
+    up_ptr, up_idx = csr_from_lists(ups)
+    lvl, _, _ = topology_levels(up_ptr, up_idx)
+    with RoutingPlan(up_ptr, up_idx, params) as plan:
+        got = plan.route(nsteps, qts, short, qlat, q0)
+    want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params, q0, qlat, short, det=True)[:, 1:, :]
+    return got, want
+
+
+@pytest.mark.parametrize("nseg", [1, 2, 63, 64, 65, 1000, 6000])
+@pytest.mark.parametrize("short", [True, False])
+def test_random_forests_bit_identical(nseg, short):
+    rng = np.random.default_rng(1000 + nseg)
+    to = H.random_network(rng, nseg)
+    _, _, ups = H.reaches_from_to(to)
+    nsteps, qts = 30, 4
+    params, qlat, q0 = synth_inputs(rng, nseg, 8)
+    got, want = run_both(ups, params, qlat, q0, nsteps, qts, short)
+    assert_bit_identical(got, want, f"forest n={nseg} short={short}")
+
+
+@pytest.mark.parametrize("nsteps,qts", [(1, 1), (65, 1), (130, 12), (64, 64)])
+def test_timestep_and_forcing_shapes(nsteps, qts):
+    """Tile edges of the result transpose (64-step tiles), qts = 1 (one forcing column per step), one
+    single step."""
+    rng = np.random.default_rng(nsteps * 7 + qts)
+    nseg = 777
+    _, _, ups = H.reaches_from_to(H.random_network(rng, nseg))
+    nq = (nsteps - 1) // qts + 1
+    params, qlat, q0 = synth_inputs(rng, nseg, nq)
+    for short in (True, False):
+        got, want = run_both(ups, params, qlat, q0, nsteps, qts, short)
+        assert_bit_identical(got, want, f"nsteps={nsteps} qts={qts} short={short}")
+
+
+def test_deep_chain_and_wide_junction():
+    """A single 1500-segment reach (1500 levels, width 1) and a junction with 6 tributaries."""
+    rng = np.random.default_rng(9)
+    n = 1500
+    ups = [[]] + [[i - 1] for i in range(1, n)]
+    params, qlat, q0 = synth_inputs(rng, n, 3)
+    for short in (True, False):
+        got, want = run_both(ups, params, qlat, q0, 20, 12, short)
+        assert_bit_identical(got, want, "deep chain")
+    ups = [[] for _ in range(6)] + [[3, 0, 5, 1, 4, 2]] + [[6]]          # summation order is the given order
+    params, qlat, q0 = synth_inputs(rng, 8, 3)
+    for short in (True, False):
+        got, want = run_both(ups, params, qlat, q0, 20, 12, short)
+        assert_bit_identical(got, want, "wide junction")
+
+
+def test_non_uniform_dt_column():
+    rng = np.random.default_rng(11)
+    nseg = 500
+    _, _, ups = H.reaches_from_to(H.random_network(rng, nseg))
+    params, qlat, q0 = synth_inputs(rng, nseg, 4, dt_uniform=False)
+    for short in (True, False):
+        got, want = run_both(ups, params, qlat, q0, 24, 6, short)
+        assert_bit_identical(got, want, "per-segment dt")
+
+
+def test_zero_forcing_zero_state_stays_zero():
+    rng = np.random.default_rng(12)
+    nseg = 300
+    _, _, ups = H.reaches_from_to(H.random_network(rng, nseg))
+    params, qlat, q0 = synth_inputs(rng, nseg, 2)
+    got, _ = run_both(ups, params, np.zeros_like(qlat), np.zeros_like(q0), 12, 12, False)
+    assert (got == 0).all()
+
+
+def test_random_forest_fp64_close_to_oracle():
+    rng = np.random.default_rng(13)
+    nseg = 2000
+    _, _, ups = H.reaches_from_to(H.random_network(rng, nseg))
+    params, qlat, q0 = synth_inputs(rng, nseg, 4)
+    up_ptr, up_idx = csr_from_lists(ups)
+    lvl, _, _ = topology_levels(up_ptr, up_idx)
+    with RoutingPlan(up_ptr, up_idx, params, precision=64) as plan:
+        got = plan.route(24, 6, True, qlat, q0)
+    want = O.network_by_segment(24, 6, up_ptr, up_idx, lvl, params.astype(np.float64), q0, qlat, True)[:, 1:, :]
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-9)
+    assert np.quantile(rel, 0.999) < 1e-9 and rel.max() < 1e-6
+
+
+# ---- the reference's error behaviour ---------------------------------------------------------------------
+def test_errors_match_reference(lc):
+    base = lambda **k: mc_only_args(lc.nts, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols,  # noqa: E731
+                                    lc.data_values, lc.q0, lc.qlat, **k)
+    a = base()
+    a[9] = lc.qlat[:-1]
+    with pytest.raises(ValueError, match="Number of rows in Qlat is incorrect"):
+        compute_network_structured(*a)
+    a = base()
+    a[9] = lc.qlat[:, :10]
+    with pytest.raises(ValueError, match="Number of columns"):
+        compute_network_structured(*a)
+    a = base()
+    a[7] = lc.data_values[:, :5]
+    with pytest.raises(ValueError, match="data_values shape mismatch"):
+        compute_network_structured(*a)
+    a = base()
+    a[3] = [(r, 0) for r in lc.reaches[:-1]] + [(lc.reaches[-1] + [123456789], 0)]
+    with pytest.raises(ValueError, match="not found"):
+        compute_network_structured(*a)
+    a = base()
+    a[3] = [(lc.reaches[0], 1)] + a[3][1:]
+    with pytest.raises(NotImplementedError):
+        compute_network_structured(*a)
