@@ -189,11 +189,13 @@ def network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_id
 
 
 def network_by_segment(nsteps, qts_subdivisions, up_ptr, up_idx, level, params, q0, qlat, assume_short_ts,
-                       **kw):
+                       routed=None, **kw):
     """Drive the loop with every segment as its own one-segment reach, visited in level order.
     Identical arithmetic to reach-wise execution: inside a reach the reference hands segment i+1
     exactly (q[i,t-1], q[i,t]) (mc_reach.pyx:133-138), which is what a one-element upstream sum gives."""
     order = np.argsort(level, kind="stable").astype(np.int64)
+    if routed is not None:                      # rows with a prescribed hydrograph are in no reach
+        order = order[np.asarray(routed, dtype=bool)[order]]
     n = order.shape[0]
     reach_ptr = np.arange(n + 1, dtype=np.int64)
     cnt = (up_ptr[1:] - up_ptr[:-1])[order]

@@ -1,0 +1,104 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the sharded router with an oracle-backed plan.
+
+Checks the partition (independent networks + dominant basin cut at tributary mouths), the
+phase-0 -> trunk hydrograph hand-off and the final outlet gather: the sharded job must reproduce
+the single-process result bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from troute_amd import sharding, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_conus(seed=5, nseg=6000, nnet=40):
+    return synthetic.generate(nseg=nseg, nnet=nnet, seed=seed, nq=3)
+
+
+def test_partition_properties():
+    net = small_conus()
+    to = net["to"]
+    for nparts in (1, 2, 4, 8):
+        part = sharding.partition(to, nparts)
+        piece, phase, owner = part["piece"], part["phase"], part["owner"]
+        assert piece.min() >= 0 and piece.max() == phase.shape[0] - 1
+        sizes = np.bincount(piece, minlength=phase.shape[0])
+        assert (sizes > 0).all()
+        # flow never enters a phase-0 piece from another piece; trunks are fed only through cut rows
+        has = to >= 0
+        src = np.flatnonzero(has)
+        dst = to[src]
+        cross = piece[src] != piece[dst]
+        assert (phase[piece[dst[cross]]] == 1).all() and (phase[piece[src[cross]]] == 0).all()
+        assert sorted(src[cross].tolist()) == sorted(part["cut_rows"].tolist())
+        if nparts == 1:
+            assert part["cut_rows"].size == 0
+        else:
+            load = np.bincount(owner[phase == 0], weights=sizes[phase == 0], minlength=nparts)
+            assert load.max() <= 1.25 * load.mean() + 50
+
+
+def test_outlet_and_subtree_helpers():
+    to = np.array([1, 2, -1, 2, -1, 4], np.int64)
+    assert sharding.outlet_of(to).tolist() == [2, 2, 2, 2, 4, 4]
+    assert sharding.subtree_sizes(to).tolist() == [1, 2, 4, 1, 2, 1]
+    part, load = sharding.lpt_assign([5, 4, 3, 3, 1], 2)
+    assert sorted(load.tolist()) == [8, 8]
+
+
+def _worker(rank, world, port, tmp, short):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle_plan import OraclePlan
+    from troute_amd.distributed import ShardedRouter
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = small_conus()
+
+    def all_gather_np(arr):
+        arr = np.ascontiguousarray(arr)
+        n = torch.tensor([arr.shape[0]], dtype=torch.int64)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        ns = [int(x) for x in ns]
+        buf = torch.zeros((max(ns),) + arr.shape[1:], dtype=torch.from_numpy(arr[:0]).dtype)
+        if arr.shape[0]:
+            buf[:arr.shape[0]] = torch.from_numpy(arr)
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        return [o[:k].numpy() for o, k in zip(outs, ns)]
+
+    router = ShardedRouter(net["to"], net["params"], rank=rank, world=world, plan_factory=OraclePlan)
+    q0 = np.zeros((net["to"].shape[0], 3), np.float32)
+    router.upload(24, net["qlat"], q0)
+    rows, hyd = router.route(12, short, all_gather_np)
+    np.savez(os.path.join(tmp, f"out_{rank}.npz"), rows=rows, hyd=hyd, ncut=router.cut_rows.shape[0],
+             has_trunk=router.plan1 is not None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("short", [True, False])
+def test_world2_gloo_equals_single_process(tmp_path, short):
+    import torch.multiprocessing as mp
+    from oracle_plan import OraclePlan
+    from troute_amd.distributed import ShardedRouter
+    net = small_conus()
+    q0 = np.zeros((net["to"].shape[0], 3), np.float32)
+    single = ShardedRouter(net["to"], net["params"], plan_factory=OraclePlan)
+    single.upload(24, net["qlat"], q0)
+    rows1, hyd1 = single.route(12, short)
+    assert rows1.shape[0] == 40                                     # one outlet per independent network
+    port = 29500 + (os.getpid() % 2000) + (1 if short else 0)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), short), nprocs=2, join=True)
+    outs = [np.load(tmp_path / f"out_{r}.npz") for r in range(2)]
+    assert int(outs[0]["ncut"]) > 0 and (bool(outs[0]["has_trunk"]) or bool(outs[1]["has_trunk"]))
+    for o in outs:                                                  # every rank ends with the full gather
+        assert np.array_equal(o["rows"], rows1)
+        assert np.array_equal(o["hyd"].view(np.uint32), hyd1.view(np.uint32))

@@ -1,0 +1,100 @@
+"""compute_nhd_routing_v02 drop-in on the GPU: DataFrame in, the reference's results list out."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import helpers as H
+from oracle import oracle as O
+from troute_amd import nhd_network as nn
+from troute_amd.routing.compute import _compute_func_map, compute_nhd_routing_v02, new_q0
+
+pytestmark = pytest.mark.gpu
+
+
+def frames(ids, params9, q0, qlat):
+    cols = ["dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0"]
+    param_df = pd.DataFrame(params9[:, 1:], index=ids, columns=cols[1:])
+    param_df["alt"] = 0.0
+    param_df["musk"] = 3600.0                              # extra columns the reference table carries
+    q0_df = pd.DataFrame(q0, index=ids, columns=["qu0", "qd0", "h0"])
+    qlat_df = pd.DataFrame(qlat, index=ids)
+    return param_df, q0_df, qlat_df
+
+
+def call(conn, param_df, q0_df, qlat_df, nts, qts, short, method="by-network"):
+    ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
+    e = pd.DataFrame()
+    return compute_nhd_routing_v02(
+        conn, rconn, {}, reaches_bytw, "V02-structured", method, 10000, 4, None, 300.0, nts, qts, ind,
+        param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, short, False, e, {}, e, False,
+        [{}, {}]), reaches_bytw, ind
+
+
+@pytest.mark.parametrize("short", [True, False])
+def test_lowercolorado_through_compute_nhd_routing_v02(short):
+    lc = H.LowerColorado()
+    conn = {int(s): ([int(t)] if t != 0 else []) for s, t in zip(lc.ids, lc.to)}
+    rng = np.random.default_rng(0)
+    shuffle = rng.permutation(lc.nseg)                     # the caller's table need not be sorted
+    param_df, q0_df, qlat_df = frames(lc.ids[shuffle], lc.params9[shuffle], lc.q0[shuffle], lc.qlat[shuffle])
+    results, reaches_bytw, ind = call(conn, param_df, q0_df, qlat_df, lc.nts, lc.qts, short)
+    assert len(results) == 1 and len(results[0]) == 10
+    ids, fvd = results[0][0], results[0][1]
+    assert np.array_equal(ids, lc.ids) and fvd.shape == (lc.nseg, lc.nts * 3)
+    reaches, ups = lc.row_lists()
+    want = O.network(lc.nts, lc.qts, reaches, ups, lc.params9, lc.q0, lc.qlat, short, det=True)[:, 1:, :]
+    assert np.array_equal(fvd.reshape(lc.nseg, lc.nts, 3).view(np.uint32), want.view(np.uint32))
+    nq0 = new_q0(results)
+    assert np.array_equal(nq0.values, want[:, -1, :][:, [0, 0, 2]])
+
+
+def test_many_networks_one_plan_results_per_tailwater():
+    """All independent networks of the call are routed by ONE plan; the result list still has one
+    tuple per tailwater, each equal to routing that network alone."""
+    toy = H.load_toy()
+    conn = {int(k): v for k, v in toy["expected_connections"].items()}
+    ids = np.array(sorted(conn), np.int64)
+    rng = np.random.default_rng(4)
+    n = len(ids)
+    p = np.stack([np.full(n, 300.0), rng.uniform(300, 3000, n), rng.uniform(1, 9, n), np.zeros(n), np.zeros(n),
+                  np.full(n, 0.06), np.full(n, 0.12), rng.uniform(0.2, 1.5, n), rng.uniform(1e-3, 2e-2, n)], 1)
+    p[:, 3] = p[:, 2] * 5 / 3
+    p[:, 4] = 3 * p[:, 3]
+    p = p.astype(np.float32)
+    qlat = rng.uniform(0, 0.4, (n, 3)).astype(np.float32)
+    q0 = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    param_df, q0_df, qlat_df = frames(ids, p, q0, qlat)
+    for method in ("serial", "by-subnetwork-jit-clustered"):
+        results, reaches_bytw, ind = call(conn, param_df, q0_df, qlat_df, 24, 12, False, method)
+        assert [sorted(r[0].tolist()) for r in results] == [sorted(ind[tw]) for tw in reaches_bytw]
+        row = {int(s): i for i, s in enumerate(ids)}
+        for r, tw in zip(results, reaches_bytw):
+            sel = np.array([row[int(s)] for s in r[0]])
+            loc = {int(s): i for i, s in enumerate(r[0])}
+            rl = [np.array([loc[s] for s in reach]) for reach in reaches_bytw[tw]]
+            ul = [np.array([loc[s] for s in ind[tw].get(reach[0], [])], dtype=np.int64) for reach in reaches_bytw[tw]]
+            want = O.network(24, 12, rl, ul, p[sel], q0[sel], qlat[sel], False, det=True)[:, 1:, :]
+            assert np.array_equal(r[1].reshape(len(sel), 24, 3).view(np.uint32), want.view(np.uint32))
+
+
+def test_plugin_seam_and_unsupported_inputs():
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured
+    assert _compute_func_map["V02-structured"] is compute_network_structured
+    assert _compute_func_map["anything-else"] is compute_network_structured        # defaultdict, compute.py:21
+    toy = H.load_toy()
+    conn = {int(k): v for k, v in toy["expected_connections"].items()}
+    ids = np.array(sorted(conn), np.int64)
+    n = len(ids)
+    p = np.ones((n, 9), np.float32)
+    param_df, q0_df, qlat_df = frames(ids, p, np.zeros((n, 3), np.float32), np.zeros((n, 2), np.float32))
+    ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
+    e = pd.DataFrame()
+    wb = pd.DataFrame({"LkArea": [1.0]}, index=[401])
+    with pytest.raises(NotImplementedError, match="waterbodies_df"):
+        compute_nhd_routing_v02(conn, rconn, {}, reaches_bytw, "V02-structured", "serial", 1, 1, None, 300.0, 12, 12,
+                                ind, param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, wb,
+                                {}, e, False, [{}, {}])
+    with pytest.raises(ValueError, match="Number of columns"):
+        compute_nhd_routing_v02(conn, rconn, {}, reaches_bytw, "V02-structured", "serial", 1, 1, None, 300.0, 48, 12,
+                                ind, param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, e,
+                                {}, e, False, [{}, {}])
