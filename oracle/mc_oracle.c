@@ -27,7 +27,7 @@
 #include "../t-route_amd/csrc/det_pow.h"
 #define REAL float
 #define SFX(x) x##_f32det
-#define POW trmc_det_powf
+#define POW(x, y) trmc_det_powf((x), (y), trmc_pow_tab_init)
 #define SQRT sqrtf
 #define FABS fabsf
 #include "mc_oracle_impl.inc"
@@ -40,7 +40,7 @@
 void mc_oracle_det_powf(long n, const float *x, const float *y, float *out)
 {
     long i;
-    for (i = 0; i < n; ++i) out[i] = trmc_det_powf(x[i], y[i]);
+    for (i = 0; i < n; ++i) out[i] = trmc_det_powf(x[i], y[i], trmc_pow_tab_init);
 }
 
 #define REAL double

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrmc.so")
+# TRMC_LIB_PATH: developer hook for A/B timing of experimental builds of the SAME library
+LIB_PATH = os.environ.get("TRMC_LIB_PATH") or os.path.join(_HERE, "libtrmc.so")
 
 TRMC_OK, TRMC_EINVAL, TRMC_ECYCLE, TRMC_ENODEVICE, TRMC_EHIP, TRMC_ENOMEM, TRMC_ESTATE = 0, -1, -2, -3, -4, -5, -6
 NPARAM = 9

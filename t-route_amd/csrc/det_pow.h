@@ -1,30 +1,41 @@
 /*
- * det_pow.h -- bit-reproducible x**y for the fp32 Muskingum-Cunge path.
+ * det_pow.h -- bit-reproducible powf for the fp32 Muskingum-Cunge path:
+ * a restatement of the powf of the C library the reference links against.
  *
  * Why: the reference kernel calls libm powf 8-9 times per segment-step
  * (R**(2/3), R**(5/3), ... MCsingleSegStime_f2py_NOLOOP.f90:169,:251-264,:328,
  * :356-362).  Every other operation it uses (+ - * / sqrt, comparisons) is
  * IEEE-exact and therefore identical on x86 and on gfx950; powf is the one
- * operation whose last bit depends on the library (glibc: 0.82 ulp, ocml:
- * different rounding).  Without the short-timestep assumption the reference
- * recurrence is numerically chaotic from a cold start (a 1e-15 relative input
- * change moves p99 of the flows by 20 % in fp64), so "close" is not testable
- * there -- only bit-equality is.  This header defines powf in terms of
- * operations that ARE exactly reproducible:
+ * operation whose last bit depends on the library.  Without the short-timestep
+ * assumption the reference recurrence is numerically chaotic from a cold
+ * start, so "close" is not testable there -- only bit-equality is.
  *
- *     powf(x, y) := RN_float( exp2_d( (double)y * log2_d((double)x) ) )
+ * Third-party algorithm restated here (not part of the reference tree):
+ *   GNU C Library 2.35 (Ubuntu GLIBC 2.35-0ubuntu3.11, the libm the reference
+ *   Fortran links in this image), powf:
+ *     sysdeps/ieee754/flt-32/e_powf.c            (log2_inline, exp2_inline, powf)
+ *     sysdeps/ieee754/flt-32/e_powf_log2_data.c  (16-entry {1/c, log2 c} table, degree-5 polynomial)
+ *     sysdeps/ieee754/flt-32/e_exp2f_data.c      (32-entry 2**(i/32) table, degree-3 polynomial)
+ *   (upstream: ARM optimized-routines, math/powf.c; published error 0.82 ulp).
+ *   The x86-64 build dispatches to the variant compiled with FMA contraction
+ *   (sysdeps/x86_64/fpu/multiarch/e_powf.c) on every FMA-capable CPU, so each
+ *   a*b+c below is ONE fused operation, written explicitly.
+ *   powf(x,y) = (float) exp2_d( (double)y * log2_d(x) ), all in IEEE double:
+ *     log2_d : x = 2**k * z, z in [0x1.66p-1, 0x1.66p0); table entry i from the
+ *              top 4 mantissa bits; r = z/c - 1; degree-5 polynomial in r
+ *     exp2_d : p = n/32 + r; table entry n mod 32 with the exponent n div 32
+ *              added into its bits; degree-3 polynomial in r
+ *   Since only IEEE double operations and integer bit manipulation occur, the
+ *   same source gives the same bits on the host and on the device, and
+ *   tests/powf_exhaustive.c shows it equals this image's libm powf for EVERY
+ *   float x at the two exponents the kernel uses.
  *
- * with log2_d / exp2_d built from IEEE double + - * / and fma only, in a fixed
- * order (no libm, no hardware transcendental, no tables).  Their error is
- * ~1e-15, so the float result is the correctly rounded power except with
- * probability ~1e-7 per call: at least as accurate as the libm it stands in for.
+ * The tables live in caller-provided memory so the device can keep them in LDS
+ * (64 doubles = 512 B): layout  tab[0..31]  = {invc_i, logc_i} i = 0..15
+ *                               tab[32..63] = bits of exp2 table as doubles' storage
  *
- * The same source is compiled for the device (HIP) and, by the TEST oracle
- * (oracle/mc_oracle.c, "det" instantiation), for the host, which is what makes
- * GPU-vs-oracle comparisons bit-exact.  Requires -ffp-contract=off (all fused
- * operations are written explicitly) and round-to-nearest.
- *
- * Plain C99 / C++ / HIP.
+ * Requires -ffp-contract=off (every fused operation is explicit) and
+ * round-to-nearest.  Plain C99 / C++ / HIP.
  */
 #ifndef TRMC_DET_POW_H
 #define TRMC_DET_POW_H
@@ -38,6 +49,29 @@
 #define TRMC_DP_FN static inline
 #endif
 
+#define TRMC_POW_TAB_WORDS 64 /* 64-bit words */
+
+/* glibc 2.35 __powf_log2_data.tab ({invc, logc}) followed by __exp2f_data.tab */
+#define TRMC_POW_TAB_VALUES {\
+    0x3ff661ec79f8f3beull, 0xbfdefec65b963019ull, 0x3ff571ed4aaf883dull, 0xbfdb0b6832d4fca4ull,\
+    0x3ff49539f0f010b0ull, 0xbfd7418b0a1fb77bull, 0x3ff3c995b0b80385ull, 0xbfd39de91a6dcf7bull,\
+    0x3ff30d190c8864a5ull, 0xbfd01d9bf3f2b631ull, 0x3ff25e227b0b8ea0ull, 0xbfc97c1d1b3b7af0ull,\
+    0x3ff1bb4a4a1a343full, 0xbfc2f9e393af3c9full, 0x3ff12358f08ae5baull, 0xbfb960cbbf788d5cull,\
+    0x3ff0953f419900a7ull, 0xbfaa6f9db6475fceull, 0x3ff0000000000000ull, 0x0000000000000000ull,\
+    0x3fee608cfd9a47acull, 0x3fb338ca9f24f53dull, 0x3feca4b31f026aa0ull, 0x3fc476a9543891baull,\
+    0x3feb2036576afce6ull, 0x3fce840b4ac4e4d2ull, 0x3fe9c2d163a1aa2dull, 0x3fd40645f0c6651cull,\
+    0x3fe886e6037841edull, 0x3fd88e9c2c1b9ff8ull, 0x3fe767dcf5534862ull, 0x3fdce0a44eb17bccull,\
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,\
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,\
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,\
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,\
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,\
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,\
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,\
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,\
+}
+static const uint64_t trmc_pow_tab_init[TRMC_POW_TAB_WORDS] = TRMC_POW_TAB_VALUES;
+
 TRMC_DP_FN uint64_t trmc_dp_bits(double x)
 {
     uint64_t u;
@@ -50,81 +84,77 @@ TRMC_DP_FN double trmc_dp_from_bits(uint64_t u)
     memcpy(&x, &u, sizeof x);
     return x;
 }
-
-/* log2(x) for a double that was converted from a float (so: never a double
- * subnormal).  x < 0 or NaN -> NaN ; 0 -> -inf ; +inf -> +inf. */
-TRMC_DP_FN double trmc_det_log2(double x)
+TRMC_DP_FN uint32_t trmc_sp_bits(float x)
 {
-    const uint64_t b = trmc_dp_bits(x);
-    if (x != x || (b >> 63)) {               /* NaN or negative (incl. -0: pow(-0,y>0)=0 handled below) */
-        if (x == 0.0) return trmc_dp_from_bits(0xfff0000000000000ull); /* -0 -> -inf */
-        return trmc_dp_from_bits(0x7ff8000000000000ull);
+    uint32_t u;
+    memcpy(&u, &x, sizeof u);
+    return u;
+}
+TRMC_DP_FN float trmc_sp_from_bits(uint32_t u)
+{
+    float x;
+    memcpy(&x, &u, sizeof x);
+    return x;
+}
+
+/* log2(x) as glibc's powf forms it, plus the special values its callers rely on:
+ * NaN or finite x < 0 -> NaN ; +-0 -> -inf ; +-inf -> +inf (y is a positive non-integer). */
+TRMC_DP_FN double trmc_det_log2(float x, const uint64_t *tab)
+{
+    uint32_t ix = trmc_sp_bits(x);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) { /* x < 0x1p-126, inf or nan */
+        if ((ix << 1) == 0) return trmc_dp_from_bits(0xfff0000000000000ull);          /* +-0 */
+        if ((ix << 1) == 0xff000000u) return trmc_dp_from_bits(0x7ff0000000000000ull); /* +-inf */
+        if ((ix << 1) > 0xff000000u || (ix >> 31)) return trmc_dp_from_bits(0x7ff8000000000000ull);
+        ix = trmc_sp_bits(x * 8388608.0f /* 0x1p23f */); /* subnormal: normalise */
+        ix &= 0x7fffffffu;
+        ix -= 23u << 23;
     }
-    if (x == 0.0) return trmc_dp_from_bits(0xfff0000000000000ull);
-    if (b == 0x7ff0000000000000ull) return x;
-
-    int64_t e = (int64_t)((b >> 52) & 0x7ff) - 1023;
-    uint64_t mant = b & 0x000fffffffffffffull;
-    uint64_t mb = mant | 0x3ff0000000000000ull;             /* m in [1,2) */
-    if (mant > 0x6a09e667f3bcdull) {                        /* m > sqrt(2): halve */
-        mb = mant | 0x3fe0000000000000ull;
-        e += 1;
-    }
-    const double m = trmc_dp_from_bits(mb);                 /* [sqrt(2)/2, sqrt(2)] */
-    const double f = m - 1.0;                               /* exact */
-    const double s = f / (2.0 + f);                         /* |s| <= 0.1716 */
-    const double z = s * s;
-    /* atanh series: log(1+f) = 2s (1 + z/3 + z^2/5 + ... + z^8/17), remainder < 1e-15 rel */
-    double q = 1.0 / 17.0;
-    q = __builtin_fma(z, q, 1.0 / 15.0);
-    q = __builtin_fma(z, q, 1.0 / 13.0);
-    q = __builtin_fma(z, q, 1.0 / 11.0);
-    q = __builtin_fma(z, q, 1.0 / 9.0);
-    q = __builtin_fma(z, q, 1.0 / 7.0);
-    q = __builtin_fma(z, q, 1.0 / 5.0);
-    q = __builtin_fma(z, q, 1.0 / 3.0);
-    const double p = __builtin_fma(z, q, 1.0);
-    const double lg = (s + s) * p;                          /* ln(m) */
-    return __builtin_fma(lg, 1.4426950408889634 /* log2(e) */, (double)e);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int32_t k = (int32_t)top >> 23;
+    const double invc = trmc_dp_from_bits(tab[2 * i]);
+    const double logc = trmc_dp_from_bits(tab[2 * i + 1]);
+    const double z = (double)trmc_sp_from_bits(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double y = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(0x1.71547652ab82bp0, r, y0);
+    q = __builtin_fma(p, r2, q);
+    y = __builtin_fma(y, r4, q);
+    return y;
 }
 
-/* 2**p as a double, for |p| small enough that the result is a normal double
- * (callers clamp).  NaN -> NaN. */
-TRMC_DP_FN double trmc_det_exp2(double p)
+/* x**y (y > 0, not an integer) from L = trmc_det_log2(x). */
+TRMC_DP_FN float trmc_det_powf_from_log(double L, float y, const uint64_t *tab)
 {
-    if (p != p) return p;
-    if (p > 1000.0) return trmc_dp_from_bits(0x7ff0000000000000ull);
-    if (p < -1000.0) return 0.0;
-    const int64_t n = (int64_t)(p + (p >= 0.0 ? 0.5 : -0.5)); /* round half away, exact */
-    const double r = p - (double)n;                           /* exact, |r| <= 0.5 */
-    const double u = r * 0.6931471805599453;                  /* ln 2 */
-    /* e**u, |u| <= 0.3466, Taylor to u^13/13! (remainder < 2e-17) */
-    double t = 1.0 / 6227020800.0;
-    t = __builtin_fma(u, t, 1.0 / 479001600.0);
-    t = __builtin_fma(u, t, 1.0 / 39916800.0);
-    t = __builtin_fma(u, t, 1.0 / 3628800.0);
-    t = __builtin_fma(u, t, 1.0 / 362880.0);
-    t = __builtin_fma(u, t, 1.0 / 40320.0);
-    t = __builtin_fma(u, t, 1.0 / 5040.0);
-    t = __builtin_fma(u, t, 1.0 / 720.0);
-    t = __builtin_fma(u, t, 1.0 / 120.0);
-    t = __builtin_fma(u, t, 1.0 / 24.0);
-    t = __builtin_fma(u, t, 1.0 / 6.0);
-    t = __builtin_fma(u, t, 0.5);
-    t = __builtin_fma(u, t, 1.0);
-    t = __builtin_fma(u, t, 1.0);                             /* in (0.70, 1.42) */
-    return trmc_dp_from_bits(trmc_dp_bits(t) + ((uint64_t)n << 52)); /* * 2**n, exact */
+    const double ylogx = (double)y * L;
+    if (ylogx != ylogx) return trmc_sp_from_bits(0x7fc00000u);
+    if (ylogx > 0x1.fffffffd1d571p+6) return trmc_sp_from_bits(0x7f800000u); /* overflow */
+    if (ylogx <= -150.0) return 0.0f;                                        /* underflow */
+    double kd = ylogx + 0x1.8p+47;            /* round to a multiple of 1/32 */
+    const uint64_t ki = trmc_dp_bits(kd);
+    kd -= 0x1.8p+47;
+    const double r = ylogx - kd;
+    uint64_t t = tab[32 + (ki & 31u)];
+    t += ki << 47;
+    const double s = trmc_dp_from_bits(t);
+    const double z = __builtin_fma(0x1.c6af84b912394p-5, r, 0x1.ebfce50fac4f3p-3);
+    const double r2 = r * r;
+    double w = __builtin_fma(0x1.62e42ff0c52d6p-1, r, 1.0);
+    w = __builtin_fma(z, r2, w);
+    w = w * s;
+    return (float)w;
 }
 
-/* x**y for y > 0 from the precomputed L = trmc_det_log2((double)x). */
-TRMC_DP_FN float trmc_det_powf_from_log(double L, float y)
+TRMC_DP_FN float trmc_det_powf(float x, float y, const uint64_t *tab)
 {
-    return (float)trmc_det_exp2((double)y * L);
-}
-
-TRMC_DP_FN float trmc_det_powf(float x, float y)
-{
-    return trmc_det_powf_from_log(trmc_det_log2((double)x), y);
+    return trmc_det_powf_from_log(trmc_det_log2(x, tab), y, tab);
 }
 
 #endif /* TRMC_DET_POW_H */

@@ -20,8 +20,8 @@
 // fp32 instantiation is bit-comparable with the fp32 Fortran wherever pow()
 // agrees; compile with -ffp-contract=off.
 //
-// Math policy M:  M::sqrt(x); M::pow(x, y); and, so that x**a and x**b can share
-// one logarithm, M::Log, M::log_of(x), M::pow_l(log_of(x), x, y) == M::pow(x, y).
+// Math policy M:  m.sqrt(x); m.pow(x, y); and, so that x**a and x**b can share
+// one logarithm, M::Log, m.log_of(x), m.pow_l(log_of(x), x, y) == m.pow(x, y).
 //
 // The header is host/device neutral on purpose: tests/host_harness.cpp
 // instantiates it with libm on the CPU to check the logic against the oracle
@@ -59,7 +59,7 @@ template <class T> struct ChannelConst {
 };
 
 template <class T, class M>
-MC_HD ChannelConst<T> make_const(const ChannelParams<T> &p)
+MC_HD ChannelConst<T> make_const(const ChannelParams<T> &p, const M &m)
 {
     ChannelConst<T> c;
     c.z = (p.cs == T(0)) ? T(1) : T(1) / p.cs;
@@ -69,8 +69,8 @@ MC_HD ChannelConst<T> make_const(const ChannelParams<T> &p)
         c.bfd = p.bw / (T(2) * c.z);
     else
         c.bfd = (p.tw - p.bw) / (T(2) * c.z);
-    c.sqrt_s0 = M::sqrt(p.s0);
-    c.sq1pz2 = M::sqrt(T(1) + c.z * c.z);
+    c.sqrt_s0 = m.sqrt(p.s0);
+    c.sq1pz2 = m.sqrt(T(1) + c.z * c.z);
     c.s0_n = c.sqrt_s0 / p.n;
     c.s0_ncc = c.sqrt_s0 / p.ncc;
     c.two_sq = T(2) * c.sq1pz2;
@@ -85,7 +85,7 @@ template <class T> struct Section {
 };
 
 template <class T, class M>
-MC_HD Section<T> section_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c)
+MC_HD Section<T> section_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
 {
     Section<T> s;
     s.twl = p.bw + T(2) * c.z * h;
@@ -119,24 +119,24 @@ template <class T> struct Inflow {
 //   LOWER=true : "interval 2": X from the coefficients just left in `k`, clamp [0.25,0.5]
 template <class T, class M, bool LOWER>
 MC_HD T secant_residual(T h, T qj_prev, const ChannelParams<T> &p, const ChannelConst<T> &c,
-                        const Inflow<T> &f, MuskCoef<T> &k)
+                        const Inflow<T> &f, MuskCoef<T> &k, const M &m)
 {
     const T c23 = T(2) / T(3), c53 = T(5) / T(3);
-    const Section<T> s = section_at<T, M>(h, p, c);
+    const Section<T> s = section_at<T, M>(h, p, c, m);
     const bool over = (h > c.bfd) && c.fp_ok;
 
     // R**(2/3) and R**(5/3) share one logarithm (M::Log), see det_pow.h
-    const typename M::Log lr = M::log_of(s.R);
-    const T r23 = M::pow_l(lr, s.R, c23);
+    const typename M::Log lr = m.log_of(s.R);
+    const T r23 = m.pow_l(lr, s.R, c23);
     T ck;
     if (over) {
-        ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * M::pow_l(lr, s.R, c53)
+        ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
                                                   * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
                                * s.area
-                           + (c.s0_ncc * c53 * M::pow(h - c.bfd, c23)) * s.areac)
+                           + (c.s0_ncc * c53 * m.pow(h - c.bfd, c23)) * s.areac)
                               / (s.area + s.areac));
     } else if (h > T(0)) {
-        ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * M::pow_l(lr, s.R, c53)
+        ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
                                                  * (c.two_sq / (p.bw + T(2) * h * c.z)))));
     } else {
         ck = T(0);
@@ -179,15 +179,15 @@ MC_HD T secant_residual(T h, T qj_prev, const ChannelParams<T> &p, const Channel
 
 // Kinematic celerity and Courant number at depth h (f90:342-367; unguarded).
 template <class T, class M>
-MC_HD void courant_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, T &ck, T &cn)
+MC_HD void courant_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, T &ck, T &cn, const M &m)
 {
     const T c23 = T(2) / T(3), c53 = T(5) / T(3);
-    const Section<T> s = section_at<T, M>(h, p, c);
-    const typename M::Log lr = M::log_of(s.R);
-    ck = mc_max(T(0), (c.s0_n * (c53 * M::pow_l(lr, s.R, c23)
-                                  - (c23 * M::pow_l(lr, s.R, c53) * (c.two_sq / (p.bw + T(2) * s.h_in * c.z))))
+    const Section<T> s = section_at<T, M>(h, p, c, m);
+    const typename M::Log lr = m.log_of(s.R);
+    ck = mc_max(T(0), (c.s0_n * (c53 * m.pow_l(lr, s.R, c23)
+                                  - (c23 * m.pow_l(lr, s.R, c53) * (c.two_sq / (p.bw + T(2) * s.h_in * c.z))))
                            * s.area
-                       + (c.s0_ncc * c53 * M::pow(s.h_over, c23)) * s.areac)
+                       + (c.s0_ncc * c53 * m.pow(s.h_over, c23)) * s.areac)
                           / (s.area + s.areac));
     cn = ck * (p.dt / p.dx);
 }
@@ -200,9 +200,9 @@ template <class T> struct StepResult {
 
 // One segment, one timestep (f90:8-186).
 template <class T, class M>
-MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &f, T depthp)
+MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &f, T depthp, const M &m)
 {
-    const ChannelConst<T> c = make_const<T, M>(p);
+    const ChannelConst<T> c = make_const<T, M>(p, m);
     const T mindepth = T(0.01);
     StepResult<T> out;
 
@@ -222,8 +222,8 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &
         T qj_0 = T(0);
         int iter = 0;
         while (rerror > T(0.01) && aerror >= mindepth && iter <= maxiter) {
-            qj_0 = secant_residual<T, M, false>(h_0, qj_0, p, c, f, k);
-            const T qj = secant_residual<T, M, true>(h, T(0), p, c, f, k);
+            qj_0 = secant_residual<T, M, false>(h_0, qj_0, p, c, f, k, m);
+            const T qj = secant_residual<T, M, true>(h, T(0), p, c, f, k, m);
             T h_1;
             if (qj_0 - qj != T(0)) {
                 h_1 = h - ((qj * (h_0 - h)) / (qj_0 - qj));
@@ -264,8 +264,8 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &
 
     const T twl = p.bw + T(2) * c.z * h;
     const T a = (twl - p.bw) / T(2);
-    const T R = (h * (p.bw + twl) / T(2)) / (p.bw + T(2) * M::sqrt(a * a + h * h));
-    out.velc = (T(1) / p.n) * M::pow(R, T(2) / T(3)) * c.sqrt_s0;
+    const T R = (h * (p.bw + twl) / T(2)) / (p.bw + T(2) * m.sqrt(a * a + h * h));
+    out.velc = (T(1) / p.n) * m.pow(R, T(2) / T(3)) * c.sqrt_s0;
     out.depthc = h;
     out.h = h;
     out.X = k.X;

@@ -62,21 +62,50 @@ int fail(int code, const std::string &msg)
 // fp32: the bit-reproducible power of det_pow.h (IEEE double + - * / fma only), so the
 // whole fp32 path is bit-comparable with the host oracle; sqrtf and / are the
 // correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+#ifndef TRMC_EXPERIMENT_POW   // 0: det_pow.h (product).  1: ocml powf, 2: hardware log/exp -- timing experiments only
+#define TRMC_EXPERIMENT_POW 0
+#endif
+__device__ const uint64_t d_pow_tab[TRMC_POW_TAB_WORDS] = TRMC_POW_TAB_VALUES;
+
+// fp32: the bit-reproducible powf of det_pow.h (tables staged in LDS by the kernel), so the whole
+// fp32 path is bit-comparable with the host; sqrtf and / are the correctly rounded forms (hipcc
+// default -fhip-fp32-correctly-rounded-divide-sqrt).
 struct DevMathF {
+    const uint64_t *tab; // LDS copy of d_pow_tab
+#if TRMC_EXPERIMENT_POW == 0
     using Log = double;
-    static __device__ __forceinline__ Log log_of(float x) { return trmc_det_log2((double)x); }
-    static __device__ __forceinline__ float pow_l(Log l, float, float y) { return trmc_det_powf_from_log(l, y); }
-    static __device__ __forceinline__ float pow(float x, float y) { return trmc_det_powf(x, y); }
-    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    __device__ __forceinline__ Log log_of(float x) const { return trmc_det_log2(x, tab); }
+    __device__ __forceinline__ float pow_l(Log l, float, float y) const { return trmc_det_powf_from_log(l, y, tab); }
+    __device__ __forceinline__ float pow(float x, float y) const { return trmc_det_powf(x, y, tab); }
+#elif TRMC_EXPERIMENT_POW == 1
+    using Log = float;
+    __device__ __forceinline__ Log log_of(float x) const { return x; }
+    __device__ __forceinline__ float pow_l(Log, float x, float y) const { return ::powf(x, y); }
+    __device__ __forceinline__ float pow(float x, float y) const { return ::powf(x, y); }
+#else
+    using Log = float;
+    __device__ __forceinline__ Log log_of(float x) const { return __builtin_amdgcn_logf(x); }
+    __device__ __forceinline__ float pow_l(Log l, float, float y) const { return __builtin_amdgcn_exp2f(y * l); }
+    __device__ __forceinline__ float pow(float x, float y) const { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#endif
+    __device__ __forceinline__ float sqrt(float x) const { return ::sqrtf(x); }
 };
 // fp64: device libm pow (about 1 ulp; not bit-reproducible against glibc)
 struct DevMathD {
+    const uint64_t *tab; // unused
     using Log = double;
-    static __device__ __forceinline__ Log log_of(double x) { return x; }
-    static __device__ __forceinline__ double pow_l(Log, double x, double y) { return ::pow(x, y); }
-    static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
-    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    __device__ __forceinline__ Log log_of(double x) const { return x; }
+    __device__ __forceinline__ double pow_l(Log, double x, double y) const { return ::pow(x, y); }
+    __device__ __forceinline__ double pow(double x, double y) const { return ::pow(x, y); }
+    __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
 };
+// every kernel that evaluates segment steps stages the 512-byte power tables into LDS first
+__device__ __forceinline__ const uint64_t *stage_pow_tables(uint64_t *s_tab)
+{
+    if (threadIdx.x < TRMC_POW_TAB_WORDS) s_tab[threadIdx.x] = d_pow_tab[threadIdx.x];
+    __syncthreads();
+    return s_tab;
+}
 template <class T> struct DevMath;
 template <> struct DevMath<float> { using type = DevMathF; };
 template <> struct DevMath<double> { using type = DevMathD; };
@@ -102,6 +131,8 @@ __global__ void __launch_bounds__(kBlock)
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag)
 {
     using M = typename DevMath<T>::type;
+    __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    const M m{stage_pow_tables(s_tab)};
     const int32_t s = s_begin + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (s >= s_end) return;
     const int32_t t = SHORT ? diag : diag - a.level[s];
@@ -137,7 +168,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     f.qup = qup;
     f.quc = SHORT ? qup : quc;
 
-    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp);
+    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp, m);
     a.q_tm[row_c + s] = r.qdc;
     a.v_tm[row_c + s] = r.velc;
     a.d_tm[row_c + s] = r.depthc;
@@ -260,6 +291,8 @@ __global__ void __launch_bounds__(kBlock)
 k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
 {
     using M = typename DevMath<T>::type;
+    __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    const M m{stage_pow_tables(s_tab)};
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const T *x = in + i * 15;
@@ -269,10 +302,10 @@ k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
     p.dx = x[5]; p.bw = x[6]; p.tw = x[7]; p.twcc = x[8]; p.n = x[9]; p.ncc = x[10];
     p.cs = x[11]; p.s0 = x[12];
     const T depthp = x[14];
-    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp);
+    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp, m);
     T ck, cn;
-    const trmc::ChannelConst<T> c = trmc::make_const<T, M>(p);
-    trmc::courant_at<T, M>(r.h, p, c, ck, cn);
+    const trmc::ChannelConst<T> c = trmc::make_const<T, M>(p, m);
+    trmc::courant_at<T, M>(r.h, p, c, ck, cn, m);
     T *o = out + i * 6;
     o[0] = r.qdc; o[1] = r.velc; o[2] = r.depthc; o[3] = ck; o[4] = cn; o[5] = r.X;
 }
