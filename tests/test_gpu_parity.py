@@ -318,3 +318,74 @@ def test_errors_match_reference(lc):
     a[3] = [(lc.reaches[0], 1)] + a[3][1:]
     with pytest.raises(NotImplementedError):
         compute_network_structured(*a)
+
+
+# ---- BASELINE's full size: synthetic CONUS, 2 729 077 segments x 288 steps ------------------------------
+@pytest.fixture(scope="module")
+def conus():
+    from troute_amd import synthetic
+    net = synthetic.generate(cache_dir="/tmp/trmc_cache")
+    up_ptr, up_idx = synthetic.upstream_csr(net["to"])
+    return net, up_ptr, up_idx
+
+
+@pytest.mark.parametrize("short", [True, False])
+def test_conus_full_size_samples_bit_identical_to_oracle(conus, short):
+    """Size-independent property at full size: independent networks do not interact, so any
+    sub-collection of them routed ALONE by the oracle must equal -- bit for bit -- what the GPU
+    produced for them inside the 2.7 M-segment run (outlet and interior hydrographs, final state)."""
+    from troute_amd import sharding
+    from troute_amd.distributed import restrict_csr
+    net, up_ptr, up_idx = conus
+    to = net["to"]
+    nseg = to.shape[0]
+    nsteps, qts = 288, 12
+    q0 = np.zeros((nseg, 3), np.float32)
+    rng = np.random.default_rng(77)
+    outlet = sharding.outlet_of(to)
+    uniq, lab = np.unique(outlet, return_inverse=True)
+    sizes = np.bincount(lab)
+    cand = np.flatnonzero((sizes >= 50) & (sizes <= 20000))
+    pick = np.concatenate([rng.choice(cand, 80, replace=False), rng.choice(np.flatnonzero(sizes < 50), 200, replace=False)])
+    rows = np.flatnonzero(np.isin(lab, pick))
+    assert 10000 < rows.size < 400000
+    with RoutingPlan(up_ptr, up_idx, net["params"]) as plan:
+        plan.upload_forcing(nsteps, net["qlat"], q0)
+        st = plan.route_device(nsteps, qts, short)
+        hyd = plan.gather_flow_rows(rows)
+        final = plan.download_final_state()
+    assert st["segment_steps"] == nseg * nsteps
+    g2l = np.full(nseg, -1, np.int64)
+    g2l[rows] = np.arange(rows.size)
+    lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)
+    lvl, _, _ = topology_levels(lp, li)
+    want = O.network_by_segment(nsteps, qts, lp, li, lvl, net["params"][rows], q0[rows], net["qlat"][rows], short,
+                                det=True)
+    assert_bit_identical(hyd, want[:, 1:, 0], f"CONUS sample hydrographs short={short}")
+    assert_bit_identical(final[rows], want[:, -1, :][:, [0, 0, 2]], "CONUS sample final state")
+    assert np.isfinite(final).all() and (final[:, 0] >= 0).all()
+
+
+def test_conus_row_relabelling_invariance(conus):
+    """Permuting the caller's row labels must permute the result and change nothing else (bitwise):
+    exercises the level flattening, the gather maps and the result transpose at full width."""
+    net, up_ptr, up_idx = conus
+    to = net["to"]
+    nseg = to.shape[0]
+    nsteps, qts = 24, 12
+    q0 = np.zeros((nseg, 3), np.float32)
+    with RoutingPlan(up_ptr, up_idx, net["params"]) as plan:
+        plan.upload_forcing(nsteps, net["qlat"], q0)
+        plan.route_device(nsteps, qts, False)
+        a = plan.download_final_state()
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(nseg)                     # new row of old row r = perm[r]
+    inv = np.empty(nseg, np.int64)
+    inv[perm] = np.arange(nseg)
+    from troute_amd.distributed import restrict_csr
+    p2, i2 = restrict_csr(up_ptr, up_idx, inv, perm)  # same upstream lists (same summation order), new labels
+    with RoutingPlan(p2, i2, net["params"][inv]) as plan:
+        plan.upload_forcing(nsteps, net["qlat"][inv], q0)
+        plan.route_device(nsteps, qts, False)
+        b = plan.download_final_state()
+    assert_bit_identical(a, b[perm], "relabelled CONUS")
