@@ -6,6 +6,13 @@
  */
 #include <math.h>
 
+/* analysis aid (not thread-safe): when set, the network loops count secant iterations per
+ * segment-step into hist[0..1000] */
+static long *mc_oracle_iter_hist = 0;
+void mc_oracle_set_iter_hist(long *hist) { mc_oracle_iter_hist = hist; }
+static unsigned char *mc_oracle_iter_map = 0; /* [nseg][nsteps] iterations per segment-step */
+void mc_oracle_set_iter_map(unsigned char *m) { mc_oracle_iter_map = m; }
+
 #define REAL float
 #define SFX(x) x##_f32
 #define POW powf

@@ -114,40 +114,60 @@ template <class T> struct Inflow {
     T qup, quc, qdp, ql;
 };
 
-// Residual Q_mc(h) - Q_manning(h) at depth h (f90:198-334).
-//   LOWER=false: "interval 1": X from the previous residual `qj_prev`, clamp [0,0.5]
-//   LOWER=true : "interval 2": X from the coefficients just left in `k`, clamp [0.25,0.5]
-template <class T, class M, bool LOWER>
-MC_HD T secant_residual(T h, T qj_prev, const ChannelParams<T> &p, const ChannelConst<T> &c,
-                        const Inflow<T> &f, MuskCoef<T> &k, const M &m)
+// Everything the residual needs that depends on the depth alone (f90:244-275): wetted geometry,
+// R**(2/3), kinematic celerity Ck and the Muskingum K.  The secant loop evaluates the residual at
+// (h_0, h) and then moves h_0 <- h, so the point computed for h in one iteration IS the point for
+// h_0 in the next: it is kept instead of being recomputed (same operations on the same inputs, hence
+// the same bits -- only work is saved).
+template <class T> struct HydraulicPoint {
+    T twl, area_sum, wp_sum, wn_sum; // top width; AREA+AREAC; WP+WPC; WP*n + WPC*ncc
+    T r23, ck, km;
+    bool over;
+};
+
+template <class T, class M>
+MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
 {
     const T c23 = T(2) / T(3), c53 = T(5) / T(3);
     const Section<T> s = section_at<T, M>(h, p, c, m);
-    const bool over = (h > c.bfd) && c.fp_ok;
+    HydraulicPoint<T> hp;
+    hp.over = (h > c.bfd) && c.fp_ok;
+    hp.twl = s.twl;
+    hp.area_sum = s.area + s.areac;
+    hp.wp_sum = s.wp + s.wpc;
+    hp.wn_sum = (s.wp * p.n) + (s.wpc * p.ncc);
 
     // R**(2/3) and R**(5/3) share one logarithm (M::Log), see det_pow.h
     const typename M::Log lr = m.log_of(s.R);
-    const T r23 = m.pow_l(lr, s.R, c23);
-    T ck;
-    if (over) {
-        ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
-                                                  * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
-                               * s.area
-                           + (c.s0_ncc * c53 * m.pow(h - c.bfd, c23)) * s.areac)
-                              / (s.area + s.areac));
+    hp.r23 = m.pow_l(lr, s.R, c23);
+    if (hp.over) {
+        hp.ck = mc_max(T(0), (c.s0_n * (c53 * hp.r23 - (c23 * m.pow_l(lr, s.R, c53)
+                                                        * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
+                                  * s.area
+                              + (c.s0_ncc * c53 * m.pow(h - c.bfd, c23)) * s.areac)
+                                 / (s.area + s.areac));
     } else if (h > T(0)) {
-        ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
-                                                 * (c.two_sq / (p.bw + T(2) * h * c.z)))));
+        hp.ck = mc_max(T(0), c.s0_n * (c53 * hp.r23 - (c23 * m.pow_l(lr, s.R, c53)
+                                                       * (c.two_sq / (p.bw + T(2) * h * c.z)))));
     } else {
-        ck = T(0);
+        hp.ck = T(0);
     }
+    hp.km = (hp.ck > T(0)) ? mc_max(p.dt, p.dx / hp.ck) : p.dt;
+    return hp;
+}
 
-    const T km = (ck > T(0)) ? mc_max(p.dt, p.dx / ck) : p.dt;
-
+// Residual Q_mc(h) - Q_manning(h) at the hydraulic point of depth h (f90:277-332).
+//   LOWER=false: "interval 1": X from the previous residual `qj_prev`, clamp [0,0.5]
+//   LOWER=true : "interval 2": X from the coefficients just left in `k`, clamp [0.25,0.5]
+template <class T, class M, bool LOWER>
+MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelParams<T> &p,
+                        const ChannelConst<T> &c, const Inflow<T> &f, MuskCoef<T> &k)
+{
+    const T km = hp.km;
     T x;
-    if (ck > T(0)) {
-        const T width = over ? p.twcc : s.twl;
-        const T denom = T(2) * width * p.s0 * ck * p.dx;
+    if (hp.ck > T(0)) {
+        const T width = hp.over ? p.twcc : hp.twl;
+        const T denom = T(2) * width * p.s0 * hp.ck * p.dx;
         if (!LOWER)
             x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - (qj_prev / denom))));
         else
@@ -170,10 +190,9 @@ MC_HD T secant_residual(T h, T qj_prev, const ChannelParams<T> &p, const Channel
         if ((k.C4 < T(0)) && (mc_abs(k.C4) > w)) k.C4 = -w;
     }
 
-    if ((s.wp + s.wpc) > T(0))
+    if (hp.wp_sum > T(0))
         return ((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4)
-               - ((T(1) / (((s.wp * p.n) + (s.wpc * p.ncc)) / (s.wp + s.wpc))) * (s.area + s.areac) * r23
-                  * c.sqrt_s0);
+               - ((T(1) / (hp.wn_sum / hp.wp_sum)) * hp.area_sum * hp.r23 * c.sqrt_s0);
     return T(0);
 }
 
@@ -196,13 +215,14 @@ template <class T> struct StepResult {
     T qdc, velc, depthc; // outflow, velocity, depth at the new time level
     T h;                 // depth the iteration ended on (courant uses it even with no flow)
     T X;                 // last weighting factor (0 when nothing was routed)
+    int iters;           // secant iterations spent (all retries together)
 };
 
-// One segment, one timestep (f90:8-186).
+// One segment, one timestep (f90:8-186), with the segment-invariant constants supplied.
 template <class T, class M>
-MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &f, T depthp, const M &m)
+MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelConst<T> &c, const Inflow<T> &f,
+                                    T depthp, const M &m)
 {
-    const ChannelConst<T> c = make_const<T, M>(p, m);
     const T mindepth = T(0.01);
     StepResult<T> out;
 
@@ -211,19 +231,23 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &
     T h_0 = (depth0 * T(0.67));
 
     if (!(f.ql > T(0) || f.qup > T(0) || f.quc > T(0) || f.qdp > T(0))) {
-        out.qdc = T(0); out.velc = T(0); out.depthc = T(0); out.h = h; out.X = T(0);
+        out.qdc = T(0); out.velc = T(0); out.depthc = T(0); out.h = h; out.X = T(0); out.iters = 0;
         return out;
     }
 
     MuskCoef<T> k{T(0), T(0), T(0), T(0), T(0)};
     T aerror = T(0.01), rerror = T(1);
-    int maxiter = 100, tries = 0;
+    int maxiter = 100, tries = 0, total_iter = 0;
+    HydraulicPoint<T> at_h; // the point of the current h, carried into the next iteration as h_0's
+    bool carried = false;
     for (;;) {
         T qj_0 = T(0);
         int iter = 0;
         while (rerror > T(0.01) && aerror >= mindepth && iter <= maxiter) {
-            qj_0 = secant_residual<T, M, false>(h_0, qj_0, p, c, f, k, m);
-            const T qj = secant_residual<T, M, true>(h, T(0), p, c, f, k, m);
+            const HydraulicPoint<T> at_h0 = carried ? at_h : hydraulics_at<T, M>(h_0, p, c, m);
+            qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k);
+            at_h = hydraulics_at<T, M>(h, p, c, m);
+            const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k);
             T h_1;
             if (qj_0 - qj != T(0)) {
                 h_1 = h - ((qj * (h_0 - h)) / (qj_0 - qj));
@@ -238,15 +262,18 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &
                 rerror = T(0);
                 aerror = T(0.9);
             }
+            carried = (h >= T(0)); // then the next h_0 = max(0, h) is h itself (always, h is never negative)
             h_0 = mc_max(T(0), h);
             h = mc_max(T(0), h_1);
             ++iter;
+            ++total_iter;
             if (h < mindepth) break;
         }
         if (iter >= maxiter && ++tries <= 4) { // widen the bracket and retry
             h = h * T(1.33);
             h_0 = h_0 * T(0.67);
             maxiter += 25;
+            carried = false;
             continue;
         }
         break;
@@ -269,7 +296,15 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &
     out.depthc = h;
     out.h = h;
     out.X = k.X;
+    out.iters = total_iter;
     return out;
+}
+
+// One segment, one timestep, constants formed on the spot.
+template <class T, class M>
+MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const Inflow<T> &f, T depthp, const M &m)
+{
+    return mc_segment_step<T, M>(p, make_const<T, M>(p, m), f, depthp, m);
 }
 
 } // namespace trmc

@@ -114,64 +114,192 @@ constexpr int kBlock = 256;
 
 // ---------------------------------------------------------------- kernels
 template <class T> struct StepArgs {
-    const T *dx, *bw, *tw, *twcc, *n, *ncc, *cs, *s0;
+    const T *dx, *bw, *twcc, *n, *ncc, *s0;            // raw channel parameters the step still reads
+    const T *z, *bfd, *sqrt_s0, *sq1pz2, *s0_n, *s0_ncc; // segment-invariant constants formed at plan time (k_make_const)
     const T *dt_col; // nullptr -> uniform dt
     T dt;
     const int32_t *up_ptr, *up_idx, *level;
     const T *qlat_tm;
     T *q_tm, *v_tm, *d_tm;
+    uint8_t *it_prev; // secant iterations each position needed on its previous step
     int64_t nseg_pad;
     int32_t nsteps, qts;
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
 // positions [s_begin, s_end).
-template <class T, bool SHORT>
-__global__ void __launch_bounds__(kBlock)
+//
+// Divergence control.  The secant loop runs 0 (no flow), 1 (depth below the 1 cm floor: early
+// exit, f90:120-122), 2 (wet channel) or, rarely, 3+ iterations per segment-step, and a segment
+// repeats its count from one step to the next 99.3 % of the time.  In plan order a 64-lane wave
+// nearly always holds a 2-iteration lane (mean wave cost 2.5 iterations against a lane mean of
+// 1.44).  Each block therefore owns IPT*256 consecutive positions, reads the iteration count
+// every one of them needed on its previous step (one byte, `it_prev`), and stably partitions its
+// items by that class in LDS before touching anything else; wave-pass p then works on items
+// perm[p*256 + tid], which are of one class except at class boundaries.  Results do not depend on
+// the order items are visited in.
+#ifndef TRMC_EXPERIMENT_WAVES
+#define TRMC_EXPERIMENT_WAVES 1
+#endif
+template <class T, bool SHORT, int IPT>
+__global__ void __launch_bounds__(kBlock, TRMC_EXPERIMENT_WAVES)
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag)
 {
     using M = typename DevMath<T>::type;
+    constexpr int kChunk = IPT * kBlock;
+    constexpr int kWaves = kBlock / 64;
+    constexpr int kClasses = 5; // 0, 1, 2, 3+ iterations, and "nothing to do" (out of range)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    __shared__ uint16_t s_perm[kChunk];
+    __shared__ int32_t s_cnt[kClasses][IPT][kWaves];
     const M m{stage_pow_tables(s_tab)};
-    const int32_t s = s_begin + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
-    if (s >= s_end) return;
-    const int32_t t = SHORT ? diag : diag - a.level[s];
-    if (t < 1 || t > a.nsteps) return;
 
-    const size_t row_p = (size_t)(t - 1) * (size_t)a.nseg_pad; // previous time level
-    const size_t row_c = (size_t)t * (size_t)a.nseg_pad;       // current time level
+    const int32_t base = s_begin + (int32_t)blockIdx.x * kChunk;
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    trmc::ChannelParams<T> p;
-    p.dt = a.dt_col ? a.dt_col[s] : a.dt;
-    p.dx = a.dx[s];
-    p.bw = a.bw[s];
-    p.tw = a.tw[s];
-    p.twcc = a.twcc[s];
-    p.n = a.n[s];
-    p.ncc = a.ncc[s];
-    p.cs = a.cs[s];
-    p.s0 = a.s0[s];
-
-    trmc::Inflow<T> f;
-    f.qdp = a.q_tm[row_p + s];
-    const T depthp = a.d_tm[row_p + s];
-    f.ql = a.qlat_tm[(size_t)((t - 1) / a.qts) * (size_t)a.nseg_pad + s];
-
-    // junction sums in the reference's order (mc_reach.pyx:499-502)
-    T qup = T(0), quc = T(0);
-    const int32_t k0 = a.up_ptr[s], k1 = a.up_ptr[s + 1];
-    for (int32_t k = k0; k < k1; ++k) {
-        const int32_t u = a.up_idx[k];
-        qup += a.q_tm[row_p + u];
-        if (!SHORT) quc += a.q_tm[row_c + u];
+    // ---- class of my IPT items, per-wave counts -------------------------------------------------
+    int32_t cls[IPT], rank[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int32_t s = base + j * kBlock + (int32_t)threadIdx.x;
+        int32_t c = kClasses - 1;
+        if (s < s_end) {
+            const int32_t t = SHORT ? diag : diag - a.level[s];
+#ifdef TRMC_EXPERIMENT_NOSORT // timing experiment: keep plan order
+            if (t >= 1 && t <= a.nsteps) c = 0;
+#else
+            if (t >= 1 && t <= a.nsteps) c = min((int32_t)a.it_prev[s], 3);
+#endif
+        }
+        cls[j] = c;
+#pragma unroll
+        for (int b = 0; b < kClasses; ++b) {
+            const unsigned long long mask = __ballot(c == b);
+            if (c == b) rank[j] = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[b][j][wave] = __popcll(mask);
+        }
     }
-    f.qup = qup;
-    f.quc = SHORT ? qup : quc;
+    __syncthreads();
+    // exclusive scan of the IPT*kWaves*kClasses counts (class-major: stable by item index inside a
+    // class), done by wave 0 with lane shuffles: entry e = lane and e = lane + 64
+    if (wave == 0) {
+        constexpr int kEntries = kClasses * IPT * kWaves;
+        static_assert(kEntries <= 128, "scan handles two entries per lane");
+        int32_t *flat = &s_cnt[0][0][0];
+        const int32_t v0 = lane < kEntries ? flat[lane] : 0;
+        const int32_t v1 = lane + 64 < kEntries ? flat[lane + 64] : 0;
+        int32_t i0 = v0, i1 = v1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t t0 = __shfl_up(i0, d), t1 = __shfl_up(i1, d);
+            if (lane >= d) {
+                i0 += t0;
+                i1 += t1;
+            }
+        }
+        const int32_t total0 = __shfl(i0, 63);
+        if (lane < kEntries) flat[lane] = i0 - v0;
+        if (lane + 64 < kEntries) flat[lane + 64] = total0 + i1 - v1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+        s_perm[s_cnt[cls[j]][j][wave] + rank[j]] = (uint16_t)(j * kBlock + (int32_t)threadIdx.x);
+    __syncthreads();
+    const int32_t n_work = s_cnt[kClasses - 1][0][0]; // items of classes 0..3 come first
 
-    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp, m);
-    a.q_tm[row_c + s] = r.qdc;
-    a.v_tm[row_c + s] = r.velc;
-    a.d_tm[row_c + s] = r.depthc;
+    // ---- the segment steps, one class-sorted wave-pass at a time ---------------------------------
+    for (int pass = 0; pass < IPT; ++pass) {
+        const int32_t w = pass * kBlock + (int32_t)threadIdx.x;
+        if (w >= n_work) break;
+        const int32_t s = base + (int32_t)s_perm[w];
+        const int32_t t = SHORT ? diag : diag - a.level[s];
+
+        const size_t row_p = (size_t)(t - 1) * (size_t)a.nseg_pad; // previous time level
+        const size_t row_c = (size_t)t * (size_t)a.nseg_pad;       // current time level
+
+        trmc::ChannelParams<T> p;
+        p.dt = a.dt_col ? a.dt_col[s] : a.dt;
+        p.dx = a.dx[s];
+        p.bw = a.bw[s];
+        p.twcc = a.twcc[s];
+        p.n = a.n[s];
+        p.ncc = a.ncc[s];
+        p.s0 = a.s0[s];
+        p.tw = p.cs = T(0); // only enter the constants below
+        trmc::ChannelConst<T> c;
+        c.z = a.z[s];
+        c.bfd = a.bfd[s];
+        c.sqrt_s0 = a.sqrt_s0[s];
+        c.sq1pz2 = a.sq1pz2[s];
+        c.s0_n = a.s0_n[s];
+        c.s0_ncc = a.s0_ncc[s];
+        c.two_sq = T(2) * c.sq1pz2;
+        c.half_dt = p.dt / T(2);
+        c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
+
+        trmc::Inflow<T> f;
+        f.qdp = a.q_tm[row_p + s];
+        const T depthp = a.d_tm[row_p + s];
+        f.ql = a.qlat_tm[(size_t)((t - 1) / a.qts) * (size_t)a.nseg_pad + s];
+
+        // junction sums in the reference's order (mc_reach.pyx:499-502)
+        T qup = T(0), quc = T(0);
+        const int32_t k0 = a.up_ptr[s], k1 = a.up_ptr[s + 1];
+        for (int32_t k = k0; k < k1; ++k) {
+            const int32_t u = a.up_idx[k];
+            qup += a.q_tm[row_p + u];
+            if (!SHORT) quc += a.q_tm[row_c + u];
+        }
+        f.qup = qup;
+        f.quc = SHORT ? qup : quc;
+
+#ifdef TRMC_EXPERIMENT_MEMONLY // timing experiment: all loads and stores, no arithmetic to speak of
+        trmc::StepResult<T> r;
+        r.qdc = p.dt + p.dx + p.bw + c.z + c.bfd + f.qup + f.quc + f.qdp;
+        r.velc = p.twcc + p.n + p.ncc + f.ql + c.sqrt_s0 + c.sq1pz2;
+        r.depthc = c.s0_n + c.s0_ncc + p.s0 + depthp;
+        r.iters = 0;
+#else
+        const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, c, f, depthp, m);
+#endif
+        a.q_tm[row_c + s] = r.qdc;
+        a.v_tm[row_c + s] = r.velc;
+        a.d_tm[row_c + s] = r.depthc;
+        a.it_prev[s] = (uint8_t)min(r.iters, 255);
+    }
+}
+
+// plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
+// written as six more SoA columns behind the nine parameter columns (same device arithmetic the
+// step kernel would otherwise repeat every timestep: 4 divisions and 2 square roots per segment-step)
+constexpr int kConstCols = 6, kTotalCols = TRMC_NPARAM + kConstCols;
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_make_const(T *cols, int32_t nseg, int64_t nseg_pad)
+{
+    using M = typename DevMath<T>::type;
+    const int32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= nseg) return;
+    const M m{nullptr}; // make_const uses sqrt and divide only, never the power tables
+    trmc::ChannelParams<T> p;
+    p.dt = cols[(size_t)TRMC_P_DT * nseg_pad + s];
+    p.dx = cols[(size_t)TRMC_P_DX * nseg_pad + s];
+    p.bw = cols[(size_t)TRMC_P_BW * nseg_pad + s];
+    p.tw = cols[(size_t)TRMC_P_TW * nseg_pad + s];
+    p.twcc = cols[(size_t)TRMC_P_TWCC * nseg_pad + s];
+    p.n = cols[(size_t)TRMC_P_N * nseg_pad + s];
+    p.ncc = cols[(size_t)TRMC_P_NCC * nseg_pad + s];
+    p.cs = cols[(size_t)TRMC_P_CS * nseg_pad + s];
+    p.s0 = cols[(size_t)TRMC_P_S0 * nseg_pad + s];
+    const trmc::ChannelConst<T> c = trmc::make_const<T, M>(p, m);
+    T *o = cols + (size_t)TRMC_NPARAM * nseg_pad + s;
+    o[0 * nseg_pad] = c.z;
+    o[1 * nseg_pad] = c.bfd;
+    o[2 * nseg_pad] = c.sqrt_s0;
+    o[3 * nseg_pad] = c.sq1pz2;
+    o[4 * nseg_pad] = c.s0_n;
+    o[5 * nseg_pad] = c.s0_ncc;
 }
 
 // forcing: in[row][nq] (caller order) -> qlat_tm[j][pos]; LDS tile of 64 positions x 32 columns
@@ -347,7 +475,7 @@ struct trmc_plan {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // static, plan order
     DevBuf params; // 9 columns x nseg_pad
-    DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row;
+    DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev;
     // per window
     DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch;
     int64_t nq = 0;
@@ -364,13 +492,20 @@ template <class T> int upload_params(trmc_plan *pl, const float *params)
 {
     const int64_t n = pl->nseg, np = pl->nseg_pad;
     std::vector<T> host((size_t)TRMC_NPARAM * np, T(0));
+    const size_t all_cols = (size_t)kTotalCols * np;
     // a benign channel for the padding lanes (never routed, never read back)
     for (int64_t p = 0; p < n; ++p) {
         const float *src = params + (size_t)pl->topo.row_of_pos[p] * TRMC_NPARAM;
         for (int c = 0; c < TRMC_NPARAM; ++c) host[(size_t)c * np + p] = (T)src[c];
     }
-    if (int rc = pl->params.ensure(host.size() * sizeof(T))) return rc;
+    if (int rc = pl->params.ensure(all_cols * sizeof(T))) return rc;
     HIP_TRY(hipMemcpy(pl->params.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (n > 0) {
+        hipLaunchKernelGGL((k_make_const<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, pl->stream,
+                           (T *)pl->params.p, (int32_t)n, np);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(pl->stream));
+    }
     return 0;
 }
 
@@ -395,15 +530,20 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.dt = (T)pl->dt;
     a.dx = col<T>(pl, TRMC_P_DX);
     a.bw = col<T>(pl, TRMC_P_BW);
-    a.tw = col<T>(pl, TRMC_P_TW);
     a.twcc = col<T>(pl, TRMC_P_TWCC);
     a.n = col<T>(pl, TRMC_P_N);
     a.ncc = col<T>(pl, TRMC_P_NCC);
-    a.cs = col<T>(pl, TRMC_P_CS);
     a.s0 = col<T>(pl, TRMC_P_S0);
+    a.z = col<T>(pl, TRMC_NPARAM + 0);
+    a.bfd = col<T>(pl, TRMC_NPARAM + 1);
+    a.sqrt_s0 = col<T>(pl, TRMC_NPARAM + 2);
+    a.sq1pz2 = col<T>(pl, TRMC_NPARAM + 3);
+    a.s0_n = col<T>(pl, TRMC_NPARAM + 4);
+    a.s0_ncc = col<T>(pl, TRMC_NPARAM + 5);
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.level = (const int32_t *)pl->level.p;
+    a.it_prev = (uint8_t *)pl->it_prev.p;
     a.qlat_tm = (const T *)pl->qlat_tm.p;
     const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
     a.q_tm = (T *)pl->tm.p;
@@ -416,6 +556,25 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// wide slices: 4 items per thread (1024-position chunks sort better and still give > 8 blocks per CU);
+// narrow slices keep one item per thread so that every CU gets work
+template <class T, bool SHORT>
+inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d)
+{
+    const int64_t n = (int64_t)s1 - s0;
+    // measured on MI355X (CONUS, 2.73 M positions per launch): 1024-position chunks sort better (fewer
+    // VALU instructions) but run 14 % slower than 256-position chunks because four serial passes per
+    // block lengthen every block; kept selectable for experiments only
+#ifdef TRMC_EXPERIMENT_IPT4
+    if (n >= (int64_t)4 * kBlock * 256 * 4)
+#else
+    if (false)
+#endif
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 4>), dim3((unsigned)((n + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, st, a, s0, s1, d);
+    else
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), dim3(blocks_for(n)), dim3(kBlock), 0, st, a, s0, s1, d);
+}
 
 template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int short_ts)
 {
@@ -431,6 +590,7 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
 
     HIP_TRY(hipEventRecord(pl->ev[0], st));
+    HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st)); // no history at the start of a window
     // every element the result reads is written below: time row 0 by k_init_state, rows 1..nsteps
     // of routed positions by k_mc_step and of boundary positions by k_fill_boundary (the padding
     // lanes of each row are never read), so the reference's zero fill (mc_reach.pyx:253) is moot
@@ -451,7 +611,7 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
         if (short_ts) {
             const int32_t s0 = tp.lvl_ptr[0], s1 = tp.lvl_ptr[L];
             for (int32_t t = 1; t <= nsteps; ++t) {
-                hipLaunchKernelGGL((k_mc_step<T, true>), dim3(blocks_for(s1 - s0)), dim3(kBlock), 0, st, a, s0, s1, t);
+                launch_step<T, true>(st, a, s0, s1, t);
                 ++launches;
             }
         } else {
@@ -460,7 +620,7 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
                 const int32_t hi = d - 1 < L - 1 ? d - 1 : L - 1;
                 const int32_t s0 = tp.lvl_ptr[lo], s1 = tp.lvl_ptr[hi + 1];
                 if (s1 <= s0) continue;
-                hipLaunchKernelGGL((k_mc_step<T, false>), dim3(blocks_for(s1 - s0)), dim3(kBlock), 0, st, a, s0, s1, d);
+                launch_step<T, false>(st, a, s0, s1, d);
                 ++launches;
             }
         }
@@ -612,6 +772,7 @@ int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
     if ((rc = upload_i32(pl->up_idx, pl->topo.up_idx, 1))) return bail(rc);
     if ((rc = upload_i32(pl->row_of_pos, pl->topo.row_of_pos, 1))) return bail(rc);
     if ((rc = upload_i32(pl->pos_of_row, pl->topo.pos_of_row, 1))) return bail(rc);
+    if ((rc = pl->it_prev.ensure((size_t)pl->nseg_pad))) return bail(rc);
     *out = pl;
     return 0;
 }
@@ -620,7 +781,7 @@ void trmc_plan_destroy(trmc_plan *pl)
 {
     if (!pl) return;
     (void)hipSetDevice(pl->device);
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch})
         b->release();
     for (auto &e : pl->ev)
