@@ -120,9 +120,10 @@ template <class T> struct Inflow {
 // h_0 in the next: it is kept instead of being recomputed (same operations on the same inputs, hence
 // the same bits -- only work is saved).
 template <class T> struct HydraulicPoint {
-    T twl, area_sum, wp_sum, wn_sum; // top width; AREA+AREAC; WP+WPC; WP*n + WPC*ncc
-    T r23, ck, km;
-    bool over;
+    T ck, km;      // kinematic celerity, Muskingum K
+    T denom;       // 2 * width * s0 * Ck * dx, the divisor of the X formula (width = twcc over bank, else twl)
+    T q_manning;   // (1/n_composite) * (AREA+AREAC) * R**(2/3) * sqrt(s0); 0-flagged by has_wp
+    bool has_wp;   // WP + WPC > 0
 };
 
 template <class T, class M>
@@ -131,28 +132,28 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
     const T c23 = T(2) / T(3), c53 = T(5) / T(3);
     const Section<T> s = section_at<T, M>(h, p, c, m);
     HydraulicPoint<T> hp;
-    hp.over = (h > c.bfd) && c.fp_ok;
-    hp.twl = s.twl;
-    hp.area_sum = s.area + s.areac;
-    hp.wp_sum = s.wp + s.wpc;
-    hp.wn_sum = (s.wp * p.n) + (s.wpc * p.ncc);
+    const bool over = (h > c.bfd) && c.fp_ok;
 
     // R**(2/3) and R**(5/3) share one logarithm (M::Log), see det_pow.h
     const typename M::Log lr = m.log_of(s.R);
-    hp.r23 = m.pow_l(lr, s.R, c23);
-    if (hp.over) {
-        hp.ck = mc_max(T(0), (c.s0_n * (c53 * hp.r23 - (c23 * m.pow_l(lr, s.R, c53)
-                                                        * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
+    const T r23 = m.pow_l(lr, s.R, c23);
+    if (over) {
+        hp.ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
+                                                     * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
                                   * s.area
                               + (c.s0_ncc * c53 * m.pow(h - c.bfd, c23)) * s.areac)
                                  / (s.area + s.areac));
     } else if (h > T(0)) {
-        hp.ck = mc_max(T(0), c.s0_n * (c53 * hp.r23 - (c23 * m.pow_l(lr, s.R, c53)
-                                                       * (c.two_sq / (p.bw + T(2) * h * c.z)))));
+        hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
+                                                    * (c.two_sq / (p.bw + T(2) * h * c.z)))));
     } else {
         hp.ck = T(0);
     }
     hp.km = (hp.ck > T(0)) ? mc_max(p.dt, p.dx / hp.ck) : p.dt;
+    hp.denom = T(2) * (over ? p.twcc : s.twl) * p.s0 * hp.ck * p.dx;
+    hp.has_wp = (s.wp + s.wpc) > T(0);
+    hp.q_manning = (T(1) / (((s.wp * p.n) + (s.wpc * p.ncc)) / (s.wp + s.wpc))) * (s.area + s.areac) * r23
+                   * c.sqrt_s0;
     return hp;
 }
 
@@ -166,8 +167,7 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
     const T km = hp.km;
     T x;
     if (hp.ck > T(0)) {
-        const T width = hp.over ? p.twcc : hp.twl;
-        const T denom = T(2) * width * p.s0 * hp.ck * p.dx;
+        const T denom = hp.denom;
         if (!LOWER)
             x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - (qj_prev / denom))));
         else
@@ -190,9 +190,7 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
         if ((k.C4 < T(0)) && (mc_abs(k.C4) > w)) k.C4 = -w;
     }
 
-    if (hp.wp_sum > T(0))
-        return ((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4)
-               - ((T(1) / (hp.wn_sum / hp.wp_sum)) * hp.area_sum * hp.r23 * c.sqrt_s0);
+    if (hp.has_wp) return ((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4) - hp.q_manning;
     return T(0);
 }
 
