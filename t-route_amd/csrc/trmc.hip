@@ -355,18 +355,24 @@ k_fill_boundary(const T *__restrict__ bfvd, T *q_tm, T *v_tm, T *d_tm, int32_t n
     d_tm[dst] = bfvd[src + 2];
 }
 
-// result: time-major SoA -> out[row][t-1][3]; tile = 64 positions x 64 steps through LDS
+// result: time-major SoA -> out[row][t-1][3]; tile = 64 positions x kEmitSteps steps through LDS
+// (32 steps: 24.8 KB of LDS per block -> 6 blocks per CU keep enough loads in flight; row chunks of
+// 384 contiguous bytes on the store side)
+#ifndef TRMC_EMIT_STEPS
+#define TRMC_EMIT_STEPS 32
+#endif
+constexpr int kEmitSteps = TRMC_EMIT_STEPS;
 template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_emit(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restrict__ d_tm,
        const int32_t *__restrict__ row_of_pos, T *__restrict__ out, int32_t nseg, int64_t nseg_pad,
-       int32_t nsteps)
+       int32_t nsteps, int32_t t_begin, int32_t t_end)
 {
-    __shared__ T tile[64][3 * 64 + 1]; // [position][step*3 + c]
+    __shared__ T tile[64][3 * kEmitSteps + 1]; // [position][step*3 + c]
     const int32_t p0 = blockIdx.x * 64;
-    const int32_t t0 = blockIdx.y * 64; // zero-based output step
-    const int32_t nt = min(64, nsteps - t0);
-    for (int32_t i = threadIdx.x; i < 64 * 64; i += kBlock) {
+    const int32_t t0 = t_begin + (int32_t)blockIdx.y * kEmitSteps; // zero-based output step
+    const int32_t nt = min(kEmitSteps, t_end - t0);
+    for (int32_t i = threadIdx.x; i < 64 * kEmitSteps; i += kBlock) {
         const int32_t tl = i / 64, pl = i % 64;
         const int32_t p = p0 + pl;
         if (p < nseg && tl < nt) {
@@ -473,6 +479,9 @@ struct trmc_plan {
     double dt = 0.0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream2 = nullptr;       // result transpose, overlapped with the step launches
+    std::vector<hipEvent_t> tile_ev;     // "time tile b is complete" (main stream -> stream2)
+    hipEvent_t ev_emit = nullptr;        // "all tiles emitted" (stream2 -> main stream)
     // static, plan order
     DevBuf params; // 9 columns x nseg_pad
     DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev;
@@ -605,6 +614,31 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
                            (const T *)pl->in_bfvd.p, a.q_tm, a.v_tm, a.d_tm, (int32_t)tp.nboundary, nsteps, np);
     HIP_TRY(hipEventRecord(pl->ev[1], st));
 
+    // The result transpose (memory-bound) runs on a second stream, one 64-step time tile at a time,
+    // as soon as the launches that complete the tile have been queued: it overlaps with the
+    // VALU-bound step kernels instead of trailing them.
+    const int32_t ntiles = (nsteps + 63) / 64;
+    while ((int32_t)pl->tile_ev.size() < ntiles) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pl->tile_ev.push_back(e);
+    }
+    int32_t tiles_done = 0;
+    auto emit_tiles_through = [&](int32_t t_complete) -> int { // all steps <= t_complete are queued on st
+        while (tiles_done < ntiles && ((tiles_done + 1) * 64 <= t_complete || t_complete >= nsteps)) {
+            HIP_TRY(hipEventRecord(pl->tile_ev[tiles_done], st));
+            HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->tile_ev[tiles_done], 0));
+            if (n > 0) {
+                const int32_t tb = tiles_done * 64, te = min(nsteps, tb + 64);
+                hipLaunchKernelGGL((k_emit<T>), dim3((n + 63) / 64, (unsigned)((te - tb + kEmitSteps - 1) / kEmitSteps)),
+                                   dim3(kBlock), 0, pl->stream2, a.q_tm, a.v_tm, a.d_tm, row_of_pos, (T *)pl->out.p, n,
+                                   np, nsteps, tb, te);
+            }
+            ++tiles_done;
+        }
+        return 0;
+    };
+
     int32_t launches = 0;
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
@@ -613,22 +647,28 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
             for (int32_t t = 1; t <= nsteps; ++t) {
                 launch_step<T, true>(st, a, s0, s1, t);
                 ++launches;
+                if (t % 64 == 0 && t < nsteps)
+                    if (int rc = emit_tiles_through(t)) return rc;
             }
         } else {
             for (int32_t d = 1; d <= L - 1 + nsteps; ++d) {
                 const int32_t lo = d - nsteps > 0 ? d - nsteps : 0;
                 const int32_t hi = d - 1 < L - 1 ? d - 1 : L - 1;
                 const int32_t s0 = tp.lvl_ptr[lo], s1 = tp.lvl_ptr[hi + 1];
-                if (s1 <= s0) continue;
-                launch_step<T, false>(st, a, s0, s1, d);
-                ++launches;
+                if (s1 > s0) {
+                    launch_step<T, false>(st, a, s0, s1, d);
+                    ++launches;
+                }
+                const int32_t t_done = d - (L - 1); // every level has reached step t_done
+                if (t_done > 0 && t_done % 64 == 0 && t_done < nsteps)
+                    if (int rc = emit_tiles_through(t_done)) return rc;
             }
         }
     }
     HIP_TRY(hipEventRecord(pl->ev[2], st));
-    if (n > 0)
-        hipLaunchKernelGGL((k_emit<T>), dim3((n + 63) / 64, (unsigned)((nsteps + 63) / 64)), dim3(kBlock), 0, st, a.q_tm,
-                           a.v_tm, a.d_tm, row_of_pos, (T *)pl->out.p, n, np, nsteps);
+    if (int rc = emit_tiles_through(nsteps)) return rc; // whatever is left (at least the last tile)
+    HIP_TRY(hipEventRecord(pl->ev_emit, pl->stream2));
+    HIP_TRY(hipStreamWaitEvent(st, pl->ev_emit, 0));
     HIP_TRY(hipEventRecord(pl->ev[3], st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
@@ -759,7 +799,13 @@ int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
     };
     {
         hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+        // step launches on a high-priority stream, the overlapped transpose on a low-priority one:
+        // the transpose should fill gaps, not displace the VALU-bound step kernel
+        int prio_lo = 0, prio_hi = 0;
+        if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&pl->stream, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&pl->stream2, hipStreamNonBlocking, prio_lo);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_emit, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
         if (e != hipSuccess) return bail(fail(TRMC_EHIP, std::string("stream/event setup: ") + hipGetErrorString(e)));
     }
@@ -786,6 +832,10 @@ void trmc_plan_destroy(trmc_plan *pl)
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : pl->tile_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (pl->ev_emit) (void)hipEventDestroy(pl->ev_emit);
+    if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
     delete pl;
 }
