@@ -122,7 +122,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("TRMC_FORCE_DIST"))   # the env var exercises the RCCL path at N=1
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -153,27 +154,26 @@ def main():
     nseg = to.shape[0]
     q0 = np.zeros((nseg, 3), dtype=np.float32)
 
-    def all_gather_np(arr):
-        """all_gather of ragged numpy blocks over RCCL (padded to the largest block)."""
+    def all_gather_tensor(t):
+        """[world, *t.shape] over RCCL (xGMI); t has the same shape on every rank"""
         import torch
-        arr = np.ascontiguousarray(arr)
-        n = torch.tensor([arr.shape[0]], device="cuda", dtype=torch.int64)
-        ns = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(ns, n)
-        ns = [int(x.item()) for x in ns]
-        tail = arr.shape[1:]
-        buf = torch.zeros((max(ns),) + tail, device="cuda", dtype=torch.from_numpy(arr[:0]).dtype)
-        if arr.shape[0]:
-            buf[:arr.shape[0]] = torch.from_numpy(arr).cuda()
-        outs = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(outs, buf)
-        return [o[:k].cpu().numpy() for o, k in zip(outs, ns)]
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out
 
     t0 = time.perf_counter()
     router = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision)
     t_plan = time.perf_counter() - t0
     router.upload(a.nsteps, qlat, q0)
-    ag = all_gather_np if world > 1 else None
+    if use_dist:
+        import torch
+        router.enable_device_exchange(torch, torch.device("cuda", local_rank))
+        router.upload_trunk()
+
+    def route_once(short_ts):
+        if use_dist:   # every hand-off stays in HBM: gather kernels -> RCCL all-gather -> boundary rows
+            return router.route_on_device(a.qts, short_ts, all_gather_tensor)
+        return router.route(a.qts, short_ts, None)
 
     def sync():
         if dist is not None:
@@ -183,12 +183,12 @@ def main():
 
     def timed(short_ts, steps, warmup):
         for _ in range(warmup):
-            router.route(a.qts, short_ts, ag)
+            route_once(short_ts)
         sync()
         t0 = time.perf_counter()
         mains, totals, launches = [], [], 0
         for _ in range(steps):
-            rows, hyd = router.route(a.qts, short_ts, ag)
+            rows, hyd = route_once(short_ts)
             st = router.last_stats["phase0"]
             mains.append(st["ms_main"])
             totals.append(st["ms_total"])

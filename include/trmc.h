@@ -132,6 +132,14 @@ int trmc_upload_forcing(trmc_plan *plan, int nsteps, const void *qlat, int64_t n
                         const void *q0, const void *boundary_fvd);
 
 /*
+ * Supply the boundary rows' flow hydrographs from a DEVICE buffer q_dev[nboundary][nsteps] (ascending
+ * boundary row order) after trmc_upload_forcing(..., boundary_fvd = NULL): the multi-GPU hand-off of
+ * sub-basin outlet hydrographs to the trunk (reference: flowveldepth_interorder, compute.py:882-897)
+ * without a host round trip.  Velocity/depth of boundary rows are not inputs of the routing.
+ */
+int trmc_set_boundary_flow_device(trmc_plan *plan, int nsteps, const void *q_dev);
+
+/*
  * Route nsteps timesteps on the device (asynchronous launches on the plan's
  * stream, then waits for completion).  Replaces the time x reach loop of [R1]
  * (mc_reach.pyx:492-505, :719-750) and the per-reach chain of

@@ -488,6 +488,7 @@ struct trmc_plan {
     // per window
     DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch;
     int64_t nq = 0;
+    bool have_boundary = true;  // boundary hydrographs present for the staged window
     int32_t staged_nsteps = -1; // nsteps the staged forcing was uploaded for
     int32_t routed_nsteps = -1; // nsteps of the last completed route
     trmc_stats stats{};
@@ -869,8 +870,7 @@ int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq,
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
     if (pl->nseg > 0 && (!qlat || !q0)) return fail(TRMC_EINVAL, "qlat/q0 is NULL");
-    if (pl->topo.nboundary > 0 && !boundary_fvd)
-        return fail(TRMC_EINVAL, "plan has boundary rows but boundary_fvd is NULL");
+    // boundary_fvd may be NULL here when trmc_set_boundary_flow_device() supplies the hydrographs later
     if (int rc = use_device(pl)) return rc;
     const size_t e = pl->esz;
     if (int rc = pl->in_qlat.ensure((size_t)pl->nseg * nq * e)) return rc;
@@ -879,14 +879,35 @@ int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq,
         HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, (size_t)pl->nseg * nq * e, hipMemcpyHostToDevice, pl->stream));
         HIP_TRY(hipMemcpyAsync(pl->in_q0.p, q0, (size_t)pl->nseg * 3 * e, hipMemcpyHostToDevice, pl->stream));
     }
-    if (pl->topo.nboundary > 0) {
+    if (pl->topo.nboundary > 0 && boundary_fvd) {
         const size_t b = (size_t)pl->topo.nboundary * nsteps * 3 * e;
         if (int rc = pl->in_bfvd.ensure(b)) return rc;
         HIP_TRY(hipMemcpyAsync(pl->in_bfvd.p, boundary_fvd, b, hipMemcpyHostToDevice, pl->stream));
     }
     HIP_TRY(hipStreamSynchronize(pl->stream));
     pl->nq = nq;
+    pl->have_boundary = pl->topo.nboundary == 0 || boundary_fvd != nullptr;
     pl->staged_nsteps = nsteps;
+    pl->routed_nsteps = -1;
+    return 0;
+}
+
+int trmc_set_boundary_flow_device(trmc_plan *pl, int nsteps, const void *q_dev)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->staged_nsteps < 0) return fail(TRMC_ESTATE, "trmc_upload_forcing must precede trmc_set_boundary_flow_device");
+    if (nsteps != pl->staged_nsteps) return fail(TRMC_EINVAL, "nsteps differs from the staged forcing");
+    const int64_t nb = pl->topo.nboundary;
+    if (nb == 0) return 0;
+    if (!q_dev) return fail(TRMC_EINVAL, "q_dev is NULL");
+    if (int rc = use_device(pl)) return rc;
+    const size_t e = pl->esz;
+    if (int rc = pl->in_bfvd.ensure((size_t)nb * nsteps * 3 * e)) return rc;
+    // expand [b][t] -> [b][t][q,0,0] on the device (velocity and depth of a boundary row are never read)
+    HIP_TRY(hipMemsetAsync(pl->in_bfvd.p, 0, (size_t)nb * nsteps * 3 * e, pl->stream));
+    HIP_TRY(hipMemcpy2DAsync(pl->in_bfvd.p, 3 * e, q_dev, e, e, (size_t)nb * nsteps, hipMemcpyDeviceToDevice, pl->stream));
+    HIP_TRY(hipStreamSynchronize(pl->stream));
+    pl->have_boundary = true;
     pl->routed_nsteps = -1;
     return 0;
 }
@@ -899,6 +920,7 @@ int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assum
     if (qts_subdivisions < 1) return fail(TRMC_EINVAL, "qts_subdivisions must be >= 1");
     if (pl->topo.nboundary > 0 && nsteps != pl->staged_nsteps)
         return fail(TRMC_EINVAL, "nsteps differs from the staged boundary hydrographs");
+    if (!pl->have_boundary) return fail(TRMC_ESTATE, "plan has boundary rows but no boundary hydrographs were supplied");
     // the reference's precondition, mc_reach.pyx:246-247
     if ((int64_t)(nsteps - 1) / qts_subdivisions >= pl->nq)
         return fail(TRMC_EINVAL, "Number of columns (timesteps) in Qlat is incorrect: need "

@@ -95,6 +95,78 @@ class ShardedRouter:
             o1 = outlets[np.isin(outlets, trunk_rows)]
             self.my_out1_global, self.my_out1_local = o1, g2l1[o1]
 
+    # ---- device-resident exchange (torch tensors; NCCL = RCCL over xGMI on the GPU box) --------------
+    def enable_device_exchange(self, torch, device):
+        """Precompute the index maps for route_on_device(): every rank knows the whole partition, so the
+        position of every cut row / outlet row inside the all-gathered buffers is known up front."""
+        self._torch, self._tdev = torch, device
+        world = self.world
+        part = self.part
+        piece, phase, owner = part["piece"], part["phase"], part["owner"]
+        row_phase, row_owner = phase[piece], owner[piece]
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        self._tdt = tdt
+        # cut rows: slot (owner, index within the owner's ascending list)
+        ncut = self.cut_rows.shape[0]
+        self._max_cut = 0
+        if ncut:
+            counts = np.bincount(self.cut_owner, minlength=world)
+            self._max_cut = int(counts.max())
+            idx_in_owner = np.zeros(ncut, dtype=np.int64)
+            for r in range(world):
+                m = self.cut_owner == r
+                idx_in_owner[m] = np.arange(int(m.sum()))
+            flat = self.cut_owner.astype(np.int64) * self._max_cut + idx_in_owner
+            if self.plan1 is not None:
+                self._t_b_index = torch.from_numpy(flat[self.b_cut_index]).to(device)
+        # outlets: per rank, phase-0 outlets (ascending) followed by trunk outlets (ascending)
+        outlets = self.outlets
+        per_rank = []
+        for r in range(world):
+            o0 = outlets[(row_phase[outlets] == 0) & (row_owner[outlets] == r)]
+            o1 = outlets[(row_phase[outlets] == 1) & (row_owner[outlets] == r)]
+            per_rank.append(np.concatenate([o0, o1]))
+        self._max_out = max(1, max(len(x) for x in per_rank))
+        rows = np.concatenate(per_rank)
+        slot = np.concatenate([r * self._max_out + np.arange(len(x)) for r, x in enumerate(per_rank)])
+        order = np.argsort(rows, kind="stable")
+        self._out_rows = rows[order]
+        self._t_out_index = torch.from_numpy(slot[order].astype(np.int64)).to(device)
+
+    def upload_trunk(self):
+        """Stage the trunk's forcing once (its boundary hydrographs arrive per route via the exchange)."""
+        if self.plan1 is not None:
+            self.plan1.upload_forcing(self.nsteps, self._qlat[self.rows1], self._q0[self.rows1], None)
+
+    def route_on_device(self, qts_subdivisions, assume_short_ts, all_gather_tensor):
+        """As route(), but every hand-off stays in HBM.  ``all_gather_tensor(t) -> [world, *t.shape]``
+        (torch.distributed.all_gather_into_tensor).  Returns (outlet_rows, hydrographs tensor on device)."""
+        torch, dev, nsteps = self._torch, self._tdev, self.nsteps
+        stats = {"phase0": self.plan0.route_device(nsteps, qts_subdivisions, assume_short_ts)}
+        if self._max_cut:
+            send = torch.zeros((self._max_cut, nsteps), dtype=self._tdt, device=dev)
+            if self.my_cut_local.size:
+                torch.cuda.current_stream().synchronize()
+                self.plan0.gather_flow_rows(self.my_cut_local, device_ptr=send.data_ptr())
+            recv = all_gather_tensor(send)
+            if self.plan1 is not None:
+                bq = recv.reshape(-1, nsteps).index_select(0, self._t_b_index).contiguous()
+                torch.cuda.current_stream().synchronize()
+                self.plan1.set_boundary_flow_device(nsteps, bq.data_ptr())
+        if self.plan1 is not None:
+            stats["phase1"] = self.plan1.route_device(nsteps, qts_subdivisions, assume_short_ts)
+        send_o = torch.zeros((self._max_out, nsteps), dtype=self._tdt, device=dev)
+        torch.cuda.current_stream().synchronize()
+        n0 = self.my_out0_local.shape[0]
+        if n0:
+            self.plan0.gather_flow_rows(self.my_out0_local, device_ptr=send_o.data_ptr())
+        if self.plan1 is not None and self.my_out1_global.size:
+            self.plan1.gather_flow_rows(self.my_out1_local, device_ptr=send_o[n0:].data_ptr())
+        recv_o = all_gather_tensor(send_o)
+        hyd = recv_o.reshape(-1, nsteps).index_select(0, self._t_out_index)
+        self.last_stats = stats
+        return self._out_rows, hyd
+
     def close(self):
         self.plan0.close()
         if self.plan1 is not None:

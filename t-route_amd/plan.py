@@ -109,13 +109,17 @@ class RoutingPlan:
         if q0.shape != (self.nseg, 3):
             raise ValueError("initial_conditions shape mismatch")
         bf = None
-        if self.nboundary:
+        if self.nboundary and boundary_fvd is not None:   # None: set_boundary_flow_device() follows
             bf = np.ascontiguousarray(boundary_fvd, dtype=self.dtype)
             if bf.shape != (self.nboundary, nsteps, 3):
                 raise ValueError("boundary hydrograph shape mismatch")
         _lib.check(_lib.lib().trmc_upload_forcing(self._h, nsteps, _lib.ptr(qlat), qlat.shape[1], _lib.ptr(q0),
                                                   _lib.ptr(bf)))
         self._nsteps = nsteps
+
+    def set_boundary_flow_device(self, nsteps, device_ptr):
+        """Boundary rows' flow hydrographs from a device buffer [nboundary][nsteps] (plan precision)."""
+        _lib.check(_lib.lib().trmc_set_boundary_flow_device(self._h, nsteps, C.c_void_p(device_ptr)))
 
     def route_device(self, nsteps, qts_subdivisions, assume_short_ts):
         _lib.check(_lib.lib().trmc_route_device(self._h, nsteps, qts_subdivisions, int(bool(assume_short_ts))))
