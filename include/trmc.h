@@ -140,6 +140,23 @@ int trmc_upload_forcing(trmc_plan *plan, int nsteps, const void *qlat, int64_t n
 int trmc_set_boundary_flow_device(trmc_plan *plan, int nsteps, const void *q_dev);
 
 /*
+ * Streamflow nudging at gages for the staged window.  Reference: simple_da
+ * (src/troute-routing/troute/routing/fast_reach/simple_da.pyx:22-95) applied to the gage segment after
+ * its reach has been routed for the timestep (mc_reach.pyx:761-796).  Which of simple_da's three
+ * branches is taken at (gage, step) depends on the observation record only, so the caller resolves it
+ * (troute_amd does, with the reference's float/double arithmetic incl. libc exp for the decay weight):
+ *   mode[g][t-1] = 0  no observation, no last observation: the model value passes through
+ *                  1  valid observation a[g][t-1]: flow := a, nudge := a - model
+ *                  2  decay: nudge := (a - model) * w, flow := model + nudge   (a = last observation)
+ * arrays [ngage][nsteps] (a, w in the plan's precision); gage_rows = rows of the gage segments.
+ * Call after trmc_upload_forcing (which clears the tables); ngage = 0 switches nudging off.
+ */
+int trmc_set_nudging(trmc_plan *plan, int nsteps, int64_t ngage, const int64_t *gage_rows,
+                     const uint8_t *mode, const void *a, const void *w);
+/* nudge_out[ngage][nsteps]: the nudge applied at every gage and step (mc_reach.pyx:793). D2H. */
+int trmc_download_nudge(trmc_plan *plan, void *nudge_out);
+
+/*
  * Route nsteps timesteps on the device (asynchronous launches on the plan's
  * stream, then waits for completion).  Replaces the time x reach loop of [R1]
  * (mc_reach.pyx:492-505, :719-750) and the per-reach chain of

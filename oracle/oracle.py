@@ -138,7 +138,7 @@ def wrf_segments(inputs):
 
 
 def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assume_short_ts,
-            prefilled=None, fvd_init=None, ref_name=None, return_iters=False, det=False):
+            prefilled=None, fvd_init=None, ref_name=None, return_iters=False, det=False, da=None):
     """Reference network loop (mc_reach.pyx:492-750 restated).
 
     reaches   : list of int arrays (row positions, upstream->downstream), list order
@@ -154,13 +154,42 @@ def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assu
     up_ptr[1:] = np.cumsum([len(u) for u in upstreams])
     up_idx = (np.concatenate([np.asarray(u, dtype=np.int64) for u in upstreams] + [np.zeros(0, np.int64)]))
     return network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_idx, params, q0, qlat,
-                          assume_short_ts, prefilled, fvd_init, ref_name, return_iters, det)
+                          assume_short_ts, prefilled, fvd_init, ref_name, return_iters, det, da)
+
+
+class DA(C.Structure):
+    """mirror of da_t (float instantiations) in mc_oracle_impl.inc"""
+    _fields_ = [("ngage", C.c_long), ("gage_maxtimestep", C.c_long), ("usgs_values", C.POINTER(C.c_float)),
+                ("gage_row", C.POINTER(C.c_long)), ("gage_of_reach", C.POINTER(C.c_long)),
+                ("decay_coeff", C.c_float), ("routing_period", C.c_float),
+                ("lastobs_time", C.POINTER(C.c_float)), ("lastobs_val", C.POINTER(C.c_float)),
+                ("nudge", C.POINTER(C.c_float))]
+
+
+def simple_da(timestep, routing_period, decay_coeff, gage_maxtimestep, target, model, lastobs_time, lastobs_val):
+    """Restated simple_da (simple_da.pyx:22-95), float32: (replacement, nudge, lastobs_time, lastobs_val)."""
+    out = (C.c_float * 4)()
+    fn = lib().mc_oracle_simple_da_f32
+    fn.restype = None
+    fn(*(C.c_float(float(v)) for v in (timestep, routing_period, decay_coeff, gage_maxtimestep, target, model,
+                                       lastobs_time, lastobs_val)), out)
+    return tuple(np.float32(v) for v in out)
+
+
+def simple_da_with_decay(last_valid_obs, model_val, minutes, decay_coeff):
+    fn = lib().mc_oracle_simple_da_with_decay_f32
+    fn.restype = C.c_float
+    return np.float32(fn(C.c_float(last_valid_obs), C.c_float(model_val), C.c_float(minutes), C.c_float(decay_coeff)))
 
 
 def network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_idx, params, q0, qlat,
                    assume_short_ts, prefilled=None, fvd_init=None, ref_name=None, return_iters=False,
-                   det=False):
-    """As network(), with the reach lists already flattened to CSR arrays (int64)."""
+                   det=False, da=None):
+    """As network(), with the reach lists already flattened to CSR arrays (int64).
+
+    da (float32 only): dict(usgs_values [ngage, nobs] (NaN = missing), gage_row [ngage], gage_of_reach
+    [nreach] (-1 = none), decay_coeff, routing_period, lastobs_time [ngage], lastobs_val [ngage]); on
+    return it also holds 'nudge' [ngage, nsteps+1] and the final lastobs arrays (mc_reach.pyx:761-796)."""
     params = np.ascontiguousarray(params)
     dt = params.dtype
     ct, sfx = _sfx(dt, det)
@@ -184,8 +213,28 @@ def network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_id
        _ptr(reach_ptr, C.c_long), _ptr(reach_seg, C.c_long), _ptr(up_ptr, C.c_long),
        _ptr(up_idx, C.c_long), _ptr(params, ct), _ptr(q0, ct), _ptr(qlat, ct),
        C.c_long(qlat.shape[1]), C.c_int(int(bool(assume_short_ts))),
-       None if pre is None else _ptr(pre, C.c_ubyte), _ptr(fvd, ct), ref, C.byref(iters))
+       None if pre is None else _ptr(pre, C.c_ubyte), _ptr(fvd, ct), ref, C.byref(iters), _da_struct(da, nsteps, dt))
     return (fvd, iters.value) if return_iters else fvd
+
+
+def _da_struct(da, nsteps, dtype):
+    if da is None:
+        return None
+    if np.dtype(dtype) != np.float32:
+        raise ValueError("nudging is restated for float32 only")
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)  # noqa: E731
+    da["usgs_values"] = f32(da["usgs_values"])
+    da["gage_row"], da["gage_of_reach"] = i64(da["gage_row"]), i64(da["gage_of_reach"])
+    da["lastobs_time"], da["lastobs_val"] = f32(da["lastobs_time"]).copy(), f32(da["lastobs_val"]).copy()
+    ngage = da["gage_row"].shape[0]
+    da["nudge"] = np.zeros((ngage, nsteps + 1), dtype=np.float32)
+    st = DA(ngage, da["usgs_values"].shape[1] if da["usgs_values"].ndim == 2 else 0,
+            _ptr(da["usgs_values"], C.c_float), _ptr(da["gage_row"], C.c_long), _ptr(da["gage_of_reach"], C.c_long),
+            float(da["decay_coeff"]), float(da["routing_period"]), _ptr(da["lastobs_time"], C.c_float),
+            _ptr(da["lastobs_val"], C.c_float), _ptr(da["nudge"], C.c_float))
+    da["_struct"] = st
+    return C.byref(st)
 
 
 def network_by_segment(nsteps, qts_subdivisions, up_ptr, up_idx, level, params, q0, qlat, assume_short_ts,

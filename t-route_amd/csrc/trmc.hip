@@ -122,6 +122,11 @@ template <class T> struct StepArgs {
     const T *qlat_tm;
     T *q_tm, *v_tm, *d_tm;
     uint8_t *it_prev; // secant iterations each position needed on its previous step
+    // streamflow nudging at gage positions (nullptr = off), tables [gage][nsteps], see trmc_set_nudging
+    const int32_t *gage_of_pos;
+    const uint8_t *da_mode;
+    const T *da_a, *da_w;
+    T *da_nudge;
     int64_t nseg_pad;
     int32_t nsteps, qts;
 };
@@ -263,7 +268,24 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 #else
         const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, c, f, depthp, m);
 #endif
-        a.q_tm[row_c + s] = r.qdc;
+        T q_new = r.qdc;
+        if (a.gage_of_pos) { // reference hook mc_reach.pyx:761-796; arithmetic of simple_da.pyx:47-76
+            const int32_t g = a.gage_of_pos[s];
+            if (g >= 0) {
+                const size_t e = (size_t)g * (size_t)a.nsteps + (size_t)(t - 1);
+                const uint8_t mode = a.da_mode[e];
+                T nudge = T(0);
+                if (mode == 1) {            // valid observation: replace
+                    nudge = a.da_a[e] - q_new;
+                    q_new = a.da_a[e];
+                } else if (mode == 2) {     // decay the last observation towards the model value
+                    nudge = (a.da_a[e] - q_new) * a.da_w[e];
+                    q_new = q_new + nudge;
+                }
+                a.da_nudge[e] = nudge;
+            }
+        }
+        a.q_tm[row_c + s] = q_new;
         a.v_tm[row_c + s] = r.velc;
         a.d_tm[row_c + s] = r.depthc;
         a.it_prev[s] = (uint8_t)min(r.iters, 255);
@@ -485,6 +507,9 @@ struct trmc_plan {
     // static, plan order
     DevBuf params; // 9 columns x nseg_pad
     DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev;
+    DevBuf gage_of_pos, da_mode, da_a, da_w, da_nudge; // nudging tables of the staged window
+    int64_t ngage = 0;
+    int32_t da_nsteps = -1;
     // per window
     DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch;
     int64_t nq = 0;
@@ -554,6 +579,12 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.level = (const int32_t *)pl->level.p;
     a.it_prev = (uint8_t *)pl->it_prev.p;
+    const bool da = pl->ngage > 0;
+    a.gage_of_pos = da ? (const int32_t *)pl->gage_of_pos.p : nullptr;
+    a.da_mode = (const uint8_t *)pl->da_mode.p;
+    a.da_a = (const T *)pl->da_a.p;
+    a.da_w = (const T *)pl->da_w.p;
+    a.da_nudge = (T *)pl->da_nudge.p;
     a.qlat_tm = (const T *)pl->qlat_tm.p;
     const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
     a.q_tm = (T *)pl->tm.p;
@@ -828,7 +859,8 @@ void trmc_plan_destroy(trmc_plan *pl)
 {
     if (!pl) return;
     (void)hipSetDevice(pl->device);
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->gage_of_pos,
+                      &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch})
         b->release();
     for (auto &e : pl->ev)
@@ -887,6 +919,7 @@ int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq,
     HIP_TRY(hipStreamSynchronize(pl->stream));
     pl->nq = nq;
     pl->have_boundary = pl->topo.nboundary == 0 || boundary_fvd != nullptr;
+    pl->ngage = 0; // nudging tables belong to one window: trmc_set_nudging() after each upload
     pl->staged_nsteps = nsteps;
     pl->routed_nsteps = -1;
     return 0;
@@ -912,6 +945,50 @@ int trmc_set_boundary_flow_device(trmc_plan *pl, int nsteps, const void *q_dev)
     return 0;
 }
 
+int trmc_set_nudging(trmc_plan *pl, int nsteps, int64_t ngage, const int64_t *gage_rows, const uint8_t *mode,
+                     const void *a, const void *w)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->staged_nsteps < 0) return fail(TRMC_ESTATE, "trmc_upload_forcing must precede trmc_set_nudging");
+    if (ngage < 0 || nsteps < 1) return fail(TRMC_EINVAL, "bad ngage/nsteps");
+    pl->ngage = 0;
+    if (ngage == 0) return 0;
+    if (!gage_rows || !mode || !a || !w) return fail(TRMC_EINVAL, "nudging table pointer is NULL");
+    if (int rc = use_device(pl)) return rc;
+    std::vector<int32_t> g_of_pos((size_t)pl->nseg_pad, -1);
+    for (int64_t g = 0; g < ngage; ++g) {
+        const int64_t r = gage_rows[g];
+        if (r < 0 || r >= pl->nseg) return fail(TRMC_EINVAL, "gage row out of range");
+        if (pl->topo.level_of_row[r] < 0) return fail(TRMC_EINVAL, "gage on a boundary row");
+        g_of_pos[pl->topo.pos_of_row[r]] = (int32_t)g; // one gage per segment: the last listed wins, as reach_has_gage does
+    }
+    const size_t n = (size_t)ngage * nsteps, e = pl->esz;
+    if (int rc = upload_i32(pl->gage_of_pos, g_of_pos, 1)) return rc;
+    if (int rc = pl->da_mode.ensure(n)) return rc;
+    if (int rc = pl->da_a.ensure(n * e)) return rc;
+    if (int rc = pl->da_w.ensure(n * e)) return rc;
+    if (int rc = pl->da_nudge.ensure(n * e)) return rc;
+    HIP_TRY(hipMemcpy(pl->da_mode.p, mode, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pl->da_a.p, a, n * e, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pl->da_w.p, w, n * e, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(pl->da_nudge.p, 0, n * e));
+    pl->ngage = ngage;
+    pl->da_nsteps = nsteps;
+    pl->routed_nsteps = -1;
+    return 0;
+}
+
+int trmc_download_nudge(trmc_plan *pl, void *nudge_out)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (pl->ngage == 0) return 0;
+    if (!nudge_out) return fail(TRMC_EINVAL, "nudge_out is NULL");
+    if (int rc = use_device(pl)) return rc;
+    HIP_TRY(hipMemcpy(nudge_out, pl->da_nudge.p, (size_t)pl->ngage * pl->da_nsteps * pl->esz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts)
 {
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
@@ -921,6 +998,7 @@ int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assum
     if (pl->topo.nboundary > 0 && nsteps != pl->staged_nsteps)
         return fail(TRMC_EINVAL, "nsteps differs from the staged boundary hydrographs");
     if (!pl->have_boundary) return fail(TRMC_ESTATE, "plan has boundary rows but no boundary hydrographs were supplied");
+    if (pl->ngage > 0 && pl->da_nsteps != nsteps) return fail(TRMC_EINVAL, "nudging tables were set for a different nsteps");
     // the reference's precondition, mc_reach.pyx:246-247
     if ((int64_t)(nsteps - 1) / qts_subdivisions >= pl->nq)
         return fail(TRMC_EINVAL, "Number of columns (timesteps) in Qlat is incorrect: need "

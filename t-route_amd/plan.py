@@ -121,6 +121,24 @@ class RoutingPlan:
         """Boundary rows' flow hydrographs from a device buffer [nboundary][nsteps] (plan precision)."""
         _lib.check(_lib.lib().trmc_set_boundary_flow_device(self._h, nsteps, C.c_void_p(device_ptr)))
 
+    def set_nudging(self, nsteps, gage_rows, mode, a, w):
+        """Nudging tables [ngage, nsteps] for the staged window (see include/trmc.h trmc_set_nudging)."""
+        gage_rows = np.ascontiguousarray(gage_rows, dtype=np.int64)
+        mode = np.ascontiguousarray(mode, dtype=np.uint8)
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        w = np.ascontiguousarray(w, dtype=self.dtype)
+        ng = gage_rows.shape[0]
+        if mode.shape != (ng, nsteps) or a.shape != (ng, nsteps) or w.shape != (ng, nsteps):
+            raise ValueError("nudging tables must be [ngage, nsteps]")
+        self._ngage = ng
+        _lib.check(_lib.lib().trmc_set_nudging(self._h, nsteps, ng, _lib.ptr(gage_rows), _lib.ptr(mode),
+                                               _lib.ptr(a), _lib.ptr(w)))
+
+    def download_nudge(self):
+        out = np.zeros((getattr(self, "_ngage", 0), self._nsteps), dtype=self.dtype)
+        _lib.check(_lib.lib().trmc_download_nudge(self._h, _lib.ptr(out)))
+        return out
+
     def route_device(self, nsteps, qts_subdivisions, assume_short_ts):
         _lib.check(_lib.lib().trmc_route_device(self._h, nsteps, qts_subdivisions, int(bool(assume_short_ts))))
         self._nsteps = nsteps

@@ -6,8 +6,8 @@ return of the reference's Cython function
 :811-845) and can be registered in the reference's ``_compute_func_map``
 (src/troute-routing/troute/routing/compute.py:21-26) -- see INTEGRATION.md.
 
-Only the MC branch is implemented (this project's scope): reservoir reaches
-(reach_type 1) and gage nudging raise NotImplementedError.  All arithmetic
+The MC branch and streamflow nudging at gages (simple_da, SURVEY 8f rank 1) are implemented;
+reservoir reaches (reach_type 1) raise NotImplementedError.  All arithmetic
 runs in libtrmc.so on the GPU; there is no Python fallback.
 """
 import numpy as np
@@ -176,9 +176,8 @@ def compute_network_structured(
     if data_values.shape[0] != nseg or data_values.shape[1] != len(data_cols):
         raise ValueError("data_values shape mismatch")
 
-    usgs_positions = np.asarray(usgs_positions)
-    if usgs_positions.shape[0] != 0:
-        raise NotImplementedError("streamflow nudging (usgs gages) is outside the Muskingum-Cunge hot path")
+    usgs_positions = np.asarray(usgs_positions, dtype=np.int64)
+    gages_size = usgs_positions.shape[0]
 
     params = np.ascontiguousarray(np.asarray(data_values, dtype=np.float32)[:, column_mapper(list(data_cols))])
     up_ptr, up_idx, in_reach = _flatten_network(reaches_wTypes, upstream_connections, data_idx)
@@ -201,6 +200,38 @@ def compute_network_structured(
         bvals[fill_index] = res
         q0[fill_index, 0] = initial_conditions[fill_index, 0]
         q0[fill_index, 2] = initial_conditions[fill_index, 2]
+    # ---- streamflow nudging (mc_reach.pyx:380-411): tables resolved on the host, applied on the GPU ----
+    nudging = None
+    if gages_size:
+        from . import simple_da as _da
+        usgs_values = np.asarray(usgs_values, dtype=np.float32)
+        upr = np.asarray(usgs_positions_reach, dtype=np.int64)
+        upg = np.asarray(usgs_positions_gage, dtype=np.int64)
+        # reach_has_gage[reach] = gage index; the nudge is applied to usgs_positions[that gage] after the
+        # whole reach has been routed, so the engine needs the gage segment to END its reach (which the
+        # reference's gage-splitting network builders guarantee, nhd_network.py:319-338)
+        reach_gage = {}
+        for gi in range(gages_size):
+            reach_gage[int(upr[gi])] = int(upg[gi])
+        active = sorted(set(reach_gage.values()))
+        for ri, gi in reach_gage.items():
+            last_row = binary_find(data_idx, [reaches_wTypes[ri][0][-1]])[0]
+            if last_row != int(usgs_positions[gi]):
+                raise NotImplementedError("a gage segment that is not the last segment of its reach")
+        mode, a_tab, w_tab, lt_fin, lv_fin = _da.resolve_tables(
+            nsteps, dt, da_decay_coefficient, usgs_values, lastobs_values_init, time_since_lastobs_init)
+        act = np.asarray(active, dtype=np.int64)
+        if precision != 32:
+            a_tab, w_tab = a_tab.astype(dtype), w_tab.astype(dtype)
+        nudging = (usgs_positions[act], mode[act], a_tab[act], w_tab[act], act)
+        # gages that own no reach are never visited by the loop: their lastobs stay at the initial values
+        idle = np.setdiff1d(np.arange(gages_size), act)
+        lt_fin[idle] = np.asarray(time_since_lastobs_init, dtype=np.float32)[idle]
+        lv_fin[idle] = np.asarray(lastobs_values_init, dtype=np.float32)[idle]
+        if usgs_values.ndim == 2 and usgs_values.shape[1] > 0:      # initial flow <- first observation (:404-411)
+            v0 = usgs_values[:, 0]
+            ok = ~np.isnan(v0)
+            q0[usgs_positions[ok], 0] = v0[ok]
     brow = np.flatnonzero(boundary)
     boundary_fvd = None
     if brow.size:
@@ -209,8 +240,15 @@ def compute_network_structured(
             if r in bvals:
                 boundary_fvd[k] = bvals[r]
 
+    nudge = np.zeros((gages_size, nsteps + 1), dtype="float32")
     with RoutingPlan(up_ptr, up_idx, params, boundary if brow.size else None, precision, device) as plan:
-        fvd = plan.route(nsteps, qts_subdivisions, assume_short_ts, qlat_values, q0, boundary_fvd)
+        plan.upload_forcing(nsteps, qlat_values, q0, boundary_fvd)
+        if nudging is not None:
+            plan.set_nudging(nsteps, nudging[0], nudging[1], nudging[2], nudging[3])
+        plan.route_device(nsteps, qts_subdivisions, assume_short_ts)
+        fvd = plan.download_fvd()
+        if nudging is not None:
+            nudge[nudging[4], 1:] = plan.download_nudge()
         stats = plan.stats()
 
     out_dtype = np.float32 if precision == 32 else np.float64
@@ -224,9 +262,9 @@ def compute_network_structured(
         flowveldepth,
         0,
         (
-            np.asarray([], dtype=np.int64),
-            np.full(0, np.nan, dtype="float32"),
-            np.full(0, np.nan, dtype="float32"),
+            np.asarray([data_idx[p] for p in usgs_positions]),
+            (lt_fin if gages_size else np.full(0, np.nan, dtype="float32")),
+            (lv_fin if gages_size else np.full(0, np.nan, dtype="float32")),
         ),
         (
             i32(reservoir_usgs_wbody_idx),
@@ -248,7 +286,7 @@ def compute_network_structured(
             f32(reservoir_rfc_update_time) - t_end,
             i32(reservoir_rfc_timeseries_idx),
         ),
-        np.zeros((0, nsteps + 1), dtype="float32"),
+        nudge,
         (
             i32(great_lakes_param_idx),
             f32(great_lakes_param_prev_assim_flow),

@@ -334,8 +334,59 @@ def lowercolorado(nn):
     np.savez_compressed(os.path.join(HERE, "lowercolorado_golden.npz"), **gold)
 
 
+# ----------------------------------------------------------------------------
+def nudging_vectors():
+    """simple_da golden vectors from the reference's own Cython source
+    (src/troute-routing/troute/routing/fast_reach/simple_da.pyx), compiled where it lies; a 10-line
+    probe .pyx (written here, into a temp dir) exposes the cdef function to Python."""
+    import shutil
+    td = tempfile.mkdtemp()
+    try:
+        open(os.path.join(td, "da_probe.pyx"), "w").write(
+            "# cython: language_level=3\n"
+            "from troute.routing.fast_reach.simple_da cimport simple_da, simple_da_with_decay\n"
+            "def call_simple_da(float t, float rp, float dc, float gm, float target, float model, float lt, float lv):\n"
+            "    cdef (float, float, float, float) r = simple_da(t, rp, dc, gm, target, model, lt, lv, 0)\n"
+            "    return (r[0], r[1], r[2], r[3])\n"
+            "def call_decay(float lo, float m, float minutes, float decay):\n"
+            "    return simple_da_with_decay(lo, m, minutes, decay)\n")
+        open(os.path.join(td, "setup.py"), "w").write(
+            "from setuptools import setup, Extension\nfrom Cython.Build import cythonize\n"
+            f"R='{REF}/src/troute-routing'\n"
+            "exts=[Extension('troute.routing.fast_reach.simple_da',[R+'/troute/routing/fast_reach/simple_da.pyx']),"
+            "Extension('da_probe',['da_probe.pyx'])]\n"
+            "setup(ext_modules=cythonize(exts, include_path=[R], build_dir='build_c'))\n")
+        subprocess.check_call([sys.executable, "setup.py", "build_ext", "--build-lib", "out", "--build-temp", "tmp"],
+                              cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        sys.path.insert(0, os.path.join(td, "out"))
+        import da_probe
+        rng = np.random.default_rng(42)
+        n = 20000
+        nan = np.float32(np.nan)
+        t = rng.integers(1, 400, n).astype(np.float32)
+        gm = rng.choice([0, 12, 100, 288, 289, 400], n).astype(np.float32)
+        target = np.where(rng.random(n) < 0.35, nan, rng.lognormal(0, 2, n)).astype(np.float32)
+        model = rng.lognormal(0, 2, n).astype(np.float32)
+        lt = np.where(rng.random(n) < 0.2, nan, rng.uniform(-86400, 86400, n)).astype(np.float32)
+        lv = np.where(np.isnan(lt) | (rng.random(n) < 0.1), nan, rng.lognormal(0, 2, n)).astype(np.float32)
+        dc = rng.choice([1.0, 60.0, 120.0, 720.0], n).astype(np.float32)
+        rp = rng.choice([60.0, 300.0, 3600.0], n).astype(np.float32)
+        x = np.stack([t, rp, dc, gm, target, model, lt, lv], 1)
+        y = np.array([da_probe.call_simple_da(*map(float, r)) for r in x], dtype=np.float32)
+        mine = np.array([O.simple_da(*map(float, r)) for r in x], dtype=np.float32)
+        assert np.array_equal(y.view(np.uint32), mine.view(np.uint32)), "oracle simple_da != reference"
+        kat = np.float32(da_probe.call_decay(9.5, 12.0, 60.0, 120.0))       # test_compute.py:33-42
+        assert abs(float(kat) - 10.483673095703125) < 2.3e-6 * 10.5
+        np.savez_compressed(os.path.join(HERE, "simple_da_vectors.npz"), inputs=x, outputs=y, kat_decay=kat)
+        print("simple_da vectors:", x.shape, "branches:",
+              int(((t <= gm) & ~np.isnan(target)).sum()), int((np.isnan(target) & np.isnan(lv)).sum()))
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 if __name__ == "__main__":
     O.build()
+    nudging_vectors()
     nn = import_ref_nhd_network()
     kernel_vectors()
     toy_network(nn)

@@ -1,0 +1,137 @@
+"""Streamflow nudging: reference simple_da -> oracle -> host tables -> GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import oracle as O
+from troute_amd import nhd_network as nn
+from troute_amd.routing.fast_reach import simple_da as DA
+
+GOLD = np.load(os.path.join(H.GOLDEN, "simple_da_vectors.npz"))
+
+
+def test_oracle_simple_da_equals_reference_cython_bitwise():
+    """20 000 vectors through the reference's own simple_da.pyx (compiled by make_fixtures.py)."""
+    x, y = GOLD["inputs"], GOLD["outputs"]
+    got = np.array([O.simple_da(*map(float, r)) for r in x], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), y.view(np.uint32))
+
+
+def test_reference_unit_test_value():
+    """src/troute-routing/troute/routing/test_compute.py:33-42"""
+    assert float(GOLD["kat_decay"]) == pytest.approx(10.483673095703125, rel=2.3e-6)
+    assert DA.simple_da_with_decay_py(9.5, 12, 60, 120) == GOLD["kat_decay"]
+    assert O.simple_da_with_decay(9.5, 12, 60, 120) == GOLD["kat_decay"]
+
+
+def test_python_scalar_simple_da_equals_reference():
+    x, y = GOLD["inputs"][:4000], GOLD["outputs"][:4000]
+    got = np.array([DA.simple_da(*r) for r in x], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), y.view(np.uint32))
+
+
+def test_resolved_tables_reproduce_sequential_simple_da():
+    """The branch of simple_da never depends on the modelled flow: applying the host-resolved tables
+    gives the same flows, nudges and final lastobs as running the restated simple_da step by step."""
+    rng = np.random.default_rng(3)
+    ng, nsteps, gmax = 300, 60, 40
+    usgs = np.where(rng.random((ng, gmax)) < 0.3, np.nan, rng.lognormal(0, 1, (ng, gmax))).astype(np.float32)
+    lv0 = np.where(rng.random(ng) < 0.3, np.nan, rng.lognormal(0, 1, ng)).astype(np.float32)
+    lt0 = np.where(np.isnan(lv0), np.nan, -rng.uniform(0, 7200, ng)).astype(np.float32)
+    model = rng.lognormal(0, 1, (ng, nsteps + 1)).astype(np.float32)
+    mode, a, w, lt_fin, lv_fin = DA.resolve_tables(nsteps, 300.0, 120.0, usgs, lv0, lt0)
+    lt, lv = lt0.copy(), lv0.copy()
+    for t in range(1, nsteps + 1):
+        for g in range(ng):
+            target = np.float32(np.nan) if t >= gmax else usgs[g, t]
+            rep, nud, lt[g], lv[g] = O.simple_da(t, 300.0, 120.0, gmax, target, model[g, t], lt[g], lv[g])
+            m = mode[g, t - 1]
+            q = model[g, t]
+            if m == 1:
+                got_n, got_q = a[g, t - 1] - q, a[g, t - 1]
+            elif m == 2:
+                got_n = np.float32((a[g, t - 1] - q) * w[g, t - 1])
+                got_q = np.float32(q + got_n)
+            else:
+                got_n, got_q = np.float32(0), q
+            assert np.float32(got_q).tobytes() == np.float32(rep).tobytes(), (g, t, m)
+            assert np.float32(got_n).tobytes() == np.float32(nud).tobytes(), (g, t, m)
+    assert np.array_equal(lt.view(np.uint32), lt_fin.view(np.uint32))
+    assert np.array_equal(lv.view(np.uint32), lv_fin.view(np.uint32))
+
+
+def gaged_lowercolorado(ngage=60, gmax=200, seed=8):
+    lc = H.LowerColorado()
+    conn = {int(s): ([int(t)] if t != 0 else []) for s, t in zip(lc.ids, lc.to)}
+    rng = np.random.default_rng(seed)
+    gage_ids = sorted(rng.choice(lc.ids, ngage, replace=False).tolist())
+    ind, reaches_bytw, rconn = nn.organize_independent_networks(conn, set(), set(gage_ids))
+    reaches = reaches_bytw[lc.tailwaters[0]]
+    net = ind[lc.tailwaters[0]]
+    row = {int(s): i for i, s in enumerate(lc.ids)}
+    reach_of = {r[-1]: i for i, r in enumerate(reaches)}
+    assert all(g in reach_of for g in gage_ids)                      # every gage ends its reach
+    usgs_positions = np.array([row[g] for g in gage_ids], np.int32)
+    usgs_positions_reach = np.array([reach_of[g] for g in gage_ids], np.int32)
+    usgs_positions_gage = np.arange(ngage, dtype=np.int32)
+    usgs = rng.lognormal(np.log(0.05), 1.0, (ngage, gmax)).astype(np.float32)
+    usgs[rng.random((ngage, gmax)) < 0.25] = np.nan
+    usgs[:5, :] = np.nan                                             # gages with no observation at all
+    lv0 = rng.lognormal(np.log(0.05), 1.0, ngage).astype(np.float32)
+    lt0 = (-rng.uniform(0, 7200, ngage)).astype(np.float32)
+    lv0[:3] = np.nan
+    lt0[:3] = np.nan
+    return lc, reaches, net, gage_ids, usgs_positions, usgs_positions_reach, usgs_positions_gage, usgs, lv0, lt0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("short", [True, False])
+def test_gpu_nudging_bit_identical_to_oracle(short):
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+    lc, reaches, net, gage_ids, upos, upr, upg, usgs, lv0, lt0 = gaged_lowercolorado()
+    decay = 120.0
+    args = mc_only_args(lc.nts, lc.dt, lc.qts, reaches, net, lc.ids, lc.data_cols, lc.data_values, lc.q0, lc.qlat,
+                        assume_short_ts=short)
+    args[16], args[17], args[18], args[19] = usgs, upos, upr, upg
+    args[20], args[21], args[22] = lv0, lt0, decay
+    r = compute_network_structured(*args)
+    fvd = r[1].reshape(lc.nseg, lc.nts, 3)
+
+    row = {int(s): i for i, s in enumerate(lc.ids)}
+    rl = [np.array([row[s] for s in rr], dtype=np.int64) for rr in reaches]
+    ul = [np.array([row[s] for s in net.get(rr[0], [])], dtype=np.int64) for rr in reaches]
+    gage_of_reach = np.full(len(reaches), -1, np.int64)
+    gage_of_reach[upr] = upg
+    da = dict(usgs_values=usgs, gage_row=upos, gage_of_reach=gage_of_reach, decay_coeff=decay, routing_period=lc.dt,
+              lastobs_time=lt0, lastobs_val=lv0)
+    want = O.network(lc.nts, lc.qts, rl, ul, lc.params9, lc.q0, lc.qlat, short, det=True, da=da)
+    assert np.array_equal(fvd.view(np.uint32), np.ascontiguousarray(want[:, 1:, :]).view(np.uint32))
+    assert np.array_equal(r[8].view(np.uint32), da["nudge"].view(np.uint32))            # nudge [ngage, nsteps+1]
+    assert r[8].shape == (len(gage_ids), lc.nts + 1) and np.abs(r[8]).max() > 0
+    assert np.array_equal(r[3][0], np.array(gage_ids))
+    assert np.array_equal(r[3][1].view(np.uint32), da["lastobs_time"].view(np.uint32))
+    assert np.array_equal(r[3][2].view(np.uint32), da["lastobs_val"].view(np.uint32))
+    # the nudged gage flows really are the observations where one exists
+    t_obs = 50
+    ok = ~np.isnan(usgs[:, t_obs])
+    assert np.array_equal(fvd[upos[ok], t_obs - 1, 0], usgs[ok, t_obs])
+
+
+@pytest.mark.gpu
+def test_gpu_nudging_rejects_gage_inside_reach():
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+    lc = H.LowerColorado()
+    long_reach = next(i for i, r in enumerate(lc.reaches) if len(r) >= 3)
+    args = mc_only_args(12, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, lc.q0, lc.qlat)
+    row = {int(s): i for i, s in enumerate(lc.ids)}
+    args[16] = np.ones((1, 5), np.float32)
+    args[17] = np.array([row[lc.reaches[long_reach][0]]], np.int32)
+    args[18] = np.array([long_reach], np.int32)
+    args[19] = np.array([0], np.int32)
+    args[20] = np.ones(1, np.float32)
+    args[21] = np.zeros(1, np.float32)
+    args[22] = 120.0
+    with pytest.raises(NotImplementedError, match="last segment of its reach"):
+        compute_network_structured(*args)
