@@ -146,7 +146,7 @@ template <class T> struct StepArgs {
 #ifndef TRMC_EXPERIMENT_WAVES
 #define TRMC_EXPERIMENT_WAVES 1
 #endif
-template <class T, bool SHORT, int IPT>
+template <class T, bool SHORT, int IPT, bool SORT = true>
 __global__ void __launch_bounds__(kBlock, TRMC_EXPERIMENT_WAVES)
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag)
 {
@@ -162,6 +162,15 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     const int32_t base = s_begin + (int32_t)blockIdx.x * kChunk;
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
+    int32_t n_work;
+    if (!SORT) {
+        // narrow slices (a few blocks per launch) are latency-bound: the partition's loads and barriers
+        // would only lengthen the critical path, so positions are visited in plan order
+        static_assert(SORT || IPT == 1, "the unsorted form handles one position per thread");
+        s_perm[threadIdx.x] = (uint16_t)threadIdx.x;
+        n_work = min(kChunk, s_end - base);
+        __syncthreads();
+    } else {
     // ---- class of my IPT items, per-wave counts -------------------------------------------------
     int32_t cls[IPT], rank[IPT];
 #pragma unroll
@@ -211,7 +220,8 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     for (int j = 0; j < IPT; ++j)
         s_perm[s_cnt[cls[j]][j][wave] + rank[j]] = (uint16_t)(j * kBlock + (int32_t)threadIdx.x);
     __syncthreads();
-    const int32_t n_work = s_cnt[kClasses - 1][0][0]; // items of classes 0..3 come first
+    n_work = s_cnt[kClasses - 1][0][0]; // items of classes 0..3 come first
+    }
 
     // ---- the segment steps, one class-sorted wave-pass at a time ---------------------------------
     for (int pass = 0; pass < IPT; ++pass) {
@@ -219,6 +229,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         if (w >= n_work) break;
         const int32_t s = base + (int32_t)s_perm[w];
         const int32_t t = SHORT ? diag : diag - a.level[s];
+        if (!SORT && (t < 1 || t > a.nsteps)) continue;
 
         const size_t row_p = (size_t)(t - 1) * (size_t)a.nseg_pad; // previous time level
         const size_t row_c = (size_t)t * (size_t)a.nseg_pad;       // current time level
@@ -288,7 +299,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         a.q_tm[row_c + s] = q_new;
         a.v_tm[row_c + s] = r.velc;
         a.d_tm[row_c + s] = r.depthc;
-        a.it_prev[s] = (uint8_t)min(r.iters, 255);
+        if (SORT) a.it_prev[s] = (uint8_t)min(r.iters, 255);
     }
 }
 
@@ -613,8 +624,10 @@ inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_
     if (false)
 #endif
         hipLaunchKernelGGL((k_mc_step<T, SHORT, 4>), dim3((unsigned)((n + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, st, a, s0, s1, d);
-    else
+    else if (n >= (int64_t)kBlock * 512)
         hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), dim3(blocks_for(n)), dim3(kBlock), 0, st, a, s0, s1, d);
+    else // fewer than two blocks per CU: latency-bound, skip the class partition
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), dim3(blocks_for(n)), dim3(kBlock), 0, st, a, s0, s1, d);
 }
 
 template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int short_ts)
