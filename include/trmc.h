@@ -178,6 +178,9 @@ int trmc_download_final_state(trmc_plan *plan, void *q0_out);
  * plan's device (used to hand outlet hydrographs to RCCL without a host trip). */
 int trmc_gather_flow_rows(trmc_plan *plan, const int64_t *rows, int64_t nrows, void *out,
                           int dst_is_device);
+/* With out == NULL and dst_is_device != 0 the gathered block stays in plan-owned HBM (results are
+ * device-resident); this copies it to the host later: out[nrows][nsteps] of that gather. */
+int trmc_download_gathered(trmc_plan *plan, void *out);
 
 int trmc_get_stats(const trmc_plan *plan, trmc_stats *stats);
 

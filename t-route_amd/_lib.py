@@ -49,6 +49,7 @@ SIGNATURES = {
     "trmc_download_fvd": (_int, [_vp, _vp]),
     "trmc_download_final_state": (_int, [_vp, _vp]),
     "trmc_gather_flow_rows": (_int, [_vp, _vp, _i64, _vp, _int]),
+    "trmc_download_gathered": (_int, [_vp, _vp]),
     "trmc_get_stats": (_int, [_vp, _P(Stats)]),
     "trmc_route": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "trmc_segments": (_int, [_int, _int, _i64, _vp, _vp]),

@@ -522,7 +522,8 @@ struct trmc_plan {
     int64_t ngage = 0;
     int32_t da_nsteps = -1;
     // per window
-    DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch;
+    DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch, gathered;
+    size_t gathered_bytes = 0;
     int64_t nq = 0;
     bool have_boundary = true;  // boundary hydrographs present for the staged window
     int32_t staged_nsteps = -1; // nsteps the staged forcing was uploaded for
@@ -874,7 +875,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     (void)hipSetDevice(pl->device);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1063,7 +1064,7 @@ int trmc_gather_flow_rows(trmc_plan *pl, const int64_t *rows, int64_t nrows, voi
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
     if (nrows == 0) return 0;
-    if (!rows || !out) return fail(TRMC_EINVAL, "rows/out is NULL");
+    if (!rows || (!out && !dst_is_device)) return fail(TRMC_EINVAL, "rows/out is NULL");
     if (int rc = use_device(pl)) return rc;
     std::vector<int32_t> pos((size_t)nrows);
     for (int64_t i = 0; i < nrows; ++i) {
@@ -1075,6 +1076,11 @@ int trmc_gather_flow_rows(trmc_plan *pl, const int64_t *rows, int64_t nrows, voi
     const size_t pbytes = ((size_t)nrows * sizeof(int32_t) + 255) / 256 * 256;
     if (int rc = pl->scratch.ensure(pbytes + (dst_is_device ? 0 : obytes))) return rc;
     HIP_TRY(hipMemcpyAsync(pl->scratch.p, pos.data(), (size_t)nrows * sizeof(int32_t), hipMemcpyHostToDevice, pl->stream));
+    if (dst_is_device && !out) { // keep the block in plan-owned HBM; fetch with trmc_download_gathered()
+        if (int rc = pl->gathered.ensure(obytes)) return rc;
+        out = pl->gathered.p;
+        pl->gathered_bytes = obytes;
+    }
     void *dst = dst_is_device ? out : (void *)((char *)pl->scratch.p + pbytes);
     if (pl->precision == 32)
         hipLaunchKernelGGL((k_gather_rows<float>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream,
@@ -1085,6 +1091,15 @@ int trmc_gather_flow_rows(trmc_plan *pl, const int64_t *rows, int64_t nrows, voi
     HIP_TRY(hipGetLastError());
     if (!dst_is_device) HIP_TRY(hipMemcpyAsync(out, dst, obytes, hipMemcpyDeviceToHost, pl->stream));
     HIP_TRY(hipStreamSynchronize(pl->stream));
+    return 0;
+}
+
+int trmc_download_gathered(trmc_plan *pl, void *out)
+{
+    if (!pl || !out) return fail(TRMC_EINVAL, "plan/out is NULL");
+    if (pl->gathered_bytes == 0) return fail(TRMC_ESTATE, "no device-resident gather to download");
+    if (int rc = use_device(pl)) return rc;
+    HIP_TRY(hipMemcpy(out, pl->gathered.p, pl->gathered_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -178,6 +178,18 @@ class ShardedRouter:
         self._qlat, self._q0 = qlat, q0
         self.plan0.upload_forcing(nsteps, qlat[self.rows0], q0[self.rows0])
 
+    def route_resident(self, qts_subdivisions, assume_short_ts):
+        """Single-rank form that leaves the outlet hydrographs in HBM (throughput mode): returns the
+        outlet rows; ``outlet_hydrographs()`` copies the block to the host when it is wanted."""
+        if self.world != 1:
+            raise ValueError("route_resident is the one-GPU path; use route_on_device with a process group")
+        self.last_stats = {"phase0": self.plan0.route_device(self.nsteps, qts_subdivisions, assume_short_ts)}
+        self.plan0.gather_flow_rows_resident(self.my_out0_local)
+        return self.my_out0_global
+
+    def outlet_hydrographs(self):
+        return self.plan0.download_gathered()
+
     def route(self, qts_subdivisions, assume_short_ts, all_gather=None):
         """One routing window.  ``all_gather(array) -> list of arrays (one per rank)``.
         Returns (outlet_rows, outlet_hydrographs[nout, nsteps]) for the whole job."""

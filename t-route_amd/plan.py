@@ -154,6 +154,18 @@ class RoutingPlan:
         _lib.check(_lib.lib().trmc_download_final_state(self._h, _lib.ptr(out)))
         return out
 
+    def gather_flow_rows_resident(self, rows):
+        """Gather into plan-owned HBM (no host copy); download_gathered() fetches it later."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        self._gathered_shape = (rows.shape[0], self._nsteps)
+        _lib.check(_lib.lib().trmc_gather_flow_rows(self._h, _lib.ptr(rows), rows.shape[0], None, 1))
+
+    def download_gathered(self):
+        out = np.empty(self._gathered_shape, dtype=self.dtype)
+        if out.size:
+            _lib.check(_lib.lib().trmc_download_gathered(self._h, _lib.ptr(out)))
+        return out
+
     def gather_flow_rows(self, rows, device_ptr=None):
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         if device_ptr is not None:
