@@ -140,6 +140,25 @@ int trmc_upload_forcing(trmc_plan *plan, int nsteps, const void *qlat, int64_t n
 int trmc_set_boundary_flow_device(trmc_plan *plan, int nsteps, const void *q_dev);
 
 /*
+ * Level-pool reservoirs of the plan.  Reference: the RESERVOIR_LP branch of the
+ * network loop, mc_reach.pyx:283-356 (setup) and :507-716 (wbody_type_code 1), around
+ * LEVELPOOL_PHYSICS (src/kernel/reservoir/Level_Pool/module_levelpool.F:233-427).  A reservoir is one
+ * row of the table (the reference's waterbody node); its inflow is the junction sum of its upstream
+ * rows, its result row holds (outflow, 0, water elevation).
+ *   res_rows [nres]     rows of the reservoirs
+ *   par      [nres][9]  area max_depth orifice_area orifice_coefficient orifice_elevation
+ *                       weir_coefficient weir_elevation weir_length dam_length  (plan precision)
+ *   routing_period      seconds (the dt argument of compute_network_structured)
+ * The initial outflow and water elevation of a reservoir row travel in q0[row] = (qd0, -, h0) of
+ * trmc_upload_forcing.  nres = 0 removes the reservoirs.
+ */
+int trmc_set_reservoirs(trmc_plan *plan, int64_t nres, const int64_t *res_rows, const void *par,
+                        double routing_period);
+/* inflow_out[nres][nsteps]: the inflow every reservoir received at every step (the reservoir rows of the
+ * reference's upstream_array, mc_reach.pyx:710).  D2H. */
+int trmc_download_reservoir_inflow(trmc_plan *plan, void *inflow_out);
+
+/*
  * Streamflow nudging at gages for the staged window.  Reference: simple_da
  * (src/troute-routing/troute/routing/fast_reach/simple_da.pyx:22-95) applied to the gage segment after
  * its reach has been routed for the timestep (mc_reach.pyx:761-796).  Which of simple_da's three

@@ -138,7 +138,7 @@ def wrf_segments(inputs):
 
 
 def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assume_short_ts,
-            prefilled=None, fvd_init=None, ref_name=None, return_iters=False, det=False, da=None):
+            prefilled=None, fvd_init=None, ref_name=None, return_iters=False, det=False, da=None, res=None):
     """Reference network loop (mc_reach.pyx:492-750 restated).
 
     reaches   : list of int arrays (row positions, upstream->downstream), list order
@@ -154,7 +154,7 @@ def network(nsteps, qts_subdivisions, reaches, upstreams, params, q0, qlat, assu
     up_ptr[1:] = np.cumsum([len(u) for u in upstreams])
     up_idx = (np.concatenate([np.asarray(u, dtype=np.int64) for u in upstreams] + [np.zeros(0, np.int64)]))
     return network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_idx, params, q0, qlat,
-                          assume_short_ts, prefilled, fvd_init, ref_name, return_iters, det, da)
+                          assume_short_ts, prefilled, fvd_init, ref_name, return_iters, det, da, res)
 
 
 class DA(C.Structure):
@@ -164,6 +164,27 @@ class DA(C.Structure):
                 ("decay_coeff", C.c_float), ("routing_period", C.c_float),
                 ("lastobs_time", C.POINTER(C.c_float)), ("lastobs_val", C.POINTER(C.c_float)),
                 ("nudge", C.POINTER(C.c_float))]
+
+
+class RES(C.Structure):
+    """mirror of res_t (float instantiations) in mc_oracle_impl.inc"""
+    _fields_ = [("nres", C.c_long), ("res_of_reach", C.POINTER(C.c_long)), ("par", C.POINTER(C.c_float)),
+                ("water_elevation", C.POINTER(C.c_float)), ("routing_period", C.c_float),
+                ("inflow_out", C.POINTER(C.c_float))]
+
+
+LP_PAR = ("area", "max_depth", "orifice_area", "orifice_coefficient", "orifice_elevation", "weir_coefficient",
+          "weir_elevation", "weir_length", "dam_length")
+
+
+def levelpool(inflow, dt, water_elevation, par, lateral=0.0):
+    """One routing period of the restated LEVELPOOL_PHYSICS (float32): (outflow, new water elevation)."""
+    par = np.ascontiguousarray(par, dtype=np.float32)
+    h = C.c_float(float(water_elevation))
+    fn = lib().mc_oracle_levelpool_flat_f32
+    fn.restype = C.c_float
+    q = fn(C.c_float(float(inflow)), C.c_float(float(lateral)), C.c_float(float(dt)), C.byref(h), _ptr(par, C.c_float))
+    return np.float32(q), np.float32(h.value)
 
 
 def simple_da(timestep, routing_period, decay_coeff, gage_maxtimestep, target, model, lastobs_time, lastobs_val):
@@ -184,8 +205,12 @@ def simple_da_with_decay(last_valid_obs, model_val, minutes, decay_coeff):
 
 def network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_idx, params, q0, qlat,
                    assume_short_ts, prefilled=None, fvd_init=None, ref_name=None, return_iters=False,
-                   det=False, da=None):
+                   det=False, da=None, res=None):
     """As network(), with the reach lists already flattened to CSR arrays (int64).
+
+    res (float32 only): dict(res_of_reach [nreach] (-1 = not a reservoir), par [nres, 9] (LP_PAR order),
+    water_elevation [nres], routing_period); on return also 'inflow' [nres, nsteps+1] and the final
+    water elevations (mc_reach.pyx:507-716, level-pool branch).
 
     da (float32 only): dict(usgs_values [ngage, nobs] (NaN = missing), gage_row [ngage], gage_of_reach
     [nreach] (-1 = none), decay_coeff, routing_period, lastobs_time [ngage], lastobs_val [ngage]); on
@@ -213,8 +238,25 @@ def network_arrays(nsteps, qts_subdivisions, reach_ptr, reach_seg, up_ptr, up_id
        _ptr(reach_ptr, C.c_long), _ptr(reach_seg, C.c_long), _ptr(up_ptr, C.c_long),
        _ptr(up_idx, C.c_long), _ptr(params, ct), _ptr(q0, ct), _ptr(qlat, ct),
        C.c_long(qlat.shape[1]), C.c_int(int(bool(assume_short_ts))),
-       None if pre is None else _ptr(pre, C.c_ubyte), _ptr(fvd, ct), ref, C.byref(iters), _da_struct(da, nsteps, dt))
+       None if pre is None else _ptr(pre, C.c_ubyte), _ptr(fvd, ct), ref, C.byref(iters), _da_struct(da, nsteps, dt),
+       _res_struct(res, nsteps, dt))
     return (fvd, iters.value) if return_iters else fvd
+
+
+def _res_struct(res, nsteps, dtype):
+    if res is None:
+        return None
+    if np.dtype(dtype) != np.float32:
+        raise ValueError("reservoirs are restated for float32 only")
+    res["res_of_reach"] = np.ascontiguousarray(res["res_of_reach"], dtype=np.int64)
+    res["par"] = np.ascontiguousarray(res["par"], dtype=np.float32)
+    res["water_elevation"] = np.array(res["water_elevation"], dtype=np.float32, copy=True)
+    nres = res["par"].shape[0]
+    res["inflow"] = np.zeros((nres, nsteps + 1), dtype=np.float32)
+    st = RES(nres, _ptr(res["res_of_reach"], C.c_long), _ptr(res["par"], C.c_float),
+             _ptr(res["water_elevation"], C.c_float), float(res["routing_period"]), _ptr(res["inflow"], C.c_float))
+    res["_struct"] = st
+    return C.byref(st)
 
 
 def _da_struct(da, nsteps, dtype):

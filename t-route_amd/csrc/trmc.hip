@@ -38,6 +38,7 @@
 #include "../../include/trmc.h"
 #include "det_pow.h"
 #include "mc_segment.hpp"
+#include "levelpool.hpp"
 #include "topology.hpp"
 
 namespace {
@@ -122,6 +123,12 @@ template <class T> struct StepArgs {
     const T *qlat_tm;
     T *q_tm, *v_tm, *d_tm;
     uint8_t *it_prev; // secant iterations each position needed on its previous step
+    // level-pool reservoirs (nullptr = none): reservoir index of a position, parameters [nres][9],
+    // inflow series [nres][nsteps] (the reference's upstream_array rows), routing period
+    const int32_t *res_of_pos;
+    const T *res_par;
+    T *res_inflow;
+    T res_dt;
     // streamflow nudging at gage positions (nullptr = off), tables [gage][nsteps], see trmc_set_nudging
     const int32_t *gage_of_pos;
     const uint8_t *da_mode;
@@ -269,6 +276,22 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         }
         f.qup = qup;
         f.quc = SHORT ? qup : quc;
+
+        if (a.res_of_pos) { // reference loop branch mc_reach.pyx:507-510,:551-553,:706-710
+            const int32_t ri = a.res_of_pos[s];
+            if (ri >= 0) {
+                const T *rp = a.res_par + (size_t)ri * 9;
+                const trmc::LevelPoolParams<T> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
+                T H = depthp; // a reservoir row keeps its water elevation in the depth slot
+                const T outflow = trmc::levelpool_step<T, M>(f.quc, T(0), a.res_dt, H, lp, m);
+                a.q_tm[row_c + s] = outflow;
+                a.v_tm[row_c + s] = T(0);
+                a.d_tm[row_c + s] = H;
+                a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
+                if (SORT) a.it_prev[s] = 0;
+                continue;
+            }
+        }
 
 #ifdef TRMC_EXPERIMENT_MEMONLY // timing experiment: all loads and stores, no arithmetic to speak of
         trmc::StepResult<T> r;
@@ -519,6 +542,9 @@ struct trmc_plan {
     DevBuf params; // 9 columns x nseg_pad
     DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev;
     DevBuf gage_of_pos, da_mode, da_a, da_w, da_nudge; // nudging tables of the staged window
+    DevBuf res_of_pos, res_par, res_inflow;             // level-pool reservoirs of the plan
+    int64_t nres = 0;
+    double res_dt = 0.0;
     int64_t ngage = 0;
     int32_t da_nsteps = -1;
     // per window
@@ -591,6 +617,10 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.level = (const int32_t *)pl->level.p;
     a.it_prev = (uint8_t *)pl->it_prev.p;
+    a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
+    a.res_par = (const T *)pl->res_par.p;
+    a.res_inflow = (T *)pl->res_inflow.p;
+    a.res_dt = (T)pl->res_dt;
     const bool da = pl->ngage > 0;
     a.gage_of_pos = da ? (const int32_t *)pl->gage_of_pos.p : nullptr;
     a.da_mode = (const uint8_t *)pl->da_mode.p;
@@ -641,6 +671,8 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
     if (int rc = pl->tm.ensure(3 * plane * sizeof(T))) return rc;
     if (int rc = pl->qlat_tm.ensure((size_t)pl->nq * np * sizeof(T))) return rc;
     if (int rc = pl->out.ensure((size_t)pl->nseg * nsteps * 3 * sizeof(T))) return rc;
+    if (pl->nres > 0)
+        if (int rc = pl->res_inflow.ensure((size_t)pl->nres * nsteps * sizeof(T))) return rc;
     StepArgs<T> a = step_args<T>(pl, nsteps, qts);
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
 
@@ -874,7 +906,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->gage_of_pos,
-                      &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge,
+                      &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
     for (auto &e : pl->ev)
@@ -956,6 +988,43 @@ int trmc_set_boundary_flow_device(trmc_plan *pl, int nsteps, const void *q_dev)
     HIP_TRY(hipStreamSynchronize(pl->stream));
     pl->have_boundary = true;
     pl->routed_nsteps = -1;
+    return 0;
+}
+
+int trmc_set_reservoirs(trmc_plan *pl, int64_t nres, const int64_t *res_rows, const void *par, double routing_period)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (nres < 0) return fail(TRMC_EINVAL, "nres < 0");
+    pl->nres = 0;
+    if (nres == 0) return 0;
+    if (!res_rows || !par) return fail(TRMC_EINVAL, "res_rows/par is NULL");
+    if (int rc = use_device(pl)) return rc;
+    std::vector<int32_t> r_of_pos((size_t)pl->nseg_pad, -1);
+    for (int64_t i = 0; i < nres; ++i) {
+        const int64_t r = res_rows[i];
+        if (r < 0 || r >= pl->nseg) return fail(TRMC_EINVAL, "reservoir row out of range");
+        if (pl->topo.level_of_row[r] < 0) return fail(TRMC_EINVAL, "reservoir on a boundary row");
+        if (r_of_pos[pl->topo.pos_of_row[r]] >= 0) return fail(TRMC_EINVAL, "two reservoirs on one row");
+        r_of_pos[pl->topo.pos_of_row[r]] = (int32_t)i;
+    }
+    if (int rc = upload_i32(pl->res_of_pos, r_of_pos, 1)) return rc;
+    const size_t bytes = (size_t)nres * 9 * pl->esz;
+    if (int rc = pl->res_par.ensure(bytes)) return rc;
+    HIP_TRY(hipMemcpy(pl->res_par.p, par, bytes, hipMemcpyHostToDevice));
+    pl->nres = nres;
+    pl->res_dt = routing_period;
+    pl->routed_nsteps = -1;
+    return 0;
+}
+
+int trmc_download_reservoir_inflow(trmc_plan *pl, void *inflow_out)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (pl->nres == 0) return 0;
+    if (!inflow_out) return fail(TRMC_EINVAL, "inflow_out is NULL");
+    if (int rc = use_device(pl)) return rc;
+    HIP_TRY(hipMemcpy(inflow_out, pl->res_inflow.p, (size_t)pl->nres * pl->routed_nsteps * pl->esz, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -53,6 +53,45 @@ def extract_connections(rows, target_col, terminal_codes=None):
     return network
 
 
+def extract_waterbody_connections(rows, target_col="waterbody", waterbody_null=-9999):
+    """{segment id: lake id} for segments lying inside a waterbody (nhd_network.py:55-78)."""
+    col = rows[target_col]
+    sel = col != waterbody_null
+    return {int(k): int(v) for k, v in zip(rows.index[sel].tolist(), col[sel].tolist())}
+
+
+def replace_waterbodies_connections(connections, waterbodies):
+    """Collapse every waterbody to ONE node named by its lake id (nhd_network.py:637-689).
+
+    connections  {segment: [downstream segments]};  waterbodies {segment: lake id}
+    Returns (new_conn, link_lake): the segments inside a waterbody disappear, the lake node drains to the
+    segments just outside the footprint, segments flowing into the footprint point at the lake id;
+    link_lake maps each lake id to one of its in-waterbody outlet segments."""
+    members = {}
+    for seg, lake in waterbodies.items():
+        members.setdefault(lake, []).append(seg)
+    new_conn, link_lake = {}, {}
+    for n, dsts in connections.items():
+        lake = waterbodies.get(n)
+        if lake is not None:
+            if lake in new_conn:
+                continue
+            inside = set(members[lake])
+            shore = []                                      # downstream neighbours outside the footprint
+            for m in members[lake]:
+                for d in connections.get(m, ()):
+                    if d not in inside and d not in shore:
+                        shore.append(d)
+            new_conn[lake] = shore
+            if shore:                                       # a member that drains to the first shore segment
+                link_lake[lake] = next(m for m in members[lake] if shore[0] in connections.get(m, ()))
+        elif any(d in waterbodies for d in dsts):
+            new_conn[n] = [waterbodies.get(d, d) for d in dsts]
+        else:
+            new_conn[n] = dsts
+    return new_conn, link_lake
+
+
 def reverse_network(N):
     """{node: [nodes that list it as a target]} -- sources keep the iteration order of N."""
     rg = {}

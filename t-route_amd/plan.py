@@ -121,6 +121,21 @@ class RoutingPlan:
         """Boundary rows' flow hydrographs from a device buffer [nboundary][nsteps] (plan precision)."""
         _lib.check(_lib.lib().trmc_set_boundary_flow_device(self._h, nsteps, C.c_void_p(device_ptr)))
 
+    def set_reservoirs(self, res_rows, par, routing_period):
+        """Level-pool reservoirs: rows [nres], parameters [nres, 9] (include/trmc.h trmc_set_reservoirs)."""
+        res_rows = np.ascontiguousarray(res_rows, dtype=np.int64)
+        par = np.ascontiguousarray(par, dtype=self.dtype)
+        if par.shape != (res_rows.shape[0], 9):
+            raise ValueError("reservoir parameters must be [nres, 9]")
+        self._nres = res_rows.shape[0]
+        _lib.check(_lib.lib().trmc_set_reservoirs(self._h, self._nres, _lib.ptr(res_rows), _lib.ptr(par),
+                                                  float(routing_period)))
+
+    def download_reservoir_inflow(self):
+        out = np.zeros((getattr(self, "_nres", 0), self._nsteps), dtype=self.dtype)
+        _lib.check(_lib.lib().trmc_download_reservoir_inflow(self._h, _lib.ptr(out)))
+        return out
+
     def set_nudging(self, nsteps, gage_rows, mode, a, w):
         """Nudging tables [ngage, nsteps] for the staged window (see include/trmc.h trmc_set_nudging)."""
         gage_rows = np.ascontiguousarray(gage_rows, dtype=np.int64)

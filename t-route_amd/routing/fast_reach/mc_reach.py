@@ -6,8 +6,9 @@ return of the reference's Cython function
 :811-845) and can be registered in the reference's ``_compute_func_map``
 (src/troute-routing/troute/routing/compute.py:21-26) -- see INTEGRATION.md.
 
-The MC branch and streamflow nudging at gages (simple_da, SURVEY 8f rank 1) are implemented;
-reservoir reaches (reach_type 1) raise NotImplementedError.  All arithmetic
+Implemented: the MC branch, streamflow nudging at gages (simple_da) and level-pool
+reservoir reaches (reach_type 1 with reservoir type 1).  Hybrid-persistence, RFC and
+Great Lakes reservoir data assimilation raise NotImplementedError.  All arithmetic
 runs in libtrmc.so on the GPU; there is no Python fallback.
 """
 import numpy as np
@@ -25,6 +26,8 @@ def binary_find(arr, els):
     els = np.asarray(list(els) if not isinstance(els, np.ndarray) else els, dtype=arr.dtype)
     if els.size == 0:
         return []
+    if arr.shape[0] == 0:
+        raise ValueError(f"element {els[0]} not found in {arr}")
     idx = np.searchsorted(arr, els)
     idx_c = np.minimum(idx, arr.shape[0] - 1)
     bad = arr[idx_c] != els
@@ -52,10 +55,8 @@ def _flatten_network(reaches_wTypes, upstream_connections, data_idx):
     flat = []
     starts = []
     for reach, reach_type in reaches_wTypes:
-        if reach_type == 1:
-            raise NotImplementedError(
-                "reservoir reaches (reach_type 1) are outside the Muskingum-Cunge hot path; "
-                "run MC-only (break_network_at_waterbodies: False)")
+        if reach_type == 1 and len(reach) != 1:
+            raise ValueError("a reservoir reach must be the single waterbody node")   # mc_reach.pyx:293
         starts.append(len(flat))
         flat.extend(reach)
         heads.append(reach[0])
@@ -182,6 +183,29 @@ def compute_network_structured(
     params = np.ascontiguousarray(np.asarray(data_values, dtype=np.float32)[:, column_mapper(list(data_cols))])
     up_ptr, up_idx, in_reach = _flatten_network(reaches_wTypes, upstream_connections, data_idx)
 
+    # ---- level-pool reservoirs (mc_reach.pyx:283-356): one-node reaches of type 1 ----------------------
+    res_rows, res_par, res_q0 = [], [], []
+    if any(rt == 1 for _, rt in reaches_wTypes):
+        wb = np.asarray(wbody_cols, dtype=np.float64)
+        rtypes = np.asarray(reservoir_types)
+        for reach, rt in reaches_wTypes:
+            if rt != 1:
+                continue
+            my_id = binary_find(data_idx, reach)[0]
+            wbody_index = binary_find(lake_numbers_col, reach)[0]
+            if reservoir_type_specified and rtypes.size and int(rtypes[wbody_index][0]) != 1:
+                raise NotImplementedError(
+                    f"waterbody {reach[0]}: reservoir type {int(rtypes[wbody_index][0])} (hybrid persistence / RFC "
+                    "forecast / Great Lakes data assimilation) is outside this engine; level pool (type 1) only")
+            a = wb[wbody_index].astype(np.float32)     # levelpool.pyx:63-73: area max_depth orifice_area
+            #   orifice_coefficient orifice_elevation weir_coefficient weir_elevation weir_length ifd (qd0) h0
+            h0 = a[10]
+            if h0 < np.float32(-900000000):              # cold start (levelpool_structs.c init_levelpool_reach)
+                h0 = np.float32(a[4] + np.float32(np.float32(a[1] - a[4]) * a[8]))
+            res_rows.append(my_id)
+            res_par.append([a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], np.float32(10.0)])  # dam_length = 10
+            res_q0.append((np.float32(wb[wbody_index, 9]), h0))
+
     # rows that carry a prescribed hydrograph: upstream_results (mc_reach.pyx:451-469);
     # rows in no reach at all stay zero in the reference -- prescribed zero hydrograph
     fill_index_mask = np.ones(nseg, dtype=bool)
@@ -190,6 +214,8 @@ def compute_network_structured(
     bvals = {}
     q0 = np.array(initial_conditions, dtype=dtype, copy=True)
     q0[boundary] = 0
+    for r, (qd0, h0) in zip(res_rows, res_q0):           # initial outflow (:297) and water elevation of the pool
+        q0[r] = (qd0, 0, h0)
     for _tw, tmp in upstream_results.items():
         fill_index = int(tmp["position_index"])
         fill_index_mask[fill_index] = False
@@ -242,6 +268,8 @@ def compute_network_structured(
 
     nudge = np.zeros((gages_size, nsteps + 1), dtype="float32")
     with RoutingPlan(up_ptr, up_idx, params, boundary if brow.size else None, precision, device) as plan:
+        if res_rows:
+            plan.set_reservoirs(res_rows, np.asarray(res_par, dtype=dtype), dt)
         plan.upload_forcing(nsteps, qlat_values, q0, boundary_fvd)
         if nudging is not None:
             plan.set_nudging(nsteps, nudging[0], nudging[1], nudging[2], nudging[3])
@@ -249,11 +277,15 @@ def compute_network_structured(
         fvd = plan.download_fvd()
         if nudging is not None:
             nudge[nudging[4], 1:] = plan.download_nudge()
+        res_inflow = plan.download_reservoir_inflow() if res_rows else None
         stats = plan.stats()
 
     out_dtype = np.float32 if precision == 32 else np.float64
     flowveldepth = fvd.reshape(nseg, nsteps * 3).astype(out_dtype, copy=False)[fill_index_mask]
-    upstream = np.zeros((nseg, nsteps), dtype="float32")[fill_index_mask]  # np.empty in the reference (:487)
+    upstream = np.zeros((nseg, nsteps), dtype="float32")  # np.empty in the reference (:487), reservoir rows filled (:710)
+    if res_rows:
+        upstream[res_rows] = res_inflow
+    upstream = upstream[fill_index_mask]
     t_end = nsteps * dt
     f32 = lambda a: np.asarray(a, dtype="float32")  # noqa: E731
     i32 = lambda a: np.asarray(a, dtype="int32")  # noqa: E731

@@ -292,6 +292,42 @@ def lowercolorado(nn):
     )
     print("lowercolorado: nseg", len(ids), "networks", len(tws), "reaches", len(reach_ptr) - 1)
 
+    # ---- waterbodies: LAKEPARM + NHDWaterbodyComID, reference graph collapse --------
+    wb = h5var(rl, "NHDWaterbodyComID", np.int32).astype(np.int64)[keep][order]
+    lp = f"{d}/domain/LAKEPARM.nc"
+    lake_id = h5var(lp, "lake_id", np.int32).astype(np.int64)
+    lcols = ["LkArea", "LkMxE", "OrificeA", "OrificeC", "OrificeE", "WeirC", "WeirE", "WeirL", "ifd"]
+    ltab = np.stack([h5var(lp, c, np.float64 if h5var(lp, c, np.uint8).size == 8 * lake_id.size else np.float32)
+                     for c in lcols], 1).astype(np.float64)
+    wbody_map = {int(s_): int(w) for s_, w in zip(ids, wb) if w != -9999}     # extract_waterbody_connections
+    present = np.array(sorted(set(wbody_map.values())), dtype=np.int64)
+    lsel = np.array([int(np.flatnonzero(lake_id == w)[0]) for w in present])   # first row per lake id
+    conn_wb, link_lake = nn.replace_waterbodies_connections(connections, wbody_map)
+    rconn_wb = nn.reverse_network(conn_wb)
+    ind_wb = nn.reachable_network(rconn_wb)
+    wbset = set(present.tolist())
+    wb_nodes, wb_to, wr_ptr, wr_ids, wr_tw = [], [], [0], [], []
+    for n_, dst in conn_wb.items():
+        wb_nodes.append(n_)
+        wb_to.append(dst[0] if dst else 0)
+        assert len(dst) <= 1
+    for tw, net in ind_wb.items():
+        rl_ = nn.dfs_decomposition(net, partial(nn.split_at_waterbodies_and_junctions, wbset, net))
+        for r_ in rl_:
+            wr_ids.extend(r_)
+            wr_ptr.append(len(wr_ids))
+            wr_tw.append(tw)
+    np.savez_compressed(
+        os.path.join(HERE, "lowercolorado_waterbodies.npz"),
+        seg_ids=ids, wb_of_seg=wb, lake_ids=present, lake_cols=np.array(lcols), lake_table=ltab[lsel],
+        ref_conn_nodes=np.array(wb_nodes, dtype=np.int64), ref_conn_to=np.array(wb_to, dtype=np.int64),
+        ref_link_lake_keys=np.array(list(link_lake.keys()), dtype=np.int64),
+        ref_link_lake_vals=np.array(list(link_lake.values()), dtype=np.int64),
+        ref_reach_ptr=np.array(wr_ptr, dtype=np.int64), ref_reach_ids=np.array(wr_ids, dtype=np.int64),
+        ref_reach_tw=np.array(wr_tw, dtype=np.int64))
+    print("waterbodies:", len(present), "lakes,", int((wb != -9999).sum()), "segments inside,",
+          len(wb_nodes), "nodes after collapse,", len(wr_ptr) - 1, "reaches")
+
     # ---- network goldens -----------------------------------------------------------------
     nseg = len(ids)
     row = {int(s): i for i, s in enumerate(ids)}

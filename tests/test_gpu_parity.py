@@ -315,8 +315,9 @@ def test_errors_match_reference(lc):
     with pytest.raises(ValueError, match="not found"):
         compute_network_structured(*a)
     a = base()
-    a[3] = [(lc.reaches[0], 1)] + a[3][1:]
-    with pytest.raises(NotImplementedError):
+    single = next(r for r in lc.reaches if len(r) == 1)
+    a[3] = [(r, 1 if r is single else 0) for r in lc.reaches]      # a "reservoir" that is in no lake table
+    with pytest.raises(ValueError, match="not found"):
         compute_network_structured(*a)
 
 
