@@ -160,5 +160,8 @@ def test_flatten_network_matches_reference_structs():
             assert up_idx[up_ptr[row[r[0]]]:up_ptr[row[r[0]] + 1]].tolist() == [row[u] for u in net[r[0]]]
             for a, b in zip(r[:-1], r[1:]):
                 assert up_idx[up_ptr[row[b]]:up_ptr[row[b] + 1]].tolist() == [row[a]]
-    with pytest.raises(NotImplementedError):
-        _flatten_network([([1], 1)], {}, np.array([1], np.int64))
+    # a reservoir reach is the single waterbody node (mc_reach.pyx:293)
+    up_ptr, up_idx, in_reach = _flatten_network([([1], 0), ([7], 1)], {7: [1]}, np.array([1, 7], np.int64))
+    assert up_idx[up_ptr[1]:up_ptr[2]].tolist() == [0] and in_reach.all()
+    with pytest.raises(ValueError, match="single waterbody node"):
+        _flatten_network([([1, 7], 1)], {}, np.array([1, 7], np.int64))
