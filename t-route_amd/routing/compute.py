@@ -18,15 +18,15 @@ What is different, on purpose (MI355X-first, SURVEY.md 8b "Threading"):
     result list (``cpu_pool`` and ``subnetwork_target_size`` are ignored).
   * the per-call argument preparation of the reference (pandas ``.loc`` slicing
     per network, compute.py:1399-1467) is done once for the whole table.
-Out of scope (raise NotImplementedError): reservoirs / waterbodies, gage
-nudging and every other data-assimilation input, the diffusive branch.
+Level-pool waterbodies (``waterbodies_df``, reservoir type 1) are routed; gage / reservoir
+data-assimilation DataFrames raise NotImplementedError here (the kernel callable
+``compute_network_structured`` accepts gage arrays directly), as does the diffusive branch.
 """
 from collections import defaultdict
 
 import numpy as np
 
 from .fast_reach.mc_reach import _KERNEL_COLS, compute_network_structured  # noqa: F401
-from ..plan import RoutingPlan, csr_from_lists
 
 _compute_func_map = defaultdict(
     lambda: compute_network_structured,
@@ -95,13 +95,13 @@ def compute_nhd_routing_v02(
     """
     if parallel_compute_method not in _PARALLEL_METHODS and parallel_compute_method is not None:
         raise ValueError(f"unknown parallel_compute_method {parallel_compute_method!r}")
-    for name, df in (("waterbodies_df", waterbodies_df), ("usgs_df", usgs_df), ("lastobs_df", lastobs_df),
+    for name, df in (("usgs_df", usgs_df), ("lastobs_df", lastobs_df),
                      ("reservoir_usgs_df", reservoir_usgs_df), ("reservoir_usace_df", reservoir_usace_df),
                      ("reservoir_rfc_df", reservoir_rfc_df), ("great_lakes_df", great_lakes_df)):
         if not _is_empty(df):
             raise NotImplementedError(
-                f"{name} is not empty: reservoirs and data assimilation are outside the Muskingum-Cunge "
-                "hot path of this engine (run MC-only: break_network_at_waterbodies False, DA off)")
+                f"{name} is not empty: gage / reservoir data-assimilation tables are not wired through this "
+                "driver (the kernel callable itself accepts gage arrays: compute_network_structured)")
     if flowveldepth_interorder:
         raise NotImplementedError("flowveldepth_interorder hand-off is only needed by the reference's "
                                   "sub-network orders; call compute_network_structured for that")
@@ -109,59 +109,64 @@ def compute_nhd_routing_v02(
     # compute.py:548-549
     param_df = param_df.copy()
     param_df["dt"] = dt
-    param_df = param_df.astype("float32").sort_index()
-    ids = param_df.index.values.astype("int64")
-    nseg = ids.shape[0]
-    params = np.ascontiguousarray(param_df[list(_KERNEL_COLS)].values, dtype=np.float32)
-    q0_v = np.ascontiguousarray(q0.loc[param_df.index].values, dtype=np.float32)
-    qlat_v = np.ascontiguousarray(qlats.loc[param_df.index].values, dtype=np.float32)
-    if qlat_v.shape[1] < nts / qts_subdivisions:
-        raise ValueError(
-            f"Number of columns (timesteps) in Qlat is incorrect: expected at most ({nseg}), got "
-            f"({qlat_v.shape[1]}). The number of columns in Qlat must be equal to or less than the number "
-            "of routing timesteps")
+    param_df = param_df.astype("float32")
+    cols = ["dt", "bw", "tw", "twcc", "dx", "n", "ncc", "cs", "s0"] + (["alt"] if "alt" in param_df.columns else [])
 
-    # one upstream list per row, reference order: head of reach <- independent_networks[tw][head],
-    # inside a reach <- previous segment (mc_reach.pyx:288-289, :133-138)
-    ups = [()] * nseg
-    owner = np.full(nseg, -1, dtype=np.int64)
+    # ---- one table for every network of the call (reference: one table per tailwater, compute.py:1399-1467)
     tws = list(reaches_bytw.keys())
-    flat_ids, flat_kind, head_lists = [], [], []
+    param_ids = set(param_df.index.tolist())
+    reaches_wTypes, reach_owner, upstream_connections = [], [], {}
+    seg_ids, lake_ids = [], []
     for k, tw in enumerate(tws):
-        net = independent_networks[tw]
+        upstream_connections.update(independent_networks[tw])
         for reach in reaches_bytw[tw]:
-            flat_ids.extend(reach)
-            flat_kind.extend([k] * len(reach))
-            head_lists.append((reach, net.get(reach[0], ())))
-    flat_ids = np.asarray(flat_ids, dtype=np.int64)
-    rows = np.searchsorted(ids, flat_ids)
-    if rows.size and ((rows >= nseg).any() or (ids[np.minimum(rows, nseg - 1)] != flat_ids).any()):
-        bad = flat_ids[(rows >= nseg) | (ids[np.minimum(rows, nseg - 1)] != flat_ids)][0]
-        raise ValueError(f"element {bad} not found in {ids}")
-    owner[rows] = np.asarray(flat_kind, dtype=np.int64)
-    row_of = dict(zip(flat_ids.tolist(), rows.tolist()))
-    pos = 0
-    for reach, head_ups in head_lists:
-        r0 = rows[pos]
-        lst = []
-        for u in head_ups:
-            if u not in row_of:
-                raise ValueError(f"element {u} not found in {ids}")
-            lst.append(row_of[u])
-        ups[r0] = lst
-        for j in range(1, len(reach)):
-            ups[rows[pos + j]] = (rows[pos + j - 1],)
-        pos += len(reach)
-    if (owner < 0).any():
-        raise ValueError("param_df contains segments that are in no reach of reaches_bytw")
+            is_wb = any(s not in param_ids for s in reach)          # _build_reach_type_list, compute.py:40-46
+            reaches_wTypes.append((list(reach), 1 if is_wb else 0))
+            reach_owner.append(k)
+            (lake_ids if is_wb else seg_ids).extend(reach)
+    have_wb = bool(lake_ids)
+    if have_wb and _is_empty(waterbodies_df):
+        raise ValueError("reaches contain waterbody nodes but waterbodies_df is empty")
+    lake_segs = sorted(lake_ids)
+    if have_wb:
+        missing = [l for l in lake_segs if l not in waterbodies_df.index]
+        if missing:
+            raise ValueError(f"element {missing[0]} not found in {list(waterbodies_df.index)}")
+        wb_cols = ["LkArea", "LkMxE", "OrificeA", "OrificeC", "OrificeE", "WeirC", "WeirE", "WeirL", "ifd", "qd0", "h0"]
+        waterbodies_sub = waterbodies_df.loc[lake_segs, wb_cols].values.astype("float64")       # compute.py:1421-1436
+        if not _is_empty(waterbody_types_df):
+            types_sub = waterbody_types_df.loc[lake_segs, ["reservoir_type"]].values.astype("int32")
+        else:
+            types_sub = np.zeros((0, 1), dtype="int32")
+    else:
+        waterbodies_sub = np.zeros((0, 0), dtype="float64")
+        types_sub = np.zeros((0, 0), dtype="int32")
 
-    up_ptr, up_idx = csr_from_lists(ups)
-    with RoutingPlan(up_ptr, up_idx, params, None, precision, device) as plan:
-        fvd = plan.route(nts, qts_subdivisions, assume_short_ts, qlat_v, q0_v)
-    fvd = fvd.reshape(nseg, nts * 3)
+    table = param_df.loc[sorted(seg_ids), cols].reindex(sorted(seg_ids) + lake_segs).sort_index()   # :1447-1465
+    ids = table.index.values.astype("int64")
+    nseg = ids.shape[0]
+    q0_v = q0.reindex(table.index).fillna(0.0).values.astype("float32")
+    qlat_v = qlats.reindex(table.index).fillna(0.0).values.astype("float32")
 
-    e_f1 = np.zeros(0, dtype="float32")
-    e_i1 = np.zeros(0, dtype="int32")
+    e_f2, e_f1, e_i1 = np.zeros((0, 0), "float32"), np.zeros(0, "float32"), np.zeros(0, "int32")
+    r = compute_network_structured(
+        nts, dt, qts_subdivisions, reaches_wTypes, upstream_connections, ids, table.columns.values,
+        table.values.astype("float32"), q0_v, qlat_v, lake_segs, waterbodies_sub, data_assimilation_parameters,
+        types_sub, bool(waterbody_type_specified),
+        t0.strftime('%Y-%m-%d_%H:%M:%S') if hasattr(t0, "strftime") else str(t0),
+        e_f2, e_i1, e_i1, e_i1, e_f1, e_f1, da_parameter_dict.get("da_decay_coefficient", 0) if da_parameter_dict else 0,
+        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
+        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
+        e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
+        e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
+        {}, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device)
+    fvd, upstream = r[1], r[6]
+
+    # ---- back to the reference's per-tailwater result list ---------------------------------------------
+    owner = np.full(nseg, -1, dtype=np.int64)
+    flat = np.fromiter((s for reach, _ in reaches_wTypes for s in reach), dtype=np.int64)
+    own = np.repeat(np.asarray(reach_owner, dtype=np.int64), [len(reach) for reach, _ in reaches_wTypes])
+    owner[np.searchsorted(ids, flat)] = own
     results = []
     for k in range(len(tws)):
         sel = np.flatnonzero(owner == k)
@@ -172,7 +177,7 @@ def compute_nhd_routing_v02(
             (np.asarray([], dtype=np.int64), np.full(0, np.nan, "float32"), np.full(0, np.nan, "float32")),
             (e_i1, e_f1, e_f1, e_f1, e_f1),
             (e_i1, e_f1, e_f1, e_f1, e_f1),
-            np.zeros((sel.shape[0], nts), dtype="float32"),
+            upstream[sel],
             (e_i1, e_f1, e_i1),
             np.zeros((0, nts + 1), dtype="float32"),
             (e_i1, e_f1, e_i1, e_i1),

@@ -140,3 +140,35 @@ def test_gpu_unsupported_reservoir_type_raises():
     args[14] = True
     with pytest.raises(NotImplementedError, match="reservoir type 2"):
         compute_network_structured(*args)
+
+
+@pytest.mark.gpu
+def test_gpu_compute_nhd_routing_v02_with_waterbodies():
+    """The top-level seam with break_network_at_waterbodies: DataFrames in, per-tailwater results out,
+    equal to the kernel callable's result for the same table."""
+    import pandas as pd
+    from troute_amd.routing.compute import compute_nhd_routing_v02
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+    lc, ids, dv, ql, q0, reaches, net, lakes, wbody_cols, lakeset, nts = reservoir_case(nts=48)
+    conn = {int(s): ([int(t)] if t != 0 else []) for s, t in zip(lc.ids, lc.to)}
+    wbody_map = {int(s): int(w) for s, w in zip(WB["seg_ids"], WB["wb_of_seg"]) if w != -9999}
+    conn_wb, _ = nn.replace_waterbodies_connections(conn, wbody_map)
+    ind, reaches_bytw, rconn = nn.organize_independent_networks(conn_wb, lakeset, set())
+    is_lake = np.isin(ids, lakes)
+    cols = list(lc.data_cols)
+    param_df = pd.DataFrame(dv[~is_lake], index=ids[~is_lake], columns=cols).drop(columns=["dt"])
+    q0_df = pd.DataFrame(q0[~is_lake], index=ids[~is_lake], columns=["qu0", "qd0", "h0"])
+    ql_df = pd.DataFrame(ql[~is_lake], index=ids[~is_lake])
+    wb_df = pd.DataFrame(wbody_cols, index=lakes, columns=["LkArea", "LkMxE", "OrificeA", "OrificeC", "OrificeE", "WeirC",
+                                                           "WeirE", "WeirL", "ifd", "qd0", "h0"])
+    e = pd.DataFrame()
+    res = compute_nhd_routing_v02(conn_wb, rconn, wbody_map, reaches_bytw, "V02-structured", "by-network", 10000, 4,
+                                  None, lc.dt, nts, lc.qts, ind, param_df, q0_df, ql_df, e, e, e, e, e, e, e, e, e, e, e,
+                                  {}, True, False, wb_df, {}, e, False, [{}, {}])
+    assert len(res) == 1 and np.array_equal(res[0][0], ids)
+    args = mc_only_args(nts, lc.dt, lc.qts, reaches, net, ids, lc.data_cols, dv, q0, ql, assume_short_ts=True)
+    args[3] = [(r, 1 if r[0] in lakeset else 0) for r in reaches]
+    args[10], args[11], args[13], args[14] = lakes.tolist(), wbody_cols, np.ones((len(lakes), 1), np.int32), False
+    want = compute_network_structured(*args)
+    assert np.array_equal(res[0][1].view(np.uint32), want[1].view(np.uint32))
+    assert np.array_equal(res[0][6], want[6])
