@@ -150,16 +150,22 @@ template <class T> struct StepArgs {
 // items by that class in LDS before touching anything else; wave-pass p then works on items
 // perm[p*256 + tid], which are of one class except at class boundaries.  Results do not depend on
 // the order items are visited in.
+#ifndef TRMC_STEP_BLOCK // threads per block of the step kernel = positions partitioned together (measured on MI355X,
+// CONUS: 64 -> 100.4 us per launch, 128 -> 97.2, 192 -> 99.1, 256 -> 100.2, 512 -> 115.5, 1024 -> 132: small blocks
+// free their wave slots sooner once the partition has made wave run times unequal)
+#define TRMC_STEP_BLOCK 128
+#endif
+constexpr int kStepBlock = TRMC_STEP_BLOCK;
 #ifndef TRMC_EXPERIMENT_WAVES
 #define TRMC_EXPERIMENT_WAVES 1
 #endif
 template <class T, bool SHORT, int IPT, bool SORT = true>
-__global__ void __launch_bounds__(kBlock, TRMC_EXPERIMENT_WAVES)
+__global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES)
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag)
 {
     using M = typename DevMath<T>::type;
-    constexpr int kChunk = IPT * kBlock;
-    constexpr int kWaves = kBlock / 64;
+    constexpr int kChunk = IPT * kStepBlock;
+    constexpr int kWaves = kStepBlock / 64;
     constexpr int kClasses = 5; // 0, 1, 2, 3+ iterations, and "nothing to do" (out of range)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ uint16_t s_perm[kChunk];
@@ -182,7 +188,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     int32_t cls[IPT], rank[IPT];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-        const int32_t s = base + j * kBlock + (int32_t)threadIdx.x;
+        const int32_t s = base + j * kStepBlock + (int32_t)threadIdx.x;
         int32_t c = kClasses - 1;
         if (s < s_end) {
             const int32_t t = SHORT ? diag : diag - a.level[s];
@@ -225,14 +231,14 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < IPT; ++j)
-        s_perm[s_cnt[cls[j]][j][wave] + rank[j]] = (uint16_t)(j * kBlock + (int32_t)threadIdx.x);
+        s_perm[s_cnt[cls[j]][j][wave] + rank[j]] = (uint16_t)(j * kStepBlock + (int32_t)threadIdx.x);
     __syncthreads();
     n_work = s_cnt[kClasses - 1][0][0]; // items of classes 0..3 come first
     }
 
     // ---- the segment steps, one class-sorted wave-pass at a time ---------------------------------
     for (int pass = 0; pass < IPT; ++pass) {
-        const int32_t w = pass * kBlock + (int32_t)threadIdx.x;
+        const int32_t w = pass * kStepBlock + (int32_t)threadIdx.x;
         if (w >= n_work) break;
         const int32_t s = base + (int32_t)s_perm[w];
         const int32_t t = SHORT ? diag : diag - a.level[s];
@@ -640,25 +646,19 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// wide slices: 4 items per thread (1024-position chunks sort better and still give > 8 blocks per CU);
-// narrow slices keep one item per thread so that every CU gets work
+// wide slices are class-partitioned per block; narrow slices (latency-bound) are not
+
 template <class T, bool SHORT>
 inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d)
 {
     const int64_t n = (int64_t)s1 - s0;
-    // measured on MI355X (CONUS, 2.73 M positions per launch): 1024-position chunks sort better (fewer
-    // VALU instructions) but run 14 % slower than 256-position chunks because four serial passes per
-    // block lengthen every block; kept selectable for experiments only
-#ifdef TRMC_EXPERIMENT_IPT4
-    if (n >= (int64_t)4 * kBlock * 256 * 4)
-#else
-    if (false)
-#endif
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 4>), dim3((unsigned)((n + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, st, a, s0, s1, d);
-    else if (n >= (int64_t)kBlock * 512)
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), dim3(blocks_for(n)), dim3(kBlock), 0, st, a, s0, s1, d);
+    // (1024-position chunks handled as four serial passes per block sort better -- fewer VALU
+    // instructions -- but measured 14 % slower on MI355X because every block gets four times longer;
+    // the kernel keeps its IPT parameter, the launcher uses one position per thread)
+    if (n >= (int64_t)kStepBlock * 512)
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), dim3((unsigned)((n + kStepBlock - 1) / kStepBlock)), dim3(kStepBlock), 0, st, a, s0, s1, d);
     else // fewer than two blocks per CU: latency-bound, skip the class partition
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), dim3(blocks_for(n)), dim3(kBlock), 0, st, a, s0, s1, d);
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), dim3((unsigned)((n + kStepBlock - 1) / kStepBlock)), dim3(kStepBlock), 0, st, a, s0, s1, d);
 }
 
 template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int short_ts)
