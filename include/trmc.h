@@ -124,7 +124,10 @@ int trmc_plan_levels(const trmc_plan *plan, int32_t *level_of_row, int64_t *plan
  * element type per the plan's precision.
  *   qlat          [nseg][nq]   lateral inflow per forcing interval
  *   q0            [nseg][3]    qu0 qd0 h0  (mc_reach.pyx:361: initial q = column
- *                              0, initial depth = column 2)
+ *                              0, initial depth = column 2); NULL = continue from the state
+ *                              the previous window left in HBM (the reference's new_q0 warm
+ *                              start between max_loop_size windows, AbstractNetwork.py:177-191,
+ *                              without the host round trip)
  *   boundary_fvd  [nboundary][nsteps][3] q,v,d hydrographs of the boundary rows
  *                 in ascending row order, or NULL when the plan has none
  */

@@ -947,7 +947,9 @@ int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq,
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
-    if (pl->nseg > 0 && (!qlat || !q0)) return fail(TRMC_EINVAL, "qlat/q0 is NULL");
+    if (pl->nseg > 0 && !qlat) return fail(TRMC_EINVAL, "qlat is NULL");
+    if (pl->nseg > 0 && !q0 && pl->routed_nsteps < 0)
+        return fail(TRMC_ESTATE, "q0 is NULL (continue from the resident state) but nothing has been routed yet");
     // boundary_fvd may be NULL here when trmc_set_boundary_flow_device() supplies the hydrographs later
     if (int rc = use_device(pl)) return rc;
     const size_t e = pl->esz;
@@ -955,7 +957,22 @@ int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq,
     if (int rc = pl->in_q0.ensure((size_t)pl->nseg * 3 * e)) return rc;
     if (pl->nseg > 0) {
         HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, (size_t)pl->nseg * nq * e, hipMemcpyHostToDevice, pl->stream));
-        HIP_TRY(hipMemcpyAsync(pl->in_q0.p, q0, (size_t)pl->nseg * 3 * e, hipMemcpyHostToDevice, pl->stream));
+        if (q0) {
+            HIP_TRY(hipMemcpyAsync(pl->in_q0.p, q0, (size_t)pl->nseg * 3 * e, hipMemcpyHostToDevice, pl->stream));
+        } else { // warm start in HBM: (q_T, q_T, depth_T) of the previous window, AbstractNetwork.py:182-190
+            const int32_t n = (int32_t)pl->nseg, T_ = pl->routed_nsteps;
+            const size_t plane = (size_t)(T_ + 1) * pl->nseg_pad;
+            if (pl->precision == 32) {
+                const float *q = (const float *)pl->tm.p;
+                hipLaunchKernelGGL((k_final_state<float>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
+                                   (const int32_t *)pl->row_of_pos.p, (float *)pl->in_q0.p, n, pl->nseg_pad, T_);
+            } else {
+                const double *q = (const double *)pl->tm.p;
+                hipLaunchKernelGGL((k_final_state<double>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
+                                   (const int32_t *)pl->row_of_pos.p, (double *)pl->in_q0.p, n, pl->nseg_pad, T_);
+            }
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (pl->topo.nboundary > 0 && boundary_fvd) {
         const size_t b = (size_t)pl->topo.nboundary * nsteps * 3 * e;

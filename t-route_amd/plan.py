@@ -103,11 +103,12 @@ class RoutingPlan:
     # -- one routing window -------------------------------------------------------------
     def upload_forcing(self, nsteps, qlat, q0, boundary_fvd=None):
         qlat = np.ascontiguousarray(qlat, dtype=self.dtype)
-        q0 = np.ascontiguousarray(q0, dtype=self.dtype)
         if qlat.ndim != 2 or qlat.shape[0] != self.nseg:
             raise ValueError(f"Number of rows in Qlat is incorrect: expected ({self.nseg}), got ({qlat.shape[0]})")
-        if q0.shape != (self.nseg, 3):
-            raise ValueError("initial_conditions shape mismatch")
+        if q0 is not None:                       # None: continue from the state resident in HBM
+            q0 = np.ascontiguousarray(q0, dtype=self.dtype)
+            if q0.shape != (self.nseg, 3):
+                raise ValueError("initial_conditions shape mismatch")
         bf = None
         if self.nboundary and boundary_fvd is not None:   # None: set_boundary_flow_device() follows
             bf = np.ascontiguousarray(boundary_fvd, dtype=self.dtype)

@@ -390,3 +390,23 @@ def test_conus_row_relabelling_invariance(conus):
         plan.route_device(nsteps, qts, False)
         b = plan.download_final_state()
     assert_bit_identical(a, b[perm], "relabelled CONUS")
+
+
+def test_resident_warm_start_between_windows(lc):
+    """Long runs are chunked into windows warm-started from new_q0 = fvd[:, [-3,-3,-1]]
+    (AbstractNetwork.py:177-191).  Keeping that state in HBM (q0 = None) is bit-identical to
+    downloading it and uploading it again, and two 144-step windows reproduce one 288-step window
+    when the forcing columns line up."""
+    from troute_amd.routing.fast_reach.mc_reach import _flatten_network
+    up_ptr, up_idx, _ = _flatten_network([(r, 0) for r in lc.reaches], lc.rconn, lc.ids)
+    for short in (True, False):
+        with RoutingPlan(up_ptr, up_idx, lc.params9) as plan:
+            whole = plan.route(288, 12, short, lc.qlat, lc.q0)
+            a1 = plan.route(144, 12, short, lc.qlat[:, :12], lc.q0)
+            state = plan.download_final_state()
+            plan.upload_forcing(144, lc.qlat[:, 12:24], None)          # resident warm start
+            plan.route_device(144, 12, short)
+            a2 = plan.download_fvd()
+            b2 = plan.route(144, 12, short, lc.qlat[:, 12:24], state)   # host round trip
+        assert_bit_identical(a2, b2, "resident vs re-uploaded warm start")
+        assert_bit_identical(np.concatenate([a1, a2], 1), whole, f"two windows vs one (short={short})")
