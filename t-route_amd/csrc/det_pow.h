@@ -134,9 +134,11 @@ TRMC_DP_FN double trmc_det_log2(float x, const uint64_t *tab)
 TRMC_DP_FN float trmc_det_powf_from_log(double L, float y, const uint64_t *tab)
 {
     const double ylogx = (double)y * L;
-    if (ylogx != ylogx) return trmc_sp_from_bits(0x7fc00000u);
-    if (ylogx > 0x1.fffffffd1d571p+6) return trmc_sp_from_bits(0x7f800000u); /* overflow */
-    if (ylogx <= -150.0) return 0.0f;                                        /* underflow */
+    if (!(__builtin_fabs(ylogx) < 126.0)) { /* one test on the common path; the three cases of e_powf.c behind it */
+        if (ylogx != ylogx) return trmc_sp_from_bits(0x7fc00000u);
+        if (ylogx > 0x1.fffffffd1d571p+6) return trmc_sp_from_bits(0x7f800000u); /* overflow */
+        if (ylogx <= -150.0) return 0.0f;                                        /* underflow */
+    }
     double kd = ylogx + 0x1.8p+47;            /* round to a multiple of 1/32 */
     const uint64_t ki = trmc_dp_bits(kd);
     kd -= 0x1.8p+47;

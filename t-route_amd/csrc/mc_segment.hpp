@@ -21,7 +21,9 @@
 // agrees; compile with -ffp-contract=off.
 //
 // Math policy M:  m.sqrt(x); m.pow(x, y); and, so that x**a and x**b can share
-// one logarithm, M::Log, m.log_of(x), m.pow_l(log_of(x), x, y) == m.pow(x, y).
+// one logarithm, M::Log, m.log_of(x), m.pow_l(log_of(x), x, y) == m.pow(x, y);
+// m.div4(n1, n2, n3, n4, d, q1, q2, q3, q4): qi = ni / d, the four correctly rounded quotients by one
+// divisor (the Muskingum coefficients) -- a policy may share the reciprocal between them.
 //
 // The header is host/device neutral on purpose: tests/host_harness.cpp
 // instantiates it with libm on the CPU to check the logic against the oracle
@@ -162,7 +164,7 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
 //   LOWER=true : "interval 2": X from the coefficients just left in `k`, clamp [0.25,0.5]
 template <class T, class M, bool LOWER>
 MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelParams<T> &p,
-                        const ChannelConst<T> &c, const Inflow<T> &f, MuskCoef<T> &k)
+                        const ChannelConst<T> &c, const Inflow<T> &f, MuskCoef<T> &k, const M &m)
 {
     const T km = hp.km;
     T x;
@@ -180,10 +182,8 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
     }
 
     const T d = (km * (T(1) - x) + c.half_dt);
-    k.C1 = (km * x + c.half_dt) / d;
-    k.C2 = (c.half_dt - km * x) / d;
-    k.C3 = (km * (T(1) - x) - c.half_dt) / d;
-    k.C4 = (f.ql * p.dt) / d;
+    m.div4(km * x + c.half_dt, c.half_dt - km * x, km * (T(1) - x) - c.half_dt, f.ql * p.dt, d,
+           k.C1, k.C2, k.C3, k.C4);
     k.X = x;
     if (LOWER) {
         const T w = (k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp);
@@ -243,9 +243,9 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
         int iter = 0;
         while (rerror > T(0.01) && aerror >= mindepth && iter <= maxiter) {
             const HydraulicPoint<T> at_h0 = carried ? at_h : hydraulics_at<T, M>(h_0, p, c, m);
-            qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k);
+            qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k, m);
             at_h = hydraulics_at<T, M>(h, p, c, m);
-            const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k);
+            const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k, m);
             T h_1;
             if (qj_0 - qj != T(0)) {
                 h_1 = h - ((qj * (h_0 - h)) / (qj_0 - qj));

@@ -63,6 +63,9 @@ int fail(int code, const std::string &msg)
 // fp32: the bit-reproducible power of det_pow.h (IEEE double + - * / fma only), so the
 // whole fp32 path is bit-comparable with the host oracle; sqrtf and / are the
 // correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+#ifndef TRMC_EXPERIMENT_DIV   // 0: one shared reciprocal for the four Muskingum coefficients (product).  1: plain divisions
+#define TRMC_EXPERIMENT_DIV 0
+#endif
 #ifndef TRMC_EXPERIMENT_POW   // 0: det_pow.h (product).  1: ocml powf, 2: hardware log/exp -- timing experiments only
 #define TRMC_EXPERIMENT_POW 0
 #endif
@@ -90,6 +93,57 @@ struct DevMathF {
     __device__ __forceinline__ float pow(float x, float y) const { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 #endif
     __device__ __forceinline__ float sqrt(float x) const { return ::sqrtf(x); }
+
+    // The four Muskingum coefficients C1..C4 = n_i / D (f90:303-312) with ONE reciprocal.
+    // hipcc expands an fp32 division into  v_div_scale x2, v_rcp, the refinement
+    //     y1 = fma(fma(-b, y0, 1), y0, y0);  q0 = a*y1;  q1 = fma(fma(-b, q0, a), y1, q0);
+    //     q  = div_fmas(fma(-b, q1, a), y1, q1)
+    // and v_div_fixup.  v_div_scale / v_div_fmas / v_div_fixup only act on operands that are zero,
+    // non-finite, subnormal or more than 2**96 apart, or on a subnormal quotient (CDNA3 ISA guide,
+    // V_DIV_SCALE_F32 / V_DIV_FIXUP_F32); otherwise they are the identity and the division IS the
+    // refinement above.  The kernel proves once per segment-step (`coef_ok`: dt in [2**-20, 2**40] and
+    // n4 = ql*dt either +0 or 2**-60 <= |n4| <= 2**60) and once per coefficient set (D <= 2**52) that
+    // all four divisions are of that kind: D >= dt/2 >= 2**-21; n1 = Km*X + dt/2 in [2**-21, 2**52];
+    // n2, n3 are differences of two such floats, hence +0 or of magnitude >= 2**-45; so no scaling,
+    // no fix-up, every quotient normal or +0 (for which the refinement returns +0 as IEEE does).  Then
+    // the same instructions are issued, minus the three helpers, and y1 once instead of four times:
+    // bit-identical by construction.  Anything else takes the plain divisions.
+#if TRMC_EXPERIMENT_DIV == 0
+    bool coef_ok;
+    __device__ __forceinline__ static float refined_quot(float a, float b, float y1)
+    {
+        const float q0 = a * y1;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y1, q0);
+        return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y1, q1);
+    }
+    __device__ __forceinline__ void div4(float n1, float n2, float n3, float n4, float d, float &q1, float &q2,
+                                         float &q3, float &q4) const
+    {
+        if (coef_ok && d <= 0x1p52f) {
+            const float y0 = __builtin_amdgcn_rcpf(d);
+            const float y1 = __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
+            q1 = refined_quot(n1, d, y1);
+            q2 = refined_quot(n2, d, y1);
+            q3 = refined_quot(n3, d, y1);
+            q4 = refined_quot(n4, d, y1);
+        } else {
+            q1 = n1 / d;
+            q2 = n2 / d;
+            q3 = n3 / d;
+            q4 = n4 / d;
+        }
+    }
+#else
+    bool coef_ok;
+    __device__ __forceinline__ void div4(float n1, float n2, float n3, float n4, float d, float &q1, float &q2,
+                                         float &q3, float &q4) const
+    {
+        q1 = n1 / d;
+        q2 = n2 / d;
+        q3 = n3 / d;
+        q4 = n4 / d;
+    }
+#endif
 };
 // fp64: device libm pow (about 1 ulp; not bit-reproducible against glibc)
 struct DevMathD {
@@ -99,6 +153,15 @@ struct DevMathD {
     __device__ __forceinline__ double pow_l(Log, double x, double y) const { return ::pow(x, y); }
     __device__ __forceinline__ double pow(double x, double y) const { return ::pow(x, y); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    bool coef_ok; // unused
+    __device__ __forceinline__ void div4(double n1, double n2, double n3, double n4, double d, double &q1, double &q2,
+                                         double &q3, double &q4) const
+    {
+        q1 = n1 / d;
+        q2 = n2 / d;
+        q3 = n3 / d;
+        q4 = n4 / d;
+    }
 };
 // every kernel that evaluates segment steps stages the 512-byte power tables into LDS first
 __device__ __forceinline__ const uint64_t *stage_pow_tables(uint64_t *s_tab)
@@ -107,11 +170,28 @@ __device__ __forceinline__ const uint64_t *stage_pow_tables(uint64_t *s_tab)
     __syncthreads();
     return s_tab;
 }
+// the once-per-segment-step part of DevMathF::div4's proof obligation (see there)
+__device__ __forceinline__ bool coef_guard(float dt, float ql)
+{
+    const float n4 = ql * dt, an4 = __builtin_fabsf(n4);
+    return (dt >= 0x1p-20f) && (dt <= 0x1p40f) && ((__float_as_uint(n4) == 0u) || (an4 >= 0x1p-60f && an4 <= 0x1p60f));
+}
+__device__ __forceinline__ bool coef_guard(double, double) { return false; }
 template <class T> struct DevMath;
 template <> struct DevMath<float> { using type = DevMathF; };
 template <> struct DevMath<double> { using type = DevMathD; };
 
 constexpr int kBlock = 256;
+
+// element of a column at a 32-bit BYTE offset from a (wave-uniform) base pointer
+template <class T> __device__ __forceinline__ T &at(T *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
+}
+template <class T> __device__ __forceinline__ const T &at(const T *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
 
 // ---------------------------------------------------------------- kernels
 template <class T> struct StepArgs {
@@ -170,7 +250,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ uint16_t s_perm[kChunk];
     __shared__ int32_t s_cnt[kClasses][IPT][kWaves];
-    const M m{stage_pow_tables(s_tab)};
+    M m{stage_pow_tables(s_tab), false};
 
     const int32_t base = s_begin + (int32_t)blockIdx.x * kChunk;
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -244,41 +324,50 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         const int32_t t = SHORT ? diag : diag - a.level[s];
         if (!SORT && (t < 1 || t > a.nsteps)) continue;
 
+        // 32-bit unsigned position: with uniform (SGPR) array bases every load below is
+        // `global_load v, v_off, s[base]` with ONE shared byte offset instead of a 64-bit add per array
+        const uint32_t su = (uint32_t)s;
+        uint32_t ob = su * (uint32_t)sizeof(T); // byte offset of position s in any T column (nseg_pad * 8 < 2**32)
         const size_t row_p = (size_t)(t - 1) * (size_t)a.nseg_pad; // previous time level
         const size_t row_c = (size_t)t * (size_t)a.nseg_pad;       // current time level
+        const T *const q_prev = a.q_tm + row_p;
+        const T *const q_curr = a.q_tm + row_c;
 
         trmc::ChannelParams<T> p;
-        p.dt = a.dt_col ? a.dt_col[s] : a.dt;
-        p.dx = a.dx[s];
-        p.bw = a.bw[s];
-        p.twcc = a.twcc[s];
-        p.n = a.n[s];
-        p.ncc = a.ncc[s];
-        p.s0 = a.s0[s];
+        p.dt = a.dt_col ? at(a.dt_col, ob) : a.dt;
+        // (the zero-extension of the offset has to be visible in the basic block of the loads for the
+        // SGPR-base addressing form to be selected: re-introduce it after every branch)
+        asm volatile("" : "+v"(ob));
+        p.dx = at(a.dx, ob);
+        p.bw = at(a.bw, ob);
+        p.twcc = at(a.twcc, ob);
+        p.n = at(a.n, ob);
+        p.ncc = at(a.ncc, ob);
+        p.s0 = at(a.s0, ob);
         p.tw = p.cs = T(0); // only enter the constants below
         trmc::ChannelConst<T> c;
-        c.z = a.z[s];
-        c.bfd = a.bfd[s];
-        c.sqrt_s0 = a.sqrt_s0[s];
-        c.sq1pz2 = a.sq1pz2[s];
-        c.s0_n = a.s0_n[s];
-        c.s0_ncc = a.s0_ncc[s];
+        c.z = at(a.z, ob);
+        c.bfd = at(a.bfd, ob);
+        c.sqrt_s0 = at(a.sqrt_s0, ob);
+        c.sq1pz2 = at(a.sq1pz2, ob);
+        c.s0_n = at(a.s0_n, ob);
+        c.s0_ncc = at(a.s0_ncc, ob);
         c.two_sq = T(2) * c.sq1pz2;
         c.half_dt = p.dt / T(2);
         c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
 
         trmc::Inflow<T> f;
-        f.qdp = a.q_tm[row_p + s];
-        const T depthp = a.d_tm[row_p + s];
-        f.ql = a.qlat_tm[(size_t)((t - 1) / a.qts) * (size_t)a.nseg_pad + s];
+        f.qdp = at(q_prev, ob);
+        const T depthp = at(a.d_tm + row_p, ob);
+        f.ql = at(a.qlat_tm + (size_t)((t - 1) / a.qts) * (size_t)a.nseg_pad, ob);
 
         // junction sums in the reference's order (mc_reach.pyx:499-502)
         T qup = T(0), quc = T(0);
-        const int32_t k0 = a.up_ptr[s], k1 = a.up_ptr[s + 1];
+        const int32_t k0 = a.up_ptr[su], k1 = a.up_ptr[su + 1];
         for (int32_t k = k0; k < k1; ++k) {
-            const int32_t u = a.up_idx[k];
-            qup += a.q_tm[row_p + u];
-            if (!SHORT) quc += a.q_tm[row_c + u];
+            const uint32_t ub = (uint32_t)a.up_idx[k] * (uint32_t)sizeof(T);
+            qup += at(q_prev, ub);
+            if (!SHORT) quc += at(q_curr, ub);
         }
         f.qup = qup;
         f.quc = SHORT ? qup : quc;
@@ -306,6 +395,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         r.depthc = c.s0_n + c.s0_ncc + p.s0 + depthp;
         r.iters = 0;
 #else
+        m.coef_ok = coef_guard(p.dt, f.ql);
         const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, c, f, depthp, m);
 #endif
         T q_new = r.qdc;
@@ -325,10 +415,11 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 a.da_nudge[e] = nudge;
             }
         }
-        a.q_tm[row_c + s] = q_new;
-        a.v_tm[row_c + s] = r.velc;
-        a.d_tm[row_c + s] = r.depthc;
-        if (SORT) a.it_prev[s] = (uint8_t)min(r.iters, 255);
+        asm volatile("" : "+v"(ob));
+        at(a.q_tm + row_c, ob) = q_new;
+        at(a.v_tm + row_c, ob) = r.velc;
+        at(a.d_tm + row_c, ob) = r.depthc;
+        if (SORT) a.it_prev[su] = (uint8_t)min(r.iters, 255);
     }
 }
 
@@ -343,7 +434,7 @@ k_make_const(T *cols, int32_t nseg, int64_t nseg_pad)
     using M = typename DevMath<T>::type;
     const int32_t s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= nseg) return;
-    const M m{nullptr}; // make_const uses sqrt and divide only, never the power tables
+    const M m{nullptr, false}; // make_const uses sqrt and divide only, never the power tables
     trmc::ChannelParams<T> p;
     p.dt = cols[(size_t)TRMC_P_DT * nseg_pad + s];
     p.dx = cols[(size_t)TRMC_P_DX * nseg_pad + s];
@@ -488,7 +579,7 @@ k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
 {
     using M = typename DevMath<T>::type;
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
-    const M m{stage_pow_tables(s_tab)};
+    M m{stage_pow_tables(s_tab), false};
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const T *x = in + i * 15;
@@ -498,6 +589,7 @@ k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
     p.dx = x[5]; p.bw = x[6]; p.tw = x[7]; p.twcc = x[8]; p.n = x[9]; p.ncc = x[10];
     p.cs = x[11]; p.s0 = x[12];
     const T depthp = x[14];
+    m.coef_ok = coef_guard(p.dt, f.ql);
     const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp, m);
     T ck, cn;
     const trmc::ChannelConst<T> c = trmc::make_const<T, M>(p, m);
