@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--nsteps", type=int, default=288)
     ap.add_argument("--qts", type=int, default=12)
     ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--chunks", type=int, default=None, help="time chunks of the multi-GPU hand-off pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-ts", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -154,12 +155,9 @@ def main():
     nseg = to.shape[0]
     q0 = np.zeros((nseg, 3), dtype=np.float32)
 
-    def all_gather_tensor(t):
-        """[world, *t.shape] over RCCL (xGMI); t has the same shape on every rank"""
-        import torch
-        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    def all_gather_into(out, t):
+        """out[world, *t.shape] <- every rank's t, over RCCL (xGMI), ordered against the current stream"""
         dist.all_gather_into_tensor(out, t)
-        return out
 
     t0 = time.perf_counter()
     router = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision)
@@ -172,7 +170,7 @@ def main():
 
     def route_once(short_ts):
         if use_dist:   # every hand-off stays in HBM: gather kernels -> RCCL all-gather -> boundary rows
-            return router.route_on_device(a.qts, short_ts, all_gather_tensor)
+            return router.route_on_device(a.qts, short_ts, all_gather_into, a.chunks)
         return router.route_resident(a.qts, short_ts), None   # outlet hydrographs stay in HBM
 
     def sync():

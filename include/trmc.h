@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 1
+#define TRMC_ABI_VERSION 2
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -189,12 +189,55 @@ int trmc_download_nudge(trmc_plan *plan, void *nudge_out);
  */
 int trmc_route_device(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_short_ts);
 
+/*
+ * The same window in parts, so that a caller can interleave other device work with it -- the multi-GPU
+ * hand-off: sub-basin outlet hydrographs leave for the trunk's owner one time chunk at a time while the
+ * later chunks are still being routed (reference: the ordered sub-network loop with its
+ * flowveldepth_interorder hand-off, compute.py:553-1209, here pipelined in time instead of serialised).
+ * Every call only queues work on the plan's stream (trmc_plan_stream) and returns; trmc_route_end waits.
+ *   trmc_route_begin     as trmc_route_device up to the first timestep; boundary hydrographs may still be
+ *                        missing (they then arrive through trmc_set_boundary_flow_range)
+ *   trmc_route_advance   queue the launches (done, t_end]; launch d = timestep d (of the rows without lag)
+ *   trmc_route_end       finish the result layout, wait, fill trmc_stats
+ * trmc_route_device == begin + advance(nsteps) + end.
+ */
+int trmc_route_begin(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_short_ts);
+int trmc_route_advance(trmc_plan *plan, int t_end);
+int trmc_route_end(trmc_plan *plan);
+/* The plan's HIP stream (hipStream_t as void*), for ordering foreign work (RCCL) against the plan's. */
+int trmc_plan_stream(trmc_plan *plan, void **stream_out);
+/* Register a set of rows once (their plan positions are kept in HBM); *id_out names it. */
+int trmc_rowset_create(trmc_plan *plan, const int64_t *rows, int64_t nrows, int32_t *id_out);
+/* Queue: dst_dev[i * dst_stride + (t - 1 - t_begin)] = flow of row i of the set at step t, t in (t_begin, t_end],
+ * all of which must already be queued (trmc_route_advance) or routed.  dst_dev is device memory. */
+int trmc_gather_flow_range(trmc_plan *plan, int32_t rowset, int t_begin, int t_end, void *dst_dev,
+                           int64_t dst_stride);
+/* Queue: boundary row b (ascending row order) takes flow q_dev[b * src_stride + (t - 1 - t_begin)] at the steps
+ * (t_begin, t_end]; ranges must be supplied in order, t_begin = end of the previous one (0 first). */
+int trmc_set_boundary_flow_range(trmc_plan *plan, int t_begin, int t_end, const void *q_dev, int64_t src_stride,
+                                 void *stream /* hipStream_t to queue the copy on; NULL = the plan's */);
+/*
+ * Time-skewed rows (assume_short_ts only).  lag_of_row[nseg] holds 0 or one common value L: launch d of the
+ * window routes the rows without lag at step d and the lagged rows at step d - L, so a window takes
+ * nsteps + L launches (trmc_route_advance counts launches).  Use: the trunk of a cut basin rides in the
+ * launches of this GPU's sub-basins L steps behind them, which gives the cut-edge hydrographs of the other
+ * GPUs L steps to arrive (boundary rows may feed lagged rows only) -- no launch of its own, no waiting.
+ * With assume_short_ts a row at step t reads its upstream rows at step t-1 only, which the skew preserves.
+ * NULL clears the lag.  Call before trmc_rowset_create.
+ */
+int trmc_plan_set_lag(trmc_plan *plan, const int32_t *lag_of_row);
+
 /* Full result, row order: fvd_out[nseg][nsteps][3] = (q, vel, depth) per step,
  * i.e. flowveldepth[:, 1:, :] of [R1] (mc_reach.pyx:807-813).  D2H. */
 int trmc_download_fvd(trmc_plan *plan, void *fvd_out);
 /* Final state in the reference's q0 layout, new_q0 = fvd[:, [-3,-3,-1]]
  * (AbstractNetwork.py:182-190): q0_out[nseg][3] = (q_T, q_T, depth_T).  D2H. */
 int trmc_download_final_state(trmc_plan *plan, void *q0_out);
+/* Convergence diagnostic: iters_out[nseg] = secant iterations (all retries together, capped at 255) each row
+ * spent on the LAST routed timestep (0 for boundary/reservoir rows and rows without flow; the reference
+ * does not report its count, MCsingleSegStime_f2py_NOLOOP.f90:83-134).  Rows of slices too narrow for
+ * the class partition keep 0.  D2H. */
+int trmc_download_iterations(trmc_plan *plan, uint8_t *iters_out);
 /* Flow hydrographs of selected rows (e.g. network outlets):
  * out[nrows][nsteps].  dst_is_device != 0: `out` is a device pointer on the
  * plan's device (used to hand outlet hydrographs to RCCL without a host trip). */

@@ -48,8 +48,17 @@ SIGNATURES = {
     "trmc_set_nudging": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp]),
     "trmc_download_nudge": (_int, [_vp, _vp]),
     "trmc_route_device": (_int, [_vp, _int, _int, _int]),
+    "trmc_route_begin": (_int, [_vp, _int, _int, _int]),
+    "trmc_route_advance": (_int, [_vp, _int]),
+    "trmc_route_end": (_int, [_vp]),
+    "trmc_plan_stream": (_int, [_vp, _P(_vp)]),
+    "trmc_rowset_create": (_int, [_vp, _vp, _i64, _P(_i32)]),
+    "trmc_gather_flow_range": (_int, [_vp, _i32, _int, _int, _vp, _i64]),
+    "trmc_set_boundary_flow_range": (_int, [_vp, _int, _int, _vp, _i64, _vp]),
+    "trmc_plan_set_lag": (_int, [_vp, _vp]),
     "trmc_download_fvd": (_int, [_vp, _vp]),
     "trmc_download_final_state": (_int, [_vp, _vp]),
+    "trmc_download_iterations": (_int, [_vp, _vp]),
     "trmc_gather_flow_rows": (_int, [_vp, _vp, _i64, _vp, _int]),
     "trmc_download_gathered": (_int, [_vp, _vp]),
     "trmc_get_stats": (_int, [_vp, _P(Stats)]),

@@ -200,6 +200,7 @@ template <class T> struct StepArgs {
     const T *dt_col; // nullptr -> uniform dt
     T dt;
     const int32_t *up_ptr, *up_idx, *level;
+    const int32_t *lag; // LAG form of the short-timestep kernel: position s is at step diag - lag[s]
     const T *qlat_tm;
     T *q_tm, *v_tm, *d_tm;
     uint8_t *it_prev; // secant iterations each position needed on its previous step
@@ -236,10 +237,13 @@ template <class T> struct StepArgs {
 #define TRMC_STEP_BLOCK 128
 #endif
 constexpr int kStepBlock = TRMC_STEP_BLOCK;
+#ifndef TRMC_EMIT_TILE // timesteps per overlapped transpose launch (a multiple of kEmitSteps)
+#define TRMC_EMIT_TILE 64
+#endif
 #ifndef TRMC_EXPERIMENT_WAVES
 #define TRMC_EXPERIMENT_WAVES 1
 #endif
-template <class T, bool SHORT, int IPT, bool SORT = true>
+template <class T, bool SHORT, int IPT, bool SORT = true, bool LAG = false>
 __global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES)
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag)
 {
@@ -271,7 +275,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         const int32_t s = base + j * kStepBlock + (int32_t)threadIdx.x;
         int32_t c = kClasses - 1;
         if (s < s_end) {
-            const int32_t t = SHORT ? diag : diag - a.level[s];
+            const int32_t t = SHORT ? (LAG ? diag - a.lag[s] : diag) : diag - a.level[s];
 #ifdef TRMC_EXPERIMENT_NOSORT // timing experiment: keep plan order
             if (t >= 1 && t <= a.nsteps) c = 0;
 #else
@@ -321,8 +325,8 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         const int32_t w = pass * kStepBlock + (int32_t)threadIdx.x;
         if (w >= n_work) break;
         const int32_t s = base + (int32_t)s_perm[w];
-        const int32_t t = SHORT ? diag : diag - a.level[s];
-        if (!SORT && (t < 1 || t > a.nsteps)) continue;
+        const int32_t t = SHORT ? (LAG ? diag - a.lag[s] : diag) : diag - a.level[s];
+        if ((!SORT || LAG) && (t < 1 || t > a.nsteps)) continue;
 
         // 32-bit unsigned position: with uniform (SGPR) array bases every load below is
         // `global_load v, v_off, s[base]` with ONE shared byte offset instead of a 64-bit add per array
@@ -572,6 +576,36 @@ k_gather_rows(const T *__restrict__ q_tm, const int32_t *__restrict__ pos, T *__
     out[i] = q_tm[(size_t)t * nseg_pad + pos[r]];
 }
 
+// flows of selected positions over the steps (t_begin, t_end]: out[r * stride + (t - 1 - t_begin)]
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_gather_range(const T *__restrict__ q_tm, const int32_t *__restrict__ pos, T *__restrict__ out, int64_t nrows,
+               int64_t nseg_pad, int32_t t_begin, int32_t t_end, int64_t stride)
+{
+    const int32_t w = t_end - t_begin;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrows * w) return;
+    const int64_t r = i / w;
+    const int32_t k = (int32_t)(i % w);
+    out[r * stride + k] = q_tm[(size_t)(t_begin + 1 + k) * nseg_pad + pos[r]];
+}
+
+// boundary positions (the first nboundary of the plan order) <- q[b * stride + (t - 1 - t_begin)], t in (t_begin, t_end]
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_fill_boundary_range(const T *__restrict__ q, T *q_tm, T *v_tm, T *d_tm, int32_t nboundary, int64_t nseg_pad,
+                      int32_t t_begin, int32_t t_end, int64_t stride)
+{
+    const int32_t w = t_end - t_begin;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)nboundary * w) return;
+    const int32_t b = (int32_t)(i / w), k = (int32_t)(i % w);
+    const size_t dst = (size_t)(t_begin + 1 + k) * nseg_pad + b;
+    q_tm[dst] = q[(size_t)b * stride + k];
+    v_tm[dst] = T(0);
+    d_tm[dst] = T(0);
+}
+
 // independent single-segment steps: in[n][15] -> out[n][6] (with courant), cf. reach.pyx:66-103
 template <class T>
 __global__ void __launch_bounds__(kBlock)
@@ -623,6 +657,15 @@ struct DevBuf {
 
 } // namespace
 
+struct RouteRun { // the routing window in progress (route_begin_t .. route_end_t)
+    bool active = false;
+    int32_t nsteps = 0, qts = 1, short_ts = 0;
+    int32_t t_done = 0;           // launches ("diagonals") 1..t_done are queued: rows without lag are at step t_done,
+                                  // lagged rows at step t_done - maxlag; the window ends at nsteps + maxlag
+    int32_t boundary_through = 0; // boundary rows hold their hydrographs for steps 1..boundary_through
+    int32_t tiles_done = 0, launches = 0;
+};
+
 struct trmc_plan {
     int device = 0;
     int precision = 32;
@@ -638,7 +681,9 @@ struct trmc_plan {
     hipEvent_t ev_emit = nullptr;        // "all tiles emitted" (stream2 -> main stream)
     // static, plan order
     DevBuf params; // 9 columns x nseg_pad
-    DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev;
+    DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev, lag;
+    int32_t maxlag = 0;                  // trmc_plan_set_lag: rows routed `maxlag` launches behind the others
+    std::vector<int32_t> lag_of_row;
     DevBuf gage_of_pos, da_mode, da_a, da_w, da_nudge; // nudging tables of the staged window
     DevBuf res_of_pos, res_par, res_inflow;             // level-pool reservoirs of the plan
     int64_t nres = 0;
@@ -653,6 +698,10 @@ struct trmc_plan {
     int32_t staged_nsteps = -1; // nsteps the staged forcing was uploaded for
     int32_t routed_nsteps = -1; // nsteps of the last completed route
     trmc_stats stats{};
+    RouteRun run;
+    std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
+    std::vector<int64_t> rowset_n;
+    std::vector<int32_t> rowset_lag;
 };
 
 namespace {
@@ -714,6 +763,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.level = (const int32_t *)pl->level.p;
+    a.lag = pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr;
     a.it_prev = (uint8_t *)pl->it_prev.p;
     a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
     a.res_par = (const T *)pl->res_par.p;
@@ -744,16 +794,53 @@ template <class T, bool SHORT>
 inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d)
 {
     const int64_t n = (int64_t)s1 - s0;
+    const dim3 grid((unsigned)((n + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
     // (1024-position chunks handled as four serial passes per block sort better -- fewer VALU
     // instructions -- but measured 14 % slower on MI355X because every block gets four times longer;
     // the kernel keeps its IPT parameter, the launcher uses one position per thread)
-    if (n >= (int64_t)kStepBlock * 512)
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), dim3((unsigned)((n + kStepBlock - 1) / kStepBlock)), dim3(kStepBlock), 0, st, a, s0, s1, d);
-    else // fewer than two blocks per CU: latency-bound, skip the class partition
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), dim3((unsigned)((n + kStepBlock - 1) / kStepBlock)), dim3(kStepBlock), 0, st, a, s0, s1, d);
+    const bool sort = n >= (int64_t)kStepBlock * 512; // fewer than two blocks per CU: latency-bound, skip the class partition
+    if (SHORT && a.lag) {
+        if (sort)
+            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, true, SHORT>), grid, block, 0, st, a, s0, s1, d);
+        else
+            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false, SHORT>), grid, block, 0, st, a, s0, s1, d);
+    } else if (sort)
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), grid, block, 0, st, a, s0, s1, d);
+    else
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), grid, block, 0, st, a, s0, s1, d);
 }
 
-template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int short_ts)
+// A routing window runs in three parts so that a caller can interleave other device work (the multi-GPU
+// hand-off of cut-edge hydrographs, distributed.py) with it, everything asynchronous on the plan's stream:
+//   route_begin_t    forcing transpose, initial state, boundary rows (if already staged)
+//   route_advance_t  the step launches for the timesteps (t_done, t_end]
+//   route_end_t      the rest of the result transpose, completion, timing
+template <class T> int emit_tiles_through(trmc_plan *pl, int32_t t_complete) // all steps <= t_complete are queued
+{
+    // The result transpose (memory-bound) runs on a second stream, one time tile at a time, as soon as the
+    // launches that complete the tile have been queued: it overlaps with the VALU-bound step kernels
+    // instead of trailing them.
+    constexpr int32_t kTile = TRMC_EMIT_TILE;
+    RouteRun &r = pl->run;
+    const int32_t n = (int32_t)pl->nseg, nsteps = r.nsteps;
+    const int32_t ntiles = (nsteps + kTile - 1) / kTile;
+    const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
+    const T *q_tm = (const T *)pl->tm.p;
+    while (r.tiles_done < ntiles && ((r.tiles_done + 1) * kTile <= t_complete || t_complete >= nsteps)) {
+        HIP_TRY(hipEventRecord(pl->tile_ev[r.tiles_done], pl->stream));
+        HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->tile_ev[r.tiles_done], 0));
+        if (n > 0) {
+            const int32_t tb = r.tiles_done * kTile, te = min(nsteps, tb + kTile);
+            hipLaunchKernelGGL((k_emit<T>), dim3((n + 63) / 64, (unsigned)((te - tb + kEmitSteps - 1) / kEmitSteps)),
+                               dim3(kBlock), 0, pl->stream2, q_tm, q_tm + plane, q_tm + 2 * plane,
+                               (const int32_t *)pl->row_of_pos.p, (T *)pl->out.p, n, pl->nseg_pad, nsteps, tb, te);
+        }
+        ++r.tiles_done;
+    }
+    return 0;
+}
+
+template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int short_ts)
 {
     const trmc::Topology &tp = pl->topo;
     const int32_t n = (int32_t)pl->nseg;
@@ -767,6 +854,13 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
         if (int rc = pl->res_inflow.ensure((size_t)pl->nres * nsteps * sizeof(T))) return rc;
     StepArgs<T> a = step_args<T>(pl, nsteps, qts);
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
+    constexpr int32_t kTile = TRMC_EMIT_TILE;
+    const int32_t ntiles = (nsteps + kTile - 1) / kTile;
+    while ((int32_t)pl->tile_ev.size() < ntiles) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pl->tile_ev.push_back(e);
+    }
 
     HIP_TRY(hipEventRecord(pl->ev[0], st));
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st)); // no history at the start of a window
@@ -779,64 +873,74 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
         hipLaunchKernelGGL((k_init_state<T>), dim3(blocks_for(n)), dim3(kBlock), 0, st, (const T *)pl->in_q0.p,
                            row_of_pos, a.q_tm, a.v_tm, a.d_tm, n);
     }
-    if (tp.nboundary > 0)
+    RouteRun &r = pl->run;
+    r = RouteRun{};
+    r.active = true;
+    r.nsteps = nsteps;
+    r.qts = qts;
+    r.short_ts = short_ts ? 1 : 0;
+    r.boundary_through = tp.nboundary > 0 ? 0 : nsteps;
+    if (tp.nboundary > 0 && pl->have_boundary) {
         hipLaunchKernelGGL((k_fill_boundary<T>), dim3(blocks_for(tp.nboundary * (int64_t)nsteps)), dim3(kBlock), 0, st,
                            (const T *)pl->in_bfvd.p, a.q_tm, a.v_tm, a.d_tm, (int32_t)tp.nboundary, nsteps, np);
-    HIP_TRY(hipEventRecord(pl->ev[1], st));
-
-    // The result transpose (memory-bound) runs on a second stream, one 64-step time tile at a time,
-    // as soon as the launches that complete the tile have been queued: it overlaps with the
-    // VALU-bound step kernels instead of trailing them.
-    const int32_t ntiles = (nsteps + 63) / 64;
-    while ((int32_t)pl->tile_ev.size() < ntiles) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        pl->tile_ev.push_back(e);
+        r.boundary_through = nsteps;
     }
-    int32_t tiles_done = 0;
-    auto emit_tiles_through = [&](int32_t t_complete) -> int { // all steps <= t_complete are queued on st
-        while (tiles_done < ntiles && ((tiles_done + 1) * 64 <= t_complete || t_complete >= nsteps)) {
-            HIP_TRY(hipEventRecord(pl->tile_ev[tiles_done], st));
-            HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->tile_ev[tiles_done], 0));
-            if (n > 0) {
-                const int32_t tb = tiles_done * 64, te = min(nsteps, tb + 64);
-                hipLaunchKernelGGL((k_emit<T>), dim3((n + 63) / 64, (unsigned)((te - tb + kEmitSteps - 1) / kEmitSteps)),
-                                   dim3(kBlock), 0, pl->stream2, a.q_tm, a.v_tm, a.d_tm, row_of_pos, (T *)pl->out.p, n,
-                                   np, nsteps, tb, te);
-            }
-            ++tiles_done;
-        }
-        return 0;
-    };
+    HIP_TRY(hipEventRecord(pl->ev[1], st));
+    HIP_TRY(hipGetLastError());
+    pl->routed_nsteps = -1;
+    return 0;
+}
 
-    int32_t launches = 0;
+template <class T> int route_advance_t(trmc_plan *pl, int t_end)
+{
+    const trmc::Topology &tp = pl->topo;
+    RouteRun &r = pl->run;
+    constexpr int32_t kTile = TRMC_EMIT_TILE;
+    const int32_t nsteps = r.nsteps, t0 = r.t_done;
+    StepArgs<T> a = step_args<T>(pl, nsteps, r.qts);
+    hipStream_t st = pl->stream;
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
-        if (short_ts) {
+        if (r.short_ts) {
             const int32_t s0 = tp.lvl_ptr[0], s1 = tp.lvl_ptr[L];
-            for (int32_t t = 1; t <= nsteps; ++t) {
+            const int32_t lagmax = pl->maxlag;
+            for (int32_t t = t0 + 1; t <= t_end; ++t) { // launch t: rows at step t, lagged rows at step t - lagmax
                 launch_step<T, true>(st, a, s0, s1, t);
-                ++launches;
-                if (t % 64 == 0 && t < nsteps)
-                    if (int rc = emit_tiles_through(t)) return rc;
+                ++r.launches;
+                const int32_t t_all = t - lagmax; // every row has reached step t_all
+                if (t_all > 0 && t_all % kTile == 0 && t_all < nsteps)
+                    if (int rc = emit_tiles_through<T>(pl, t_all)) return rc;
             }
         } else {
-            for (int32_t d = 1; d <= L - 1 + nsteps; ++d) {
-                const int32_t lo = d - nsteps > 0 ? d - nsteps : 0;
+            // level wavefront over the window (t0, t_end]: diagonal d runs (level l, step t0 + d - l)
+            const int32_t W = t_end - t0;
+            for (int32_t d = 1; d <= L - 1 + W; ++d) {
+                const int32_t lo = d - W > 0 ? d - W : 0;
                 const int32_t hi = d - 1 < L - 1 ? d - 1 : L - 1;
                 const int32_t s0 = tp.lvl_ptr[lo], s1 = tp.lvl_ptr[hi + 1];
                 if (s1 > s0) {
-                    launch_step<T, false>(st, a, s0, s1, d);
-                    ++launches;
+                    launch_step<T, false>(st, a, s0, s1, t0 + d);
+                    ++r.launches;
                 }
-                const int32_t t_done = d - (L - 1); // every level has reached step t_done
-                if (t_done > 0 && t_done % 64 == 0 && t_done < nsteps)
-                    if (int rc = emit_tiles_through(t_done)) return rc;
+                const int32_t t_all = t0 + d - (L - 1); // every level has reached step t_all
+                if (t_all > t0 && t_all % kTile == 0 && t_all < nsteps)
+                    if (int rc = emit_tiles_through<T>(pl, t_all)) return rc;
             }
         }
     }
+    HIP_TRY(hipGetLastError());
+    r.t_done = t_end;
+    return 0;
+}
+
+template <class T> int route_end_t(trmc_plan *pl)
+{
+    const trmc::Topology &tp = pl->topo;
+    RouteRun &r = pl->run;
+    hipStream_t st = pl->stream;
+    const int32_t nsteps = r.nsteps;
     HIP_TRY(hipEventRecord(pl->ev[2], st));
-    if (int rc = emit_tiles_through(nsteps)) return rc; // whatever is left (at least the last tile)
+    if (int rc = emit_tiles_through<T>(pl, nsteps)) return rc; // whatever is left (at least the last tile)
     HIP_TRY(hipEventRecord(pl->ev_emit, pl->stream2));
     HIP_TRY(hipStreamWaitEvent(st, pl->ev_emit, 0));
     HIP_TRY(hipEventRecord(pl->ev[3], st));
@@ -852,14 +956,15 @@ template <class T> int route_device_t(trmc_plan *pl, int nsteps, int qts, int sh
     s.nseg_routed = pl->nrouted;
     s.nlevels = tp.nlevels;
     s.nsteps = nsteps;
-    s.assume_short_ts = short_ts ? 1 : 0;
-    s.main_launches = launches;
+    s.assume_short_ts = r.short_ts;
+    s.main_launches = r.launches;
     s.segment_steps = pl->nrouted * (int64_t)nsteps;
     s.ms_prep = ms01;
     s.ms_main = ms12;
     s.ms_emit = ms23;
     s.ms_total = (double)ms01 + ms12 + ms23;
     pl->routed_nsteps = nsteps;
+    r.active = false;
     return 0;
 }
 
@@ -997,7 +1102,8 @@ void trmc_plan_destroy(trmc_plan *pl)
 {
     if (!pl) return;
     (void)hipSetDevice(pl->device);
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->gage_of_pos,
+    for (DevBuf &b : pl->rowsets) b.release();
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->lag, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
@@ -1181,23 +1287,210 @@ int trmc_download_nudge(trmc_plan *pl, void *nudge_out)
     return 0;
 }
 
-int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts)
+static int route_check(trmc_plan *pl, int nsteps, int qts_subdivisions, bool boundary_later)
 {
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
-    if (pl->staged_nsteps < 0) return fail(TRMC_ESTATE, "trmc_upload_forcing must precede trmc_route_device");
+    if (pl->staged_nsteps < 0) return fail(TRMC_ESTATE, "trmc_upload_forcing must precede routing");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is already in progress (trmc_route_end it first)");
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (qts_subdivisions < 1) return fail(TRMC_EINVAL, "qts_subdivisions must be >= 1");
     if (pl->topo.nboundary > 0 && nsteps != pl->staged_nsteps)
         return fail(TRMC_EINVAL, "nsteps differs from the staged boundary hydrographs");
-    if (!pl->have_boundary) return fail(TRMC_ESTATE, "plan has boundary rows but no boundary hydrographs were supplied");
+    if (!pl->have_boundary && !boundary_later)
+        return fail(TRMC_ESTATE, "plan has boundary rows but no boundary hydrographs were supplied");
     if (pl->ngage > 0 && pl->da_nsteps != nsteps) return fail(TRMC_EINVAL, "nudging tables were set for a different nsteps");
     // the reference's precondition, mc_reach.pyx:246-247
     if ((int64_t)(nsteps - 1) / qts_subdivisions >= pl->nq)
         return fail(TRMC_EINVAL, "Number of columns (timesteps) in Qlat is incorrect: need "
                                      + std::to_string((nsteps - 1) / qts_subdivisions + 1) + ", got " + std::to_string(pl->nq));
+    return use_device(pl);
+}
+
+static int lag_check(trmc_plan *pl, int assume_short_ts)
+{
+    if (pl->maxlag > 0 && !assume_short_ts)
+        return fail(TRMC_EINVAL, "a plan with lagged rows (trmc_plan_set_lag) routes with assume_short_ts only");
+    return 0;
+}
+
+int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts)
+{
+    if (int rc = route_check(pl, nsteps, qts_subdivisions, false)) return rc;
+    if (int rc = lag_check(pl, assume_short_ts)) return rc;
+    const bool f = pl->precision == 32;
+    int rc = f ? route_begin_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
+               : route_begin_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
+    const int t_last = nsteps + (assume_short_ts ? pl->maxlag : 0);
+    if (!rc) rc = f ? route_advance_t<float>(pl, t_last) : route_advance_t<double>(pl, t_last);
+    if (!rc) rc = f ? route_end_t<float>(pl) : route_end_t<double>(pl);
+    if (rc) pl->run.active = false;
+    return rc;
+}
+
+int trmc_route_begin(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts)
+{
+    if (int rc = route_check(pl, nsteps, qts_subdivisions, true)) return rc;
+    if (int rc = lag_check(pl, assume_short_ts)) return rc;
+    const int rc = pl->precision == 32 ? route_begin_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
+                                       : route_begin_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
+    if (rc) pl->run.active = false;
+    return rc;
+}
+
+int trmc_route_advance(trmc_plan *pl, int t_end)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (!pl->run.active) return fail(TRMC_ESTATE, "trmc_route_begin must precede trmc_route_advance");
+    const int32_t lagmax = pl->run.short_ts ? pl->maxlag : 0;
+    if (t_end < pl->run.t_done || t_end > pl->run.nsteps + lagmax)
+        return fail(TRMC_EINVAL, "t_end outside [launches done, nsteps + lag]");
+    // boundary rows feed the lagged rows when the plan has a lag (trmc_plan_set_lag), all rows otherwise
+    const int32_t need = t_end - lagmax < pl->run.nsteps ? t_end - lagmax : pl->run.nsteps;
+    if (need > pl->run.boundary_through)
+        return fail(TRMC_ESTATE, "boundary hydrographs are staged through step " + std::to_string(pl->run.boundary_through)
+                                     + " only (trmc_set_boundary_flow_range)");
+    if (t_end == pl->run.t_done) return 0;
     if (int rc = use_device(pl)) return rc;
-    return pl->precision == 32 ? route_device_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
-                               : route_device_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
+    return pl->precision == 32 ? route_advance_t<float>(pl, t_end) : route_advance_t<double>(pl, t_end);
+}
+
+int trmc_route_end(trmc_plan *pl)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (!pl->run.active) return fail(TRMC_ESTATE, "no routing window in progress");
+    if (pl->run.t_done != pl->run.nsteps + (pl->run.short_ts ? pl->maxlag : 0)) {
+        // abandon the window: drain the queue so the plan can be reused
+        (void)hipStreamSynchronize(pl->stream);
+        (void)hipStreamSynchronize(pl->stream2);
+        pl->run.active = false;
+        return fail(TRMC_ESTATE, "trmc_route_end before every timestep was queued; window abandoned");
+    }
+    if (int rc = use_device(pl)) return rc;
+    const int rc = pl->precision == 32 ? route_end_t<float>(pl) : route_end_t<double>(pl);
+    if (rc) pl->run.active = false;
+    return rc;
+}
+
+int trmc_plan_stream(trmc_plan *pl, void **stream_out)
+{
+    if (!pl || !stream_out) return fail(TRMC_EINVAL, "plan/stream_out is NULL");
+    *stream_out = (void *)pl->stream;
+    return 0;
+}
+
+int trmc_plan_set_lag(trmc_plan *pl, const int32_t *lag_of_row)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
+    if (!pl->rowsets.empty()) return fail(TRMC_ESTATE, "set the lag before registering row sets");
+    pl->maxlag = 0;
+    pl->lag_of_row.clear();
+    if (!lag_of_row) return 0;
+    int32_t mx = 0;
+    for (int64_t r = 0; r < pl->nseg; ++r) {
+        if (lag_of_row[r] < 0) return fail(TRMC_EINVAL, "negative lag");
+        mx = std::max(mx, lag_of_row[r]);
+    }
+    if (mx == 0) return 0;
+    // two classes only: in step, or `mx` launches behind; an upstream neighbour is never behind its consumer
+    std::vector<int32_t> by_pos((size_t)pl->nseg_pad, 0);
+    for (int64_t r = 0; r < pl->nseg; ++r) {
+        if (lag_of_row[r] != 0 && lag_of_row[r] != mx) return fail(TRMC_EINVAL, "lag must be 0 or one common value");
+        by_pos[(size_t)pl->topo.pos_of_row[r]] = lag_of_row[r];
+    }
+    for (int64_t p = pl->topo.nboundary; p < pl->nseg; ++p)
+        for (int32_t k = pl->topo.up_ptr[p]; k < pl->topo.up_ptr[p + 1]; ++k) {
+            const int32_t u = pl->topo.up_idx[k];
+            if (u >= pl->topo.nboundary && by_pos[(size_t)u] > by_pos[(size_t)p])
+                return fail(TRMC_EINVAL, "a lagged row feeds a row that is not lagged");
+            if (u < pl->topo.nboundary && by_pos[(size_t)p] != mx)
+                return fail(TRMC_EINVAL, "with a lag, boundary rows may only feed lagged rows");
+        }
+    if (int rc = use_device(pl)) return rc;
+    if (int rc = pl->lag.ensure((size_t)pl->nseg_pad * sizeof(int32_t))) return rc;
+    HIP_TRY(hipMemcpy(pl->lag.p, by_pos.data(), (size_t)pl->nseg_pad * sizeof(int32_t), hipMemcpyHostToDevice));
+    pl->lag_of_row.assign(lag_of_row, lag_of_row + pl->nseg);
+    pl->maxlag = mx;
+    return 0;
+}
+
+int trmc_rowset_create(trmc_plan *pl, const int64_t *rows, int64_t nrows, int32_t *id_out)
+{
+    if (!pl || !id_out) return fail(TRMC_EINVAL, "plan/id_out is NULL");
+    if (nrows < 0 || (nrows > 0 && !rows)) return fail(TRMC_EINVAL, "rows is NULL");
+    if (int rc = use_device(pl)) return rc;
+    std::vector<int32_t> pos((size_t)nrows);
+    for (int64_t i = 0; i < nrows; ++i) {
+        if (rows[i] < 0 || rows[i] >= pl->nseg) return fail(TRMC_EINVAL, "row out of range");
+        pos[i] = pl->topo.pos_of_row[rows[i]];
+    }
+    DevBuf b;
+    if (int rc = b.ensure((size_t)(nrows > 0 ? nrows : 1) * sizeof(int32_t))) return rc;
+    if (nrows > 0) HIP_TRY(hipMemcpy(b.p, pos.data(), (size_t)nrows * sizeof(int32_t), hipMemcpyHostToDevice));
+    int32_t rs_lag = 0; // a set with lagged rows is complete `maxlag` launches later
+    if (pl->maxlag > 0)
+        for (int64_t i = 0; i < nrows; ++i) rs_lag = std::max(rs_lag, pl->lag_of_row[(size_t)rows[i]]);
+    pl->rowsets.push_back(b);
+    pl->rowset_n.push_back(nrows);
+    pl->rowset_lag.push_back(rs_lag);
+    *id_out = (int32_t)pl->rowsets.size() - 1;
+    return 0;
+}
+
+int trmc_gather_flow_range(trmc_plan *pl, int32_t rowset, int t_begin, int t_end, void *dst_dev, int64_t dst_stride)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (rowset < 0 || rowset >= (int32_t)pl->rowsets.size()) return fail(TRMC_EINVAL, "unknown row set");
+    const int32_t through = pl->run.active ? std::min(pl->run.nsteps, pl->run.t_done - (pl->run.short_ts ? pl->rowset_lag[rowset] : 0))
+                                           : pl->routed_nsteps;
+    if (t_begin < 0 || t_end < t_begin || t_end > through)
+        return fail(TRMC_ESTATE, "steps (t_begin, t_end] are not all routed yet");
+    const int64_t nrows = pl->rowset_n[rowset];
+    if (nrows == 0 || t_end == t_begin) return 0;
+    if (!dst_dev || dst_stride < t_end - t_begin) return fail(TRMC_EINVAL, "dst_dev is NULL or dst_stride too small");
+    if (int rc = use_device(pl)) return rc;
+    const int64_t work = nrows * (t_end - t_begin);
+    if (pl->precision == 32)
+        hipLaunchKernelGGL((k_gather_range<float>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const float *)pl->tm.p,
+                           (const int32_t *)pl->rowsets[rowset].p, (float *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride);
+    else
+        hipLaunchKernelGGL((k_gather_range<double>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const double *)pl->tm.p,
+                           (const int32_t *)pl->rowsets[rowset].p, (double *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int trmc_set_boundary_flow_range(trmc_plan *pl, int t_begin, int t_end, const void *q_dev, int64_t src_stride,
+                                 void *stream)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (!pl->run.active) return fail(TRMC_ESTATE, "trmc_route_begin must precede trmc_set_boundary_flow_range");
+    RouteRun &r = pl->run;
+    if (t_begin != r.boundary_through || t_end < t_begin || t_end > r.nsteps)
+        return fail(TRMC_EINVAL, "ranges must continue where the staged boundary hydrographs end (step "
+                                     + std::to_string(r.boundary_through) + ")");
+    const int64_t nb = pl->topo.nboundary;
+    if (nb == 0 || t_end == t_begin) {
+        r.boundary_through = t_end;
+        return 0;
+    }
+    if (!q_dev || src_stride < t_end - t_begin) return fail(TRMC_EINVAL, "q_dev is NULL or src_stride too small");
+    if (int rc = use_device(pl)) return rc;
+    const size_t plane = (size_t)(r.nsteps + 1) * pl->nseg_pad;
+    const int64_t work = nb * (t_end - t_begin);
+    hipStream_t st = stream ? (hipStream_t)stream : pl->stream;
+    if (pl->precision == 32) {
+        float *q = (float *)pl->tm.p;
+        hipLaunchKernelGGL((k_fill_boundary_range<float>), dim3(blocks_for(work)), dim3(kBlock), 0, st, (const float *)q_dev,
+                           q, q + plane, q + 2 * plane, (int32_t)nb, pl->nseg_pad, t_begin, t_end, src_stride);
+    } else {
+        double *q = (double *)pl->tm.p;
+        hipLaunchKernelGGL((k_fill_boundary_range<double>), dim3(blocks_for(work)), dim3(kBlock), 0, st, (const double *)q_dev,
+                           q, q + plane, q + 2 * plane, (int32_t)nb, pl->nseg_pad, t_begin, t_end, src_stride);
+    }
+    HIP_TRY(hipGetLastError());
+    r.boundary_through = t_end;
+    return 0;
 }
 
 int trmc_download_fvd(trmc_plan *pl, void *fvd_out)
@@ -1208,6 +1501,17 @@ int trmc_download_fvd(trmc_plan *pl, void *fvd_out)
     if (!fvd_out) return fail(TRMC_EINVAL, "fvd_out is NULL");
     if (int rc = use_device(pl)) return rc;
     HIP_TRY(hipMemcpy(fvd_out, pl->out.p, (size_t)pl->nseg * pl->routed_nsteps * 3 * pl->esz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int trmc_download_iterations(trmc_plan *pl, uint8_t *iters_out)
+{
+    if (!pl || !iters_out) return fail(TRMC_EINVAL, "plan/iters_out is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (int rc = use_device(pl)) return rc;
+    std::vector<uint8_t> by_pos((size_t)pl->nseg_pad);
+    HIP_TRY(hipMemcpy(by_pos.data(), pl->it_prev.p, (size_t)pl->nseg_pad, hipMemcpyDeviceToHost));
+    for (int64_t p = 0; p < pl->nseg; ++p) iters_out[pl->topo.row_of_pos[p]] = by_pos[(size_t)p];
     return 0;
 }
 

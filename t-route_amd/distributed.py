@@ -55,6 +55,9 @@ class ShardedRouter:
         g2l[self.rows0] = np.arange(self.rows0.shape[0])
         lp, li = restrict_csr(up_ptr, up_idx, self.rows0, g2l)
         self.plan0 = plan_factory(lp, li, params[self.rows0], None, precision, device)
+        self._mk = {"factory": plan_factory, "precision": precision, "device": device, "params": params,
+                    "csr0": (lp, li)}
+        self.planM = None     # sub-basins + time-skewed trunk in one plan (short-timestep device path)
         # cut rows: every rank knows the global list (ascending); mine are a subset
         self.cut_rows = part["cut_rows"]
         self.cut_owner = row_owner[self.cut_rows] if self.cut_rows.size else np.zeros(0, np.int32)
@@ -92,6 +95,7 @@ class ShardedRouter:
             # position of each boundary row (ascending local row) in the global cut list
             self.b_cut_index = np.searchsorted(self.cut_rows, rows1[boundary])
             self.plan1 = plan_factory(lp1, li1, params[rows1], boundary.astype(np.uint8), precision, device)
+            self._mk["csr1"] = (lp1, li1)
             o1 = outlets[np.isin(outlets, trunk_rows)]
             self.my_out1_global, self.my_out1_local = o1, g2l1[o1]
 
@@ -138,36 +142,224 @@ class ShardedRouter:
         if self.plan1 is not None:
             self.plan1.upload_forcing(self.nsteps, self._qlat[self.rows1], self._q0[self.rows1], None)
 
-    def route_on_device(self, qts_subdivisions, assume_short_ts, all_gather_tensor):
-        """As route(), but every hand-off stays in HBM.  ``all_gather_tensor(t) -> [world, *t.shape]``
-        (torch.distributed.all_gather_into_tensor).  Returns (outlet_rows, hydrographs tensor on device)."""
-        torch, dev, nsteps = self._torch, self._tdev, self.nsteps
-        stats = {"phase0": self.plan0.route_device(nsteps, qts_subdivisions, assume_short_ts)}
-        if self._max_cut:
-            send = torch.zeros((self._max_cut, nsteps), dtype=self._tdt, device=dev)
-            if self.my_cut_local.size:
-                torch.cuda.current_stream().synchronize()
-                self.plan0.gather_flow_rows(self.my_cut_local, device_ptr=send.data_ptr())
-            recv = all_gather_tensor(send)
-            if self.plan1 is not None:
-                bq = recv.reshape(-1, nsteps).index_select(0, self._t_b_index).contiguous()
-                torch.cuda.current_stream().synchronize()
-                self.plan1.set_boundary_flow_device(nsteps, bq.data_ptr())
-        if self.plan1 is not None:
-            stats["phase1"] = self.plan1.route_device(nsteps, qts_subdivisions, assume_short_ts)
-        send_o = torch.zeros((self._max_out, nsteps), dtype=self._tdt, device=dev)
-        torch.cuda.current_stream().synchronize()
+    def _exchange_buffers(self, bounds):
+        """Send/receive blocks of every time chunk and the stream/row-set handles, made once per window shape."""
+        key = tuple(int(x) for x in bounds)
+        if getattr(self, "_xbuf_key", None) == key:
+            return self._xbuf
+        torch, dev, tdt, world = self._torch, self._tdev, self._tdt, self.world
+        if not hasattr(self, "_s0"):
+            self._s0 = torch.cuda.ExternalStream(self.plan0.stream(), device=dev)
+            self._s1 = torch.cuda.ExternalStream(self.plan1.stream(), device=dev) if self.plan1 is not None else None
+            self._sc = torch.cuda.Stream(device=dev)          # exchange stream: RCCL is ordered against it
+            self._rs_cut = self.plan0.rowset(self.my_cut_local)
+            self._rs_out0 = self.plan0.rowset(self.my_out0_local)
+            self._rs_out1 = self.plan1.rowset(self.my_out1_local) if self.plan1 is not None else None
+        x = {"send": [], "recv": [], "bq": []}
+        for c in range(len(key) - 1):
+            w = key[c + 1] - key[c]
+            if self._max_cut:
+                x["send"].append(torch.zeros((self._max_cut, w), dtype=tdt, device=dev))
+                x["recv"].append(torch.zeros((world, self._max_cut, w), dtype=tdt, device=dev))
+                x["bq"].append(torch.zeros((int(self._t_b_index.shape[0]), w), dtype=tdt, device=dev)
+                               if self.plan1 is not None else None)
+        x["send_o"] = torch.zeros((self._max_out, key[-1]), dtype=tdt, device=dev)
+        x["recv_o"] = torch.zeros((world, self._max_out, key[-1]), dtype=tdt, device=dev)
+        torch.cuda.synchronize(dev)
+        self._xbuf_key, self._xbuf = key, x
+        return x
+
+    def route_on_device(self, qts_subdivisions, assume_short_ts, all_gather_into, nchunks=None):
+        """One routing window with every hand-off in HBM; returns (outlet_rows, hydrographs tensor on device).
+        ``all_gather_into(out[world, *in.shape], in)`` = torch.distributed.all_gather_into_tensor (RCCL over
+        xGMI), ordered against the current torch stream.
+
+        assume_short_ts: the trunk rides in the launches of this rank's sub-basins, `2 * chunk` steps behind
+        them (`_route_skewed`); otherwise sub-basins first, trunk after the exchange (`_route_phased`)."""
+        if assume_short_ts:
+            return self._route_skewed(qts_subdivisions, all_gather_into, 24 if nchunks is None else nchunks)
+        return self._route_phased(qts_subdivisions, assume_short_ts, all_gather_into, nchunks)
+
+    # ---- short-timestep path: one plan, trunk time-skewed -----------------------------------------------
+    def _merged_plan(self, lag):
+        """plan0's table followed by the trunk table (trunk rows + boundary copies of the cut rows that feed
+        it); trunk rows carry `lag`.  Built once per lag, forcing staged once per upload()."""
+        if self.plan1 is None:                      # nothing to merge: plan0 itself, forcing staged by upload()
+            if not hasattr(self, "_sM"):
+                self._sM = self._torch.cuda.ExternalStream(self.plan0.stream(), device=self._tdev)
+                self._rsM_cut = self.plan0.rowset(self.my_cut_local)
+                self._rsM_out0 = self.plan0.rowset(self.my_out0_local)
+                self._rsM_out1 = None
+            return self.plan0
+        if self.planM is not None and self._planM_lag == lag and self._planM_upload is self._qlat:
+            return self.planM
+        mk = self._mk
+        n0 = self.rows0.shape[0]
+        if self.planM is None or self._planM_lag != lag:
+            if self.planM is not None:
+                self.planM.close()
+            lp0, li0 = mk["csr0"]
+            lp1, li1 = mk["csr1"]
+            up_ptr = np.concatenate([lp0, lp0[-1] + lp1[1:]])
+            up_idx = np.concatenate([li0, li1 + n0])
+            rows = np.concatenate([self.rows0, self.rows1])
+            boundary = np.concatenate([np.zeros(n0, np.uint8), self.boundary1.astype(np.uint8)])
+            lagv = np.concatenate([np.zeros(n0, np.int32), np.where(self.boundary1, 0, lag).astype(np.int32)])
+            self._rowsM = rows
+            self.planM = mk["factory"](up_ptr, up_idx, mk["params"][rows], boundary, mk["precision"], mk["device"])
+            self.planM.set_lag(lagv)
+            self._planM_lag = lag
+            self._sM = self._torch.cuda.ExternalStream(self.planM.stream(), device=self._tdev)
+            self._rsM_cut = self.planM.rowset(self.my_cut_local)
+            self._rsM_out0 = self.planM.rowset(self.my_out0_local)
+            self._rsM_out1 = self.planM.rowset(n0 + self.my_out1_local) if self.my_out1_global.size else None
+        self.planM.upload_forcing(self.nsteps, self._qlat[self._rowsM], self._q0[self._rowsM], None)
+        self._planM_upload = self._qlat
+        return self.planM
+
+    def _skew_buffers(self, nsteps, K):
+        key = ("skew", nsteps, K)
+        if getattr(self, "_sbuf_key", None) == key:
+            return self._sbuf
+        torch, dev, tdt, world = self._torch, self._tdev, self._tdt, self.world
+        if not hasattr(self, "_sc"):
+            self._sc = torch.cuda.Stream(device=dev)          # exchange stream: RCCL is ordered against it
+        C = -(-nsteps // K)
+        x = {"send": [], "recv": [], "bq": []}
+        for c in range(C):
+            w = min(nsteps, (c + 1) * K) - c * K
+            if self._max_cut:
+                x["send"].append(torch.zeros((self._max_cut, w), dtype=tdt, device=dev))
+                x["recv"].append(torch.zeros((world, self._max_cut, w), dtype=tdt, device=dev))
+                x["bq"].append(torch.zeros((int(self._t_b_index.shape[0]), w), dtype=tdt, device=dev)
+                               if self.plan1 is not None else None)
+        x["send_o"] = torch.zeros((self._max_out, nsteps), dtype=tdt, device=dev)
+        x["recv_o"] = torch.zeros((world, self._max_out, nsteps), dtype=tdt, device=dev)
+        torch.cuda.synchronize(dev)
+        self._sbuf_key, self._sbuf = key, x
+        return x
+
+    def _route_skewed(self, qts_subdivisions, all_gather_into, nchunks):
+        """assume_short_ts: a row at step t reads its upstream rows at step t-1 only.  The window is cut into
+        chunks of K steps.  After this rank's sub-basins have been queued through chunk c, the chunk's
+        cut-edge hydrographs are gathered (plan stream), all-gathered and written into the trunk's boundary
+        rows (exchange stream).  The trunk rows sit in the SAME launches as the sub-basins, 2K steps behind:
+        when a launch needs chunk c's boundary values, their exchange was queued a whole chunk of launches
+        earlier, so the plan stream's wait on it never stalls, and the trunk costs no launches of its own
+        except the 2K that drain it at the end.  The host never waits inside the window."""
+        torch, nsteps = self._torch, self.nsteps
+        K = max(1, -(-nsteps // max(1, int(nchunks))))
+        C = -(-nsteps // K)
+        lag = 2 * K if self.plan1 is not None else 0
+        P = self._merged_plan(lag)
+        x = self._skew_buffers(nsteps, K)
+        sP, sc = self._sM, self._sc
+        P.route_begin(nsteps, qts_subdivisions, True)
+        filled = [None] * C
+        last = nsteps + lag
+        c = 0
+        while True:
+            d_end = min((c + 1) * K, last)
+            if lag and c >= 2 and filled[min(c - 2, C - 1)] is not None:
+                sP.wait_event(filled[min(c - 2, C - 1)])   # boundary values of chunk c-2: queued a chunk ago
+            P.route_advance(d_end)
+            if c < C and self._max_cut:
+                tb, te = c * K, min(nsteps, (c + 1) * K)
+                w = te - tb
+                P.gather_flow_range(self._rsM_cut, tb, te, x["send"][c].data_ptr(), w)
+                ev = torch.cuda.Event()
+                ev.record(sP)
+                sc.wait_event(ev)
+                with torch.cuda.stream(sc):
+                    all_gather_into(x["recv"][c], x["send"][c])
+                    if self.plan1 is not None:
+                        torch.index_select(x["recv"][c].view(-1, w), 0, self._t_b_index, out=x["bq"][c])
+                if self.plan1 is not None:
+                    P.set_boundary_flow_range(tb, te, x["bq"][c].data_ptr(), w, stream=sc.cuda_stream)
+                    filled[c] = torch.cuda.Event()
+                    filled[c].record(sc)
+            if d_end >= last:
+                break
+            c += 1
+        # network outlets: phase-0 outlets then trunk outlets in this rank's slot of the final all-gather
+        send_o, recv_o = x["send_o"], x["recv_o"]
         n0 = self.my_out0_local.shape[0]
-        if n0:
-            self.plan0.gather_flow_rows(self.my_out0_local, device_ptr=send_o.data_ptr())
-        if self.plan1 is not None and self.my_out1_global.size:
-            self.plan1.gather_flow_rows(self.my_out1_local, device_ptr=send_o[n0:].data_ptr())
-        recv_o = all_gather_tensor(send_o)
-        hyd = recv_o.reshape(-1, nsteps).index_select(0, self._t_out_index)
+        P.gather_flow_range(self._rsM_out0, 0, nsteps, send_o.data_ptr(), nsteps)
+        if self._rsM_out1 is not None:
+            P.gather_flow_range(self._rsM_out1, 0, nsteps, send_o[n0:].data_ptr(), nsteps)
+        ev = torch.cuda.Event()
+        ev.record(sP)
+        sc.wait_event(ev)
+        with torch.cuda.stream(sc):
+            all_gather_into(recv_o, send_o)
+            hyd = recv_o.view(-1, nsteps).index_select(0, self._t_out_index)
+        self.last_stats = {"phase0": P.route_end()}
+        sc.synchronize()
+        return self._out_rows, hyd
+
+    # ---- general path: sub-basins, exchange, trunk (optionally pipelined in time chunks) ---------------------
+    def _route_phased(self, qts_subdivisions, assume_short_ts, all_gather_into, nchunks=None):
+        """Sub-basins on plan0's stream, trunk on plan1's, the exchange between them on a third stream; with
+        nchunks > 1 the three are pipelined in time (the level wavefront of the general mode restarts per
+        chunk, so the default keeps the window whole)."""
+        torch, nsteps = self._torch, self.nsteps
+        if nchunks is None:
+            nchunks = 1
+        nchunks = max(1, min(int(nchunks), nsteps))
+        bounds = np.round(np.linspace(0, nsteps, nchunks + 1)).astype(np.int64)
+        x = self._exchange_buffers(bounds)
+        s0, s1, sc = self._s0, self._s1, self._sc
+        self.plan0.route_begin(nsteps, qts_subdivisions, assume_short_ts)
+        if self.plan1 is not None:
+            self.plan1.route_begin(nsteps, qts_subdivisions, assume_short_ts)
+        for c in range(nchunks):
+            tb, te = int(bounds[c]), int(bounds[c + 1])
+            w = te - tb
+            self.plan0.route_advance(te)
+            if self._max_cut:
+                self.plan0.gather_flow_range(self._rs_cut, tb, te, x["send"][c].data_ptr(), w)
+                ev = torch.cuda.Event()
+                ev.record(s0)
+                sc.wait_event(ev)
+                with torch.cuda.stream(sc):
+                    all_gather_into(x["recv"][c], x["send"][c])
+                if self.plan1 is not None:
+                    ev2 = torch.cuda.Event()
+                    ev2.record(sc)
+                    s1.wait_event(ev2)
+                    with torch.cuda.stream(s1):
+                        torch.index_select(x["recv"][c].view(-1, w), 0, self._t_b_index, out=x["bq"][c])
+                    self.plan1.set_boundary_flow_range(tb, te, x["bq"][c].data_ptr(), w)
+            if self.plan1 is not None:
+                if not self._max_cut:
+                    self.plan1.set_boundary_flow_range(tb, te, 0, w)
+                self.plan1.route_advance(te)
+        # network outlets: phase-0 outlets then trunk outlets in this rank's slot of the final all-gather
+        send_o, recv_o = x["send_o"], x["recv_o"]
+        n0 = self.my_out0_local.shape[0]
+        self.plan0.gather_flow_range(self._rs_out0, 0, nsteps, send_o.data_ptr(), nsteps)
+        ev = torch.cuda.Event()
+        ev.record(s0)
+        sc.wait_event(ev)
+        if self.plan1 is not None:
+            if self.my_out1_global.size:
+                self.plan1.gather_flow_range(self._rs_out1, 0, nsteps, send_o[n0:].data_ptr(), nsteps)
+            ev1 = torch.cuda.Event()
+            ev1.record(s1)
+            sc.wait_event(ev1)
+        with torch.cuda.stream(sc):
+            all_gather_into(recv_o, send_o)
+            hyd = recv_o.view(-1, nsteps).index_select(0, self._t_out_index)
+        stats = {"phase0": self.plan0.route_end()}
+        if self.plan1 is not None:
+            stats["phase1"] = self.plan1.route_end()
+        sc.synchronize()
         self.last_stats = stats
         return self._out_rows, hyd
 
     def close(self):
+        if self.planM is not None:
+            self.planM.close()
         self.plan0.close()
         if self.plan1 is not None:
             self.plan1.close()

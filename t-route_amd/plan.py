@@ -61,6 +61,7 @@ class RoutingPlan:
                                                _lib.ptr(b), precision, device, C.byref(h)))
         self._h = h
         self._nsteps = None
+        self.maxlag = 0
 
     # -- lifetime ---------------------------------------------------------------------
     def close(self):
@@ -160,6 +161,47 @@ class RoutingPlan:
         self._nsteps = nsteps
         return self.stats()
 
+    # -- the same window in parts (asynchronous; see include/trmc.h) ------------------------------
+    def route_begin(self, nsteps, qts_subdivisions, assume_short_ts):
+        _lib.check(_lib.lib().trmc_route_begin(self._h, nsteps, qts_subdivisions, int(bool(assume_short_ts))))
+        self._nsteps = nsteps
+
+    def route_advance(self, t_end):
+        _lib.check(_lib.lib().trmc_route_advance(self._h, int(t_end)))
+
+    def route_end(self):
+        _lib.check(_lib.lib().trmc_route_end(self._h))
+        return self.stats()
+
+    def stream(self):
+        """hipStream_t of the plan as an integer (wrap with torch.cuda.ExternalStream to order RCCL against it)."""
+        s = C.c_void_p(0)
+        _lib.check(_lib.lib().trmc_plan_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def rowset(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        rid = C.c_int32(-1)
+        _lib.check(_lib.lib().trmc_rowset_create(self._h, _lib.ptr(rows), rows.shape[0], C.byref(rid)))
+        return rid.value
+
+    def gather_flow_range(self, rowset, t_begin, t_end, device_ptr, stride):
+        _lib.check(_lib.lib().trmc_gather_flow_range(self._h, rowset, int(t_begin), int(t_end),
+                                                     C.c_void_p(device_ptr), int(stride)))
+
+    def set_boundary_flow_range(self, t_begin, t_end, device_ptr, stride, stream=None):
+        _lib.check(_lib.lib().trmc_set_boundary_flow_range(self._h, int(t_begin), int(t_end),
+                                                           C.c_void_p(device_ptr), int(stride),
+                                                           C.c_void_p(stream) if stream else None))
+
+    def set_lag(self, lag_of_row):
+        """Rows with lag L are routed L launches behind the others (include/trmc.h trmc_plan_set_lag)."""
+        lag = None if lag_of_row is None else np.ascontiguousarray(lag_of_row, dtype=np.int32)
+        if lag is not None and lag.shape != (self.nseg,):
+            raise ValueError("lag_of_row must be [nseg]")
+        _lib.check(_lib.lib().trmc_plan_set_lag(self._h, _lib.ptr(lag)))
+        self.maxlag = 0 if lag is None else int(lag.max(initial=0))
+
     def download_fvd(self):
         out = np.empty((self.nseg, self._nsteps, 3), dtype=self.dtype)
         _lib.check(_lib.lib().trmc_download_fvd(self._h, _lib.ptr(out)))
@@ -168,6 +210,12 @@ class RoutingPlan:
     def download_final_state(self):
         out = np.empty((self.nseg, 3), dtype=self.dtype)
         _lib.check(_lib.lib().trmc_download_final_state(self._h, _lib.ptr(out)))
+        return out
+
+    def download_iterations(self):
+        """uint8 [nseg]: secant iterations each row spent on the last routed timestep (diagnostic)."""
+        out = np.zeros(self.nseg, dtype=np.uint8)
+        _lib.check(_lib.lib().trmc_download_iterations(self._h, _lib.ptr(out)))
         return out
 
     def gather_flow_rows_resident(self, rows):

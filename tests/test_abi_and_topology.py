@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in trmc.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with trmc.h"
-    assert lib.trmc_abi_version() == 1
+    assert lib.trmc_abi_version() == 2
 
 
 @pytest.mark.skipif(_lib.device_count() > 0, reason="CPU-only check")

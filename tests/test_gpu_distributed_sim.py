@@ -1,4 +1,4 @@
-"""Device-resident multi-rank path (ShardedRouter.route_on_device) on ONE GPU: two ranks run as two
+"""Device-resident, time-pipelined multi-rank path (ShardedRouter.route_on_device) on ONE GPU: two ranks run as two
 threads of this process and exchange through an in-process stand-in for
 torch.distributed.all_gather_into_tensor.  Checks that the HBM-to-HBM hand-off (sub-basin outlets ->
 trunk boundary rows, final outlet gather) reproduces the single-rank result bit for bit."""
@@ -20,20 +20,22 @@ class ThreadAllGather:
         self.barrier = threading.Barrier(world)
 
     def for_rank(self, rank):
-        def all_gather_tensor(t):
+        def all_gather_into(out, t):
+            """torch.distributed.all_gather_into_tensor for threads of one process: ordered against the
+            caller's current stream like the real collective (waits for it, leaves the result on it)"""
             import torch
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
             self.slots[rank] = t
             self.barrier.wait()
-            out = torch.stack([self.slots[r] for r in range(self.world)])
-            torch.cuda.synchronize()
+            for r in range(self.world):
+                out[r].copy_(self.slots[r])
+            torch.cuda.current_stream().synchronize()
             self.barrier.wait()
-            return out
-        return all_gather_tensor
+        return all_gather_into
 
 
-@pytest.mark.parametrize("short", [True, False])
-def test_two_ranks_device_exchange_equals_single_rank(short):
+@pytest.mark.parametrize("short,nchunks", [(True, None), (True, 1), (True, 5), (False, None), (False, 3)])
+def test_two_ranks_device_exchange_equals_single_rank(short, nchunks):
     import torch
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
@@ -57,7 +59,7 @@ def test_two_ranks_device_exchange_equals_single_rank(short):
             r.upload(nsteps, net["qlat"], q0)
             r.upload_trunk()
             for _ in range(2):                          # twice: the staged buffers must be reusable
-                rows, hyd = r.route_on_device(qts, short, ag.for_rank(rank))
+                rows, hyd = r.route_on_device(qts, short, ag.for_rank(rank), nchunks)
             results[rank] = (rows, hyd.cpu().numpy(), r.cut_rows.shape[0], r.plan1 is not None)
             r.close()
         except Exception as e:                          # pragma: no cover

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Time every rank's share of an N-GPU CONUS run on ONE GPU, one rank after the other.
+
+The cut-edge hydrographs a rank would receive from its peers are taken from a complete single-GPU route
+(so the trunk sees its true inflows); the collective is an in-process copy.  Reports, per rank, the wall
+time of route_on_device -- the job time of the real N-GPU run is about the maximum (plus RCCL latency).
+
+    python tools/sim_ranks.py --world 8 [--chunks 8] [--full-ts]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--chunks", type=int, default=None)
+    ap.add_argument("--full-ts", action="store_true")
+    ap.add_argument("--nseg", type=int, default=None)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--ranks", type=str, default=None, help="comma list (default: all)")
+    a = ap.parse_args()
+    import torch
+    from troute_amd import sharding, synthetic
+    from troute_amd.distributed import ShardedRouter
+
+    kw = {"nseg": a.nseg, "nnet": max(3, a.nseg // 185)} if a.nseg else {}
+    net = synthetic.generate(cache_dir=os.environ.get("TRMC_CACHE", "/tmp/trmc_cache"), **kw)
+    to, params, qlat = net["to"], net["params"], net["qlat"]
+    nseg = to.shape[0]
+    q0 = np.zeros((nseg, 3), np.float32)
+    nsteps, qts, short = 288, 12, not a.full_ts
+    dev = torch.device("cuda", 0)
+
+    part = sharding.partition(to, a.world)
+    # true hydrographs of the cut rows from a whole-network route
+    single = ShardedRouter(to, params)
+    single.upload(nsteps, qlat, q0)
+    single.route_resident(qts, short)
+    t0 = time.perf_counter()
+    single.route_resident(qts, short)
+    t_single = time.perf_counter() - t0
+    cut_rows = part["cut_rows"]
+    cut_q = single.plan0.gather_flow_rows(cut_rows) if cut_rows.size else np.zeros((0, nsteps), np.float32)
+    ref_rows = single.my_out0_global
+    ref_hyd = single.outlet_hydrographs()
+    single.close()
+    print(f"single GPU: {t_single * 1e3:.2f} ms   cut rows {cut_rows.size}")
+
+    worst = 0.0
+    for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
+        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part)
+        r.enable_device_exchange(torch, dev)
+        r.upload(nsteps, qlat, q0)
+        r.upload_trunk()
+        # what the peers would contribute to each all-gather, laid out [world, max_cut, nsteps]
+        peers = torch.zeros((a.world, max(r._max_cut, 1), nsteps), dtype=torch.float32, device=dev)
+        if cut_rows.size:
+            idx = np.zeros(cut_rows.size, dtype=np.int64)
+            for k in range(a.world):
+                m = r.cut_owner == k
+                idx[m] = np.arange(int(m.sum()))
+            peers[torch.from_numpy(r.cut_owner.astype(np.int64)).to(dev), torch.from_numpy(idx).to(dev)] = \
+                torch.from_numpy(cut_q).to(dev)
+        nchunks_eff = (a.chunks if a.chunks else 24) if short else (a.chunks if a.chunks else 1)
+        state = {"t": 0, "call": 0}
+
+        def all_gather_into(out, t):
+            # the router issues one all-gather per time chunk (when there are cut rows), then the outlet gather
+            is_cut = r._max_cut > 0 and state["call"] < nchunks_eff
+            state["call"] += 1
+            if is_cut:
+                w = out.shape[2]
+                out.copy_(peers[:, :, state["t"]:state["t"] + w])
+                out[rank].copy_(t)
+                state["t"] += w
+            else:
+                out.zero_()
+                out[rank].copy_(t)
+
+        acc = {}
+        if os.environ.get("TRMC_SIM_TRACE"):     # host-side time per call site
+            def wrap(obj, name):
+                fn = getattr(obj, name)
+                def timed(*args, **kw):
+                    t0 = time.perf_counter()
+                    try:
+                        return fn(*args, **kw)
+                    finally:
+                        acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+                setattr(obj, name, timed)
+            for nm in ("route_begin", "route_advance", "route_end", "gather_flow_range", "set_boundary_flow_range"):
+                wrap(r.plan0, nm)
+                if r.plan1 is not None and short:
+                    wrap(r._merged_plan(2 * -(-nsteps // nchunks_eff)), nm)
+            _ag = all_gather_into
+            def all_gather_into(out, t, _ag=_ag):
+                t0 = time.perf_counter()
+                _ag(out, t)
+                acc["all_gather"] = acc.get("all_gather", 0.0) + time.perf_counter() - t0
+        times = []
+        for _ in range(a.reps + 1):
+            state["t"], state["call"] = 0, 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rows, hyd = r.route_on_device(qts, short, all_gather_into, a.chunks)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        t = min(times[1:])
+        worst = max(worst, t)
+        st = r.last_stats
+        # check my own outlets against the single-GPU run
+        mine = np.concatenate([r.my_out0_global, r.my_out1_global])
+        h = hyd.cpu().numpy()
+        sel = np.searchsorted(rows, mine)
+        ok = np.array_equal(h[sel].view(np.uint32), ref_hyd[np.searchsorted(ref_rows, mine)].view(np.uint32))
+        print(f"rank {rank}: {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
+              + (f"  trunk {r.rows1.size} rows" + (f" main {st['phase1']['ms_main']:.2f} ms" if "phase1" in st else " (skewed)") if r.plan1 is not None else "")
+              + f"  outlets bit-identical: {ok}")
+        if acc:
+            print("   host ms (all reps):", {k: round(v * 1e3, 2) for k, v in acc.items()})
+        r.close()
+    print(f"max over ranks {worst * 1e3:.2f} ms -> speed-up vs single {t_single / worst:.2f}x at world {a.world}")
+
+
+if __name__ == "__main__":
+    main()
