@@ -18,9 +18,10 @@ What is different, on purpose (MI355X-first, SURVEY.md 8b "Threading"):
     result list (``cpu_pool`` and ``subnetwork_target_size`` are ignored).
   * the per-call argument preparation of the reference (pandas ``.loc`` slicing
     per network, compute.py:1399-1467) is done once for the whole table.
-Level-pool waterbodies (``waterbodies_df``, reservoir type 1) are routed; gage / reservoir
-data-assimilation DataFrames raise NotImplementedError here (the kernel callable
-``compute_network_structured`` accepts gage arrays directly), as does the diffusive branch.
+Level-pool waterbodies (``waterbodies_df``, reservoir type 1) are routed and gage observations
+(``usgs_df`` / ``lastobs_df``, streamflow nudging) are prepared as the reference prepares them
+(``_prep_da_dataframes``, ``_prep_da_positions_byreach``); reservoir data-assimilation DataFrames raise
+NotImplementedError, as does the diffusive branch.
 """
 from collections import defaultdict
 
@@ -42,6 +43,42 @@ _PARALLEL_METHODS = ("serial", "by-network", "by-subnetwork", "by-subnetwork-jit
 
 def _is_empty(df):
     return df is None or getattr(df, "empty", True) or len(df) == 0
+
+
+def _prep_da_dataframes(usgs_df, lastobs_df, param_df_sub_idx, exclude_segments=None):
+    """Gage observation series and last-valid observations of the gages inside one segment table.
+
+    Same name, arguments and return as the reference helper (compute.py:49-123):
+    ``(usgs_df_sub, lastobs_df_sub, da_positions_list_byseg)`` for the four presence cases
+    (both: analysis & assimilation, gage order = lastobs order; lastobs only: forecast, an observation
+    table with no columns; usgs only: cold start, an all-NaN lastobs table; neither: open loop)."""
+    import pandas as pd
+    table = param_df_sub_idx
+    inside = table.difference(set(exclude_segments)) if exclude_segments else table
+    have_u, have_l = not _is_empty(usgs_df), not _is_empty(lastobs_df)
+    if not have_u and not have_l:
+        return pd.DataFrame(), pd.DataFrame(), []
+    if have_l:
+        gages = [g for g in lastobs_df.index if g in inside]            # lastobs order decides
+        lastobs_sub = lastobs_df.loc[gages]
+        usgs_sub = usgs_df.loc[gages] if have_u else pd.DataFrame(index=lastobs_sub.index, columns=[])
+    else:
+        gages = [g for g in usgs_df.index if g in inside]
+        usgs_sub = usgs_df.loc[gages]
+        lastobs_sub = pd.DataFrame(index=usgs_sub.index, columns=["discharge", "time", "model_discharge"])
+    return usgs_sub, lastobs_sub, table.get_indexer(gages)
+
+
+def _prep_da_positions_byreach(reach_list, gage_index):
+    """(reach numbers that hold a gage, the gage number of each) in reach-list order -- compute.py:125-140."""
+    where = {g: i for i, g in enumerate(gage_index)}
+    reach_key, gage_i = [], []
+    for i, reach in enumerate(reach_list):
+        for s in reach:
+            if s in where:
+                reach_key.append(i)
+                gage_i.append(where[s])
+    return reach_key, np.asarray(gage_i, dtype=np.intp)
 
 
 def compute_nhd_routing_v02(
@@ -95,13 +132,12 @@ def compute_nhd_routing_v02(
     """
     if parallel_compute_method not in _PARALLEL_METHODS and parallel_compute_method is not None:
         raise ValueError(f"unknown parallel_compute_method {parallel_compute_method!r}")
-    for name, df in (("usgs_df", usgs_df), ("lastobs_df", lastobs_df),
-                     ("reservoir_usgs_df", reservoir_usgs_df), ("reservoir_usace_df", reservoir_usace_df),
+    for name, df in (("reservoir_usgs_df", reservoir_usgs_df), ("reservoir_usace_df", reservoir_usace_df),
                      ("reservoir_rfc_df", reservoir_rfc_df), ("great_lakes_df", great_lakes_df)):
         if not _is_empty(df):
             raise NotImplementedError(
-                f"{name} is not empty: gage / reservoir data-assimilation tables are not wired through this "
-                "driver (the kernel callable itself accepts gage arrays: compute_network_structured)")
+                f"{name} is not empty: reservoir data assimilation (hybrid persistence, RFC forecasts, Great "
+                "Lakes) is outside the Muskingum-Cunge path this package replaces")
     if flowveldepth_interorder:
         raise NotImplementedError("flowveldepth_interorder hand-off is only needed by the reference's "
                                   "sub-network orders; call compute_network_structured for that")
@@ -149,18 +185,36 @@ def compute_nhd_routing_v02(
     qlat_v = qlats.reindex(table.index).fillna(0.0).values.astype("float32")
 
     e_f2, e_f1, e_i1 = np.zeros((0, 0), "float32"), np.zeros(0, "float32"), np.zeros(0, "int32")
+    # streamflow nudging tables of the whole call (reference: per tailwater, compute.py:1468-1469)
+    import pandas as pd
+    usgs_sub, lastobs_sub, da_byseg = _prep_da_dataframes(
+        pd.DataFrame() if usgs_df is None else usgs_df, pd.DataFrame() if lastobs_df is None else lastobs_df, table.index)
+    da_byreach, da_bygage = _prep_da_positions_byreach([reach for reach, _ in reaches_wTypes], lastobs_sub.index)
+    ngage = len(da_byseg)
+    if ngage:
+        usgs_v = usgs_sub.values.astype("float32")
+        null = pd.Series(index=lastobs_sub.index, name="Null", dtype="float32")
+        lastobs_v = lastobs_sub.get("lastobs_discharge", null).values.astype("float32")     # compute.py:1533-1535
+        lastobs_t = lastobs_sub.get("time_since_lastobs", null).values.astype("float32")
+        gage_args = (usgs_v, np.array(da_byseg, dtype="int32"), np.array(da_byreach, dtype="int32"),
+                     np.array(da_bygage, dtype="int32"), lastobs_v, lastobs_t)
+    else:
+        gage_args = (e_f2, e_i1, e_i1, e_i1, e_f1, e_f1)
     r = compute_network_structured(
         nts, dt, qts_subdivisions, reaches_wTypes, upstream_connections, ids, table.columns.values,
         table.values.astype("float32"), q0_v, qlat_v, lake_segs, waterbodies_sub, data_assimilation_parameters,
         types_sub, bool(waterbody_type_specified),
         t0.strftime('%Y-%m-%d_%H:%M:%S') if hasattr(t0, "strftime") else str(t0),
-        e_f2, e_i1, e_i1, e_i1, e_f1, e_f1, da_parameter_dict.get("da_decay_coefficient", 0) if da_parameter_dict else 0,
+        *gage_args, da_parameter_dict.get("da_decay_coefficient", 0) if da_parameter_dict else 0,
         e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
         e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
         e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
         e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
         {}, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device)
     fvd, upstream = r[1], r[6]
+    gage_ids, lastobs_times, lastobs_values = r[3]
+    nudge = r[8]
+    gage_row = np.asarray(da_byseg, dtype=np.int64)
 
     # ---- back to the reference's per-tailwater result list ---------------------------------------------
     owner = np.full(nseg, -1, dtype=np.int64)
@@ -170,16 +224,18 @@ def compute_nhd_routing_v02(
     results = []
     for k in range(len(tws)):
         sel = np.flatnonzero(owner == k)
+        gk = np.flatnonzero(owner[gage_row] == k) if ngage else np.zeros(0, dtype=np.int64)   # this network's gages
         results.append((
             ids[sel].astype(np.intp),
             fvd[sel],
             0,
+            (np.asarray(gage_ids)[gk], np.asarray(lastobs_times)[gk], np.asarray(lastobs_values)[gk]) if ngage else
             (np.asarray([], dtype=np.int64), np.full(0, np.nan, "float32"), np.full(0, np.nan, "float32")),
             (e_i1, e_f1, e_f1, e_f1, e_f1),
             (e_i1, e_f1, e_f1, e_f1, e_f1),
             upstream[sel],
             (e_i1, e_f1, e_i1),
-            np.zeros((0, nts + 1), dtype="float32"),
+            nudge[gk] if ngage else np.zeros((0, nts + 1), dtype="float32"),
             (e_i1, e_f1, e_i1, e_i1),
         ))
     return results

@@ -420,10 +420,91 @@ def nudging_vectors():
         shutil.rmtree(td, ignore_errors=True)
 
 
+def import_ref_compute(nn):
+    """The reference's routing/compute.py, for its pure-pandas helpers.  The modules it imports that cannot exist
+    here (compiled Cython extensions, the diffusive utilities) are replaced by empty stand-ins: none of them is
+    on the path of _prep_da_dataframes / _prep_da_positions_byreach."""
+    for name in ("troute", "troute.routing", "troute.routing.fast_reach"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["troute.nhd_network"] = nn
+    sys.modules["troute"].nhd_network = nn
+    mc = types.ModuleType("troute.routing.fast_reach.mc_reach")
+    mc.compute_network_structured = lambda *a, **k: None
+    sys.modules["troute.routing.fast_reach.mc_reach"] = mc
+    for name in ("troute.routing.diffusive_utils_v02", "troute.routing.fast_reach.diffusive"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["troute.routing"].diffusive_utils_v02 = sys.modules["troute.routing.diffusive_utils_v02"]
+    sys.modules["troute.routing.fast_reach"].diffusive = sys.modules["troute.routing.fast_reach.diffusive"]
+    if "joblib" not in sys.modules:
+        try:
+            import joblib  # noqa: F401
+        except Exception:
+            jb = types.ModuleType("joblib")
+            jb.delayed = jb.Parallel = None
+            sys.modules["joblib"] = jb
+    spec = importlib.util.spec_from_file_location(
+        "ref_compute", os.path.join(REF, "src/troute-routing/troute/routing/compute.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def da_prep_vectors(nn):
+    """_prep_da_dataframes / _prep_da_positions_byreach (compute.py:49-140) on seeded tables, the four
+    (usgs_df, lastobs_df) presence cases -> tests/golden/da_prep_vectors.json."""
+    import pandas as pd
+    rc = import_ref_compute(nn)
+    rng = np.random.default_rng(21)
+    seg_ids = np.sort(rng.choice(np.arange(1000, 9000), 400, replace=False))
+    idx = pd.Index(seg_ids)
+    # reaches: consecutive runs of the sorted ids, 1-4 long
+    reaches, i = [], 0
+    while i < len(seg_ids):
+        k = int(rng.integers(1, 5))
+        reaches.append([int(x) for x in seg_ids[i:i + k]])
+        i += k
+    cases = []
+    for case in range(8):
+        off = rng.choice(np.arange(9000, 9500), 6, replace=False)           # gages outside the table
+        g_usgs = np.concatenate([rng.choice(seg_ids, 30, replace=False), off[:3]])
+        g_last = np.concatenate([rng.permutation(g_usgs)[:25], rng.choice(seg_ids, 6, replace=False), off[3:]])
+        g_last = np.array(list(dict.fromkeys(g_last.tolist())))
+        rng.shuffle(g_usgs)
+        usgs = pd.DataFrame(rng.lognormal(0, 1, (len(g_usgs), 5)).astype("float32"), index=g_usgs)
+        last = pd.DataFrame({"time_since_lastobs": -rng.uniform(0, 7200, len(g_last)).astype("float32"),
+                             "lastobs_discharge": rng.lognormal(0, 1, len(g_last)).astype("float32")}, index=g_last)
+        which = case % 4
+        if which == 0:   # both present: the reference indexes usgs_df by the lastobs gages (compute.py:93-99),
+            last = last.loc[[g for g in last.index if g in set(usgs.index)]]   # so they must be a subset
+        u = usgs if which in (0, 2) else pd.DataFrame()
+        l = last if which in (0, 1) else pd.DataFrame()
+        excl = [int(x) for x in rng.choice(seg_ids, 20, replace=False)] if case >= 4 else None
+        us, ls, byseg = rc._prep_da_dataframes(u, l, idx, excl)
+        byreach, bygage = rc._prep_da_positions_byreach(reaches, ls.index)
+        cases.append({
+            "usgs_index": [int(x) for x in u.index], "usgs_values": np.asarray(u.values, dtype="float64").tolist(),
+            "lastobs_index": [int(x) for x in l.index],
+            "lastobs_cols": [str(c) for c in l.columns], "lastobs_values": np.asarray(l.values, dtype="float64").tolist(),
+            "exclude": excl,
+            "out_usgs_index": [int(x) for x in us.index], "out_usgs_shape": list(us.shape),
+            "out_usgs_values": np.asarray(us.values, dtype="float64").tolist(),
+            "out_lastobs_index": [int(x) for x in ls.index], "out_lastobs_cols": [str(c) for c in ls.columns],
+            "out_byseg": [int(x) for x in byseg], "out_byreach": [int(x) for x in byreach],
+            "out_bygage": [int(x) for x in bygage],
+        })
+    with open(os.path.join(HERE, "da_prep_vectors.json"), "w") as f:
+        json.dump({"seg_ids": [int(x) for x in seg_ids], "reaches": reaches, "cases": cases}, f)
+    print("da_prep_vectors.json:", len(cases), "cases")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "da_prep":
+        da_prep_vectors(import_ref_nhd_network())
+        sys.exit(0)
     O.build()
     nudging_vectors()
     nn = import_ref_nhd_network()
     kernel_vectors()
     toy_network(nn)
     lowercolorado(nn)
+    da_prep_vectors(nn)

@@ -90,9 +90,9 @@ def test_plugin_seam_and_unsupported_inputs():
     ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
     e = pd.DataFrame()
     usgs = pd.DataFrame({"0": [1.0]}, index=[14])
-    with pytest.raises(NotImplementedError, match="usgs_df"):
+    with pytest.raises(NotImplementedError, match="reservoir_usgs_df"):
         compute_nhd_routing_v02(conn, rconn, {}, reaches_bytw, "V02-structured", "serial", 1, 1, None, 300.0, 12, 12,
-                                ind, param_df, q0_df, qlat_df, usgs, e, e, e, e, e, e, e, e, e, e, {}, True, False, e,
+                                ind, param_df, q0_df, qlat_df, e, e, usgs, e, e, e, e, e, e, e, e, {}, True, False, e,
                                 {}, e, False, [{}, {}])
     with pytest.raises(ValueError, match="Number of columns"):
         compute_nhd_routing_v02(conn, rconn, {}, reaches_bytw, "V02-structured", "serial", 1, 1, None, 300.0, 48, 12,
