@@ -135,6 +135,22 @@ int trmc_upload_forcing(trmc_plan *plan, int nsteps, const void *qlat, int64_t n
                         const void *q0, const void *boundary_fvd);
 
 /*
+ * The same, with the lateral inflow taken straight from packed WRF-Hydro CHRTOUT columns:
+ * the device decodes, joins on the feature axis and lays the forcing out -- replaces the host-side
+ * get_ql_from_chrtout + DataFrame join (src/troute-network/troute/nhd_io.py:397-434, NHDNetwork.py:376-386).
+ *   raw_a, raw_b  [nq][nfeat] int32, one row per forcing file, file order of the feature axis (qBucket and
+ *                 qSfcLatRunoff; raw_b may be NULL: single variable q_lateral)
+ *   pack_a/b      [6] doubles: scale_factor, add_offset, _FillValue, missing_value, valid_min, valid_max
+ *                 (NaN for a fill value or bound the file does not define)
+ *   feat_of_row   [nseg] position of each row's id on the feature axis, -1 = not in the files (inflow 0)
+ * value = float32( unpack(a) + unpack(b) ), unpack(raw) = 0 where raw is masked (equal to a fill value or outside
+ * the valid range, netCDF4's default auto-mask then .filled(0.0)), else raw * scale_factor + add_offset in double.
+ */
+int trmc_upload_forcing_packed(trmc_plan *plan, int nsteps, int64_t nq, int64_t nfeat, const int32_t *raw_a,
+                               const int32_t *raw_b, const double *pack_a, const double *pack_b,
+                               const int64_t *feat_of_row, const void *q0, const void *boundary_fvd);
+
+/*
  * Supply the boundary rows' flow hydrographs from a DEVICE buffer q_dev[nboundary][nsteps] (ascending
  * boundary row order) after trmc_upload_forcing(..., boundary_fvd = NULL): the multi-GPU hand-off of
  * sub-basin outlet hydrographs to the trunk (reference: flowveldepth_interorder, compute.py:882-897)

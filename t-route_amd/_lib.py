@@ -42,6 +42,7 @@ SIGNATURES = {
     "trmc_plan_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i32), _P(_i32), _P(_i32)]),
     "trmc_plan_levels": (_int, [_vp, _vp, _vp]),
     "trmc_upload_forcing": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
+    "trmc_upload_forcing_packed": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trmc_set_boundary_flow_device": (_int, [_vp, _int, _vp]),
     "trmc_set_reservoirs": (_int, [_vp, _i64, _vp, _vp, C.c_double]),
     "trmc_download_reservoir_inflow": (_int, [_vp, _vp]),

@@ -482,6 +482,40 @@ k_prep_qlat(const T *__restrict__ in, const int32_t *__restrict__ row_of_pos, T 
     }
 }
 
+// forcing from packed CHRTOUT columns: raw_a/raw_b [nq][nfeat] int32 (file order) -> qlat_tm[j][pos], decoding,
+// the join on feature id (feat_of_pos) and the transposition in one pass.  Unpacking follows netCDF4-python's
+// default read (nhd_io.py:397-434 get_ql_from_chrtout: masked where == _FillValue / missing_value or outside the
+// valid range, filled with 0; otherwise raw * scale_factor + add_offset evaluated in double), the sum of the two
+// variables in double, then the reference's cast to float32 (compute.py / qlat_sub.values.astype("float32")).
+struct PackSpec {
+    double scale, offset;
+    int32_t fill1, fill2, vmin, vmax;
+    int32_t use1, use2; // a fill value that is absent from the file arrives as NaN
+};
+__device__ __forceinline__ double unpack_cf(int32_t raw, const PackSpec &k)
+{
+    if ((k.use1 && raw == k.fill1) || (k.use2 && raw == k.fill2) || raw < k.vmin || raw > k.vmax) return 0.0;
+    return (double)raw * k.scale + k.offset;
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_ingest_packed(const int32_t *__restrict__ raw_a, const int32_t *__restrict__ raw_b, const PackSpec ka, const PackSpec kb,
+                const int32_t *__restrict__ feat_of_pos, T *__restrict__ qlat_tm, int32_t nseg, int64_t nseg_pad, int32_t nq,
+                int64_t nfeat)
+{
+    const int32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= nseg) return;
+    const int32_t f = feat_of_pos[p];
+    for (int32_t j = 0; j < nq; ++j) {
+        double v = 0.0;
+        if (f >= 0) {
+            v = unpack_cf(raw_a[(size_t)j * nfeat + f], ka);
+            if (raw_b) v = v + unpack_cf(raw_b[(size_t)j * nfeat + f], kb);
+        }
+        qlat_tm[(size_t)j * nseg_pad + p] = (T)(float)v;
+    }
+}
+
 // initial state: time row 0 <- q0[row] = (qu0, qd0, h0)   (mc_reach.pyx:361)
 template <class T>
 __global__ void __launch_bounds__(kBlock)
@@ -694,6 +728,7 @@ struct trmc_plan {
     DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch, gathered;
     size_t gathered_bytes = 0;
     int64_t nq = 0;
+    bool qlat_direct = false;   // qlat_tm was filled by trmc_upload_forcing_packed: no transpose at route time
     bool have_boundary = true;  // boundary hydrographs present for the staged window
     int32_t staged_nsteps = -1; // nsteps the staged forcing was uploaded for
     int32_t routed_nsteps = -1; // nsteps of the last completed route
@@ -868,8 +903,9 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     // of routed positions by k_mc_step and of boundary positions by k_fill_boundary (the padding
     // lanes of each row are never read), so the reference's zero fill (mc_reach.pyx:253) is moot
     if (n > 0) {
-        hipLaunchKernelGGL((k_prep_qlat<T>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
-                           (const T *)pl->in_qlat.p, row_of_pos, (T *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);
+        if (!pl->qlat_direct)
+            hipLaunchKernelGGL((k_prep_qlat<T>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
+                               (const T *)pl->in_qlat.p, row_of_pos, (T *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);
         hipLaunchKernelGGL((k_init_state<T>), dim3(blocks_for(n)), dim3(kBlock), 0, st, (const T *)pl->in_q0.p,
                            row_of_pos, a.q_tm, a.v_tm, a.d_tm, n);
     }
@@ -1139,22 +1175,12 @@ int trmc_plan_levels(const trmc_plan *pl, int32_t *level_of_row, int64_t *plan_p
     return 0;
 }
 
-int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq, const void *q0,
-                        const void *boundary_fvd)
+// initial state (or warm start), boundary hydrographs, and the bookkeeping common to every forcing upload
+static int stage_state(trmc_plan *pl, int nsteps, int64_t nq, const void *q0, const void *boundary_fvd)
 {
-    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
-    if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
-    if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
-    if (pl->nseg > 0 && !qlat) return fail(TRMC_EINVAL, "qlat is NULL");
-    if (pl->nseg > 0 && !q0 && pl->routed_nsteps < 0)
-        return fail(TRMC_ESTATE, "q0 is NULL (continue from the resident state) but nothing has been routed yet");
-    // boundary_fvd may be NULL here when trmc_set_boundary_flow_device() supplies the hydrographs later
-    if (int rc = use_device(pl)) return rc;
     const size_t e = pl->esz;
-    if (int rc = pl->in_qlat.ensure((size_t)pl->nseg * nq * e)) return rc;
     if (int rc = pl->in_q0.ensure((size_t)pl->nseg * 3 * e)) return rc;
     if (pl->nseg > 0) {
-        HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, (size_t)pl->nseg * nq * e, hipMemcpyHostToDevice, pl->stream));
         if (q0) {
             HIP_TRY(hipMemcpyAsync(pl->in_q0.p, q0, (size_t)pl->nseg * 3 * e, hipMemcpyHostToDevice, pl->stream));
         } else { // warm start in HBM: (q_T, q_T, depth_T) of the previous window, AbstractNetwork.py:182-190
@@ -1184,6 +1210,83 @@ int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq,
     pl->staged_nsteps = nsteps;
     pl->routed_nsteps = -1;
     return 0;
+}
+
+static int upload_check(trmc_plan *pl, int nsteps, int64_t nq, const void *q0)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
+    if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
+    if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
+    if (pl->nseg > 0 && !q0 && pl->routed_nsteps < 0)
+        return fail(TRMC_ESTATE, "q0 is NULL (continue from the resident state) but nothing has been routed yet");
+    return use_device(pl);
+}
+
+int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq, const void *q0,
+                        const void *boundary_fvd)
+{
+    if (int rc = upload_check(pl, nsteps, nq, q0)) return rc;
+    if (pl->nseg > 0 && !qlat) return fail(TRMC_EINVAL, "qlat is NULL");
+    // boundary_fvd may be NULL here when trmc_set_boundary_flow_device() supplies the hydrographs later
+    const size_t e = pl->esz;
+    if (int rc = pl->in_qlat.ensure((size_t)pl->nseg * nq * e)) return rc;
+    if (pl->nseg > 0)
+        HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, (size_t)pl->nseg * nq * e, hipMemcpyHostToDevice, pl->stream));
+    pl->qlat_direct = false;
+    return stage_state(pl, nsteps, nq, q0, boundary_fvd);
+}
+
+int trmc_upload_forcing_packed(trmc_plan *pl, int nsteps, int64_t nq, int64_t nfeat, const int32_t *raw_a,
+                               const int32_t *raw_b, const double *pack_a, const double *pack_b,
+                               const int64_t *feat_of_row, const void *q0, const void *boundary_fvd)
+{
+    if (int rc = upload_check(pl, nsteps, nq, q0)) return rc;
+    if (nfeat < 0 || (pl->nseg > 0 && (!raw_a || !pack_a || !feat_of_row))) return fail(TRMC_EINVAL, "raw_a/pack_a/feat_of_row is NULL");
+    if (raw_b && !pack_b) return fail(TRMC_EINVAL, "pack_b is NULL");
+    if (nfeat > INT32_MAX) return fail(TRMC_EINVAL, "feature axis too long");
+    auto spec = [](const double *k) {
+        PackSpec s;
+        s.scale = k[0];
+        s.offset = k[1];
+        s.use1 = k[2] == k[2];
+        s.use2 = k[3] == k[3];
+        s.fill1 = s.use1 ? (int32_t)k[2] : 0;
+        s.fill2 = s.use2 ? (int32_t)k[3] : 0;
+        s.vmin = k[4] == k[4] ? (int32_t)k[4] : INT32_MIN; // NaN: no lower / upper bound in the file
+        s.vmax = k[5] == k[5] ? (int32_t)k[5] : INT32_MAX;
+        return s;
+    };
+    const PackSpec ka = spec(pack_a), kb = raw_b ? spec(pack_b) : PackSpec{1.0, 0.0, 0, 0, INT32_MIN, INT32_MAX, 0, 0};
+    const int64_t n = pl->nseg;
+    std::vector<int32_t> feat_of_pos((size_t)(n > 0 ? n : 1), -1);
+    for (int64_t p = 0; p < n; ++p) {
+        const int64_t f = feat_of_row[pl->topo.row_of_pos[p]];
+        if (f >= nfeat) return fail(TRMC_EINVAL, "feat_of_row entry outside the feature axis");
+        feat_of_pos[(size_t)p] = f < 0 ? -1 : (int32_t)f;
+    }
+    const size_t raw_bytes = (size_t)nq * (size_t)nfeat * sizeof(int32_t);
+    const size_t pbytes = ((size_t)(n > 0 ? n : 1) * sizeof(int32_t) + 255) / 256 * 256;
+    if (int rc = pl->in_qlat.ensure((raw_b ? 2 : 1) * raw_bytes)) return rc; // staging for the raw columns
+    if (int rc = pl->scratch.ensure(pbytes)) return rc;
+    if (int rc = pl->qlat_tm.ensure((size_t)nq * pl->nseg_pad * pl->esz)) return rc;
+    if (n > 0) {
+        int32_t *da = (int32_t *)pl->in_qlat.p, *db = raw_b ? da + (size_t)nq * nfeat : nullptr;
+        HIP_TRY(hipMemcpyAsync(da, raw_a, raw_bytes, hipMemcpyHostToDevice, pl->stream));
+        if (raw_b) HIP_TRY(hipMemcpyAsync(db, raw_b, raw_bytes, hipMemcpyHostToDevice, pl->stream));
+        HIP_TRY(hipMemcpyAsync(pl->scratch.p, feat_of_pos.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, pl->stream));
+        if (pl->precision == 32)
+            hipLaunchKernelGGL((k_ingest_packed<float>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, da, db, ka, kb,
+                               (const int32_t *)pl->scratch.p, (float *)pl->qlat_tm.p, (int32_t)n, pl->nseg_pad, (int32_t)nq, nfeat);
+        else
+            hipLaunchKernelGGL((k_ingest_packed<double>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, da, db, ka, kb,
+                               (const int32_t *)pl->scratch.p, (double *)pl->qlat_tm.p, (int32_t)n, pl->nseg_pad, (int32_t)nq, nfeat);
+        HIP_TRY(hipGetLastError());
+    }
+    pl->qlat_direct = true;
+    // (feat_of_pos is pageable host memory: the copy above must have been consumed before it goes out of scope;
+    // stage_state ends with a stream synchronisation)
+    return stage_state(pl, nsteps, nq, q0, boundary_fvd);
 }
 
 int trmc_set_boundary_flow_device(trmc_plan *pl, int nsteps, const void *q_dev)

@@ -119,6 +119,35 @@ class RoutingPlan:
                                                   _lib.ptr(bf)))
         self._nsteps = nsteps
 
+    def upload_forcing_packed(self, nsteps, packed, row_ids, q0, boundary_fvd=None):
+        """Forcing straight from packed CHRTOUT columns (``nhd_io.chrtout_packed``): the device decodes, joins
+        on feature id and lays the forcing out.  row_ids: int64 [nseg] id of every row of the table."""
+        feat = np.asarray(packed["feature_id"], dtype=np.int64)
+        row_ids = np.asarray(row_ids, dtype=np.int64)
+        if row_ids.shape != (self.nseg,):
+            raise ValueError("row_ids must be [nseg]")
+        order = np.argsort(feat, kind="stable")
+        where = np.searchsorted(feat[order], row_ids)
+        where = np.clip(where, 0, max(0, feat.shape[0] - 1))
+        hit = feat[order][where] == row_ids if feat.size else np.zeros(self.nseg, dtype=bool)
+        feat_of_row = np.where(hit, order[where], -1).astype(np.int64)
+        raw_a = np.ascontiguousarray(packed["raw_a"], dtype=np.int32)
+        raw_b = None if packed["raw_b"] is None else np.ascontiguousarray(packed["raw_b"], dtype=np.int32)
+        pa = np.ascontiguousarray(packed["pack_a"], dtype=np.float64)
+        pb = None if packed["pack_b"] is None else np.ascontiguousarray(packed["pack_b"], dtype=np.float64)
+        if q0 is not None:
+            q0 = np.ascontiguousarray(q0, dtype=self.dtype)
+            if q0.shape != (self.nseg, 3):
+                raise ValueError("initial_conditions shape mismatch")
+        bf = None
+        if self.nboundary and boundary_fvd is not None:
+            bf = np.ascontiguousarray(boundary_fvd, dtype=self.dtype)
+        _lib.check(_lib.lib().trmc_upload_forcing_packed(
+            self._h, nsteps, raw_a.shape[0], raw_a.shape[1], _lib.ptr(raw_a), _lib.ptr(raw_b), _lib.ptr(pa),
+            _lib.ptr(pb), _lib.ptr(feat_of_row), _lib.ptr(q0), _lib.ptr(bf)))
+        self._nsteps = nsteps
+        return feat_of_row
+
     def set_boundary_flow_device(self, nsteps, device_ptr):
         """Boundary rows' flow hydrographs from a device buffer [nboundary][nsteps] (plan precision)."""
         _lib.check(_lib.lib().trmc_set_boundary_flow_device(self._h, nsteps, C.c_void_p(device_ptr)))

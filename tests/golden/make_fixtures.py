@@ -420,6 +420,31 @@ def nudging_vectors():
         shutil.rmtree(td, ignore_errors=True)
 
 
+def file_format_vectors():
+    """Expected contents of the data files copied from the reference's test tree into
+    tests/golden/lowercolorado_files/ (two CHRTOUT forcing files, the HYDRO_RST restart), read with h5dump --
+    independent of troute_amd.h5 -- plus RouteLink's link ids in file order (the restart's crosswalk)."""
+    import shutil
+    d = f"{REF}/test/LowerColorado_TX"
+    out = os.path.join(HERE, "lowercolorado_files")
+    os.makedirs(out, exist_ok=True)
+    files = sorted(os.listdir(f"{d}/channel_forcing"))[:2]
+    for f in files:
+        shutil.copyfile(f"{d}/channel_forcing/{f}", os.path.join(out, f))
+    rst = "HYDRO_RST.2021-08-23_12:00_DOMAIN1"
+    shutil.copyfile(f"{d}/restart/{rst}", os.path.join(out, rst.replace(":", "_")))
+    exp = {"link": h5var(f"{d}/domain/RouteLink.nc", "link", np.int32)}
+    for v in ("qlink1", "qlink2", "hlink"):
+        exp[v] = h5var(f"{d}/restart/{rst}", v, np.float32)
+    for k, f in enumerate(files):
+        exp[f"feature_id_{k}"] = h5var(f"{d}/channel_forcing/{f}", "feature_id", np.int64)
+        exp[f"qBucket_{k}"] = h5var(f"{d}/channel_forcing/{f}", "qBucket", np.int32)
+        exp[f"qSfcLatRunoff_{k}"] = h5var(f"{d}/channel_forcing/{f}", "qSfcLatRunoff", np.int32)
+        exp[f"streamflow_{k}"] = h5var(f"{d}/channel_forcing/{f}", "streamflow", np.int32)
+    np.savez_compressed(os.path.join(HERE, "lowercolorado_files_expected.npz"), **exp)
+    print("lowercolorado_files_expected.npz:", {k: v.shape for k, v in exp.items()})
+
+
 def import_ref_compute(nn):
     """The reference's routing/compute.py, for its pure-pandas helpers.  The modules it imports that cannot exist
     here (compiled Cython extensions, the diffusive utilities) are replaced by empty stand-ins: none of them is
@@ -501,6 +526,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "da_prep":
         da_prep_vectors(import_ref_nhd_network())
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "files":
+        file_format_vectors()
+        sys.exit(0)
     O.build()
     nudging_vectors()
     nn = import_ref_nhd_network()
@@ -508,3 +536,4 @@ if __name__ == "__main__":
     toy_network(nn)
     lowercolorado(nn)
     da_prep_vectors(nn)
+    file_format_vectors()

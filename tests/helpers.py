@@ -46,6 +46,12 @@ class LowerColorado:
         ups = [np.array([row[s] for s in self.rconn.get(r[0], [])], dtype=np.int64) for r in self.reaches]
         return reaches, ups
 
+    def csr(self):
+        """upstream rows per row (reference summation order) as CSR arrays for RoutingPlan"""
+        from troute_amd.plan import csr_from_lists
+        row = {int(s): i for i, s in enumerate(self.ids)}
+        return csr_from_lists([[row[u] for u in self.rconn.get(int(s), [])] for s in self.ids])
+
     def golden(self):
         return np.load(os.path.join(GOLDEN, "lowercolorado_golden.npz"))
 
