@@ -25,6 +25,13 @@ import os
 import sys
 import time
 
+# Before any HIP runtime is loaded: at most two hardware queues for ordinary-priority streams (the exchange stream,
+# RCCL's).  With the ROCm 7.2 default of four, a stream of another hardware queue waiting on events of the plan's
+# stream intermittently put that stream's launches in a slow mode (17 ms instead of 6.4 ms per 340 k-row rank,
+# depending on which queue the waiting stream happened to get: tools/sim_ranks.py); one or two
+# queues never did, and the single-GPU path (priority streams only) is unaffected either way.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
