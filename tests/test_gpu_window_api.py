@@ -1,0 +1,168 @@
+"""The routing window in parts (trmc_route_begin / _advance / _end), row sets, ranged gather / boundary feed and
+time-skewed rows (trmc_plan_set_lag) on one GPU: equal to the one-call route bit for bit, call-order errors
+reported as RuntimeError / ValueError instead of undefined behaviour."""
+import numpy as np
+import pytest
+
+try:                      # before libtrmc.so is loaded: torch ships its own HIP runtime (see conftest.py)
+    import torch
+except Exception:         # pragma: no cover
+    torch = None
+
+import helpers as H
+from troute_amd import _lib
+from troute_amd.plan import RoutingPlan, csr_from_lists
+
+pytestmark = pytest.mark.gpu
+
+
+def small_forest(seed=2, nseg=3000):
+    rng = np.random.default_rng(seed)
+    to = H.random_network(rng, nseg)
+    _, _, ups = H.reaches_from_to(to)
+    up_ptr, up_idx = csr_from_lists(ups)
+    p = np.stack([np.full(nseg, 300.0), rng.uniform(300, 3000, nseg), rng.uniform(1, 9, nseg), np.zeros(nseg), np.zeros(nseg),
+                  np.full(nseg, 0.06), np.full(nseg, 0.12), rng.uniform(0.2, 1.5, nseg), rng.uniform(1e-3, 2e-2, nseg)], 1)
+    p[:, 3] = p[:, 2] * 5 / 3
+    p[:, 4] = 3 * p[:, 3]
+    qlat = rng.uniform(0, 0.4, (nseg, 4)).astype(np.float32)
+    q0 = rng.uniform(0, 1, (nseg, 3)).astype(np.float32)
+    return to, ups, up_ptr, up_idx, p.astype(np.float32), qlat, q0
+
+
+@pytest.mark.parametrize("short", [True, False])
+def test_window_in_parts_equals_one_call(short):
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest()
+    nsteps, qts = 40, 12
+    with RoutingPlan(up_ptr, up_idx, p) as plan:
+        want = plan.route(nsteps, qts, short, qlat, q0)
+        plan.upload_forcing(nsteps, qlat, q0)
+        plan.route_begin(nsteps, qts, short)
+        rows = np.array([5, 17, 2999, 0], np.int64)
+        rs = plan.rowset(rows)
+        buf = torch.zeros((4, nsteps), dtype=torch.float32, device="cuda")
+        done = 0
+        for t_end in (1, 1, 7, 23, 40):                      # uneven chunks, one empty
+            plan.route_advance(t_end)
+            plan.gather_flow_range(rs, done, t_end, buf[:, done:].data_ptr(), nsteps)
+            done = t_end
+        st = plan.route_end()
+        assert st["nsteps"] == nsteps and st["main_launches"] >= nsteps
+        got = plan.download_fvd()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(buf.cpu().numpy().view(np.uint32), want[rows, :, 0].view(np.uint32))
+
+
+def test_call_order_errors():
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=200)
+    with RoutingPlan(up_ptr, up_idx, p) as plan:
+        with pytest.raises(RuntimeError, match="trmc_upload_forcing must precede"):
+            plan.route_begin(12, 12, True)
+        plan.upload_forcing(12, qlat, q0)
+        with pytest.raises(RuntimeError, match="trmc_route_begin must precede"):
+            plan.route_advance(3)
+        with pytest.raises(RuntimeError, match="no routing window"):
+            plan.route_end()
+        plan.route_begin(12, 12, True)
+        with pytest.raises(RuntimeError, match="already in progress"):
+            plan.route_begin(12, 12, True)
+        with pytest.raises(RuntimeError, match="in progress"):
+            plan.upload_forcing(12, qlat, q0)
+        with pytest.raises(ValueError, match="t_end outside"):
+            plan.route_advance(13)
+        plan.route_advance(5)
+        with pytest.raises(ValueError, match="t_end outside"):
+            plan.route_advance(4)
+        rs = plan.rowset(np.array([0], np.int64))
+        with pytest.raises(RuntimeError, match="not all routed"):
+            plan.gather_flow_range(rs, 0, 6, 1, 6)
+        with pytest.raises(ValueError, match="unknown row set"):
+            plan.gather_flow_range(99, 0, 5, 1, 5)
+        with pytest.raises(RuntimeError, match="window abandoned"):
+            plan.route_end()                                  # not every step queued: abandoned, plan reusable
+        with pytest.raises(RuntimeError, match="nothing routed"):
+            plan.download_fvd()
+        plan.route_device(12, 12, True)                       # and it is
+        assert np.isfinite(plan.download_fvd()).all()
+        with pytest.raises(ValueError, match="row out of range"):
+            plan.rowset(np.array([200], np.int64))
+
+
+def test_time_skewed_rows_equal_two_phase_routing():
+    """A chain 0..9 feeding (through a cut) a chain 10..19: routing both in one plan with the lower chain lagged
+    and its boundary values supplied chunk by chunk equals routing them one after the other."""
+    n = 10
+    rng = np.random.default_rng(7)
+    p = np.stack([np.full(2 * n, 300.0), rng.uniform(300, 3000, 2 * n), rng.uniform(1, 9, 2 * n), np.zeros(2 * n),
+                  np.zeros(2 * n), np.full(2 * n, 0.06), np.full(2 * n, 0.12), rng.uniform(0.2, 1.5, 2 * n),
+                  rng.uniform(1e-3, 2e-2, 2 * n)], 1)
+    p[:, 3] = p[:, 2] * 5 / 3
+    p[:, 4] = 3 * p[:, 3]
+    p = p.astype(np.float32)
+    qlat = rng.uniform(0, 0.4, (2 * n, 3)).astype(np.float32)
+    q0 = rng.uniform(0, 1, (2 * n, 3)).astype(np.float32)
+    nsteps, qts, K = 30, 12, 4
+    # reference: the whole chain in one ordinary plan
+    ups = [[]] + [[i - 1] for i in range(1, 2 * n)]
+    with RoutingPlan(*csr_from_lists(ups), p) as plan:
+        want = plan.route(nsteps, qts, True, qlat, q0)
+    # merged table: rows 0..9 upper chain, row 10 = boundary copy of row 9, rows 11..20 = lower chain (lag 2K)
+    ups_m = [[]] + [[i - 1] for i in range(1, n)] + [[]] + [[n]] + [[i - 1] for i in range(n + 2, 2 * n + 1)]
+    sel = list(range(n)) + [n - 1] + list(range(n, 2 * n))
+    boundary = np.zeros(2 * n + 1, np.uint8)
+    boundary[n] = 1
+    lag = np.zeros(2 * n + 1, np.int32)
+    lag[n + 1:] = 2 * K
+    with RoutingPlan(*csr_from_lists(ups_m), p[sel], boundary) as plan:
+        with pytest.raises(ValueError, match="0 or one common value"):
+            plan.set_lag(np.arange(2 * n + 1, dtype=np.int32))
+        bad = lag.copy()
+        bad[:n] = 2 * K
+        bad[n + 1:] = 0
+        with pytest.raises(ValueError, match="lagged row feeds|boundary rows may only feed"):
+            plan.set_lag(bad)
+        plan.set_lag(lag)
+        plan.upload_forcing(nsteps, qlat[sel], q0[sel], None)
+        with pytest.raises(ValueError, match="assume_short_ts only"):
+            plan.route_begin(nsteps, qts, False)
+        plan.route_begin(nsteps, qts, True)
+        rs = plan.rowset(np.array([n - 1], np.int64))
+        last = nsteps + 2 * K
+        C_ = -(-nsteps // K)
+        bufs = []
+        c = 0
+        with pytest.raises(RuntimeError, match="boundary hydrographs are staged through"):
+            plan.route_advance(last)
+        while True:
+            d_end = min((c + 1) * K, last)
+            plan.route_advance(d_end)
+            if c < C_:
+                tb, te = c * K, min(nsteps, (c + 1) * K)
+                b = torch.zeros((1, te - tb), dtype=torch.float32, device="cuda")
+                plan.gather_flow_range(rs, tb, te, b.data_ptr(), te - tb)
+                plan.set_boundary_flow_range(tb, te, b.data_ptr(), te - tb)
+                bufs.append(b)
+            if d_end >= last:
+                break
+            c += 1
+        st = plan.route_end()
+        assert st["main_launches"] == last
+        got = plan.download_fvd()
+    assert np.array_equal(got[:n].view(np.uint32), want[:n].view(np.uint32))
+    assert np.array_equal(got[n + 1:].view(np.uint32), want[n:].view(np.uint32))
+
+
+def test_packed_forcing_argument_errors():
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=50)
+    lib = _lib.lib()
+    with RoutingPlan(up_ptr, up_idx, p) as plan:
+        raw = np.zeros((2, 60), np.int32)
+        pk = np.array([1e-5, 0, np.nan, np.nan, np.nan, np.nan])
+        feat = np.arange(50, dtype=np.int64)
+        feat[3] = 60                                          # outside the feature axis
+        rc = lib.trmc_upload_forcing_packed(plan._h, 12, 2, 60, _lib.ptr(raw), None, _lib.ptr(pk), None, _lib.ptr(feat),
+                                            _lib.ptr(q0), None)
+        assert rc == _lib.TRMC_EINVAL and b"feature axis" in lib.trmc_last_error()
+        rc = lib.trmc_upload_forcing_packed(plan._h, 12, 2, 60, _lib.ptr(raw), _lib.ptr(raw), _lib.ptr(pk), None,
+                                            _lib.ptr(np.arange(50, dtype=np.int64)), _lib.ptr(q0), None)
+        assert rc == _lib.TRMC_EINVAL and b"pack_b" in lib.trmc_last_error()
