@@ -1,0 +1,61 @@
+// TEST INFRASTRUCTURE ONLY -- host instantiation of the diffusive-wave solver (t-route_amd/csrc/diffusive_core.hpp,
+// the same source the HIP kernel compiles) behind the argument list of the reference's c_diffnw
+// (src/kernel/diffusive/pydiffusive.f90:8-55).  Built with libm and without FMA contraction; validated against the
+// reference Fortran built from its own sources (oracle/_ref/libdiff_ref.so) by tests/test_diffusive.py.
+#include <stdlib.h>
+#include <string.h>
+
+#include "../t-route_amd/csrc/diffusive_core.hpp"
+
+extern "C" int dw_oracle_diffnw(
+    const double *timestep_ar_g, const int *nts_ql_g, const int *nts_ub_g, const int *nts_db_g, const int *ntss_ev_g,
+    const int *nts_qtrib_g, const int *nts_da_g, const int *mxncomp_g, const int *nrch_g, const double *z_ar_g,
+    const double *bo_ar_g, const double *traps_ar_g, const double *tw_ar_g, const double *twcc_ar_g, const double *mann_ar_g,
+    const double *manncc_ar_g, const double *so_ar_g, const double *dx_ar_g, const double *iniq, const int *frnw_col,
+    const int *frnw_ar_g, const double *qlat_g, const double *ubcd_g, const double *dbcd_g, const double *qtrib_g,
+    const int *paradim, const double *para_ar_g, const int *mxnbathy_g, const double *x_bathy_g, const double *z_bathy_g,
+    const double *mann_bathy_g, const int *size_bathy_g, const double *usgs_da_g, const int *usgs_da_reach_g,
+    const double *rdx_ar_g, const int *cwnrow_g, const int *cwncol_g, const double *crosswalk_g, const double *z_thalweg_g,
+    double *q_ev_g, double *elv_ev_g, double *depth_ev_g)
+{
+    (void)nts_da_g; (void)so_ar_g; (void)ubcd_g; (void)paradim; (void)x_bathy_g; (void)z_bathy_g; (void)mann_bathy_g;
+    (void)size_bathy_g; (void)usgs_da_g; (void)usgs_da_reach_g; (void)rdx_ar_g; (void)cwncol_g; (void)crosswalk_g;
+    (void)z_thalweg_g;
+    if (*mxnbathy_g != 0 || *cwnrow_g != 0) return -1; // natural sections / crosswalk: not covered
+    trdw::Problem p;
+    memset(&p, 0, sizeof p);
+    p.timestep_ar = timestep_ar_g;
+    p.nts_ql = *nts_ql_g; p.nts_ub = *nts_ub_g; p.nts_db = *nts_db_g; p.ntss_ev = *ntss_ev_g; p.nts_qtrib = *nts_qtrib_g;
+    p.nts_da = *nts_da_g; p.mxncomp = *mxncomp_g; p.nrch = *nrch_g;
+    p.z_ar = z_ar_g; p.bo_ar = bo_ar_g; p.traps_ar = traps_ar_g; p.tw_ar = tw_ar_g; p.twcc_ar = twcc_ar_g;
+    p.mann_ar = mann_ar_g; p.manncc_ar = manncc_ar_g; p.dx_ar = dx_ar_g; p.iniq = iniq;
+    p.frnw_col = *frnw_col; p.frnw = frnw_ar_g; p.qlat = qlat_g; p.dbcd = dbcd_g; p.qtrib = qtrib_g; p.para_ar = para_ar_g;
+    p.q_ev = q_ev_g; p.elv_ev = elv_ev_g; p.depth_ev = depth_ev_g;
+    const long long nout = (long long)p.ntss_ev * p.mxncomp * p.nrch;
+    for (long long e = 0; e < nout; ++e) q_ev_g[e] = elv_ev_g[e] = depth_ev_g[e] = 0.0;
+    double *w = (double *)calloc((size_t)trdw::work_doubles(p.mxncomp, p.nrch, p.nts_ql, p.nts_qtrib, p.nts_db), sizeof(double));
+    int32_t *frj = (int32_t *)calloc((size_t)p.nrch + 1, sizeof(int32_t));
+    if (!w || !frj) return -2;
+    trdw::bind_work(p, w);
+    p.mstem_frj = frj;
+    const double minDx = trdw::setup_scalars(p);
+    // tables of every mainstem node; the node's bed elevation becomes the notch of its section
+    for (int m = 0; m < p.nmstem; ++m) {
+        const int j = p.mstem_frj[m], ncomp = p.frnw[(j - 1) + 0];
+        for (int k = 1; k <= ncomp; ++k) {
+            trdw::Section s;
+            trdw::make_section(p, k, j, s);
+            for (int l = 1; l <= trdw::kNel; ++l) trdw::table_row(p, s, k, j, l);
+            p.z[(k - 1) + (long long)(j - 1) * p.mxncomp] = s.el_min;
+        }
+    }
+    for (int m = 0; m < p.nmstem; ++m) {
+        const int j = p.mstem_frj[m], ncomp = p.frnw[(j - 1) + 0];
+        for (int k = 1; k <= ncomp; ++k)
+            for (int l = trdw::kNel; l >= 1; --l) trdw::table_row_finish(p, k, j, l);
+    }
+    trdw::solve(p, minDx);
+    free(w);
+    free(frj);
+    return 0;
+}

@@ -1,0 +1,731 @@
+// diffusive_core.hpp -- diffusive-wave routing of a mainstem network (Crank-Nicolson + Hermite interpolation
+// for the flow, a Newton/bisection depth solve per node), precision double, host/device neutral.
+//
+// Semantics follow the reference Fortran (paths relative to the T-Route tree), synthetic cross sections only:
+//   src/kernel/diffusive/diffusive.f90
+//     diffnw :75-940 (set-up :261-560, ordered time loop :632-870), calculateDT :942-991,
+//     mesh_diffusive_forward :1108-1355, mesh_diffusive_backward :1357-1553, rtsafe :1555-1662,
+//     funcd_diffdepth :1664-1711, intp_xsec_tab :1713-1754, readXsection :2093-2443 (RouteLink trapezoid +
+//     flood plain), the geometry helpers :2445-2520, r_interpol :2553-2594, LInterpol / intp_y / locate :2650-2755
+// The boundary is the bind(c) symbol c_diffnw (src/kernel/diffusive/pydiffusive.f90:8-55): same arguments,
+// Fortran (column-major) arrays.
+//
+// Not covered (the entry point refuses them): natural cross sections (mxnbathy_g > 0,
+// readXsection_natural_mann_vertices :1756-2091) and the refactored-hydrofabric crosswalk (cwnrow_g > 0, :873-925).
+// The streamflow-DA branch is commented out in the reference itself (:1301-1327).
+//
+// Layout of the computation (not of the reference's call tree):
+//   * tables     per node, 501 water elevations x the 8 hydraulic columns the solver reads; independent per
+//                (node, level): table_row() -- the only data-parallel part, one thread per (node, level);
+//   * the ordered time loop is a recurrence over (sub-step, reach, node): solve() runs it in one thread.
+// Single-precision literals of the Fortran source that are not exactly representable are written as float
+// literals here (0.01f, 0.3f, ...): they enter the double arithmetic with their single-precision value.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DW_HD __host__ __device__
+#else
+#define DW_HD
+#endif
+
+namespace trdw {
+
+constexpr int kNel = 501;   // rows of every lookup table (diffnw :275)
+constexpr int kCols = 8;    // columns kept per table row
+// column ids of the reference's xsec_tab (1 elevation, 2 area, 3 perimeter, 5 conveyance, 6 top width,
+// 9 dK/dA, 10 uniform flow, 11 compound 1/n) -> slot in this table
+enum { C_ELEV = 0, C_AREA, C_PERI, C_CONV, C_TOPW, C_DKDA, C_UNIF, C_SKK };
+
+struct Problem {
+    // ---- the c_diffnw arguments (column-major) -------------------------------------------------------------
+    const double *timestep_ar;
+    int nts_ql, nts_ub, nts_db, ntss_ev, nts_qtrib, nts_da, mxncomp, nrch;
+    const double *z_ar, *bo_ar, *traps_ar, *tw_ar, *twcc_ar, *mann_ar, *manncc_ar, *dx_ar, *iniq;
+    int frnw_col;
+    const int32_t *frnw;
+    const double *qlat, *dbcd, *qtrib;
+    const double *para_ar;
+    double *q_ev, *elv_ev, *depth_ev;
+    // ---- work space (caller allocated; sizes in work_doubles()) ---------------------------------------------
+    double *tab;            // [nrch*mxncomp][kCols][kNel]
+    double *z, *dx, *bo, *sk, *pere, *celerity, *diffusivity, *qpx, *qp, *oldQ, *newQ, *oldArea, *newArea, *oldY, *newY,
+        *lateralFlow;                                        // [mxncomp*nrch] each
+    double *eei, *ffi, *exi, *fxi, *celerity2, *diffusivity2, *co; // [mxncomp] each
+    double *tarr_ql, *varr_ql, *tarr_qtrib, *varr_qtrib, *tarr_db, *varr_db;
+    int32_t *mstem_frj;     // [nrch]
+    int nmstem;
+    // ---- scalars of diffnw ------------------------------------------------------------------------------------
+    double dtini, dtini_min, cfl, C_llm, D_llm, D_ulm, q_llm, so_llm, theta;
+    int dsbc_option;
+};
+
+DW_HD inline int64_t work_doubles(int mxncomp, int nrch, int nts_ql, int nts_qtrib, int nts_db)
+{
+    const int64_t nn = (int64_t)mxncomp * nrch;
+    return nn * kCols * kNel + 16 * nn + 7 * (int64_t)mxncomp + 2 * ((int64_t)nts_ql + 1) + 2 * (int64_t)nts_qtrib
+           + 2 * (int64_t)nts_db + 8;
+}
+
+// carve the work space out of one allocation
+DW_HD inline void bind_work(Problem &p, double *w)
+{
+    const int64_t nn = (int64_t)p.mxncomp * p.nrch;
+    p.tab = w; w += nn * kCols * kNel;
+    double **grid[] = {&p.z, &p.dx, &p.bo, &p.sk, &p.pere, &p.celerity, &p.diffusivity, &p.qpx, &p.qp, &p.oldQ, &p.newQ,
+                       &p.oldArea, &p.newArea, &p.oldY, &p.newY, &p.lateralFlow};
+    for (int k = 0; k < 16; ++k) { *grid[k] = w; w += nn; }
+    double **line[] = {&p.eei, &p.ffi, &p.exi, &p.fxi, &p.celerity2, &p.diffusivity2, &p.co};
+    for (int k = 0; k < 7; ++k) { *line[k] = w; w += p.mxncomp; }
+    p.tarr_ql = w; w += p.nts_ql + 1;
+    p.varr_ql = w; w += p.nts_ql + 1;
+    p.tarr_qtrib = w; w += p.nts_qtrib;
+    p.varr_qtrib = w; w += p.nts_qtrib;
+    p.tarr_db = w; w += p.nts_db;
+    p.varr_db = w; w += p.nts_db;
+}
+
+// 1-based accessors in the reference's index order
+#define DW_G(a, i, j) (a)[((i) - 1) + (int64_t)((j) - 1) * p.mxncomp]
+#define DW_FRNW(j, c) p.frnw[((j) - 1) + (int64_t)((c) - 1) * p.nrch]
+#define DW_TAB(col, iel, i, j) p.tab[((((int64_t)((j) - 1) * p.mxncomp + ((i) - 1)) * kCols + (col)) * kNel) + ((iel) - 1)]
+#define DW_EV(a, ts, i, j) (a)[((ts) - 1) + (int64_t)p.ntss_ev * (((i) - 1) + (int64_t)p.mxncomp * ((j) - 1))]
+
+DW_HD inline double dmax(double a, double b) { return a > b ? a : b; }
+DW_HD inline double dmin(double a, double b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------------------------------------ interpolation
+// Numerical Recipes' locate (:2715-2753): j with x between xx(j) and xx(j+1); 0 / n out of range.  xx 0-based here.
+DW_HD inline int locate(const double *xx, int n, double x)
+{
+    const bool ascnd = xx[n - 1] >= xx[0];
+    int jl = 0, ju = n + 1;
+    while (ju - jl > 1) {
+        const int jm = (ju + jl) / 2;
+        if (ascnd == (x >= xx[jm - 1])) jl = jm; else ju = jm;
+    }
+    if (x == xx[0]) return 1;
+    if (x == xx[n - 1]) return n - 1;
+    return jl;
+}
+DW_HD inline double linterpol(double x1, double y1, double x2, double y2, double x)
+{
+    if (fabs(x2 - x1) < (double)0.0001f) return 0.5 * (y1 + y2);       // :2660-2666
+    return (y2 - y1) / (x2 - x1) * (x - x1) + y1;
+}
+DW_HD inline double intp_y(int n, const double *xarr, const double *yarr, double x)
+{
+    int irow = locate(xarr, n, x);
+    if (irow == 0) irow = 1;
+    if (irow == n) irow = n - 1;
+    return linterpol(xarr[irow - 1], yarr[irow - 1], xarr[irow], yarr[irow], x);
+}
+// r_interpol (:2553-2594): first bracketing interval from the left; beyond the top: extrapolate; below: min(y)
+DW_HD inline double r_interpol(const double *x, const double *y, int kk, double xrt)
+{
+    double xmax = x[0], xmin = x[0];
+    for (int k = 1; k < kk; ++k) { xmax = dmax(xmax, x[k]); xmin = dmin(xmin, x[k]); }
+    if (xrt <= xmax && xrt >= xmin) {
+        for (int k = 0; k < kk - 1; ++k)
+            if ((x[k] - xrt) * (x[k + 1] - xrt) <= 0.0) return (xrt - x[k]) / (x[k + 1] - x[k]) * (y[k + 1] - y[k]) + y[k];
+        return 0.0; // (not reached for a table that brackets xrt)
+    }
+    if (xrt >= xmax) return (xrt - x[kk - 2]) / (x[kk - 1] - x[kk - 2]) * (y[kk - 1] - y[kk - 2]) + y[kk - 2];
+    double ymin = y[0];
+    for (int k = 1; k < kk; ++k) ymin = dmin(ymin, y[k]);
+    return ymin;
+}
+DW_HD inline double intp_tab(const Problem &p, int i, int j, int xcol, int ycol, double x)
+{
+    const double *xa = &DW_TAB(xcol, 1, i, j), *ya = &DW_TAB(ycol, 1, i, j);
+    return intp_y(kNel, xa, ya, x);
+}
+
+// ------------------------------------------------------------------------------------------------ cross sections
+DW_HD inline double cal_tri_area(double el, double x0, double x1, double y1) { return fabs(0.5 * (x1 - x0) * (el - y1)); }
+DW_HD inline double cal_dist(double x1, double y1, double x2, double y2)
+{
+    return sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (double)1.e-32f);
+}
+// vertices (1-based arrays of 8) i1..i2
+DW_HD inline double cal_multi_area(double el, const double *xx, const double *yy, int i1, int i2)
+{
+    double area = 0.0;
+    for (int i = i1; i <= i2 - 1; ++i) area = area + fabs(0.5 * (xx[i + 1] - xx[i]) * (el - yy[i] + el - yy[i + 1]));
+    return area;
+}
+DW_HD inline double cal_perimeter(const double *xx, const double *yy, int i1, int i2)
+{
+    double pp = 0.0;
+    for (int i = i1; i <= i2 - 1; ++i) pp = pp + cal_dist(xx[i], yy[i], xx[i + 1], yy[i + 1]);
+    return pp;
+}
+
+// The three sub-sections (left flood plain, main channel, right flood plain) of the RouteLink trapezoid with
+// compound channel, as vertex lists, and the elevation grid of the table (readXsection :2148-2262).
+struct Section {
+    double xs[3][9], ys[3][9]; // 1-based vertices per sub-section
+    int num[3];
+    double mann[3];
+    double el_min;             // lowest point (the 1 cm notch): becomes the node's bed elevation z
+    double el_range, el_incr, elev5;
+};
+DW_HD inline void make_section(const Problem &p, int k, int jr, Section &s)
+{
+    const double timesDepth = 4.0;
+    const double z_g = DW_G(p.z_ar, k, jr), bo_g = DW_G(p.bo_ar, k, jr), traps_g = DW_G(p.traps_ar, k, jr);
+    const double tw_g = DW_G(p.tw_ar, k, jr), twcc_g = DW_G(p.twcc_ar, k, jr);
+    const double hbf = (tw_g - bo_g) / (2.0 * traps_g);
+    double xcs[9], ycs[9];
+    xcs[1] = 0.0;                       ycs[1] = z_g + timesDepth * hbf;
+    xcs[2] = 0.0;                       ycs[2] = z_g + hbf;
+    xcs[3] = (twcc_g - tw_g) / 2.0;     ycs[3] = z_g + hbf;
+    xcs[4] = xcs[3] + traps_g * hbf;    ycs[4] = z_g;
+    xcs[5] = xcs[4] + bo_g;             ycs[5] = z_g;
+    xcs[6] = xcs[5] + traps_g * hbf;    ycs[6] = z_g + hbf;
+    xcs[7] = twcc_g;                    ycs[7] = z_g + hbf;
+    xcs[8] = xcs[7];                    ycs[8] = z_g + timesDepth * hbf;
+    double el_min = (double)99999.f, el_max = -(double)99999.f;
+    for (int i = 2; i <= 8; ++i) {   // (the reference's loop bound is its vertex counter after the loop: 2..8)
+        if (ycs[i] < el_min) el_min = ycs[i];
+        if (ycs[i] > el_max) el_max = ycs[i];
+    }
+    const double el_range = (el_max - el_min) * 2.0;
+    const double top = el_min + el_range + 1.0;
+    // left flood plain
+    s.xs[0][1] = xcs[1]; s.ys[0][1] = top;
+    for (int i = 1; i <= 3; ++i) { s.xs[0][i + 1] = xcs[i]; s.ys[0][i + 1] = ycs[i]; }
+    s.xs[0][5] = xcs[3]; s.ys[0][5] = top;
+    // main channel (with the 1 cm notch at mid-bottom)
+    s.xs[1][1] = xcs[3]; s.ys[1][1] = top;
+    for (int i = 3; i <= 4; ++i) { s.xs[1][i - 1] = xcs[i]; s.ys[1][i - 1] = ycs[i]; }
+    for (int i = 5; i <= 6; ++i) { s.xs[1][i] = xcs[i]; s.ys[1][i] = ycs[i]; }
+    s.xs[1][7] = xcs[6]; s.ys[1][7] = top;
+    s.xs[1][4] = (s.xs[1][3] + s.xs[1][5]) / 2.0;
+    s.ys[1][4] = s.ys[1][3] - (double)0.01f;
+    // right flood plain
+    for (int i = 6; i <= 8; ++i) { s.xs[2][i - 4] = xcs[i]; s.ys[2][i - 4] = ycs[i]; }
+    s.xs[2][1] = s.xs[2][2]; s.ys[2][1] = top;
+    s.xs[2][5] = s.xs[2][4]; s.ys[2][5] = top;
+    s.num[0] = 5; s.num[1] = 7; s.num[2] = 5;
+    s.mann[0] = 1.0 / (1.0 / DW_G(p.manncc_ar, k, jr)); // lftBnkMann = 1/skLeft, skLeft = 1/manncc (:445-452)
+    s.mann[1] = 1.0 / (1.0 / DW_G(p.mann_ar, k, jr));
+    s.mann[2] = s.mann[0];
+    s.el_min = s.ys[1][4];
+    s.el_range = el_range;
+    s.elev5 = s.el_min + (double)0.01f;
+    s.el_incr = el_range / (double)(float)(kNel - 6.0f);
+}
+DW_HD inline double table_elev(const Section &s, int j) // elev(j), j = 1..nel (:2250-2262)
+{
+    if (j == 1) return s.el_min;
+    if (j == 2) return s.el_min + (double)(0.01f / 4.f);
+    if (j == 3) return s.el_min + (double)(0.01f / 4.f * 2.f);
+    if (j == 4) return s.el_min + (double)(0.01f / 4.f * 3.f);
+    if (j == 5) return s.elev5;
+    return s.elev5 + s.el_incr * (double)(float)(j - 5);
+}
+// wetted area, perimeter, conveyance and top width of sub-section kkk at table level j (:2270-2352)
+DW_HD inline void subsection_at(const Section &s, int kkk, int j, double &el_out, double &area, double &peri, double &conv,
+                                double &topw)
+{
+    const double TOL = (double)1e-8f;
+    const double *xcs = s.xs[kkk], *ycs = s.ys[kkk];
+    const int num = s.num[kkk];
+    double el_now = table_elev(s, j);
+    if (fabs(el_now - s.el_min) < TOL) el_now = el_now + (double)0.00001f;
+    int i_start[8], i_end[8], i_area = 0, i_find = 0;
+    i_start[1] = -999; i_end[1] = -999;
+    for (int i = 1; i <= num - 1; ++i) {
+        const double y1 = ycs[i], y2 = ycs[i + 1];
+        if (el_now <= y1 && el_now > y2 && i_find == 0) { i_find = 1; ++i_area; i_start[i_area] = i; }
+        if (el_now > y1 && el_now <= y2 && i_find == 1) { i_find = 0; i_end[i_area] = i; }
+    }
+    double cal_area = 0.0, cal_peri = 0.0, cal_topW = 0.0;
+    for (int i = 1; i <= i_area; ++i) {
+        double x1 = xcs[i_start[i]], x2 = xcs[i_start[i] + 1], y1 = ycs[i_start[i]], y2 = ycs[i_start[i] + 1];
+        const double x_start = (y1 == y2) ? x1 : x1 + (el_now - y1) / (y2 - y1) * (x2 - x1);
+        x1 = xcs[i_end[i]]; x2 = xcs[i_end[i] + 1]; y1 = ycs[i_end[i]]; y2 = ycs[i_end[i] + 1];
+        const double x_end = (y1 == y2) ? x1 : x1 + (el_now - y1) / (y2 - y1) * (x2 - x1);
+        cal_topW = x_end - x_start + cal_topW;
+        const int i1 = i_start[i], i2 = i_end[i];
+        cal_area = cal_area + cal_tri_area(el_now, x_start, xcs[i1 + 1], ycs[i1 + 1]) + cal_multi_area(el_now, xcs, ycs, i1 + 1, i2)
+                   + cal_tri_area(el_now, x_end, xcs[i2], ycs[i2]);
+        cal_peri = cal_peri + cal_dist(x_start, el_now, xcs[i1 + 1], ycs[i1 + 1]) + cal_perimeter(xcs, ycs, i1 + 1, i2)
+                   + cal_dist(x_end, el_now, xcs[i2], ycs[i2]);
+        if (i1 == 1) cal_peri = cal_peri - cal_dist(x_start, el_now, xcs[i1 + 1], ycs[i1 + 1]);
+        if (i2 == num - 1) cal_peri = cal_peri - cal_dist(x_end, el_now, xcs[i2], ycs[i2]);
+    }
+    el_out = el_now;
+    area = cal_area;
+    peri = cal_peri;
+    double redi = area / peri;
+    conv = 1.0 / s.mann[kkk] * area * pow(redi, (double)(2.f / 3.f));
+    if (peri <= TOL) conv = 0.0;
+    topw = cal_topW;
+}
+
+// One table row (node k of reach jr, level j): the columns that depend on this level only; dK/dA needs level
+// j-1 too and is formed from the sums stored here (table_row_finish).  sums[0..2] = total area, perimeter, conveyance.
+DW_HD inline void table_row(Problem &p, const Section &s, int k, int jr, int j)
+{
+    double el1 = 0.0, a[3], pe[3], cv[3], tw[3];
+    for (int kkk = 0; kkk < 3; ++kkk) {
+        double el;
+        subsection_at(s, kkk, j, el, a[kkk], pe[kkk], cv[kkk], tw[kkk]);
+        if (kkk == 0) el1 = el;
+    }
+    const double sa = (a[0] + a[1]) + a[2], sp = (pe[0] + pe[1]) + pe[2], sc = (cv[0] + cv[1]) + cv[2];
+    const double lm = s.mann[0], mm = s.mann[1], rm = s.mann[2];
+    const double compoundMann = sqrt((fabs(pe[0]) * (lm * lm) + fabs(pe[1]) * (mm * mm) + fabs(pe[2]) * (rm * rm))
+                                     / (fabs(pe[0]) + fabs(pe[1]) + fabs(pe[2])));
+    DW_TAB(C_ELEV, j, k, jr) = el1;
+    DW_TAB(C_AREA, j, k, jr) = sa;
+    DW_TAB(C_PERI, j, k, jr) = sp;
+    DW_TAB(C_CONV, j, k, jr) = sc;
+    DW_TAB(C_TOPW, j, k, jr) = fabs(tw[0]) + fabs(tw[1]) + fabs(tw[2]);
+    DW_TAB(C_SKK, j, k, jr) = 1.0 / compoundMann;
+}
+// dK/dA (:2395-2401) and the uniform-flow column (:470-486), after every row of the node exists and z is final
+DW_HD inline void table_row_finish(Problem &p, int k, int jr, int j)
+{
+    const double sa = DW_TAB(C_AREA, j, k, jr), sc = DW_TAB(C_CONV, j, k, jr);
+    DW_TAB(C_DKDA, j, k, jr) = (j == 1) ? sc / sa : (sc - DW_TAB(C_CONV, j - 1, k, jr)) / (sa - DW_TAB(C_AREA, j - 1, k, jr));
+    const int ncomp = DW_FRNW(jr, 1);
+    double slope = (k < ncomp) ? (DW_G(p.z, k, jr) - DW_G(p.z, k + 1, jr)) / DW_G(p.dx, k, jr)
+                               : (DW_G(p.z, k - 1, jr) - DW_G(p.z, k, jr)) / DW_G(p.dx, k - 1, jr);
+    if (slope <= p.so_llm) slope = p.so_llm;
+    DW_TAB(C_UNIF, j, k, jr) = sc * sqrt(slope);
+}
+
+// ------------------------------------------------------------------------------------------------ the solver
+DW_HD inline bool is_mainstem(const Problem &p, int j)
+{
+    for (int m = 0; m < p.nmstem; ++m)
+        if (p.mstem_frj[m] == j) return true;
+    return false;
+}
+
+// scalars, the mainstem list, dx / minDx (diffnw :261-412); returns minDx
+DW_HD inline double setup_scalars(Problem &p)
+{
+    p.dtini = p.timestep_ar[0];
+    p.dtini_min = p.dtini / p.timestep_ar[9];
+    p.cfl = p.para_ar[0];
+    p.C_llm = p.para_ar[1];
+    p.D_llm = p.para_ar[2];
+    p.D_ulm = p.para_ar[3];
+    p.q_llm = p.para_ar[7];
+    p.so_llm = p.para_ar[8];
+    p.theta = p.para_ar[9];
+    p.dsbc_option = (int)p.para_ar[10];
+    const int64_t nn = (int64_t)p.mxncomp * p.nrch;
+    for (int64_t e = 0; e < nn; ++e) {
+        p.z[e] = p.z_ar[e];
+        p.oldQ[e] = p.iniq[e];
+        p.newQ[e] = p.iniq[e];
+        p.qp[e] = p.iniq[e];
+        p.dx[e] = 0.0;
+        p.qpx[e] = 0.0;
+        p.newY[e] = -999.0;
+        p.oldY[e] = 0.0;   // (the reference leaves the unset entries undefined; none is read before being written)
+        p.oldArea[e] = 0.0; p.newArea[e] = 0.0; p.bo[e] = 0.0; p.sk[e] = 0.0; p.pere[e] = 0.0;
+        p.celerity[e] = 0.0; p.diffusivity[e] = 0.0; p.lateralFlow[e] = 0.0;
+    }
+    p.nmstem = 0;
+    for (int j = 1; j <= p.nrch; ++j) {
+        const int nus = DW_FRNW(j, 3);
+        if (DW_FRNW(j, 3 + nus + 1) == 555) p.mstem_frj[p.nmstem++] = j;
+    }
+    double minDx = 1e10;
+    for (int m = 0; m < p.nmstem; ++m) {
+        const int j = p.mstem_frj[m], ncomp = DW_FRNW(j, 1);
+        for (int i = 1; i <= ncomp - 1; ++i) {
+            DW_G(p.dx, i, j) = DW_G(p.dx_ar, i, j);
+            minDx = dmin(minDx, DW_G(p.dx, i, j));
+        }
+    }
+    return minDx;
+}
+
+struct Depth {  // funcd_diffdepth (:1664-1711): f and df/dy at depth y_cur of node i
+    double f, df;
+};
+DW_HD inline Depth funcd(const Problem &p, int i, int j, double Q_cur, double Q_ds, double z_cur, double z_ds, double y_cur,
+                         double y_ds)
+{
+    const double elv_ds = y_ds + z_ds;
+    const double conv_ds = intp_tab(p, i + 1, j, C_ELEV, C_CONV, elv_ds);
+    const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
+    const double elv_cur = y_cur + z_cur;
+    const double conv_cur = intp_tab(p, i, j, C_ELEV, C_CONV, elv_cur);
+    const double sf_cur = fabs(Q_cur) * Q_cur / (conv_cur * conv_cur);
+    double slope = (DW_G(p.z, i, j) - DW_G(p.z, i + 1, j)) / DW_G(p.dx, i, j);
+    slope = dmax(slope, p.so_llm);
+    Depth r;
+    r.f = y_cur - y_ds + slope * DW_G(p.dx, i, j) - 0.50 * (sf_cur + sf_ds) * DW_G(p.dx, i, j);
+    const double dKdA = intp_tab(p, i, j, C_ELEV, C_DKDA, elv_cur);
+    const double topw = intp_tab(p, i, j, C_ELEV, C_TOPW, elv_cur);
+    r.df = 1.0 + (fabs(Q_cur) * Q_cur / (conv_cur * conv_cur * conv_cur)) * DW_G(p.dx, i, j) * topw * dKdA;
+    return r;
+}
+// rtsafe (:1555-1662): Newton-Raphson safeguarded by bisection for the depth of node i given node i+1
+DW_HD inline double rtsafe(const Problem &p, int i, int j, double Q_cur, double Q_ds, double z_cur, double z_ds, double y_ds)
+{
+    const int maxit = 40;
+    const double xacc = (double)1e-4f;
+    const double elv_norm = intp_tab(p, i, j, C_UNIF, C_ELEV, fabs(Q_cur));
+    const double y_norm = elv_norm - DW_G(p.z, i, j);
+    const double y_old = DW_G(p.oldY, i, j) - DW_G(p.z, i, j);
+    const double x1 = 0.5 * (y_norm + y_old) * (double)0.1f;
+    const double x2 = 0.5 * (y_norm + y_old) * 2.0;
+    const double fl = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, x1, y_ds).f;
+    const double fh = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, x2, y_ds).f;
+    if ((fl > 0.0 && fh > 0.0) || (fl < 0.0 && fh < 0.0)) return y_norm;
+    if (fl == 0.0) return x1;
+    if (fh == 0.0) return x2;
+    double xl, xh;
+    if (fl < 0.0) { xl = x1; xh = x2; } else { xh = x1; xl = x2; }
+    double rt = 0.50 * (x1 + x2);
+    double dxold = fabs(x2 - x1), dxx = dxold;
+    Depth d = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, rt, y_ds);
+    for (int iter = 1; iter <= maxit; ++iter) {
+        if (((rt - xh) * d.df - d.f) * ((rt - xl) * d.df - d.f) > 0.0 || fabs(2.0 * d.f) > fabs(dxold * d.df)) {
+            dxold = dxx;
+            dxx = 0.50 * (xh - xl);
+            rt = xl + dxx;
+            if (xl == rt) return rt;
+        } else {
+            dxold = dxx;
+            dxx = d.f / d.df;
+            const double temp = rt;
+            rt = rt - dxx;
+            if (temp == rt) return rt;
+        }
+        if (fabs(dxx) < xacc) return rt;
+        d = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, rt, y_ds);
+        if (d.f < 0.0) xl = rt; else xh = rt;
+    }
+    return y_norm;
+}
+
+// mesh_diffusive_forward (:1108-1355): Crank-Nicolson flow along reach j (Thomas recurrences eei/ffi, exi/fxi)
+DW_HD inline void forward(Problem &p, int j)
+{
+    const int ncomp = DW_FRNW(j, 1);
+    const double dtini = p.dtini, theta = p.theta;
+    p.eei[0] = 1.0; p.ffi[0] = 0.0; p.exi[0] = 0.0; p.fxi[0] = 0.0;
+    double allqlat = 0.0;
+    for (int i = 2; i <= ncomp - 1; ++i) allqlat = allqlat + DW_G(p.lateralFlow, i, j) * DW_G(p.dx, i, j);
+    for (int i = 2; i <= ncomp; ++i) {
+        const double dxm = DW_G(p.dx, i - 1, j);
+        const double cour = dtini / dxm;
+        const double cour2 = fabs(DW_G(p.celerity, i, j)) * cour;
+        const double c2 = cour2 * cour2, c3 = cour2 * cour2 * cour2;
+        const double a1 = 3.0 * c2 - 2.0 * c3;
+        const double a2 = 1 - a1;
+        const double a3 = (c2 - c3) * dxm;
+        const double a4 = (-1.0 * cour2 + 2.0 * c2 - c3) * dxm;
+        const double b1 = (6.0 * cour2 - 6.0 * c2) / (-1.0 * dxm);
+        const double b2 = -b1;
+        const double b3 = (2.0 * cour2 - 3.0 * c2) * (-1.0);
+        const double b4 = (-1.0 + 4.0 * cour2 - 3.0 * c2) * (-1.0);
+        const double dd1 = (6.0 - 12.0 * cour2) / (dxm * dxm);
+        const double dd2 = -dd1;
+        const double dd3 = (2.0 - 6.0 * cour2) / dxm;
+        const double dd4 = (4.0 - 6.0 * cour2) / dxm;
+        const double h1 = 12.0 / (dxm * dxm * dxm);
+        const double h2 = -h1;
+        const double h3 = 6.0 / (dxm * dxm);
+        const double h4 = h3;
+        const double alpha = (i == ncomp) ? 1.0 : DW_G(p.dx, i, j) / DW_G(p.dx, i - 1, j);
+        const double qa = DW_G(p.oldQ, i - 1, j), qb = DW_G(p.oldQ, i, j);
+        const double xa = DW_G(p.qpx, i - 1, j), xb = DW_G(p.qpx, i, j);
+        const double qy = a1 * qa + a2 * qb + a3 * xa + a4 * xb;
+        const double qxy = b1 * qa + b2 * qb + b3 * xa + b4 * xb;
+        const double qxxy = dd1 * qa + dd2 * qb + dd3 * xa + dd4 * xb;
+        const double qxxxy = h1 * qa + h2 * qb + h3 * xa + h4 * xb;
+        const double dif = DW_G(p.diffusivity, i, j);
+        const double ppi = -theta * dif * dtini / (dxm * dxm) * 2.0 / (alpha * (alpha + 1.0)) * alpha;
+        const double qqi = 1.0 - ppi * (alpha + 1.0) / alpha;
+        const double rri = ppi / alpha;
+        const double ssi = qy + dtini * dif * (1.0 - theta) * qxxy;
+        const double sxi = qxy + dtini * dif * (1.0 - theta) * qxxxy;
+        p.eei[i - 1] = -1.0 * rri / (ppi * p.eei[i - 2] + qqi);
+        p.ffi[i - 1] = (ssi - ppi * p.ffi[i - 2]) / (ppi * p.eei[i - 2] + qqi);
+        p.exi[i - 1] = -1.0 * rri / (ppi * p.exi[i - 2] + qqi);
+        p.fxi[i - 1] = (sxi - ppi * p.fxi[i - 2]) / (ppi * p.exi[i - 2] + qqi);
+    }
+    // (the reference also forms the coefficients of a ghost point behind the last node, :1239-1290, and never uses
+    // them: qp(ncomp) = eei(ncomp) * oldQ(ncomp-1) + ffi(ncomp), :1305-1322)
+    const double qp_ghost = DW_G(p.oldQ, ncomp - 1, j), qpx_ghost = 0.0;
+    DW_G(p.qp, ncomp, j) = p.eei[ncomp - 1] * qp_ghost + p.ffi[ncomp - 1];
+    DW_G(p.qpx, ncomp, j) = p.exi[ncomp - 1] * qpx_ghost + p.fxi[ncomp - 1];
+    for (int i = ncomp - 1; i >= 1; --i) {
+        DW_G(p.qp, i, j) = p.eei[i - 1] * DW_G(p.qp, i + 1, j) + p.ffi[i - 1];
+        DW_G(p.qpx, i, j) = p.exi[i - 1] * DW_G(p.qpx, i + 1, j) + p.fxi[i - 1];
+    }
+    DW_G(p.qp, 1, j) = DW_G(p.newQ, 1, j);
+    DW_G(p.qp, 1, j) = DW_G(p.qp, 1, j) + allqlat;
+    for (int i = 1; i <= ncomp; ++i)
+        if (fabs(DW_G(p.qp, i, j)) < p.q_llm) DW_G(p.qp, i, j) = p.q_llm;
+    for (int i = 1; i <= ncomp; ++i) DW_G(p.newQ, i, j) = DW_G(p.qp, i, j);
+}
+
+// mesh_diffusive_backward (:1357-1553): water surface along reach j from its bottom node upwards
+DW_HD inline void backward(Problem &p, int j)
+{
+    const int ncomp = DW_FRNW(j, 1);
+    DW_G(p.newArea, ncomp, j) = r_interpol(&DW_TAB(C_ELEV, 1, ncomp, j), &DW_TAB(C_AREA, 1, ncomp, j), kNel, DW_G(p.newY, ncomp, j));
+    DW_G(p.bo, ncomp, j) = r_interpol(&DW_TAB(C_ELEV, 1, ncomp, j), &DW_TAB(C_TOPW, 1, ncomp, j), kNel, DW_G(p.newY, ncomp, j));
+    for (int i = ncomp; i >= 1; --i) {
+        const double *elevT = &DW_TAB(C_ELEV, 1, i, j);
+        const double xt = DW_G(p.newY, i, j);
+        const double zz = DW_G(p.z, i, j);
+        // conveyance against squared depth (:1413-1416): the same bracketing search on (elev - z)**2
+        {
+            const double target = (xt - zz) * (xt - zz);
+            const double *convT = &DW_TAB(C_CONV, 1, i, j);
+            double xmax = (elevT[0] - zz) * (elevT[0] - zz), xmin = xmax;
+            for (int k = 1; k < kNel; ++k) {
+                const double v = (elevT[k] - zz) * (elevT[k] - zz);
+                xmax = dmax(xmax, v);
+                xmin = dmin(xmin, v);
+            }
+            double yt = 0.0;
+            if (target <= xmax && target >= xmin) {
+                for (int k = 0; k < kNel - 1; ++k) {
+                    const double xk = (elevT[k] - zz) * (elevT[k] - zz), xk1 = (elevT[k + 1] - zz) * (elevT[k + 1] - zz);
+                    if ((xk - target) * (xk1 - target) <= 0.0) {
+                        yt = (target - xk) / (xk1 - xk) * (convT[k + 1] - convT[k]) + convT[k];
+                        break;
+                    }
+                }
+            } else if (target >= xmax) {
+                const double xa = (elevT[kNel - 2] - zz) * (elevT[kNel - 2] - zz), xb = (elevT[kNel - 1] - zz) * (elevT[kNel - 1] - zz);
+                yt = (target - xa) / (xb - xa) * (convT[kNel - 1] - convT[kNel - 2]) + convT[kNel - 2];
+            } else {
+                yt = convT[0];
+                for (int k = 1; k < kNel; ++k) yt = dmin(yt, convT[k]);
+            }
+            p.co[i - 1] = 1.0 * yt;
+        }
+        DW_G(p.newArea, i, j) = r_interpol(elevT, &DW_TAB(C_AREA, 1, i, j), kNel, xt);
+        DW_G(p.pere, i, j) = r_interpol(elevT, &DW_TAB(C_PERI, 1, i, j), kNel, xt);
+        DW_G(p.bo, i, j) = r_interpol(elevT, &DW_TAB(C_TOPW, 1, i, j), kNel, xt);
+        DW_G(p.sk, i, j) = r_interpol(elevT, &DW_TAB(C_SKK, 1, i, j), kNel, xt);
+        const double qpi = DW_G(p.qp, i, j);
+        const double sfi = qpi * fabs(qpi) / (p.co[i - 1] * p.co[i - 1]);
+        p.celerity2[i - 1] = (double)(5.0f / 3.0f) * pow(fabs(sfi), (double)0.3f) * pow(fabs(qpi), (double)0.4f)
+                             / pow(DW_G(p.bo, i, j), (double)0.4f) / pow(1. / (DW_G(p.sk, i, j) * 1.0), (double)0.6f);
+        const double C_ulm = (i > 1) ? p.cfl * DW_G(p.dx, i - 1, j) / p.dtini_min : p.cfl * DW_G(p.dx, i, j) / p.dtini_min;
+        if (p.celerity2[i - 1] > C_ulm) p.celerity2[i - 1] = C_ulm;
+        p.diffusivity2[i - 1] = fabs(qpi) / 2.0 / DW_G(p.bo, i, j) / fabs(sfi);
+        if (i > 1) {
+            const double Q_cur = DW_G(p.qp, i - 1, j), Q_ds = qpi;
+            const double z_cur = DW_G(p.z, i - 1, j), z_ds = zz;
+            double y_ds = DW_G(p.newY, i, j) - zz;
+            y_ds = dmax(y_ds, (double)0.005f);
+            const double y_cur = rtsafe(p, i - 1, j, Q_cur, Q_ds, z_cur, z_ds, y_ds);
+            DW_G(p.newY, i - 1, j) = y_cur + DW_G(p.z, i - 1, j);
+            if (DW_G(p.newY, i - 1, j) > 100000.0) DW_G(p.newY, i - 1, j) = 100000.0;
+        }
+    }
+    double cs = 0.0, ds = 0.0;
+    for (int i = 1; i <= ncomp; ++i) { cs = cs + p.celerity2[i - 1]; ds = ds + p.diffusivity2[i - 1]; }
+    double cel = cs / ncomp;
+    if (cel < p.C_llm) cel = p.C_llm;
+    double dif = ds / ncomp;
+    for (int i = 1; i <= ncomp; ++i) {
+        DW_G(p.celerity, i, j) = cel;
+        double d = dif;
+        if (d > p.D_ulm) d = p.D_ulm;
+        if (d < p.D_llm) d = p.D_llm;
+        DW_G(p.diffusivity, i, j) = d;
+    }
+}
+
+// calculateDT (:942-991)
+DW_HD inline void calculate_dt(Problem &p, double initialTime, double time, double saveInterval, double tfin, double max_C_dx)
+{
+    p.dtini = p.cfl / max_C_dx;
+    const int a = (int)floor((time - initialTime * 60.) / (saveInterval / 60.));
+    const int b = (int)floor(((time - initialTime * 60.) + p.dtini / 60.) / (saveInterval / 60.));
+    if (b > a) p.dtini = (a + 1) * (saveInterval) - (time - initialTime * 60.) * 60.;
+    if (time + p.dtini / 60. > tfin * 60.) p.dtini = (tfin * 60. - time) * 60.;
+}
+
+// Everything of diffnw after the tables exist (:488-870), in one thread.
+DW_HD inline void solve(Problem &p, double minDx)
+{
+    const double TOL = (double)1e-8f;
+    const double mindepth_nstab = (double)0.1f;
+    const double t0 = p.timestep_ar[1], tfin = p.timestep_ar[2], saveInterval = p.timestep_ar[3];
+    const double dt_ql = p.timestep_ar[4], dt_db = p.timestep_ar[6], dt_qtrib = p.timestep_ar[7];
+    const double dtini_given = p.timestep_ar[0];
+    const int nts_ql = p.nts_ql, nts_qtrib = p.nts_qtrib, nts_db = p.nts_db, nlinks = p.nrch;
+    // ---- time axes (:491-530)
+    for (int n = 1; n <= nts_ql; ++n) p.tarr_ql[n] = t0 * 60.0 + dt_ql * (double)n / 60.0;
+    p.tarr_ql[0] = t0 * 60;
+    for (int n = 1; n <= nts_qtrib; ++n) p.tarr_qtrib[n - 1] = t0 * 60.0 + dt_qtrib * (double)(n - 1) / 60.0;
+    for (int n = 1; n <= nts_db; ++n) p.tarr_db[n - 1] = t0 * 60.0 + dt_db * (double)(n - 1) / 60.0;
+    // ---- initial water surface, downstream to upstream (:533-583)
+    double t = t0 * 60.0;
+    for (int jm = p.nmstem; jm >= 1; --jm) {
+        const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
+        if (DW_FRNW(j, 2) < 0) {
+            if (p.dsbc_option == 1) {
+                for (int n = 1; n <= nts_db; ++n) p.varr_db[n - 1] = p.dbcd[n - 1] + DW_G(p.z, ncomp, j);
+                t = t0 * 60.0;
+                DW_G(p.oldY, ncomp, j) = intp_y(nts_db, p.tarr_db, p.varr_db, t);
+                DW_G(p.newY, ncomp, j) = DW_G(p.oldY, ncomp, j);
+                if ((DW_G(p.newY, ncomp, j) - DW_G(p.z, ncomp, j)) < mindepth_nstab)
+                    DW_G(p.newY, ncomp, j) = mindepth_nstab + DW_G(p.z, ncomp, j);
+            } else if (p.dsbc_option == 2) {
+                DW_G(p.oldY, ncomp, j) = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, DW_G(p.oldQ, ncomp, j));
+                DW_G(p.newY, ncomp, j) = DW_G(p.oldY, ncomp, j);
+            }
+        } else {
+            const int linknb = DW_FRNW(j, 2);
+            DW_G(p.newY, ncomp, j) = DW_G(p.newY, 1, linknb);
+        }
+        const double wdepth = DW_G(p.newY, ncomp, j) - DW_G(p.z, ncomp, j);
+        for (int i = 1; i <= ncomp - 1; ++i) DW_G(p.oldY, i, j) = wdepth + DW_G(p.z, i, j);
+        backward(p, j);
+        for (int i = 1; i <= ncomp; ++i) {
+            DW_G(p.oldY, i, j) = DW_G(p.newY, i, j);
+            if (DW_G(p.oldY, i, j) < DW_G(p.oldY, ncomp, nlinks)) DW_G(p.oldY, i, j) = DW_G(p.oldY, ncomp, nlinks);
+        }
+    }
+    // ---- tributary hydrographs into the output arrays (:590-607)
+    int ts_ev = 1;
+    while (t <= tfin * 60.0) {
+        if (fmod((t - t0 * 60.) * 60., saveInterval) <= TOL || t == tfin * 60.) {
+            for (int j = 1; j <= nlinks; ++j)
+                if (!is_mainstem(p, j)) {
+                    for (int n = 1; n <= nts_qtrib; ++n) p.varr_qtrib[n - 1] = p.qtrib[(n - 1) + (int64_t)(j - 1) * nts_qtrib];
+                    const int nc = DW_FRNW(j, 1);
+                    if (ts_ev <= p.ntss_ev) {
+                        DW_EV(p.q_ev, ts_ev, nc, j) = intp_y(nts_qtrib, p.tarr_qtrib, p.varr_qtrib, t);
+                        DW_EV(p.q_ev, ts_ev, 1, j) = DW_EV(p.q_ev, ts_ev, nc, j);
+                    }
+                }
+            ts_ev = ts_ev + 1;
+        }
+        t = t + p.dtini / 60.;
+    }
+    // ---- the ordered time loop (:612-870)
+    double maxCelDx = 1.0 / minDx;
+    ts_ev = 1;
+    t = t0 * 60.0;
+    while (t < tfin * 60.) {
+        // predictor: flow, upstream to downstream
+        for (int jm = 1; jm <= p.nmstem; ++jm) {
+            const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
+            if (jm == 1) calculate_dt(p, t0, t, saveInterval, tfin, maxCelDx);
+            for (int i = 1; i <= ncomp - 1; ++i) {
+                for (int n = 1; n <= nts_ql; ++n) p.varr_ql[n] = p.qlat[(n - 1) + (int64_t)nts_ql * ((i - 1) + (int64_t)p.mxncomp * (j - 1))];
+                p.varr_ql[0] = p.qlat[0 + (int64_t)nts_ql * ((i - 1) + (int64_t)p.mxncomp * (j - 1))];
+                DW_G(p.lateralFlow, i, j) = intp_y(nts_ql + 1, p.tarr_ql, p.varr_ql, t);
+            }
+            if (DW_FRNW(j, 3) > 0) {
+                DW_G(p.newQ, 1, j) = 0.0;
+                for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
+                    const int usrchj = DW_FRNW(j, 3 + k);
+                    double q_usrch;
+                    if (is_mainstem(p, usrchj)) {
+                        q_usrch = DW_G(p.newQ, DW_FRNW(usrchj, 1), usrchj);
+                    } else {
+                        for (int n = 1; n <= nts_qtrib; ++n) p.varr_qtrib[n - 1] = p.qtrib[(n - 1) + (int64_t)(usrchj - 1) * nts_qtrib];
+                        const double tf0 = t + p.dtini / 60.;
+                        q_usrch = intp_y(nts_qtrib, p.tarr_qtrib, p.varr_qtrib, tf0);
+                    }
+                    DW_G(p.newQ, 1, j) = DW_G(p.newQ, 1, j) + q_usrch;
+                }
+            } else {
+                DW_G(p.newQ, 1, j) = 0.0;
+            }
+            DW_G(p.newQ, 1, j) = DW_G(p.newQ, 1, j) + DW_G(p.lateralFlow, 1, j) * DW_G(p.dx, 1, j);
+            forward(p, j);
+        }
+        // corrector: depth, downstream to upstream
+        for (int jm = p.nmstem; jm >= 1; --jm) {
+            const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
+            if (DW_FRNW(j, 2) >= 0) {
+                const int linknb = DW_FRNW(j, 2);
+                DW_G(p.newY, ncomp, j) = DW_G(p.newY, 1, linknb);
+            } else if (p.dsbc_option == 1) {
+                DW_G(p.newY, ncomp, j) = intp_y(nts_db, p.tarr_db, p.varr_db, t + p.dtini / 60.);
+                if ((DW_G(p.newY, ncomp, j) - DW_G(p.z, ncomp, j)) < mindepth_nstab)
+                    DW_G(p.newY, ncomp, j) = mindepth_nstab + DW_G(p.z, ncomp, j);
+                DW_G(p.newArea, ncomp, j) = intp_tab(p, ncomp, j, C_ELEV, C_AREA, DW_G(p.newY, ncomp, j));
+            } else if (p.dsbc_option == 2) {
+                DW_G(p.newY, ncomp, j) = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, fabs(DW_G(p.newQ, ncomp, j)));
+                DW_G(p.newArea, ncomp, j) = intp_tab(p, ncomp, j, C_ELEV, C_AREA, DW_G(p.newY, ncomp, j));
+            }
+            backward(p, j);
+            if (jm == 1) {
+                maxCelDx = 0.;
+                for (int m = 1; m <= p.nmstem; ++m) {
+                    const int jj = p.mstem_frj[m - 1];
+                    for (int kkk = 1; kkk <= DW_FRNW(jj, 1) - 1; ++kkk)
+                        maxCelDx = dmax(maxCelDx, DW_G(p.celerity, kkk, jj) / DW_G(p.dx, kkk, jj));
+                }
+            }
+        }
+        t = t + p.dtini / 60.;
+        // results at the recording instants (:787-810)
+        if (fmod((t - t0 * 60.) * 60., saveInterval) <= TOL || t == tfin * 60.) {
+            for (int jm = 1; jm <= p.nmstem; ++jm) {
+                const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
+                if (ts_ev + 1 <= p.ntss_ev) {
+                    for (int i = 1; i <= ncomp; ++i) {
+                        DW_EV(p.q_ev, ts_ev + 1, i, j) = DW_G(p.newQ, i, j);
+                        DW_EV(p.elv_ev, ts_ev + 1, i, j) = DW_G(p.newY, i, j);
+                        DW_EV(p.depth_ev, ts_ev + 1, i, j) = DW_EV(p.elv_ev, ts_ev + 1, i, j) - DW_G(p.z, i, j);
+                    }
+                    for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
+                        const int usrchj = DW_FRNW(j, 3 + k);
+                        if (!is_mainstem(p, usrchj)) {
+                            const double wdepth = DW_G(p.newY, 1, j) - DW_G(p.z, 1, j);
+                            DW_EV(p.elv_ev, ts_ev + 1, DW_FRNW(usrchj, 1), usrchj) = DW_G(p.newY, 1, j);
+                            DW_EV(p.depth_ev, ts_ev + 1, DW_FRNW(usrchj, 1), usrchj) = wdepth;
+                        }
+                    }
+                }
+            }
+            ts_ev = ts_ev + 1;
+        }
+        // the initial state, once the first sub-step is known (:813-832; t0 in hours against t in minutes, as written)
+        if (t == t0 + p.dtini / 60.) {
+            for (int jm = 1; jm <= p.nmstem; ++jm) {
+                const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
+                for (int i = 1; i <= ncomp; ++i) {
+                    DW_EV(p.q_ev, 1, i, j) = DW_G(p.oldQ, i, j);
+                    DW_EV(p.elv_ev, 1, i, j) = DW_G(p.oldY, i, j);
+                    DW_EV(p.depth_ev, 1, i, j) = DW_EV(p.elv_ev, 1, i, j) - DW_G(p.z, i, j);
+                }
+                for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
+                    const int usrchj = DW_FRNW(j, 3 + k);
+                    if (!is_mainstem(p, usrchj)) {
+                        const double wdepth = DW_G(p.oldY, 1, j) - DW_G(p.z, 1, j);
+                        DW_EV(p.elv_ev, 1, DW_FRNW(usrchj, 1), usrchj) = DW_G(p.oldY, 1, j);
+                        DW_EV(p.depth_ev, 1, DW_FRNW(usrchj, 1), usrchj) = wdepth;
+                    }
+                }
+            }
+        }
+        const int64_t nn = (int64_t)p.mxncomp * p.nrch;
+        for (int64_t e = 0; e < nn; ++e) {
+            p.oldY[e] = p.newY[e]; p.newY[e] = -999.0;
+            p.oldQ[e] = p.newQ[e]; p.newQ[e] = -999.0;
+            p.oldArea[e] = p.newArea[e]; p.newArea[e] = -999.0;
+            p.pere[e] = -999.0;
+        }
+    }
+    (void)dtini_given;
+}
+
+} // namespace trdw
