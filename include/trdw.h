@@ -1,0 +1,58 @@
+/*
+ * trdw.h -- C ABI of the MI355X diffusive-wave mainstem solver, exported by libtrmc.so
+ * (t-route_amd/csrc/diffusive.hip + diffusive_core.hpp).
+ *
+ * Reference interface replaced (paths relative to the T-Route tree):
+ *   src/kernel/diffusive/pydiffusive.f90:8-55          c_diffnw(...) bind(c) -- the symbol the Cython wrapper
+ *   src/troute-routing/troute/routing/fast_reach/pydiffusive.h, fortran_wrappers.pxd   binds
+ *   src/troute-routing/troute/routing/fast_reach/diffusive.pyx:8-127  (cdef diffnw -> c_diffnw)
+ *   src/kernel/diffusive/diffusive.f90:75-940          diffnw, the routine behind it
+ *
+ * trdw_diffnw takes c_diffnw's arguments in c_diffnw's order, every one by reference, arrays column-major
+ * (Fortran order) in double / int32 -- a Fortran or Cython caller can bind it in place of c_diffnw.  The only
+ * additions are the int return value (0, or a negative status with the text in trdw_last_error()) and
+ * trdw_select_device().  One call = one tailwater domain: the cross-section tables are built by one thread per
+ * (node, water level); the ordered time loop runs in one wavefront whose lanes share every table scan.
+ * Covered: synthetic (RouteLink) cross sections, both downstream-boundary options.  Refused with
+ * TRDW_EUNSUPPORTED: natural cross sections (mxnbathy_g > 0) and the refactored-hydrofabric crosswalk
+ * (cwnrow_g > 0).  No CPU fallback: without a HIP device the call fails with TRDW_ENODEVICE.
+ */
+#ifndef TRDW_H
+#define TRDW_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum trdw_status {
+    TRDW_OK = 0,
+    TRDW_EINVAL = -1,
+    TRDW_EUNSUPPORTED = -2,
+    TRDW_ENODEVICE = -3,
+    TRDW_EHIP = -4,
+    TRDW_ENOMEM = -5
+} trdw_status;
+
+const char *trdw_last_error(void);
+/* HIP device ordinal used by the calling thread's next trdw_diffnw calls (default 0). */
+int trdw_select_device(int device);
+
+int trdw_diffnw(const double *timestep_ar_g, const int *nts_ql_g, const int *nts_ub_g, const int *nts_db_g,
+                const int *ntss_ev_g, const int *nts_qtrib_g, const int *nts_da_g, const int *mxncomp_g,
+                const int *nrch_g, const double *z_ar_g, const double *bo_ar_g, const double *traps_ar_g,
+                const double *tw_ar_g, const double *twcc_ar_g, const double *mann_ar_g, const double *manncc_ar_g,
+                const double *so_ar_g, const double *dx_ar_g, const double *iniq, const int *frnw_col,
+                const int *frnw_ar_g, const double *qlat_g, const double *ubcd_g, const double *dbcd_g,
+                const double *qtrib_g, const int *paradim, const double *para_ar_g, const int *mxnbathy_g,
+                const double *x_bathy_g, const double *z_bathy_g, const double *mann_bathy_g, const int *size_bathy_g,
+                const double *usgs_da_g, const int *usgs_da_reach_g, const double *rdx_ar_g, const int *cwnrow_g,
+                const int *cwncol_g, const double *crosswalk_g, const double *z_thalweg_g, double *q_ev_g,
+                double *elv_ev_g, double *depth_ev_g);
+
+/* Device time of the last trdw_diffnw call of this thread: tables_ms (cross-section tables), solve_ms (time loop). */
+int trdw_last_timing(double *tables_ms, double *solve_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRDW_H */

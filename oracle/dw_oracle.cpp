@@ -2,6 +2,7 @@
 // the same source the HIP kernel compiles) behind the argument list of the reference's c_diffnw
 // (src/kernel/diffusive/pydiffusive.f90:8-55).  Built with libm and without FMA contraction; validated against the
 // reference Fortran built from its own sources (oracle/_ref/libdiff_ref.so) by tests/test_diffusive.py.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,10 +35,11 @@ extern "C" int dw_oracle_diffnw(
     const long long nout = (long long)p.ntss_ev * p.mxncomp * p.nrch;
     for (long long e = 0; e < nout; ++e) q_ev_g[e] = elv_ev_g[e] = depth_ev_g[e] = 0.0;
     double *w = (double *)calloc((size_t)trdw::work_doubles(p.mxncomp, p.nrch, p.nts_ql, p.nts_qtrib, p.nts_db), sizeof(double));
-    int32_t *frj = (int32_t *)calloc((size_t)p.nrch + 1, sizeof(int32_t));
+    int32_t *frj = (int32_t *)calloc(2 * (size_t)p.nrch + 2, sizeof(int32_t));
     if (!w || !frj) return -2;
     trdw::bind_work(p, w);
     p.mstem_frj = frj;
+    p.is_main = frj + p.nrch;
     const double minDx = trdw::setup_scalars(p);
     // tables of every mainstem node; the node's bed elevation becomes the notch of its section
     for (int m = 0; m < p.nmstem; ++m) {
@@ -54,8 +56,13 @@ extern "C" int dw_oracle_diffnw(
         for (int k = 1; k <= ncomp; ++k)
             for (int l = trdw::kNel; l >= 1; --l) trdw::table_row_finish(p, k, j, l);
     }
-    trdw::solve(p, minDx);
+    static long long counters[4];
+    counters[0] = counters[1] = counters[2] = 0;
+    p.counters = (int64_t *)counters;
+    trdw::SerialScan scan;
+    trdw::solve(p, minDx, scan);
     free(w);
     free(frj);
+    if (getenv("DW_ORACLE_COUNTERS")) fprintf(stderr, "sub-steps %lld node sweeps %lld funcd %lld\n", counters[0], counters[1], counters[2]);
     return 0;
 }

@@ -67,6 +67,14 @@ SIGNATURES = {
     "trmc_segments": (_int, [_int, _int, _i64, _vp, _vp]),
 }
 
+# include/trdw.h (the diffusive-wave mainstem solver, same shared library)
+SIGNATURES_DW = {
+    "trdw_last_error": (C.c_char_p, []),
+    "trdw_select_device": (_int, [_int]),
+    "trdw_diffnw": (_int, [_vp] * 42),
+    "trdw_last_timing": (_int, [_P(C.c_double), _P(C.c_double)]),
+}
+
 _LIB = None
 
 
@@ -79,7 +87,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C t-route_amd/csrc).  There is no CPU fallback.")
         h = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_DW.items()):
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args

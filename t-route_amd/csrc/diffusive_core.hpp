@@ -55,7 +55,9 @@ struct Problem {
         *lateralFlow;                                        // [mxncomp*nrch] each
     double *eei, *ffi, *exi, *fxi, *celerity2, *diffusivity2, *co; // [mxncomp] each
     double *tarr_ql, *varr_ql, *tarr_qtrib, *varr_qtrib, *tarr_db, *varr_db;
-    int32_t *mstem_frj;     // [nrch]
+    int32_t *mstem_frj;     // [nrch] mainstem reaches, upstream first; then [nrch + 1] flags "reach j is mainstem"
+    int32_t *is_main;
+    int64_t *counters;      // optional [4]: sub-steps, node sweeps, depth-solve function evaluations (diagnostics)
     int nmstem;
     // ---- scalars of diffnw ------------------------------------------------------------------------------------
     double dtini, dtini_min, cfl, C_llm, D_llm, D_ulm, q_llm, so_llm, theta;
@@ -137,10 +139,80 @@ DW_HD inline double r_interpol(const double *x, const double *y, int kk, double 
     for (int k = 1; k < kk; ++k) ymin = dmin(ymin, y[k]);
     return ymin;
 }
+// r_interpol's search separated from its arithmetic, so that one search serves every column looked up at the same
+// abscissa (mesh_diffusive_backward reads four columns at the same water elevation).  mode 0: interval k brackets,
+// 1: above the table (extrapolate from the last interval), 2: below (minimum of the ordinate), 3: no bracket found.
+struct Bracket {
+    int mode, k;
+    double xk, xk1; // abscissae of the interval used
+};
+// X: k -> abscissa (the elevation column, or its squared depth above the bed)
+template <class X> DW_HD inline Bracket bracket_serial(const X &xf, int kk, double xrt)
+{
+    double xmax = xf(0), xmin = xf(0);
+    for (int k = 1; k < kk; ++k) { const double v = xf(k); xmax = dmax(xmax, v); xmin = dmin(xmin, v); }
+    Bracket b;
+    if (xrt <= xmax && xrt >= xmin) {
+        for (int k = 0; k < kk - 1; ++k) {
+            const double xk = xf(k), xk1 = xf(k + 1);
+            if ((xk - xrt) * (xk1 - xrt) <= 0.0) { b.mode = 0; b.k = k; b.xk = xk; b.xk1 = xk1; return b; }
+        }
+        b.mode = 3; b.k = 0; b.xk = b.xk1 = 0.0;
+        return b;
+    }
+    if (xrt >= xmax) { b.mode = 1; b.k = kk - 2; b.xk = xf(kk - 2); b.xk1 = xf(kk - 1); return b; }
+    b.mode = 2; b.k = 0; b.xk = b.xk1 = 0.0;
+    return b;
+}
+struct ElevAt { const double *x; DW_HD double operator()(int k) const { return x[k]; } };
+struct SqDepthAt { const double *e; double zz; DW_HD double operator()(int k) const { return (e[k] - zz) * (e[k] - zz); } };
+
+// the [kCols][kNel] table block of node i of reach j
+DW_HD inline const double *node_block(const Problem &p, int i, int j) { return &DW_TAB(0, 1, i, j); }
+struct SerialScan {
+    DW_HD void begin_node(const Problem &, int, int) const {}
+    DW_HD const double *table(const Problem &p, int i, int j) const { return node_block(p, i, j); }
+    DW_HD int locate_row(const double *xx, int n, double x) const { return locate(xx, n, x); }
+    DW_HD Bracket bracket(const double *elev, bool squared, double zz, int kk, double xrt) const
+    {
+        return squared ? bracket_serial(SqDepthAt{elev, zz}, kk, xrt) : bracket_serial(ElevAt{elev}, kk, xrt);
+    }
+    // r_interpol's value for ordinate column y at a bracket (:2567-2591)
+    DW_HD double apply(const Bracket &b, const double *y, int kk, double xrt) const
+    {
+        if (b.mode <= 1) return (xrt - b.xk) / (b.xk1 - b.xk) * (y[b.k + 1] - y[b.k]) + y[b.k];
+        if (b.mode == 3) return 0.0;
+        double ymin = y[0];
+        for (int k = 1; k < kk; ++k) ymin = dmin(ymin, y[k]);
+        return ymin;
+    }
+};
+
+DW_HD inline double intp_blk(const double *tb, int xcol, int ycol, double x)
+{
+    return intp_y(kNel, tb + xcol * kNel, tb + ycol * kNel, x);
+}
+// intp_xsec_tab split in two: the row (search left to the scan policy) and the interpolation in a column at that
+// row, so that columns looked up at the same abscissa share the search
+template <class Scan> DW_HD inline int row_blk(const Scan &scan, const double *tb, int xcol, double x)
+{
+    int irow = scan.locate_row(tb + xcol * kNel, kNel, x);
+    if (irow == 0) irow = 1;
+    if (irow == kNel) irow = kNel - 1;
+    return irow;
+}
+DW_HD inline double at_row(const double *tb, int xcol, int ycol, int irow, double x)
+{
+    const double *xarr = tb + xcol * kNel, *yarr = tb + ycol * kNel;
+    return linterpol(xarr[irow - 1], yarr[irow - 1], xarr[irow], yarr[irow], x);
+}
+template <class Scan> DW_HD inline double intp_blk(const Scan &scan, const double *tb, int xcol, int ycol, double x)
+{
+    return at_row(tb, xcol, ycol, row_blk(scan, tb, xcol, x), x);
+}
 DW_HD inline double intp_tab(const Problem &p, int i, int j, int xcol, int ycol, double x)
 {
-    const double *xa = &DW_TAB(xcol, 1, i, j), *ya = &DW_TAB(ycol, 1, i, j);
-    return intp_y(kNel, xa, ya, x);
+    return intp_blk(node_block(p, i, j), xcol, ycol, x);
 }
 
 // ------------------------------------------------------------------------------------------------ cross sections
@@ -301,12 +373,7 @@ DW_HD inline void table_row_finish(Problem &p, int k, int jr, int j)
 }
 
 // ------------------------------------------------------------------------------------------------ the solver
-DW_HD inline bool is_mainstem(const Problem &p, int j)
-{
-    for (int m = 0; m < p.nmstem; ++m)
-        if (p.mstem_frj[m] == j) return true;
-    return false;
-}
+DW_HD inline bool is_mainstem(const Problem &p, int j) { return p.is_main[j] != 0; }
 
 // scalars, the mainstem list, dx / minDx (diffnw :261-412); returns minDx
 DW_HD inline double setup_scalars(Problem &p)
@@ -337,7 +404,8 @@ DW_HD inline double setup_scalars(Problem &p)
     p.nmstem = 0;
     for (int j = 1; j <= p.nrch; ++j) {
         const int nus = DW_FRNW(j, 3);
-        if (DW_FRNW(j, 3 + nus + 1) == 555) p.mstem_frj[p.nmstem++] = j;
+        p.is_main[j] = DW_FRNW(j, 3 + nus + 1) == 555;
+        if (p.is_main[j]) p.mstem_frj[p.nmstem++] = j;
     }
     double minDx = 1e10;
     for (int m = 0; m < p.nmstem; ++m) {
@@ -353,36 +421,42 @@ DW_HD inline double setup_scalars(Problem &p)
 struct Depth {  // funcd_diffdepth (:1664-1711): f and df/dy at depth y_cur of node i
     double f, df;
 };
-DW_HD inline Depth funcd(const Problem &p, int i, int j, double Q_cur, double Q_ds, double z_cur, double z_ds, double y_cur,
-                         double y_ds)
+// sf_ds, the energy slope at the node below, does not depend on y_cur: rtsafe forms it once (same operations)
+template <class Scan>
+DW_HD inline Depth funcd(const Problem &p, const Scan &scan, const double *tb, int i, int j, double Q_cur, double sf_ds,
+                         double z_cur, double y_cur, double y_ds)
 {
-    const double elv_ds = y_ds + z_ds;
-    const double conv_ds = intp_tab(p, i + 1, j, C_ELEV, C_CONV, elv_ds);
-    const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
+    if (p.counters) p.counters[2] += 1;
     const double elv_cur = y_cur + z_cur;
-    const double conv_cur = intp_tab(p, i, j, C_ELEV, C_CONV, elv_cur);
+    const int irow = row_blk(scan, tb, C_ELEV, elv_cur);       // one search: conveyance, dK/dA and top width
+    const double conv_cur = at_row(tb, C_ELEV, C_CONV, irow, elv_cur);
     const double sf_cur = fabs(Q_cur) * Q_cur / (conv_cur * conv_cur);
     double slope = (DW_G(p.z, i, j) - DW_G(p.z, i + 1, j)) / DW_G(p.dx, i, j);
     slope = dmax(slope, p.so_llm);
     Depth r;
     r.f = y_cur - y_ds + slope * DW_G(p.dx, i, j) - 0.50 * (sf_cur + sf_ds) * DW_G(p.dx, i, j);
-    const double dKdA = intp_tab(p, i, j, C_ELEV, C_DKDA, elv_cur);
-    const double topw = intp_tab(p, i, j, C_ELEV, C_TOPW, elv_cur);
+    const double dKdA = at_row(tb, C_ELEV, C_DKDA, irow, elv_cur);
+    const double topw = at_row(tb, C_ELEV, C_TOPW, irow, elv_cur);
     r.df = 1.0 + (fabs(Q_cur) * Q_cur / (conv_cur * conv_cur * conv_cur)) * DW_G(p.dx, i, j) * topw * dKdA;
     return r;
 }
 // rtsafe (:1555-1662): Newton-Raphson safeguarded by bisection for the depth of node i given node i+1
-DW_HD inline double rtsafe(const Problem &p, int i, int j, double Q_cur, double Q_ds, double z_cur, double z_ds, double y_ds)
+template <class Scan>
+DW_HD inline double rtsafe(const Problem &p, const Scan &scan, const double *tb, const double *tb_ds, int i, int j, double Q_cur,
+                          double Q_ds, double z_cur, double z_ds, double y_ds)
 {
     const int maxit = 40;
     const double xacc = (double)1e-4f;
-    const double elv_norm = intp_tab(p, i, j, C_UNIF, C_ELEV, fabs(Q_cur));
+    const double elv_ds = y_ds + z_ds;
+    const double conv_ds = intp_blk(scan, tb_ds, C_ELEV, C_CONV, elv_ds);
+    const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
+    const double elv_norm = intp_blk(scan, tb, C_UNIF, C_ELEV, fabs(Q_cur));
     const double y_norm = elv_norm - DW_G(p.z, i, j);
     const double y_old = DW_G(p.oldY, i, j) - DW_G(p.z, i, j);
     const double x1 = 0.5 * (y_norm + y_old) * (double)0.1f;
     const double x2 = 0.5 * (y_norm + y_old) * 2.0;
-    const double fl = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, x1, y_ds).f;
-    const double fh = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, x2, y_ds).f;
+    const double fl = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, x1, y_ds).f;
+    const double fh = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, x2, y_ds).f;
     if ((fl > 0.0 && fh > 0.0) || (fl < 0.0 && fh < 0.0)) return y_norm;
     if (fl == 0.0) return x1;
     if (fh == 0.0) return x2;
@@ -390,7 +464,7 @@ DW_HD inline double rtsafe(const Problem &p, int i, int j, double Q_cur, double 
     if (fl < 0.0) { xl = x1; xh = x2; } else { xh = x1; xl = x2; }
     double rt = 0.50 * (x1 + x2);
     double dxold = fabs(x2 - x1), dxx = dxold;
-    Depth d = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, rt, y_ds);
+    Depth d = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, rt, y_ds);
     for (int iter = 1; iter <= maxit; ++iter) {
         if (((rt - xh) * d.df - d.f) * ((rt - xl) * d.df - d.f) > 0.0 || fabs(2.0 * d.f) > fabs(dxold * d.df)) {
             dxold = dxx;
@@ -405,7 +479,7 @@ DW_HD inline double rtsafe(const Problem &p, int i, int j, double Q_cur, double 
             if (temp == rt) return rt;
         }
         if (fabs(dxx) < xacc) return rt;
-        d = funcd(p, i, j, Q_cur, Q_ds, z_cur, z_ds, rt, y_ds);
+        d = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, rt, y_ds);
         if (d.f < 0.0) xl = rt; else xh = rt;
     }
     return y_norm;
@@ -475,47 +549,31 @@ DW_HD inline void forward(Problem &p, int j)
 }
 
 // mesh_diffusive_backward (:1357-1553): water surface along reach j from its bottom node upwards
-DW_HD inline void backward(Problem &p, int j)
+template <class Scan> DW_HD inline void backward(Problem &p, int j, Scan &scan)
 {
     const int ncomp = DW_FRNW(j, 1);
-    DW_G(p.newArea, ncomp, j) = r_interpol(&DW_TAB(C_ELEV, 1, ncomp, j), &DW_TAB(C_AREA, 1, ncomp, j), kNel, DW_G(p.newY, ncomp, j));
-    DW_G(p.bo, ncomp, j) = r_interpol(&DW_TAB(C_ELEV, 1, ncomp, j), &DW_TAB(C_TOPW, 1, ncomp, j), kNel, DW_G(p.newY, ncomp, j));
+    scan.begin_node(p, ncomp, j);
+    {
+        const double *tb = scan.table(p, ncomp, j);
+        const double yb = DW_G(p.newY, ncomp, j);
+        const Bracket bb = scan.bracket(tb + C_ELEV * kNel, false, 0.0, kNel, yb);
+        DW_G(p.newArea, ncomp, j) = scan.apply(bb, tb + C_AREA * kNel, kNel, yb);
+        DW_G(p.bo, ncomp, j) = scan.apply(bb, tb + C_TOPW * kNel, kNel, yb);
+    }
     for (int i = ncomp; i >= 1; --i) {
-        const double *elevT = &DW_TAB(C_ELEV, 1, i, j);
+        scan.begin_node(p, i, j);               // node i (and i-1, which the depth solve reads) become resident
+        if (p.counters) p.counters[1] += 1;
+        const double *tb = scan.table(p, i, j);
+        const double *elevT = tb + C_ELEV * kNel;
         const double xt = DW_G(p.newY, i, j);
         const double zz = DW_G(p.z, i, j);
-        // conveyance against squared depth (:1413-1416): the same bracketing search on (elev - z)**2
-        {
-            const double target = (xt - zz) * (xt - zz);
-            const double *convT = &DW_TAB(C_CONV, 1, i, j);
-            double xmax = (elevT[0] - zz) * (elevT[0] - zz), xmin = xmax;
-            for (int k = 1; k < kNel; ++k) {
-                const double v = (elevT[k] - zz) * (elevT[k] - zz);
-                xmax = dmax(xmax, v);
-                xmin = dmin(xmin, v);
-            }
-            double yt = 0.0;
-            if (target <= xmax && target >= xmin) {
-                for (int k = 0; k < kNel - 1; ++k) {
-                    const double xk = (elevT[k] - zz) * (elevT[k] - zz), xk1 = (elevT[k + 1] - zz) * (elevT[k + 1] - zz);
-                    if ((xk - target) * (xk1 - target) <= 0.0) {
-                        yt = (target - xk) / (xk1 - xk) * (convT[k + 1] - convT[k]) + convT[k];
-                        break;
-                    }
-                }
-            } else if (target >= xmax) {
-                const double xa = (elevT[kNel - 2] - zz) * (elevT[kNel - 2] - zz), xb = (elevT[kNel - 1] - zz) * (elevT[kNel - 1] - zz);
-                yt = (target - xa) / (xb - xa) * (convT[kNel - 1] - convT[kNel - 2]) + convT[kNel - 2];
-            } else {
-                yt = convT[0];
-                for (int k = 1; k < kNel; ++k) yt = dmin(yt, convT[k]);
-            }
-            p.co[i - 1] = 1.0 * yt;
-        }
-        DW_G(p.newArea, i, j) = r_interpol(elevT, &DW_TAB(C_AREA, 1, i, j), kNel, xt);
-        DW_G(p.pere, i, j) = r_interpol(elevT, &DW_TAB(C_PERI, 1, i, j), kNel, xt);
-        DW_G(p.bo, i, j) = r_interpol(elevT, &DW_TAB(C_TOPW, 1, i, j), kNel, xt);
-        DW_G(p.sk, i, j) = r_interpol(elevT, &DW_TAB(C_SKK, 1, i, j), kNel, xt);
+        const double sq = (xt - zz) * (xt - zz);
+        p.co[i - 1] = 1.0 * scan.apply(scan.bracket(elevT, true, zz, kNel, sq), tb + C_CONV * kNel, kNel, sq);
+        const Bracket be = scan.bracket(elevT, false, 0.0, kNel, xt); // one search for the four columns at xt
+        DW_G(p.newArea, i, j) = scan.apply(be, tb + C_AREA * kNel, kNel, xt);
+        DW_G(p.pere, i, j) = scan.apply(be, tb + C_PERI * kNel, kNel, xt);
+        DW_G(p.bo, i, j) = scan.apply(be, tb + C_TOPW * kNel, kNel, xt);
+        DW_G(p.sk, i, j) = scan.apply(be, tb + C_SKK * kNel, kNel, xt);
         const double qpi = DW_G(p.qp, i, j);
         const double sfi = qpi * fabs(qpi) / (p.co[i - 1] * p.co[i - 1]);
         p.celerity2[i - 1] = (double)(5.0f / 3.0f) * pow(fabs(sfi), (double)0.3f) * pow(fabs(qpi), (double)0.4f)
@@ -528,7 +586,7 @@ DW_HD inline void backward(Problem &p, int j)
             const double z_cur = DW_G(p.z, i - 1, j), z_ds = zz;
             double y_ds = DW_G(p.newY, i, j) - zz;
             y_ds = dmax(y_ds, (double)0.005f);
-            const double y_cur = rtsafe(p, i - 1, j, Q_cur, Q_ds, z_cur, z_ds, y_ds);
+            const double y_cur = rtsafe(p, scan, scan.table(p, i - 1, j), tb, i - 1, j, Q_cur, Q_ds, z_cur, z_ds, y_ds);
             DW_G(p.newY, i - 1, j) = y_cur + DW_G(p.z, i - 1, j);
             if (DW_G(p.newY, i - 1, j) > 100000.0) DW_G(p.newY, i - 1, j) = 100000.0;
         }
@@ -558,7 +616,7 @@ DW_HD inline void calculate_dt(Problem &p, double initialTime, double time, doub
 }
 
 // Everything of diffnw after the tables exist (:488-870), in one thread.
-DW_HD inline void solve(Problem &p, double minDx)
+template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &scan)
 {
     const double TOL = (double)1e-8f;
     const double mindepth_nstab = (double)0.1f;
@@ -593,7 +651,7 @@ DW_HD inline void solve(Problem &p, double minDx)
         }
         const double wdepth = DW_G(p.newY, ncomp, j) - DW_G(p.z, ncomp, j);
         for (int i = 1; i <= ncomp - 1; ++i) DW_G(p.oldY, i, j) = wdepth + DW_G(p.z, i, j);
-        backward(p, j);
+        backward(p, j, scan);
         for (int i = 1; i <= ncomp; ++i) {
             DW_G(p.oldY, i, j) = DW_G(p.newY, i, j);
             if (DW_G(p.oldY, i, j) < DW_G(p.oldY, ncomp, nlinks)) DW_G(p.oldY, i, j) = DW_G(p.oldY, ncomp, nlinks);
@@ -621,14 +679,20 @@ DW_HD inline void solve(Problem &p, double minDx)
     ts_ev = 1;
     t = t0 * 60.0;
     while (t < tfin * 60.) {
+        if (p.counters) p.counters[0] += 1;
         // predictor: flow, upstream to downstream
+        int ql_row = locate(p.tarr_ql, nts_ql + 1, t);
+        if (ql_row == 0) ql_row = 1;
+        if (ql_row == nts_ql + 1) ql_row = nts_ql;
         for (int jm = 1; jm <= p.nmstem; ++jm) {
             const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
             if (jm == 1) calculate_dt(p, t0, t, saveInterval, tfin, maxCelDx);
+            // lateral inflow at time t (:650-657): the time axis is shared, so the bracketing interval is found once
+            // per sub-step (ql_row); varr_ql(n+1) = qlat_g(n, i, j), varr_ql(1) = qlat_g(1, i, j)
             for (int i = 1; i <= ncomp - 1; ++i) {
-                for (int n = 1; n <= nts_ql; ++n) p.varr_ql[n] = p.qlat[(n - 1) + (int64_t)nts_ql * ((i - 1) + (int64_t)p.mxncomp * (j - 1))];
-                p.varr_ql[0] = p.qlat[0 + (int64_t)nts_ql * ((i - 1) + (int64_t)p.mxncomp * (j - 1))];
-                DW_G(p.lateralFlow, i, j) = intp_y(nts_ql + 1, p.tarr_ql, p.varr_ql, t);
+                const double *ql = p.qlat + (int64_t)nts_ql * ((i - 1) + (int64_t)p.mxncomp * (j - 1));
+                const double y1 = ql_row == 1 ? ql[0] : ql[ql_row - 2], y2 = ql[ql_row - 1];
+                DW_G(p.lateralFlow, i, j) = linterpol(p.tarr_ql[ql_row - 1], y1, p.tarr_ql[ql_row], y2, t);
             }
             if (DW_FRNW(j, 3) > 0) {
                 DW_G(p.newQ, 1, j) = 0.0;
@@ -665,7 +729,7 @@ DW_HD inline void solve(Problem &p, double minDx)
                 DW_G(p.newY, ncomp, j) = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, fabs(DW_G(p.newQ, ncomp, j)));
                 DW_G(p.newArea, ncomp, j) = intp_tab(p, ncomp, j, C_ELEV, C_AREA, DW_G(p.newY, ncomp, j));
             }
-            backward(p, j);
+            backward(p, j, scan);
             if (jm == 1) {
                 maxCelDx = 0.;
                 for (int m = 1; m <= p.nmstem; ++m) {
@@ -717,13 +781,11 @@ DW_HD inline void solve(Problem &p, double minDx)
                 }
             }
         }
-        const int64_t nn = (int64_t)p.mxncomp * p.nrch;
-        for (int64_t e = 0; e < nn; ++e) {
-            p.oldY[e] = p.newY[e]; p.newY[e] = -999.0;
-            p.oldQ[e] = p.newQ[e]; p.newQ[e] = -999.0;
-            p.oldArea[e] = p.newArea[e]; p.newArea[e] = -999.0;
-            p.pere[e] = -999.0;
-        }
+        // old <- new (:835-841).  The reference copies the arrays and refills the new ones with -999; every entry of
+        // newY / newQ that is read in a sub-step is written earlier in the same sub-step, so exchanging the roles of
+        // the two buffers is equivalent (oldArea, newArea, pere are never read back).
+        { double *sw = p.oldY; p.oldY = p.newY; p.newY = sw; }
+        { double *sw = p.oldQ; p.oldQ = p.newQ; p.newQ = sw; }
     }
     (void)dtini_given;
 }

@@ -24,6 +24,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in trmc.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with trmc.h"
     assert lib.trmc_abi_version() == 2
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "trdw.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(trdw_[a-z0-9_]+)\s*\(", hdr))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in trdw.h but not exported"
+    assert declared == set(_lib.SIGNATURES_DW), "ctypes signature table out of sync with trdw.h"
 
 
 @pytest.mark.skipif(_lib.device_count() > 0, reason="CPU-only check")
