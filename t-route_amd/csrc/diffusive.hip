@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) k_dw_setup(trdw::Problem p, double *min_dx
 {
     if (threadIdx.x == 0) *min_dx = trdw::setup_scalars(p);
 }
-__global__ void __launch_bounds__(64) k_dw_solve(trdw::Problem p, const double *min_dx)
+__global__ void __launch_bounds__(64) k_dw_solve(trdw::Problem p, const double *min_dx, int64_t lds_state)
 {
     // setup_scalars ran in its own launch; its scalar results are recomputed here (they live in the by-value
     // Problem), the arrays it filled are in the work space
@@ -190,6 +190,27 @@ __global__ void __launch_bounds__(64) k_dw_solve(trdw::Problem p, const double *
     WaveScan scan;
     scan.lds = s_tables;
     scan.gcol[0] = scan.gcol[1] = nullptr;
+    // The per-node state of the sweeps (ten arrays) and the per-reach scratch lines move into LDS when they fit:
+    // a lone wavefront cannot hide the latency of the hundreds of dependent loads a sub-step makes, and from LDS
+    // each costs tens of cycles instead of an L2 round trip.  (lds_state = number of doubles granted by the host.)
+    if (lds_state > 0) {
+        const int64_t nn = (int64_t)p.mxncomp * p.nrch;
+        double *w = s_tables + 2 * trdw::kNel;
+        double **grid[] = {&p.z, &p.dx, &p.celerity, &p.diffusivity, &p.qpx, &p.qp, &p.oldQ, &p.newQ, &p.oldY, &p.newY};
+        for (int a = 0; a < 10; ++a) {
+            double *src = *grid[a];
+            for (int64_t e = threadIdx.x & 63; e < nn; e += 64) w[e] = src[e];
+            *grid[a] = w;
+            w += nn;
+        }
+        double **line[] = {&p.eei, &p.ffi, &p.exi, &p.fxi, &p.celerity2, &p.diffusivity2, &p.co};
+        for (int a = 0; a < 7; ++a) { *line[a] = w; w += p.mxncomp; }
+        double *tq = w;
+        for (int e = threadIdx.x & 63; e < p.nts_qtrib; e += 64) tq[e] = 0.0;
+        p.tarr_qtrib = tq;     // (filled by solve() itself)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     trdw::solve(p, *min_dx, scan);
 }
 
@@ -334,8 +355,15 @@ int trdw_diffnw(const double *timestep_ar_g, const int *nts_ql_g, const int *nts
     hipLaunchKernelGGL(k_dw_bed, dim3((nnodes + 255) / 256), dim3(256), 0, 0, p, d_nk, d_nj, nnodes);
     hipLaunchKernelGGL(k_dw_tables_finish, dim3(rows), dim3(256), 0, 0, p, d_nk, d_nj, nnodes);
     DW_TRY(hipEventRecord(ev[1], 0));
-    constexpr size_t kLds = 2 * (size_t)trdw::kNel * sizeof(double);
-    hipLaunchKernelGGL(k_dw_solve, dim3(1), dim3(64), kLds, 0, p, d_min);
+    size_t lds_bytes = 2 * (size_t)trdw::kNel * sizeof(double);
+    const int64_t state_doubles = 10 * (int64_t)nn + 7 * (int64_t)mx + nqt;
+    int64_t lds_state = 0;
+    if (lds_bytes + (size_t)state_doubles * sizeof(double) <= 160 * 1024 - 1024) { // the CU's 160 KB
+        lds_state = state_doubles;
+        lds_bytes += (size_t)state_doubles * sizeof(double);
+        DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
+    hipLaunchKernelGGL(k_dw_solve, dim3(1), dim3(64), lds_bytes, 0, p, d_min, lds_state);
     DW_TRY(hipEventRecord(ev[2], 0));
     DW_TRY(hipGetLastError());
     DW_TRY(hipDeviceSynchronize());

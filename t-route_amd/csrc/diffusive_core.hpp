@@ -25,10 +25,20 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "det_pow64.h"
+
 #if defined(__HIPCC__)
 #define DW_HD __host__ __device__
 #else
 #define DW_HD
+#endif
+
+// x**y for the solver's fractional exponents: the C library's pow on the host (what the reference Fortran calls);
+// on the device the restatement of that library's algorithm (det_pow64.h), so that both give the same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DW_POW(x, y) det_pow64((x), (y))
+#else
+#define DW_POW(x, y) pow((x), (y))
 #endif
 
 namespace trdw {
@@ -334,7 +344,7 @@ DW_HD inline void subsection_at(const Section &s, int kkk, int j, double &el_out
     area = cal_area;
     peri = cal_peri;
     double redi = area / peri;
-    conv = 1.0 / s.mann[kkk] * area * pow(redi, (double)(2.f / 3.f));
+    conv = 1.0 / s.mann[kkk] * area * DW_POW(redi, (double)(2.f / 3.f));
     if (peri <= TOL) conv = 0.0;
     topw = cal_topW;
 }
@@ -576,8 +586,8 @@ template <class Scan> DW_HD inline void backward(Problem &p, int j, Scan &scan)
         DW_G(p.sk, i, j) = scan.apply(be, tb + C_SKK * kNel, kNel, xt);
         const double qpi = DW_G(p.qp, i, j);
         const double sfi = qpi * fabs(qpi) / (p.co[i - 1] * p.co[i - 1]);
-        p.celerity2[i - 1] = (double)(5.0f / 3.0f) * pow(fabs(sfi), (double)0.3f) * pow(fabs(qpi), (double)0.4f)
-                             / pow(DW_G(p.bo, i, j), (double)0.4f) / pow(1. / (DW_G(p.sk, i, j) * 1.0), (double)0.6f);
+        p.celerity2[i - 1] = (double)(5.0f / 3.0f) * DW_POW(fabs(sfi), (double)0.3f) * DW_POW(fabs(qpi), (double)0.4f)
+                             / DW_POW(DW_G(p.bo, i, j), (double)0.4f) / DW_POW(1. / (DW_G(p.sk, i, j) * 1.0), (double)0.6f);
         const double C_ulm = (i > 1) ? p.cfl * DW_G(p.dx, i - 1, j) / p.dtini_min : p.cfl * DW_G(p.dx, i, j) / p.dtini_min;
         if (p.celerity2[i - 1] > C_ulm) p.celerity2[i - 1] = C_ulm;
         p.diffusivity2[i - 1] = fabs(qpi) / 2.0 / DW_G(p.bo, i, j) / fabs(sfi);
@@ -702,9 +712,8 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
                     if (is_mainstem(p, usrchj)) {
                         q_usrch = DW_G(p.newQ, DW_FRNW(usrchj, 1), usrchj);
                     } else {
-                        for (int n = 1; n <= nts_qtrib; ++n) p.varr_qtrib[n - 1] = p.qtrib[(n - 1) + (int64_t)(usrchj - 1) * nts_qtrib];
-                        const double tf0 = t + p.dtini / 60.;
-                        q_usrch = intp_y(nts_qtrib, p.tarr_qtrib, p.varr_qtrib, tf0);
+                        const double tf0 = t + p.dtini / 60.;   // (the tributary's hydrograph column is read in place)
+                        q_usrch = intp_y(nts_qtrib, p.tarr_qtrib, p.qtrib + (int64_t)(usrchj - 1) * nts_qtrib, tf0);
                     }
                     DW_G(p.newQ, 1, j) = DW_G(p.newQ, 1, j) + q_usrch;
                 }
