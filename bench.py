@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=None, help="time chunks of the multi-GPU hand-off pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-ts", action="store_true")
+    ap.add_argument("--no-diffusive", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
 
@@ -122,6 +123,83 @@ def cpu_baseline(net, nsteps, qts, short_ts, target_s):
                   f"{per_thread} segments, incl. the dominant basin, left out) x "
                   f"{nsteps} steps, {dt:.1f} s wall, {len(jobs)} threads, by-network parallelism",
     }
+
+
+def _diffusive_inputs(gold, nsteps):
+    z = np.load(gold)
+    ins = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    ins["timestep_ar_g"] = ins["timestep_ar_g"].copy()
+    ins["timestep_ar_g"][2] = 300.0 * nsteps / 3600.0
+    ins["ntss_ev_g"] = np.array(nsteps + 1)
+    return ins
+
+
+def _diffusive_call(gold, nsteps, path, sym):
+    """c_diffnw's argument list on a host library (the reference build or the host restatement): (seconds, outputs)."""
+    import ctypes as C
+    from troute_amd.routing.fast_reach import diffusive as D
+    ins = _diffusive_inputs(gold, nsteps)
+    lib = C.CDLL(path)
+    keep, args = [], []
+    for k in D.ARG_ORDER:
+        v = ins[k]
+        if k in D._INT_SCALARS:
+            c = C.c_int(int(v))
+            keep.append(c)
+            args.append(C.byref(c))
+        else:
+            arr = np.asfortranarray(v, dtype=np.int32 if k in D._INT_ARRAYS else np.float64)
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=arr.dtype)
+            keep.append(arr)
+            args.append(arr.ctypes.data_as(C.c_void_p))
+    shape = (nsteps + 1, int(ins["mxncomp_g"]), int(ins["nrch_g"]))
+    outs = [np.zeros(shape, dtype=np.float64, order="F") for _ in range(3)]
+    args += [o.ctypes.data_as(C.c_void_p) for o in outs]
+    t0 = time.perf_counter()
+    getattr(lib, sym)(*args)
+    return time.perf_counter() - t0, [np.ascontiguousarray(o) for o in outs]
+
+
+def diffusive_leg(nsteps=12):
+    """Side measurement (BASELINE configs[4]): the diffusive-wave mainstem of the LowerColorado
+    coastal subset on the GPU (trdw_diffnw) beside the reference Fortran diffnw on one host core (oracle/_ref, built from
+    the reference's own sources) and the host instantiation of the same restatement; inputs = the committed golden
+    (marshalled by the reference's diffusive_input_data_v02), shortened to `nsteps` x 300 s."""
+    gold = os.path.join(ROOT, "tests", "golden", "diffusive_lowercolorado.npz")
+    ins = _diffusive_inputs(gold, nsteps)
+    from troute_amd.routing.fast_reach import diffusive as D
+    D.compute_diffusive(ins)                                   # warm-up (module load)
+    t0 = time.perf_counter()
+    got = D.compute_diffusive(ins)
+    gpu_s = time.perf_counter() - t0
+    tables_ms, solve_ms = D.last_timing()
+    out = {"workload": f"LowerColorado_TX coastal subset (hybrid config): {int(ins['nrch_g'])} reaches, "
+                       f"{int((ins['frnw_g'] == 555).sum())} diffusive, {nsteps} x 300 s, synthetic cross sections, fp64",
+           "gpu_s": gpu_s, "gpu_tables_ms": tables_ms, "gpu_solve_ms": solve_ms}
+
+    host = os.path.join(ROOT, "oracle", "libdw_oracle.so")
+    if os.path.exists(host):
+        out["host_restatement_s"], h = _diffusive_call(gold, nsteps, host, "dw_oracle_diffnw")
+        out["gpu_bit_identical_to_host_restatement"] = bool(all(np.array_equal(np.asarray(g), np.asarray(w)) for g, w in zip(got, h)))
+    ref = os.path.join(ROOT, "oracle", "_ref", "libdiff_ref.so")
+    if os.path.exists(ref):
+        # in a child process: the Fortran runtime prints its progress to stdout and flushes it at exit
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            child = (
+                "import sys, time, ctypes as C, numpy as np\n"
+                f"sys.path.insert(0, {ROOT!r})\n"
+                "import bench\n"
+                f"t, outs = bench._diffusive_call({gold!r}, {nsteps}, {ref!r}, 'c_diffnw')\n"
+                f"np.savez({os.path.join(td, 'r.npz')!r}, t=t, q=outs[0], e=outs[1], d=outs[2])\n")
+            subprocess.run([sys.executable, "-c", child], stdout=subprocess.DEVNULL, check=True)
+            r = np.load(os.path.join(td, "r.npz"))
+            out["reference_fortran_s"] = float(r["t"])
+            out["reference_fortran_cores"] = 1
+            out["gpu_bit_identical_to_reference"] = bool(all(np.array_equal(np.asarray(g), r[k]) for g, k in zip(got, "qed")))
+    return out
 
 
 def main():
@@ -235,6 +313,13 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             cpu = {"error": repr(e)}
 
+    diffusive = None
+    if rank == 0 and world == 1 and not a.no_diffusive:
+        try:
+            diffusive = diffusive_leg()
+        except Exception as e:
+            diffusive = {"error": repr(e)}
+
     if rank == 0:
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -275,6 +360,7 @@ def main():
             "cpu_baseline": cpu,
             "full_ts": full,
             "outlet_hydrographs": list(hyd.shape),
+            "diffusive": diffusive,
         }
         print(json.dumps(line))
     router.close()

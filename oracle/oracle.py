@@ -36,6 +36,8 @@ def build(force=False):
         for f in ("mc_oracle.c", "mc_oracle_impl.inc")
     ):
         subprocess.check_call(["make", "-C", _HERE, "libmc_oracle.so"], stdout=subprocess.DEVNULL)
+    # host instantiation of the diffusive-wave solver (make decides whether it is stale)
+    subprocess.check_call(["make", "-C", _HERE, "libdw_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src/kernel/muskingum"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
