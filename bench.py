@@ -178,6 +178,13 @@ def diffusive_leg(nsteps=12):
                        f"{int((ins['frnw_g'] == 555).sum())} diffusive, {nsteps} x 300 s, synthetic cross sections, fp64",
            "gpu_s": gpu_s, "gpu_tables_ms": tables_ms, "gpu_solve_ms": solve_ms}
 
+    # many domains in one launch (one compute unit each): 64 copies of the domain stand in for 64 tailwaters
+    nb = 64
+    t0 = time.perf_counter()
+    many = D.compute_diffusive_batch([ins] * nb)
+    out["batch"] = {"domains": nb, "gpu_s": time.perf_counter() - t0, "gpu_solve_ms": D.last_timing()[1],
+                    "identical_to_single": bool(all(np.array_equal(m[0], got[0]) and np.array_equal(m[2], got[2]) for m in many))}
+    del many
     host = os.path.join(ROOT, "oracle", "libdw_oracle.so")
     if os.path.exists(host):
         out["host_restatement_s"], h = _diffusive_call(gold, nsteps, host, "dw_oracle_diffnw")

@@ -49,7 +49,32 @@ int trdw_diffnw(const double *timestep_ar_g, const int *nts_ql_g, const int *nts
                 const int *cwncol_g, const double *crosswalk_g, const double *z_thalweg_g, double *q_ev_g,
                 double *elv_ev_g, double *depth_ev_g);
 
-/* Device time of the last trdw_diffnw call of this thread: tables_ms (cross-section tables), solve_ms (time loop). */
+/*
+ * Several tailwater domains at once: trdw_args holds one c_diffnw argument list (same pointers, same order); block
+ * b of ONE launch runs the time loop of domain b, so independent domains -- which the reference routes one after the
+ * other (compute.py:1762, "TODO by-network parallel loop") -- advance side by side, one compute unit each.
+ */
+typedef struct trdw_args {
+    const double *timestep_ar_g;
+    const int *nts_ql_g, *nts_ub_g, *nts_db_g, *ntss_ev_g, *nts_qtrib_g, *nts_da_g, *mxncomp_g, *nrch_g;
+    const double *z_ar_g, *bo_ar_g, *traps_ar_g, *tw_ar_g, *twcc_ar_g, *mann_ar_g, *manncc_ar_g, *so_ar_g, *dx_ar_g, *iniq;
+    const int *frnw_col, *frnw_ar_g;
+    const double *qlat_g, *ubcd_g, *dbcd_g, *qtrib_g;
+    const int *paradim;
+    const double *para_ar_g;
+    const int *mxnbathy_g;
+    const double *x_bathy_g, *z_bathy_g, *mann_bathy_g;
+    const int *size_bathy_g;
+    const double *usgs_da_g;
+    const int *usgs_da_reach_g;
+    const double *rdx_ar_g;
+    const int *cwnrow_g, *cwncol_g;
+    const double *crosswalk_g, *z_thalweg_g;
+    double *q_ev_g, *elv_ev_g, *depth_ev_g;
+} trdw_args;
+int trdw_diffnw_batch(int ndomains, const trdw_args *args);
+
+/* Device time of the last trdw_diffnw / trdw_diffnw_batch call of this thread: tables_ms (cross-section tables), solve_ms (time loop). */
 int trdw_last_timing(double *tables_ms, double *solve_ms);
 
 #ifdef __cplusplus

@@ -72,6 +72,7 @@ SIGNATURES_DW = {
     "trdw_last_error": (C.c_char_p, []),
     "trdw_select_device": (_int, [_int]),
     "trdw_diffnw": (_int, [_vp] * 42),
+    "trdw_diffnw_batch": (_int, [_int, _vp]),
     "trdw_last_timing": (_int, [_P(C.c_double), _P(C.c_double)]),
 }
 

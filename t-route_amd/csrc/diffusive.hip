@@ -173,12 +173,24 @@ __global__ void __launch_bounds__(256) k_dw_tables_finish(trdw::Problem p, const
     // dK/dA of level l reads the conveyance and area of level l-1, which this pass does not modify
     trdw::table_row_finish(p, node_k[n], node_j[n], l);
 }
-__global__ void __launch_bounds__(64) k_dw_setup(trdw::Problem p, double *min_dx)
+// one domain of a batch: its problem, where its minDx lives, how many doubles of LDS state it was granted
+struct BatchItem {
+    trdw::Problem p;
+    double *min_dx;
+    int64_t lds_state;
+};
+__global__ void __launch_bounds__(64) k_dw_setup(const BatchItem *items)
 {
-    if (threadIdx.x == 0) *min_dx = trdw::setup_scalars(p);
+    if (threadIdx.x == 0) {
+        trdw::Problem p = items[blockIdx.x].p;
+        *items[blockIdx.x].min_dx = trdw::setup_scalars(p);
+    }
 }
-__global__ void __launch_bounds__(64) k_dw_solve(trdw::Problem p, const double *min_dx, int64_t lds_state)
+// grid = domains: block b runs the whole time loop of domain b in its one wavefront
+__global__ void __launch_bounds__(64) k_dw_solve(const BatchItem *items)
 {
+    trdw::Problem p = items[blockIdx.x].p;
+    const int64_t lds_state = items[blockIdx.x].lds_state;
     // setup_scalars ran in its own launch; its scalar results are recomputed here (they live in the by-value
     // Problem), the arrays it filled are in the work space
     p.dtini = p.timestep_ar[0];
@@ -211,7 +223,184 @@ __global__ void __launch_bounds__(64) k_dw_solve(trdw::Problem p, const double *
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    trdw::solve(p, *min_dx, scan);
+    trdw::solve(p, *items[blockIdx.x].min_dx, scan);
+}
+
+// host side of one domain: device copies of its inputs, its work space, its node list
+struct Domain {
+    std::vector<void *> ptrs;
+    trdw::Problem p;
+    double *d_out = nullptr, *d_min = nullptr;
+    int32_t *d_nk = nullptr, *d_nj = nullptr;
+    int nnodes = 0;
+    size_t nout = 0;
+    int64_t lds_state = 0;
+    size_t lds_bytes = 0;
+    double *q_ev = nullptr, *elv_ev = nullptr, *depth_ev = nullptr; // the caller's output arrays
+    ~Domain() { for (void *q : ptrs) (void)hipFree(q); }
+    int up(const void *src, size_t bytes, void **out, hipStream_t st)
+    {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) return -1;
+        ptrs.push_back(d);
+        if (src && bytes && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        *out = d;
+        return 0;
+    }
+};
+
+// validate one domain's arguments, copy them to the device, queue its table kernels on `st`
+int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
+{
+    if (!a.timestep_ar_g || !a.nts_ql_g || !a.nts_db_g || !a.ntss_ev_g || !a.nts_qtrib_g || !a.mxncomp_g || !a.nrch_g || !a.frnw_col
+        || !a.frnw_ar_g || !a.paradim || !a.para_ar_g || !a.mxnbathy_g || !a.cwnrow_g || !a.q_ev_g || !a.elv_ev_g || !a.depth_ev_g
+        || !a.nts_ub_g || !a.nts_da_g)
+        return dw_fail(TRDW_EINVAL, "a required argument is NULL");
+    if (*a.mxnbathy_g != 0) return dw_fail(TRDW_EUNSUPPORTED, "natural cross sections (mxnbathy_g > 0) are not covered");
+    if (*a.cwnrow_g != 0) return dw_fail(TRDW_EUNSUPPORTED, "the refactored-hydrofabric crosswalk (cwnrow_g > 0) is not covered");
+    if (*a.paradim < 11) return dw_fail(TRDW_EINVAL, "para_ar_g needs 11 entries");
+    const int mx = *a.mxncomp_g, nr = *a.nrch_g, nql = *a.nts_ql_g, nqt = *a.nts_qtrib_g, ndb = *a.nts_db_g, nev = *a.ntss_ev_g,
+              fc = *a.frnw_col;
+    if (mx < 2 || nr < 1 || nql < 1 || nqt < 2 || ndb < 1 || nev < 1 || fc < 5) return dw_fail(TRDW_EINVAL, "bad dimensions");
+    // mainstem nodes (frnw flag 555 behind the upstream list, diffnw :383-394)
+    std::vector<int32_t> node_k, node_j;
+    int nmstem = 0;
+    for (int j = 1; j <= nr; ++j) {
+        const int nus = a.frnw_ar_g[(j - 1) + (size_t)2 * nr];
+        if (nus < 0 || 3 + nus + 1 > fc) return dw_fail(TRDW_EINVAL, "frnw_ar_g: upstream count does not fit frnw_col");
+        const int ncomp = a.frnw_ar_g[(j - 1)];
+        if (ncomp < 2 || ncomp > mx) return dw_fail(TRDW_EINVAL, "frnw_ar_g: node count of a reach outside [2, mxncomp_g]");
+        if (a.frnw_ar_g[(j - 1) + (size_t)(3 + nus) * nr] == 555) {
+            ++nmstem;
+            for (int k = 1; k <= ncomp; ++k) {
+                node_k.push_back(k);
+                node_j.push_back(j);
+            }
+        }
+    }
+    dom.nnodes = (int)node_k.size();
+    if (dom.nnodes == 0) return dw_fail(TRDW_EINVAL, "no mainstem reach (flag 555) in frnw_ar_g");
+    const size_t nn = (size_t)mx * nr;
+    trdw::Problem &p = dom.p;
+    std::memset(&p, 0, sizeof p);
+    p.nts_ql = nql; p.nts_ub = *a.nts_ub_g; p.nts_db = ndb; p.ntss_ev = nev; p.nts_qtrib = nqt; p.nts_da = *a.nts_da_g;
+    p.mxncomp = mx; p.nrch = nr; p.frnw_col = fc;
+    void *d = nullptr;
+#define DW_UP(field, src, count_, type)                                                                                    \
+    if (dom.up(src, (size_t)(count_) * sizeof(type), &d, st)) return dw_fail(TRDW_ENOMEM, "device allocation/copy failed: " #field); \
+    p.field = (const type *)d;
+    DW_UP(timestep_ar, a.timestep_ar_g, 10, double)
+    DW_UP(z_ar, a.z_ar_g, nn, double)
+    DW_UP(bo_ar, a.bo_ar_g, nn, double)
+    DW_UP(traps_ar, a.traps_ar_g, nn, double)
+    DW_UP(tw_ar, a.tw_ar_g, nn, double)
+    DW_UP(twcc_ar, a.twcc_ar_g, nn, double)
+    DW_UP(mann_ar, a.mann_ar_g, nn, double)
+    DW_UP(manncc_ar, a.manncc_ar_g, nn, double)
+    DW_UP(dx_ar, a.dx_ar_g, nn, double)
+    DW_UP(iniq, a.iniq, nn, double)
+    DW_UP(frnw, a.frnw_ar_g, (size_t)nr * fc, int32_t)
+    DW_UP(qlat, a.qlat_g, (size_t)nql * nn, double)
+    DW_UP(dbcd, a.dbcd_g, ndb, double)
+    DW_UP(qtrib, a.qtrib_g, (size_t)nqt * nr, double)
+    DW_UP(para_ar, a.para_ar_g, 11, double)
+#undef DW_UP
+    dom.nout = (size_t)nev * nn;
+    double *d_work = nullptr;
+    int32_t *d_frj = nullptr;
+    if (dom.up(nullptr, 3 * dom.nout * sizeof(double), (void **)&dom.d_out, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed: outputs");
+    const int64_t nwork = trdw::work_doubles(mx, nr, nql, nqt, ndb);
+    if (dom.up(nullptr, (size_t)nwork * sizeof(double), (void **)&d_work, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed: work space");
+    if (dom.up(nullptr, sizeof(double), (void **)&dom.d_min, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    if (dom.up(nullptr, (2 * (size_t)nr + 2) * sizeof(int32_t), (void **)&d_frj, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    if (dom.up(node_k.data(), (size_t)dom.nnodes * sizeof(int32_t), (void **)&dom.d_nk, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    if (dom.up(node_j.data(), (size_t)dom.nnodes * sizeof(int32_t), (void **)&dom.d_nj, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    DW_TRY(hipStreamSynchronize(st)); // node_k / node_j are about to go out of scope
+    DW_TRY(hipMemsetAsync(dom.d_out, 0, 3 * dom.nout * sizeof(double), st));
+    DW_TRY(hipMemsetAsync(d_work, 0, (size_t)nwork * sizeof(double), st));
+    p.q_ev = dom.d_out; p.elv_ev = dom.d_out + dom.nout; p.depth_ev = dom.d_out + 2 * dom.nout;
+    trdw::bind_work(p, d_work);
+    p.mstem_frj = d_frj;
+    p.is_main = d_frj + nr;
+    p.nmstem = nmstem;
+    p.so_llm = a.para_ar_g[8];
+    dom.q_ev = a.q_ev_g; dom.elv_ev = a.elv_ev_g; dom.depth_ev = a.depth_ev_g;
+    // LDS: two elevation columns, plus the sweep state when it fits the CU's 160 KB
+    dom.lds_bytes = 2 * (size_t)trdw::kNel * sizeof(double);
+    const int64_t state_doubles = 10 * (int64_t)nn + 7 * (int64_t)mx + nqt;
+    if (dom.lds_bytes + (size_t)state_doubles * sizeof(double) <= 160 * 1024 - 1024) {
+        dom.lds_state = state_doubles;
+        dom.lds_bytes += (size_t)state_doubles * sizeof(double);
+    }
+    return 0;
+}
+
+// route `n` domains: tables per domain, then ONE launch whose blocks are the domains
+int run_batch(const trdw_args *args, int n)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return dw_fail(TRDW_ENODEVICE, "no HIP device available; this library has no CPU fallback");
+    DW_TRY(hipSetDevice(g_dw_device < count ? g_dw_device : 0));
+    struct Run {
+        hipStream_t st = nullptr;
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        void *d_items = nullptr;
+        std::vector<Domain> doms;
+        ~Run()
+        {
+            if (st) (void)hipStreamSynchronize(st);
+            doms.clear();
+            if (d_items) (void)hipFree(d_items);
+            for (auto &e : ev)
+                if (e) (void)hipEventDestroy(e);
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } run;
+    // a stream of its own, so that calls from several host threads also overlap on the device
+    DW_TRY(hipStreamCreateWithFlags(&run.st, hipStreamNonBlocking));
+    hipStream_t st = run.st;
+    for (int k = 0; k < 3; ++k) DW_TRY(hipEventCreate(&run.ev[k]));
+    run.doms.resize((size_t)n);
+    DW_TRY(hipEventRecord(run.ev[0], st));
+    std::vector<BatchItem> items((size_t)n);
+    size_t lds_max = 0;
+    for (int b = 0; b < n; ++b) {
+        if (int rc = prepare(args[b], run.doms[b], st)) return rc;
+        items[b].p = run.doms[b].p;
+        items[b].min_dx = run.doms[b].d_min;
+        items[b].lds_state = run.doms[b].lds_state;
+        lds_max = lds_max > run.doms[b].lds_bytes ? lds_max : run.doms[b].lds_bytes;
+    }
+    DW_TRY(hipMalloc(&run.d_items, (size_t)n * sizeof(BatchItem)));
+    DW_TRY(hipMemcpyAsync(run.d_items, items.data(), (size_t)n * sizeof(BatchItem), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_dw_setup, dim3(n), dim3(64), 0, st, (const BatchItem *)run.d_items);
+    for (int b = 0; b < n; ++b) {
+        Domain &dm = run.doms[b];
+        const unsigned rows = (unsigned)(((int64_t)dm.nnodes * trdw::kNel + 255) / 256);
+        hipLaunchKernelGGL(k_dw_tables, dim3(rows), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+        hipLaunchKernelGGL(k_dw_bed, dim3((dm.nnodes + 255) / 256), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+        hipLaunchKernelGGL(k_dw_tables_finish, dim3(rows), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+    }
+    DW_TRY(hipEventRecord(run.ev[1], st));
+    if (lds_max > 64 * 1024)
+        DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    hipLaunchKernelGGL(k_dw_solve, dim3(n), dim3(64), lds_max, st, (const BatchItem *)run.d_items);
+    DW_TRY(hipEventRecord(run.ev[2], st));
+    DW_TRY(hipGetLastError());
+    for (int b = 0; b < n; ++b) {
+        Domain &dm = run.doms[b];
+        DW_TRY(hipMemcpyAsync(dm.q_ev, dm.d_out, dm.nout * sizeof(double), hipMemcpyDeviceToHost, st));
+        DW_TRY(hipMemcpyAsync(dm.elv_ev, dm.d_out + dm.nout, dm.nout * sizeof(double), hipMemcpyDeviceToHost, st));
+        DW_TRY(hipMemcpyAsync(dm.depth_ev, dm.d_out + 2 * dm.nout, dm.nout * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    DW_TRY(hipStreamSynchronize(st));
+    float t01 = 0, t12 = 0;
+    DW_TRY(hipEventElapsedTime(&t01, run.ev[0], run.ev[1]));
+    DW_TRY(hipEventElapsedTime(&t12, run.ev[1], run.ev[2]));
+    g_dw_tables_ms = t01;
+    g_dw_solve_ms = t12;
+    return 0;
 }
 
 } // namespace
@@ -249,134 +438,18 @@ int trdw_diffnw(const double *timestep_ar_g, const int *nts_ql_g, const int *nts
                 const int *cwncol_g, const double *crosswalk_g, const double *z_thalweg_g, double *q_ev_g,
                 double *elv_ev_g, double *depth_ev_g)
 {
-    (void)so_ar_g; (void)ubcd_g; (void)x_bathy_g; (void)z_bathy_g; (void)mann_bathy_g; (void)size_bathy_g; (void)usgs_da_g;
-    (void)usgs_da_reach_g; (void)rdx_ar_g; (void)cwncol_g; (void)crosswalk_g; (void)z_thalweg_g; (void)nts_ub_g; (void)nts_da_g;
-    if (!timestep_ar_g || !nts_ql_g || !nts_db_g || !ntss_ev_g || !nts_qtrib_g || !mxncomp_g || !nrch_g || !frnw_col || !frnw_ar_g
-        || !paradim || !para_ar_g || !mxnbathy_g || !cwnrow_g || !q_ev_g || !elv_ev_g || !depth_ev_g)
-        return dw_fail(TRDW_EINVAL, "a required argument is NULL");
-    if (*mxnbathy_g != 0) return dw_fail(TRDW_EUNSUPPORTED, "natural cross sections (mxnbathy_g > 0) are not covered");
-    if (*cwnrow_g != 0) return dw_fail(TRDW_EUNSUPPORTED, "the refactored-hydrofabric crosswalk (cwnrow_g > 0) is not covered");
-    if (*paradim < 11) return dw_fail(TRDW_EINVAL, "para_ar_g needs 11 entries");
-    const int mx = *mxncomp_g, nr = *nrch_g, nql = *nts_ql_g, nqt = *nts_qtrib_g, ndb = *nts_db_g, nev = *ntss_ev_g, fc = *frnw_col;
-    if (mx < 2 || nr < 1 || nql < 1 || nqt < 2 || ndb < 1 || nev < 1 || fc < 5) return dw_fail(TRDW_EINVAL, "bad dimensions");
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-        return dw_fail(TRDW_ENODEVICE, "no HIP device available; this library has no CPU fallback");
-    DW_TRY(hipSetDevice(g_dw_device < count ? g_dw_device : 0));
+    const trdw_args a = {timestep_ar_g, nts_ql_g, nts_ub_g, nts_db_g, ntss_ev_g, nts_qtrib_g, nts_da_g, mxncomp_g, nrch_g,
+                         z_ar_g, bo_ar_g, traps_ar_g, tw_ar_g, twcc_ar_g, mann_ar_g, manncc_ar_g, so_ar_g, dx_ar_g, iniq,
+                         frnw_col, frnw_ar_g, qlat_g, ubcd_g, dbcd_g, qtrib_g, paradim, para_ar_g, mxnbathy_g, x_bathy_g,
+                         z_bathy_g, mann_bathy_g, size_bathy_g, usgs_da_g, usgs_da_reach_g, rdx_ar_g, cwnrow_g, cwncol_g,
+                         crosswalk_g, z_thalweg_g, q_ev_g, elv_ev_g, depth_ev_g};
+    return run_batch(&a, 1);
+}
 
-    // mainstem nodes (frnw flag 555 behind the upstream list, diffnw :383-394)
-    std::vector<int32_t> node_k, node_j;
-    for (int j = 1; j <= nr; ++j) {
-        const int nus = frnw_ar_g[(j - 1) + (size_t)2 * nr];
-        if (nus < 0 || 3 + nus + 1 > fc) return dw_fail(TRDW_EINVAL, "frnw_ar_g: upstream count does not fit frnw_col");
-        const int ncomp = frnw_ar_g[(j - 1)];
-        if (ncomp < 2 || ncomp > mx) return dw_fail(TRDW_EINVAL, "frnw_ar_g: node count of a reach outside [2, mxncomp_g]");
-        if (frnw_ar_g[(j - 1) + (size_t)(3 + nus) * nr] == 555)
-            for (int k = 1; k <= ncomp; ++k) {
-                node_k.push_back(k);
-                node_j.push_back(j);
-            }
-    }
-    const int nnodes = (int)node_k.size();
-    if (nnodes == 0) return dw_fail(TRDW_EINVAL, "no mainstem reach (flag 555) in frnw_ar_g");
-
-    const size_t nn = (size_t)mx * nr;
-    struct Dev {
-        std::vector<void *> ptrs;
-        ~Dev() { for (void *q : ptrs) (void)hipFree(q); }
-        int up(const void *src, size_t bytes, void **out)
-        {
-            void *d = nullptr;
-            if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) return -1;
-            ptrs.push_back(d);
-            if (src && bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return -1;
-            *out = d;
-            return 0;
-        }
-    } dev;
-    trdw::Problem p;
-    std::memset(&p, 0, sizeof p);
-    p.nts_ql = nql; p.nts_ub = *nts_ub_g; p.nts_db = ndb; p.ntss_ev = nev; p.nts_qtrib = nqt; p.nts_da = *nts_da_g;
-    p.mxncomp = mx; p.nrch = nr; p.frnw_col = fc;
-    void *d = nullptr;
-#define DW_UP(field, src, count_, type)                                                                  \
-    if (dev.up(src, (size_t)(count_) * sizeof(type), &d)) return dw_fail(TRDW_ENOMEM, "device allocation/copy failed: " #field); \
-    p.field = (const type *)d;
-    DW_UP(timestep_ar, timestep_ar_g, 10, double)
-    DW_UP(z_ar, z_ar_g, nn, double)
-    DW_UP(bo_ar, bo_ar_g, nn, double)
-    DW_UP(traps_ar, traps_ar_g, nn, double)
-    DW_UP(tw_ar, tw_ar_g, nn, double)
-    DW_UP(twcc_ar, twcc_ar_g, nn, double)
-    DW_UP(mann_ar, mann_ar_g, nn, double)
-    DW_UP(manncc_ar, manncc_ar_g, nn, double)
-    DW_UP(dx_ar, dx_ar_g, nn, double)
-    DW_UP(iniq, iniq, nn, double)
-    DW_UP(frnw, frnw_ar_g, (size_t)nr * fc, int32_t)
-    DW_UP(qlat, qlat_g, (size_t)nql * nn, double)
-    DW_UP(dbcd, dbcd_g, ndb, double)
-    DW_UP(qtrib, qtrib_g, (size_t)nqt * nr, double)
-    DW_UP(para_ar, para_ar_g, 11, double)
-#undef DW_UP
-    const size_t nout = (size_t)nev * nn;
-    double *d_out = nullptr, *d_work = nullptr, *d_min = nullptr;
-    int32_t *d_frj = nullptr, *d_nk = nullptr, *d_nj = nullptr;
-    if (dev.up(nullptr, 3 * nout * sizeof(double), (void **)&d_out)) return dw_fail(TRDW_ENOMEM, "device allocation failed: outputs");
-    const int64_t nwork = trdw::work_doubles(mx, nr, nql, nqt, ndb);
-    if (dev.up(nullptr, (size_t)nwork * sizeof(double), (void **)&d_work)) return dw_fail(TRDW_ENOMEM, "device allocation failed: work space");
-    if (dev.up(nullptr, sizeof(double), (void **)&d_min)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
-    if (dev.up(nullptr, (2 * (size_t)nr + 2) * sizeof(int32_t), (void **)&d_frj)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
-    if (dev.up(node_k.data(), (size_t)nnodes * sizeof(int32_t), (void **)&d_nk)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
-    if (dev.up(node_j.data(), (size_t)nnodes * sizeof(int32_t), (void **)&d_nj)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
-    DW_TRY(hipMemset(d_out, 0, 3 * nout * sizeof(double)));
-    DW_TRY(hipMemset(d_work, 0, (size_t)nwork * sizeof(double)));
-    p.q_ev = d_out; p.elv_ev = d_out + nout; p.depth_ev = d_out + 2 * nout;
-    trdw::bind_work(p, d_work);
-    p.mstem_frj = d_frj;
-    p.is_main = d_frj + nr;
-
-    hipEvent_t ev[3];
-    for (auto &e : ev) DW_TRY(hipEventCreate(&e));
-    DW_TRY(hipEventRecord(ev[0], 0));
-    hipLaunchKernelGGL(k_dw_setup, dim3(1), dim3(64), 0, 0, p, d_min);
-    // (setup_scalars fills p.nmstem in the kernel's copy of p: recompute it for the launches below)
-    p.nmstem = 0;
-    {
-        std::vector<int32_t> frj;
-        for (int j = 1; j <= nr; ++j) {
-            const int nus = frnw_ar_g[(j - 1) + (size_t)2 * nr];
-            if (frnw_ar_g[(j - 1) + (size_t)(3 + nus) * nr] == 555) frj.push_back(j);
-        }
-        p.nmstem = (int)frj.size();
-    }
-    p.so_llm = para_ar_g[8];
-    const unsigned rows = (unsigned)(((int64_t)nnodes * trdw::kNel + 255) / 256);
-    hipLaunchKernelGGL(k_dw_tables, dim3(rows), dim3(256), 0, 0, p, d_nk, d_nj, nnodes);
-    hipLaunchKernelGGL(k_dw_bed, dim3((nnodes + 255) / 256), dim3(256), 0, 0, p, d_nk, d_nj, nnodes);
-    hipLaunchKernelGGL(k_dw_tables_finish, dim3(rows), dim3(256), 0, 0, p, d_nk, d_nj, nnodes);
-    DW_TRY(hipEventRecord(ev[1], 0));
-    size_t lds_bytes = 2 * (size_t)trdw::kNel * sizeof(double);
-    const int64_t state_doubles = 10 * (int64_t)nn + 7 * (int64_t)mx + nqt;
-    int64_t lds_state = 0;
-    if (lds_bytes + (size_t)state_doubles * sizeof(double) <= 160 * 1024 - 1024) { // the CU's 160 KB
-        lds_state = state_doubles;
-        lds_bytes += (size_t)state_doubles * sizeof(double);
-        DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
-    hipLaunchKernelGGL(k_dw_solve, dim3(1), dim3(64), lds_bytes, 0, p, d_min, lds_state);
-    DW_TRY(hipEventRecord(ev[2], 0));
-    DW_TRY(hipGetLastError());
-    DW_TRY(hipDeviceSynchronize());
-    float t01 = 0, t12 = 0;
-    DW_TRY(hipEventElapsedTime(&t01, ev[0], ev[1]));
-    DW_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
-    g_dw_tables_ms = t01;
-    g_dw_solve_ms = t12;
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    DW_TRY(hipMemcpy(q_ev_g, d_out, nout * sizeof(double), hipMemcpyDeviceToHost));
-    DW_TRY(hipMemcpy(elv_ev_g, d_out + nout, nout * sizeof(double), hipMemcpyDeviceToHost));
-    DW_TRY(hipMemcpy(depth_ev_g, d_out + 2 * nout, nout * sizeof(double), hipMemcpyDeviceToHost));
-    return 0;
+int trdw_diffnw_batch(int ndomains, const trdw_args *args)
+{
+    if (ndomains < 1 || !args) return dw_fail(TRDW_EINVAL, "ndomains must be >= 1 and args non-NULL");
+    return run_batch(args, ndomains);
 }
 
 } // extern "C"

@@ -21,8 +21,8 @@ _INT_ARRAYS = {"frnw_g", "size_bathy_g", "usgs_da_reach_g"}
 TRDW_EINVAL, TRDW_EUNSUPPORTED, TRDW_ENOMEM = -1, -2, -5
 
 
-def compute_diffusive(diff_inputs, device=0):
-    lib = _lib.lib()
+def _marshal(diff_inputs):
+    """(keep-alive list, the 42 argument pointers in c_diffnw's order, the three Fortran-ordered output arrays)"""
     keep, args = [], []
     for k in ARG_ORDER:
         v = diff_inputs[k]
@@ -39,9 +39,10 @@ def compute_diffusive(diff_inputs, device=0):
     shape = (int(diff_inputs["ntss_ev_g"]), int(diff_inputs["mxncomp_g"]), int(diff_inputs["nrch_g"]))
     outs = [np.zeros(shape, dtype=np.float64, order="F") for _ in range(3)]
     args += [o.ctypes.data_as(C.c_void_p) for o in outs]
-    rc = lib.trdw_select_device(int(device))
-    if rc == 0:
-        rc = lib.trdw_diffnw(*args)
+    return keep, args, outs
+
+
+def _raise(lib, rc):
     if rc != 0:
         msg = lib.trdw_last_error().decode("utf-8", "replace")
         if rc == TRDW_EUNSUPPORTED:
@@ -51,8 +52,39 @@ def compute_diffusive(diff_inputs, device=0):
         if rc == TRDW_ENOMEM:
             raise MemoryError(msg)
         raise RuntimeError(f"trdw error {rc}: {msg}")
+
+
+def compute_diffusive(diff_inputs, device=0):
+    lib = _lib.lib()
+    keep, args, outs = _marshal(diff_inputs)
+    rc = lib.trdw_select_device(int(device))
+    if rc == 0:
+        rc = lib.trdw_diffnw(*args)
+    _raise(lib, rc)
     # the reference hands back C-ordered copies (diffusive.pyx:124-126)
     return tuple(np.ascontiguousarray(o) for o in outs)
+
+
+def compute_diffusive_batch(diff_inputs_list, device=0):
+    """Several tailwater domains in one launch (trdw_diffnw_batch): one (out_q, out_elv, out_depth) per domain.
+    The reference calls compute_diffusive once per tailwater, one after the other (compute.py:1762-1850)."""
+    lib = _lib.lib()
+    n = len(diff_inputs_list)
+    if n == 0:
+        return []
+    arr = ((C.c_void_p * 42) * n)()
+    keep_all, outs_all = [], []
+    for b, ins in enumerate(diff_inputs_list):
+        keep, args, outs = _marshal(ins)
+        keep_all.append(keep)
+        outs_all.append(outs)
+        for k, a in enumerate(args):
+            arr[b][k] = a.value if isinstance(a, C.c_void_p) else C.cast(a, C.c_void_p).value
+    rc = lib.trdw_select_device(int(device))
+    if rc == 0:
+        rc = lib.trdw_diffnw_batch(n, C.cast(arr, C.c_void_p))
+    _raise(lib, rc)
+    return [tuple(np.ascontiguousarray(o) for o in outs) for outs in outs_all]
 
 
 def last_timing():

@@ -193,6 +193,25 @@ def test_gpu_equals_reference_fortran_bitwise_lowercolorado():
 
 
 @pytest.mark.gpu
+def test_gpu_batch_of_domains_in_one_launch():
+    """trdw_diffnw_batch: different domains (sizes, reach layouts) as the blocks of one launch, each bit-identical to
+    its reference golden -- and to itself when it appears several times in the batch."""
+    from troute_amd.routing.fast_reach import diffusive as D
+    names = ["comb", "chain1", "y3", "comb", "y3"]
+    cases = [load_small(n) for n in names]
+    outs = D.compute_diffusive_batch([c[0] for c in cases])
+    assert len(outs) == len(names)
+    for (ins, want), got in zip(cases, outs):
+        for g, w in zip(got, want):
+            assert same_bits(g, w)
+    assert D.compute_diffusive_batch([]) == []
+    bad = dict(cases[1][0])
+    bad["mxnbathy_g"] = np.array(1)
+    with pytest.raises(NotImplementedError):
+        D.compute_diffusive_batch([cases[0][0], bad])
+
+
+@pytest.mark.gpu
 def test_gpu_given_depth_boundary_equals_host_restatement():
     """Downstream boundary option 1 (a prescribed depth series, the coastal coupling) has no reference golden here:
     the GPU is held to the host instantiation, which is itself pinned to the reference on option 2."""
