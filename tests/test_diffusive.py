@@ -193,6 +193,27 @@ def test_gpu_equals_reference_fortran_bitwise_lowercolorado():
 
 
 @pytest.mark.gpu
+def test_gpu_hybrid_coupling_tributary_flows():
+    """The hybrid configuration end to end on the device: the tributary hydrographs the diffusive solver is fed
+    (qtrib_g of the golden, made from the reference-equivalent MC flows) are, bit for bit, what the GPU MC engine
+    produces for the tributary segments -- so MC on the GPU followed by trdw_diffnw reproduces the reference's
+    MC + diffnw chain (compute.py:1766-1781 hands over results[...][x, ::3])."""
+    from troute_amd.plan import RoutingPlan
+    z = np.load(os.path.join(H.GOLDEN, "diffusive_lowercolorado.npz"))
+    trib = z["trib"]
+    qtrib = z["in_qtrib_g"]                       # [nts_qtrib, nrch]; row 0 = initial condition, rows 1.. = MC flows
+    lc = H.LowerColorado()
+    nsteps = qtrib.shape[0] - 1
+    up_ptr, up_idx = lc.csr()
+    with RoutingPlan(up_ptr, up_idx, lc.params9) as plan:
+        fvd = plan.route(nsteps, lc.qts, True, lc.qlat, lc.q0)
+    row = {int(s): i for i, s in enumerate(lc.ids)}
+    flows = fvd[[row[int(s)] for s in trib], :, 0].astype(np.float64)          # junction_inflows as float64
+    cols = {qtrib[1:, j].tobytes() for j in range(qtrib.shape[1])}
+    assert len(trib) == 115 and all(f.tobytes() in cols for f in flows) and np.abs(flows).max() > 0.1
+
+
+@pytest.mark.gpu
 def test_gpu_batch_of_domains_in_one_launch():
     """trdw_diffnw_batch: different domains (sizes, reach layouts) as the blocks of one launch, each bit-identical to
     its reference golden -- and to itself when it appears several times in the batch."""
