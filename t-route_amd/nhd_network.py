@@ -230,6 +230,43 @@ def dfs_decomposition(N, path_func, source_nodes=None):
     return reaches
 
 
+def dfs_decomposition_depth_tuple(RN, path_func, source_nodes=None):
+    """``dfs_decomposition`` with the junction order of every reach: a list of ``(depth, reach)`` in the order of the
+    decomposition, depth 0 for the reach that ends at the tailwater, +1 across every reach break upstream of it.
+    Reference: nhd_network.py:362-419 (which walks the coalesced reach graph a second time and zips the two lists)."""
+    reaches = dfs_decomposition(RN, path_func, source_nodes)
+    reach_of_tail = {r[-1]: k for k, r in enumerate(reaches)}
+    down = {}
+    for n, ups in RN.items():
+        for u in ups:
+            down[u] = n
+    depth = [None] * len(reaches)
+
+    def depth_of(k):
+        chain = []
+        while depth[k] is None:
+            nxt = down.get(reaches[k][-1])
+            if nxt is None:                       # the tailwater reach
+                depth[k] = 0
+                break
+            chain.append(k)
+            # the reach that contains the node below this reach's last segment starts with it or holds it inside;
+            # find it through its tail by walking down its members
+            n = nxt
+            while n not in reach_of_tail:
+                n = down[n]
+            k = reach_of_tail[n]
+        base = depth[k]
+        for j, c in enumerate(reversed(chain)):
+            depth[c] = base + j + 1
+        return base
+
+    for k in range(len(reaches)):
+        if depth[k] is None:
+            depth_of(k)
+    return list(zip(depth, reaches))
+
+
 def organize_independent_networks(connections, wbody_break_segments=None, gage_break_segments=None):
     """(independent_networks, reaches_bytw, rconn), nhd_network_utilities_v02.py:133-200."""
     rconn = reverse_network(connections)

@@ -241,6 +241,56 @@ def compute_nhd_routing_v02(
     return results
 
 
+def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt, nts, q0, qlats, qts_subdivisions, usgs_df,
+                              lastobs_df, da_parameter_dict, waterbodies_df, topobathy, refactored_diffusive_domain,
+                              refactored_reaches, coastal_boundary_depth_df, unrefactored_topobathy, *, device=0):
+    """Diffusive-wave routing of the mainstem domains after the Muskingum-Cunge pass -- same signature and result list
+    as the reference (compute.py:1740-1885): per tailwater, the MC flows of the tributary segments
+    (``results[...][1][x, ::3]``) become the junction inflows, ``diffusive_input_data_v02`` marshals the solver's
+    arguments, the solver runs, ``unpack_output`` turns its arrays into result rows, tributary rows are masked out.
+    Different on purpose: every tailwater domain of the call is solved in ONE launch
+    (``compute_diffusive_batch``, one compute unit per domain) instead of one after the other."""
+    import pandas as pd
+    from . import diffusive_utils_v02 as diff_utils
+    from .fast_reach import diffusive
+
+    def empty(df):
+        return df is None or getattr(df, "empty", True)
+    if not empty(topobathy) or not empty(unrefactored_topobathy):
+        raise NotImplementedError("natural cross sections (topobathy) are not covered by the device solver")
+    if refactored_diffusive_domain:
+        raise NotImplementedError("the refactored hydrofabric is not covered by the device solver")
+    tws = list(diffusive_network_data)
+    inputs = []
+    for tw in tws:
+        dn = diffusive_network_data[tw]
+        trib_segs, trib_flow = None, None
+        for r in results:                                                    # compute.py:1766-1781
+            x = np.isin(r[0], dn["tributary_segments"])
+            if x.sum() > 0:
+                trib_segs = r[0][x] if trib_segs is None else np.append(trib_segs, r[0][x])
+                trib_flow = r[1][x, ::3] if trib_flow is None else np.append(trib_flow, r[1][x, ::3], axis=0)
+        junction_inflows = pd.DataFrame(data=trib_flow, index=trib_segs)
+        coastal = (coastal_boundary_depth_df.loc[tw].to_frame().T
+                   if not empty(coastal_boundary_depth_df) and tw in coastal_boundary_depth_df.index else pd.DataFrame())
+        dq = qlats.copy()
+        dq.columns = range(dq.shape[1])                                       # compute.py:1822-1823
+        inputs.append(diff_utils.diffusive_input_data_v02(
+            tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
+            dn["param_df"], dq, q0, junction_inflows, qts_subdivisions, t0, nts, dt, waterbodies_df, pd.DataFrame(),
+            pd.DataFrame(), None, None, coastal, pd.DataFrame()))
+    outs = diffusive.compute_diffusive_batch(inputs, device=device)
+    e = np.asarray([])
+    results_diffusive = []
+    for tw, ins, (out_q, out_elv, out_depth) in zip(tws, inputs, outs):
+        rch_list, dat_all = diff_utils.unpack_output(ins["pynw"], ins["ordered_reaches"], out_q, out_depth)
+        x = np.isin(rch_list, diffusive_network_data[tw]["tributary_segments"])    # MC already routed these
+        results_diffusive.append((
+            rch_list[~x], dat_all[~x, 3:], 0, (e, e, e), (e, e, e, e, e), (e, e, e, e, e),
+            np.zeros(dat_all[~x, 3::3].shape), (e, e, e), np.empty(shape=(0, nts + 1), dtype="float32"), (e, e, e, e)))
+    return results_diffusive
+
+
 def new_q0(run_results, index=None):
     """State for the next routing window from a results list: ``[qu0, qd0, h0] = fvd[:, [-3,-3,-1]]``
     (AbstractNetwork.new_q0, AbstractNetwork.py:177-191), as a DataFrame indexed by segment id."""

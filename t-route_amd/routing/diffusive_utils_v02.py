@@ -1,0 +1,198 @@
+"""Input marshalling and output unpacking of the diffusive-wave solver -- the host side of SURVEY 8f rank 3.
+
+Same names, arguments and results as the reference module
+``src/troute-routing/troute/routing/diffusive_utils_v02.py`` for what the Muskingum-Cunge + diffusive hybrid
+configuration uses:
+
+  diffusive_input_data_v02   :659-1155  network of one tailwater -> the argument dictionary of the solver
+                             (``troute_amd.routing.fast_reach.diffusive.compute_diffusive`` / ``c_diffnw``)
+  unpack_output              :1156-1212 solver outputs -> (segment ids, [flow, nan, depth] x time) rows
+
+Own implementation: the reference fills its arrays one ``DataFrame.loc`` scalar at a time inside four nested loops;
+here every reach is one block of rows taken from the parameter / forcing tables.  The arithmetic types are the
+reference's (float32 table columns, e.g. ``qlat / dx`` and ``1 / cs`` are formed in float32 and then stored in the
+float64 arrays), so the dictionaries are equal to the reference's bit for bit -- pinned on the LowerColorado coastal
+subset against the dictionary the reference itself produced (tests/golden/diffusive_lowercolorado.npz).
+
+Not covered (NotImplementedError): natural cross sections (``topobathy_bytw`` non-empty), the refactored hydrofabric
+(``refactored_diffusive_domain``), coastal boundary depth forcing, gage data for diffusive nudging.
+"""
+import math
+from functools import partial
+
+import numpy as np
+
+from .. import nhd_network
+
+
+def _fake_id(seg):
+    """id of the ghost node the reference appends below the last segment of a reach (:771, :828)"""
+    return int(str(seg) + str(2))
+
+
+def _ordered_reaches(tw, connections, rconn, junction_inflows):
+    """Reaches by junction order, in the reference's enumeration (:765-806): ``ordered[o]`` = list of
+    ``[head, {number_segments, segments_list (with the ghost node), upstream_bottom_segments, downstream_head_segment}]``;
+    ``pynw[frj]`` = head segment of Fortran reach frj (orders from the highest down, list order inside an order)."""
+    path_func = partial(nhd_network.split_at_waterbodies_and_junctions, set(junction_inflows.index.to_list()), rconn)
+    tr = nhd_network.dfs_decomposition_depth_tuple(rconn, path_func)
+    jorder_reaches = sorted(tr, key=lambda x: x[0])
+    mx_jorder = max(o for o, _ in jorder_reaches)
+    ordered, bottoms = {}, {}
+    for o, rch in jorder_reaches:
+        rch = list(rch) + [_fake_id(rch[-1])]
+        meta = {
+            "number_segments": len(rch),
+            "segments_list": rch,
+            "upstream_bottom_segments": [_fake_id(x) for x in rconn[rch[0]]],
+            "downstream_head_segment": connections[rch[-2]],
+        }
+        ordered.setdefault(o, []).append([rch[0], meta])
+        bottoms[rch[-1]] = rch
+    pynw, frj = {}, -1
+    for x in range(mx_jorder, -1, -1):
+        for head, _ in ordered[x]:
+            frj += 1
+            pynw[frj] = head
+    return ordered, bottoms, pynw, mx_jorder
+
+
+def fp_network_map(mainstem_seg_list, trib_seg_list, mx_jorder, ordered_reaches, rchbottom_reaches, nrch_g, frnw_col,
+                   dbfksegID, pynw):
+    """Fortran network map (:55-165): per reach [node count, downstream reach (1-based; -99 at the tailwater),
+    number of upstream reaches, their indices (1-based) ..., 555 mainstem / -555 tributary]."""
+    frnw_g = np.zeros((nrch_g, frnw_col), dtype="int32")
+    frj_of_head = {head: frj for frj, head in pynw.items()}
+    main, trib = set(mainstem_seg_list), set(trib_seg_list)
+    frj = -1
+    for x in range(mx_jorder, -1, -1):
+        for head, reach in ordered_reaches[x]:
+            frj += 1
+            segs = reach["segments_list"]
+            frnw_g[frj, 0] = reach["number_segments"]
+            ups = list(reach["upstream_bottom_segments"])
+            frnw_g[frj, 2] = len(ups)
+            col = 3
+            for b in ups:
+                # the reach whose ghost node is b: its head names the Fortran index
+                frnw_g[frj, col] = frj_of_head[rchbottom_reaches[b][0]] + 1
+                col += 1
+            if head in main:
+                frnw_g[frj, 3 + len(ups)] = 555
+            if head in trib:
+                frnw_g[frj, 3 + len(ups)] = -555
+            if dbfksegID in segs:
+                frnw_g[frj, 1] = -100 + 1
+            else:
+                frnw_g[frj, 1] = frj_of_head[reach["downstream_head_segment"][0]] + 1
+    return frnw_g
+
+
+def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_list, trib_seg_list, diffusive_parameters,
+                             param_df, qlat, initial_conditions, junction_inflows, qts_subdivisions, t0, nsteps, dt,
+                             waterbodies_df, topobathy_bytw, usgs_df, refactored_diffusive_domain, refactored_reaches,
+                             coastal_boundary_depth_df, unrefactored_topobathy_bytw):
+    """The solver's argument dictionary for the network draining to tailwater `tw` (reference :659-1155)."""
+    def empty(df):
+        return df is None or getattr(df, "empty", True)
+    if not empty(topobathy_bytw) or not empty(unrefactored_topobathy_bytw):
+        raise NotImplementedError("natural cross sections (topobathy) are not covered by the device solver")
+    if refactored_diffusive_domain:
+        raise NotImplementedError("the refactored hydrofabric (crosswalk) is not covered by the device solver")
+    if not empty(coastal_boundary_depth_df):
+        raise NotImplementedError("coastal boundary depth forcing is not marshalled here (normal depth at the tailwater)")
+    if not empty(usgs_df):
+        raise NotImplementedError("gage data for diffusive nudging: the branch is disabled in the reference solver itself")
+
+    # ---- time and numerical parameters (:700-745)
+    dt_ql_g, saveinterval, tfin_g = 3600.0, dt, (dt * nsteps) / 60 / 60
+    timestep_ar_g = np.zeros(10)
+    timestep_ar_g[[0, 1, 2, 3, 4, 5, 7, 8, 9]] = [dt, 0.0, tfin_g, saveinterval, dt_ql_g, dt, dt, dt, 10.0]
+    para_ar_g = np.array([0.95, 0.5, 10.0, 10000.0, -15.0, -10.0, 1.0, 0.02831, 0.0001, 1.0, 2.0])
+
+    nrch_g = len(reach_list)
+    mxncomp_g = max(len(r) + 1 for r in reach_list)
+    ordered, bottoms, pynw, mx_jorder = _ordered_reaches(tw, connections, rconn, junction_inflows)
+    dbfksegID = _fake_id(tw)
+    frnw_col = 20
+    frnw_g = fp_network_map(mainstem_seg_list, trib_seg_list, mx_jorder, ordered, bottoms, nrch_g, frnw_col, dbfksegID, pynw)
+
+    # ---- per-reach blocks of the parameter table (fp_chgeo_map :168-240, adj_alt1 :10-52, iniq :858-872,
+    #      fp_qlat_map :242-289, tributary hydrographs :905-912)
+    shape = (mxncomp_g, nrch_g)
+    z_ar_g, bo_ar_g, traps_ar_g, tw_ar_g, twcc_ar_g = (np.zeros(shape) for _ in range(5))
+    mann_ar_g, manncc_ar_g, so_ar_g, dx_ar_g, iniq = (np.zeros(shape) for _ in range(5))
+    nts_ql_g = math.ceil(tfin_g * 3600.0 / dt_ql_g)
+    qlat_g = np.zeros((nts_ql_g, mxncomp_g, nrch_g))
+    nts_qtrib_g = int(tfin_g * 3600.0 / dt) + 1
+    qtrib_g = np.zeros((nts_qtrib_g, nrch_g))
+    main = set(mainstem_seg_list)
+    cols = {c: param_df[c] for c in ("bw", "cs", "tw", "twcc", "n", "ncc", "s0", "dx", "alt")}
+    qu0 = initial_conditions["qu0"]
+    qlat_cols = list(range(nts_ql_g))
+    by_frj = [m for x in range(mx_jorder, -1, -1) for _, m in ordered[x]]     # the enumeration pynw follows
+    for frj, head in pynw.items():
+        reach = by_frj[frj]
+        segs = reach["segments_list"]
+        n = reach["number_segments"]
+        real = segs[:-1]                              # without the ghost node
+        src = real + [real[-1]]                       # the bottom node repeats the last segment's geometry
+        bo_ar_g[:n, frj] = cols["bw"].loc[src].values
+        traps_ar_g[:n, frj] = 1 / cols["cs"].loc[src].values
+        tw_ar_g[:n, frj] = cols["tw"].loc[src].values
+        twcc_ar_g[:n, frj] = cols["twcc"].loc[src].values
+        mann_ar_g[:n, frj] = cols["n"].loc[src].values
+        manncc_ar_g[:n, frj] = cols["ncc"].loc[src].values
+        so_ar_g[:n, frj] = cols["s0"].loc[src].values
+        dx_ar_g[:n, frj] = cols["dx"].loc[src].values
+        # node elevations: the segments' altitudes; the bottom node takes the head altitude of the reach below, or,
+        # at the tailwater, drops by slope x length of the last segment
+        z_ar_g[:n - 1, frj] = cols["alt"].loc[real].values
+        if dbfksegID in segs:
+            last = real[-1]
+            z_ar_g[n - 1, frj] = z_ar_g[n - 2, frj] - cols["s0"].loc[last] * cols["dx"].loc[last]
+        else:
+            z_ar_g[n - 1, frj] = float(cols["alt"].loc[reach["downstream_head_segment"]].iloc[0])
+        q = qu0.loc[src].values.astype(np.float64)
+        iniq[:n, frj] = np.where(q < 0.0001, 0.0001, q)
+        qlat_g[:, :n - 1, frj] = (qlat.loc[real, qlat_cols].values / cols["dx"].loc[real].values[:, None]).T
+        if head not in main:
+            qtrib_g[1:, frj] = junction_inflows.loc[head]
+            qtrib_g[0, frj] = qu0.loc[head]
+
+    nts_ub_g = int(tfin_g * 3600.0 / dt)
+    dt_db_g, nts_db_g = 3600.0, int(tfin_g * 3600.0 / 3600.0) + 1   # fp_coastal_boundary_input_map, empty table (:648-654)
+    timestep_ar_g[6] = dt_db_g
+    nts_da_g = int(tfin_g * 3600.0 / dt) + 1                        # fp_da_map, empty table (:537-539)
+    return {
+        "timestep_ar_g": timestep_ar_g, "nts_ql_g": nts_ql_g, "nts_ub_g": nts_ub_g, "nts_db_g": nts_db_g,
+        "nts_qtrib_g": nts_qtrib_g, "ntss_ev_g": int(tfin_g * 3600.0 / dt) + 1, "nts_da_g": nts_da_g,
+        "mxncomp_g": mxncomp_g, "nrch_g": nrch_g, "z_ar_g": z_ar_g, "bo_ar_g": bo_ar_g, "traps_ar_g": traps_ar_g,
+        "tw_ar_g": tw_ar_g, "twcc_ar_g": twcc_ar_g, "mann_ar_g": mann_ar_g, "manncc_ar_g": manncc_ar_g,
+        "so_ar_g": so_ar_g, "dx_ar_g": dx_ar_g, "frnw_col": frnw_col, "frnw_g": frnw_g, "qlat_g": qlat_g,
+        "ubcd_g": np.zeros((nts_ub_g, nrch_g)), "dbcd_g": np.zeros(nts_db_g), "qtrib_g": qtrib_g, "paradim": 11,
+        "para_ar_g": para_ar_g, "mxnbathy_g": 0, "x_bathy_g": np.array([]).reshape(0, 0, 0),
+        "z_bathy_g": np.array([]).reshape(0, 0, 0), "mann_bathy_g": np.array([]).reshape(0, 0, 0),
+        "size_bathy_g": np.array([], dtype="i4").reshape(0, 0), "iniq": iniq, "pynw": pynw, "ordered_reaches": ordered,
+        "usgs_da_g": -4444.0 * np.ones((nts_da_g, nrch_g)), "usgs_da_reach_g": np.zeros(nrch_g, dtype="i4"),
+        "rdx_ar_g": np.array([]).reshape(0, 0), "cwnrow_g": 0, "cwncol_g": 0, "crosswalk_g": np.array([]).reshape(0, 0),
+        "z_thalweg_g": np.array([]).reshape(0, 0),
+    }
+
+
+def unpack_output(pynw, ordered_reaches, out_q, out_elv):
+    """(segment ids, rows [flow, nan, depth-or-elevation] x recorded times, float32) -- reference :1156-1212: node k+1
+    of a reach carries segment k's result; reaches in the dictionary order of `ordered_reaches`."""
+    frj_of_head = {head: frj for frj, head in pynw.items()}
+    nts = out_q.shape[0]
+    ids, blocks = [], []
+    for o in ordered_reaches.keys():
+        for head, meta in ordered_reaches[o]:
+            segs = meta["segments_list"]
+            j = frj_of_head[head]
+            ids.extend(segs[:-1])
+            blk = np.full((len(segs) - 1, nts * 3), np.nan)
+            blk[:, ::3] = np.asarray(out_q)[:, 1:len(segs), j].T
+            blk[:, 2::3] = np.asarray(out_elv)[:, 1:len(segs), j].T
+            blocks.append(blk)
+    return np.asarray(ids, dtype=np.intp), np.asarray(np.concatenate(blocks), dtype="float32")

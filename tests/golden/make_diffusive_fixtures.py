@@ -120,7 +120,13 @@ def lowercolorado(nn, du, nsteps):
         tw, connections, rconn, reaches, mainstem, trib, None, param_df, qlat_df, q0, junction_inflows, lc.qts,
         pd.Timestamp("2021-08-23 13:00"), nsteps, lc.dt, pd.DataFrame(), pd.DataFrame(), pd.DataFrame(), None, None,
         pd.DataFrame(), pd.DataFrame())
-    return ins, {"mainstem": np.array(mainstem), "trib": np.array(trib)}
+    extra = {"mainstem": np.array(mainstem), "trib": np.array(trib), "tw": np.array(tw),
+             "alt": param_df_alt(alt, lc), "junction_inflows": junction_inflows.values}
+    return ins, extra
+
+
+def param_df_alt(alt, lc):
+    return alt.reindex(lc.ids).values.astype(np.float32)
 
 
 def small_cases():
@@ -214,5 +220,9 @@ if __name__ == "__main__":
           int((np.asarray(ins["frnw_g"]) == 555).sum()), "q max", outs[0].max(), "depth max", outs[2].max())
     z = pack(ins, outs)
     z.update(segs)
+    # the reference's unpacking of these outputs (diffusive_utils_v02.py:1156-1212, called with out_depth as in
+    # compute.py:1852-1857)
+    ids, dat = du.unpack_output(ins["pynw"], ins["ordered_reaches"], outs[0], outs[2])
+    z["unpacked_ids"], z["unpacked_dat"] = ids, dat
     np.savez_compressed(os.path.join(HERE, "diffusive_lowercolorado.npz"), **z)
     print({k: os.path.getsize(os.path.join(HERE, k)) for k in ("diffusive_small.npz", "diffusive_lowercolorado.npz")})

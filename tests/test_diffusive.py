@@ -104,6 +104,63 @@ def test_host_restatement_equals_reference_fortran_bitwise_lowercolorado():
     assert want[0].max() > 0.3 and want[2].max() > 0.1
 
 
+def lowercolorado_diffusive_network():
+    """The diffusive domain of the shipped hybrid configuration, built with THIS package's graph utilities the way
+    AbstractRouting.py:255-310 builds it; raw tables from the fixtures."""
+    import pandas as pd
+    from functools import partial
+    from troute_amd import nhd_network as nn
+    z = np.load(os.path.join(H.GOLDEN, "diffusive_lowercolorado.npz"))
+    lc = H.LowerColorado()
+    tw = int(z["tw"])
+    mainstem, trib = [int(x) for x in z["mainstem"]], [int(x) for x in z["trib"]]
+    conn_all = {int(s): ([int(t)] if t != 0 else []) for s, t in zip(lc.ids, lc.to)}
+    connections = {k: conn_all[k] for k in (mainstem + trib)}
+    connections[tw] = []
+    rconn = nn.reverse_network(connections)
+    net = nn.reachable_network(rconn)
+    reaches = nn.dfs_decomposition(net[tw], partial(nn.split_at_waterbodies_and_junctions, set(trib), net[tw]))
+    cols = {c: lc.params9[:, i] for i, c in enumerate(("dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0"))}
+    param_df = pd.DataFrame(cols, index=lc.ids)
+    param_df["alt"] = z["alt"]
+    dn = {"connections": connections, "rconn": rconn, "reaches": reaches, "mainstem_segs": mainstem,
+          "tributary_segments": trib, "param_df": param_df.loc[mainstem + trib]}
+    qlat_df = pd.DataFrame(lc.qlat, index=lc.ids)
+    q0 = pd.DataFrame(lc.q0, index=lc.ids, columns=["qu0", "qd0", "h0"])
+    return z, lc, tw, dn, qlat_df, q0
+
+
+def test_input_marshalling_equals_reference_dictionary():
+    """troute_amd.routing.diffusive_utils_v02.diffusive_input_data_v02 against the dictionary the reference's own
+    function produced for the same network (every array of the c_diffnw call, bit for bit), and unpack_output against
+    the reference's unpacking of the reference outputs."""
+    import pandas as pd
+    from troute_amd.routing import diffusive_utils_v02 as DU
+    z, lc, tw, dn, qlat_df, q0 = lowercolorado_diffusive_network()
+    nsteps = int(z["in_ntss_ev_g"]) - 1
+    junction_inflows = pd.DataFrame(z["junction_inflows"], index=dn["tributary_segments"])
+    ins = DU.diffusive_input_data_v02(
+        tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
+        dn["param_df"], qlat_df, q0, junction_inflows, lc.qts, pd.Timestamp("2021-08-23 13:00"), nsteps, lc.dt,
+        pd.DataFrame(), pd.DataFrame(), pd.DataFrame(), None, None, pd.DataFrame(), pd.DataFrame())
+    for k in ARG_ORDER:
+        want = z["in_" + k]
+        got = np.asarray(ins[k])
+        if k in INT_SCALARS:
+            assert int(got) == int(want), k
+        else:
+            assert got.shape == want.shape or got.size == want.size == 0, k
+            assert np.array_equal(got.astype(want.dtype), want), k
+    ids, dat = DU.unpack_output(ins["pynw"], ins["ordered_reaches"], z["out_q"], z["out_depth"])
+    assert np.array_equal(ids, z["unpacked_ids"])
+    assert dat.dtype == np.float32 and np.array_equal(dat, z["unpacked_dat"], equal_nan=True)
+    with pytest.raises(NotImplementedError, match="natural cross sections"):
+        DU.diffusive_input_data_v02(tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"],
+                                    dn["tributary_segments"], None, dn["param_df"], qlat_df, q0, junction_inflows, lc.qts,
+                                    None, nsteps, lc.dt, pd.DataFrame(), pd.DataFrame({"z": [1.0]}), pd.DataFrame(), None, None,
+                                    pd.DataFrame(), pd.DataFrame())
+
+
 def test_det_pow64_equals_libm_pow():
     """The restated glibc pow (det_pow64.h) against this machine's libm at the solver's exponents."""
     import subprocess
@@ -211,6 +268,40 @@ def test_gpu_hybrid_coupling_tributary_flows():
     flows = fvd[[row[int(s)] for s in trib], :, 0].astype(np.float64)          # junction_inflows as float64
     cols = {qtrib[1:, j].tobytes() for j in range(qtrib.shape[1])}
     assert len(trib) == 115 and all(f.tobytes() in cols for f in flows) and np.abs(flows).max() > 0.1
+
+
+@pytest.mark.gpu
+def test_gpu_hybrid_driver_mc_then_diffusive():
+    """compute_nhd_routing_v02 (MC, GPU) -> compute_diffusive_routing (marshalling mirror + GPU solver) on the
+    LowerColorado hybrid domain, 12 steps: the mainstem rows equal the reference's unpacking of the reference Fortran's
+    outputs (flows bit for bit; the last record to 1e-13, see load_lowercolorado)."""
+    import pandas as pd
+    from troute_amd import nhd_network as nn
+    from troute_amd.routing.compute import compute_diffusive_routing, compute_nhd_routing_v02
+    z, lc, tw, dn, qlat_df, q0 = lowercolorado_diffusive_network()
+    nts = 12
+    conn = {int(s): ([int(t)] if t != 0 else []) for s, t in zip(lc.ids, lc.to)}
+    ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
+    param_df = dn["param_df"].reindex(lc.ids)
+    cols = {c: lc.params9[:, i] for i, c in enumerate(("dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0"))}
+    full = pd.DataFrame(cols, index=lc.ids).drop(columns="dt")
+    full["alt"] = z["alt"]
+    e = pd.DataFrame()
+    t0 = pd.Timestamp("2021-08-23 13:00")
+    results = compute_nhd_routing_v02(
+        conn, rconn, {}, reaches_bytw, "V02-structured", "by-network", 10000, 4, t0, lc.dt, nts, lc.qts, ind, full, q0,
+        qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, e, {}, e, False, [{}, {}])
+    rd = compute_diffusive_routing(results, {tw: dn}, 1, t0, lc.dt, nts, q0, qlat_df, lc.qts, e, e, {}, e, e, None, None, e, e)
+    assert len(rd) == 1 and len(rd[0]) == 10
+    ids, dat = rd[0][0], rd[0][1]
+    keep = ~np.isin(z["unpacked_ids"], dn["tributary_segments"])
+    assert np.array_equal(ids, z["unpacked_ids"][keep])
+    want = z["unpacked_dat"][keep][:, 3:3 * (nts + 1)]
+    assert dat.shape == want.shape == (len(dn["mainstem_segs"]), 3 * nts)
+    assert np.array_equal(dat[:, :-3], want[:, :-3], equal_nan=True)
+    assert np.allclose(dat[:, -3:], want[:, -3:], rtol=1e-6, equal_nan=True)
+    assert rd[0][6].shape == (len(ids), nts)
+    del param_df
 
 
 @pytest.mark.gpu
