@@ -13,8 +13,8 @@
  * additions are the int return value (0, or a negative status with the text in trdw_last_error()) and
  * trdw_select_device().  One call = one tailwater domain: the cross-section tables are built by one thread per
  * (node, water level); the ordered time loop runs in one wavefront whose lanes share every table scan.
- * Covered: synthetic (RouteLink) cross sections, both downstream-boundary options.  Refused with
- * TRDW_EUNSUPPORTED: natural cross sections (mxnbathy_g > 0) and the refactored-hydrofabric crosswalk
+ * Covered: synthetic (RouteLink) and natural (bathymetry, mxnbathy_g > 0) cross sections, both
+ * downstream-boundary options.  Refused with TRDW_EUNSUPPORTED: the refactored-hydrofabric crosswalk
  * (cwnrow_g > 0).  No CPU fallback: without a HIP device the call fails with TRDW_ENODEVICE.
  */
 #ifndef TRDW_H

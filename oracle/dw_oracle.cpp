@@ -19,10 +19,9 @@ extern "C" int dw_oracle_diffnw(
     const double *rdx_ar_g, const int *cwnrow_g, const int *cwncol_g, const double *crosswalk_g, const double *z_thalweg_g,
     double *q_ev_g, double *elv_ev_g, double *depth_ev_g)
 {
-    (void)nts_da_g; (void)so_ar_g; (void)ubcd_g; (void)paradim; (void)x_bathy_g; (void)z_bathy_g; (void)mann_bathy_g;
-    (void)size_bathy_g; (void)usgs_da_g; (void)usgs_da_reach_g; (void)rdx_ar_g; (void)cwncol_g; (void)crosswalk_g;
+    (void)nts_da_g; (void)so_ar_g; (void)ubcd_g; (void)paradim; (void)usgs_da_g; (void)usgs_da_reach_g; (void)rdx_ar_g; (void)cwncol_g; (void)crosswalk_g;
     (void)z_thalweg_g;
-    if (*mxnbathy_g != 0 || *cwnrow_g != 0) return -1; // natural sections / crosswalk: not covered
+    if (*cwnrow_g != 0) return -1; // crosswalk: not covered
     trdw::Problem p;
     memset(&p, 0, sizeof p);
     p.timestep_ar = timestep_ar_g;
@@ -31,30 +30,42 @@ extern "C" int dw_oracle_diffnw(
     p.z_ar = z_ar_g; p.bo_ar = bo_ar_g; p.traps_ar = traps_ar_g; p.tw_ar = tw_ar_g; p.twcc_ar = twcc_ar_g;
     p.mann_ar = mann_ar_g; p.manncc_ar = manncc_ar_g; p.dx_ar = dx_ar_g; p.iniq = iniq;
     p.frnw_col = *frnw_col; p.frnw = frnw_ar_g; p.qlat = qlat_g; p.dbcd = dbcd_g; p.qtrib = qtrib_g; p.para_ar = para_ar_g;
+    p.mxnbathy = *mxnbathy_g; p.x_bathy = x_bathy_g; p.z_bathy = z_bathy_g; p.mann_bathy = mann_bathy_g; p.size_bathy = size_bathy_g;
     p.q_ev = q_ev_g; p.elv_ev = elv_ev_g; p.depth_ev = depth_ev_g;
     const long long nout = (long long)p.ntss_ev * p.mxncomp * p.nrch;
     for (long long e = 0; e < nout; ++e) q_ev_g[e] = elv_ev_g[e] = depth_ev_g[e] = 0.0;
-    double *w = (double *)calloc((size_t)trdw::work_doubles(p.mxncomp, p.nrch, p.nts_ql, p.nts_qtrib, p.nts_db), sizeof(double));
+    double *w = (double *)calloc((size_t)trdw::work_doubles(p.mxncomp, p.nrch, p.nts_ql, p.nts_qtrib, p.nts_db, p.mxnbathy), sizeof(double));
     int32_t *frj = (int32_t *)calloc(2 * (size_t)p.nrch + 2, sizeof(int32_t));
     if (!w || !frj) return -2;
     trdw::bind_work(p, w);
     p.mstem_frj = frj;
     p.is_main = frj + p.nrch;
     const double minDx = trdw::setup_scalars(p);
-    // tables of every mainstem node; the node's bed elevation becomes the notch of its section
+    // tables of every mainstem node; the node's bed elevation becomes the lowest point of its section
+    const bool natural = p.mxnbathy > 0;
     for (int m = 0; m < p.nmstem; ++m) {
         const int j = p.mstem_frj[m], ncomp = p.frnw[(j - 1) + 0];
         for (int k = 1; k <= ncomp; ++k) {
-            trdw::Section s;
-            trdw::make_section(p, k, j, s);
-            for (int l = 1; l <= trdw::kNel; ++l) trdw::table_row(p, s, k, j, l);
-            p.z[(k - 1) + (long long)(j - 1) * p.mxncomp] = s.el_min;
+            if (natural) {
+                trdw::nat_vertices(p, k, j);
+                const trdw::NatSection s = trdw::nat_section(p, k, j);
+                for (int l = 1; l <= trdw::kNel; ++l) trdw::nat_row(p, s, k, j, l);
+                trdw::nat_smooth(p, k, j);
+                p.z[(k - 1) + (long long)(j - 1) * p.mxncomp] = s.el_min;
+            } else {
+                trdw::Section s;
+                trdw::make_section(p, k, j, s);
+                for (int l = 1; l <= trdw::kNel; ++l) trdw::table_row(p, s, k, j, l);
+                p.z[(k - 1) + (long long)(j - 1) * p.mxncomp] = s.el_min;
+            }
         }
     }
     for (int m = 0; m < p.nmstem; ++m) {
         const int j = p.mstem_frj[m], ncomp = p.frnw[(j - 1) + 0];
         for (int k = 1; k <= ncomp; ++k)
-            for (int l = trdw::kNel; l >= 1; --l) trdw::table_row_finish(p, k, j, l);
+            for (int l = trdw::kNel; l >= 1; --l) {
+                if (natural) trdw::nat_row_finish(p, k, j, l); else trdw::table_row_finish(p, k, j, l);
+            }
     }
     static long long counters[4];
     counters[0] = counters[1] = counters[2] = 0;

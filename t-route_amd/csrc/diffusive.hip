@@ -171,7 +171,29 @@ __global__ void __launch_bounds__(256) k_dw_tables_finish(trdw::Problem p, const
     if (g >= (int64_t)nnodes * trdw::kNel) return;
     const int n = (int)(g / trdw::kNel), l = (int)(g % trdw::kNel) + 1;
     // dK/dA of level l reads the conveyance and area of level l-1, which this pass does not modify
-    trdw::table_row_finish(p, node_k[n], node_j[n], l);
+    if (p.mxnbathy > 0) trdw::nat_row_finish(p, node_k[n], node_j[n], l);
+    else trdw::table_row_finish(p, node_k[n], node_j[n], l);
+}
+// natural cross sections: vertex lists (one thread per node), table levels (one thread per (node, level)), then the
+// two monotonicity passes over the levels of a node, which are sequential in the level (one thread per node)
+__global__ void __launch_bounds__(256) k_dw_nat_vertices(trdw::Problem p, const int32_t *node_k, const int32_t *node_j, int nnodes)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < nnodes) trdw::nat_vertices(p, node_k[n], node_j[n]);
+}
+__global__ void __launch_bounds__(256) k_dw_nat_rows(trdw::Problem p, const int32_t *node_k, const int32_t *node_j, int nnodes)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (int64_t)nnodes * trdw::kNel) return;
+    const int n = (int)(g / trdw::kNel), l = (int)(g % trdw::kNel) + 1;
+    trdw::nat_row(p, trdw::nat_section(p, node_k[n], node_j[n]), node_k[n], node_j[n], l);
+}
+__global__ void __launch_bounds__(64) k_dw_nat_smooth(trdw::Problem p, const int32_t *node_k, const int32_t *node_j, int nnodes)
+{
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= nnodes) return;
+    trdw::nat_smooth(p, node_k[n], node_j[n]);
+    p.z[(node_k[n] - 1) + (int64_t)(node_j[n] - 1) * p.mxncomp] = trdw::nat_section(p, node_k[n], node_j[n]).el_min; // :2031
 }
 // one domain of a batch: its problem, where its minDx lives, how many doubles of LDS state it was granted
 struct BatchItem {
@@ -256,7 +278,9 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
         || !a.frnw_ar_g || !a.paradim || !a.para_ar_g || !a.mxnbathy_g || !a.cwnrow_g || !a.q_ev_g || !a.elv_ev_g || !a.depth_ev_g
         || !a.nts_ub_g || !a.nts_da_g)
         return dw_fail(TRDW_EINVAL, "a required argument is NULL");
-    if (*a.mxnbathy_g != 0) return dw_fail(TRDW_EUNSUPPORTED, "natural cross sections (mxnbathy_g > 0) are not covered");
+    if (*a.mxnbathy_g < 0) return dw_fail(TRDW_EINVAL, "mxnbathy_g is negative");
+    if (*a.mxnbathy_g > 0 && (!a.x_bathy_g || !a.z_bathy_g || !a.mann_bathy_g || !a.size_bathy_g))
+        return dw_fail(TRDW_EINVAL, "bathymetry arrays are NULL although mxnbathy_g > 0");
     if (*a.cwnrow_g != 0) return dw_fail(TRDW_EUNSUPPORTED, "the refactored-hydrofabric crosswalk (cwnrow_g > 0) is not covered");
     if (*a.paradim < 11) return dw_fail(TRDW_EINVAL, "para_ar_g needs 11 entries");
     const int mx = *a.mxncomp_g, nr = *a.nrch_g, nql = *a.nts_ql_g, nqt = *a.nts_qtrib_g, ndb = *a.nts_db_g, nev = *a.ntss_ev_g,
@@ -304,12 +328,24 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
     DW_UP(dbcd, a.dbcd_g, ndb, double)
     DW_UP(qtrib, a.qtrib_g, (size_t)nqt * nr, double)
     DW_UP(para_ar, a.para_ar_g, 11, double)
+    p.mxnbathy = *a.mxnbathy_g;
+    if (p.mxnbathy > 0) {
+        for (size_t e = 0; e < nn; ++e)
+            if (a.size_bathy_g[e] < 0 || a.size_bathy_g[e] > p.mxnbathy) return dw_fail(TRDW_EINVAL, "size_bathy_g entry outside [0, mxnbathy_g]");
+        for (int n_ = 0; n_ < dom.nnodes; ++n_)
+            if (a.size_bathy_g[(node_k[n_] - 1) + (size_t)(node_j[n_] - 1) * mx] < 2)
+                return dw_fail(TRDW_EINVAL, "a mainstem node has fewer than two bathymetry stations");
+        DW_UP(x_bathy, a.x_bathy_g, (size_t)p.mxnbathy * nn, double)
+        DW_UP(z_bathy, a.z_bathy_g, (size_t)p.mxnbathy * nn, double)
+        DW_UP(mann_bathy, a.mann_bathy_g, (size_t)p.mxnbathy * nn, double)
+        DW_UP(size_bathy, a.size_bathy_g, nn, int32_t)
+    }
 #undef DW_UP
     dom.nout = (size_t)nev * nn;
     double *d_work = nullptr;
     int32_t *d_frj = nullptr;
     if (dom.up(nullptr, 3 * dom.nout * sizeof(double), (void **)&dom.d_out, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed: outputs");
-    const int64_t nwork = trdw::work_doubles(mx, nr, nql, nqt, ndb);
+    const int64_t nwork = trdw::work_doubles(mx, nr, nql, nqt, ndb, p.mxnbathy);
     if (dom.up(nullptr, (size_t)nwork * sizeof(double), (void **)&d_work, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed: work space");
     if (dom.up(nullptr, sizeof(double), (void **)&dom.d_min, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     if (dom.up(nullptr, (2 * (size_t)nr + 2) * sizeof(int32_t), (void **)&d_frj, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
@@ -378,8 +414,14 @@ int run_batch(const trdw_args *args, int n)
     for (int b = 0; b < n; ++b) {
         Domain &dm = run.doms[b];
         const unsigned rows = (unsigned)(((int64_t)dm.nnodes * trdw::kNel + 255) / 256);
-        hipLaunchKernelGGL(k_dw_tables, dim3(rows), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
-        hipLaunchKernelGGL(k_dw_bed, dim3((dm.nnodes + 255) / 256), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+        if (dm.p.mxnbathy > 0) {
+            hipLaunchKernelGGL(k_dw_nat_vertices, dim3((dm.nnodes + 255) / 256), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+            hipLaunchKernelGGL(k_dw_nat_rows, dim3(rows), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+            hipLaunchKernelGGL(k_dw_nat_smooth, dim3((dm.nnodes + 63) / 64), dim3(64), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+        } else {
+            hipLaunchKernelGGL(k_dw_tables, dim3(rows), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+            hipLaunchKernelGGL(k_dw_bed, dim3((dm.nnodes + 255) / 256), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
+        }
         hipLaunchKernelGGL(k_dw_tables_finish, dim3(rows), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
     }
     DW_TRY(hipEventRecord(run.ev[1], st));

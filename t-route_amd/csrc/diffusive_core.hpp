@@ -10,8 +10,8 @@
 // The boundary is the bind(c) symbol c_diffnw (src/kernel/diffusive/pydiffusive.f90:8-55): same arguments,
 // Fortran (column-major) arrays.
 //
-// Not covered (the entry point refuses them): natural cross sections (mxnbathy_g > 0,
-// readXsection_natural_mann_vertices :1756-2091) and the refactored-hydrofabric crosswalk (cwnrow_g > 0, :873-925).
+// Natural cross sections (mxnbathy_g > 0, readXsection_natural_mann_vertices :1756-2091) are covered as well.
+// Not covered (the entry point refuses it): the refactored-hydrofabric crosswalk (cwnrow_g > 0, :873-925).
 // The streamflow-DA branch is commented out in the reference itself (:1301-1327).
 //
 // Layout of the computation (not of the reference's call tree):
@@ -57,6 +57,10 @@ struct Problem {
     int frnw_col;
     const int32_t *frnw;
     const double *qlat, *dbcd, *qtrib;
+    int mxnbathy;                               // > 0: natural cross sections (bathymetry stations per node)
+    const double *x_bathy, *z_bathy, *mann_bathy; // [mxnbathy][mxncomp][nrch]
+    const int32_t *size_bathy;                  // [mxncomp][nrch]
+    double *nat_v;                              // work: vertex lists [mxncomp*nrch][3][mxnbathy + 2]
     const double *para_ar;
     double *q_ev, *elv_ev, *depth_ev;
     // ---- work space (caller allocated; sizes in work_doubles()) ---------------------------------------------
@@ -74,11 +78,11 @@ struct Problem {
     int dsbc_option;
 };
 
-DW_HD inline int64_t work_doubles(int mxncomp, int nrch, int nts_ql, int nts_qtrib, int nts_db)
+DW_HD inline int64_t work_doubles(int mxncomp, int nrch, int nts_ql, int nts_qtrib, int nts_db, int mxnbathy)
 {
     const int64_t nn = (int64_t)mxncomp * nrch;
     return nn * kCols * kNel + 16 * nn + 7 * (int64_t)mxncomp + 2 * ((int64_t)nts_ql + 1) + 2 * (int64_t)nts_qtrib
-           + 2 * (int64_t)nts_db + 8;
+           + 2 * (int64_t)nts_db + 8 + (mxnbathy > 0 ? nn * 3 * (int64_t)(mxnbathy + 3) : 0);
 }
 
 // carve the work space out of one allocation
@@ -97,6 +101,7 @@ DW_HD inline void bind_work(Problem &p, double *w)
     p.varr_qtrib = w; w += p.nts_qtrib;
     p.tarr_db = w; w += p.nts_db;
     p.varr_db = w; w += p.nts_db;
+    p.nat_v = w;
 }
 
 // 1-based accessors in the reference's index order
@@ -347,6 +352,147 @@ DW_HD inline void subsection_at(const Section &s, int kkk, int j, double &el_out
     conv = 1.0 / s.mann[kkk] * area * DW_POW(redi, (double)(2.f / 3.f));
     if (peri <= TOL) conv = 0.0;
     topw = cal_topW;
+}
+
+// ---- natural cross sections (readXsection_natural_mann_vertices, diffusive.f90:1756-2091) ----------------------
+// Vertices of node (k, jr): the bathymetry stations shifted to start at x = 0, Manning's n capped at 0.15, and one
+// vertex on an infinite vertical wall at either end; 1-based arrays xcs/ycs/mcs[1..num] inside p.nat_v.
+struct NatSection {
+    const double *xcs, *ycs, *mcs; // 1-based views (index 0 unused)
+    int num;
+    double el_min, el_range, el_incr;
+};
+DW_HD inline double *nat_block(const Problem &p, int k, int jr)
+{
+    return p.nat_v + (((int64_t)(jr - 1) * p.mxncomp + (k - 1)) * 3) * (int64_t)(p.mxnbathy + 3);
+}
+#define DW_BATHY(a, ic, k, jr) (a)[((ic) - 1) + (int64_t)p.mxnbathy * (((k) - 1) + (int64_t)p.mxncomp * ((jr) - 1))]
+DW_HD inline void nat_vertices(Problem &p, int k, int jr)
+{
+    const int nb = p.size_bathy[(k - 1) + (int64_t)(jr - 1) * p.mxncomp];
+    const int num = nb + 2;
+    double *xcs = nat_block(p, k, jr), *ycs = xcs + (p.mxnbathy + 3), *mcs = ycs + (p.mxnbathy + 3);
+    const double x0 = DW_BATHY(p.x_bathy, 1, k, jr);
+    for (int ic = 2; ic <= nb + 1; ++ic) {
+        xcs[ic] = (-x0 + DW_BATHY(p.x_bathy, ic - 1, k, jr)) * 1.0;
+        ycs[ic] = DW_BATHY(p.z_bathy, ic - 1, k, jr) * 1.0;
+        double m = DW_BATHY(p.mann_bathy, ic - 1, k, jr);
+        if (m > (double)0.15f) m = (double)0.15f;
+        mcs[ic] = m;
+    }
+    double el_min = (double)99999.f, el_max = -(double)99999.f;
+    for (int ic = 2; ic <= num - 1; ++ic) {
+        if (ycs[ic] < el_min) el_min = ycs[ic];
+        if (ycs[ic] > el_max) el_max = ycs[ic];
+    }
+    const double el_range = (el_max - el_min) * 4.0; // timesDepth
+    xcs[1] = xcs[2];
+    ycs[1] = el_min + el_range + 1.0;
+    xcs[num] = xcs[num - 1];
+    ycs[num] = el_min + el_range + 1.0;
+    mcs[1] = 0.0;
+    mcs[num - 1] = 0.0;
+    mcs[num] = 0.0;
+    xcs[0] = el_min;   // slot 0 of the three lists carries the scalars of the section
+    ycs[0] = el_range;
+    mcs[0] = (double)num;
+}
+DW_HD inline NatSection nat_section(const Problem &p, int k, int jr)
+{
+    NatSection s;
+    const double *b = nat_block(p, k, jr);
+    s.xcs = b; s.ycs = b + (p.mxnbathy + 3); s.mcs = s.ycs + (p.mxnbathy + 3);
+    s.el_min = s.xcs[0]; s.el_range = s.ycs[0]; s.num = (int)s.mcs[0];
+    s.el_incr = s.el_range / (double)(float)(kNel - 1.0f);
+    return s;
+}
+// one table level of a natural section (:1840-1927): elevation, area, perimeter, top width, conveyance with the
+// equivalent Manning's n of the wetted vertices, 1/n; sub-areas are accumulated as they close (the order the reference
+// adds them in)
+DW_HD inline void nat_row(Problem &p, const NatSection &s, int k, int jr, int iel)
+{
+    const double TOL = (double)1e-8f;
+    const double *xcs = s.xcs, *ycs = s.ycs, *mcs = s.mcs;
+    const int num = s.num;
+    double el_now = s.el_min + (double)(float)(iel - 1) * s.el_incr;
+    if (fabs(el_now - s.el_min) < TOL) el_now = el_now + (double)0.00001f;
+    double cal_area = 0.0, cal_peri = 0.0, cal_topW = 0.0, cal_mann = 0.0;
+    int i_find = 0, i1 = -999;
+    for (int ic = 1; ic <= num - 1; ++ic) {
+        const double y1 = ycs[ic], y2 = ycs[ic + 1];
+        if (el_now <= y1 && el_now > y2 && i_find == 0) { i_find = 1; i1 = ic; }
+        if (el_now > y1 && el_now <= y2 && i_find == 1) {
+            i_find = 0;
+            const int i2 = ic;
+            double xa = xcs[i1], xb = xcs[i1 + 1], ya = ycs[i1], yb = ycs[i1 + 1];
+            const double x_start = (ya == yb) ? xa : xa + (el_now - ya) / (yb - ya) * (xb - xa);
+            xa = xcs[i2]; xb = xcs[i2 + 1]; ya = ycs[i2]; yb = ycs[i2 + 1];
+            const double x_end = (ya == yb) ? xa : xa + (el_now - ya) / (yb - ya) * (xb - xa);
+            cal_topW = x_end - x_start + cal_topW;
+            cal_area = cal_area + cal_tri_area(el_now, x_start, xcs[i1 + 1], ycs[i1 + 1]) + cal_multi_area(el_now, xcs, ycs, i1 + 1, i2)
+                       + cal_tri_area(el_now, x_end, xcs[i2], ycs[i2]);
+            cal_peri = cal_peri + cal_dist(x_start, el_now, xcs[i1 + 1], ycs[i1 + 1]) + cal_perimeter(xcs, ycs, i1 + 1, i2)
+                       + cal_dist(x_end, el_now, xcs[i2], ycs[i2]);
+            double pm = 0.0;
+            for (int i = i1 + 1; i <= i2 - 1; ++i) pm = pm + cal_dist(xcs[i], ycs[i], xcs[i + 1], ycs[i + 1]) * DW_POW(mcs[i], 1.5);
+            cal_mann = cal_mann + cal_dist(x_start, el_now, xcs[i1 + 1], ycs[i1 + 1]) * DW_POW(mcs[i1], 1.5) + pm
+                       + cal_dist(x_end, el_now, xcs[i2], ycs[i2]) * DW_POW(mcs[i2], 1.5);
+            if (i1 == 1) cal_peri = cal_peri - cal_dist(x_start, el_now, xcs[i1 + 1], ycs[i1 + 1]);
+            if (i2 == num - 1) cal_peri = cal_peri - cal_dist(x_end, el_now, xcs[i2], ycs[i2]);
+        }
+    }
+    const double redi = cal_area / cal_peri;
+    const double equiv_mann = DW_POW(cal_mann / cal_peri, (double)(2.0f / 3.0f));
+    double conv = (1.0 / equiv_mann) * cal_area * DW_POW(redi, (double)(2.0f / 3.0f));
+    if (cal_peri <= TOL) conv = 0.0;
+    DW_TAB(C_ELEV, iel, k, jr) = el_now;
+    DW_TAB(C_AREA, iel, k, jr) = cal_area;
+    DW_TAB(C_PERI, iel, k, jr) = cal_peri;
+    DW_TAB(C_CONV, iel, k, jr) = conv;
+    DW_TAB(C_TOPW, iel, k, jr) = cal_topW;
+    DW_TAB(C_SKK, iel, k, jr) = 1.0 / equiv_mann;
+}
+// dK/dA and the two monotonicity passes over the levels of one node (:1929-1990) -- sequential in the level
+DW_HD inline void nat_smooth(Problem &p, int k, int jr)
+{
+    double *conv = &DW_TAB(C_CONV, 1, k, jr) - 1, *dkda = &DW_TAB(C_DKDA, 1, k, jr) - 1; // 1-based views
+    const double *a1 = &DW_TAB(C_AREA, 1, k, jr) - 1, *el1 = &DW_TAB(C_ELEV, 1, k, jr) - 1;
+    for (int iel = 1; iel <= kNel; ++iel)
+        dkda[iel] = (iel == 1) ? conv[iel] / a1[iel] : (conv[iel] - conv[iel - 1]) / (a1[iel] - a1[iel - 1]);
+    const double incr_rate = (double)0.01f;
+    // (the reference assigns to its loop variable's start inside the loop, which a Fortran do-loop ignores: every
+    // level from 2 to nel is visited)
+    for (int iel = 2; iel <= kNel; ++iel) {
+        if (conv[iel] <= conv[iel - 1]) {
+            int ii = iel;
+            while (conv[ii] < conv[iel - 1] && ii < kNel) ii = ii + 1;
+            const int inc = ii;
+            if (inc >= kNel && conv[inc] < conv[iel - 1]) conv[inc] = (1.0 + incr_rate) * conv[iel - 1];
+            const double pos_slope = (conv[inc] - conv[iel - 1]) / (el1[inc] - el1[iel - 1]);
+            for (int q = iel; q <= inc - 1; ++q) conv[q] = conv[iel - 1] + pos_slope * (el1[q] - el1[iel - 1]);
+            for (int q = iel; q <= inc - 1; ++q)
+                dkda[q] = (q == 1) ? conv[q] / a1[q] : (conv[q] - conv[q - 1]) / (a1[q] - a1[q - 1]);
+        }
+    }
+    for (int iel = 2; iel <= kNel; ++iel) {
+        if (dkda[iel] <= dkda[iel - 1]) {
+            int ii = iel;
+            while (dkda[ii] < dkda[iel - 1] && ii < kNel) ii = ii + 1;
+            const int inc = ii;
+            if (inc >= kNel && dkda[inc] < dkda[iel - 1]) dkda[inc] = (1.0 + incr_rate) * dkda[iel - 1];
+            const double pos_slope = (dkda[inc] - dkda[iel - 1]) / (el1[inc] - el1[iel - 1]);
+            for (int q = iel; q <= inc - 1; ++q) dkda[q] = dkda[iel - 1] + pos_slope * (el1[q] - el1[iel - 1]);
+        }
+    }
+}
+// the uniform-flow column of a natural-section node (:470-486; dK/dA is already final)
+DW_HD inline void nat_row_finish(Problem &p, int k, int jr, int j)
+{
+    const int ncomp = DW_FRNW(jr, 1);
+    double slope = (k < ncomp) ? (DW_G(p.z, k, jr) - DW_G(p.z, k + 1, jr)) / DW_G(p.dx, k, jr)
+                               : (DW_G(p.z, k - 1, jr) - DW_G(p.z, k, jr)) / DW_G(p.dx, k - 1, jr);
+    if (slope <= p.so_llm) slope = p.so_llm;
+    DW_TAB(C_UNIF, j, k, jr) = DW_TAB(C_CONV, j, k, jr) * sqrt(slope);
 }
 
 // One table row (node k of reach jr, level j): the columns that depend on this level only; dK/dA needs level

@@ -199,6 +199,27 @@ def small_cases():
              "rdx_ar_g": np.zeros((0, 0)), "cwnrow_g": 0, "cwncol_g": 0, "crosswalk_g": np.zeros((0, 0)),
              "z_thalweg_g": np.zeros((0, 0))}
         cases.append((name, d))
+        if name in ("y3", "comb"):
+            # the same mainstem with natural cross sections (use_natl_xsections: True): 7-13 surveyed stations per node,
+            # x negative left of the stream line, Manning's n per station (some above the 0.15 cap), bed = the node elevation
+            dn = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+            mxb = 13
+            xb, zb, mb = (np.zeros((mxb, mx, nrch)) for _ in range(3))
+            sb = np.zeros((mx, nrch), np.int32)
+            for j, r in enumerate(layout):
+                for k in range(r["n"]):
+                    ns = int(rng.integers(7, mxb + 1))
+                    half = rng.uniform(15.0, 60.0)
+                    x = np.sort(rng.uniform(-half, half, ns))
+                    x[0], x[-1] = -half, half
+                    prof = 0.002 * x ** 2 + 0.6 * np.abs(np.sin(x / 9.0)) * (np.abs(x) > 6.0)   # a channel and bumpy overbanks
+                    prof[np.argmin(np.abs(x))] = 0.0
+                    sb[k, j] = ns
+                    xb[:ns, k, j] = x
+                    zb[:ns, k, j] = geo["z"][k, j] + prof
+                    mb[:ns, k, j] = np.where(np.abs(x) > 8.0, rng.uniform(0.06, 0.2, ns), rng.uniform(0.025, 0.045, ns))
+            dn.update({"mxnbathy_g": mxb, "x_bathy_g": xb, "z_bathy_g": zb, "mann_bathy_g": mb, "size_bathy_g": sb})
+            cases.append((name + "_nat", dn))
     return cases
 
 

@@ -22,7 +22,7 @@ ARG_ORDER = ["timestep_ar_g", "nts_ql_g", "nts_ub_g", "nts_db_g", "ntss_ev_g", "
 INT_SCALARS = {"nts_ql_g", "nts_ub_g", "nts_db_g", "ntss_ev_g", "nts_qtrib_g", "nts_da_g", "mxncomp_g", "nrch_g", "frnw_col",
                "paradim", "mxnbathy_g", "cwnrow_g", "cwncol_g"}
 INT_ARRAYS = {"frnw_g", "size_bathy_g", "usgs_da_reach_g"}
-SMALL = ("chain1", "y3", "comb")
+SMALL = ("chain1", "y3", "comb", "y3_nat", "comb_nat")       # *_nat: natural (bathymetry) cross sections
 
 
 def load_small(name):
@@ -173,13 +173,13 @@ static unsigned long long s = 88172645463325252ull;
 static double rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (s >> 11) * (1.0 / 9007199254740992.0); }
 int main(void)
 {
-    const float ef[5] = {0.3f, 0.4f, 0.6f, 2.f / 3.f, 5.f / 3.f};
+    const float ef[6] = {0.3f, 0.4f, 0.6f, 2.f / 3.f, 5.f / 3.f, 1.5f};   /* 1.5: natural-section Manning weights */
     long bad = 0;
     volatile double probe = 6.1817510939031299e-05;      /* libm's result here is not the correctly rounded one */
     double a = pow(probe, (double)0.4f), c = det_pow64(probe, (double)0.4f);
     bad += memcmp(&a, &c, 8) != 0;
     const double edge[] = {0.0, 1.0, 2.2250738585072014e-308, 4.9406564584124654e-324, 1e-310, 1.7976931348623157e308, 0.5, 2.0};
-    for (int e = 0; e < 5; ++e) {
+    for (int e = 0; e < 6; ++e) {
         const double y = (double)ef[e];
         for (unsigned k = 0; k < sizeof edge / sizeof edge[0]; ++k) {
             volatile double x = edge[k];
@@ -212,9 +212,9 @@ def test_python_mirror_refuses_what_is_not_covered_and_has_no_cpu_fallback():
         with pytest.raises(RuntimeError, match="no HIP device"):
             D.compute_diffusive(ins)
         return
-    bad = dict(ins)
-    bad["mxnbathy_g"] = np.array(3)
-    with pytest.raises(NotImplementedError, match="natural cross sections"):
+    bad = dict(load_small("y3_nat")[0])
+    bad["size_bathy_g"] = np.where(bad["size_bathy_g"] > 0, 1, 0).astype(bad["size_bathy_g"].dtype)
+    with pytest.raises(ValueError, match="fewer than two bathymetry stations"):
         D.compute_diffusive(bad)
     bad = dict(ins)
     bad["cwnrow_g"] = np.array(2)
@@ -309,7 +309,7 @@ def test_gpu_batch_of_domains_in_one_launch():
     """trdw_diffnw_batch: different domains (sizes, reach layouts) as the blocks of one launch, each bit-identical to
     its reference golden -- and to itself when it appears several times in the batch."""
     from troute_amd.routing.fast_reach import diffusive as D
-    names = ["comb", "chain1", "y3", "comb", "y3"]
+    names = ["comb", "chain1", "y3_nat", "y3", "comb", "comb_nat", "y3"]
     cases = [load_small(n) for n in names]
     outs = D.compute_diffusive_batch([c[0] for c in cases])
     assert len(outs) == len(names)
@@ -318,7 +318,7 @@ def test_gpu_batch_of_domains_in_one_launch():
             assert same_bits(g, w)
     assert D.compute_diffusive_batch([]) == []
     bad = dict(cases[1][0])
-    bad["mxnbathy_g"] = np.array(1)
+    bad["cwnrow_g"] = np.array(1)
     with pytest.raises(NotImplementedError):
         D.compute_diffusive_batch([cases[0][0], bad])
 
