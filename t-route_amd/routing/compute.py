@@ -256,8 +256,6 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
 
     def empty(df):
         return df is None or getattr(df, "empty", True)
-    if not empty(topobathy) or not empty(unrefactored_topobathy):
-        raise NotImplementedError("natural cross sections (topobathy) are not covered by the device solver")
     if refactored_diffusive_domain:
         raise NotImplementedError("the refactored hydrofabric is not covered by the device solver")
     tws = list(diffusive_network_data)
@@ -273,11 +271,12 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
         junction_inflows = pd.DataFrame(data=trib_flow, index=trib_segs)
         coastal = (coastal_boundary_depth_df.loc[tw].to_frame().T
                    if not empty(coastal_boundary_depth_df) and tw in coastal_boundary_depth_df.index else pd.DataFrame())
+        topo = topobathy.loc[dn["mainstem_segs"]] if not empty(topobathy) else pd.DataFrame()      # compute.py:1783-1796
         dq = qlats.copy()
         dq.columns = range(dq.shape[1])                                       # compute.py:1822-1823
         inputs.append(diff_utils.diffusive_input_data_v02(
             tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
-            dn["param_df"], dq, q0, junction_inflows, qts_subdivisions, t0, nts, dt, waterbodies_df, pd.DataFrame(),
+            dn["param_df"], dq, q0, junction_inflows, qts_subdivisions, t0, nts, dt, waterbodies_df, topo,
             pd.DataFrame(), None, None, coastal, pd.DataFrame()))
     outs = diffusive.compute_diffusive_batch(inputs, device=device)
     e = np.asarray([])

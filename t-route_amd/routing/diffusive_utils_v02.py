@@ -14,8 +14,11 @@ reference's (float32 table columns, e.g. ``qlat / dx`` and ``1 / cs`` are formed
 float64 arrays), so the dictionaries are equal to the reference's bit for bit -- pinned on the LowerColorado coastal
 subset against the dictionary the reference itself produced (tests/golden/diffusive_lowercolorado.npz).
 
-Not covered (NotImplementedError): natural cross sections (``topobathy_bytw`` non-empty), the refactored hydrofabric
-(``refactored_diffusive_domain``), coastal boundary depth forcing, gage data for diffusive nudging.
+Natural cross sections (``topobathy_bytw``, fp_naturalxsec_map :394-510) and the coastal depth boundary
+(``coastal_boundary_depth_df``, fp_coastal_boundary_input_map :575-657) are marshalled as the reference does.
+
+Not covered (NotImplementedError): the refactored hydrofabric (``refactored_diffusive_domain``) and gage data for
+diffusive nudging (the branch is switched off inside the reference solver).
 """
 import math
 from functools import partial
@@ -88,6 +91,72 @@ def fp_network_map(mainstem_seg_list, trib_seg_list, mx_jorder, ordered_reaches,
     return frnw_g
 
 
+def fp_naturalxsec_map(ordered_reaches, mainstem_seg_list, topobathy_bytw, param_df, mx_jorder, mxncomp_g, nrch_g,
+                       dbfksegID):
+    """Station tables of the mainstem nodes (:394-510): ``x/z/mann_bathy_g[station, node, reach]`` and the station
+    count per node.  A node carries its segment's cross section; the bottom node of a reach takes the head segment of
+    the reach below; the tailwater's bottom node repeats the last segment's section lowered by slope x length."""
+    if topobathy_bytw is None or topobathy_bytw.empty:
+        z3 = np.array([]).reshape(0, 0, 0)
+        return z3, z3.copy(), z3.copy(), np.array([], dtype="i4").reshape(0, 0), 0
+    newer = "cs_id" in topobathy_bytw.columns                       # the two column vocabularies of the input file
+    cx, cz, cn = ("relative_dist", "Z", "roughness") if newer else ("xid_d", "z", "n")
+    mxnbathy_g = int(topobathy_bytw.index.value_counts().max())
+    x_bathy_g, z_bathy_g, mann_bathy_g = (np.zeros((mxnbathy_g, mxncomp_g, nrch_g)) for _ in range(3))
+    size_bathy_g = np.zeros((mxncomp_g, nrch_g), dtype="i4")
+    # one pass over the table: rows of every cross section, in file order
+    rows = {}
+    for pos, key in enumerate(topobathy_bytw.index.values):
+        rows.setdefault(key, []).append(pos)
+    xs, zs, ns = (topobathy_bytw[c].values for c in (cx, cz, cn))
+    main = set(mainstem_seg_list)
+    frj = -1
+    for o in range(mx_jorder, -1, -1):
+        for head, reach in ordered_reaches[o]:
+            frj += 1
+            if head not in main:
+                continue
+            segs, ncomp = reach["segments_list"], reach["number_segments"]
+            for k, seg in enumerate(segs):
+                if k == ncomp - 1 and o > 0:
+                    src = reach["downstream_head_segment"][0]
+                elif seg == dbfksegID:
+                    src = segs[k - 1]
+                else:
+                    src = seg
+                r = rows[src]
+                m = len(r)
+                size_bathy_g[k, frj] = m
+                x_bathy_g[:m, k, frj] = xs[r]
+                z_bathy_g[:m, k, frj] = zs[r]
+                mann_bathy_g[:m, k, frj] = ns[r]
+                if seg == dbfksegID:
+                    z_bathy_g[:m, k, frj] = z_bathy_g[:m, k, frj] - param_df.loc[src].s0 * param_df.loc[src].dx
+    return x_bathy_g, z_bathy_g, mann_bathy_g, size_bathy_g, mxnbathy_g
+
+
+def fp_coastal_boundary_input_map(tw, coastal_boundary_depth_df, nrch_g, t0, t0_g, tfin_g):
+    """Water depth series at the tailwater (:575-657) -> (interval [s], boundary option, count, series).  Depths <= 0
+    become the smallest positive depth of the row; gaps are bridged linearly over at most 6 records from either side;
+    anything still missing in ANY row of the table switches the domain back to the normal-depth boundary (option 2)."""
+    import pandas as pd
+    if coastal_boundary_depth_df is None or coastal_boundary_depth_df.empty:
+        nts_db_g = int((tfin_g - t0_g) * 3600.0 / 3600.0) + 1
+        return 3600.0, 2, nts_db_g, np.zeros(nts_db_g)
+    c = coastal_boundary_depth_df.columns
+    dt_db_g = (c[1] - c[0]).total_seconds()
+    nts_db_g = int((tfin_g - t0_g) * 3600.0 / dt_db_g) + 1
+    step = pd.Timedelta(minutes=dt_db_g / 60.0)
+    stamps = pd.date_range(t0, t0 + step * (nts_db_g - 1), freq=step)
+    df = coastal_boundary_depth_df.reindex(columns=stamps).astype(float)
+    row = df.loc[tw]
+    df.loc[tw, row <= 0] = row.where(row > 0).min()
+    df = df.interpolate(axis="columns", limit_direction="both", limit=6)
+    if df.isnull().values.any():
+        return dt_db_g, 2, nts_db_g, np.zeros(nts_db_g)
+    return dt_db_g, 1, nts_db_g, df.loc[tw].values.astype(float)
+
+
 def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_list, trib_seg_list, diffusive_parameters,
                              param_df, qlat, initial_conditions, junction_inflows, qts_subdivisions, t0, nsteps, dt,
                              waterbodies_df, topobathy_bytw, usgs_df, refactored_diffusive_domain, refactored_reaches,
@@ -95,12 +164,8 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
     """The solver's argument dictionary for the network draining to tailwater `tw` (reference :659-1155)."""
     def empty(df):
         return df is None or getattr(df, "empty", True)
-    if not empty(topobathy_bytw) or not empty(unrefactored_topobathy_bytw):
-        raise NotImplementedError("natural cross sections (topobathy) are not covered by the device solver")
     if refactored_diffusive_domain:
         raise NotImplementedError("the refactored hydrofabric (crosswalk) is not covered by the device solver")
-    if not empty(coastal_boundary_depth_df):
-        raise NotImplementedError("coastal boundary depth forcing is not marshalled here (normal depth at the tailwater)")
     if not empty(usgs_df):
         raise NotImplementedError("gage data for diffusive nudging: the branch is disabled in the reference solver itself")
 
@@ -161,8 +226,12 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
             qtrib_g[0, frj] = qu0.loc[head]
 
     nts_ub_g = int(tfin_g * 3600.0 / dt)
-    dt_db_g, nts_db_g = 3600.0, int(tfin_g * 3600.0 / 3600.0) + 1   # fp_coastal_boundary_input_map, empty table (:648-654)
+    dt_db_g, dsbd_option, nts_db_g, dbcd_g = fp_coastal_boundary_input_map(tw, coastal_boundary_depth_df, nrch_g, t0, 0.0,
+                                                                           tfin_g)
     timestep_ar_g[6] = dt_db_g
+    para_ar_g[10] = dsbd_option
+    x_bathy_g, z_bathy_g, mann_bathy_g, size_bathy_g, mxnbathy_g = fp_naturalxsec_map(
+        ordered, mainstem_seg_list, topobathy_bytw, param_df, mx_jorder, mxncomp_g, nrch_g, dbfksegID)
     nts_da_g = int(tfin_g * 3600.0 / dt) + 1                        # fp_da_map, empty table (:537-539)
     return {
         "timestep_ar_g": timestep_ar_g, "nts_ql_g": nts_ql_g, "nts_ub_g": nts_ub_g, "nts_db_g": nts_db_g,
@@ -170,10 +239,9 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
         "mxncomp_g": mxncomp_g, "nrch_g": nrch_g, "z_ar_g": z_ar_g, "bo_ar_g": bo_ar_g, "traps_ar_g": traps_ar_g,
         "tw_ar_g": tw_ar_g, "twcc_ar_g": twcc_ar_g, "mann_ar_g": mann_ar_g, "manncc_ar_g": manncc_ar_g,
         "so_ar_g": so_ar_g, "dx_ar_g": dx_ar_g, "frnw_col": frnw_col, "frnw_g": frnw_g, "qlat_g": qlat_g,
-        "ubcd_g": np.zeros((nts_ub_g, nrch_g)), "dbcd_g": np.zeros(nts_db_g), "qtrib_g": qtrib_g, "paradim": 11,
-        "para_ar_g": para_ar_g, "mxnbathy_g": 0, "x_bathy_g": np.array([]).reshape(0, 0, 0),
-        "z_bathy_g": np.array([]).reshape(0, 0, 0), "mann_bathy_g": np.array([]).reshape(0, 0, 0),
-        "size_bathy_g": np.array([], dtype="i4").reshape(0, 0), "iniq": iniq, "pynw": pynw, "ordered_reaches": ordered,
+        "ubcd_g": np.zeros((nts_ub_g, nrch_g)), "dbcd_g": dbcd_g, "qtrib_g": qtrib_g, "paradim": 11,
+        "para_ar_g": para_ar_g, "mxnbathy_g": mxnbathy_g, "x_bathy_g": x_bathy_g, "z_bathy_g": z_bathy_g,
+        "mann_bathy_g": mann_bathy_g, "size_bathy_g": size_bathy_g, "iniq": iniq, "pynw": pynw, "ordered_reaches": ordered,
         "usgs_da_g": -4444.0 * np.ones((nts_da_g, nrch_g)), "usgs_da_reach_g": np.zeros(nrch_g, dtype="i4"),
         "rdx_ar_g": np.array([]).reshape(0, 0), "cwnrow_g": 0, "cwncol_g": 0, "crosswalk_g": np.array([]).reshape(0, 0),
         "z_thalweg_g": np.array([]).reshape(0, 0),

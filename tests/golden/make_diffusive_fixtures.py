@@ -88,7 +88,39 @@ def pack(d, outs):
     return z
 
 
-def lowercolorado(nn, du, nsteps):
+def synthetic_topobathy(mainstem, param_df, seed=5):
+    """A station table in the layout of the topobathy file (index = link id; xid_d, z, n per station): a parabolic
+    channel with bumpy overbanks around each segment's RouteLink altitude, 9-17 stations, rough overbanks."""
+    rng = np.random.default_rng(seed)
+    idx, xs, zs, ns = [], [], [], []
+    for seg in mainstem:
+        m = int(rng.integers(9, 18))
+        half = float(param_df.loc[seg, "tw"]) * rng.uniform(1.5, 3.0)
+        x = np.sort(np.concatenate([[0.0], rng.uniform(-half, half, m - 1)]))
+        prof = 6.0 * (x / half) ** 2 + 0.4 * np.abs(np.sin(x / 7.0)) * (np.abs(x) > 0.4 * half)
+        prof[np.argmin(np.abs(x))] = 0.0
+        idx += [seg] * m
+        xs.append(x - x[0])
+        zs.append(float(param_df.loc[seg, "alt"]) + prof)
+        ns.append(np.where(np.abs(x) > 0.5 * half, rng.uniform(0.06, 0.2, m), rng.uniform(0.025, 0.05, m)))
+    return pd.DataFrame({"xid_d": np.concatenate(xs), "z": np.concatenate(zs), "n": np.concatenate(ns)},
+                        index=pd.Index(idx, name="comid"))
+
+
+def synthetic_coastal_depths(tw, t0, hours):
+    """Hourly water depths at two boundary nodes: a tide with a non-positive record and a missing record at `tw`."""
+    cols = pd.date_range(t0, periods=hours, freq="h")
+    k = np.arange(hours)
+    a = 1.8 + 0.9 * np.sin(k / 2.3)
+    a[1] = -0.2
+    b = 2.5 + 0.3 * np.cos(k / 3.1)
+    df = pd.DataFrame([a, b], index=[tw, tw + 1], columns=cols)
+    if hours > 3:
+        df.iloc[0, 2] = np.nan
+    return df
+
+
+def lowercolorado(nn, du, nsteps, natural=False, coastal=False):
     lc = H.LowerColorado()
     d = f"{REF}/test/LowerColorado_TX"
     dom = yaml.safe_load(open(f"{d}/domain/coastal_domain_subset.yaml"))
@@ -116,12 +148,20 @@ def lowercolorado(nn, du, nsteps):
     junction_inflows = pd.DataFrame(fvd[[row[s] for s in trib], 1:, 0].astype(np.float32), index=trib)
     qlat_df = pd.DataFrame(lc.qlat, index=lc.ids)
     q0 = pd.DataFrame(lc.q0, index=lc.ids, columns=["qu0", "qd0", "h0"])
+    t0 = pd.Timestamp("2021-08-23 13:00")
+    topo = synthetic_topobathy(mainstem, param_df) if natural else pd.DataFrame()
+    coast = synthetic_coastal_depths(tw, t0, max(2, int(np.ceil(nsteps * lc.dt / 3600.0)) + 1)) if coastal else pd.DataFrame()
     ins = du.diffusive_input_data_v02(
         tw, connections, rconn, reaches, mainstem, trib, None, param_df, qlat_df, q0, junction_inflows, lc.qts,
-        pd.Timestamp("2021-08-23 13:00"), nsteps, lc.dt, pd.DataFrame(), pd.DataFrame(), pd.DataFrame(), None, None,
-        pd.DataFrame(), pd.DataFrame())
+        t0, nsteps, lc.dt, pd.DataFrame(), topo, pd.DataFrame(), None, None, coast, pd.DataFrame())
     extra = {"mainstem": np.array(mainstem), "trib": np.array(trib), "tw": np.array(tw),
              "alt": param_df_alt(alt, lc), "junction_inflows": junction_inflows.values}
+    if natural:
+        extra.update({"topo_index": topo.index.values, "topo_xid_d": topo["xid_d"].values, "topo_z": topo["z"].values,
+                      "topo_n": topo["n"].values})
+    if coastal:
+        extra.update({"coast_index": coast.index.values, "coast_values": coast.values,
+                      "coast_times": np.array([str(c) for c in coast.columns])})
     return ins, extra
 
 
@@ -246,4 +286,16 @@ if __name__ == "__main__":
     ids, dat = du.unpack_output(ins["pynw"], ins["ordered_reaches"], outs[0], outs[2])
     z["unpacked_ids"], z["unpacked_dat"] = ids, dat
     np.savez_compressed(os.path.join(HERE, "diffusive_lowercolorado.npz"), **z)
-    print({k: os.path.getsize(os.path.join(HERE, k)) for k in ("diffusive_small.npz", "diffusive_lowercolorado.npz")})
+    # the same domain with natural cross sections and a coastal depth boundary (use_natl_xsections / coastal_boundary_domain
+    # of the v4 hybrid configuration; the station table and the depth series are synthetic, no such file ships with the
+    # reference's test data), 36 steps = 3 h
+    ins, segs = lowercolorado(nn, du, nsteps=36, natural=True, coastal=True)
+    outs = call_reference(ins)
+    print("LowerColorado natural + coastal: mxnbathy", ins["mxnbathy_g"], "dsbd option", ins["para_ar_g"][10], "dbcd", ins["dbcd_g"],
+          "q max", outs[0].max(), "depth max", outs[2].max())
+    assert ins["mxnbathy_g"] > 0 and ins["para_ar_g"][10] == 1 and np.isfinite(outs[0]).all()
+    z = pack(ins, outs)
+    z.update(segs)
+    np.savez_compressed(os.path.join(HERE, "diffusive_lowercolorado_nat.npz"), **z)
+    print({k: os.path.getsize(os.path.join(HERE, k)) for k in ("diffusive_small.npz", "diffusive_lowercolorado.npz",
+                                                                "diffusive_lowercolorado_nat.npz")})

@@ -31,8 +31,8 @@ def load_small(name):
     return {k[3:]: v for k, v in d.items() if k.startswith("in_")}, (d["out_q"], d["out_elv"], d["out_depth"])
 
 
-def load_lowercolorado(nsteps=None):
-    z = np.load(os.path.join(H.GOLDEN, "diffusive_lowercolorado.npz"))
+def load_lowercolorado(nsteps=None, fixture="diffusive_lowercolorado.npz"):
+    z = np.load(os.path.join(H.GOLDEN, fixture))
     ins = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
     want = (z["out_q"], z["out_elv"], z["out_depth"])
     if nsteps is not None:
@@ -104,13 +104,26 @@ def test_host_restatement_equals_reference_fortran_bitwise_lowercolorado():
     assert want[0].max() > 0.3 and want[2].max() > 0.1
 
 
-def lowercolorado_diffusive_network():
+def test_host_restatement_equals_reference_fortran_bitwise_natural_sections_and_coastal_depth():
+    """The same domain with a station table per mainstem segment (natural cross sections, 9-17 stations) and a
+    prescribed water depth at the tailwater (boundary option 1) -- the v4 hybrid configuration's switches; the whole
+    36-step run of the reference Fortran, to the last bit."""
+    ins, want = load_lowercolorado(None, "diffusive_lowercolorado_nat.npz")
+    assert int(ins["mxnbathy_g"]) == 17 and ins["para_ar_g"][10] == 1.0 and ins["size_bathy_g"].max() == 17
+    rc, got = call_c(host_oracle(), "dw_oracle_diffnw", ins)
+    assert rc == 0
+    for g, w in zip(got, want):
+        assert same_bits(g, w)
+    assert want[2].max() > 2.0
+
+
+def lowercolorado_diffusive_network(fixture="diffusive_lowercolorado.npz"):
     """The diffusive domain of the shipped hybrid configuration, built with THIS package's graph utilities the way
     AbstractRouting.py:255-310 builds it; raw tables from the fixtures."""
     import pandas as pd
     from functools import partial
     from troute_amd import nhd_network as nn
-    z = np.load(os.path.join(H.GOLDEN, "diffusive_lowercolorado.npz"))
+    z = np.load(os.path.join(H.GOLDEN, fixture))
     lc = H.LowerColorado()
     tw = int(z["tw"])
     mainstem, trib = [int(x) for x in z["mainstem"]], [int(x) for x in z["trib"]]
@@ -154,11 +167,52 @@ def test_input_marshalling_equals_reference_dictionary():
     ids, dat = DU.unpack_output(ins["pynw"], ins["ordered_reaches"], z["out_q"], z["out_depth"])
     assert np.array_equal(ids, z["unpacked_ids"])
     assert dat.dtype == np.float32 and np.array_equal(dat, z["unpacked_dat"], equal_nan=True)
-    with pytest.raises(NotImplementedError, match="natural cross sections"):
+    with pytest.raises(NotImplementedError, match="refactored"):
         DU.diffusive_input_data_v02(tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"],
                                     dn["tributary_segments"], None, dn["param_df"], qlat_df, q0, junction_inflows, lc.qts,
-                                    None, nsteps, lc.dt, pd.DataFrame(), pd.DataFrame({"z": [1.0]}), pd.DataFrame(), None, None,
+                                    None, nsteps, lc.dt, pd.DataFrame(), pd.DataFrame(), pd.DataFrame(), {"links": [1]}, None,
                                     pd.DataFrame(), pd.DataFrame())
+
+
+def natural_and_coastal_tables(z):
+    import pandas as pd
+    topo = pd.DataFrame({"xid_d": z["topo_xid_d"], "z": z["topo_z"], "n": z["topo_n"]},
+                        index=pd.Index(z["topo_index"], name="comid"))
+    coast = pd.DataFrame(z["coast_values"], index=z["coast_index"], columns=pd.to_datetime(z["coast_times"]))
+    return topo, coast
+
+
+def test_input_marshalling_natural_sections_and_coastal_depth_equal_reference_dictionary():
+    """fp_naturalxsec_map and fp_coastal_boundary_input_map of the mirror against the dictionary the reference made
+    from the same station table and depth series: a non-positive depth replaced, a gap bridged, option 1 chosen."""
+    import pandas as pd
+    from troute_amd.routing import diffusive_utils_v02 as DU
+    z, lc, tw, dn, qlat_df, q0 = lowercolorado_diffusive_network("diffusive_lowercolorado_nat.npz")
+    topo, coast = natural_and_coastal_tables(z)
+    assert np.isnan(coast.values).sum() == 1 and (coast.values <= 0).sum() == 1
+    nsteps = int(z["in_ntss_ev_g"]) - 1
+    junction_inflows = pd.DataFrame(z["junction_inflows"], index=dn["tributary_segments"])
+    t0 = pd.Timestamp("2021-08-23 13:00")
+    a = (tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
+         dn["param_df"], qlat_df, q0, junction_inflows, lc.qts, t0, nsteps, lc.dt, pd.DataFrame())
+    ins = DU.diffusive_input_data_v02(*a, topo, pd.DataFrame(), None, None, coast, pd.DataFrame())
+    for k in ARG_ORDER:
+        want = z["in_" + k]
+        got = np.asarray(ins[k])
+        if k in INT_SCALARS:
+            assert int(got) == int(want), k
+        else:
+            assert got.shape == want.shape or got.size == want.size == 0, k
+            assert np.array_equal(got.astype(want.dtype), want), k
+    # a row that stays incomplete anywhere in the table sends the domain back to the normal-depth boundary (:642-645)
+    holes = coast.copy()
+    holes.iloc[1, :] = np.nan
+    ins = DU.diffusive_input_data_v02(*a, topo, pd.DataFrame(), None, None, holes, pd.DataFrame())
+    assert ins["para_ar_g"][10] == 2.0 and not ins["dbcd_g"].any() and len(ins["dbcd_g"]) == len(z["in_dbcd_g"])
+    # the newer column vocabulary of the station table (:486-489)
+    newer = topo.rename(columns={"xid_d": "relative_dist", "z": "Z", "n": "roughness"}).assign(cs_id=0)
+    ins2 = DU.diffusive_input_data_v02(*a, newer, pd.DataFrame(), None, None, coast, pd.DataFrame())
+    assert np.array_equal(ins2["z_bathy_g"], z["in_z_bathy_g"]) and np.array_equal(ins2["mann_bathy_g"], z["in_mann_bathy_g"])
 
 
 def test_det_pow64_equals_libm_pow():
@@ -247,6 +301,15 @@ def test_gpu_equals_reference_fortran_bitwise_lowercolorado():
         assert rc == 0 and same_bits(g, h)
     tables_ms, solve_ms = D.last_timing()
     assert tables_ms > 0 and solve_ms > 0
+
+
+@pytest.mark.gpu
+def test_gpu_equals_reference_fortran_bitwise_natural_sections_and_coastal_depth():
+    from troute_amd.routing.fast_reach import diffusive as D
+    ins, want = load_lowercolorado(12, "diffusive_lowercolorado_nat.npz")
+    got = D.compute_diffusive(ins)
+    check_window(got, want)
+    assert want[2].max() > 1.5
 
 
 @pytest.mark.gpu
