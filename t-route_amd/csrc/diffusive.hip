@@ -46,6 +46,7 @@ int dw_fail(int code, const std::string &msg)
 //     becomes the current one and one new column is fetched.  (Staging whole 32 KB table blocks cost more than the
 //     searches saved: 7.6 s against 5.8 s for 12 steps of the LowerColorado subset.)
 struct WaveScan {
+    __device__ static double *state(double *g) { return g; }
     double *lds;               // [2][kNel]
     const double *gcol[2];     // the global elevation column each LDS slot mirrors (nullptr = none)
 
@@ -147,6 +148,20 @@ struct WaveScan {
     }
 };
 
+// the same searches for a run whose sweep state lives in LDS: a generic pointer into LDS is (aperture << 32 | offset),
+// so the low word IS the LDS address, and accesses through it are ds_read / ds_write
+struct WaveScanLds : WaveScan {
+    typedef __attribute__((address_space(3))) double lds_double;
+    __device__ static lds_double *state(double *g)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (lds_double *)(uint32_t)(uintptr_t)g;
+#else
+        return (lds_double *)(uintptr_t)g; // (host pass of the dual compilation; never executed)
+#endif
+    }
+};
+
 // node list of the mainstem: node n -> (k, reach j), 1-based
 __global__ void __launch_bounds__(256) k_dw_tables(trdw::Problem p, const int32_t *node_k, const int32_t *node_j, int nnodes)
 {
@@ -221,7 +236,7 @@ __global__ void __launch_bounds__(64) k_dw_solve(const BatchItem *items)
     p.q_llm = p.para_ar[7]; p.so_llm = p.para_ar[8]; p.theta = p.para_ar[9];
     p.dsbc_option = (int)p.para_ar[10];
     HIP_DYNAMIC_SHARED(double, s_tables)
-    WaveScan scan;
+    WaveScanLds scan;
     scan.lds = s_tables;
     scan.gcol[0] = scan.gcol[1] = nullptr;
     // The per-node state of the sweeps (ten arrays) and the per-reach scratch lines move into LDS when they fit:
@@ -244,8 +259,10 @@ __global__ void __launch_bounds__(64) k_dw_solve(const BatchItem *items)
         p.tarr_qtrib = tq;     // (filled by solve() itself)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        trdw::solve<WaveScanLds>(p, *items[blockIdx.x].min_dx, scan);
+        return;
     }
-    trdw::solve(p, *items[blockIdx.x].min_dx, scan);
+    trdw::solve<WaveScan>(p, *items[blockIdx.x].min_dx, scan);
 }
 
 // host side of one domain: device copies of its inputs, its work space, its node list

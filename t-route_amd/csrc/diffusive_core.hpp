@@ -106,6 +106,11 @@ DW_HD inline void bind_work(Problem &p, double *w)
 
 // 1-based accessors in the reference's index order
 #define DW_G(a, i, j) (a)[((i) - 1) + (int64_t)((j) - 1) * p.mxncomp]
+// the per-node state of the sweeps and the per-reach scratch lines, through the Scan policy: Scan::state(ptr) is the
+// pointer itself on the host and for a device run whose state stays in global memory, and the same address as an LDS
+// pointer when the kernel has moved the state into LDS (ds_read/ds_write instead of flat accesses)
+#define DW_S(a, i, j) Scan::state(a)[((i) - 1) + (int64_t)((j) - 1) * p.mxncomp]
+#define DW_L(a) Scan::state(a)
 #define DW_FRNW(j, c) p.frnw[((j) - 1) + (int64_t)((c) - 1) * p.nrch]
 #define DW_TAB(col, iel, i, j) p.tab[((((int64_t)((j) - 1) * p.mxncomp + ((i) - 1)) * kCols + (col)) * kNel) + ((iel) - 1)]
 #define DW_EV(a, ts, i, j) (a)[((ts) - 1) + (int64_t)p.ntss_ev * (((i) - 1) + (int64_t)p.mxncomp * ((j) - 1))]
@@ -185,6 +190,7 @@ struct SqDepthAt { const double *e; double zz; DW_HD double operator()(int k) co
 // the [kCols][kNel] table block of node i of reach j
 DW_HD inline const double *node_block(const Problem &p, int i, int j) { return &DW_TAB(0, 1, i, j); }
 struct SerialScan {
+    DW_HD static double *state(double *g) { return g; }
     DW_HD void begin_node(const Problem &, int, int) const {}
     DW_HD const double *table(const Problem &p, int i, int j) const { return node_block(p, i, j); }
     DW_HD int locate_row(const double *xx, int n, double x) const { return locate(xx, n, x); }
@@ -587,13 +593,13 @@ DW_HD inline Depth funcd(const Problem &p, const Scan &scan, const double *tb, i
     const int irow = row_blk(scan, tb, C_ELEV, elv_cur);       // one search: conveyance, dK/dA and top width
     const double conv_cur = at_row(tb, C_ELEV, C_CONV, irow, elv_cur);
     const double sf_cur = fabs(Q_cur) * Q_cur / (conv_cur * conv_cur);
-    double slope = (DW_G(p.z, i, j) - DW_G(p.z, i + 1, j)) / DW_G(p.dx, i, j);
+    double slope = (DW_S(p.z, i, j) - DW_S(p.z, i + 1, j)) / DW_S(p.dx, i, j);
     slope = dmax(slope, p.so_llm);
     Depth r;
-    r.f = y_cur - y_ds + slope * DW_G(p.dx, i, j) - 0.50 * (sf_cur + sf_ds) * DW_G(p.dx, i, j);
+    r.f = y_cur - y_ds + slope * DW_S(p.dx, i, j) - 0.50 * (sf_cur + sf_ds) * DW_S(p.dx, i, j);
     const double dKdA = at_row(tb, C_ELEV, C_DKDA, irow, elv_cur);
     const double topw = at_row(tb, C_ELEV, C_TOPW, irow, elv_cur);
-    r.df = 1.0 + (fabs(Q_cur) * Q_cur / (conv_cur * conv_cur * conv_cur)) * DW_G(p.dx, i, j) * topw * dKdA;
+    r.df = 1.0 + (fabs(Q_cur) * Q_cur / (conv_cur * conv_cur * conv_cur)) * DW_S(p.dx, i, j) * topw * dKdA;
     return r;
 }
 // rtsafe (:1555-1662): Newton-Raphson safeguarded by bisection for the depth of node i given node i+1
@@ -607,8 +613,8 @@ DW_HD inline double rtsafe(const Problem &p, const Scan &scan, const double *tb,
     const double conv_ds = intp_blk(scan, tb_ds, C_ELEV, C_CONV, elv_ds);
     const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
     const double elv_norm = intp_blk(scan, tb, C_UNIF, C_ELEV, fabs(Q_cur));
-    const double y_norm = elv_norm - DW_G(p.z, i, j);
-    const double y_old = DW_G(p.oldY, i, j) - DW_G(p.z, i, j);
+    const double y_norm = elv_norm - DW_S(p.z, i, j);
+    const double y_old = DW_S(p.oldY, i, j) - DW_S(p.z, i, j);
     const double x1 = 0.5 * (y_norm + y_old) * (double)0.1f;
     const double x2 = 0.5 * (y_norm + y_old) * 2.0;
     const double fl = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, x1, y_ds).f;
@@ -642,17 +648,17 @@ DW_HD inline double rtsafe(const Problem &p, const Scan &scan, const double *tb,
 }
 
 // mesh_diffusive_forward (:1108-1355): Crank-Nicolson flow along reach j (Thomas recurrences eei/ffi, exi/fxi)
-DW_HD inline void forward(Problem &p, int j)
+template <class Scan> DW_HD inline void forward(Problem &p, int j)
 {
     const int ncomp = DW_FRNW(j, 1);
     const double dtini = p.dtini, theta = p.theta;
-    p.eei[0] = 1.0; p.ffi[0] = 0.0; p.exi[0] = 0.0; p.fxi[0] = 0.0;
+    DW_L(p.eei)[0] = 1.0; DW_L(p.ffi)[0] = 0.0; DW_L(p.exi)[0] = 0.0; DW_L(p.fxi)[0] = 0.0;
     double allqlat = 0.0;
-    for (int i = 2; i <= ncomp - 1; ++i) allqlat = allqlat + DW_G(p.lateralFlow, i, j) * DW_G(p.dx, i, j);
+    for (int i = 2; i <= ncomp - 1; ++i) allqlat = allqlat + DW_G(p.lateralFlow, i, j) * DW_S(p.dx, i, j);
     for (int i = 2; i <= ncomp; ++i) {
-        const double dxm = DW_G(p.dx, i - 1, j);
+        const double dxm = DW_S(p.dx, i - 1, j);
         const double cour = dtini / dxm;
-        const double cour2 = fabs(DW_G(p.celerity, i, j)) * cour;
+        const double cour2 = fabs(DW_S(p.celerity, i, j)) * cour;
         const double c2 = cour2 * cour2, c3 = cour2 * cour2 * cour2;
         const double a1 = 3.0 * c2 - 2.0 * c3;
         const double a2 = 1 - a1;
@@ -670,38 +676,38 @@ DW_HD inline void forward(Problem &p, int j)
         const double h2 = -h1;
         const double h3 = 6.0 / (dxm * dxm);
         const double h4 = h3;
-        const double alpha = (i == ncomp) ? 1.0 : DW_G(p.dx, i, j) / DW_G(p.dx, i - 1, j);
-        const double qa = DW_G(p.oldQ, i - 1, j), qb = DW_G(p.oldQ, i, j);
-        const double xa = DW_G(p.qpx, i - 1, j), xb = DW_G(p.qpx, i, j);
+        const double alpha = (i == ncomp) ? 1.0 : DW_S(p.dx, i, j) / DW_S(p.dx, i - 1, j);
+        const double qa = DW_S(p.oldQ, i - 1, j), qb = DW_S(p.oldQ, i, j);
+        const double xa = DW_S(p.qpx, i - 1, j), xb = DW_S(p.qpx, i, j);
         const double qy = a1 * qa + a2 * qb + a3 * xa + a4 * xb;
         const double qxy = b1 * qa + b2 * qb + b3 * xa + b4 * xb;
         const double qxxy = dd1 * qa + dd2 * qb + dd3 * xa + dd4 * xb;
         const double qxxxy = h1 * qa + h2 * qb + h3 * xa + h4 * xb;
-        const double dif = DW_G(p.diffusivity, i, j);
+        const double dif = DW_S(p.diffusivity, i, j);
         const double ppi = -theta * dif * dtini / (dxm * dxm) * 2.0 / (alpha * (alpha + 1.0)) * alpha;
         const double qqi = 1.0 - ppi * (alpha + 1.0) / alpha;
         const double rri = ppi / alpha;
         const double ssi = qy + dtini * dif * (1.0 - theta) * qxxy;
         const double sxi = qxy + dtini * dif * (1.0 - theta) * qxxxy;
-        p.eei[i - 1] = -1.0 * rri / (ppi * p.eei[i - 2] + qqi);
-        p.ffi[i - 1] = (ssi - ppi * p.ffi[i - 2]) / (ppi * p.eei[i - 2] + qqi);
-        p.exi[i - 1] = -1.0 * rri / (ppi * p.exi[i - 2] + qqi);
-        p.fxi[i - 1] = (sxi - ppi * p.fxi[i - 2]) / (ppi * p.exi[i - 2] + qqi);
+        DW_L(p.eei)[i - 1] = -1.0 * rri / (ppi * DW_L(p.eei)[i - 2] + qqi);
+        DW_L(p.ffi)[i - 1] = (ssi - ppi * DW_L(p.ffi)[i - 2]) / (ppi * DW_L(p.eei)[i - 2] + qqi);
+        DW_L(p.exi)[i - 1] = -1.0 * rri / (ppi * DW_L(p.exi)[i - 2] + qqi);
+        DW_L(p.fxi)[i - 1] = (sxi - ppi * DW_L(p.fxi)[i - 2]) / (ppi * DW_L(p.exi)[i - 2] + qqi);
     }
     // (the reference also forms the coefficients of a ghost point behind the last node, :1239-1290, and never uses
     // them: qp(ncomp) = eei(ncomp) * oldQ(ncomp-1) + ffi(ncomp), :1305-1322)
-    const double qp_ghost = DW_G(p.oldQ, ncomp - 1, j), qpx_ghost = 0.0;
-    DW_G(p.qp, ncomp, j) = p.eei[ncomp - 1] * qp_ghost + p.ffi[ncomp - 1];
-    DW_G(p.qpx, ncomp, j) = p.exi[ncomp - 1] * qpx_ghost + p.fxi[ncomp - 1];
+    const double qp_ghost = DW_S(p.oldQ, ncomp - 1, j), qpx_ghost = 0.0;
+    DW_S(p.qp, ncomp, j) = DW_L(p.eei)[ncomp - 1] * qp_ghost + DW_L(p.ffi)[ncomp - 1];
+    DW_S(p.qpx, ncomp, j) = DW_L(p.exi)[ncomp - 1] * qpx_ghost + DW_L(p.fxi)[ncomp - 1];
     for (int i = ncomp - 1; i >= 1; --i) {
-        DW_G(p.qp, i, j) = p.eei[i - 1] * DW_G(p.qp, i + 1, j) + p.ffi[i - 1];
-        DW_G(p.qpx, i, j) = p.exi[i - 1] * DW_G(p.qpx, i + 1, j) + p.fxi[i - 1];
+        DW_S(p.qp, i, j) = DW_L(p.eei)[i - 1] * DW_S(p.qp, i + 1, j) + DW_L(p.ffi)[i - 1];
+        DW_S(p.qpx, i, j) = DW_L(p.exi)[i - 1] * DW_S(p.qpx, i + 1, j) + DW_L(p.fxi)[i - 1];
     }
-    DW_G(p.qp, 1, j) = DW_G(p.newQ, 1, j);
-    DW_G(p.qp, 1, j) = DW_G(p.qp, 1, j) + allqlat;
+    DW_S(p.qp, 1, j) = DW_S(p.newQ, 1, j);
+    DW_S(p.qp, 1, j) = DW_S(p.qp, 1, j) + allqlat;
     for (int i = 1; i <= ncomp; ++i)
-        if (fabs(DW_G(p.qp, i, j)) < p.q_llm) DW_G(p.qp, i, j) = p.q_llm;
-    for (int i = 1; i <= ncomp; ++i) DW_G(p.newQ, i, j) = DW_G(p.qp, i, j);
+        if (fabs(DW_S(p.qp, i, j)) < p.q_llm) DW_S(p.qp, i, j) = p.q_llm;
+    for (int i = 1; i <= ncomp; ++i) DW_S(p.newQ, i, j) = DW_S(p.qp, i, j);
 }
 
 // mesh_diffusive_backward (:1357-1553): water surface along reach j from its bottom node upwards
@@ -711,7 +717,7 @@ template <class Scan> DW_HD inline void backward(Problem &p, int j, Scan &scan)
     scan.begin_node(p, ncomp, j);
     {
         const double *tb = scan.table(p, ncomp, j);
-        const double yb = DW_G(p.newY, ncomp, j);
+        const double yb = DW_S(p.newY, ncomp, j);
         const Bracket bb = scan.bracket(tb + C_ELEV * kNel, false, 0.0, kNel, yb);
         DW_G(p.newArea, ncomp, j) = scan.apply(bb, tb + C_AREA * kNel, kNel, yb);
         DW_G(p.bo, ncomp, j) = scan.apply(bb, tb + C_TOPW * kNel, kNel, yb);
@@ -721,43 +727,43 @@ template <class Scan> DW_HD inline void backward(Problem &p, int j, Scan &scan)
         if (p.counters) p.counters[1] += 1;
         const double *tb = scan.table(p, i, j);
         const double *elevT = tb + C_ELEV * kNel;
-        const double xt = DW_G(p.newY, i, j);
-        const double zz = DW_G(p.z, i, j);
+        const double xt = DW_S(p.newY, i, j);
+        const double zz = DW_S(p.z, i, j);
         const double sq = (xt - zz) * (xt - zz);
-        p.co[i - 1] = 1.0 * scan.apply(scan.bracket(elevT, true, zz, kNel, sq), tb + C_CONV * kNel, kNel, sq);
+        DW_L(p.co)[i - 1] = 1.0 * scan.apply(scan.bracket(elevT, true, zz, kNel, sq), tb + C_CONV * kNel, kNel, sq);
         const Bracket be = scan.bracket(elevT, false, 0.0, kNel, xt); // one search for the four columns at xt
         DW_G(p.newArea, i, j) = scan.apply(be, tb + C_AREA * kNel, kNel, xt);
         DW_G(p.pere, i, j) = scan.apply(be, tb + C_PERI * kNel, kNel, xt);
         DW_G(p.bo, i, j) = scan.apply(be, tb + C_TOPW * kNel, kNel, xt);
         DW_G(p.sk, i, j) = scan.apply(be, tb + C_SKK * kNel, kNel, xt);
-        const double qpi = DW_G(p.qp, i, j);
-        const double sfi = qpi * fabs(qpi) / (p.co[i - 1] * p.co[i - 1]);
-        p.celerity2[i - 1] = (double)(5.0f / 3.0f) * DW_POW(fabs(sfi), (double)0.3f) * DW_POW(fabs(qpi), (double)0.4f)
+        const double qpi = DW_S(p.qp, i, j);
+        const double sfi = qpi * fabs(qpi) / (DW_L(p.co)[i - 1] * DW_L(p.co)[i - 1]);
+        DW_L(p.celerity2)[i - 1] = (double)(5.0f / 3.0f) * DW_POW(fabs(sfi), (double)0.3f) * DW_POW(fabs(qpi), (double)0.4f)
                              / DW_POW(DW_G(p.bo, i, j), (double)0.4f) / DW_POW(1. / (DW_G(p.sk, i, j) * 1.0), (double)0.6f);
-        const double C_ulm = (i > 1) ? p.cfl * DW_G(p.dx, i - 1, j) / p.dtini_min : p.cfl * DW_G(p.dx, i, j) / p.dtini_min;
-        if (p.celerity2[i - 1] > C_ulm) p.celerity2[i - 1] = C_ulm;
-        p.diffusivity2[i - 1] = fabs(qpi) / 2.0 / DW_G(p.bo, i, j) / fabs(sfi);
+        const double C_ulm = (i > 1) ? p.cfl * DW_S(p.dx, i - 1, j) / p.dtini_min : p.cfl * DW_S(p.dx, i, j) / p.dtini_min;
+        if (DW_L(p.celerity2)[i - 1] > C_ulm) DW_L(p.celerity2)[i - 1] = C_ulm;
+        DW_L(p.diffusivity2)[i - 1] = fabs(qpi) / 2.0 / DW_G(p.bo, i, j) / fabs(sfi);
         if (i > 1) {
-            const double Q_cur = DW_G(p.qp, i - 1, j), Q_ds = qpi;
-            const double z_cur = DW_G(p.z, i - 1, j), z_ds = zz;
-            double y_ds = DW_G(p.newY, i, j) - zz;
+            const double Q_cur = DW_S(p.qp, i - 1, j), Q_ds = qpi;
+            const double z_cur = DW_S(p.z, i - 1, j), z_ds = zz;
+            double y_ds = DW_S(p.newY, i, j) - zz;
             y_ds = dmax(y_ds, (double)0.005f);
             const double y_cur = rtsafe(p, scan, scan.table(p, i - 1, j), tb, i - 1, j, Q_cur, Q_ds, z_cur, z_ds, y_ds);
-            DW_G(p.newY, i - 1, j) = y_cur + DW_G(p.z, i - 1, j);
-            if (DW_G(p.newY, i - 1, j) > 100000.0) DW_G(p.newY, i - 1, j) = 100000.0;
+            DW_S(p.newY, i - 1, j) = y_cur + DW_S(p.z, i - 1, j);
+            if (DW_S(p.newY, i - 1, j) > 100000.0) DW_S(p.newY, i - 1, j) = 100000.0;
         }
     }
     double cs = 0.0, ds = 0.0;
-    for (int i = 1; i <= ncomp; ++i) { cs = cs + p.celerity2[i - 1]; ds = ds + p.diffusivity2[i - 1]; }
+    for (int i = 1; i <= ncomp; ++i) { cs = cs + DW_L(p.celerity2)[i - 1]; ds = ds + DW_L(p.diffusivity2)[i - 1]; }
     double cel = cs / ncomp;
     if (cel < p.C_llm) cel = p.C_llm;
     double dif = ds / ncomp;
     for (int i = 1; i <= ncomp; ++i) {
-        DW_G(p.celerity, i, j) = cel;
+        DW_S(p.celerity, i, j) = cel;
         double d = dif;
         if (d > p.D_ulm) d = p.D_ulm;
         if (d < p.D_llm) d = p.D_llm;
-        DW_G(p.diffusivity, i, j) = d;
+        DW_S(p.diffusivity, i, j) = d;
     }
 }
 
@@ -791,26 +797,26 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
         const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
         if (DW_FRNW(j, 2) < 0) {
             if (p.dsbc_option == 1) {
-                for (int n = 1; n <= nts_db; ++n) p.varr_db[n - 1] = p.dbcd[n - 1] + DW_G(p.z, ncomp, j);
+                for (int n = 1; n <= nts_db; ++n) p.varr_db[n - 1] = p.dbcd[n - 1] + DW_S(p.z, ncomp, j);
                 t = t0 * 60.0;
-                DW_G(p.oldY, ncomp, j) = intp_y(nts_db, p.tarr_db, p.varr_db, t);
-                DW_G(p.newY, ncomp, j) = DW_G(p.oldY, ncomp, j);
-                if ((DW_G(p.newY, ncomp, j) - DW_G(p.z, ncomp, j)) < mindepth_nstab)
-                    DW_G(p.newY, ncomp, j) = mindepth_nstab + DW_G(p.z, ncomp, j);
+                DW_S(p.oldY, ncomp, j) = intp_y(nts_db, p.tarr_db, p.varr_db, t);
+                DW_S(p.newY, ncomp, j) = DW_S(p.oldY, ncomp, j);
+                if ((DW_S(p.newY, ncomp, j) - DW_S(p.z, ncomp, j)) < mindepth_nstab)
+                    DW_S(p.newY, ncomp, j) = mindepth_nstab + DW_S(p.z, ncomp, j);
             } else if (p.dsbc_option == 2) {
-                DW_G(p.oldY, ncomp, j) = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, DW_G(p.oldQ, ncomp, j));
-                DW_G(p.newY, ncomp, j) = DW_G(p.oldY, ncomp, j);
+                DW_S(p.oldY, ncomp, j) = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, DW_S(p.oldQ, ncomp, j));
+                DW_S(p.newY, ncomp, j) = DW_S(p.oldY, ncomp, j);
             }
         } else {
             const int linknb = DW_FRNW(j, 2);
-            DW_G(p.newY, ncomp, j) = DW_G(p.newY, 1, linknb);
+            DW_S(p.newY, ncomp, j) = DW_S(p.newY, 1, linknb);
         }
-        const double wdepth = DW_G(p.newY, ncomp, j) - DW_G(p.z, ncomp, j);
-        for (int i = 1; i <= ncomp - 1; ++i) DW_G(p.oldY, i, j) = wdepth + DW_G(p.z, i, j);
+        const double wdepth = DW_S(p.newY, ncomp, j) - DW_S(p.z, ncomp, j);
+        for (int i = 1; i <= ncomp - 1; ++i) DW_S(p.oldY, i, j) = wdepth + DW_S(p.z, i, j);
         backward(p, j, scan);
         for (int i = 1; i <= ncomp; ++i) {
-            DW_G(p.oldY, i, j) = DW_G(p.newY, i, j);
-            if (DW_G(p.oldY, i, j) < DW_G(p.oldY, ncomp, nlinks)) DW_G(p.oldY, i, j) = DW_G(p.oldY, ncomp, nlinks);
+            DW_S(p.oldY, i, j) = DW_S(p.newY, i, j);
+            if (DW_S(p.oldY, i, j) < DW_S(p.oldY, ncomp, nlinks)) DW_S(p.oldY, i, j) = DW_S(p.oldY, ncomp, nlinks);
         }
     }
     // ---- tributary hydrographs into the output arrays (:590-607)
@@ -851,38 +857,38 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
                 DW_G(p.lateralFlow, i, j) = linterpol(p.tarr_ql[ql_row - 1], y1, p.tarr_ql[ql_row], y2, t);
             }
             if (DW_FRNW(j, 3) > 0) {
-                DW_G(p.newQ, 1, j) = 0.0;
+                DW_S(p.newQ, 1, j) = 0.0;
                 for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
                     const int usrchj = DW_FRNW(j, 3 + k);
                     double q_usrch;
                     if (is_mainstem(p, usrchj)) {
-                        q_usrch = DW_G(p.newQ, DW_FRNW(usrchj, 1), usrchj);
+                        q_usrch = DW_S(p.newQ, DW_FRNW(usrchj, 1), usrchj);
                     } else {
                         const double tf0 = t + p.dtini / 60.;   // (the tributary's hydrograph column is read in place)
                         q_usrch = intp_y(nts_qtrib, p.tarr_qtrib, p.qtrib + (int64_t)(usrchj - 1) * nts_qtrib, tf0);
                     }
-                    DW_G(p.newQ, 1, j) = DW_G(p.newQ, 1, j) + q_usrch;
+                    DW_S(p.newQ, 1, j) = DW_S(p.newQ, 1, j) + q_usrch;
                 }
             } else {
-                DW_G(p.newQ, 1, j) = 0.0;
+                DW_S(p.newQ, 1, j) = 0.0;
             }
-            DW_G(p.newQ, 1, j) = DW_G(p.newQ, 1, j) + DW_G(p.lateralFlow, 1, j) * DW_G(p.dx, 1, j);
-            forward(p, j);
+            DW_S(p.newQ, 1, j) = DW_S(p.newQ, 1, j) + DW_G(p.lateralFlow, 1, j) * DW_S(p.dx, 1, j);
+            forward<Scan>(p, j);
         }
         // corrector: depth, downstream to upstream
         for (int jm = p.nmstem; jm >= 1; --jm) {
             const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
             if (DW_FRNW(j, 2) >= 0) {
                 const int linknb = DW_FRNW(j, 2);
-                DW_G(p.newY, ncomp, j) = DW_G(p.newY, 1, linknb);
+                DW_S(p.newY, ncomp, j) = DW_S(p.newY, 1, linknb);
             } else if (p.dsbc_option == 1) {
-                DW_G(p.newY, ncomp, j) = intp_y(nts_db, p.tarr_db, p.varr_db, t + p.dtini / 60.);
-                if ((DW_G(p.newY, ncomp, j) - DW_G(p.z, ncomp, j)) < mindepth_nstab)
-                    DW_G(p.newY, ncomp, j) = mindepth_nstab + DW_G(p.z, ncomp, j);
-                DW_G(p.newArea, ncomp, j) = intp_tab(p, ncomp, j, C_ELEV, C_AREA, DW_G(p.newY, ncomp, j));
+                DW_S(p.newY, ncomp, j) = intp_y(nts_db, p.tarr_db, p.varr_db, t + p.dtini / 60.);
+                if ((DW_S(p.newY, ncomp, j) - DW_S(p.z, ncomp, j)) < mindepth_nstab)
+                    DW_S(p.newY, ncomp, j) = mindepth_nstab + DW_S(p.z, ncomp, j);
+                DW_G(p.newArea, ncomp, j) = intp_tab(p, ncomp, j, C_ELEV, C_AREA, DW_S(p.newY, ncomp, j));
             } else if (p.dsbc_option == 2) {
-                DW_G(p.newY, ncomp, j) = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, fabs(DW_G(p.newQ, ncomp, j)));
-                DW_G(p.newArea, ncomp, j) = intp_tab(p, ncomp, j, C_ELEV, C_AREA, DW_G(p.newY, ncomp, j));
+                DW_S(p.newY, ncomp, j) = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, fabs(DW_S(p.newQ, ncomp, j)));
+                DW_G(p.newArea, ncomp, j) = intp_tab(p, ncomp, j, C_ELEV, C_AREA, DW_S(p.newY, ncomp, j));
             }
             backward(p, j, scan);
             if (jm == 1) {
@@ -890,7 +896,7 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
                 for (int m = 1; m <= p.nmstem; ++m) {
                     const int jj = p.mstem_frj[m - 1];
                     for (int kkk = 1; kkk <= DW_FRNW(jj, 1) - 1; ++kkk)
-                        maxCelDx = dmax(maxCelDx, DW_G(p.celerity, kkk, jj) / DW_G(p.dx, kkk, jj));
+                        maxCelDx = dmax(maxCelDx, DW_S(p.celerity, kkk, jj) / DW_S(p.dx, kkk, jj));
                 }
             }
         }
@@ -901,15 +907,15 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
                 const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
                 if (ts_ev + 1 <= p.ntss_ev) {
                     for (int i = 1; i <= ncomp; ++i) {
-                        DW_EV(p.q_ev, ts_ev + 1, i, j) = DW_G(p.newQ, i, j);
-                        DW_EV(p.elv_ev, ts_ev + 1, i, j) = DW_G(p.newY, i, j);
-                        DW_EV(p.depth_ev, ts_ev + 1, i, j) = DW_EV(p.elv_ev, ts_ev + 1, i, j) - DW_G(p.z, i, j);
+                        DW_EV(p.q_ev, ts_ev + 1, i, j) = DW_S(p.newQ, i, j);
+                        DW_EV(p.elv_ev, ts_ev + 1, i, j) = DW_S(p.newY, i, j);
+                        DW_EV(p.depth_ev, ts_ev + 1, i, j) = DW_EV(p.elv_ev, ts_ev + 1, i, j) - DW_S(p.z, i, j);
                     }
                     for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
                         const int usrchj = DW_FRNW(j, 3 + k);
                         if (!is_mainstem(p, usrchj)) {
-                            const double wdepth = DW_G(p.newY, 1, j) - DW_G(p.z, 1, j);
-                            DW_EV(p.elv_ev, ts_ev + 1, DW_FRNW(usrchj, 1), usrchj) = DW_G(p.newY, 1, j);
+                            const double wdepth = DW_S(p.newY, 1, j) - DW_S(p.z, 1, j);
+                            DW_EV(p.elv_ev, ts_ev + 1, DW_FRNW(usrchj, 1), usrchj) = DW_S(p.newY, 1, j);
                             DW_EV(p.depth_ev, ts_ev + 1, DW_FRNW(usrchj, 1), usrchj) = wdepth;
                         }
                     }
@@ -922,15 +928,15 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
             for (int jm = 1; jm <= p.nmstem; ++jm) {
                 const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1);
                 for (int i = 1; i <= ncomp; ++i) {
-                    DW_EV(p.q_ev, 1, i, j) = DW_G(p.oldQ, i, j);
-                    DW_EV(p.elv_ev, 1, i, j) = DW_G(p.oldY, i, j);
-                    DW_EV(p.depth_ev, 1, i, j) = DW_EV(p.elv_ev, 1, i, j) - DW_G(p.z, i, j);
+                    DW_EV(p.q_ev, 1, i, j) = DW_S(p.oldQ, i, j);
+                    DW_EV(p.elv_ev, 1, i, j) = DW_S(p.oldY, i, j);
+                    DW_EV(p.depth_ev, 1, i, j) = DW_EV(p.elv_ev, 1, i, j) - DW_S(p.z, i, j);
                 }
                 for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
                     const int usrchj = DW_FRNW(j, 3 + k);
                     if (!is_mainstem(p, usrchj)) {
-                        const double wdepth = DW_G(p.oldY, 1, j) - DW_G(p.z, 1, j);
-                        DW_EV(p.elv_ev, 1, DW_FRNW(usrchj, 1), usrchj) = DW_G(p.oldY, 1, j);
+                        const double wdepth = DW_S(p.oldY, 1, j) - DW_S(p.z, 1, j);
+                        DW_EV(p.elv_ev, 1, DW_FRNW(usrchj, 1), usrchj) = DW_S(p.oldY, 1, j);
                         DW_EV(p.depth_ev, 1, DW_FRNW(usrchj, 1), usrchj) = wdepth;
                     }
                 }
