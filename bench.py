@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--chunks", type=int, default=None, help="time chunks of the multi-GPU hand-off pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-ts", action="store_true")
+    ap.add_argument("--no-retune", action="store_true",
+                    help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
@@ -251,19 +253,36 @@ def main():
         """out[world, *t.shape] <- every rank's t, over RCCL (xGMI), ordered against the current stream"""
         dist.all_gather_into_tensor(out, t)
 
+    def make_router(hint):
+        r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint)
+        r.upload(a.nsteps, qlat, q0)
+        if use_dist:
+            import torch
+            r.enable_device_exchange(torch, torch.device("cuda", local_rank))
+            r.upload_trunk()
+        return r
+
     t0 = time.perf_counter()
-    router = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision)
+    router = make_router(None)
     t_plan = time.perf_counter() - t0
-    router.upload(a.nsteps, qlat, q0)
-    if use_dist:
-        import torch
-        router.enable_device_exchange(torch, torch.device("cuda", local_rank))
-        router.upload_trunk()
 
     def route_once(short_ts):
         if use_dist:   # every hand-off stays in HBM: gather kernels -> RCCL all-gather -> boundary rows
             return router.route_on_device(a.qts, short_ts, all_gather_into, a.chunks)
         return router.route_resident(a.qts, short_ts), None   # outlet hydrographs stay in HBM
+
+    # Plan tuning, outside the timed region: one window on the plain plan tells which rows are cheap (dry channel:
+    # one secant iteration) and which are not; the plan is rebuilt with that as its cost hint, so that the rows of a
+    # level sit grouped by cost and the step kernel's wavefronts are uniform.  Same results (tests/test_gpu_parity.py).
+    t_tune = 0.0
+    if not a.no_retune:
+        t0 = time.perf_counter()
+        router.collect_cost(True)
+        route_once(True)
+        hint = router.iteration_hint()
+        router.close()
+        router = make_router(hint)
+        t_tune = time.perf_counter() - t0
 
     def sync():
         if dist is not None:
@@ -355,6 +374,8 @@ def main():
                 "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
                 "generate_s": round(t_gen, 2), "plan_s": round(t_plan, 2),
+                "plan_order": "rows of a level ordered by their secant-iteration cost in a tuning window (untimed)"
+                if not a.no_retune else "topological only", "tune_s": round(t_tune, 2),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_mc_step<float,true>" if a.precision == 32 else "k_mc_step<double,true>",

@@ -103,6 +103,13 @@ int trmc_device_count(int *count);
 int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                      const float *params, const uint8_t *boundary, int precision,
                      int device, trmc_plan **out);
+/* The same with a per-row cost hint [nseg] (or NULL): the secant iterations each row needed at the end of an
+ * earlier window (trmc_download_iterations).  Inside a level the order of the rows is free; with a hint rows of equal
+ * cost sit together (wavefronts of one cost) and the costly blocks of a launch start first.  Results do not depend
+ * on the hint.  No counterpart in the reference (its reach lists are traversed serially). */
+int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                            const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
+                            int precision, int device, trmc_plan **out);
 void trmc_plan_destroy(trmc_plan *plan);
 
 /* Host-only topology flattening (no device needed): the same routine the plan
@@ -111,6 +118,11 @@ void trmc_plan_destroy(trmc_plan *plan);
 int trmc_topology_levels(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                          const uint8_t *boundary, int32_t *level_of_row,
                          int64_t *plan_pos_of_row, int32_t *nlevels);
+
+/* The same with the cost hint of trmc_plan_create_hinted (or NULL). */
+int trmc_topology_levels_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                                const uint8_t *boundary, const uint8_t *cost_hint, int32_t *level_of_row,
+                                int64_t *plan_pos_of_row, int32_t *nlevels);
 
 /* Facts about the flattened topology (host side, no device work). */
 int trmc_plan_info(const trmc_plan *plan, int64_t *nseg, int64_t *nseg_routed,
@@ -249,6 +261,12 @@ int trmc_download_fvd(trmc_plan *plan, void *fvd_out);
 /* Final state in the reference's q0 layout, new_q0 = fvd[:, [-3,-3,-1]]
  * (AbstractNetwork.py:182-190): q0_out[nseg][3] = (q_T, q_T, depth_T).  D2H. */
 int trmc_download_final_state(trmc_plan *plan, void *q0_out);
+/* Cost collection for trmc_plan_create_hinted: with it enabled, every routing window also sums, per row,
+ * min(secant iterations, 3) over its timesteps (2 more bytes read and written per segment-step); trmc_download_cost
+ * returns the sums of the last window [nseg] and its length.  Off by default.  No counterpart in the reference. */
+int trmc_plan_collect_cost(trmc_plan *plan, int enable);
+int trmc_download_cost(trmc_plan *plan, uint16_t *cost_out, int32_t *nsteps_out);
+
 /* Convergence diagnostic: iters_out[nseg] = secant iterations (all retries together, capped at 255) each row
  * spent on the LAST routed timestep (0 for boundary/reservoir rows and rows without flow; the reference
  * does not report its count, MCsingleSegStime_f2py_NOLOOP.f90:83-134).  Rows of slices too narrow for

@@ -37,8 +37,10 @@ SIGNATURES = {
     "trmc_abi_version": (_int, []),
     "trmc_device_count": (_int, [_P(_int)]),
     "trmc_plan_create": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _int, _P(_vp)]),
+    "trmc_plan_create_hinted": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _P(_vp)]),
     "trmc_plan_destroy": (None, [_vp]),
     "trmc_topology_levels": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
+    "trmc_topology_levels_hinted": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
     "trmc_plan_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i32), _P(_i32), _P(_i32)]),
     "trmc_plan_levels": (_int, [_vp, _vp, _vp]),
     "trmc_upload_forcing": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
@@ -60,6 +62,8 @@ SIGNATURES = {
     "trmc_download_fvd": (_int, [_vp, _vp]),
     "trmc_download_final_state": (_int, [_vp, _vp]),
     "trmc_download_iterations": (_int, [_vp, _vp]),
+    "trmc_plan_collect_cost": (_int, [_vp, _int]),
+    "trmc_download_cost": (_int, [_vp, _vp, _P(_i32)]),
     "trmc_gather_flow_rows": (_int, [_vp, _vp, _i64, _vp, _int]),
     "trmc_download_gathered": (_int, [_vp, _vp]),
     "trmc_get_stats": (_int, [_vp, _P(Stats)]),

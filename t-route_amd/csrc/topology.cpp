@@ -7,7 +7,7 @@
 namespace trmc {
 
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
-                   const uint8_t *boundary, Topology &t, std::string &err)
+                   const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -148,6 +148,9 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             t.row_of_pos[p] = r;
         }
     }
+    // (With a cost hint: by descending hint first -- rows of equal cost together, the costly blocks of a launch
+    // first -- then as below.  Dealing the cost groups out in block-sized chunks so that every compute unit holds a
+    // mix of costly and cheap blocks was measured too: 82.1 us per CONUS launch against 80.5 us for plain descending.)
     // Inside a level, order the rows by the position of the row they flow into (top level first, so that position
     // is known; ties -- the upstream rows of one junction -- keep the preorder, i.e. the reference's listing order;
     // outlets last).  The step kernel gathers `q[upstream of s]` for 64 consecutive s per wave: with this order the
@@ -156,7 +159,7 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
     {
         std::vector<int64_t> key;
         std::vector<int32_t> idx, rows;
-        for (int32_t l = t.nlevels - 2; l >= 0; --l) {
+        for (int32_t l = t.nlevels - (cost_hint ? 1 : 2); l >= 0; --l) {
             const int32_t p0 = t.lvl_ptr[l], p1 = t.lvl_ptr[l + 1], m = p1 - p0;
             if (m < 2) continue;
             key.resize(m);
@@ -164,7 +167,8 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             rows.assign(t.row_of_pos.begin() + p0, t.row_of_pos.begin() + p1);
             for (int32_t i = 0; i < m; ++i) {
                 const int32_t r = rows[i];
-                key[i] = down_ptr[r + 1] > down_ptr[r] ? (int64_t)t.pos_of_row[down_idx[down_ptr[r]]] : INT64_MAX;
+                const int64_t dpos = down_ptr[r + 1] > down_ptr[r] ? (int64_t)t.pos_of_row[down_idx[down_ptr[r]]] : ((int64_t)1 << 40) - 1;
+                key[i] = ((int64_t)(cost_hint ? 255 - cost_hint[r] : 0) << 40) | dpos;
                 idx[i] = i;
             }
             std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });

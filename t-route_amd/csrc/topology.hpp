@@ -34,7 +34,10 @@ struct Topology {
 };
 
 // Returns 0 on success; -1 bad argument, -2 cycle.  `err` receives a message.
+// `cost_hint` (optional, [nseg]): rows of one level are grouped by descending hint (the secant iterations a row
+// needed last time: waves then hold rows of one cost, the costly blocks of a launch start first); it only
+// chooses among the orders that are valid anyway -- results do not depend on it.
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
-                   const uint8_t *boundary, Topology &topo, std::string &err);
+                   const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr);
 
 } // namespace trmc

@@ -204,6 +204,7 @@ template <class T> struct StepArgs {
     const T *qlat_tm;
     T *q_tm, *v_tm, *d_tm;
     uint8_t *it_prev; // secant iterations each position needed on its previous step
+    uint16_t *it_sum; // nullptr, or: sum over the window of min(iterations, 3) per position (trmc_plan_collect_cost)
     // level-pool reservoirs (nullptr = none): reservoir index of a position, parameters [nres][9],
     // inflow series [nres][nsteps] (the reference's upstream_array rows), routing period
     const int32_t *res_of_pos;
@@ -424,6 +425,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         at(a.v_tm + row_c, ob) = r.velc;
         at(a.d_tm + row_c, ob) = r.depthc;
         if (SORT) a.it_prev[su] = (uint8_t)min(r.iters, 255);
+        if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + min(r.iters, 3));
     }
 }
 
@@ -716,6 +718,9 @@ struct trmc_plan {
     // static, plan order
     DevBuf params; // 9 columns x nseg_pad
     DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev, lag;
+    DevBuf it_sum;                       // per-position cost of the window (trmc_plan_collect_cost)
+    bool collect_cost = false;
+    int32_t cost_nsteps = -1;            // nsteps of the window it_sum was collected over
     int32_t maxlag = 0;                  // trmc_plan_set_lag: rows routed `maxlag` launches behind the others
     std::vector<int32_t> lag_of_row;
     DevBuf gage_of_pos, da_mode, da_a, da_w, da_nudge; // nudging tables of the staged window
@@ -800,6 +805,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.level = (const int32_t *)pl->level.p;
     a.lag = pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr;
     a.it_prev = (uint8_t *)pl->it_prev.p;
+    a.it_sum = pl->collect_cost ? (uint16_t *)pl->it_sum.p : nullptr;
     a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
     a.res_par = (const T *)pl->res_par.p;
     a.res_inflow = (T *)pl->res_inflow.p;
@@ -887,6 +893,10 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     if (int rc = pl->out.ensure((size_t)pl->nseg * nsteps * 3 * sizeof(T))) return rc;
     if (pl->nres > 0)
         if (int rc = pl->res_inflow.ensure((size_t)pl->nres * nsteps * sizeof(T))) return rc;
+    if (pl->collect_cost) {
+        if (int rc = pl->it_sum.ensure((size_t)np * sizeof(uint16_t))) return rc;
+        pl->cost_nsteps = nsteps;
+    }
     StepArgs<T> a = step_args<T>(pl, nsteps, qts);
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
     constexpr int32_t kTile = TRMC_EMIT_TILE;
@@ -899,6 +909,7 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
 
     HIP_TRY(hipEventRecord(pl->ev[0], st));
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st)); // no history at the start of a window
+    if (pl->collect_cost) HIP_TRY(hipMemsetAsync(pl->it_sum.p, 0, (size_t)np * sizeof(uint16_t), st));
     // every element the result reads is written below: time row 0 by k_init_state, rows 1..nsteps
     // of routed positions by k_mc_step and of boundary positions by k_fill_boundary (the padding
     // lanes of each row are never read), so the reference's zero fill (mc_reach.pyx:253) is moot
@@ -1060,9 +1071,15 @@ int trmc_device_count(int *count)
 int trmc_topology_levels(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
                          int32_t *level_of_row, int64_t *plan_pos_of_row, int32_t *nlevels)
 {
+    return trmc_topology_levels_hinted(nseg, up_ptr, up_idx, boundary, nullptr, level_of_row, plan_pos_of_row, nlevels);
+}
+
+int trmc_topology_levels_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
+                                const uint8_t *cost_hint, int32_t *level_of_row, int64_t *plan_pos_of_row, int32_t *nlevels)
+{
     trmc::Topology t;
     std::string err;
-    const int rc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, t, err);
+    const int rc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, t, err, cost_hint);
     if (rc) return fail(rc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
     for (int64_t r = 0; r < nseg; ++r) {
         if (level_of_row) level_of_row[r] = t.level_of_row[r];
@@ -1075,6 +1092,12 @@ int trmc_topology_levels(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
 int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
                      const uint8_t *boundary, int precision, int device, trmc_plan **out)
 {
+    return trmc_plan_create_hinted(nseg, up_ptr, up_idx, params, boundary, nullptr, precision, device, out);
+}
+
+int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
+                            const uint8_t *boundary, const uint8_t *cost_hint, int precision, int device, trmc_plan **out)
+{
     if (!out) return fail(TRMC_EINVAL, "out is NULL");
     *out = nullptr;
     if (precision != 32 && precision != 64) return fail(TRMC_EINVAL, "precision must be 32 or 64");
@@ -1084,7 +1107,7 @@ int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
     trmc_plan *pl = new (std::nothrow) trmc_plan();
     if (!pl) return fail(TRMC_ENOMEM, "out of host memory");
     std::string err;
-    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err);
+    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
@@ -1139,7 +1162,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->lag, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
@@ -1604,6 +1627,28 @@ int trmc_download_fvd(trmc_plan *pl, void *fvd_out)
     if (!fvd_out) return fail(TRMC_EINVAL, "fvd_out is NULL");
     if (int rc = use_device(pl)) return rc;
     HIP_TRY(hipMemcpy(fvd_out, pl->out.p, (size_t)pl->nseg * pl->routed_nsteps * 3 * pl->esz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int trmc_plan_collect_cost(trmc_plan *pl, int enable)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is open");
+    pl->collect_cost = enable != 0;
+    if (!pl->collect_cost) pl->cost_nsteps = -1;
+    return 0;
+}
+
+int trmc_download_cost(trmc_plan *pl, uint16_t *cost_out, int32_t *nsteps_out)
+{
+    if (!pl || !cost_out) return fail(TRMC_EINVAL, "plan/cost_out is NULL");
+    if (!pl->collect_cost || pl->cost_nsteps < 0 || pl->routed_nsteps != pl->cost_nsteps)
+        return fail(TRMC_ESTATE, "no window has been routed with cost collection on");
+    if (int rc = use_device(pl)) return rc;
+    std::vector<uint16_t> by_pos((size_t)pl->nseg_pad);
+    HIP_TRY(hipMemcpy(by_pos.data(), pl->it_sum.p, (size_t)pl->nseg_pad * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (int64_t p = 0; p < pl->nseg; ++p) cost_out[pl->topo.row_of_pos[p]] = by_pos[(size_t)p];
+    if (nsteps_out) *nsteps_out = pl->cost_nsteps;
     return 0;
 }
 

@@ -35,10 +35,26 @@ def restrict_csr(up_ptr, up_idx, rows, g2l):
 
 class ShardedRouter:
     def __init__(self, to, params, rank=0, world=1, device=0, plan_factory=None, precision=32,
-                 partition=None):
+                 partition=None, cost_hint=None):
+        """cost_hint: optional uint8 [nseg] (global rows), the ``iteration_hint()`` of a router of the same network
+        after a window -- every plan then groups the rows of a level by that cost (RoutingPlan ``cost_hint``;
+        results unchanged, the step kernel's wavefronts become uniform in cost)."""
         if plan_factory is None:
             from .plan import RoutingPlan as plan_factory  # the HIP engine; no fallback
         from .synthetic import upstream_csr
+        self._hint = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
+        if self._hint is not None:
+            if self._hint.shape != (to.shape[0],):
+                raise ValueError("cost_hint shape mismatch")
+            base_factory = plan_factory
+
+            def plan_factory(lp, li, par, boundary, prec, dev, rows=None):   # noqa: F811 - the hinted factory
+                return base_factory(lp, li, par, boundary, prec, dev, cost_hint=self._hint[rows])
+        else:
+            base_factory = plan_factory
+
+            def plan_factory(lp, li, par, boundary, prec, dev, rows=None):   # noqa: F811
+                return base_factory(lp, li, par, boundary, prec, dev)
         self.rank, self.world = rank, world
         self.nseg = to.shape[0]
         self.dtype = np.float32 if precision == 32 else np.float64
@@ -54,10 +70,11 @@ class ShardedRouter:
         g2l = np.full(self.nseg, -1, dtype=np.int64)
         g2l[self.rows0] = np.arange(self.rows0.shape[0])
         lp, li = restrict_csr(up_ptr, up_idx, self.rows0, g2l)
-        self.plan0 = plan_factory(lp, li, params[self.rows0], None, precision, device)
+        self.plan0 = plan_factory(lp, li, params[self.rows0], None, precision, device, rows=self.rows0)
         self._mk = {"factory": plan_factory, "precision": precision, "device": device, "params": params,
                     "csr0": (lp, li)}
         self.planM = None     # sub-basins + time-skewed trunk in one plan (short-timestep device path)
+        self._collect = False
         # cut rows: every rank knows the global list (ascending); mine are a subset
         self.cut_rows = part["cut_rows"]
         self.cut_owner = row_owner[self.cut_rows] if self.cut_rows.size else np.zeros(0, np.int32)
@@ -94,10 +111,45 @@ class ShardedRouter:
             self.boundary1 = boundary
             # position of each boundary row (ascending local row) in the global cut list
             self.b_cut_index = np.searchsorted(self.cut_rows, rows1[boundary])
-            self.plan1 = plan_factory(lp1, li1, params[rows1], boundary.astype(np.uint8), precision, device)
+            self.plan1 = plan_factory(lp1, li1, params[rows1], boundary.astype(np.uint8), precision, device, rows=rows1)
             self._mk["csr1"] = (lp1, li1)
             o1 = outlets[np.isin(outlets, trunk_rows)]
             self.my_out1_global, self.my_out1_local = o1, g2l1[o1]
+
+    def collect_cost(self, enable=True):
+        """Have the plans sum every row's iteration class over the windows routed from now on (a finer hint than the
+        last step alone: a row that is dry for the first hours of a window and wet afterwards sorts between the
+        always-dry and the always-wet ones)."""
+        self._collect = bool(enable)
+        for plan in (self.plan0, self.plan1, self.planM):
+            if plan is not None and hasattr(plan, "collect_cost"):
+                plan.collect_cost(enable)
+
+    def iteration_hint(self):
+        """uint8 [nseg]: the secant iterations (clamped at 3) this rank's rows needed on the last step of the last
+        window, 0 for rows of other ranks -- what ``ShardedRouter(..., cost_hint=...)`` takes.  Iteration classes
+        persist (a row repeats its count from one step to the next 99.3 % of the time), so the hint of one window
+        orders the next."""
+        hint = np.zeros(self.nseg, dtype=np.uint8)
+
+        def take(plan, rows):
+            try:
+                if self._collect:
+                    # the whole window: sum of min(iterations, 3) over its steps, in sixteenths of a step-mean
+                    cost, n = plan.download_cost()
+                    it = np.minimum((cost.astype(np.int64) * 16 + n - 1) // max(n, 1), 255)
+                else:
+                    it = np.minimum(plan.download_iterations(), 3)
+            except RuntimeError:          # this plan has not routed a window yet
+                return False
+            hint[rows] = np.maximum(hint[rows], it.astype(np.uint8))
+            return True
+        if self.planM is not None:
+            take(self.planM, self._rowsM)
+        take(self.plan0, self.rows0)
+        if self.plan1 is not None:
+            take(self.plan1, self.rows1)
+        return hint
 
     # ---- device-resident exchange (torch tensors; NCCL = RCCL over xGMI on the GPU box) --------------
     def enable_device_exchange(self, torch, device):
@@ -206,8 +258,10 @@ class ShardedRouter:
             boundary = np.concatenate([np.zeros(n0, np.uint8), self.boundary1.astype(np.uint8)])
             lagv = np.concatenate([np.zeros(n0, np.int32), np.where(self.boundary1, 0, lag).astype(np.int32)])
             self._rowsM = rows
-            self.planM = mk["factory"](up_ptr, up_idx, mk["params"][rows], boundary, mk["precision"], mk["device"])
+            self.planM = mk["factory"](up_ptr, up_idx, mk["params"][rows], boundary, mk["precision"], mk["device"], rows=rows)
             self.planM.set_lag(lagv)
+            if self._collect:
+                self.planM.collect_cost(True)
             self._planM_lag = lag
             self._sM = self._torch.cuda.ExternalStream(self.planM.stream(), device=self._tdev)
             self._rsM_cut = self.planM.rowset(self.my_cut_local)

@@ -21,7 +21,7 @@ def csr_from_lists(lists):
     return ptr, idx
 
 
-def topology_levels(up_ptr, up_idx, boundary=None):
+def topology_levels(up_ptr, up_idx, boundary=None, cost_hint=None):
     """Host-only level flattening (no GPU).  Returns (level_of_row, plan_pos_of_row, nlevels)."""
     up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
     up_idx = np.ascontiguousarray(up_idx, dtype=np.int64)
@@ -30,17 +30,20 @@ def topology_levels(up_ptr, up_idx, boundary=None):
     lvl = np.empty(nseg, dtype=np.int32)
     pos = np.empty(nseg, dtype=np.int64)
     nl = C.c_int32(0)
-    _lib.check(_lib.lib().trmc_topology_levels(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(b),
-                                               _lib.ptr(lvl), _lib.ptr(pos), C.byref(nl)))
+    h = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
+    _lib.check(_lib.lib().trmc_topology_levels_hinted(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(b), _lib.ptr(h),
+                                                      _lib.ptr(lvl), _lib.ptr(pos), C.byref(nl)))
     return lvl, pos, nl.value
 
 
 class RoutingPlan:
-    def __init__(self, up_ptr, up_idx, params, boundary=None, precision=32, device=0):
+    def __init__(self, up_ptr, up_idx, params, boundary=None, precision=32, device=0, cost_hint=None):
         """
         up_ptr/up_idx : CSR of upstream rows per row, reference summation order
         params        : float32 [nseg, 9] in _lib.PARAM_COLS order
         boundary      : optional bool/uint8 [nseg], rows with prescribed hydrographs
+        cost_hint     : optional uint8 [nseg], e.g. ``download_iterations()`` of a plan of the same network after
+                        a window: rows of equal cost are placed together inside their level (results unchanged)
         """
         self._h = C.c_void_p(0)
         up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
@@ -56,9 +59,12 @@ class RoutingPlan:
         self.precision = precision
         self.dtype = _lib.np_dtype(precision)
         self.nboundary = 0 if b is None else int(np.count_nonzero(b))
+        hint = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
+        if hint is not None and hint.shape != (nseg,):
+            raise ValueError("cost_hint shape mismatch")
         h = C.c_void_p(0)
-        _lib.check(_lib.lib().trmc_plan_create(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
-                                               _lib.ptr(b), precision, device, C.byref(h)))
+        _lib.check(_lib.lib().trmc_plan_create_hinted(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
+                                                      _lib.ptr(b), _lib.ptr(hint), precision, device, C.byref(h)))
         self._h = h
         self._nsteps = None
         self.maxlag = 0
@@ -246,6 +252,18 @@ class RoutingPlan:
         out = np.zeros(self.nseg, dtype=np.uint8)
         _lib.check(_lib.lib().trmc_download_iterations(self._h, _lib.ptr(out)))
         return out
+
+    def collect_cost(self, enable=True):
+        """Sum min(secant iterations, 3) per row over the timesteps of the windows routed from now on (the cost
+        hint of ``RoutingPlan(cost_hint=...)``); off by default."""
+        _lib.check(_lib.lib().trmc_plan_collect_cost(self._h, int(bool(enable))))
+
+    def download_cost(self):
+        """(uint16 [nseg] cost sums of the last window, its number of timesteps)"""
+        out = np.zeros(self.nseg, dtype=np.uint16)
+        n = C.c_int32(0)
+        _lib.check(_lib.lib().trmc_download_cost(self._h, _lib.ptr(out), C.byref(n)))
+        return out, n.value
 
     def gather_flow_rows_resident(self, rows):
         """Gather into plan-owned HBM (no host copy); download_gathered() fetches it later."""

@@ -140,6 +140,39 @@ def test_levels_random_forest_large():
     assert sorted(pos.tolist()) == list(range(20000))
 
 
+def test_plan_order_inside_levels_follows_downstream_rows_and_cost_hint():
+    """Order inside a level: by the position of the row flowed into (upstream gathers of consecutive rows are
+    consecutive); with a cost hint, descending hint first.  Levels themselves and the set of positions never change."""
+    rng = np.random.default_rng(5)
+    n = 60000
+    to = H.random_network(rng, n)
+    reaches, heads_up, ups = H.reaches_from_to(to)
+    up_ptr, up_idx = csr_from_lists(ups)
+    lvl, pos, nl = topology_levels(up_ptr, up_idx)
+    # rows of one level that flow into rows of the next level up sit in the order of those rows
+    order = np.argsort(pos)
+    dn = np.where(to >= 0, pos[np.maximum(to, 0)], np.iinfo(np.int64).max)
+    for l in range(nl - 1):
+        rows = order[lvl[order] == l]
+        d = dn[rows]
+        assert (np.diff(d) >= 0).all(), l
+    hint = rng.integers(0, 4, n).astype(np.uint8)
+    lvl2, pos2, nl2 = topology_levels(up_ptr, up_idx, cost_hint=hint)
+    assert nl2 == nl and np.array_equal(lvl2, lvl) and sorted(pos2.tolist()) == list(range(n))
+    # level slices are the same position ranges; inside level 0 (wide) runs of 128 positions are uniform in hint
+    for l in range(nl):
+        a, b = np.sort(pos[lvl == l]), np.sort(pos2[lvl == l])
+        assert np.array_equal(a, b)
+    order2 = np.argsort(pos2)
+    dn2 = np.where(to >= 0, pos2[np.maximum(to, 0)], np.iinfo(np.int64).max)
+    for l in range(nl):
+        rows = order2[lvl[order2] == l]
+        h = hint[rows].astype(np.int64)
+        assert (np.diff(h) <= 0).all(), l                       # costly rows first
+        same = np.diff(h) == 0
+        assert (np.diff(dn2[rows])[same] >= 0).all(), l          # and inside one cost the downstream order
+
+
 # ---- host shims of the reference's helpers -----------------------------------------------------------
 def test_binary_find_and_column_mapper():
     arr = np.array([3, 5, 9, 12], np.int64)

@@ -392,6 +392,71 @@ def test_conus_row_relabelling_invariance(conus):
     assert_bit_identical(a, b[perm], "relabelled CONUS")
 
 
+@pytest.mark.parametrize("short", [True, False])
+def test_cost_hinted_plan_order_changes_nothing(short):
+    """A plan built with a cost hint (rows of a level grouped by the secant iterations they needed in an earlier
+    window) visits the rows in another order and must produce the same bits: random hints, the plan's own iteration
+    counts as hint, a forest wide enough for the per-block class partition (> 65 536 rows)."""
+    rng = np.random.default_rng(4242)
+    nseg = 90000
+    to = H.random_network(rng, nseg)
+    _, _, ups = H.reaches_from_to(to)
+    up_ptr, up_idx = csr_from_lists(ups)
+    params, qlat, q0 = synth_inputs(rng, nseg, 4)
+    nsteps, qts = 24, 6
+    with RoutingPlan(up_ptr, up_idx, params) as plan:
+        base = plan.route(nsteps, qts, short, qlat, q0)
+        own = plan.download_iterations()
+    assert own.max() >= 2 and (own == 0).any()
+    for hint in (rng.integers(0, 4, nseg).astype(np.uint8), np.minimum(own, 3)):
+        with RoutingPlan(up_ptr, up_idx, params, cost_hint=hint) as plan:
+            got = plan.route(nsteps, qts, short, qlat, q0)
+            assert np.array_equal(plan.download_iterations(), own)
+        assert_bit_identical(got, base, f"hinted plan short={short}")
+    with pytest.raises(ValueError):
+        RoutingPlan(up_ptr, up_idx, params, cost_hint=np.zeros(3, np.uint8))
+    # cost collection: per row the sum over the window of min(iterations, 3); same flows with it on
+    with RoutingPlan(up_ptr, up_idx, params) as plan:
+        with pytest.raises(RuntimeError):
+            plan.download_cost()
+        plan.collect_cost(True)
+        got = plan.route(nsteps, qts, short, qlat, q0)
+        cost, n = plan.download_cost()
+        last = plan.download_iterations()
+        plan.collect_cost(False)
+        with pytest.raises(RuntimeError):
+            plan.download_cost()
+    assert_bit_identical(got, base, "cost collection on")
+    assert n == nsteps and cost.dtype == np.uint16 and cost.max() <= 3 * nsteps
+    assert (cost >= np.minimum(last, 3)).all() and (cost[last >= 2] >= 2).all() and (cost == 0).any()
+
+
+def test_conus_cost_hint_from_a_tuning_window(conus):
+    """The bench's sequence at full size: route, take the iteration hint, rebuild the router with it, route again --
+    same outlet hydrographs, bit for bit."""
+    from troute_amd.distributed import ShardedRouter
+    net, _, _ = conus
+    to, params, qlat = net["to"], net["params"], net["qlat"]
+    nseg = to.shape[0]
+    q0 = np.zeros((nseg, 3), np.float32)
+    nsteps, qts = 48, 12
+    r = ShardedRouter(to, params)
+    r.upload(nsteps, qlat, q0)
+    r.collect_cost(True)
+    rows = r.route_resident(qts, True)
+    a = r.outlet_hydrographs()
+    hint = r.iteration_hint()
+    r.close()
+    assert hint.shape == (nseg,) and 32 <= hint.max() <= 48 and len(np.unique(hint)) > 8
+    r = ShardedRouter(to, params, cost_hint=hint)
+    r.upload(nsteps, qlat, q0)
+    rows2 = r.route_resident(qts, True)
+    b = r.outlet_hydrographs()
+    r.close()
+    assert np.array_equal(rows, rows2)
+    assert_bit_identical(a, b, "CONUS outlets, hinted plan")
+
+
 def test_resident_warm_start_between_windows(lc):
     """Long runs are chunked into windows warm-started from new_q0 = fvd[:, [-3,-3,-1]]
     (AbstractNetwork.py:177-191).  Keeping that state in HBM (q0 = None) is bit-identical to
