@@ -205,6 +205,7 @@ template <class T> struct StepArgs {
     T *q_tm, *v_tm, *d_tm;
     uint8_t *it_prev; // secant iterations each position needed on its previous step
     uint16_t *it_sum; // nullptr, or: sum over the window of min(iterations, 3) per position (trmc_plan_collect_cost)
+    bool partition;   // blocks partition their rows by iteration class (off when the plan order already groups them)
     // level-pool reservoirs (nullptr = none): reservoir index of a position, parameters [nres][9],
     // inflow series [nres][nsteps] (the reference's upstream_array rows), routing period
     const int32_t *res_of_pos;
@@ -388,7 +389,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 a.v_tm[row_c + s] = T(0);
                 a.d_tm[row_c + s] = H;
                 a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
-                if (SORT) a.it_prev[s] = 0;
+                if (a.partition || t == a.nsteps) a.it_prev[s] = 0;
                 continue;
             }
         }
@@ -424,7 +425,9 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         at(a.q_tm + row_c, ob) = q_new;
         at(a.v_tm + row_c, ob) = r.velc;
         at(a.d_tm + row_c, ob) = r.depthc;
-        if (SORT) a.it_prev[su] = (uint8_t)min(r.iters, 255);
+        // (the partition reads it on the next step; without the partition only trmc_download_iterations does, after
+        // the window: one byte-masked store per row and step is 3 % of the launch)
+        if (a.partition || t == a.nsteps) a.it_prev[su] = (uint8_t)min(r.iters, 255);
         if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + min(r.iters, 3));
     }
 }
@@ -720,6 +723,7 @@ struct trmc_plan {
     DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev, lag;
     DevBuf it_sum;                       // per-position cost of the window (trmc_plan_collect_cost)
     bool collect_cost = false;
+    bool hinted = false;                 // created with a cost hint: rows of a level are grouped by cost
     int32_t cost_nsteps = -1;            // nsteps of the window it_sum was collected over
     int32_t maxlag = 0;                  // trmc_plan_set_lag: rows routed `maxlag` launches behind the others
     std::vector<int32_t> lag_of_row;
@@ -806,6 +810,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.lag = pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr;
     a.it_prev = (uint8_t *)pl->it_prev.p;
     a.it_sum = pl->collect_cost ? (uint16_t *)pl->it_sum.p : nullptr;
+    a.partition = !pl->hinted;
     a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
     a.res_par = (const T *)pl->res_par.p;
     a.res_inflow = (T *)pl->res_inflow.p;
@@ -839,7 +844,13 @@ inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_
     // (1024-position chunks handled as four serial passes per block sort better -- fewer VALU
     // instructions -- but measured 14 % slower on MI355X because every block gets four times longer;
     // the kernel keeps its IPT parameter, the launcher uses one position per thread)
-    const bool sort = n >= (int64_t)kStepBlock * 512; // fewer than two blocks per CU: latency-bound, skip the class partition
+#ifndef TRMC_SORT_MIN // positions per launch from which blocks partition their rows by class (A/B builds override it)
+#define TRMC_SORT_MIN ((int64_t)kStepBlock * 512)
+#endif
+    // fewer than two blocks per CU: latency-bound, skip the class partition; a plan built with a cost hint has its
+    // rows grouped by cost already (the partition's 60 instructions and three barriers then only cost: 23.7 ms per
+    // CONUS day with it, 22.3 ms without)
+    const bool sort = a.partition && n >= TRMC_SORT_MIN;
     if (SHORT && a.lag) {
         if (sort)
             hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, true, SHORT>), grid, block, 0, st, a, s0, s1, d);
@@ -1113,6 +1124,7 @@ int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
     }
     pl->device = device;
+    pl->hinted = cost_hint != nullptr;
     pl->precision = precision;
     pl->esz = precision == 32 ? 4 : 8;
     pl->nseg = nseg;
