@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--nseg", type=int, default=None)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ranks", type=str, default=None, help="comma list (default: all)")
+    ap.add_argument("--retune", action="store_true", help="rebuild every router with the cost hint of a tuning window")
     a = ap.parse_args()
     import torch
     from troute_amd import sharding, synthetic
@@ -42,7 +43,16 @@ def main():
     # true hydrographs of the cut rows from a whole-network route
     single = ShardedRouter(to, params)
     single.upload(nsteps, qlat, q0)
+    if a.retune:
+        single.collect_cost(True)
     single.route_resident(qts, short)
+    hint = None
+    if a.retune:
+        hint = single.iteration_hint()
+        single.close()
+        single = ShardedRouter(to, params, cost_hint=hint)
+        single.upload(nsteps, qlat, q0)
+        single.route_resident(qts, short)
     t0 = time.perf_counter()
     single.route_resident(qts, short)
     t_single = time.perf_counter() - t0
@@ -55,7 +65,7 @@ def main():
 
     worst = 0.0
     for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
-        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part)
+        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint)
         r.enable_device_exchange(torch, dev)
         r.upload(nsteps, qlat, q0)
         r.upload_trunk()
