@@ -602,6 +602,33 @@ DW_HD inline Depth funcd(const Problem &p, const Scan &scan, const double *tb, i
     r.df = 1.0 + (fabs(Q_cur) * Q_cur / (conv_cur * conv_cur * conv_cur)) * DW_S(p.dx, i, j) * topw * dKdA;
     return r;
 }
+// The same function at three depths at once, stage by stage (searches, then table rows, then arithmetic): the three
+// evaluations rtsafe starts with -- both ends of its bracket and the midpoint -- do not depend on each other, and a
+// lone wavefront that runs them one after the other waits for every search and every table row three times.
+// Per depth the operations are those of funcd, so the bits are too.
+template <class Scan>
+DW_HD inline void funcd3(const Problem &p, const Scan &scan, const double *tb, int i, int j, double Q_cur, double sf_ds,
+                         double z_cur, const double (&y)[3], double y_ds, Depth (&out)[3])
+{
+    if (p.counters) p.counters[2] += 3;
+    double elv[3], conv[3], dKdA[3], topw[3];
+    int irow[3];
+    for (int k = 0; k < 3; ++k) elv[k] = y[k] + z_cur;
+    for (int k = 0; k < 3; ++k) irow[k] = row_blk(scan, tb, C_ELEV, elv[k]);
+    for (int k = 0; k < 3; ++k) {
+        conv[k] = at_row(tb, C_ELEV, C_CONV, irow[k], elv[k]);
+        dKdA[k] = at_row(tb, C_ELEV, C_DKDA, irow[k], elv[k]);
+        topw[k] = at_row(tb, C_ELEV, C_TOPW, irow[k], elv[k]);
+    }
+    const double dxi = DW_S(p.dx, i, j);
+    double slope = (DW_S(p.z, i, j) - DW_S(p.z, i + 1, j)) / dxi;
+    slope = dmax(slope, p.so_llm);
+    for (int k = 0; k < 3; ++k) {
+        const double sf_cur = fabs(Q_cur) * Q_cur / (conv[k] * conv[k]);
+        out[k].f = y[k] - y_ds + slope * dxi - 0.50 * (sf_cur + sf_ds) * dxi;
+        out[k].df = 1.0 + (fabs(Q_cur) * Q_cur / (conv[k] * conv[k] * conv[k])) * dxi * topw[k] * dKdA[k];
+    }
+}
 // rtsafe (:1555-1662): Newton-Raphson safeguarded by bisection for the depth of node i given node i+1
 template <class Scan>
 DW_HD inline double rtsafe(const Problem &p, const Scan &scan, const double *tb, const double *tb_ds, int i, int j, double Q_cur,
@@ -610,23 +637,30 @@ DW_HD inline double rtsafe(const Problem &p, const Scan &scan, const double *tb,
     const int maxit = 40;
     const double xacc = (double)1e-4f;
     const double elv_ds = y_ds + z_ds;
-    const double conv_ds = intp_blk(scan, tb_ds, C_ELEV, C_CONV, elv_ds);
+    // the two look-ups that set the problem up, their searches first, then their rows
+    const int row_ds = row_blk(scan, tb_ds, C_ELEV, elv_ds);
+    const int row_norm = row_blk(scan, tb, C_UNIF, fabs(Q_cur));
+    const double conv_ds = at_row(tb_ds, C_ELEV, C_CONV, row_ds, elv_ds);
+    const double elv_norm = at_row(tb, C_UNIF, C_ELEV, row_norm, fabs(Q_cur));
     const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
-    const double elv_norm = intp_blk(scan, tb, C_UNIF, C_ELEV, fabs(Q_cur));
     const double y_norm = elv_norm - DW_S(p.z, i, j);
     const double y_old = DW_S(p.oldY, i, j) - DW_S(p.z, i, j);
     const double x1 = 0.5 * (y_norm + y_old) * (double)0.1f;
     const double x2 = 0.5 * (y_norm + y_old) * 2.0;
-    const double fl = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, x1, y_ds).f;
-    const double fh = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, x2, y_ds).f;
+    double rt = 0.50 * (x1 + x2);
+    // f at both ends of the bracket and (f, df) at the midpoint the iteration starts from, together (the reference
+    // evaluates the midpoint only when the bracket holds; its value is not used otherwise)
+    const double y3[3] = {x1, x2, rt};
+    Depth d3[3];
+    funcd3(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, y3, y_ds, d3);
+    const double fl = d3[0].f, fh = d3[1].f;
     if ((fl > 0.0 && fh > 0.0) || (fl < 0.0 && fh < 0.0)) return y_norm;
     if (fl == 0.0) return x1;
     if (fh == 0.0) return x2;
     double xl, xh;
     if (fl < 0.0) { xl = x1; xh = x2; } else { xh = x1; xl = x2; }
-    double rt = 0.50 * (x1 + x2);
     double dxold = fabs(x2 - x1), dxx = dxold;
-    Depth d = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, rt, y_ds);
+    Depth d = d3[2];
     for (int iter = 1; iter <= maxit; ++iter) {
         if (((rt - xh) * d.df - d.f) * ((rt - xl) * d.df - d.f) > 0.0 || fabs(2.0 * d.f) > fabs(dxold * d.df)) {
             dxold = dxx;
