@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 2
+#define TRMC_ABI_VERSION 3
 
 typedef enum trmc_status {
     TRMC_OK = 0,
