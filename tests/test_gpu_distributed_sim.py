@@ -34,8 +34,10 @@ class ThreadAllGather:
         return all_gather_into
 
 
-@pytest.mark.parametrize("short,nchunks", [(True, None), (True, 1), (True, 5), (False, None), (False, 3)])
-def test_two_ranks_device_exchange_equals_single_rank(short, nchunks):
+@pytest.mark.parametrize("short,nchunks,retune", [(True, None, False), (True, 1, False), (True, 5, False),
+                                                  (False, None, False), (False, 3, False), (True, None, True),
+                                                  (False, None, True)])
+def test_two_ranks_device_exchange_equals_single_rank(short, nchunks, retune):
     import torch
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
@@ -58,6 +60,16 @@ def test_two_ranks_device_exchange_equals_single_rank(short, nchunks):
             r.enable_device_exchange(torch, torch.device("cuda", 0))
             r.upload(nsteps, net["qlat"], q0)
             r.upload_trunk()
+            if retune:                                  # every rank rebuilds its plans from its own tuning window
+                r.collect_cost(True)
+                r.route_on_device(qts, short, ag.for_rank(rank), nchunks)
+                hint = r.iteration_hint()
+                assert hint.max() > 0
+                r.close()
+                r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0, cost_hint=hint)
+                r.enable_device_exchange(torch, torch.device("cuda", 0))
+                r.upload(nsteps, net["qlat"], q0)
+                r.upload_trunk()
             for _ in range(2):                          # twice: the staged buffers must be reusable
                 rows, hyd = r.route_on_device(qts, short, ag.for_rank(rank), nchunks)
             results[rank] = (rows, hyd.cpu().numpy(), r.cut_rows.shape[0], r.plan1 is not None)
