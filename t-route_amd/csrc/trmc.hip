@@ -558,33 +558,59 @@ k_fill_boundary(const T *__restrict__ bfvd, T *q_tm, T *v_tm, T *d_tm, int32_t n
 #define TRMC_EMIT_STEPS 32
 #endif
 constexpr int kEmitSteps = TRMC_EMIT_STEPS;
+// Index arithmetic is what this kernel's VALU instructions are, and it runs beside the VALU-bound step launches, so
+// both passes are written to need little of it: a thread keeps ONE position through the load pass (its time-major
+// addresses advance by a constant), and the store pass moves 16 bytes per lane -- a row's run of 32 steps is 24 such
+// pieces, two rows per wave instruction -- when the result's rows are 16-byte aligned (nsteps % 4 == 0 in fp32).
 template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_emit(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restrict__ d_tm,
        const int32_t *__restrict__ row_of_pos, T *__restrict__ out, int32_t nseg, int64_t nseg_pad,
        int32_t nsteps, int32_t t_begin, int32_t t_end)
 {
-    __shared__ T tile[64][3 * kEmitSteps + 1]; // [position][step*3 + c]
+    static_assert(kBlock == 256 && kEmitSteps % 4 == 0, "the passes below assume 4 waves and whole groups of 4 steps");
+    constexpr int kRow = 3 * kEmitSteps + 4; // row stride in elements: a multiple of 4, so that 16-byte reads are aligned
+    __shared__ __attribute__((aligned(16))) T tile[64][kRow]; // [position][step*3 + c]
     const int32_t p0 = blockIdx.x * 64;
     const int32_t t0 = t_begin + (int32_t)blockIdx.y * kEmitSteps; // zero-based output step
     const int32_t nt = min(kEmitSteps, t_end - t0);
-    for (int32_t i = threadIdx.x; i < 64 * kEmitSteps; i += kBlock) {
-        const int32_t tl = i / 64, pl = i % 64;
-        const int32_t p = p0 + pl;
-        if (p < nseg && tl < nt) {
-            const size_t src = (size_t)(t0 + tl + 1) * nseg_pad + p;
-            tile[pl][tl * 3 + 0] = q_tm[src];
-            tile[pl][tl * 3 + 1] = v_tm[src];
-            tile[pl][tl * 3 + 2] = d_tm[src];
+    const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {
+        const int32_t p = p0 + lane;
+        if (p < nseg) {
+            size_t src = (size_t)(t0 + 1 + wave) * (size_t)nseg_pad + (size_t)p;
+            T *dst = &tile[lane][wave * 3];
+            for (int32_t tl = wave; tl < nt; tl += 4) {
+                dst[0] = q_tm[src];
+                dst[1] = v_tm[src];
+                dst[2] = d_tm[src];
+                src += 4 * (size_t)nseg_pad;
+                dst += 12;
+            }
         }
     }
     __syncthreads();
-    const int32_t wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    for (int32_t pl = wave; pl < 64; pl += kBlock / 64) {
-        const int32_t p = p0 + pl;
-        if (p >= nseg) break;
-        T *dst = out + ((size_t)row_of_pos[p] * nsteps + t0) * 3;
-        for (int32_t e = lane; e < nt * 3; e += 64) dst[e] = tile[pl][e];
+    const bool vec = sizeof(T) == 4 && nt == kEmitSteps && ((size_t)nsteps * 3 * sizeof(T)) % 16 == 0 && (t0 % 4) == 0;
+    if (vec) {
+        // 24 lanes per row (96 floats = 24 x 16 B), two rows per pass: lanes 0-23 and 24-47
+        constexpr int kVecPerRow = 3 * kEmitSteps / 4;
+        const int32_t half = lane / kVecPerRow, j = lane - half * kVecPerRow;
+        if (half < 2) {
+            for (int32_t pl = wave * 16 + half; pl < wave * 16 + 16; pl += 2) {
+                const int32_t p = p0 + pl;
+                if (p >= nseg) break;
+                const float4 v = *reinterpret_cast<const float4 *>(&tile[pl][4 * j]);
+                float4 *dst = reinterpret_cast<float4 *>(out + ((size_t)row_of_pos[p] * nsteps + t0) * 3);
+                dst[j] = v;
+            }
+        }
+    } else {
+        for (int32_t pl = wave; pl < 64; pl += kBlock / 64) {
+            const int32_t p = p0 + pl;
+            if (p >= nseg) break;
+            T *dst = out + ((size_t)row_of_pos[p] * nsteps + t0) * 3;
+            for (int32_t e = lane; e < nt * 3; e += 64) dst[e] = tile[pl][e];
+        }
     }
 }
 
