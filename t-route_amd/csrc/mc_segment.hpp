@@ -170,9 +170,14 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
     T x;
     if (hp.ck > T(0)) {
         const T denom = hp.denom;
-        if (!LOWER)
-            x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - (qj_prev / denom))));
-        else
+        if (!LOWER) {
+            // every solve starts with Qj_0 = 0: 0 / denom is a zero for any non-zero denom (inf included), 1 - (+-0) = 1,
+            // x = 0.5 -- no division.  (A zero or NaN denom makes the quotient NaN and takes the arithmetic below.)
+            if (qj_prev == T(0) && (denom > T(0) || denom < T(0)))
+                x = T(0.5);
+            else
+                x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - (qj_prev / denom))));
+        } else
             x = mc_min(T(0.5),
                        mc_max(T(0.25),
                               T(0.5) * (T(1) - (((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4)
@@ -234,14 +239,18 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
     }
 
     MuskCoef<T> k{T(0), T(0), T(0), T(0), T(0)};
-    T aerror = T(0.01), rerror = T(1);
+    // The relative error |(h_1 - h) / h| (f90:108) is only ever compared with 0.01 (f90:83): `rel_open` is that
+    // comparison, decided without the division whenever the ratio is clearly on one side (a band of 1e-4 around the
+    // threshold against a rounding error of 6e-8; a NaN fails both tests and takes the division).
+    T aerror = T(0.01);
+    bool rel_open = true;
     int maxiter = 100, tries = 0, total_iter = 0;
     HydraulicPoint<T> at_h; // the point of the current h, carried into the next iteration as h_0's
     bool carried = false;
     for (;;) {
         T qj_0 = T(0);
         int iter = 0;
-        while (rerror > T(0.01) && aerror >= mindepth && iter <= maxiter) {
+        while (rel_open && aerror >= mindepth && iter <= maxiter) {
             const HydraulicPoint<T> at_h0 = carried ? at_h : hydraulics_at<T, M>(h_0, p, c, m);
             qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k, m);
             at_h = hydraulics_at<T, M>(h, p, c, m);
@@ -254,10 +263,16 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
                 h_1 = h;
             }
             if (h > T(0)) {
-                rerror = mc_abs((h_1 - h) / h);
-                aerror = mc_abs(h_1 - h);
+                const T dh = mc_abs(h_1 - h);
+                aerror = dh;
+                if (dh > T(0.010001) * h)
+                    rel_open = true;
+                else if (dh < T(0.009999) * h)
+                    rel_open = false;
+                else
+                    rel_open = mc_abs((h_1 - h) / h) > T(0.01);
             } else {
-                rerror = T(0);
+                rel_open = false; // rerror = 0
                 aerror = T(0.9);
             }
             carried = (h >= T(0)); // then the next h_0 = max(0, h) is h itself (always, h is never negative)
