@@ -23,7 +23,10 @@
 // Math policy M:  m.sqrt(x); m.pow(x, y); and, so that x**a and x**b can share
 // one logarithm, M::Log, m.log_of(x), m.pow_l(log_of(x), x, y) == m.pow(x, y);
 // m.div4(n1, n2, n3, n4, d, q1, q2, q3, q4): qi = ni / d, the four correctly rounded quotients by one
-// divisor (the Muskingum coefficients) -- a policy may share the reciprocal between them.
+// divisor (the Muskingum coefficients) -- a policy may share the reciprocal between them;
+// m.fast_ok(h, h_in, h_over) -> ok; m.div2(a1, a2, b, ok, q1, q2): qi = ai / b; m.div1(a, b, ok) = a / b: the
+// divisions of the hydraulic point, for which a policy may use a cheaper exact sequence when `ok` (its own test of
+// the operand ranges) holds.
 //
 // The header is host/device neutral on purpose: tests/host_harness.cpp
 // instantiates it with libm on the CPU to check the logic against the oracle
@@ -86,7 +89,7 @@ template <class T> struct Section {
     T twl, area, areac, wp, wpc, R, h_in, h_over;
 };
 
-template <class T, class M>
+template <class T, class M, bool WITH_R = true>
 MC_HD Section<T> section_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
 {
     Section<T> s;
@@ -101,7 +104,7 @@ MC_HD Section<T> section_at(T h, const ChannelParams<T> &p, const ChannelConst<T
     s.wp = p.bw + T(2) * s.h_in * c.sq1pz2;
     s.areac = p.twcc * s.h_over;
     s.wpc = (s.h_over > T(0)) ? p.twcc + (T(2) * s.h_over) : T(0);
-    s.R = (s.area + s.areac) / (s.wp + s.wpc);
+    if (WITH_R) s.R = (s.area + s.areac) / (s.wp + s.wpc);
     return s;
 }
 
@@ -132,9 +135,13 @@ template <class T, class M>
 MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
 {
     const T c23 = T(2) / T(3), c53 = T(5) / T(3);
-    const Section<T> s = section_at<T, M>(h, p, c, m);
+    Section<T> s = section_at<T, M, false>(h, p, c, m);
     HydraulicPoint<T> hp;
     const bool over = (h > c.bfd) && c.fp_ok;
+    // the hydraulic radius and the composite Manning n are quotients by the same wetted perimeter (f90:417, :329)
+    const bool ok = m.fast_ok(h, s.h_in, s.h_over);
+    T n_comp;
+    m.div2(s.area + s.areac, (s.wp * p.n) + (s.wpc * p.ncc), s.wp + s.wpc, ok, s.R, n_comp);
 
     // R**(2/3) and R**(5/3) share one logarithm (M::Log), see det_pow.h
     const typename M::Log lr = m.log_of(s.R);
@@ -147,15 +154,14 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
                                  / (s.area + s.areac));
     } else if (h > T(0)) {
         hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
-                                                    * (c.two_sq / (p.bw + T(2) * h * c.z)))));
+                                                    * m.div1(c.two_sq, p.bw + T(2) * h * c.z, ok))));
     } else {
         hp.ck = T(0);
     }
     hp.km = (hp.ck > T(0)) ? mc_max(p.dt, p.dx / hp.ck) : p.dt;
     hp.denom = T(2) * (over ? p.twcc : s.twl) * p.s0 * hp.ck * p.dx;
     hp.has_wp = (s.wp + s.wpc) > T(0);
-    hp.q_manning = (T(1) / (((s.wp * p.n) + (s.wpc * p.ncc)) / (s.wp + s.wpc))) * (s.area + s.areac) * r23
-                   * c.sqrt_s0;
+    hp.q_manning = m.div1(T(1), n_comp, ok) * (s.area + s.areac) * r23 * c.sqrt_s0;
     return hp;
 }
 

@@ -108,6 +108,49 @@ struct DevMathF {
     // no fix-up, every quotient normal or +0 (for which the refinement returns +0 as IEEE does).  Then
     // the same instructions are issued, minus the three helpers, and y1 once instead of four times:
     // bit-identical by construction.  Anything else takes the plain divisions.
+    // The divisions of the hydraulic point (hydraulics_at: radius and composite n by the wetted perimeter, the top-width
+    // term of the celerity, the reciprocal of the composite n) under the same argument.  `sane` is established once per
+    // plan on the host (params_sane: bw, n, cs, twcc, ncc in [2**-14, 2**17], cs, twcc and ncc possibly 0); with the in-bank and
+    // over-bank depths in [2**-30, 2**17] the operands are: perimeter W = wp + wpc in [2**-14, 2**36]; area sum in
+    // [2**-44, 2**51]; wp*n + wpc*ncc in [2**-28, 2**54]; the composite n in [2**-64, 2**18]; bw + 2hz in
+    // [2**-14, 2**36] under 2*sqrt(1 + z*z) in [2, 2**19] -- all normal, no pair more than 2**80 apart, every quotient
+    // normal: the scaling and fix-up instructions are the identity, and the refinement below IS the division.
+    bool sane;
+    __device__ __forceinline__ bool fast_ok(float h, float h_in, float h_over) const
+    {
+#if TRMC_EXPERIMENT_DIV == 0
+        return sane && h_in >= 0x1p-30f && h <= 0x1p17f && (h_over == 0.0f || h_over >= 0x1p-30f);
+#else
+        return false;
+#endif
+    }
+    __device__ __forceinline__ static float refined_rcp(float b)
+    {
+        const float y0 = __builtin_amdgcn_rcpf(b);
+        return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+    }
+    __device__ __forceinline__ void div2(float a1, float a2, float b, bool ok, float &q1, float &q2) const
+    {
+        if (ok) {
+            const float y1 = refined_rcp(b);
+            q1 = quot(a1, b, y1);
+            q2 = quot(a2, b, y1);
+        } else {
+            q1 = a1 / b;
+            q2 = a2 / b;
+        }
+    }
+    __device__ __forceinline__ float div1(float a, float b, bool ok) const
+    {
+        if (ok) return quot(a, b, refined_rcp(b));
+        return a / b;
+    }
+    __device__ __forceinline__ static float quot(float a, float b, float y1)
+    {
+        const float q0 = a * y1;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y1, q0);
+        return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y1, q1);
+    }
 #if TRMC_EXPERIMENT_DIV == 0
     bool coef_ok;
     __device__ __forceinline__ static float refined_quot(float a, float b, float y1)
@@ -154,6 +197,14 @@ struct DevMathD {
     __device__ __forceinline__ double pow(double x, double y) const { return ::pow(x, y); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     bool coef_ok; // unused
+    bool sane;    // unused
+    __device__ __forceinline__ bool fast_ok(double, double, double) const { return false; }
+    __device__ __forceinline__ void div2(double a1, double a2, double b, bool, double &q1, double &q2) const
+    {
+        q1 = a1 / b;
+        q2 = a2 / b;
+    }
+    __device__ __forceinline__ double div1(double a, double b, bool) const { return a / b; }
     __device__ __forceinline__ void div4(double n1, double n2, double n3, double n4, double d, double &q1, double &q2,
                                          double &q3, double &q4) const
     {
@@ -206,6 +257,7 @@ template <class T> struct StepArgs {
     uint8_t *it_prev; // secant iterations each position needed on its previous step
     uint16_t *it_sum; // nullptr, or: sum over the window of min(iterations, 3) per position (trmc_plan_collect_cost)
     bool partition;   // blocks partition their rows by iteration class (off when the plan order already groups them)
+    bool sane;        // every channel parameter of the plan lies in the range DevMathF::fast_ok's argument needs
     // level-pool reservoirs (nullptr = none): reservoir index of a position, parameters [nres][9],
     // inflow series [nres][nsteps] (the reference's upstream_array rows), routing period
     const int32_t *res_of_pos;
@@ -258,6 +310,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     __shared__ uint16_t s_perm[kChunk];
     __shared__ int32_t s_cnt[kClasses][IPT][kWaves];
     M m{stage_pow_tables(s_tab), false};
+    m.sane = a.sane;
 
     const int32_t base = s_begin + (int32_t)blockIdx.x * kChunk;
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -751,6 +804,7 @@ struct trmc_plan {
     DevBuf it_sum;                       // per-position cost of the window (trmc_plan_collect_cost)
     bool collect_cost = false;
     bool hinted = false;                 // created with a cost hint: rows of a level are grouped by cost
+    bool params_sane = false;            // see DevMathF::fast_ok
     int32_t cost_nsteps = -1;            // nsteps of the window it_sum was collected over
     int32_t maxlag = 0;                  // trmc_plan_set_lag: rows routed `maxlag` launches behind the others
     std::vector<int32_t> lag_of_row;
@@ -785,10 +839,17 @@ template <class T> int upload_params(trmc_plan *pl, const float *params)
     std::vector<T> host((size_t)TRMC_NPARAM * np, T(0));
     const size_t all_cols = (size_t)kTotalCols * np;
     // a benign channel for the padding lanes (never routed, never read back)
+    bool sane = true;
+    auto in_range = [](float v) { return v >= 0x1p-14f && v <= 0x1p17f; };
     for (int64_t p = 0; p < n; ++p) {
         const float *src = params + (size_t)pl->topo.row_of_pos[p] * TRMC_NPARAM;
         for (int c = 0; c < TRMC_NPARAM; ++c) host[(size_t)c * np + p] = (T)src[c];
+        const float cs = src[TRMC_P_CS];
+        // (the operands of those divisions are made of bw, the side slope, n, ncc, twcc and the depth only)
+        sane = sane && in_range(src[TRMC_P_BW]) && in_range(src[TRMC_P_N]) && (cs == 0.0f || in_range(cs))
+               && (src[TRMC_P_TWCC] == 0.0f || in_range(src[TRMC_P_TWCC])) && (src[TRMC_P_NCC] == 0.0f || in_range(src[TRMC_P_NCC]));
     }
+    pl->params_sane = sane && sizeof(T) == 4;
     if (int rc = pl->params.ensure(all_cols * sizeof(T))) return rc;
     HIP_TRY(hipMemcpy(pl->params.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     if (n > 0) {
@@ -838,6 +899,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.it_prev = (uint8_t *)pl->it_prev.p;
     a.it_sum = pl->collect_cost ? (uint16_t *)pl->it_sum.p : nullptr;
     a.partition = !pl->hinted;
+    a.sane = pl->params_sane;
     a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
     a.res_par = (const T *)pl->res_par.p;
     a.res_inflow = (T *)pl->res_inflow.p;
