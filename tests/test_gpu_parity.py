@@ -431,6 +431,52 @@ def test_cost_hinted_plan_order_changes_nothing(short):
     assert (cost >= np.minimum(last, 3)).all() and (cost[last >= 2] >= 2).all() and (cost == 0).any()
 
 
+@pytest.mark.parametrize("short", [True, False])
+def test_extreme_parameters_and_depths_around_the_fast_division_guard(short):
+    """The hydraulic point drops the scaling / fix-up steps of its divisions when a plan-wide parameter check and a
+    per-call depth test hold (DevMathF::fast_ok, trmc.hip); the oracle always divides plainly.  Forests with parameters
+    log-uniform over the whole admitted range [2**-14, 2**17] (twcc / ncc sometimes 0) and initial depths from 1e-12 to
+    1e4 -- on both sides of the depth test -- must agree bit for bit; one parameter outside the range switches the
+    plan to plain divisions, same results."""
+    rng = np.random.default_rng(77)
+    nseg = 70000
+    to = H.random_network(rng, nseg)
+    _, _, ups = H.reaches_from_to(to)
+    up_ptr, up_idx = csr_from_lists(ups)
+    lvl, _, _ = topology_levels(up_ptr, up_idx)
+
+    def logu(lo, hi, n):
+        return np.exp(rng.uniform(np.log(lo), np.log(hi), n))
+    lo, hi = 2.0 ** -14, 2.0 ** 17
+    bw = logu(lo * 1.01, 300.0, nseg)
+    tw = bw * rng.uniform(1.0, 3.0, nseg)
+    twcc = np.where(rng.random(nseg) < 0.2, 0.0, tw * rng.uniform(1.0, 4.0, nseg))
+    n = logu(lo * 1.01, 0.5, nseg)
+    ncc = np.where(rng.random(nseg) < 0.1, 0.0, n * rng.uniform(1.0, 3.0, nseg))
+    cs = logu(0.02, 50.0, nseg)
+    params = np.stack([np.full(nseg, 300.0), logu(10.0, 5e4, nseg), bw, tw, twcc, n, ncc, cs, logu(1e-5, 1.0, nseg)], 1)
+    params = params.astype(np.float32)
+    qlat = logu(1e-9, 5.0, (nseg, 3)).astype(np.float32) * (rng.random((nseg, 3)) > 0.2)
+    q0 = np.stack([logu(1e-9, 50.0, nseg), logu(1e-9, 50.0, nseg), logu(1e-12, 1e4, nseg)], 1).astype(np.float32)
+    nsteps, qts = 12, 4
+    want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params, q0, qlat, short, det=True)[:, 1:, :]
+    fin = np.isfinite(want).all(axis=(1, 2))
+    assert fin.mean() > 0.99
+    with RoutingPlan(up_ptr, up_idx, params) as plan:
+        got = plan.route(nsteps, qts, short, qlat, q0)
+    assert_bit_identical(got[fin], want[fin], f"extreme parameters short={short}")
+    assert (np.isfinite(got).all(axis=(1, 2)) == fin).all()
+    # one row outside the admitted range: the whole plan divides plainly
+    params2 = params.copy()
+    params2[0, 2] = np.float32(2.0 ** 18)
+    params2[0, 3] = np.float32(2.0 ** 19)
+    want2 = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params2, q0, qlat, short, det=True)[:, 1:, :]
+    fin2 = np.isfinite(want2).all(axis=(1, 2))
+    with RoutingPlan(up_ptr, up_idx, params2) as plan:
+        got2 = plan.route(nsteps, qts, short, qlat, q0)
+    assert_bit_identical(got2[fin2], want2[fin2], "plain divisions")
+
+
 def test_conus_cost_hint_from_a_tuning_window(conus):
     """The bench's sequence at full size: route, take the iteration hint, rebuild the router with it, route again --
     same outlet hydrographs, bit for bit."""
