@@ -251,15 +251,16 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
     T aerror = T(0.01);
     bool rel_open = true;
     int maxiter = 100, tries = 0, total_iter = 0;
-    HydraulicPoint<T> at_h; // the point of the current h, carried into the next iteration as h_0's
-    bool carried = false;
     for (;;) {
         T qj_0 = T(0);
         int iter = 0;
+        // the point of h_0: evaluated here for the bracket a (re)try starts from; inside the loop h_0 <- max(0, h) is h
+        // itself (h is never negative), so the point just evaluated for h is carried over instead of being recomputed
+        HydraulicPoint<T> at_h0;
+        if (rel_open && aerror >= mindepth && iter <= maxiter) at_h0 = hydraulics_at<T, M>(h_0, p, c, m);
         while (rel_open && aerror >= mindepth && iter <= maxiter) {
-            const HydraulicPoint<T> at_h0 = carried ? at_h : hydraulics_at<T, M>(h_0, p, c, m);
             qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k, m);
-            at_h = hydraulics_at<T, M>(h, p, c, m);
+            const HydraulicPoint<T> at_h = hydraulics_at<T, M>(h, p, c, m);
             const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k, m);
             T h_1;
             if (qj_0 - qj != T(0)) {
@@ -281,7 +282,7 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
                 rel_open = false; // rerror = 0
                 aerror = T(0.9);
             }
-            carried = (h >= T(0)); // then the next h_0 = max(0, h) is h itself (always, h is never negative)
+            at_h0 = at_h;
             h_0 = mc_max(T(0), h);
             h = mc_max(T(0), h_1);
             ++iter;
@@ -292,7 +293,6 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
             h = h * T(1.33);
             h_0 = h_0 * T(0.67);
             maxiter += 25;
-            carried = false;
             continue;
         }
         break;
