@@ -251,6 +251,7 @@ template <class T> struct StepArgs {
     const T *dt_col; // nullptr -> uniform dt
     T dt;
     const int32_t *up_ptr, *up_idx, *level;
+    const int2 *up2; // first two upstream positions of every position (see k_mc_step)
     const int32_t *lag; // LAG form of the short-timestep kernel: position s is at step diag - lag[s]
     const T *qlat_tm;
     T *q_tm, *v_tm, *d_tm;
@@ -421,13 +422,30 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         const T depthp = at(a.d_tm + row_p, ob);
         f.ql = at(a.qlat_tm + (size_t)((t - 1) / a.qts) * (size_t)a.nseg_pad, ob);
 
-        // junction sums in the reference's order (mc_reach.pyx:499-502)
+        // junction sums in the reference's order (mc_reach.pyx:499-502).  The first two upstream positions of a row
+        // sit in a table of their own (-1 = none; bit 30 of the second = "the CSR list has more"): one load beside
+        // the parameter loads instead of the dependent chain up_ptr -> up_idx -> q, and no loop for fan-in <= 2.
         T qup = T(0), quc = T(0);
-        const int32_t k0 = a.up_ptr[su], k1 = a.up_ptr[su + 1];
-        for (int32_t k = k0; k < k1; ++k) {
-            const uint32_t ub = (uint32_t)a.up_idx[k] * (uint32_t)sizeof(T);
-            qup += at(q_prev, ub);
-            if (!SHORT) quc += at(q_curr, ub);
+        {
+            const int2 u = a.up2[su];
+            if (u.x >= 0) {
+                const uint32_t ub = (uint32_t)u.x * (uint32_t)sizeof(T);
+                qup += at(q_prev, ub);
+                if (!SHORT) quc += at(q_curr, ub);
+            }
+            if (u.y >= 0) {
+                const uint32_t ub = (uint32_t)(u.y & 0x3fffffff) * (uint32_t)sizeof(T);
+                qup += at(q_prev, ub);
+                if (!SHORT) quc += at(q_curr, ub);
+                if (u.y & 0x40000000) {
+                    const int32_t k1 = a.up_ptr[su + 1];
+                    for (int32_t k = a.up_ptr[su] + 2; k < k1; ++k) {
+                        const uint32_t uk = (uint32_t)a.up_idx[k] * (uint32_t)sizeof(T);
+                        qup += at(q_prev, uk);
+                        if (!SHORT) quc += at(q_curr, uk);
+                    }
+                }
+            }
         }
         f.qup = qup;
         f.quc = SHORT ? qup : quc;
@@ -800,7 +818,7 @@ struct trmc_plan {
     hipEvent_t ev_emit = nullptr;        // "all tiles emitted" (stream2 -> main stream)
     // static, plan order
     DevBuf params; // 9 columns x nseg_pad
-    DevBuf up_ptr, up_idx, level, row_of_pos, pos_of_row, it_prev, lag;
+    DevBuf up_ptr, up_idx, up2, level, row_of_pos, pos_of_row, it_prev, lag;
     DevBuf it_sum;                       // per-position cost of the window (trmc_plan_collect_cost)
     bool collect_cost = false;
     bool hinted = false;                 // created with a cost hint: rows of a level are grouped by cost
@@ -894,6 +912,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.s0_ncc = col<T>(pl, TRMC_NPARAM + 5);
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
+    a.up2 = (const int2 *)pl->up2.p;
     a.level = (const int32_t *)pl->level.p;
     a.lag = pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr;
     a.it_prev = (uint8_t *)pl->it_prev.p;
@@ -1251,6 +1270,16 @@ int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *
     if ((rc = upload_i32(pl->level, level_plan, 1))) return bail(rc);
     if ((rc = upload_i32(pl->up_ptr, pl->topo.up_ptr, 1))) return bail(rc);
     if ((rc = upload_i32(pl->up_idx, pl->topo.up_idx, 1))) return bail(rc);
+    {
+        if (nseg >= (int64_t)1 << 30) return bail(fail(TRMC_EINVAL, "more than 2**30 segments in one plan"));
+        std::vector<int32_t> up2((size_t)pl->nseg_pad * 2, -1);
+        for (int64_t p = 0; p < nseg; ++p) {
+            const int32_t k0 = pl->topo.up_ptr[p], k1 = pl->topo.up_ptr[p + 1];
+            if (k1 - k0 >= 1) up2[2 * p] = pl->topo.up_idx[k0];
+            if (k1 - k0 >= 2) up2[2 * p + 1] = pl->topo.up_idx[k0 + 1] | (k1 - k0 > 2 ? 0x40000000 : 0);
+        }
+        if ((rc = upload_i32(pl->up2, up2, 2))) return bail(rc);
+    }
     if ((rc = upload_i32(pl->row_of_pos, pl->topo.row_of_pos, 1))) return bail(rc);
     if ((rc = upload_i32(pl->pos_of_row, pl->topo.pos_of_row, 1))) return bail(rc);
     if ((rc = pl->it_prev.ensure((size_t)pl->nseg_pad))) return bail(rc);
@@ -1263,7 +1292,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
