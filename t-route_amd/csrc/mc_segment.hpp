@@ -310,8 +310,9 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
 
     const T twl = p.bw + T(2) * c.z * h;
     const T a = (twl - p.bw) / T(2);
-    const T R = (h * (p.bw + twl) / T(2)) / (p.bw + T(2) * m.sqrt(a * a + h * h));
-    out.velc = (T(1) / p.n) * m.pow(R, T(2) / T(3)) * c.sqrt_s0;
+    const bool okv = m.fast_ok(h, h, T(0)); // (numerator in [2**-44, 2**52], denominator in [2**-14, 2**36]: see fast_ok)
+    const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), okv);
+    out.velc = m.div1(T(1), p.n, okv) * m.pow(R, T(2) / T(3)) * c.sqrt_s0;
     out.depthc = h;
     out.h = h;
     out.X = k.X;
