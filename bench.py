@@ -219,11 +219,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     use_dist = world > 1 or bool(os.environ.get("TRMC_FORCE_DIST"))   # the env var exercises the RCCL path at N=1
+    # TRMC_BENCH_BACKEND=gloo: a rehearsal of the multi-rank control flow on a box with ONE GPU -- every rank on device
+    # 0, the collectives through host memory.  Not a measurement.
+    backend = os.environ.get("TRMC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
@@ -252,7 +260,15 @@ def main():
 
     def all_gather_into(out, t):
         """out[world, *t.shape] <- every rank's t, over RCCL (xGMI), ordered against the current stream"""
-        dist.all_gather_into_tensor(out, t)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(out, t)
+        else:
+            import torch
+            torch.cuda.current_stream().synchronize()
+            mine = t.cpu()
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            out.copy_(torch.stack(parts).to(out.device))
 
     def make_router(hint):
         r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint)
@@ -307,7 +323,7 @@ def main():
         el = time.perf_counter() - t0
         if dist is not None:
             import torch
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            t = torch.tensor([el], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, float(np.mean(mains)), float(np.mean(totals)), launches, router.last_stats, hyd
