@@ -50,11 +50,11 @@ def subtree_sizes(to):
     return size
 
 
-def lpt_assign(sizes, nparts):
-    """Longest-processing-time bin packing: part index per item."""
+def lpt_assign(sizes, nparts, initial_load=None):
+    """Longest-processing-time bin packing: part index per item (`initial_load`: what the bins hold already)."""
     sizes = np.asarray(sizes, dtype=np.int64)
     part = np.zeros(sizes.shape[0], dtype=np.int32)
-    load = np.zeros(nparts, dtype=np.int64)
+    load = np.zeros(nparts, dtype=np.int64) if initial_load is None else np.asarray(initial_load, dtype=np.int64).copy()
     for i in np.argsort(-sizes, kind="stable").tolist():
         p = int(np.argmin(load))
         part[i] = p
@@ -72,6 +72,7 @@ def partition(to, nparts, max_piece_frac=None):
       cut_rows  int64 [ncut]     rows (outlets of phase-0 sub-basins) whose hydrograph is handed
                                  to the trunk they drain into
       cut_into  int64 [ncut]     trunk row each cut row flows into
+      owner_bias int64 [nparts]  rows of sub-basin a worker is spared for the trunks it owns (see below)
     With nparts == 1 everything is one phase-0 piece per independent network (no cuts).
     """
     nseg = to.shape[0]
@@ -111,13 +112,20 @@ def partition(to, nparts, max_piece_frac=None):
     npieces = phase.shape[0]
     sizes = np.bincount(piece, minlength=npieces)
     owner = np.zeros(npieces, dtype=np.int32)
-    p0 = np.flatnonzero(phase == 0)
-    owner[p0], load0 = lpt_assign(sizes[p0], nparts)
+    # trunks first; their owners then take fewer sub-basin rows.  What a trunk costs its owner, in rows of sub-basin it
+    # should be spared (fitted on ranks of an 8-, 4- and 2-way CONUS partition timed one by one): its own rows,
+    # deep in the network and among the costly ones, five times over, plus the launches that drain the time-skewed trunk
+    # at the end of a window (2 of the default 24 chunks; a partly filled GPU gains less than proportionally from
+    # having fewer rows, hence 2/15 of the rank's share rather than 1/12).
+    bias = np.zeros(nparts, dtype=np.int64)
     p1 = np.flatnonzero(phase == 1)
     if p1.size:
-        owner[p1], _ = lpt_assign(sizes[p1], nparts)
+        owner[p1], trunk_load = lpt_assign(sizes[p1], nparts)
+        bias = 5 * trunk_load + np.where(trunk_load > 0, 2 * nseg // (15 * nparts), 0)
+    p0 = np.flatnonzero(phase == 0)
+    owner[p0], load0 = lpt_assign(sizes[p0], nparts, bias)
     return {
         "piece": piece.astype(np.int32), "phase": phase, "owner": owner,
         "cut_rows": cut_rows, "cut_into": to[cut_rows] if cut_rows.size else np.zeros(0, np.int64),
-        "piece_sizes": sizes,
+        "piece_sizes": sizes, "owner_bias": bias,
     }

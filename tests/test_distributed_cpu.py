@@ -38,8 +38,10 @@ def test_partition_properties():
         if nparts == 1:
             assert part["cut_rows"].size == 0
         else:
-            load = np.bincount(owner[phase == 0], weights=sizes[phase == 0], minlength=nparts)
+            # sub-basin rows are balanced AFTER what a trunk costs its owner has been put on that worker's scale
+            load = np.bincount(owner[phase == 0], weights=sizes[phase == 0], minlength=nparts) + part["owner_bias"]
             assert load.max() <= 1.25 * load.mean() + 50
+            assert (part["owner_bias"] > 0).sum() == len(np.unique(owner[phase == 1]))
 
 
 def test_outlet_and_subtree_helpers():
