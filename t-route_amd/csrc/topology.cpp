@@ -3,11 +3,12 @@
 
 #include <algorithm>
 #include <limits>
+#include <utility>
 
 namespace trmc {
 
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
-                   const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint)
+                   const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -97,6 +98,107 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
     }
     t.nlevels = maxlevel + 1;
 
+    // upstream CSR over plan positions (boundary rows keep an empty list)
+    auto csr_in_plan_order = [&]() {
+        t.up_ptr.assign(nseg + 1, 0);
+        for (int64_t p = 0; p < nseg; ++p) {
+            const int32_t r = t.row_of_pos[p];
+            t.up_ptr[p + 1] = t.up_ptr[p] + (is_b(r) ? 0 : (int32_t)(up_ptr[r + 1] - up_ptr[r]));
+        }
+        t.up_idx.resize(t.up_ptr[nseg]);
+        for (int64_t p = 0; p < nseg; ++p) {
+            const int32_t r = t.row_of_pos[p];
+            if (is_b(r)) continue;
+            int32_t w = t.up_ptr[p];
+            for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) t.up_idx[w++] = t.pos_of_row[up_idx[k]];
+        }
+    };
+
+    if (block_rows > 0) {
+        // ---- block order of the dataflow engine (topology.hpp) ----------------------------------------------
+        t.block_rows = block_rows;
+        // rows draining through each row (itself included), in Kahn order: every upstream row is final before its
+        // downstream rows are visited.  (On a graph with bifurcations the count is an over-estimate: it only ranks.)
+        std::vector<int64_t> drain(nseg, 1);
+        for (const int32_t r : queue)
+            for (int32_t k = down_ptr[r]; k < down_ptr[r + 1]; ++k) drain[down_idx[k]] += drain[r];
+        std::vector<int32_t> outlets;
+        for (int64_t o = 0; o < nseg; ++o)
+            if (!is_b(o) && down_ptr[o + 1] == down_ptr[o]) outlets.push_back((int32_t)o);
+        std::stable_sort(outlets.begin(), outlets.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
+        std::vector<int32_t> post; // routed rows, every row after all rows draining into it
+        post.reserve(nrouted);
+        {
+            std::vector<uint8_t> seen(nseg, 0);
+            std::vector<int32_t> kids;               // scratch: routed upstream rows of the row being expanded
+            std::vector<std::pair<int32_t, int32_t>> stack; // (row, state): state 0 = expand, 1 = emit
+            for (const int32_t o : outlets) {
+                if (seen[o]) continue;
+                seen[o] = 1;
+                stack.emplace_back(o, 0);
+                while (!stack.empty()) {
+                    auto [r, st] = stack.back();
+                    stack.pop_back();
+                    if (st == 1) {
+                        post.push_back(r);
+                        continue;
+                    }
+                    stack.emplace_back(r, 1);
+                    kids.clear();
+                    for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) {
+                        const int32_t u = (int32_t)up_idx[k];
+                        if (!is_b(u) && !seen[u]) {
+                            seen[u] = 1;
+                            kids.push_back(u);
+                        }
+                    }
+                    // visited in ascending size (the largest tributary last, right before its junction): pushed in
+                    // descending order of visit
+                    std::stable_sort(kids.begin(), kids.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
+                    for (const int32_t u : kids) stack.emplace_back(u, 0);
+                }
+            }
+        }
+        if ((int64_t)post.size() != nrouted) { // cannot happen in a DAG
+            err = "internal: depth-first walk missed rows";
+            return -2;
+        }
+        t.pos_of_row.assign(nseg, -1);
+        t.row_of_pos.assign(nseg, -1);
+        for (int64_t b = 0; b < t.nboundary; ++b) {
+            t.pos_of_row[t.boundary_rows[b]] = (int32_t)b;
+            t.row_of_pos[b] = t.boundary_rows[b];
+        }
+        t.nblocks = (int32_t)((nrouted + block_rows - 1) / block_rows);
+        t.rank_of_pos.assign(nseg, 0);
+        std::vector<int32_t> idx;
+        std::vector<int64_t> key;
+        for (int32_t b = 0; b < t.nblocks; ++b) {
+            const int64_t i0 = (int64_t)b * block_rows, i1 = std::min<int64_t>(nrouted, i0 + block_rows);
+            const int32_t m = (int32_t)(i1 - i0);
+            idx.resize(m);
+            key.resize(m);
+            int32_t lo = std::numeric_limits<int32_t>::max();
+            for (int32_t i = 0; i < m; ++i) {
+                const int32_t r = post[i0 + i];
+                idx[i] = i;
+                key[i] = cost_hint ? (int64_t)cost_hint[r] : drain[r];
+                lo = std::min(lo, t.level_of_row[r]);
+            }
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t c) { return key[a] > key[c]; });
+            for (int32_t i = 0; i < m; ++i) {
+                const int32_t r = post[i0 + idx[i]];
+                const int32_t p = (int32_t)(t.nboundary + i0 + i);
+                t.pos_of_row[r] = p;
+                t.row_of_pos[p] = r;
+                t.rank_of_pos[p] = t.level_of_row[r] - lo;
+                t.maxrank = std::max(t.maxrank, t.rank_of_pos[p]);
+            }
+        }
+        csr_in_plan_order();
+        return 0;
+    }
+
     // depth-first rank from the outlets, walking upstream in the reference's order
     std::vector<int32_t> rank_order; // routed rows in preorder
     rank_order.reserve(nrouted);
@@ -179,19 +281,7 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
         }
     }
 
-    // upstream CSR over plan positions (boundary rows keep an empty list)
-    t.up_ptr.assign(nseg + 1, 0);
-    for (int64_t p = 0; p < nseg; ++p) {
-        const int32_t r = t.row_of_pos[p];
-        t.up_ptr[p + 1] = t.up_ptr[p] + (is_b(r) ? 0 : (int32_t)(up_ptr[r + 1] - up_ptr[r]));
-    }
-    t.up_idx.resize(t.up_ptr[nseg]);
-    for (int64_t p = 0; p < nseg; ++p) {
-        const int32_t r = t.row_of_pos[p];
-        if (is_b(r)) continue;
-        int32_t w = t.up_ptr[p];
-        for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) t.up_idx[w++] = t.pos_of_row[up_idx[k]];
-    }
+    csr_in_plan_order();
     return 0;
 }
 

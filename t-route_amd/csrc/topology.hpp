@@ -31,13 +31,29 @@ struct Topology {
     std::vector<int32_t> up_ptr;         // [nseg+1] CSR over plan positions
     std::vector<int32_t> up_idx;         // upstream plan positions, reference summation order
     std::vector<int32_t> boundary_rows;  // ascending rows flagged as boundary
+    // block order (build_topology with block_rows > 0), see below
+    int32_t block_rows = 0;              // 0: level-major order; else rows per block of the dataflow engine
+    int32_t nblocks = 0;                 // blocks of block_rows consecutive routed positions, from position nboundary
+    std::vector<int32_t> rank_of_pos;    // [nseg] level of the row minus the lowest level in its block (0 for boundary rows)
+    int32_t maxrank = 0;
 };
 
 // Returns 0 on success; -1 bad argument, -2 cycle.  `err` receives a message.
 // `cost_hint` (optional, [nseg]): rows of one level are grouped by descending hint (the secant iterations a row
 // needed last time: waves then hold rows of one cost, the costly blocks of a launch start first); it only
 // chooses among the orders that are valid anyway -- results do not depend on it.
+//
+// block_rows > 0 selects the BLOCK ORDER of the dataflow engine (k_mc_flow) instead of the level-major one: routed rows
+// in depth-first post-order from the outlets (largest basin first, the larger tributary of a junction last), so that
+// every row comes after all the rows draining into it and a run of consecutive positions is a handful of complete
+// sub-trees plus the chain they hang off.  The order is cut into blocks of block_rows positions -- one workgroup of the
+// engine each: a block only ever needs flows of its own rows and of EARLIER blocks -- and inside a block rows are
+// grouped by descending cost (the hint, or without one the number of rows draining through, which decides how wet a
+// channel is) so that a wavefront holds rows of one cost.  Reference analogue of the order: dfs_decomposition's
+// "every reach's upstream reaches precede it" (nhd_network.py:503-557); of the blocks: build_subnetworks
+// (nhd_network.py:691-771), here a few hundred rows instead of 10 000 and pipelined in time instead of by order.
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
-                   const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr);
+                   const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr,
+                   int32_t block_rows = 0);
 
 } // namespace trmc

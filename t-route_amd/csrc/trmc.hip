@@ -30,7 +30,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -686,45 +688,47 @@ k_emit(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restri
     }
 }
 
+// (`qs`: element stride of the flow plane -- 1 for the time-major planes of the level engine, 2 for the granule plane
+// of the dataflow engine, whose elements are {flow, tag} pairs; `d_tm` is then the depth-state column, d_row = 0)
 template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_final_state(const T *__restrict__ q_tm, const T *__restrict__ d_tm, const int32_t *__restrict__ row_of_pos,
-              T *__restrict__ q0_out, int32_t nseg, int64_t nseg_pad, int32_t nsteps)
+              T *__restrict__ q0_out, int32_t nseg, int64_t nseg_pad, int32_t nsteps, int32_t qs, int32_t d_row)
 {
     const int32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= nseg) return;
     const size_t src = (size_t)nsteps * nseg_pad + p;
     const size_t r = (size_t)row_of_pos[p] * 3;
-    const T q = q_tm[src];
+    const T q = q_tm[src * qs];
     q0_out[r + 0] = q;
     q0_out[r + 1] = q;
-    q0_out[r + 2] = d_tm[src];
+    q0_out[r + 2] = d_tm[(size_t)d_row * nseg_pad + p];
 }
 
 template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_gather_rows(const T *__restrict__ q_tm, const int32_t *__restrict__ pos, T *__restrict__ out, int64_t nrows,
-              int64_t nseg_pad, int32_t nsteps)
+              int64_t nseg_pad, int32_t nsteps, int32_t qs)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nrows * nsteps) return;
     const int64_t r = i / nsteps;
     const int32_t t = (int32_t)(i % nsteps) + 1;
-    out[i] = q_tm[(size_t)t * nseg_pad + pos[r]];
+    out[i] = q_tm[((size_t)t * nseg_pad + pos[r]) * qs];
 }
 
 // flows of selected positions over the steps (t_begin, t_end]: out[r * stride + (t - 1 - t_begin)]
 template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_gather_range(const T *__restrict__ q_tm, const int32_t *__restrict__ pos, T *__restrict__ out, int64_t nrows,
-               int64_t nseg_pad, int32_t t_begin, int32_t t_end, int64_t stride)
+               int64_t nseg_pad, int32_t t_begin, int32_t t_end, int64_t stride, int32_t qs)
 {
     const int32_t w = t_end - t_begin;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nrows * w) return;
     const int64_t r = i / w;
     const int32_t k = (int32_t)(i % w);
-    out[r * stride + k] = q_tm[(size_t)(t_begin + 1 + k) * nseg_pad + pos[r]];
+    out[r * stride + k] = q_tm[((size_t)(t_begin + 1 + k) * nseg_pad + pos[r]) * qs];
 }
 
 // boundary positions (the first nboundary of the plan order) <- q[b * stride + (t - 1 - t_begin)], t in (t_begin, t_end]
@@ -769,11 +773,295 @@ k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
     o[0] = r.qdc; o[1] = r.velc; o[2] = r.depthc; o[3] = ck; o[4] = cn; o[5] = r.X;
 }
 
+// ---------------------------------------------------------------- dataflow engine (fp32)
+// The level engine above makes a kernel boundary of every dependence: one launch per timestep (or per
+// wavefront diagonal), 12 parameter loads and 3 state loads per segment-step, and between launches the whole
+// device drains.  The dataflow engine keeps a row in ONE thread for a whole routing window instead:
+//   * rows are laid out in BLOCK ORDER (topology.hpp): depth-first post-order cut into blocks of kFlowBlock rows, rows
+//     of a block grouped by cost.  A block is a workgroup; it takes a ticket when it starts, so block k only ever
+//     needs flows of blocks <= k, all of which are running or done: no deadlock whatever the dispatch order;
+//   * a thread loads its row's parameters, constants and state ONCE, then steps through time in registers;
+//   * the only thing rows exchange is the flow they pass downstream.  Every row publishes it per step as an 8-byte
+//     GRANULE {flow bits, tag = tag_base + step} with one agent-scope store into gran[step][position]; a row reads its
+//     upstream rows' granules of the step it needs and, where the tag is not there yet, waits for it (relaxed
+//     agent-scope polls, MI355X_MICROARCH.md "handoff-1to1": a self-validating word needs no fence and no flag).
+//     A kernel boundary is never needed: producers run ahead of consumers, a consumer that catches up sleeps;
+//   * results go straight into the caller's layout out[row][step][q,v,d]: a thread stages 8 steps in LDS and writes
+//     them as one 96-byte run (whole 32-byte sectors) -- no time-major planes, no transposing pass.
+// Timestep modes: with assume_short_ts a row at step t needs its upstream rows at step t-1; without, also at step t
+// (mc_reach.pyx:499-505) -- then rows of one wavefront that feed each other cannot be at the same step, and every
+// row trails by its level rank inside the block (lane i works on step t0 + k - rank_i in round k).
+// HBM traffic per segment-step: 8 B granule + 12 B result written, <= 16 B of upstream granules read (L2), the
+// forcing every qts-th step -- against 64 B algorithmic; what bounds the engine is VALU issue.
+#ifndef TRMC_FLOW_BLOCK
+#define TRMC_FLOW_BLOCK 256
+#endif
+#ifndef TRMC_FLOW_WAVES // minimum waves per SIMD the register allocation must allow (workgroups per CU = this * 256 / block)
+#define TRMC_FLOW_WAVES 4
+#endif
+constexpr int kFlowBlock = TRMC_FLOW_BLOCK;
+constexpr int kFlowStage = 8; // steps staged per thread before they are written to `out`
+
+struct FlowArgs {
+    const float *dx, *bw, *twcc, *n, *ncc, *s0;
+    const float *z, *bfd, *sqrt_s0, *sq1pz2, *s0_n, *s0_ncc;
+    const float *dt_col;
+    float dt;
+    const int32_t *up_ptr, *up_idx;
+    const int2 *up2;
+    const int32_t *lag;            // short-timestep mode: steps a row trails by (trmc_plan_set_lag); general mode: its
+                                   // level rank inside the block; nullptr = none
+    const float *qlat_tm;
+    unsigned long long *gran;      // [nsteps + 1][nseg_pad] granules
+    float *d_state;                // [nseg_pad] depth at the last step each row has completed
+    float *out;                    // [nseg][nsteps][3]
+    const int32_t *row_of_pos;
+    uint8_t *it_prev;
+    uint16_t *it_sum;
+    bool sane, out_vec;            // out_vec: the 8-step runs of `out` are 16-byte aligned (nsteps % 4 == 0)
+    const int32_t *res_of_pos;
+    const float *res_par;
+    float *res_inflow;
+    float res_dt;
+    const int32_t *gage_of_pos;
+    const uint8_t *da_mode;
+    const float *da_a, *da_w;
+    float *da_nudge;
+    int64_t nseg_pad;
+    int32_t nsteps, qts, nseg, first; // first: position of the first routed row (= number of boundary rows)
+    uint32_t tag_base;
+    int32_t *ticket;               // [0] block tickets of this launch, [1] abort flag of the window
+    uint64_t watchdog_ticks;       // wall_clock64 ticks (100 MHz) a row may wait for one granule
+};
+
+__device__ __forceinline__ unsigned long long gran_load(const unsigned long long *g)
+{
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// flow of position `u` at the step whose tag is `want`; waits until it has been published
+__device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t want, const FlowArgs &a, bool &dead)
+{
+    unsigned long long v = gran_load(g);
+    if ((uint32_t)(v >> 32) != want) {
+        const uint64_t t_start = wall_clock64();
+        for (;;) {
+            __builtin_amdgcn_s_sleep(4);
+            v = gran_load(g);
+            if ((uint32_t)(v >> 32) == want) break;
+            if (wall_clock64() - t_start > a.watchdog_ticks
+                || __hip_atomic_load(a.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(a.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                break;
+            }
+        }
+    }
+    return __uint_as_float((uint32_t)v);
+}
+
+template <bool SHORT>
+__global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES)
+k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the launches / steps (t0, t1] of the window
+{
+    using M = DevMathF;
+    __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    __shared__ float s_out[3 * kFlowStage * kFlowBlock]; // [step slot * 3 + c][thread]
+    __shared__ int32_t s_blk;
+    if (threadIdx.x == 0) s_blk = atomicAdd(a.ticket, 1);
+    M m{stage_pow_tables(s_tab), false}; // (its barrier also publishes s_blk)
+    m.sane = a.sane;
+
+    const int32_t pos = a.first + s_blk * kFlowBlock + (int32_t)threadIdx.x;
+    const bool valid = pos < a.nseg;
+    const uint32_t su = valid ? (uint32_t)pos : (uint32_t)a.first;
+    const uint32_t ob = su * 4u;
+    const int32_t lag = a.lag ? a.lag[su] : 0;
+    // the steps [t_lo, t_hi] this row covers in this launch, and the round it starts in
+    const int32_t t_lo = SHORT ? max(t0 - lag, 0) + 1 : t0 + 1;
+    const int32_t t_hi = valid ? (SHORT ? min(t1 - lag, a.nsteps) : min(t1, a.nsteps)) : 0;
+    const int32_t delay = SHORT ? 0 : lag;
+
+    trmc::ChannelParams<float> p;
+    p.dt = a.dt_col ? at(a.dt_col, ob) : a.dt;
+    p.dx = at(a.dx, ob);
+    p.bw = at(a.bw, ob);
+    p.twcc = at(a.twcc, ob);
+    p.n = at(a.n, ob);
+    p.ncc = at(a.ncc, ob);
+    p.s0 = at(a.s0, ob);
+    p.tw = p.cs = 0.0f; // only enter the constants below
+    trmc::ChannelConst<float> c;
+    c.z = at(a.z, ob);
+    c.bfd = at(a.bfd, ob);
+    c.sqrt_s0 = at(a.sqrt_s0, ob);
+    c.sq1pz2 = at(a.sq1pz2, ob);
+    c.s0_n = at(a.s0_n, ob);
+    c.s0_ncc = at(a.s0_ncc, ob);
+    c.two_sq = 2.0f * c.sq1pz2;
+    c.half_dt = p.dt / 2.0f;
+    c.fp_ok = (p.twcc > 0.0f) && (p.ncc > 0.0f);
+    const int2 up = a.up2[su];
+    const int32_t ri = a.res_of_pos ? a.res_of_pos[su] : -1;
+    const int32_t gi = a.gage_of_pos ? a.gage_of_pos[su] : -1;
+    const size_t np = (size_t)a.nseg_pad;
+    float *const out_row = a.out + (size_t)a.row_of_pos[su] * (size_t)a.nsteps * 3;
+
+    float q_prev = 0.0f, d_prev = 0.0f, ql = 0.0f;
+    int32_t ql_col = -1, staged = 0, it_acc = 0, it_last = 0;
+    bool have_state = false, dead = false;
+
+    for (int32_t k = 0;; ++k) {
+        const int32_t t = t_lo + k - delay;
+        if (!__any(t <= t_hi) || __any(dead)) break;
+        if (t < t_lo || t > t_hi) continue;
+        const uint32_t tag_p = a.tag_base + (uint32_t)(t - 1);
+        const unsigned long long *g_prev = a.gran + (size_t)(t - 1) * np;
+        unsigned long long *g_curr = a.gran + (size_t)t * np;
+        if (!have_state) { // the state this row was left in: its own granule of step t - 1, its depth column
+            q_prev = flow_wait(g_prev + su, tag_p, a, dead);
+            d_prev = a.d_state[su];
+            have_state = true;
+        }
+        const int32_t col = (t - 1) / a.qts;
+        if (col != ql_col) {
+            ql = a.qlat_tm[(size_t)col * np + su];
+            ql_col = col;
+        }
+        // junction sums in the reference's order (mc_reach.pyx:499-502)
+        float qup = 0.0f, quc = 0.0f;
+        if (up.x >= 0) {
+            qup += flow_wait(g_prev + up.x, tag_p, a, dead);
+            if (!SHORT) quc += flow_wait(g_curr + up.x, tag_p + 1u, a, dead);
+        }
+        if (up.y >= 0) {
+            const int32_t u1 = up.y & 0x3fffffff;
+            qup += flow_wait(g_prev + u1, tag_p, a, dead);
+            if (!SHORT) quc += flow_wait(g_curr + u1, tag_p + 1u, a, dead);
+            if (up.y & 0x40000000) {
+                const int32_t k1 = a.up_ptr[su + 1];
+                for (int32_t e = a.up_ptr[su] + 2; e < k1; ++e) {
+                    const int32_t ue = a.up_idx[e];
+                    qup += flow_wait(g_prev + ue, tag_p, a, dead);
+                    if (!SHORT) quc += flow_wait(g_curr + ue, tag_p + 1u, a, dead);
+                }
+            }
+        }
+        trmc::Inflow<float> f;
+        f.qup = qup;
+        f.quc = SHORT ? qup : quc;
+        f.qdp = q_prev;
+        f.ql = ql;
+
+        float q_new, v_new, d_new;
+        if (ri >= 0) { // level-pool reservoir row, mc_reach.pyx:507-510,:551-553,:706-710 (see k_mc_step)
+            const float *rp = a.res_par + (size_t)ri * 9;
+            const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
+            float H = d_prev;
+            q_new = trmc::levelpool_step<float, M>(f.quc, 0.0f, a.res_dt, H, lp, m);
+            v_new = 0.0f;
+            d_new = H;
+            a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
+            it_last = 0;
+        } else {
+            m.coef_ok = coef_guard(p.dt, f.ql);
+            const trmc::StepResult<float> r = trmc::mc_segment_step<float, M>(p, c, f, d_prev, m);
+            q_new = r.qdc;
+            v_new = r.velc;
+            d_new = r.depthc;
+            it_last = min(r.iters, 255);
+            it_acc += min(r.iters, 3);
+            if (gi >= 0) { // streamflow nudging, mc_reach.pyx:761-796 / simple_da.pyx:47-76 (see k_mc_step)
+                const size_t e = (size_t)gi * (size_t)a.nsteps + (size_t)(t - 1);
+                const uint8_t mode = a.da_mode[e];
+                float nudge = 0.0f;
+                if (mode == 1) {
+                    nudge = a.da_a[e] - q_new;
+                    q_new = a.da_a[e];
+                } else if (mode == 2) {
+                    nudge = (a.da_a[e] - q_new) * a.da_w[e];
+                    q_new = q_new + nudge;
+                }
+                a.da_nudge[e] = nudge;
+            }
+        }
+        // publish the flow: one 8-byte agent-scope store, tag in the high word
+        __hip_atomic_store(g_curr + su, ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(q_new),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q_prev = q_new;
+        d_prev = d_new;
+        // stage (q, v, d) of step t; a run ends at every 8th step of the window and at the last step of the launch
+        {
+            const int32_t slot = (t - 1) & (kFlowStage - 1);
+            float *so = s_out + (size_t)(slot * 3) * kFlowBlock + threadIdx.x;
+            so[0] = q_new;
+            so[kFlowBlock] = v_new;
+            so[2 * kFlowBlock] = d_new;
+            ++staged;
+            if (slot == kFlowStage - 1 || t == t_hi) {
+                const int32_t s_first = slot + 1 - staged; // first staged slot
+                float *dst = out_row + (size_t)(t - staged) * 3;
+                const float *si = s_out + (size_t)(s_first * 3) * kFlowBlock + threadIdx.x;
+                if (staged == kFlowStage && a.out_vec) {
+#pragma unroll
+                    for (int j = 0; j < 3 * kFlowStage / 4; ++j) {
+                        float4 v;
+                        v.x = si[(4 * j + 0) * kFlowBlock];
+                        v.y = si[(4 * j + 1) * kFlowBlock];
+                        v.z = si[(4 * j + 2) * kFlowBlock];
+                        v.w = si[(4 * j + 3) * kFlowBlock];
+                        reinterpret_cast<float4 *>(dst)[j] = v;
+                    }
+                } else {
+                    for (int32_t e = 0; e < 3 * staged; ++e) dst[e] = si[e * kFlowBlock];
+                }
+                staged = 0;
+            }
+        }
+    }
+    if (valid && have_state) {
+        a.d_state[su] = d_prev;
+        if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)it_last;
+        if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + it_acc);
+    }
+}
+
+// initial state of the dataflow engine: granule row 0 <- qu0 (mc_reach.pyx:361), depth column <- h0
+__global__ void __launch_bounds__(kBlock)
+k_flow_init(const float *__restrict__ q0, const int32_t *__restrict__ row_of_pos, unsigned long long *gran, float *d_state,
+            int32_t nseg, uint32_t tag_base)
+{
+    const int32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= nseg) return;
+    const size_t r = (size_t)row_of_pos[p] * 3;
+    gran[p] = ((unsigned long long)tag_base << 32) | (unsigned long long)__float_as_uint(q0[r + 0]);
+    d_state[p] = q0[r + 2];
+}
+// boundary rows of the dataflow engine: hydrographs -> granules of the steps (t_begin, t_end] and the rows' result.
+// src[b * stride_b + (t - 1 - t_begin) * stride_t + c]: bfvd[b][t-1][c] (stride_t = 3, ncomp = 3) or a flow block
+// [b][t - 1 - t_begin] (stride_t = 1, ncomp = 1: velocity and depth of a boundary row are not inputs of anything, 0)
+__global__ void __launch_bounds__(kBlock)
+k_flow_boundary(const float *__restrict__ src, unsigned long long *gran, float *__restrict__ out,
+                const int32_t *__restrict__ row_of_pos, int32_t nboundary, int32_t nsteps, int64_t nseg_pad, int32_t t_begin,
+                int32_t t_end, int64_t stride_b, int32_t stride_t, int32_t ncomp, uint32_t tag_base)
+{
+    const int32_t w = t_end - t_begin;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)nboundary * w) return;
+    const int32_t b = (int32_t)(i / w), k = (int32_t)(i % w), t = t_begin + 1 + k;
+    const float *v = src + (size_t)b * stride_b + (size_t)k * stride_t;
+    const float q = v[0];
+    gran[(size_t)t * nseg_pad + b] = ((unsigned long long)(tag_base + (uint32_t)t) << 32) | (unsigned long long)__float_as_uint(q);
+    float *o = out + ((size_t)row_of_pos[b] * nsteps + (t - 1)) * 3;
+    o[0] = q;
+    o[1] = ncomp > 1 ? v[1] : 0.0f;
+    o[2] = ncomp > 2 ? v[2] : 0.0f;
+}
+
 // ---------------------------------------------------------------- plan
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    int ensure(size_t need)
+    int ensure(size_t need, bool zero_new = false)
     {
         if (need <= bytes) return 0;
         if (p) (void)hipFree(p);
@@ -782,6 +1070,10 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, need ? need : 1);
         if (e != hipSuccess) return fail(TRMC_ENOMEM, std::string("hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
         bytes = need;
+        if (zero_new && need) { // (granule planes: recycled memory must not hold a tag that could pass for a live one)
+            e = hipMemset(p, 0, need);
+            if (e != hipSuccess) return fail(TRMC_EHIP, std::string("hipMemset: ") + hipGetErrorString(e));
+        }
         return 0;
     }
     void release()
@@ -840,6 +1132,12 @@ struct trmc_plan {
     bool have_boundary = true;  // boundary hydrographs present for the staged window
     int32_t staged_nsteps = -1; // nsteps the staged forcing was uploaded for
     int32_t routed_nsteps = -1; // nsteps of the last completed route
+    // dataflow engine (k_mc_flow): the plan is in block order, `tm` holds the granule plane
+    bool flow = false;
+    uint32_t tag_base = 1;               // tag of step 0 of the current window (0 is never a live tag)
+    int32_t tag_span = 0;                // tags the current window may use (nsteps + 1)
+    DevBuf d_state, ticket, rank;        // depth column; {block ticket, abort flag}; level rank of a position inside its block
+    uint64_t watchdog_ticks = 300000000; // 3 s of wall_clock64 (100 MHz)
     trmc_stats stats{};
     RouteRun run;
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
@@ -1134,6 +1432,170 @@ template <class T> int route_end_t(trmc_plan *pl)
     return 0;
 }
 
+// ---- dataflow engine, host side (fp32 plans in block order) ------------------------------------------------------
+FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
+{
+    FlowArgs a;
+    a.dt_col = pl->dt_uniform ? nullptr : col<float>(pl, TRMC_P_DT);
+    a.dt = (float)pl->dt;
+    a.dx = col<float>(pl, TRMC_P_DX);
+    a.bw = col<float>(pl, TRMC_P_BW);
+    a.twcc = col<float>(pl, TRMC_P_TWCC);
+    a.n = col<float>(pl, TRMC_P_N);
+    a.ncc = col<float>(pl, TRMC_P_NCC);
+    a.s0 = col<float>(pl, TRMC_P_S0);
+    a.z = col<float>(pl, TRMC_NPARAM + 0);
+    a.bfd = col<float>(pl, TRMC_NPARAM + 1);
+    a.sqrt_s0 = col<float>(pl, TRMC_NPARAM + 2);
+    a.sq1pz2 = col<float>(pl, TRMC_NPARAM + 3);
+    a.s0_n = col<float>(pl, TRMC_NPARAM + 4);
+    a.s0_ncc = col<float>(pl, TRMC_NPARAM + 5);
+    a.up_ptr = (const int32_t *)pl->up_ptr.p;
+    a.up_idx = (const int32_t *)pl->up_idx.p;
+    a.up2 = (const int2 *)pl->up2.p;
+    // short-timestep mode: the skew of trmc_plan_set_lag; general mode: the level rank inside the block
+    a.lag = short_ts ? (pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr)
+                     : (pl->topo.maxrank > 0 ? (const int32_t *)pl->rank.p : nullptr);
+    a.qlat_tm = (const float *)pl->qlat_tm.p;
+    a.gran = (unsigned long long *)pl->tm.p;
+    a.d_state = (float *)pl->d_state.p;
+    a.out = (float *)pl->out.p;
+    a.row_of_pos = (const int32_t *)pl->row_of_pos.p;
+    a.it_prev = (uint8_t *)pl->it_prev.p;
+    a.it_sum = pl->collect_cost ? (uint16_t *)pl->it_sum.p : nullptr;
+    a.sane = pl->params_sane;
+    a.out_vec = nsteps % 4 == 0;
+    a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
+    a.res_par = (const float *)pl->res_par.p;
+    a.res_inflow = (float *)pl->res_inflow.p;
+    a.res_dt = (float)pl->res_dt;
+    const bool da = pl->ngage > 0;
+    a.gage_of_pos = da ? (const int32_t *)pl->gage_of_pos.p : nullptr;
+    a.da_mode = (const uint8_t *)pl->da_mode.p;
+    a.da_a = (const float *)pl->da_a.p;
+    a.da_w = (const float *)pl->da_w.p;
+    a.da_nudge = (float *)pl->da_nudge.p;
+    a.nseg_pad = pl->nseg_pad;
+    a.nsteps = nsteps;
+    a.qts = qts;
+    a.nseg = (int32_t)pl->nseg;
+    a.first = (int32_t)pl->topo.nboundary;
+    a.tag_base = pl->tag_base;
+    a.ticket = (int32_t *)pl->ticket.p;
+    a.watchdog_ticks = pl->watchdog_ticks;
+    return a;
+}
+
+int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
+{
+    const trmc::Topology &tp = pl->topo;
+    const int32_t n = (int32_t)pl->nseg;
+    const int64_t np = pl->nseg_pad;
+    hipStream_t st = pl->stream;
+    if (int rc = pl->tm.ensure((size_t)(nsteps + 1) * np * sizeof(unsigned long long), true)) return rc;
+    if (int rc = pl->d_state.ensure((size_t)np * sizeof(float))) return rc;
+    if (int rc = pl->ticket.ensure(2 * sizeof(int32_t))) return rc;
+    if (int rc = pl->qlat_tm.ensure((size_t)pl->nq * np * sizeof(float))) return rc;
+    if (int rc = pl->out.ensure((size_t)pl->nseg * nsteps * 3 * sizeof(float))) return rc;
+    if (pl->nres > 0)
+        if (int rc = pl->res_inflow.ensure((size_t)pl->nres * nsteps * sizeof(float))) return rc;
+    if (pl->collect_cost) {
+        if (int rc = pl->it_sum.ensure((size_t)np * sizeof(uint16_t))) return rc;
+        pl->cost_nsteps = nsteps;
+    }
+    // a fresh range of tags for this window: nothing an earlier window left in the plane can pass for a live granule
+    if ((uint64_t)pl->tag_base + (uint64_t)pl->tag_span + (uint64_t)nsteps + 2 >= 0xffffffffull) {
+        HIP_TRY(hipMemsetAsync(pl->tm.p, 0, pl->tm.bytes, st));
+        pl->tag_base = 1;
+        pl->tag_span = 0;
+    }
+    pl->tag_base += (uint32_t)pl->tag_span;
+    pl->tag_span = nsteps + 1;
+    const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
+    HIP_TRY(hipEventRecord(pl->ev[0], st));
+    HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st));
+    HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, 2 * sizeof(int32_t), st));
+    if (pl->collect_cost) HIP_TRY(hipMemsetAsync(pl->it_sum.p, 0, (size_t)np * sizeof(uint16_t), st));
+    if (n > 0) {
+        if (!pl->qlat_direct)
+            hipLaunchKernelGGL((k_prep_qlat<float>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
+                               (const float *)pl->in_qlat.p, row_of_pos, (float *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);
+        hipLaunchKernelGGL(k_flow_init, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const float *)pl->in_q0.p, row_of_pos,
+                           (unsigned long long *)pl->tm.p, (float *)pl->d_state.p, n, pl->tag_base);
+    }
+    RouteRun &r = pl->run;
+    r = RouteRun{};
+    r.active = true;
+    r.nsteps = nsteps;
+    r.qts = qts;
+    r.short_ts = short_ts ? 1 : 0;
+    r.boundary_through = tp.nboundary > 0 ? 0 : nsteps;
+    if (tp.nboundary > 0 && pl->have_boundary) {
+        hipLaunchKernelGGL(k_flow_boundary, dim3(blocks_for(tp.nboundary * (int64_t)nsteps)), dim3(kBlock), 0, st,
+                           (const float *)pl->in_bfvd.p, (unsigned long long *)pl->tm.p, (float *)pl->out.p, row_of_pos,
+                           (int32_t)tp.nboundary, nsteps, np, 0, nsteps, (int64_t)nsteps * 3, 3, 3, pl->tag_base);
+        r.boundary_through = nsteps;
+    }
+    HIP_TRY(hipEventRecord(pl->ev[1], st));
+    HIP_TRY(hipGetLastError());
+    pl->routed_nsteps = -1;
+    return 0;
+}
+
+// one launch routes every row through the launches / steps (t_done, t_end]
+int flow_route_advance(trmc_plan *pl, int t_end)
+{
+    RouteRun &r = pl->run;
+    hipStream_t st = pl->stream;
+    if (pl->nrouted > 0 && t_end > r.t_done) {
+        const FlowArgs a = flow_args(pl, r.nsteps, r.qts, r.short_ts != 0);
+        HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, sizeof(int32_t), st)); // block tickets restart; the abort flag stays
+        const dim3 grid((unsigned)pl->topo.nblocks), block(kFlowBlock);
+        if (r.short_ts)
+            hipLaunchKernelGGL((k_mc_flow<true>), grid, block, 0, st, a, r.t_done, t_end);
+        else
+            hipLaunchKernelGGL((k_mc_flow<false>), grid, block, 0, st, a, r.t_done, t_end);
+        ++r.launches;
+    }
+    HIP_TRY(hipGetLastError());
+    r.t_done = t_end;
+    return 0;
+}
+
+int flow_route_end(trmc_plan *pl)
+{
+    RouteRun &r = pl->run;
+    hipStream_t st = pl->stream;
+    HIP_TRY(hipEventRecord(pl->ev[2], st));
+    HIP_TRY(hipEventRecord(pl->ev[3], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int32_t flags[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flags, pl->ticket.p, sizeof flags, hipMemcpyDeviceToHost));
+    if (flags[1] != 0) {
+        r.active = false;
+        return fail(TRMC_EHIP, "dataflow engine: a row waited longer than the watchdog allows for an upstream flow "
+                               "(boundary hydrographs missing for the steps routed, or an internal error); window abandoned");
+    }
+    float ms01 = 0, ms12 = 0;
+    HIP_TRY(hipEventElapsedTime(&ms01, pl->ev[0], pl->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms12, pl->ev[1], pl->ev[2]));
+    trmc_stats &s = pl->stats;
+    s.nseg = pl->nseg;
+    s.nseg_routed = pl->nrouted;
+    s.nlevels = pl->topo.nlevels;
+    s.nsteps = r.nsteps;
+    s.assume_short_ts = r.short_ts;
+    s.main_launches = r.launches;
+    s.segment_steps = pl->nrouted * (int64_t)r.nsteps;
+    s.ms_prep = ms01;
+    s.ms_main = ms12;
+    s.ms_emit = 0.0; // results are written in the caller's layout by the routing kernel itself
+    s.ms_total = (double)ms01 + ms12;
+    pl->routed_nsteps = r.nsteps;
+    r.active = false;
+    return 0;
+}
+
 template <class T> int segments_t(int64_t n, const void *in, void *out)
 {
     DevBuf din, dout;
@@ -1225,8 +1687,19 @@ int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *
 
     trmc_plan *pl = new (std::nothrow) trmc_plan();
     if (!pl) return fail(TRMC_ENOMEM, "out of host memory");
+    // engine: fp32 plans run on the dataflow engine (block order) unless TRMC_ENGINE=levels asks for the level engine
+    // (kept for A/B measurements and as the only engine of fp64 plans)
+    {
+        const char *e = std::getenv("TRMC_ENGINE");
+        pl->flow = precision == 32 && !(e && std::strcmp(e, "levels") == 0);
+        if (e && std::strcmp(e, "levels") != 0 && std::strcmp(e, "flow") != 0) {
+            delete pl;
+            return fail(TRMC_EINVAL, "TRMC_ENGINE must be 'flow' or 'levels'");
+        }
+        if (const char *w = std::getenv("TRMC_FLOW_WATCHDOG_MS")) pl->watchdog_ticks = (uint64_t)std::max(1L, std::atol(w)) * 100000ull;
+    }
     std::string err;
-    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint);
+    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
@@ -1280,6 +1753,7 @@ int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *
         }
         if ((rc = upload_i32(pl->up2, up2, 2))) return bail(rc);
     }
+    if (pl->flow && (rc = upload_i32(pl->rank, pl->topo.rank_of_pos, 1))) return bail(rc);
     if ((rc = upload_i32(pl->row_of_pos, pl->topo.row_of_pos, 1))) return bail(rc);
     if ((rc = upload_i32(pl->pos_of_row, pl->topo.pos_of_row, 1))) return bail(rc);
     if ((rc = pl->it_prev.ensure((size_t)pl->nseg_pad))) return bail(rc);
@@ -1292,7 +1766,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
@@ -1328,6 +1802,28 @@ int trmc_plan_levels(const trmc_plan *pl, int32_t *level_of_row, int64_t *plan_p
     return 0;
 }
 
+// (q_T, q_T, depth_T) of the last routed window, row order, into device memory `dst` [nseg][3]; queued on the plan stream
+static int final_state_into(trmc_plan *pl, void *dst)
+{
+    const int32_t n = (int32_t)pl->nseg, T_ = pl->routed_nsteps;
+    const size_t plane = (size_t)(T_ + 1) * pl->nseg_pad;
+    const int32_t *rop = (const int32_t *)pl->row_of_pos.p;
+    if (pl->flow) {
+        hipLaunchKernelGGL((k_final_state<float>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, (const float *)pl->tm.p,
+                           (const float *)pl->d_state.p, rop, (float *)dst, n, pl->nseg_pad, T_, 2, 0);
+    } else if (pl->precision == 32) {
+        const float *q = (const float *)pl->tm.p;
+        hipLaunchKernelGGL((k_final_state<float>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane, rop,
+                           (float *)dst, n, pl->nseg_pad, T_, 1, T_);
+    } else {
+        const double *q = (const double *)pl->tm.p;
+        hipLaunchKernelGGL((k_final_state<double>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane, rop,
+                           (double *)dst, n, pl->nseg_pad, T_, 1, T_);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // initial state (or warm start), boundary hydrographs, and the bookkeeping common to every forcing upload
 static int stage_state(trmc_plan *pl, int nsteps, int64_t nq, const void *q0, const void *boundary_fvd)
 {
@@ -1337,18 +1833,7 @@ static int stage_state(trmc_plan *pl, int nsteps, int64_t nq, const void *q0, co
         if (q0) {
             HIP_TRY(hipMemcpyAsync(pl->in_q0.p, q0, (size_t)pl->nseg * 3 * e, hipMemcpyHostToDevice, pl->stream));
         } else { // warm start in HBM: (q_T, q_T, depth_T) of the previous window, AbstractNetwork.py:182-190
-            const int32_t n = (int32_t)pl->nseg, T_ = pl->routed_nsteps;
-            const size_t plane = (size_t)(T_ + 1) * pl->nseg_pad;
-            if (pl->precision == 32) {
-                const float *q = (const float *)pl->tm.p;
-                hipLaunchKernelGGL((k_final_state<float>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
-                                   (const int32_t *)pl->row_of_pos.p, (float *)pl->in_q0.p, n, pl->nseg_pad, T_);
-            } else {
-                const double *q = (const double *)pl->tm.p;
-                hipLaunchKernelGGL((k_final_state<double>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
-                                   (const int32_t *)pl->row_of_pos.p, (double *)pl->in_q0.p, n, pl->nseg_pad, T_);
-            }
-            HIP_TRY(hipGetLastError());
+            if (int rc = final_state_into(pl, pl->in_q0.p)) return rc;
         }
     }
     if (pl->topo.nboundary > 0 && boundary_fvd) {
@@ -1574,11 +2059,18 @@ int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assum
     if (int rc = route_check(pl, nsteps, qts_subdivisions, false)) return rc;
     if (int rc = lag_check(pl, assume_short_ts)) return rc;
     const bool f = pl->precision == 32;
-    int rc = f ? route_begin_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
-               : route_begin_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
     const int t_last = nsteps + (assume_short_ts ? pl->maxlag : 0);
-    if (!rc) rc = f ? route_advance_t<float>(pl, t_last) : route_advance_t<double>(pl, t_last);
-    if (!rc) rc = f ? route_end_t<float>(pl) : route_end_t<double>(pl);
+    int rc;
+    if (pl->flow) {
+        rc = flow_route_begin(pl, nsteps, qts_subdivisions, assume_short_ts);
+        if (!rc) rc = flow_route_advance(pl, t_last);
+        if (!rc) rc = flow_route_end(pl);
+    } else {
+        rc = f ? route_begin_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
+               : route_begin_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
+        if (!rc) rc = f ? route_advance_t<float>(pl, t_last) : route_advance_t<double>(pl, t_last);
+        if (!rc) rc = f ? route_end_t<float>(pl) : route_end_t<double>(pl);
+    }
     if (rc) pl->run.active = false;
     return rc;
 }
@@ -1587,8 +2079,9 @@ int trmc_route_begin(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume
 {
     if (int rc = route_check(pl, nsteps, qts_subdivisions, true)) return rc;
     if (int rc = lag_check(pl, assume_short_ts)) return rc;
-    const int rc = pl->precision == 32 ? route_begin_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
-                                       : route_begin_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
+    const int rc = pl->flow ? flow_route_begin(pl, nsteps, qts_subdivisions, assume_short_ts)
+                   : pl->precision == 32 ? route_begin_t<float>(pl, nsteps, qts_subdivisions, assume_short_ts)
+                                         : route_begin_t<double>(pl, nsteps, qts_subdivisions, assume_short_ts);
     if (rc) pl->run.active = false;
     return rc;
 }
@@ -1607,6 +2100,7 @@ int trmc_route_advance(trmc_plan *pl, int t_end)
                                      + " only (trmc_set_boundary_flow_range)");
     if (t_end == pl->run.t_done) return 0;
     if (int rc = use_device(pl)) return rc;
+    if (pl->flow) return flow_route_advance(pl, t_end);
     return pl->precision == 32 ? route_advance_t<float>(pl, t_end) : route_advance_t<double>(pl, t_end);
 }
 
@@ -1622,7 +2116,7 @@ int trmc_route_end(trmc_plan *pl)
         return fail(TRMC_ESTATE, "trmc_route_end before every timestep was queued; window abandoned");
     }
     if (int rc = use_device(pl)) return rc;
-    const int rc = pl->precision == 32 ? route_end_t<float>(pl) : route_end_t<double>(pl);
+    const int rc = pl->flow ? flow_route_end(pl) : pl->precision == 32 ? route_end_t<float>(pl) : route_end_t<double>(pl);
     if (rc) pl->run.active = false;
     return rc;
 }
@@ -1708,10 +2202,11 @@ int trmc_gather_flow_range(trmc_plan *pl, int32_t rowset, int t_begin, int t_end
     const int64_t work = nrows * (t_end - t_begin);
     if (pl->precision == 32)
         hipLaunchKernelGGL((k_gather_range<float>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const float *)pl->tm.p,
-                           (const int32_t *)pl->rowsets[rowset].p, (float *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride);
+                           (const int32_t *)pl->rowsets[rowset].p, (float *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride,
+                           pl->flow ? 2 : 1);
     else
         hipLaunchKernelGGL((k_gather_range<double>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const double *)pl->tm.p,
-                           (const int32_t *)pl->rowsets[rowset].p, (double *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride);
+                           (const int32_t *)pl->rowsets[rowset].p, (double *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1735,7 +2230,11 @@ int trmc_set_boundary_flow_range(trmc_plan *pl, int t_begin, int t_end, const vo
     const size_t plane = (size_t)(r.nsteps + 1) * pl->nseg_pad;
     const int64_t work = nb * (t_end - t_begin);
     hipStream_t st = stream ? (hipStream_t)stream : pl->stream;
-    if (pl->precision == 32) {
+    if (pl->flow) {
+        hipLaunchKernelGGL(k_flow_boundary, dim3(blocks_for(work)), dim3(kBlock), 0, st, (const float *)q_dev,
+                           (unsigned long long *)pl->tm.p, (float *)pl->out.p, (const int32_t *)pl->row_of_pos.p, (int32_t)nb,
+                           r.nsteps, pl->nseg_pad, t_begin, t_end, src_stride, 1, 1, pl->tag_base);
+    } else if (pl->precision == 32) {
         float *q = (float *)pl->tm.p;
         hipLaunchKernelGGL((k_fill_boundary_range<float>), dim3(blocks_for(work)), dim3(kBlock), 0, st, (const float *)q_dev,
                            q, q + plane, q + 2 * plane, (int32_t)nb, pl->nseg_pad, t_begin, t_end, src_stride);
@@ -1802,18 +2301,7 @@ int trmc_download_final_state(trmc_plan *pl, void *q0_out)
     if (int rc = use_device(pl)) return rc;
     const size_t bytes = (size_t)pl->nseg * 3 * pl->esz;
     if (int rc = pl->scratch.ensure(bytes)) return rc;
-    const int32_t n = (int32_t)pl->nseg, T_ = pl->routed_nsteps;
-    const size_t plane = (size_t)(T_ + 1) * pl->nseg_pad;
-    if (pl->precision == 32) {
-        const float *q = (const float *)pl->tm.p;
-        hipLaunchKernelGGL((k_final_state<float>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
-                           (const int32_t *)pl->row_of_pos.p, (float *)pl->scratch.p, n, pl->nseg_pad, T_);
-    } else {
-        const double *q = (const double *)pl->tm.p;
-        hipLaunchKernelGGL((k_final_state<double>), dim3(blocks_for(n)), dim3(kBlock), 0, pl->stream, q, q + 2 * plane,
-                           (const int32_t *)pl->row_of_pos.p, (double *)pl->scratch.p, n, pl->nseg_pad, T_);
-    }
-    HIP_TRY(hipGetLastError());
+    if (int rc = final_state_into(pl, pl->scratch.p)) return rc;
     HIP_TRY(hipMemcpyAsync(q0_out, pl->scratch.p, bytes, hipMemcpyDeviceToHost, pl->stream));
     HIP_TRY(hipStreamSynchronize(pl->stream));
     return 0;
@@ -1844,10 +2332,11 @@ int trmc_gather_flow_rows(trmc_plan *pl, const int64_t *rows, int64_t nrows, voi
     void *dst = dst_is_device ? out : (void *)((char *)pl->scratch.p + pbytes);
     if (pl->precision == 32)
         hipLaunchKernelGGL((k_gather_rows<float>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream,
-                           (const float *)pl->tm.p, (const int32_t *)pl->scratch.p, (float *)dst, nrows, pl->nseg_pad, T_);
+                           (const float *)pl->tm.p, (const int32_t *)pl->scratch.p, (float *)dst, nrows, pl->nseg_pad, T_,
+                           pl->flow ? 2 : 1);
     else
         hipLaunchKernelGGL((k_gather_rows<double>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream,
-                           (const double *)pl->tm.p, (const int32_t *)pl->scratch.p, (double *)dst, nrows, pl->nseg_pad, T_);
+                           (const double *)pl->tm.p, (const int32_t *)pl->scratch.p, (double *)dst, nrows, pl->nseg_pad, T_, 1);
     HIP_TRY(hipGetLastError());
     if (!dst_is_device) HIP_TRY(hipMemcpyAsync(out, dst, obytes, hipMemcpyDeviceToHost, pl->stream));
     HIP_TRY(hipStreamSynchronize(pl->stream));

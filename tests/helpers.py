@@ -112,3 +112,9 @@ def reaches_from_to(to):
                 done[chain] = True
     assert done.all()
     return reaches, heads_up, ups
+
+
+def flow_engine(precision=32):
+    """True when plans of this precision run on the dataflow engine (k_mc_flow), False on the level engine."""
+    import os
+    return precision == 32 and os.environ.get("TRMC_ENGINE", "flow") != "levels"

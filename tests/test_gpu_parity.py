@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 
 import helpers as H
+from helpers import flow_engine
 from oracle import oracle as O
 from troute_amd import _lib
 from troute_amd.plan import RoutingPlan, csr_from_lists, segments, topology_levels
@@ -102,7 +103,8 @@ def test_lowercolorado_fp32_bit_identical_to_det_oracle(lc, short):
     assert_bit_identical(fvd, want, f"LowerColorado short={short}")
     st = r[-1]
     assert st["nlevels"] == 649 and st["nseg_routed"] == 11248
-    assert st["main_launches"] == (288 if short else 649 + 288 - 1)
+    # level engine: one launch per timestep / per wavefront diagonal; dataflow engine: one launch per window
+    assert st["main_launches"] == (1 if flow_engine() else 288 if short else 649 + 288 - 1)
 
 
 def test_lowercolorado_return_tuple_shape(lc):

@@ -10,6 +10,7 @@ except Exception:         # pragma: no cover
     torch = None
 
 import helpers as H
+from helpers import flow_engine
 from troute_amd import _lib
 from troute_amd.plan import RoutingPlan, csr_from_lists
 
@@ -47,7 +48,7 @@ def test_window_in_parts_equals_one_call(short):
             plan.gather_flow_range(rs, done, t_end, buf[:, done:].data_ptr(), nsteps)
             done = t_end
         st = plan.route_end()
-        assert st["nsteps"] == nsteps and st["main_launches"] >= nsteps
+        assert st["nsteps"] == nsteps and st["main_launches"] >= (4 if flow_engine() else nsteps)
         got = plan.download_fvd()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert np.array_equal(buf.cpu().numpy().view(np.uint32), want[rows, :, 0].view(np.uint32))
@@ -146,7 +147,7 @@ def test_time_skewed_rows_equal_two_phase_routing():
                 break
             c += 1
         st = plan.route_end()
-        assert st["main_launches"] == last
+        assert st["main_launches"] == (c + 1 if flow_engine() else last)   # one launch per advance / per timestep
         got = plan.download_fvd()
     assert np.array_equal(got[:n].view(np.uint32), want[:n].view(np.uint32))
     assert np.array_equal(got[n + 1:].view(np.uint32), want[n:].view(np.uint32))

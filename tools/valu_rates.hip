@@ -82,6 +82,7 @@ KERNEL64(k_cmp_f64, "v_cmp_lt_f64 vcc, %0, %1")
 KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %1")
 KERNEL64(k_pk_fma, "v_pk_fma_f32 %0, %0, %1, %2")
 KERNEL64(k_pk_mul, "v_pk_mul_f32 %0, %0, %1")
+KERNEL64(k_pk_add, "v_pk_add_f32 %0, %0, %1")
 KERNEL64(k_mov_b64, "v_mov_b64 %0, %1")
 KERNELCVT(k_cvt_pair)
 
@@ -111,6 +112,6 @@ int main()
     R32(k_mul_f32) R32(k_add_f32) R32(k_rcp_f32) R32(k_sqrt_f32) R32(k_rsq_f32) R32(k_log_f32) R32(k_exp_f32)
     R32(k_div_scale) R32(k_div_fmas) R32(k_div_fixup) R32(k_cndmask) R32(k_cmp_f32) R32(k_cmp_class) R32(k_mov) R32(k_and)
     R32(k_lshl_add_u32) R32(k_cvt_pair) R32(k_cndmask_s) R32(k_cndmask_dep) R32(k_cmp_s) R32(k_max_f32) R32(k_mul_abs) R32(k_fmac_f32) R32(k_add_u32) R32(k_lshlrev) R32(k_cvt_i32) R32(k_mul_lit) R32(k_bcnt) R32(k_ldexp)
-    R64(k_fma_f64) R64(k_mul_f64) R64(k_add_f64) R64(k_rcp_f64) R64(k_cmp_f64) R64(k_lshl_add_u64) R64(k_pk_fma) R64(k_pk_mul) R64(k_mov_b64)
+    R64(k_fma_f64) R64(k_mul_f64) R64(k_add_f64) R64(k_rcp_f64) R64(k_cmp_f64) R64(k_lshl_add_u64) R64(k_pk_fma) R64(k_pk_mul) R64(k_pk_add) R64(k_mov_b64)
     return 0;
 }
