@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 3
+#define TRMC_ABI_VERSION 5
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -110,6 +110,26 @@ int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
 int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                             const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
                             int precision, int device, trmc_plan **out);
+/* The same with flags: which engine runs the plan, and which timestep mode it is meant for.
+ *   engine  TRMC_ENGINE_LEVELS   level engine: rows in level-major order, one launch per timestep (assume_short_ts) or per
+ *                                wavefront diagonal (k_mc_step); the only engine of precision-64 plans
+ *           TRMC_ENGINE_FLOW     dataflow engine (precision 32): rows in block order, one persistent launch per window,
+ *                                rows exchange flows through tagged granules (k_mc_flow)
+ *           TRMC_ENGINE_AUTO     flow, except for a precision-32 plan of 500 000 routed rows or more that is meant for
+ *                                assume_short_ts: there every launch fills the device many times over and wavefronts
+ *                                that are uniform in cost across a whole level outweigh the launch boundaries
+ *   mode    TRMC_PLAN_SHORT_TS / TRMC_PLAN_FULL_TS: the assume_short_ts value the plan will be routed with, if the caller
+ *           knows it (compute_nhd_routing_v02 does).  A plan routes correctly in either mode whatever it was built for;
+ *           the flag chooses the row order that is fast for that mode (block order with cost tiers for the first, plain
+ *           sub-tree blocks for the second and when unknown).
+ * The environment variable TRMC_ENGINE=levels|flow overrides TRMC_ENGINE_AUTO (A/B measurements). */
+enum { TRMC_ENGINE_AUTO = 0, TRMC_ENGINE_LEVELS = 1, TRMC_ENGINE_FLOW = 2, TRMC_ENGINE_MASK = 3,
+       TRMC_PLAN_SHORT_TS = 4, TRMC_PLAN_FULL_TS = 8 };
+int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                        const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
+                        int precision, int device, int flags, trmc_plan **out);
+/* 1 if the plan runs on the dataflow engine, 0 on the level engine. */
+int trmc_plan_engine(const trmc_plan *plan, int32_t *is_flow);
 void trmc_plan_destroy(trmc_plan *plan);
 
 /* Host-only topology flattening (no device needed): the same routine the plan
@@ -123,6 +143,16 @@ int trmc_topology_levels(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
 int trmc_topology_levels_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                                 const uint8_t *boundary, const uint8_t *cost_hint, int32_t *level_of_row,
                                 int64_t *plan_pos_of_row, int32_t *nlevels);
+
+/* Host-only: the BLOCK ORDER of the dataflow engine (fp32 plans; csrc/topology.hpp) -- routed rows in depth-first
+ * post-order, stably sorted by a downstream-monotone cost tier (cost_tiers != 0), cut into blocks of *block_rows positions (one workgroup
+ * each; boundary rows come first and belong to no block), rows of a block grouped by cost.  Every row's upstream rows
+ * sit in its own block or an earlier one.  plan_pos_of_row[nseg]; rank_of_row[nseg] = dependency depth of the row
+ * inside its block (the steps it trails by without assume_short_ts).  Outputs may be NULL.
+ * Reference analogue: dfs_decomposition's reach order (nhd_network.py:503-557) and build_subnetworks (:691-771). */
+int trmc_topology_blocks(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                         const uint8_t *boundary, const uint8_t *cost_hint, int cost_tiers,
+                         int64_t *plan_pos_of_row, int32_t *rank_of_row, int32_t *block_rows, int32_t *nblocks);
 
 /* Facts about the flattened topology (host side, no device work). */
 int trmc_plan_info(const trmc_plan *plan, int64_t *nseg, int64_t *nseg_routed,

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRMC_LIB_PATH") or os.path.join(_HERE, "libtrmc.so")
 
 TRMC_OK, TRMC_EINVAL, TRMC_ECYCLE, TRMC_ENODEVICE, TRMC_EHIP, TRMC_ENOMEM, TRMC_ESTATE = 0, -1, -2, -3, -4, -5, -6
+ENGINE_AUTO, ENGINE_LEVELS, ENGINE_FLOW, PLAN_SHORT_TS, PLAN_FULL_TS = 0, 1, 2, 4, 8   # trmc.h plan flags
 NPARAM = 9
 PARAM_COLS = ("dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0")  # trmc.h TRMC_P_*
 
@@ -38,9 +39,12 @@ SIGNATURES = {
     "trmc_device_count": (_int, [_P(_int)]),
     "trmc_plan_create": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _int, _P(_vp)]),
     "trmc_plan_create_hinted": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _P(_vp)]),
+    "trmc_plan_create_ex": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _P(_vp)]),
+    "trmc_plan_engine": (_int, [_vp, _P(_i32)]),
     "trmc_plan_destroy": (None, [_vp]),
     "trmc_topology_levels": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
     "trmc_topology_levels_hinted": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
+    "trmc_topology_blocks": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _P(_i32), _P(_i32)]),
     "trmc_plan_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i32), _P(_i32), _P(_i32)]),
     "trmc_plan_levels": (_int, [_vp, _vp, _vp]),
     "trmc_upload_forcing": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),

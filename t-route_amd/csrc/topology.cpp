@@ -8,7 +8,8 @@
 namespace trmc {
 
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
-                   const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows)
+                   const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows,
+                   bool cost_tiers)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -163,6 +164,34 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             err = "internal: depth-first walk missed rows";
             return -2;
         }
+        if (!cost_tiers) cost_hint = nullptr;
+        // Cost tiers.  A block runs at the pace of its costliest wavefront, so blocks should hold rows of one cost.  Every
+        // row gets a tier -- its hint quantised to at most 8 steps, or without a hint the size class of its drainage --
+        // made monotone downstream (a row is at least as costly as anything draining into it: how wet a channel is only
+        // grows downstream, and the closure repairs the exceptions), and the post-order is stably sorted by tier: cheap
+        // rows first.  Every edge still points from an earlier to a later position, so the order stays a valid one.
+        {
+            std::vector<uint8_t> tier(nseg, 0);
+            if (cost_hint) {
+                int lo = 255, hi = 0;
+                for (const int32_t r : post) {
+                    lo = std::min(lo, (int)cost_hint[r]);
+                    hi = std::max(hi, (int)cost_hint[r]);
+                }
+                const int span = hi - lo + 1, nt = std::min(8, span);
+                for (const int32_t r : post) tier[r] = (uint8_t)(((int)cost_hint[r] - lo) * nt / span);
+            } else {
+                for (const int32_t r : post) {
+                    int b = 0;
+                    for (int64_t d = drain[r]; d >= 4 && b < 3; d >>= 2) ++b; // 1-3, 4-15, 16-63, 64 and more rows
+                    tier[r] = (uint8_t)b;
+                }
+            }
+            for (const int32_t r : queue) // Kahn order: a row's tier is final before it is pushed downstream
+                for (int32_t k = down_ptr[r]; k < down_ptr[r + 1]; ++k)
+                    tier[down_idx[k]] = std::max(tier[down_idx[k]], tier[r]);
+            if (cost_tiers) std::stable_sort(post.begin(), post.end(), [&](int32_t a, int32_t b) { return tier[a] < tier[b]; });
+        }
         t.pos_of_row.assign(nseg, -1);
         t.row_of_pos.assign(nseg, -1);
         for (int64_t b = 0; b < t.nboundary; ++b) {
@@ -178,12 +207,10 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             const int32_t m = (int32_t)(i1 - i0);
             idx.resize(m);
             key.resize(m);
-            int32_t lo = std::numeric_limits<int32_t>::max();
             for (int32_t i = 0; i < m; ++i) {
                 const int32_t r = post[i0 + i];
                 idx[i] = i;
                 key[i] = cost_hint ? (int64_t)cost_hint[r] : drain[r];
-                lo = std::min(lo, t.level_of_row[r]);
             }
             std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t c) { return key[a] > key[c]; });
             for (int32_t i = 0; i < m; ++i) {
@@ -191,11 +218,38 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                 const int32_t p = (int32_t)(t.nboundary + i0 + i);
                 t.pos_of_row[r] = p;
                 t.row_of_pos[p] = r;
-                t.rank_of_pos[p] = t.level_of_row[r] - lo;
-                t.maxrank = std::max(t.maxrank, t.rank_of_pos[p]);
             }
         }
         csr_in_plan_order();
+        // Rank of a position inside its block: 0 for a row none of whose upstream rows shares its block, else one more
+        // than the highest rank among those that do (the depth of the dependence graph the block induces).  Without the
+        // short-timestep assumption a row needs its upstream rows at the SAME step, and the lanes of a wavefront advance
+        // together: lane i therefore works `rank` steps behind (k_mc_flow, round k = step t0 + k - rank), so that in
+        // any round a lane only needs what lanes of its block produced in EARLIER rounds -- by induction over the rounds
+        // no wavefront of the block ever waits for another one in a cycle.  (A rank per wavefront would not do: two
+        // wavefronts may feed each other within one step through different rows.)  Rows of earlier blocks are waited for.
+        {
+            std::vector<int32_t> lanes;
+            const int64_t B = block_rows;
+            for (int64_t w0 = t.nboundary; w0 < nseg; w0 += B) {
+                const int64_t w1 = std::min<int64_t>(nseg, w0 + B);
+                lanes.clear();
+                for (int64_t p = w0; p < w1; ++p) lanes.push_back((int32_t)p);
+                // (levels order the rows of a block topologically)
+                std::sort(lanes.begin(), lanes.end(), [&](int32_t a, int32_t b) {
+                    return t.level_of_row[t.row_of_pos[a]] < t.level_of_row[t.row_of_pos[b]];
+                });
+                for (const int32_t p : lanes) {
+                    int32_t rk = 0;
+                    for (int32_t k = t.up_ptr[p]; k < t.up_ptr[p + 1]; ++k) {
+                        const int32_t u = t.up_idx[k];
+                        if (u >= w0 && u < w1) rk = std::max(rk, t.rank_of_pos[u] + 1);
+                    }
+                    t.rank_of_pos[p] = rk;
+                    t.maxrank = std::max(t.maxrank, rk);
+                }
+            }
+        }
         return 0;
     }
 

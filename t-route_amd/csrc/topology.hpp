@@ -34,7 +34,7 @@ struct Topology {
     // block order (build_topology with block_rows > 0), see below
     int32_t block_rows = 0;              // 0: level-major order; else rows per block of the dataflow engine
     int32_t nblocks = 0;                 // blocks of block_rows consecutive routed positions, from position nboundary
-    std::vector<int32_t> rank_of_pos;    // [nseg] level of the row minus the lowest level in its block (0 for boundary rows)
+    std::vector<int32_t> rank_of_pos;    // [nseg] dependency depth of a position inside its block (topology.cpp)
     int32_t maxrank = 0;
 };
 
@@ -47,13 +47,17 @@ struct Topology {
 // in depth-first post-order from the outlets (largest basin first, the larger tributary of a junction last), so that
 // every row comes after all the rows draining into it and a run of consecutive positions is a handful of complete
 // sub-trees plus the chain they hang off.  The order is cut into blocks of block_rows positions -- one workgroup of the
-// engine each: a block only ever needs flows of its own rows and of EARLIER blocks -- and inside a block rows are
-// grouped by descending cost (the hint, or without one the number of rows draining through, which decides how wet a
-// channel is) so that a wavefront holds rows of one cost.  Reference analogue of the order: dfs_decomposition's
+// engine each: a block only ever needs flows of its own rows and of EARLIER blocks.  Cost grouping happens twice: the
+// whole order is stably sorted by a downstream-monotone cost tier (cheap rows first; still a valid order), so a block
+// holds rows of one tier, and inside a block rows are grouped by descending cost (the hint, or without one the number
+// of rows draining through, which decides how wet a channel is) so that a wavefront holds rows of one cost.
+// cost_tiers = false keeps the plain post-order (blocks = whole sub-trees) and ignores the hint: the order for routing
+// WITHOUT the short-timestep assumption, where rows of a wavefront trail each other by their dependency depth and what
+// counts is that a block's rows are close in the network, not close in cost (k_mc_flow).  Reference analogue of the order: dfs_decomposition's
 // "every reach's upstream reaches precede it" (nhd_network.py:503-557); of the blocks: build_subnetworks
 // (nhd_network.py:691-771), here a few hundred rows instead of 10 000 and pipelined in time instead of by order.
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr,
-                   int32_t block_rows = 0);
+                   int32_t block_rows = 0, bool cost_tiers = true);
 
 } // namespace trmc

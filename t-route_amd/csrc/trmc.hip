@@ -800,7 +800,10 @@ k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
 #define TRMC_FLOW_WAVES 4
 #endif
 constexpr int kFlowBlock = TRMC_FLOW_BLOCK;
-constexpr int kFlowStage = 8; // steps staged per thread before they are written to `out`
+#ifndef TRMC_FLOW_STAGE
+#define TRMC_FLOW_STAGE 8
+#endif
+constexpr int kFlowStage = TRMC_FLOW_STAGE; // steps staged per thread before they are written to `out`
 
 struct FlowArgs {
     const float *dx, *bw, *twcc, *n, *ncc, *s0;
@@ -832,54 +835,132 @@ struct FlowArgs {
     uint32_t tag_base;
     int32_t *ticket;               // [0] block tickets of this launch, [1] abort flag of the window
     uint64_t watchdog_ticks;       // wall_clock64 ticks (100 MHz) a row may wait for one granule
+    unsigned long long *dbg;       // nullptr, or [nblocks][2]: wall clock at the start and the end of every block (TRMC_FLOW_DEBUG)
 };
 
 __device__ __forceinline__ unsigned long long gran_load(const unsigned long long *g)
 {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// flow of position `u` at the step whose tag is `want`; waits until it has been published
+// flow of position `u` at the step whose tag is `want`; waits until it has been published.  A waiting row costs
+// the others as little as possible: long sleeps, and a poll counter for a watchdog instead of a clock read per poll
+// (the clock is only consulted every 1024th poll).
+#ifndef TRMC_FLOW_SLEEP
+#define TRMC_FLOW_SLEEP 16 // x 64 clocks between two polls of a granule that is not there yet
+#endif
+__device__ __forceinline__ bool flow_watchdog(uint32_t &polls, uint64_t &t_start, const FlowArgs &a)
+{
+    if ((++polls & 1023u) != 0u) return false;
+    if (t_start == 0) {
+        t_start = wall_clock64();
+        return false;
+    }
+    if (wall_clock64() - t_start > a.watchdog_ticks
+        || __hip_atomic_load(a.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(a.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    return false;
+}
 __device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t want, const FlowArgs &a, bool &dead)
 {
     unsigned long long v = gran_load(g);
+#ifdef TRMC_FLOW_EXP_NOWAIT // timing experiment: no dependence between rows (wrong results)
+    return __uint_as_float((uint32_t)v);
+#endif
     if ((uint32_t)(v >> 32) != want) {
-        const uint64_t t_start = wall_clock64();
-        for (;;) {
-            __builtin_amdgcn_s_sleep(4);
+        uint32_t polls = 0;
+        uint64_t t_start = 0;
+        do {
+            __builtin_amdgcn_s_sleep(TRMC_FLOW_SLEEP);
             v = gran_load(g);
-            if ((uint32_t)(v >> 32) == want) break;
-            if (wall_clock64() - t_start > a.watchdog_ticks
-                || __hip_atomic_load(a.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(a.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dead = true;
-                break;
+            if (flow_watchdog(polls, t_start, a)) dead = true;
+        } while ((uint32_t)(v >> 32) != want && !dead);
+    }
+    return __uint_as_float((uint32_t)v);
+}
+
+// One upstream edge of a row.  In-block edges are read from the block's LDS ring while producer and consumer run in
+// step; an edge whose producer runs well ahead (its ring slot is already overwritten: a cheap row feeding a costly one)
+// or lives in another block is read from the granule plane, one step ahead of its use (the load is in flight during the
+// arithmetic of the current step).
+struct FlowEdge {
+    int32_t u;                // plan position of the upstream row, -1 = none
+    int32_t l;                // its index in the block's LDS ring, -1 = not eligible (other block, other lag)
+    bool ahead;               // read through the granule plane, prefetched
+    bool pre_ok;
+    unsigned long long pre;   // the prefetched granule
+};
+#ifndef TRMC_FLOW_RING
+#define TRMC_FLOW_RING 4
+#endif
+constexpr int kFlowRing = TRMC_FLOW_RING;  // steps the LDS ring of a block holds (a power of two)
+
+__device__ __forceinline__ float flow_edge_get(FlowEdge &e, const unsigned long long *plane_row, unsigned long long *ring,
+                                               int32_t ws, uint32_t want, const FlowArgs &a, bool &dead)
+{
+    unsigned long long v = e.pre;
+    if (!(e.ahead && e.pre_ok && (uint32_t)(v >> 32) == want)) {
+        bool got = false;
+        if (e.l >= 0) {
+            const unsigned long long *slot = ring + (size_t)(ws & (kFlowRing - 1)) * kFlowBlock + e.l;
+            v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((int32_t)((uint32_t)(v >> 32) - want) < 0) { // not produced yet: the producer is a wave of this block
+                uint32_t polls = 0;
+                uint64_t t_start = 0;
+                do {
+                    __builtin_amdgcn_s_sleep(TRMC_FLOW_SLEEP);
+                    v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (flow_watchdog(polls, t_start, a)) dead = true;
+                } while ((int32_t)((uint32_t)(v >> 32) - want) < 0 && !dead);
             }
+            got = (uint32_t)(v >> 32) == want;
+            e.ahead = !got; // overwritten: the producer is ahead by more than the ring holds
+        }
+        if (!got) {
+            const float q = flow_wait(plane_row + e.u, want, a, dead);
+            return q;
         }
     }
     return __uint_as_float((uint32_t)v);
 }
 
+#ifdef TRMC_FLOW_VGPRS // experiment: cap the register allocation (more wavefronts per SIMD, possibly spills)
+#define TRMC_FLOW_ATTR __attribute__((amdgpu_num_vgpr(TRMC_FLOW_VGPRS)))
+#else
+#define TRMC_FLOW_ATTR
+#endif
 template <bool SHORT>
-__global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES)
+__global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES) TRMC_FLOW_ATTR
 k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the launches / steps (t0, t1] of the window
 {
     using M = DevMathF;
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
-    __shared__ float s_out[3 * kFlowStage * kFlowBlock]; // [step slot * 3 + c][thread]
+    __shared__ float s_out[3 * kFlowStage * kFlowBlock];             // [step slot * 3 + c][thread]
+    __shared__ unsigned long long s_ring[kFlowRing * kFlowBlock];    // [step % kFlowRing][thread] granules
     __shared__ int32_t s_blk;
     if (threadIdx.x == 0) s_blk = atomicAdd(a.ticket, 1);
-    M m{stage_pow_tables(s_tab), false}; // (its barrier also publishes s_blk)
+#pragma unroll
+    for (int j = 0; j < kFlowRing; ++j) s_ring[j * kFlowBlock + threadIdx.x] = 0ull; // tag 0: older than any live tag
+    M m{stage_pow_tables(s_tab), false}; // (its barrier also publishes s_blk and the cleared ring)
     m.sane = a.sane;
 
-    const int32_t pos = a.first + s_blk * kFlowBlock + (int32_t)threadIdx.x;
+    const int32_t blk_base = a.first + s_blk * kFlowBlock;
+    const int32_t pos = blk_base + (int32_t)threadIdx.x;
     const bool valid = pos < a.nseg;
     const uint32_t su = valid ? (uint32_t)pos : (uint32_t)a.first;
     const uint32_t ob = su * 4u;
     const int32_t lag = a.lag ? a.lag[su] : 0;
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * s_blk] = wall_clock64();
     // the steps [t_lo, t_hi] this row covers in this launch, and the round it starts in
     const int32_t t_lo = SHORT ? max(t0 - lag, 0) + 1 : t0 + 1;
     const int32_t t_hi = valid ? (SHORT ? min(t1 - lag, a.nsteps) : min(t1, a.nsteps)) : 0;
     const int32_t delay = SHORT ? 0 : lag;
+    // General mode: a wavefront whose rows trail each other deeply sits on a long chain of the network -- the critical
+    // path of the window (a row at level l cannot finish step t before l rows have, one after the other).  It gets
+    // issue priority over the wavefronts it shares its SIMD with, so that the chain advances at the pace of one
+    // wavefront alone while the bulk of the network fills the remaining issue slots.
+    if (!SHORT && __any(delay >= 16)) __builtin_amdgcn_s_setprio(3);
 
     trmc::ChannelParams<float> p;
     p.dt = a.dt_col ? at(a.dt_col, ob) : a.dt;
@@ -901,12 +982,38 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
     c.half_dt = p.dt / 2.0f;
     c.fp_ok = (p.twcc > 0.0f) && (p.ncc > 0.0f);
     const int2 up = a.up2[su];
+    const bool more = up.y >= 0 && (up.y & 0x40000000);
+    FlowEdge e0, e1;
+    {
+        auto init = [&](FlowEdge &e, int32_t u) {
+            e.u = valid ? u : -1;
+            e.l = -1;
+            e.pre = 0ull;
+            e.pre_ok = false;
+            if (e.u >= 0) {
+                const bool inb = u >= blk_base && u < blk_base + kFlowBlock;
+                // (a skewed row and a row in step never share the ring: their step windows differ)
+                const bool same = !SHORT || !a.lag || a.lag[u] == lag;
+#ifndef TRMC_FLOW_EXP_NOLDS // (timing experiment: every edge through the granule plane)
+                if (inb && same) e.l = u - blk_base;
+#endif
+            }
+            e.ahead = e.l < 0;
+        };
+#ifdef TRMC_FLOW_EXP_NOUP
+        init(e0, -1);
+        init(e1, -1);
+#else
+        init(e0, up.x);
+        init(e1, up.y >= 0 ? (up.y & 0x3fffffff) : -1);
+#endif
+    }
     const int32_t ri = a.res_of_pos ? a.res_of_pos[su] : -1;
     const int32_t gi = a.gage_of_pos ? a.gage_of_pos[su] : -1;
     const size_t np = (size_t)a.nseg_pad;
     float *const out_row = a.out + (size_t)a.row_of_pos[su] * (size_t)a.nsteps * 3;
 
-    float q_prev = 0.0f, d_prev = 0.0f, ql = 0.0f;
+    float q_prev = 0.0f, d_prev = 0.0f, ql = 0.0f, xp0 = 0.0f, xp1 = 0.0f;
     int32_t ql_col = -1, staged = 0, it_acc = 0, it_last = 0;
     bool have_state = false, dead = false;
 
@@ -920,6 +1027,13 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
         if (!have_state) { // the state this row was left in: its own granule of step t - 1, its depth column
             q_prev = flow_wait(g_prev + su, tag_p, a, dead);
             d_prev = a.d_state[su];
+            __hip_atomic_store(s_ring + (size_t)((t - 1) & (kFlowRing - 1)) * kFlowBlock + threadIdx.x,
+                               ((unsigned long long)tag_p << 32) | (unsigned long long)__float_as_uint(q_prev),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!SHORT) { // the general mode also needs its upstream rows at the step before its first one
+                if (e0.u >= 0) xp0 = flow_wait(g_prev + e0.u, tag_p, a, dead);
+                if (e1.u >= 0) xp1 = flow_wait(g_prev + e1.u, tag_p, a, dead);
+            }
             have_state = true;
         }
         const int32_t col = (t - 1) / a.qts;
@@ -927,25 +1041,40 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
             ql = a.qlat_tm[(size_t)col * np + su];
             ql_col = col;
         }
-        // junction sums in the reference's order (mc_reach.pyx:499-502)
-        float qup = 0.0f, quc = 0.0f;
-        if (up.x >= 0) {
-            qup += flow_wait(g_prev + up.x, tag_p, a, dead);
-            if (!SHORT) quc += flow_wait(g_curr + up.x, tag_p + 1u, a, dead);
+        // junction sums in the reference's order (mc_reach.pyx:499-502): with assume_short_ts the upstream flows of
+        // step t - 1 (they are also `quc`, :504-505), without it those of step t and -- kept from the round before --
+        // of step t - 1
+        const int32_t ws = SHORT ? t - 1 : t;
+        const uint32_t want = SHORT ? tag_p : tag_p + 1u;
+        const unsigned long long *g_want = SHORT ? g_prev : g_curr;
+        float x0 = 0.0f, x1 = 0.0f;
+        if (e0.u >= 0) x0 = flow_edge_get(e0, g_want, s_ring, ws, want, a, dead);
+        if (e1.u >= 0) x1 = flow_edge_get(e1, g_want, s_ring, ws, want, a, dead);
+        // edges read through the granule plane: next step's granule starts its way here now
+        if (t < t_hi) {
+            if (e0.u >= 0 && e0.ahead) e0.pre = gran_load(g_want + np + e0.u);
+            if (e1.u >= 0 && e1.ahead) e1.pre = gran_load(g_want + np + e1.u);
         }
-        if (up.y >= 0) {
-            const int32_t u1 = up.y & 0x3fffffff;
-            qup += flow_wait(g_prev + u1, tag_p, a, dead);
-            if (!SHORT) quc += flow_wait(g_curr + u1, tag_p + 1u, a, dead);
-            if (up.y & 0x40000000) {
-                const int32_t k1 = a.up_ptr[su + 1];
-                for (int32_t e = a.up_ptr[su] + 2; e < k1; ++e) {
-                    const int32_t ue = a.up_idx[e];
-                    qup += flow_wait(g_prev + ue, tag_p, a, dead);
-                    if (!SHORT) quc += flow_wait(g_curr + ue, tag_p + 1u, a, dead);
-                }
+        e0.pre_ok = e1.pre_ok = t < t_hi;
+        float qup = 0.0f, quc = 0.0f;
+        if (e0.u >= 0) {
+            qup += SHORT ? x0 : xp0;
+            quc += x0;
+        }
+        if (e1.u >= 0) {
+            qup += SHORT ? x1 : xp1;
+            quc += x1;
+        }
+        if (more) { // fan-in above two (0.2 % of junctions): straight from the granule plane
+            const int32_t k1 = a.up_ptr[su + 1];
+            for (int32_t e = a.up_ptr[su] + 2; e < k1; ++e) {
+                const int32_t ue = a.up_idx[e];
+                qup += flow_wait(g_prev + ue, tag_p, a, dead);
+                if (!SHORT) quc += flow_wait(g_curr + ue, tag_p + 1u, a, dead);
             }
         }
+        xp0 = x0;
+        xp1 = x1;
         trmc::Inflow<float> f;
         f.qup = qup;
         f.quc = SHORT ? qup : quc;
@@ -984,12 +1113,19 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
                 a.da_nudge[e] = nudge;
             }
         }
-        // publish the flow: one 8-byte agent-scope store, tag in the high word
-        __hip_atomic_store(g_curr + su, ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(q_new),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // publish the flow: the block's ring, and one 8-byte agent-scope store into the plane; tag in the high word
+        {
+            const unsigned long long g = ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(q_new);
+            __hip_atomic_store(s_ring + (size_t)(t & (kFlowRing - 1)) * kFlowBlock + threadIdx.x, g, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g_curr + su, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         q_prev = q_new;
         d_prev = d_new;
         // stage (q, v, d) of step t; a run ends at every 8th step of the window and at the last step of the launch
+#ifdef TRMC_FLOW_EXP_NOOUT // timing experiment: results are not written
+        if (q_new + v_new + d_new == 12345.678f)
+#endif
         {
             const int32_t slot = (t - 1) & (kFlowStage - 1);
             float *so = s_out + (size_t)(slot * 3) * kFlowBlock + threadIdx.x;
@@ -1018,6 +1154,7 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
             }
         }
     }
+    if (a.dbg) atomicMax(a.dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
     if (valid && have_state) {
         a.d_state[su] = d_prev;
         if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)it_last;
@@ -1136,7 +1273,7 @@ struct trmc_plan {
     bool flow = false;
     uint32_t tag_base = 1;               // tag of step 0 of the current window (0 is never a live tag)
     int32_t tag_span = 0;                // tags the current window may use (nsteps + 1)
-    DevBuf d_state, ticket, rank;        // depth column; {block ticket, abort flag}; level rank of a position inside its block
+    DevBuf d_state, ticket, rank, dbg;   // depth column; {block ticket, abort flag}; level rank of a position inside its block
     uint64_t watchdog_ticks = 300000000; // 3 s of wall_clock64 (100 MHz)
     trmc_stats stats{};
     RouteRun run;
@@ -1483,6 +1620,7 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     a.tag_base = pl->tag_base;
     a.ticket = (int32_t *)pl->ticket.p;
     a.watchdog_ticks = pl->watchdog_ticks;
+    a.dbg = std::getenv("TRMC_FLOW_DEBUG") ? (unsigned long long *)pl->dbg.p : nullptr;
     return a;
 }
 
@@ -1495,6 +1633,10 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     if (int rc = pl->tm.ensure((size_t)(nsteps + 1) * np * sizeof(unsigned long long), true)) return rc;
     if (int rc = pl->d_state.ensure((size_t)np * sizeof(float))) return rc;
     if (int rc = pl->ticket.ensure(2 * sizeof(int32_t))) return rc;
+    if (std::getenv("TRMC_FLOW_DEBUG")) {
+        if (int rc = pl->dbg.ensure((size_t)(tp.nblocks + 1) * 2 * sizeof(unsigned long long))) return rc;
+        HIP_TRY(hipMemset(pl->dbg.p, 0, pl->dbg.bytes));
+    }
     if (int rc = pl->qlat_tm.ensure((size_t)pl->nq * np * sizeof(float))) return rc;
     if (int rc = pl->out.ensure((size_t)pl->nseg * nsteps * 3 * sizeof(float))) return rc;
     if (pl->nres > 0)
@@ -1575,6 +1717,33 @@ int flow_route_end(trmc_plan *pl)
         r.active = false;
         return fail(TRMC_EHIP, "dataflow engine: a row waited longer than the watchdog allows for an upstream flow "
                                "(boundary hydrographs missing for the steps routed, or an internal error); window abandoned");
+    }
+    if (std::getenv("TRMC_FLOW_DEBUG") && pl->topo.nblocks > 0) { // developer aid: when did every block run?
+        const int32_t nb = pl->topo.nblocks;
+        std::vector<unsigned long long> d((size_t)nb * 2);
+        HIP_TRY(hipMemcpy(d.data(), pl->dbg.p, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t_min = ~0ull, t_max = 0;
+        for (int32_t b = 0; b < nb; ++b) {
+            t_min = std::min(t_min, d[2 * b]);
+            t_max = std::max(t_max, d[2 * b + 1]);
+        }
+        std::vector<int32_t> by_end(nb);
+        for (int32_t b = 0; b < nb; ++b) by_end[b] = b;
+        std::sort(by_end.begin(), by_end.end(), [&](int32_t x, int32_t y) { return d[2 * x + 1] > d[2 * y + 1]; });
+        std::fprintf(stderr, "[flow debug] %d blocks, span %.3f ms; blocks ending last (id, start ms, end ms, duration ms):\n", nb,
+                     (t_max - t_min) * 1e-5);
+        for (int32_t i = 0; i < std::min(nb, 12); ++i) {
+            const int32_t b = by_end[i];
+            std::fprintf(stderr, "   %6d  %9.3f %9.3f %9.3f\n", b, (d[2 * b] - t_min) * 1e-5, (d[2 * b + 1] - t_min) * 1e-5,
+                         (d[2 * b + 1] - d[2 * b]) * 1e-5);
+        }
+        // how many blocks are running at a few instants
+        for (int k = 1; k <= 10; ++k) {
+            const unsigned long long tt = t_min + (t_max - t_min) * k / 11;
+            int32_t live = 0;
+            for (int32_t b = 0; b < nb; ++b) live += d[2 * b] <= tt && d[2 * b + 1] > tt;
+            std::fprintf(stderr, "   at %8.3f ms: %d blocks live\n", (tt - t_min) * 1e-5, live);
+        }
     }
     float ms01 = 0, ms12 = 0;
     HIP_TRY(hipEventElapsedTime(&ms01, pl->ev[0], pl->ev[1]));
@@ -1670,6 +1839,23 @@ int trmc_topology_levels_hinted(int64_t nseg, const int64_t *up_ptr, const int64
     return 0;
 }
 
+int trmc_topology_blocks(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
+                         const uint8_t *cost_hint, int cost_tiers, int64_t *plan_pos_of_row, int32_t *rank_of_row,
+                         int32_t *block_rows, int32_t *nblocks)
+{
+    trmc::Topology t;
+    std::string err;
+    const int rc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, t, err, cost_hint, kFlowBlock, cost_tiers != 0);
+    if (rc) return fail(rc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
+    for (int64_t r = 0; r < nseg; ++r) {
+        if (plan_pos_of_row) plan_pos_of_row[r] = t.pos_of_row[r];
+        if (rank_of_row) rank_of_row[r] = t.rank_of_pos[t.pos_of_row[r]];
+    }
+    if (block_rows) *block_rows = t.block_rows;
+    if (nblocks) *nblocks = t.nblocks;
+    return 0;
+}
+
 int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
                      const uint8_t *boundary, int precision, int device, trmc_plan **out)
 {
@@ -1679,33 +1865,62 @@ int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
 int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
                             const uint8_t *boundary, const uint8_t *cost_hint, int precision, int device, trmc_plan **out)
 {
+    return trmc_plan_create_ex(nseg, up_ptr, up_idx, params, boundary, cost_hint, precision, device, TRMC_ENGINE_AUTO, out);
+}
+
+int trmc_plan_engine(const trmc_plan *pl, int32_t *is_flow)
+{
+    if (!pl || !is_flow) return fail(TRMC_EINVAL, "plan/is_flow is NULL");
+    *is_flow = pl->flow ? 1 : 0;
+    return 0;
+}
+
+int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
+                        const uint8_t *boundary, const uint8_t *cost_hint, int precision, int device, int flags,
+                        trmc_plan **out)
+{
     if (!out) return fail(TRMC_EINVAL, "out is NULL");
     *out = nullptr;
     if (precision != 32 && precision != 64) return fail(TRMC_EINVAL, "precision must be 32 or 64");
     if (nseg > 0 && !params) return fail(TRMC_EINVAL, "params is NULL");
+    if ((flags & ~(TRMC_ENGINE_MASK | TRMC_PLAN_SHORT_TS | TRMC_PLAN_FULL_TS)) || (flags & TRMC_ENGINE_MASK) == 3
+        || ((flags & TRMC_PLAN_SHORT_TS) && (flags & TRMC_PLAN_FULL_TS)))
+        return fail(TRMC_EINVAL, "bad plan flags");
+    int engine = flags & TRMC_ENGINE_MASK;
+    if (engine == TRMC_ENGINE_FLOW && precision != 32) return fail(TRMC_EINVAL, "the dataflow engine runs precision-32 plans only");
     if (int rc = check_device(device)) return rc;
 
     trmc_plan *pl = new (std::nothrow) trmc_plan();
     if (!pl) return fail(TRMC_ENOMEM, "out of host memory");
-    // engine: fp32 plans run on the dataflow engine (block order) unless TRMC_ENGINE=levels asks for the level engine
-    // (kept for A/B measurements and as the only engine of fp64 plans)
     {
         const char *e = std::getenv("TRMC_ENGINE");
-        pl->flow = precision == 32 && !(e && std::strcmp(e, "levels") == 0);
         if (e && std::strcmp(e, "levels") != 0 && std::strcmp(e, "flow") != 0) {
             delete pl;
             return fail(TRMC_EINVAL, "TRMC_ENGINE must be 'flow' or 'levels'");
         }
+        if (engine == TRMC_ENGINE_AUTO) {
+            if (precision != 32)
+                engine = TRMC_ENGINE_LEVELS;
+            else if (e)
+                engine = std::strcmp(e, "levels") == 0 ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
+            else {
+                int64_t nb = 0;
+                for (int64_t r = 0; boundary && r < nseg; ++r) nb += boundary[r] != 0;
+                engine = ((flags & TRMC_PLAN_SHORT_TS) && nseg - nb >= 500000) ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
+            }
+        }
+        pl->flow = engine == TRMC_ENGINE_FLOW;
         if (const char *w = std::getenv("TRMC_FLOW_WATCHDOG_MS")) pl->watchdog_ticks = (uint64_t)std::max(1L, std::atol(w)) * 100000ull;
     }
+    const bool tiers = (flags & TRMC_PLAN_SHORT_TS) != 0;
     std::string err;
-    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0);
+    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0, tiers);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
     }
     pl->device = device;
-    pl->hinted = cost_hint != nullptr;
+    pl->hinted = cost_hint != nullptr && (!pl->flow || tiers);
     pl->precision = precision;
     pl->esz = precision == 32 ? 4 : 8;
     pl->nseg = nseg;
@@ -1766,7 +1981,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();

@@ -35,12 +35,16 @@ def restrict_csr(up_ptr, up_idx, rows, g2l):
 
 class ShardedRouter:
     def __init__(self, to, params, rank=0, world=1, device=0, plan_factory=None, precision=32,
-                 partition=None, cost_hint=None):
+                 partition=None, cost_hint=None, assume_short_ts=None, engine="auto"):
         """cost_hint: optional uint8 [nseg] (global rows), the ``iteration_hint()`` of a router of the same network
-        after a window -- every plan then groups the rows of a level by that cost (RoutingPlan ``cost_hint``;
-        results unchanged, the step kernel's wavefronts become uniform in cost)."""
+        after a window -- every plan then groups its rows by that cost (RoutingPlan ``cost_hint``; results unchanged,
+        the kernels' wavefronts become uniform in cost).  assume_short_ts / engine: passed to every RoutingPlan (the
+        timestep mode the router will be used with, if known; "auto" | "levels" | "flow")."""
         if plan_factory is None:
-            from .plan import RoutingPlan as plan_factory  # the HIP engine; no fallback
+            from .plan import RoutingPlan  # the HIP engine; no fallback
+
+            def plan_factory(lp, li, par, boundary, prec, dev, **kw):
+                return RoutingPlan(lp, li, par, boundary, prec, dev, assume_short_ts=assume_short_ts, engine=engine, **kw)
         from .synthetic import upstream_csr
         self._hint = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
         if self._hint is not None:

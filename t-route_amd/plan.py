@@ -36,9 +36,29 @@ def topology_levels(up_ptr, up_idx, boundary=None, cost_hint=None):
     return lvl, pos, nl.value
 
 
+def topology_blocks(up_ptr, up_idx, boundary=None, cost_hint=None, cost_tiers=True):
+    """Host-only block order of the dataflow engine (no GPU).  Returns (plan_pos_of_row, rank_of_row, block_rows, nblocks)."""
+    up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
+    up_idx = np.ascontiguousarray(up_idx, dtype=np.int64)
+    nseg = up_ptr.shape[0] - 1
+    b = None if boundary is None else np.ascontiguousarray(boundary, dtype=np.uint8)
+    h = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
+    pos = np.empty(nseg, dtype=np.int64)
+    rank = np.empty(nseg, dtype=np.int32)
+    br, nb = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.lib().trmc_topology_blocks(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(b), _lib.ptr(h),
+                                               int(bool(cost_tiers)), _lib.ptr(pos), _lib.ptr(rank), C.byref(br),
+                                               C.byref(nb)))
+    return pos, rank, br.value, nb.value
+
+
 class RoutingPlan:
-    def __init__(self, up_ptr, up_idx, params, boundary=None, precision=32, device=0, cost_hint=None):
+    def __init__(self, up_ptr, up_idx, params, boundary=None, precision=32, device=0, cost_hint=None,
+                 assume_short_ts=None, engine="auto"):
         """
+        assume_short_ts : the timestep mode the plan will be routed with, if known (None: unknown) -- it routes
+                        correctly either way, the value picks the row order that is fast for the mode
+        engine        : "auto" | "levels" | "flow"  (include/trmc.h, trmc_plan_create_ex)
         up_ptr/up_idx : CSR of upstream rows per row, reference summation order
         params        : float32 [nseg, 9] in _lib.PARAM_COLS order
         boundary      : optional bool/uint8 [nseg], rows with prescribed hydrographs
@@ -63,9 +83,15 @@ class RoutingPlan:
         if hint is not None and hint.shape != (nseg,):
             raise ValueError("cost_hint shape mismatch")
         h = C.c_void_p(0)
-        _lib.check(_lib.lib().trmc_plan_create_hinted(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
-                                                      _lib.ptr(b), _lib.ptr(hint), precision, device, C.byref(h)))
+        flags = {"auto": _lib.ENGINE_AUTO, "levels": _lib.ENGINE_LEVELS, "flow": _lib.ENGINE_FLOW}[engine]
+        if assume_short_ts is not None:
+            flags |= _lib.PLAN_SHORT_TS if assume_short_ts else _lib.PLAN_FULL_TS
+        _lib.check(_lib.lib().trmc_plan_create_ex(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
+                                                  _lib.ptr(b), _lib.ptr(hint), precision, device, flags, C.byref(h)))
         self._h = h
+        f = C.c_int32(0)
+        _lib.check(_lib.lib().trmc_plan_engine(self._h, C.byref(f)))
+        self.engine = "flow" if f.value else "levels"
         self._nsteps = None
         self.maxlag = 0
 

@@ -41,7 +41,8 @@ def main():
 
     part = sharding.partition(to, a.world)
     # true hydrographs of the cut rows from a whole-network route
-    single = ShardedRouter(to, params)
+    eng = os.environ.get("PROBE_ENGINE", "auto")
+    single = ShardedRouter(to, params, assume_short_ts=short, engine=eng)
     single.upload(nsteps, qlat, q0)
     if a.retune:
         single.collect_cost(True)
@@ -50,7 +51,7 @@ def main():
     if a.retune:
         hint = single.iteration_hint()
         single.close()
-        single = ShardedRouter(to, params, cost_hint=hint)
+        single = ShardedRouter(to, params, cost_hint=hint, assume_short_ts=short, engine=eng)
         single.upload(nsteps, qlat, q0)
         single.route_resident(qts, short)
     t0 = time.perf_counter()
@@ -60,12 +61,14 @@ def main():
     cut_q = single.plan0.gather_flow_rows(cut_rows) if cut_rows.size else np.zeros((0, nsteps), np.float32)
     ref_rows = single.my_out0_global
     ref_hyd = single.outlet_hydrographs()
+    single_engine = single.plan0.engine
     single.close()
-    print(f"single GPU: {t_single * 1e3:.2f} ms   cut rows {cut_rows.size}")
+    print(f"single GPU ({single_engine} engine): {t_single * 1e3:.2f} ms   cut rows {cut_rows.size}")
 
     worst = 0.0
     for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
-        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint)
+        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
+                          assume_short_ts=short, engine=eng)
         r.enable_device_exchange(torch, dev)
         r.upload(nsteps, qlat, q0)
         r.upload_trunk()
@@ -130,7 +133,7 @@ def main():
         h = hyd.cpu().numpy()
         sel = np.searchsorted(rows, mine)
         ok = np.array_equal(h[sel].view(np.uint32), ref_hyd[np.searchsorted(ref_rows, mine)].view(np.uint32))
-        print(f"rank {rank}: {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
+        print(f"rank {rank} ({r.plan0.engine}): {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
               + (f"  trunk {r.rows1.size} rows" + (f" main {st['phase1']['ms_main']:.2f} ms" if "phase1" in st else " (skewed)") if r.plan1 is not None else "")
               + f"  outlets bit-identical: {ok}")
         if acc:
