@@ -221,6 +221,33 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             }
         }
         csr_in_plan_order();
+        // Issue priority of every wavefront.  A row stays in its wavefront for a whole window, so the window lasts as long
+        // as its slowest wavefront needs -- one that holds rows of three secant iterations per step takes twice the
+        // instructions of one that holds dry channels, and everything downstream of it waits.  The costlier a wavefront,
+        // the higher its priority on the SIMD it shares (s_setprio): the slow ones run at the pace of a wavefront alone,
+        // the cheap ones fill the issue slots they leave.
+        {
+            int64_t lo = std::numeric_limits<int64_t>::max(), hi = 0;
+            auto cost_of = [&](int32_t r) -> int64_t {
+                if (cost_hint) return cost_hint[r];
+                int64_t b = 0;
+                for (int64_t d = drain[r]; d >= 4 && b < 3; d >>= 2) ++b;
+                return b;
+            };
+            for (const int32_t r : post) {
+                lo = std::min(lo, cost_of(r));
+                hi = std::max(hi, cost_of(r));
+            }
+            const int64_t span = std::max<int64_t>(1, hi - lo + 1);
+            const int64_t nw = (nrouted + 63) / 64;
+            t.prio_of_wave.assign((size_t)nw, 0);
+            for (int64_t w = 0; w < nw; ++w) {
+                int64_t mx = lo;
+                for (int64_t p = t.nboundary + w * 64; p < std::min<int64_t>(nseg, t.nboundary + (w + 1) * 64); ++p)
+                    mx = std::max(mx, cost_of(t.row_of_pos[p]));
+                t.prio_of_wave[(size_t)w] = (uint8_t)std::min<int64_t>(3, (mx - lo) * 4 / span);
+            }
+        }
         // Rank of a position inside its block: 0 for a row none of whose upstream rows shares its block, else one more
         // than the highest rank among those that do (the depth of the dependence graph the block induces).  Without the
         // short-timestep assumption a row needs its upstream rows at the SAME step, and the lanes of a wavefront advance

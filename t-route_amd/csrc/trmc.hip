@@ -835,6 +835,7 @@ struct FlowArgs {
     uint32_t tag_base;
     int32_t *ticket;               // [0] block tickets of this launch, [1] abort flag of the window
     uint64_t watchdog_ticks;       // wall_clock64 ticks (100 MHz) a row may wait for one granule
+    const uint8_t *prio;           // issue priority 0..3 of every wavefront of the block order (topology.cpp)
     unsigned long long *dbg;       // nullptr, or [nblocks][2]: wall clock at the start and the end of every block (TRMC_FLOW_DEBUG)
 };
 
@@ -1162,6 +1163,209 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
     }
 }
 
+// The short-timestep form of the engine, written for occupancy: with assume_short_ts a row only ever needs flows of the
+// step before, all rows of a block advance together, and the whole window is VALU-bound -- what decides the pace of a
+// partly filled device (one rank of a multi-GPU job: 340 k rows are 5 455 wavefronts against 4 096 slots at four per
+// SIMD) is whether every wavefront of the job is resident at once.  So a thread keeps only what it must in registers
+// (its flow, its depth, its forcing, two upstream positions, one result offset): the twelve parameter and constant
+// columns of its row wait in LDS (48 B per row, read back at every step), results are stored step by step (12 B;
+// neighbouring steps of a row merge in the L2 / Infinity Cache), the LDS ring holds two steps.  LAG: rows with a skew
+// (trmc_plan_set_lag) -- then the step is a per-lane quantity; without, it is wave-uniform and lives in SGPRs.
+#ifndef TRMC_LEAN_WAVES
+#define TRMC_LEAN_WAVES 6
+#endif
+constexpr int kLeanRing = 2;
+constexpr int kLeanCols = 12;
+
+__device__ __forceinline__ float lean_edge_get(int32_t u, int32_t l, uint32_t &flags, uint32_t ahead_bit, uint32_t never_bit,
+                                               const unsigned long long *plane_row, const unsigned long long *ring, int32_t ws,
+                                               uint32_t want, const FlowArgs &a, bool &dead)
+{
+    if (!(flags & (ahead_bit | never_bit))) {
+        const unsigned long long *slot = ring + (size_t)(ws & (kLeanRing - 1)) * kFlowBlock + l;
+        unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((int32_t)((uint32_t)(v >> 32) - want) < 0) { // not produced yet: the producer is a wave of this block
+            uint32_t polls = 0;
+            uint64_t t_start = 0;
+            do {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (flow_watchdog(polls, t_start, a)) dead = true;
+            } while ((int32_t)((uint32_t)(v >> 32) - want) < 0 && !dead);
+        }
+        if ((uint32_t)(v >> 32) == want) return __uint_as_float((uint32_t)v);
+        flags |= ahead_bit; // overwritten: the producer runs ahead of what the ring holds
+    }
+    return flow_wait(plane_row + u, want, a, dead);
+}
+
+template <bool LAG>
+__global__ void __launch_bounds__(kFlowBlock, TRMC_LEAN_WAVES)
+k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
+{
+    using M = DevMathF;
+    __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    __shared__ float s_par[kLeanCols * kFlowBlock];                 // [column][thread]
+    __shared__ unsigned long long s_ring[kLeanRing * kFlowBlock];   // [step % 2][thread] granules
+    __shared__ int32_t s_blk;
+    if (threadIdx.x == 0) s_blk = atomicAdd(a.ticket, 1);
+#pragma unroll
+    for (int j = 0; j < kLeanRing; ++j) s_ring[j * kFlowBlock + threadIdx.x] = 0ull;
+    M m{stage_pow_tables(s_tab), false}; // (its barrier also publishes s_blk and the cleared ring)
+    m.sane = a.sane;
+    const int32_t blk_base = a.first + s_blk * kFlowBlock;
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * s_blk] = wall_clock64();
+    if (a.prio) { // the costlier a wavefront, the higher its issue priority (topology.cpp)
+        const int pr = __builtin_amdgcn_readfirstlane((int)a.prio[(s_blk * kFlowBlock + (int32_t)threadIdx.x) >> 6]);
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    if (blk_base + (int32_t)threadIdx.x >= a.nseg) return; // (no block-wide barrier below)
+    const uint32_t su = (uint32_t)(blk_base + (int32_t)threadIdx.x);
+    {
+        const uint32_t ob = su * 4u;
+        float *sp = s_par + threadIdx.x;
+        sp[0 * kFlowBlock] = at(a.dx, ob);
+        sp[1 * kFlowBlock] = at(a.bw, ob);
+        sp[2 * kFlowBlock] = at(a.twcc, ob);
+        sp[3 * kFlowBlock] = at(a.n, ob);
+        sp[4 * kFlowBlock] = at(a.ncc, ob);
+        sp[5 * kFlowBlock] = at(a.s0, ob);
+        sp[6 * kFlowBlock] = at(a.z, ob);
+        sp[7 * kFlowBlock] = at(a.bfd, ob);
+        sp[8 * kFlowBlock] = at(a.sqrt_s0, ob);
+        sp[9 * kFlowBlock] = at(a.sq1pz2, ob);
+        sp[10 * kFlowBlock] = at(a.s0_n, ob);
+        sp[11 * kFlowBlock] = at(a.s0_ncc, ob);
+    }
+    const float dt = a.dt_col ? a.dt_col[su] : a.dt;
+    const int32_t lag = LAG ? a.lag[su] : 0;
+    const int32_t t_lo = LAG ? max(t0 - lag, 0) + 1 : t0 + 1;
+    const int32_t t_hi = LAG ? min(t1 - lag, a.nsteps) : min(t1, a.nsteps);
+    // flag bits: 0 edge 0 ahead, 1 edge 0 never through the ring, 2 / 3 the same for edge 1, 4 more than two upstream
+    // rows, 5 reservoir row, 6 gage row
+    uint32_t flags = 0;
+    int32_t u0, u1;
+    {
+        const int2 up = a.up2[su];
+        u0 = up.x;
+        u1 = up.y >= 0 ? (up.y & 0x3fffffff) : -1;
+        if (up.y >= 0 && (up.y & 0x40000000)) flags |= 16u;
+        auto ring_ok = [&](int32_t u) { return u >= blk_base && u < blk_base + kFlowBlock && (!LAG || a.lag[u] == lag); };
+        if (u0 >= 0 && !ring_ok(u0)) flags |= 2u;
+        if (u1 >= 0 && !ring_ok(u1)) flags |= 8u;
+        if (a.res_of_pos && a.res_of_pos[su] >= 0) flags |= 32u;
+        if (a.gage_of_pos && a.gage_of_pos[su] >= 0) flags |= 64u;
+#ifdef TRMC_FLOW_EXP_NOUP
+        u0 = u1 = -1;
+#endif
+    }
+    const size_t np = (size_t)a.nseg_pad;
+    const uint32_t out_idx = (uint32_t)a.row_of_pos[su] * (uint32_t)a.nsteps * 3u; // (the host checks nseg * nsteps * 3 < 2**32)
+    bool dead = false;
+    if (t_lo > t_hi) return;
+    float q_prev = flow_wait(a.gran + (size_t)(t_lo - 1) * np + su, a.tag_base + (uint32_t)(t_lo - 1), a, dead);
+    float d_prev = a.d_state[su];
+    __hip_atomic_store(s_ring + (size_t)((t_lo - 1) & (kLeanRing - 1)) * kFlowBlock + threadIdx.x,
+                       ((unsigned long long)(a.tag_base + (uint32_t)(t_lo - 1)) << 32) | (unsigned long long)__float_as_uint(q_prev),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    float ql = 0.0f;
+    uint32_t its = 0; // iterations: low 24 bits the sum of min(iterations, 3), high 8 bits those of the last step
+
+    for (int32_t t = t_lo; t <= t_hi && !dead; ++t) {
+        const uint32_t tag_p = a.tag_base + (uint32_t)(t - 1);
+        const unsigned long long *g_prev = a.gran + (size_t)(t - 1) * np;
+        if (t == t_lo || (t - 1) % a.qts == 0) ql = a.qlat_tm[(size_t)((t - 1) / a.qts) * np + su];
+        if ((t & 15) == 0) flags &= ~5u; // a producer that ran ahead may have been caught up with: try the ring again
+        // junction sum in the reference's order (mc_reach.pyx:499-505)
+        float qup = 0.0f;
+        if (u0 >= 0) qup += lean_edge_get(u0, u0 - blk_base, flags, 1u, 2u, g_prev, s_ring, t - 1, tag_p, a, dead);
+        if (u1 >= 0) qup += lean_edge_get(u1, u1 - blk_base, flags, 4u, 8u, g_prev, s_ring, t - 1, tag_p, a, dead);
+        if (flags & 16u) {
+            const int32_t k1 = a.up_ptr[su + 1];
+            for (int32_t e = a.up_ptr[su] + 2; e < k1; ++e) qup += flow_wait(g_prev + a.up_idx[e], tag_p, a, dead);
+        }
+        float q_new, v_new, d_new;
+        if (flags & 32u) { // level-pool reservoir row (see k_mc_step)
+            const int32_t ri = a.res_of_pos[su];
+            const float *rp = a.res_par + (size_t)ri * 9;
+            const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
+            float H = d_prev;
+            q_new = trmc::levelpool_step<float, M>(qup, 0.0f, a.res_dt, H, lp, m);
+            v_new = 0.0f;
+            d_new = H;
+            a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = qup;
+            its &= 0x00ffffffu;
+        } else {
+            const float *sp = s_par + threadIdx.x;
+            trmc::ChannelParams<float> p;
+            p.dt = dt;
+            p.dx = sp[0 * kFlowBlock];
+            p.bw = sp[1 * kFlowBlock];
+            p.twcc = sp[2 * kFlowBlock];
+            p.n = sp[3 * kFlowBlock];
+            p.ncc = sp[4 * kFlowBlock];
+            p.s0 = sp[5 * kFlowBlock];
+            p.tw = p.cs = 0.0f;
+            trmc::ChannelConst<float> c;
+            c.z = sp[6 * kFlowBlock];
+            c.bfd = sp[7 * kFlowBlock];
+            c.sqrt_s0 = sp[8 * kFlowBlock];
+            c.sq1pz2 = sp[9 * kFlowBlock];
+            c.s0_n = sp[10 * kFlowBlock];
+            c.s0_ncc = sp[11 * kFlowBlock];
+            c.two_sq = 2.0f * c.sq1pz2;
+            c.half_dt = p.dt / 2.0f;
+            c.fp_ok = (p.twcc > 0.0f) && (p.ncc > 0.0f);
+            trmc::Inflow<float> f;
+            f.qup = qup;
+            f.quc = qup;
+            f.qdp = q_prev;
+            f.ql = ql;
+            m.coef_ok = coef_guard(p.dt, f.ql);
+            const trmc::StepResult<float> r = trmc::mc_segment_step<float, M>(p, c, f, d_prev, m);
+            q_new = r.qdc;
+            v_new = r.velc;
+            d_new = r.depthc;
+            its = ((its + (uint32_t)min(r.iters, 3)) & 0x00ffffffu) | ((uint32_t)min(r.iters, 255) << 24);
+            if (flags & 64u) { // streamflow nudging (see k_mc_step)
+                const size_t e = (size_t)a.gage_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1);
+                const uint8_t mode = a.da_mode[e];
+                float nudge = 0.0f;
+                if (mode == 1) {
+                    nudge = a.da_a[e] - q_new;
+                    q_new = a.da_a[e];
+                } else if (mode == 2) {
+                    nudge = (a.da_a[e] - q_new) * a.da_w[e];
+                    q_new = q_new + nudge;
+                }
+                a.da_nudge[e] = nudge;
+            }
+        }
+        {
+            const unsigned long long g = ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(q_new);
+            __hip_atomic_store(s_ring + (size_t)(t & (kLeanRing - 1)) * kFlowBlock + threadIdx.x, g, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(a.gran + (size_t)t * np + su, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        q_prev = q_new;
+        d_prev = d_new;
+#ifndef TRMC_FLOW_EXP_NOOUT
+        {
+            float *o = a.out + (size_t)(out_idx + (uint32_t)(t - 1) * 3u);
+            o[0] = q_new;
+            o[1] = v_new;
+            o[2] = d_new;
+        }
+#endif
+    }
+    if (a.dbg) atomicMax(a.dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
+    a.d_state[su] = d_prev;
+    if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)(its >> 24);
+    if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535u, (uint32_t)a.it_sum[su] + (its & 0x00ffffffu));
+}
+
 // initial state of the dataflow engine: granule row 0 <- qu0 (mc_reach.pyx:361), depth column <- h0
 __global__ void __launch_bounds__(kBlock)
 k_flow_init(const float *__restrict__ q0, const int32_t *__restrict__ row_of_pos, unsigned long long *gran, float *d_state,
@@ -1273,6 +1477,7 @@ struct trmc_plan {
     bool flow = false;
     uint32_t tag_base = 1;               // tag of step 0 of the current window (0 is never a live tag)
     int32_t tag_span = 0;                // tags the current window may use (nsteps + 1)
+    DevBuf prio;                         // issue priority per wavefront
     DevBuf d_state, ticket, rank, dbg;   // depth column; {block ticket, abort flag}; level rank of a position inside its block
     uint64_t watchdog_ticks = 300000000; // 3 s of wall_clock64 (100 MHz)
     trmc_stats stats{};
@@ -1621,6 +1826,7 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     a.ticket = (int32_t *)pl->ticket.p;
     a.watchdog_ticks = pl->watchdog_ticks;
     a.dbg = std::getenv("TRMC_FLOW_DEBUG") ? (unsigned long long *)pl->dbg.p : nullptr;
+    a.prio = std::getenv("TRMC_FLOW_NOPRIO") ? nullptr : (const uint8_t *)pl->prio.p;
     return a;
 }
 
@@ -1693,7 +1899,21 @@ int flow_route_advance(trmc_plan *pl, int t_end)
         const FlowArgs a = flow_args(pl, r.nsteps, r.qts, r.short_ts != 0);
         HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, sizeof(int32_t), st)); // block tickets restart; the abort flag stays
         const dim3 grid((unsigned)pl->topo.nblocks), block(kFlowBlock);
-        if (r.short_ts)
+        // The lean form pays where every block of the launch is resident at once (6 workgroups per compute unit: one rank
+        // of a multi-GPU job, a regional network) -- there the pace is set by latency and by the slowest wavefront, and
+        // occupancy plus wavefront priorities win (349 k rows, 288 steps: 4.8 ms against 6.1 ms).  Where blocks run in many
+        // rounds (CONUS on one GPU: 10 661 blocks) throughput counts and the staged form, which spills nothing and writes
+        // whole sectors, is ahead (25.4 ms against 30.5 ms).
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+        const char *force = std::getenv("TRMC_FLOW_LEAN"); // "0" / "1": A/B measurements
+        const bool lean = (uint64_t)pl->nseg * (uint64_t)r.nsteps * 3ull < (1ull << 32)
+                          && (force ? force[0] == '1' : pl->topo.nblocks <= TRMC_LEAN_WAVES * ncu);
+        if (r.short_ts && lean && a.lag)
+            hipLaunchKernelGGL((k_mc_flow_lean<true>), grid, block, 0, st, a, r.t_done, t_end);
+        else if (r.short_ts && lean)
+            hipLaunchKernelGGL((k_mc_flow_lean<false>), grid, block, 0, st, a, r.t_done, t_end);
+        else if (r.short_ts)
             hipLaunchKernelGGL((k_mc_flow<true>), grid, block, 0, st, a, r.t_done, t_end);
         else
             hipLaunchKernelGGL((k_mc_flow<false>), grid, block, 0, st, a, r.t_done, t_end);
@@ -1969,6 +2189,12 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
         if ((rc = upload_i32(pl->up2, up2, 2))) return bail(rc);
     }
     if (pl->flow && (rc = upload_i32(pl->rank, pl->topo.rank_of_pos, 1))) return bail(rc);
+    if (pl->flow) {
+        if ((rc = pl->prio.ensure(pl->topo.prio_of_wave.size() + 1))) return bail(rc);
+        if (!pl->topo.prio_of_wave.empty()
+            && hipMemcpy(pl->prio.p, pl->topo.prio_of_wave.data(), pl->topo.prio_of_wave.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(TRMC_EHIP, "uploading the wavefront priorities failed"));
+    }
     if ((rc = upload_i32(pl->row_of_pos, pl->topo.row_of_pos, 1))) return bail(rc);
     if ((rc = upload_i32(pl->pos_of_row, pl->topo.pos_of_row, 1))) return bail(rc);
     if ((rc = pl->it_prev.ensure((size_t)pl->nseg_pad))) return bail(rc);
@@ -1981,7 +2207,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();

@@ -203,3 +203,87 @@ def test_flatten_network_matches_reference_structs():
     assert up_idx[up_ptr[1]:up_ptr[2]].tolist() == [0] and in_reach.all()
     with pytest.raises(ValueError, match="single waterbody node"):
         _flatten_network([([1, 7], 1)], {}, np.array([1, 7], np.int64))
+
+
+# ---- block order of the dataflow engine (host only) -------------------------------------------------------
+def _check_block_order(up_ptr, up_idx, boundary, hint, tiers):
+    from troute_amd.plan import topology_blocks, topology_levels
+    n = len(up_ptr) - 1
+    pos, rank, B, nb = topology_blocks(up_ptr, up_idx, boundary, hint, tiers)
+    lvl, _, _ = topology_levels(up_ptr, up_idx, boundary)
+    assert sorted(pos) == list(range(n))                              # a permutation
+    nbound = 0 if boundary is None else int(np.count_nonzero(boundary))
+    if nbound:
+        b_rows = np.flatnonzero(boundary)
+        assert np.array_equal(np.sort(pos[b_rows]), np.arange(nbound))     # boundary rows first, ascending row order
+        assert np.array_equal(pos[b_rows], np.arange(nbound))
+    assert nb == -(-(n - nbound) // B)
+    blk = (pos - nbound) // B
+    for r in range(n):
+        if boundary is not None and boundary[r]:
+            continue
+        for u in up_idx[up_ptr[r]:up_ptr[r + 1]]:
+            if boundary is not None and boundary[u]:
+                continue
+            assert blk[u] <= blk[r], "a row needs a LATER block"
+            if blk[u] == blk[r]:
+                assert rank[u] < rank[r], "ranks must grow along the edges inside a block"
+    assert (rank[lvl <= 0] == 0).all()                                # headwaters and boundary rows trail nothing
+    return pos, rank, B
+
+
+def test_block_order_is_a_valid_dataflow_order():
+    rng = np.random.default_rng(5)
+    n = 3000
+    to = np.full(n, -1, np.int64)
+    for i in range(n):                                                  # random forest, rows in random order
+        if rng.random() > 0.003:
+            cand = rng.integers(i + 1, min(n, i + 40)) if i + 1 < n else -1
+            to[i] = cand
+    perm = rng.permutation(n)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    to_p = np.full(n, -1, np.int64)
+    to_p[inv] = np.where(to >= 0, inv[np.maximum(to, 0)], -1)           # relabelled
+    ups = [[] for _ in range(n)]
+    for r in range(n):
+        if to_p[r] >= 0:
+            ups[to_p[r]].append(r)
+    up_ptr, up_idx = csr_from_lists(ups)
+    hint = rng.integers(0, 49, n).astype(np.uint8)
+    for boundary in (None, (rng.random(n) < 0.01).astype(np.uint8)):
+        if boundary is not None:                                        # boundary rows have no routed upstream of their own here
+            up2 = [([] if boundary[r] else ups[r]) for r in range(n)]
+            bp, bi = csr_from_lists(up2)
+        else:
+            bp, bi = up_ptr, up_idx
+        for h in (None, hint):
+            for tiers in (True, False):
+                _check_block_order(bp, bi, boundary, h, tiers)
+
+
+def test_block_order_groups_rows_by_cost_tier_and_keeps_chains_together():
+    # one chain of 600 rows: post-order is the chain itself, so every block is a run of consecutive rows and the ranks
+    # inside a block count up along it
+    n = 600
+    ups = [[]] + [[i - 1] for i in range(1, n)]
+    up_ptr, up_idx = csr_from_lists(ups)
+    pos, rank, B = _check_block_order(up_ptr, up_idx, None, None, False)
+    for b in range(-(-n // B)):
+        rows = np.flatnonzero(pos // B == b)
+        assert rows.min() == b * B and rows.max() == min(n, (b + 1) * B) - 1
+        assert np.array_equal(rank[rows], rows - rows.min())
+    # with a hint and tiers: rows of a cheap tier never sit behind rows of a costlier one
+    rng = np.random.default_rng(2)
+    n = 4000
+    to = np.array([rng.integers(i + 1, min(n, i + 30)) if i + 1 < n else -1 for i in range(n)])
+    ups = [[] for _ in range(n)]
+    for r in range(n - 1):
+        ups[to[r]].append(r)
+    up_ptr, up_idx = csr_from_lists(ups)
+    hint = np.where(np.arange(n) > 3000, 48, 16).astype(np.uint8)      # the downstream end is costly
+    pos, _, B = _check_block_order(up_ptr, up_idx, None, hint, True)
+    blocks_costly = np.unique(pos[hint == 48] // B)
+    blocks_cheap_only = np.setdiff1d(np.unique(pos[hint == 16] // B), blocks_costly)
+    assert blocks_cheap_only.max() < blocks_costly.min()                # cheap blocks first
+    assert blocks_costly.size <= -(-int((hint == 48).sum() + 1) // B) + 1

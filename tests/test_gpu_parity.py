@@ -117,10 +117,13 @@ def test_lowercolorado_return_tuple_shape(lc):
     assert r[6].shape == (lc.nseg, lc.nts) and len(r[7]) == 3 and r[8].shape == (0, lc.nts + 1) and len(r[9]) == 4
 
 
+@pytest.mark.parametrize("engine", ["flow", "levels"])
 @pytest.mark.parametrize("short", [True, False])
-def test_lowercolorado_fp32_bit_identical_to_reference_golden(lc, short):
+def test_lowercolorado_fp32_bit_identical_to_reference_golden(lc, short, engine, monkeypatch):
     """Golden = reference Fortran kernel symbol driven through the restated loop (make_fixtures.py):
-    12 time slices x every segment and 100 probe segments x every step, both timestep modes."""
+    12 time slices x every segment and 100 probe segments x every step, both timestep modes, on BOTH engines
+    (the dataflow engine k_mc_flow and the level engine k_mc_step)."""
+    monkeypatch.setenv("TRMC_ENGINE", engine)
     _, fvd = route_lc(lc, short)
     g = lc.golden()
     tag = "shortts" if short else "fullts"
