@@ -125,10 +125,18 @@ def compute_nhd_routing_v02(
 ):
     """Route every independent network of the call for ``nts`` timesteps.
 
-    Returns the reference's ``results`` list: one 10-tuple per tailwater of ``reaches_bytw`` (in its
-    iteration order), each shaped like ``compute_network_structured``'s return
-    (mc_reach.pyx:811-845): ``(ids, flowveldepth[n, nts*3], 0, (..), (..), (..), upstream[n, nts],
-    (..), nudge, (..))``.
+    Returns what the reference returns (compute.py:1738): ``(results, subnetwork_list)``.  ``results`` has one
+    10-tuple per tailwater of ``reaches_bytw`` (in its iteration order), each shaped like
+    ``compute_network_structured``'s return (mc_reach.pyx:811-845): ``(ids, flowveldepth[n, nts*3], 0, (..), (..),
+    (..), upstream[n, nts], (..), nudge, (..))``; ``subnetwork_list`` is handed back unchanged (the reference fills
+    it with its sub-network decomposition for the by-subnetwork methods and passes it through for the others; here
+    every network of the call is ONE plan whatever the method, so there is nothing to cache -- ``nwm_route`` only
+    stores it and passes it back in, nwm_routing/__main__.py:1256-1257).
+
+    ``flowveldepth_interorder`` (the reference consumes the caller's dictionary in its "bmi" method, compute.py:1588-
+    1589,:1649-1655,:1729-1732): ``{segment id: {"results": flowveldepth row [nts*3]}}`` -- segments routed elsewhere
+    whose hydrographs enter this call's networks.  They join the table as rows with a prescribed hydrograph
+    (``upstream_results`` of the kernel callable) and are left out of the results, as in the reference.
     """
     if parallel_compute_method not in _PARALLEL_METHODS and parallel_compute_method is not None:
         raise ValueError(f"unknown parallel_compute_method {parallel_compute_method!r}")
@@ -138,9 +146,7 @@ def compute_nhd_routing_v02(
             raise NotImplementedError(
                 f"{name} is not empty: reservoir data assimilation (hybrid persistence, RFC forecasts, Great "
                 "Lakes) is outside the Muskingum-Cunge path this package replaces")
-    if flowveldepth_interorder:
-        raise NotImplementedError("flowveldepth_interorder hand-off is only needed by the reference's "
-                                  "sub-network orders; call compute_network_structured for that")
+    offnetwork_upstreams = sorted(int(k) for k in flowveldepth_interorder) if flowveldepth_interorder else []
 
     # compute.py:548-549
     param_df = param_df.copy()
@@ -178,11 +184,28 @@ def compute_nhd_routing_v02(
         waterbodies_sub = np.zeros((0, 0), dtype="float64")
         types_sub = np.zeros((0, 0), dtype="int32")
 
-    table = param_df.loc[sorted(seg_ids), cols].reindex(sorted(seg_ids) + lake_segs).sort_index()   # :1447-1465
+    off_segs = [u for u in offnetwork_upstreams if u in param_ids]      # compute.py:1586-1589: joined to the table
+    off_lakes = [u for u in offnetwork_upstreams if u not in param_ids]
+    if off_lakes:
+        if _is_empty(waterbodies_df) or any(l not in waterbodies_df.index for l in off_lakes):
+            raise ValueError(f"flowveldepth_interorder key {off_lakes[0]} is neither a segment of param_df nor a waterbody")
+        if not have_wb:
+            wb_cols = ["LkArea", "LkMxE", "OrificeA", "OrificeC", "OrificeE", "WeirC", "WeirE", "WeirL", "ifd", "qd0", "h0"]
+        lake_segs = sorted(set(lake_segs) | set(off_lakes))
+        waterbodies_sub = waterbodies_df.loc[lake_segs, wb_cols].values.astype("float64")
+        if not _is_empty(waterbody_types_df):
+            types_sub = waterbody_types_df.loc[lake_segs, ["reservoir_type"]].values.astype("int32")
+    seg_all = sorted(set(seg_ids) | set(off_segs))
+    table = param_df.loc[seg_all, cols].reindex(seg_all + lake_segs).sort_index()                   # :1447-1465
     ids = table.index.values.astype("int64")
     nseg = ids.shape[0]
     q0_v = q0.reindex(table.index).fillna(0.0).values.astype("float32")
     qlat_v = qlats.reindex(table.index).fillna(0.0).values.astype("float32")
+
+    upstream_results = {}
+    for u in offnetwork_upstreams:                                       # compute.py:1649-1655
+        upstream_results[u] = {"results": np.asarray(flowveldepth_interorder[u]["results"]),
+                               "position_index": int(table.index.get_loc(u))}
 
     e_f2, e_f1, e_i1 = np.zeros((0, 0), "float32"), np.zeros(0, "float32"), np.zeros(0, "int32")
     # streamflow nudging tables of the whole call (reference: per tailwater, compute.py:1468-1469)
@@ -210,11 +233,14 @@ def compute_nhd_routing_v02(
         e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
         e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
         e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
-        {}, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device)
+        upstream_results, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device)
+    ids = r[0].astype("int64")                   # (the rows of upstream_results are masked out, mc_reach.pyx:451,:812)
+    nseg = ids.shape[0]
     fvd, upstream = r[1], r[6]
     gage_ids, lastobs_times, lastobs_values = r[3]
     nudge = r[8]
-    gage_row = np.asarray(da_byseg, dtype=np.int64)
+    gage_row = np.searchsorted(ids, table.index.values[np.asarray(da_byseg, dtype=np.int64)]) if ngage else \
+        np.zeros(0, dtype=np.int64)                                     # gage rows in the (masked) result order
 
     # ---- back to the reference's per-tailwater result list ---------------------------------------------
     owner = np.full(nseg, -1, dtype=np.int64)
@@ -238,7 +264,7 @@ def compute_nhd_routing_v02(
             nudge[gk] if ngage else np.zeros((0, nts + 1), dtype="float32"),
             (e_i1, e_f1, e_i1, e_i1),
         ))
-    return results
+    return results, subnetwork_list
 
 
 def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt, nts, q0, qlats, qts_subdivisions, usgs_df,
@@ -258,6 +284,11 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
         return df is None or getattr(df, "empty", True)
     if refactored_diffusive_domain:
         raise NotImplementedError("the refactored hydrofabric is not covered by the device solver")
+    if da_parameter_dict and "diffusive_streamflow_nudging" in da_parameter_dict and not empty(usgs_df):
+        # the reference forwards usgs_df to the solver in this case (compute.py:1799-1803); nudging inside the
+        # diffusive solver is not covered here, and dropping it silently would change results
+        raise NotImplementedError("diffusive_streamflow_nudging: data assimilation inside the diffusive solver is "
+                                  "not covered by the device solver")
     tws = list(diffusive_network_data)
     inputs = []
     for tw in tws:

@@ -224,8 +224,14 @@ def compute_network_structured(
         if res.shape[0] != nsteps:
             raise ValueError("upstream_results hydrograph length does not match nsteps")
         bvals[fill_index] = res
-        q0[fill_index, 0] = initial_conditions[fill_index, 0]
-        q0[fill_index, 2] = initial_conditions[fill_index, 2]
+        if len(lake_numbers_col) and int(data_idx[fill_index]) in set(int(x) for x in lake_numbers_col):
+            # an off-network waterbody: its initial flow is the reservoir's qd0 column, the depth slot stays zero
+            # (mc_reach.pyx:463-465; initial_conditions holds NaN for lake ids in the reference's by-subnetwork driver)
+            q0[fill_index, 0] = np.asarray(wbody_cols, dtype=np.float64)[
+                binary_find(lake_numbers_col, [int(data_idx[fill_index])])[0], 9]
+        else:
+            q0[fill_index, 0] = initial_conditions[fill_index, 0]        # mc_reach.pyx:467-468
+            q0[fill_index, 2] = initial_conditions[fill_index, 2]
     # ---- streamflow nudging (mc_reach.pyx:380-411): tables resolved on the host, applied on the GPU ----
     nudging = None
     if gages_size:

@@ -62,7 +62,7 @@ def test_gage_frames_through_compute_nhd_routing_v02(short):
     results = compute_nhd_routing_v02(
         conn, rconn, {}, reaches_bytw, "V02-structured", "by-network", 10000, 4, None, lc.dt, lc.nts, lc.qts, ind,
         param_df, q0_df, qlat_df, usgs_df, lastobs_df, e, e, e, e, e, e, e, e, e, {"da_decay_coefficient": decay},
-        short, False, e, {}, e, False, [{}, {}])
+        short, False, e, {}, e, False, [{}, {}])[0]
     assert len(results) == 1
     r = results[0]
     row = {int(s): i for i, s in enumerate(lc.ids)}

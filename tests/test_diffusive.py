@@ -354,6 +354,10 @@ def test_gpu_hybrid_driver_mc_then_diffusive():
     results = compute_nhd_routing_v02(
         conn, rconn, {}, reaches_bytw, "V02-structured", "by-network", 10000, 4, t0, lc.dt, nts, lc.qts, ind, full, q0,
         qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, e, {}, e, False, [{}, {}])
+    # nwm_route's own unpacking of the return value (nwm_routing/__main__.py:1256-1257)
+    subnetwork_list = results[1]
+    results = results[0]
+    assert subnetwork_list == [{}, {}]
     rd = compute_diffusive_routing(results, {tw: dn}, 1, t0, lc.dt, nts, q0, qlat_df, lc.qts, e, e, {}, e, e, None, None, e, e)
     assert len(rd) == 1 and len(rd[0]) == 10
     ids, dat = rd[0][0], rd[0][1]

@@ -21,13 +21,20 @@ def frames(ids, params9, q0, qlat):
     return param_df, q0_df, qlat_df
 
 
-def call(conn, param_df, q0_df, qlat_df, nts, qts, short, method="by-network"):
+def call(conn, param_df, q0_df, qlat_df, nts, qts, short, method="by-network", interorder=None):
     ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
     e = pd.DataFrame()
-    return compute_nhd_routing_v02(
+    sub_in = [{}, {}]
+    out = compute_nhd_routing_v02(
         conn, rconn, {}, reaches_bytw, "V02-structured", method, 10000, 4, None, 300.0, nts, qts, ind,
         param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, short, False, e, {}, e, False,
-        [{}, {}]), reaches_bytw, ind
+        sub_in, {} if interorder is None else interorder)
+    # what the reference returns (compute.py:1738) and how nwm_route unpacks it (nwm_routing/__main__.py:1256-1257)
+    assert isinstance(out, tuple) and len(out) == 2
+    subnetwork_list = out[1]
+    results = out[0]
+    assert subnetwork_list is sub_in
+    return results, reaches_bytw, ind
 
 
 @pytest.mark.parametrize("short", [True, False])
@@ -98,3 +105,82 @@ def test_plugin_seam_and_unsupported_inputs():
         compute_nhd_routing_v02(conn, rconn, {}, reaches_bytw, "V02-structured", "serial", 1, 1, None, 300.0, 48, 12,
                                 ind, param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, e,
                                 {}, e, False, [{}, {}])
+
+
+def test_flowveldepth_interorder_feeds_the_call_like_upstream_results():
+    """The caller's flowveldepth_interorder (reference: the "bmi" method, compute.py:1588-1589,:1649-1655,:1729-1732):
+    route the upper part of a network, hand its tailwater's flowveldepth row to a second call that routes the rest, and
+    get the rows a single call over the whole network gives -- bit for bit -- with the handed-over segment left out."""
+    toy = H.load_toy()
+    conn = {int(k): v for k, v in toy["expected_connections"].items()}
+    ids = np.array(sorted(conn), np.int64)
+    rng = np.random.default_rng(8)
+    n = len(ids)
+    p = np.stack([np.full(n, 300.0), rng.uniform(300, 3000, n), rng.uniform(1, 9, n), np.zeros(n), np.zeros(n),
+                  np.full(n, 0.06), np.full(n, 0.12), rng.uniform(0.2, 1.5, n), rng.uniform(1e-3, 2e-2, n)], 1)
+    p[:, 3] = p[:, 2] * 5 / 3
+    p[:, 4] = 3 * p[:, 3]
+    p = p.astype(np.float32)
+    qlat = rng.uniform(0, 0.4, (n, 3)).astype(np.float32)
+    q0 = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    param_df, q0_df, qlat_df = frames(ids, p, q0, qlat)
+    nts, qts = 24, 12
+    whole, reaches_bytw, ind = call(conn, param_df, q0_df, qlat_df, nts, qts, True)
+    whole_rows = {int(s): r[1][i] for r in whole for i, s in enumerate(r[0])}
+    # cut at a segment that has upstream segments and a downstream one
+    rconn = nn.reverse_network(conn)
+    cut = next(s for s in sorted(conn) if rconn.get(s) and conn[s])
+    upper = nn.reachable(rconn, [cut])[cut]                 # everything that drains through `cut`
+    conn_up = {s: ([d for d in conn[s] if d in upper] if s != cut else []) for s in upper}
+    res_up, _, _ = call(conn_up, param_df, q0_df, qlat_df, nts, qts, True)
+    rows_up = {int(s): r[1][i] for r in res_up for i, s in enumerate(r[0])}
+    assert np.array_equal(rows_up[cut].view(np.uint32), whole_rows[cut].view(np.uint32))
+    lower = set(conn) - upper
+    conn_lo = {s: conn[s] for s in lower}
+    ind_lo, reaches_lo, rconn_lo = nn.organize_independent_networks(conn_lo)
+    tw = next(t for t in reaches_lo if conn[cut][0] in ind_lo[t])
+    ind_lo[tw] = dict(ind_lo[tw])
+    whole_tw = next(t for t in ind if conn[cut][0] in ind[t])
+    ind_lo[tw][conn[cut][0]] = list(ind[whole_tw][conn[cut][0]])   # the hand-over edge, in the junction's summation order
+    e = pd.DataFrame()
+    inter = {cut: {"results": rows_up[cut]}}
+    res_lo, sub = compute_nhd_routing_v02(
+        conn_lo, rconn_lo, {}, reaches_lo, "V02-structured", "serial", 10000, 4, None, 300.0, nts, qts, ind_lo,
+        param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, e, {}, e, False, [{}, {}], inter)
+    got = {int(s): r[1][i] for r in res_lo for i, s in enumerate(r[0])}
+    assert cut not in got and set(got) == lower
+    for s in lower:
+        assert np.array_equal(got[s].view(np.uint32), whole_rows[s].view(np.uint32)), s
+
+
+def test_upstream_results_of_a_waterbody_seed_its_outflow_not_the_nan_initial_condition():
+    """An off-network upstream row that is a lake: the reference seeds its time-0 flow from the waterbody table's qd0
+    column (mc_reach.pyx:463-465) -- the initial_conditions row of a lake id is NaN in its by-subnetwork driver."""
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+    rng = np.random.default_rng(1)
+    ids = np.array([10, 20, 30, 40], np.int64)            # 10 (lake, off-network) -> 20 -> 30 -> 40
+    n = 4
+    dv = np.stack([np.full(n, 300.0), rng.uniform(300, 3000, n), rng.uniform(1, 9, n), rng.uniform(10, 20, n),
+                   rng.uniform(30, 60, n), np.full(n, 0.06), np.full(n, 0.12), rng.uniform(0.2, 1.5, n),
+                   rng.uniform(1e-3, 2e-2, n)], 1).astype(np.float32)
+    cols = np.array(["dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0"], dtype=object)
+    nts, qts = 12, 12
+    qlat = rng.uniform(0, 0.4, (n, 1)).astype(np.float32)
+    q0 = rng.uniform(0.1, 1, (n, 3)).astype(np.float32)
+    q0[0] = np.nan                                          # what q0_sub.reindex(...) leaves for a lake id
+    hyd = rng.uniform(0.5, 2.0, (nts, 3)).astype(np.float32)
+    wbody = np.zeros((1, 11))
+    wbody[0, 9] = 1.75                                      # qd0
+    args = mc_only_args(nts, 300.0, qts, [[20, 30, 40]], {20: [10], 30: [20], 40: [30]}, ids, cols, dv, q0, qlat,
+                        upstream_results={10: {"results": hyd.reshape(-1), "position_index": 0}}, assume_short_ts=True)
+    args[10], args[11] = [10], wbody
+    r = compute_network_structured(*args)
+    assert np.array_equal(r[0], ids[1:]) and np.isfinite(r[1]).all()
+    # oracle: the lake row prefilled with its hydrograph, its time-0 flow = qd0, depth slot 0 (mc_reach.pyx:458-465)
+    q0o = q0.copy()
+    q0o[0] = (1.75, 0, 0)
+    init = np.zeros((n, nts + 1, 3), np.float32)
+    init[0, 1:, :] = hyd
+    want = O.network(nts, qts, [np.array([1, 2, 3])], [np.array([0])], dv, q0o, qlat, True, det=True,
+                     prefilled=np.array([1, 0, 0, 0], np.uint8), fvd_init=init)[1:, 1:, :]
+    assert np.array_equal(r[1].reshape(3, nts, 3).view(np.uint32), np.ascontiguousarray(want).view(np.uint32))

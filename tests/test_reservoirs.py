@@ -164,7 +164,7 @@ def test_gpu_compute_nhd_routing_v02_with_waterbodies():
     e = pd.DataFrame()
     res = compute_nhd_routing_v02(conn_wb, rconn, wbody_map, reaches_bytw, "V02-structured", "by-network", 10000, 4,
                                   None, lc.dt, nts, lc.qts, ind, param_df, q0_df, ql_df, e, e, e, e, e, e, e, e, e, e, e,
-                                  {}, True, False, wb_df, {}, e, False, [{}, {}])
+                                  {}, True, False, wb_df, {}, e, False, [{}, {}])[0]
     assert len(res) == 1 and np.array_equal(res[0][0], ids)
     args = mc_only_args(nts, lc.dt, lc.qts, reaches, net, ids, lc.data_cols, dv, q0, ql, assume_short_ts=True)
     args[3] = [(r, 1 if r[0] in lakeset else 0) for r in reaches]
