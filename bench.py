@@ -12,12 +12,20 @@ fp32 (the reference's arithmetic type), cold start -- forcing and topology alrea
 resident in HBM when the timed region starts, results (incl. the gathered outlet hydrographs) left in HBM in the reference's
 [segment][timestep][q,v,d] layout.
 
+The plan is tuned on day N (an untimed window) and TIMED on day N+1: the next day's forcing of the same basin, started
+from the state day N leaves in HBM.
+
 Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
-  roofline      dominant kernel (k_mc_step) against the 8 TB/s HBM roofline, timed with
-                HIP events on the plan's own stream inside this run
-  cpu_baseline  the reference Fortran kernel (oracle/_ref, amdflang -O2) driven by the
-                restated reference loop on this host's cores, bounded sample
-  full_ts       the same workload without the short-timestep assumption (level wavefront)
+  roofline          dominant kernel against the 8 TB/s HBM roofline, timed with HIP events on the plan's own stream
+                    inside this run
+  cpu_baseline      the reference Fortran kernel (oracle/_ref, amdflang -O2) over every segment, decomposed like the
+                    reference's by-subnetwork-jit method, C + OpenMP, bounded sample of the timesteps
+  untuned           the plan built from the topology alone, day N, cold start
+  value_with_d2h    outlet hydrographs + final state copied to the host inside the timed region
+  parity_mode       the whole flowveldepth array copied to the host inside the timed region
+  tuned_window_cold / independent_forcing_cold   the tuned plan on the very window it was tuned on / on an unrelated day
+  full_ts           the same workload without the short-timestep assumption (dataflow engine)
+  per_rank          (N > 1) every rank's device time
 """
 import argparse
 import json
@@ -54,77 +62,59 @@ def parse():
     ap.add_argument("--chunks", type=int, default=None, help="time chunks of the multi-GPU hand-off pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-ts", action="store_true")
-    ap.add_argument("--no-warm", action="store_true", help="skip the warm-start variant of the day")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the full-result D2H variant (9.4 GB)")
     ap.add_argument("--no-retune", action="store_true",
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: all hardware threads)")
     return ap.parse_args()
 
 
-def cpu_baseline(net, nsteps, qts, short_ts, target_s):
-    """Reference kernel on host cores over a bounded sample of the SAME workload.
+def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
+    """The reference's CPU path on this host's cores, over EVERY segment of the workload.
 
-    Sample = independent networks other than the dominant basin, smallest-cost subset
-    sized so the run lasts about `target_s` s; one network loop call per worker thread
-    (the reference's by-network parallelism, compute.py:1211-1395; ctypes drops the GIL).
+    Decomposition = the reference's by-subnetwork-jit method (compute.py:553-1209): sub-networks of at most
+    subnetwork_target_size = 10 000 segments (compute_parameters.py:51-56) in orders that run one after the other, the
+    sub-networks of an order as parallel jobs, tailwater hydrographs handed from order to order -- which is also how the
+    dominant basin (half of all segments) gets more than one core.  The time x segment loop and the job scheduling are
+    C + OpenMP (oracle/cpu_baseline.c) around the reference Fortran kernel symbol (oracle/_ref, amdflang -O2), so no
+    Python sits inside the clock.  Bounded sample: all segments, the first `ns` timesteps of the window, `ns` sized for
+    about `target_s` seconds at 1.5e6 segment-timesteps/s per thread.
     """
-    from concurrent.futures import ThreadPoolExecutor
-
     from oracle import oracle as O
-    from troute_amd import sharding
-    from troute_amd.plan import topology_levels
     from troute_amd.synthetic import upstream_csr
 
     kind, ref_name = "port", None
     if O.have_ref("libmc_ref_f32.so"):
         kind, ref_name = "reference", "libmc_ref_f32.so"
-    cores = os.cpu_count() or 1
+    threads = cpu_threads or os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or threads
+    except Exception:
+        physical = threads
     to = net["to"]
     nseg = to.shape[0]
-    outlet = sharding.outlet_of(to)
-    uniq, lab = np.unique(outlet, return_inverse=True)
-    sizes = np.bincount(lab)
-    per_thread = int(1.5e6 * target_s / nsteps)              # ~1.5 M seg-steps/s/core (SURVEY 6)
-    order = np.argsort(sizes, kind="stable")                  # small networks first
-    order = order[sizes[order] <= max(per_thread, int(sizes.min()))]   # a network never exceeds one thread's budget
-    take = order[np.cumsum(sizes[order]) <= per_thread * cores]
-    if take.size == 0:
-        take = order[:1]
-    part, _ = sharding.lpt_assign(sizes[take], cores)
-    net_worker = np.full(uniq.shape[0], -1, dtype=np.int64)
-    net_worker[take] = part
-    row_worker = net_worker[lab]
-    up_ptr, up_idx = upstream_csr(to)
-    from troute_amd.distributed import restrict_csr
-
-    jobs = []
-    for w in range(cores):
-        rows = np.flatnonzero(row_worker == w)
-        if rows.size == 0:
-            continue
-        g2l = np.full(nseg, -1, dtype=np.int64)
-        g2l[rows] = np.arange(rows.shape[0])
-        lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)
-        lvl, _, _ = topology_levels(lp, li)
-        jobs.append((lp, li, lvl, np.ascontiguousarray(net["params"][rows]),
-                     np.zeros((rows.shape[0], 3), np.float32), np.ascontiguousarray(net["qlat"][rows])))
-
-    def run(j):
-        lp, li, lvl, par, q0, ql = j
-        O.network_by_segment(nsteps, qts, lp, li, lvl, par, q0, ql, short_ts, ref_name=ref_name)
-        return par.shape[0]
-
-    O.lib()
+    ns = int(max(qts, min(nsteps, target_s * threads * 1.5e6 / nseg)))
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        done = sum(ex.map(run, jobs))
-    dt = time.perf_counter() - t0
+    order_ptr, job_ptr, rows = O.ordered_subnetworks(to, 10000)
+    up_ptr, up_idx = upstream_csr(to)
+    t_prep = time.perf_counter() - t0
+    q0 = np.zeros((nseg, 3), np.float32)
+    q, d, done, nthreads = O.cpu_baseline_route(ns, qts, short_ts, order_ptr, job_ptr, rows, up_ptr, up_idx, net["params"],
+                                                qlat, q0, ref_name=ref_name, nthreads=threads)
+    dt = O.cpu_baseline_route.last_seconds           # the C + OpenMP call alone (arrays allocated and touched before)
+    jobs = np.diff(order_ptr)
     return {
-        "value": done * nsteps / dt, "unit": "segment-timesteps/s", "cores": cores, "kind": kind,
-        "sample": f"{int(take.size)} of {int(uniq.shape[0])} independent networks ({done} segments; networks larger than "
-                  f"{per_thread} segments, incl. the dominant basin, left out) x "
-                  f"{nsteps} steps, {dt:.1f} s wall, {len(jobs)} threads, by-network parallelism",
+        "value": done / dt, "unit": "segment-timesteps/s", "cores": int(nthreads), "physical_cores": int(physical),
+        "kind": kind,
+        "per_thread": done / dt / max(nthreads, 1),
+        "sample": f"all {nseg} segments x the first {ns} of {nsteps} timesteps ({done} segment-timesteps), {dt:.1f} s wall; "
+                  f"reference decomposition by-subnetwork-jit: {int(job_ptr.shape[0] - 1)} sub-networks of <= 10000 segments in "
+                  f"{int(order_ptr.shape[0] - 1)} orders ({', '.join(str(int(j)) for j in jobs)} jobs), OpenMP dynamic, "
+                  f"C loop around the reference Fortran kernel; decomposition prepared in {t_prep:.1f} s outside the clock",
+        "_check": (q[:, ns], d),
     }
 
 
@@ -254,8 +244,13 @@ def main():
     if rank != 0:
         net = synthetic.generate(cache_dir=cache, **kw)
     t_gen = time.perf_counter() - t0
-    to, params, qlat = net["to"], net["params"], net["qlat"]
+    to, params = net["to"], net["params"]
     nseg = to.shape[0]
+    # day N: the window every plan is TUNED on (cold start).  Day N+1: the window that is TIMED -- the next day of the
+    # same basin (synthetic.forcing: yesterday's spatial pattern, row-wise lognormal day-to-day factor, a fifth of the
+    # rows drawn anew), started from the state day N ends in, which stays in HBM.
+    qlat_a = net["qlat"]
+    qlat_b = synthetic.forcing(nseg, qlat_a.shape[1], synthetic.DEFAULT_SEED + 1, previous=qlat_a)
     q0 = np.zeros((nseg, 3), dtype=np.float32)
 
     def all_gather_into(out, t):
@@ -270,36 +265,20 @@ def main():
             dist.all_gather(parts, mine)
             out.copy_(torch.stack(parts).to(out.device))
 
-    def make_router(hint):
-        r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint)
-        r.upload(a.nsteps, qlat, q0)
+    def make_router(hint, short_ts, qlat, state):
+        r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint,
+                          assume_short_ts=short_ts)
+        r.upload(a.nsteps, qlat, state)
         if use_dist:
             import torch
             r.enable_device_exchange(torch, torch.device("cuda", local_rank))
             r.upload_trunk()
         return r
 
-    t0 = time.perf_counter()
-    router = make_router(None)
-    t_plan = time.perf_counter() - t0
-
-    def route_once(short_ts):
+    def route_once(router, short_ts):
         if use_dist:   # every hand-off stays in HBM: gather kernels -> RCCL all-gather -> boundary rows
             return router.route_on_device(a.qts, short_ts, all_gather_into, a.chunks)
         return router.route_resident(a.qts, short_ts), None   # outlet hydrographs stay in HBM
-
-    # Plan tuning, outside the timed region: one window on the plain plan tells which rows are cheap (dry channel:
-    # one secant iteration) and which are not; the plan is rebuilt with that as its cost hint, so that the rows of a
-    # level sit grouped by cost and the step kernel's wavefronts are uniform.  Same results (tests/test_gpu_parity.py).
-    t_tune = 0.0
-    if not a.no_retune:
-        t0 = time.perf_counter()
-        router.collect_cost(True)
-        route_once(True)
-        hint = router.iteration_hint()
-        router.close()
-        router = make_router(hint)
-        t_tune = time.perf_counter() - t0
 
     def sync():
         if dist is not None:
@@ -307,18 +286,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(short_ts, steps, warmup):
+    def timed(router, short_ts, steps, warmup, d2h=None):
+        """EXACTLY `steps` routing windows between barriers; max over ranks.  d2h: None (results stay in HBM), "state"
+        (outlet hydrographs + final state copied to the host inside the clock: what a caller of the throughput mode
+        consumes) or "full" (the whole flowveldepth array: parity mode)."""
         for _ in range(warmup):
-            route_once(short_ts)
+            route_once(router, short_ts)
         sync()
         t0 = time.perf_counter()
-        mains, totals, launches = [], [], 0
+        mains, totals, launches, hyd = [], [], 0, None
         for _ in range(steps):
-            rows, hyd = route_once(short_ts)
+            rows, hyd = route_once(router, short_ts)
             st = router.last_stats["phase0"]
             mains.append(st["ms_main"])
             totals.append(st["ms_total"])
             launches = st["main_launches"]
+            if d2h == "state":
+                if hyd is None:
+                    hyd = router.outlet_hydrographs()
+                else:
+                    hyd = hyd.cpu().numpy()
+                router.plan0.download_final_state()
+            elif d2h == "full":
+                router.plan0.download_fvd()
         sync()
         el = time.perf_counter() - t0
         if dist is not None:
@@ -326,45 +316,107 @@ def main():
             t = torch.tensor([el], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, float(np.mean(mains)), float(np.mean(totals)), launches, router.last_stats, hyd
+        return {"el": el, "ms_main": float(np.mean(mains)), "ms_total": float(np.mean(totals)), "launches": launches,
+                "stats": router.last_stats, "hyd": hyd, "steps": steps}
 
-    el, ms_main, ms_total, launches, stats, hyd = timed(True, a.steps, a.warmup)
+    segsteps_job = nseg * a.nsteps
+    bytes_per = ALG_BYTES_PER_SEGSTEP * (a.precision // 32)
+
+    def rate(t):
+        return segsteps_job * t["steps"] / t["el"]
+
+    def frac(t):
+        return t["stats"]["phase0"]["segment_steps"] * bytes_per / (t["ms_main"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    # ---- 1. the plan as it is built from the topology alone: day N, cold start --------------------------------------
+    t0 = time.perf_counter()
+    router = make_router(None, True, qlat_a, q0)
+    t_plan = time.perf_counter() - t0
+    engine = getattr(router.plan0, "engine", "levels")
+    usteps = max(1, min(a.steps, 2))
+    unt = timed(router, True, usteps, 1)
+    untuned = {"value": rate(unt), "unit": "segment-timesteps/s", "ms_per_step": unt["el"] / usteps * 1e3,
+               "ms_main": unt["ms_main"], "roofline_frac": frac(unt), "window": "day N, cold start"}
+
+    # ---- 2. tuning, outside every timed region: day N tells which rows are cheap (dry channel: one secant iteration)
+    # and which are not; the plan is rebuilt with that as its cost hint.  Same results (tests/test_gpu_parity.py).
+    t_tune = 0.0
+    if not a.no_retune:
+        t0 = time.perf_counter()
+        router.collect_cost(True)
+        route_once(router, True)
+        hint = router.iteration_hint()
+        router.close()
+        router = make_router(hint, True, qlat_a, q0)
+        route_once(router, True)                       # day N on the tuned plan: leaves the state day N+1 starts from
+        router.upload(a.nsteps, qlat_b, None)          # day N+1, warm start from the state resident in HBM
+        t_tune = time.perf_counter() - t0
+    else:
+        route_once(router, True)
+        router.upload(a.nsteps, qlat_b, None)
+
+    # ---- 3. the headline: day N+1 on the plan tuned on day N -----------------------------------------------------------
+    head = timed(router, True, a.steps, a.warmup)
+    hyd = head["hyd"]
     if hyd is None:
         hyd = router.outlet_hydrographs()          # one D2H after the timed region, to report/check
-        assert np.isfinite(hyd).all()
-    segsteps_job = nseg * a.nsteps
-    value = segsteps_job * a.steps / el
+    else:
+        hyd = hyd.cpu().numpy()
+    assert np.isfinite(hyd).all()
+    value = rate(head)
     info = router.plan0.info()
+    stats = head["stats"]
     seg0 = stats["phase0"]["segment_steps"]
-    achieved = seg0 * ALG_BYTES_PER_SEGSTEP * (a.precision // 32) / (ms_main * 1e-3) / 1e9
+    achieved = seg0 * bytes_per / (head["ms_main"] * 1e-3) / 1e9
+    per_rank = None
+    if dist is not None:                            # every rank's device time, so that a scaling run can be diagnosed
+        import torch
+        mine = torch.tensor([head["ms_main"], float(seg0)], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "ms_main": float(t[0]), "segment_steps": int(t[1])} for i, t in enumerate(allr)]
 
-    # the warm variant of SURVEY 8(d): the same day started from the state the cold day ended in (kept in HBM)
-    warm = None
-    if not use_dist and not a.no_warm:
-        router.plan0.upload_forcing(a.nsteps, qlat[router.rows0], None)
-        wsteps = max(1, min(a.steps, 3))
-        el_w, ms_main_w, _, launches_w, stats_w, _ = timed(True, wsteps, 1)
-        warm = {"value": segsteps_job * wsteps / el_w, "unit": "segment-timesteps/s", "ms_per_step": el_w / wsteps * 1e3,
-                "ms_main": ms_main_w,
-                "roofline_frac": stats_w["phase0"]["segment_steps"] * ALG_BYTES_PER_SEGSTEP * (a.precision // 32)
-                / (ms_main_w * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        router.upload(a.nsteps, qlat, q0)
+    extra = {}
+    if not use_dist:
+        dsteps = max(1, min(a.steps, 3))
+        w = timed(router, True, dsteps, 0, d2h="state")
+        extra["value_with_d2h"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / dsteps * 1e3,
+                                   "copied": f"outlet hydrographs [{hyd.shape[0]} x {hyd.shape[1]}] + final state [{nseg} x 3], "
+                                             "pageable host memory, inside the timed region"}
+        if not a.no_parity_mode:
+            w = timed(router, True, 1, 0, d2h="full")
+            extra["parity_mode"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] * 1e3,
+                                    "copied": f"full flowveldepth [{nseg} x {a.nsteps} x 3] ({nseg * a.nsteps * 12 / 1e9:.1f} GB), "
+                                              "pageable host memory, inside the timed region"}
+        # the window the plan was tuned on, cold start (round 1's headline configuration), and an unrelated day
+        router.upload(a.nsteps, qlat_a, q0)
+        w = timed(router, True, usteps, 1)
+        extra["tuned_window_cold"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / usteps * 1e3,
+                                      "ms_main": w["ms_main"], "roofline_frac": frac(w),
+                                      "window": "day N itself (the plan was tuned on it), cold start"}
+        router.upload(a.nsteps, synthetic.forcing(nseg, qlat_a.shape[1], synthetic.DEFAULT_SEED + 2), q0)
+        w = timed(router, True, usteps, 1)
+        extra["independent_forcing_cold"] = {"value": rate(w), "unit": "segment-timesteps/s",
+                                             "ms_per_step": w["el"] / usteps * 1e3, "ms_main": w["ms_main"],
+                                             "roofline_frac": frac(w),
+                                             "window": "an independent draw of the forcing (no row keeps its magnitude), cold start"}
+    router.close()
 
     full = None
     if not a.no_full_ts:
         fsteps = max(1, min(a.steps, 3))
-        el_f, ms_main_f, ms_total_f, launches_f, stats_f, _ = timed(False, fsteps, 1)
-        full = {
-            "value": segsteps_job * fsteps / el_f, "unit": "segment-timesteps/s", "ms_per_step": el_f / fsteps * 1e3,
-            "launches": launches_f, "ms_main": ms_main_f,
-            "roofline_frac": stats_f["phase0"]["segment_steps"] * ALG_BYTES_PER_SEGSTEP * (a.precision // 32)
-            / (ms_main_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        }
+        rf = make_router(None, False, qlat_b, q0)
+        f = timed(rf, False, fsteps, 1)
+        full = {"value": rate(f), "unit": "segment-timesteps/s", "ms_per_step": f["el"] / fsteps * 1e3,
+                "launches": f["launches"], "ms_main": f["ms_main"], "roofline_frac": frac(f),
+                "engine": getattr(rf.plan0, "engine", "levels"), "window": "day N+1 forcing, cold start"}
+        rf.close()
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(net, a.nsteps, a.qts, True, a.cpu_seconds)
+            cpu = cpu_baseline(net, qlat_a, a.nsteps, a.qts, True, a.cpu_seconds, a.cpu_threads)
+            cpu.pop("_check", None)
         except Exception as e:  # the baseline must never take the GPU number down with it
             cpu = {"error": repr(e)}
 
@@ -376,13 +428,8 @@ def main():
             diffusive = {"error": repr(e)}
 
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kernel = {"levels": "k_mc_step<float,true>" if a.precision == 32 else "k_mc_step<double,true>",
+                  "flow": "k_mc_flow_lean / k_mc_flow<true>"}[engine]
         line = {
             "metric": "segment-timesteps/sec, CONUS NHD 2.7M-seg MC",
             "value": value,
@@ -390,7 +437,7 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3,
+            "ms_per_step": head["el"] / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -399,31 +446,52 @@ def main():
             "config": {
                 "workload": "synthetic CONUS NHDPlus-shaped network, MC-only, 24 h @ 300 s dt (configs[2])",
                 "segments": int(nseg), "networks": int(len(net["net_sizes"])), "timesteps": a.nsteps,
-                "qts_subdivisions": a.qts, "assume_short_ts": True, "cold_start": True,
+                "qts_subdivisions": a.qts, "assume_short_ts": True,
+                "timed_window": "day N+1 (next-day forcing of the same basin), warm start from the state day N leaves in HBM",
                 "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
+                "engine": engine,
                 "generate_s": round(t_gen, 2), "plan_s": round(t_plan, 2),
-                "plan_order": "rows of a level ordered by their secant-iteration cost in a tuning window (untimed)"
+                "plan_order": "rows grouped by their secant-iteration cost over day N (untimed tuning window); timed on day N+1"
                 if not a.no_retune else "topological only", "tune_s": round(t_tune, 2),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_mc_step<float,true>" if a.precision == 32 else "k_mc_step<double,true>",
+                "bound": "hbm", "kernel": kernel,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "launches_per_step": launches, "avg_launch_ms": ms_main / max(launches, 1),
-                "alg_bytes_per_launch": seg0 / max(launches, 1) * ALG_BYTES_PER_SEGSTEP * (a.precision // 32),
-                "ms_main": ms_main, "ms_total_device": ms_total,
+                "traffic": pmc_traffic(engine),
+                "launches_per_step": head["launches"], "avg_launch_ms": head["ms_main"] / max(head["launches"], 1),
+                "alg_bytes_per_launch": seg0 / max(head["launches"], 1) * bytes_per,
+                "ms_main": head["ms_main"], "ms_total_device": head["ms_total"],
             },
             "cpu_baseline": cpu,
-            "warm_start": warm,
+            "untuned": untuned,
             "full_ts": full,
+            "per_rank": per_rank,
             "outlet_hydrographs": list(hyd.shape),
             "diffusive": diffusive,
         }
+        line.update(extra)
         print(json.dumps(line))
-    router.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(engine):
+    """HBM bytes per launch of the dominant kernel from the round's counter passes (profiles/pmc_traffic.json, written by
+    tools/profile_round.sh) -- reported only while the kernels are the ones the counters were taken on (the file records
+    a digest of the device sources); otherwise null rather than a stale figure."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+        h = hashlib.sha256()
+        for f in ("trmc.hip", "mc_segment.hpp", "det_pow.h", "levelpool.hpp"):
+            h.update(open(os.path.join(ROOT, "t-route_amd", "csrc", f), "rb").read())
+        if rec.get("source_sha256") == h.hexdigest() and rec.get("engine") == engine:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 if __name__ == "__main__":

@@ -1,0 +1,70 @@
+/*
+ * TEST / BASELINE INFRASTRUCTURE ONLY -- never loaded by the product (t-route_amd/).
+ *
+ * CPU baseline of bench.py: the reference's parallel decomposition of one routing window, driven from C so that no
+ * Python sits inside the clock.
+ *   reference: compute_nhd_routing_v02, parallel_compute_method "by-subnetwork-jit"
+ *     (src/troute-routing/troute/routing/compute.py:553-1209): the network is cut into sub-networks of about
+ *     subnetwork_target_size segments (default 10 000, src/troute-config/troute/config/compute_parameters.py:51-56,
+ *     build_subnetworks nhd_network.py:691-771), grouped by ORDER; the sub-networks of one order are independent jobs
+ *     (joblib, compute.py:664), an order starts when the one above it has finished, and the tailwater hydrograph of
+ *     every sub-network is handed to the order below (flowveldepth_interorder, compute.py:882-897).
+ *   per job: the time x reach loop of compute_network_structured (mc_reach.pyx:492-505,:719-750), here segment by
+ *     segment in topological order (bit-identical to reach by reach: tests/test_oracle_pinning.py), calling `kernel`
+ *     -- the reference Fortran c_muskingcungenwm built in oracle/_ref, or the oracle's restatement -- once per
+ *     segment and timestep (reach.pyx:37-94 zero-initialises the outputs first).
+ * Threads: OpenMP, one job at a time per thread, dynamic schedule (the reference's loky pool takes jobs as they come).
+ *
+ * Flows live in q[row][0..nsteps] (column 0 = initial flow), depths in d[row] (updated in place).
+ */
+#include <omp.h>
+#include <stdlib.h>
+
+typedef void (*kernel_fn)(const float *dt, const float *qup, const float *quc, const float *qdp, const float *ql,
+                          const float *dx, const float *bw, const float *tw, const float *twcc, const float *n,
+                          const float *ncc, const float *cs, const float *s0, const float *velp, const float *depthp,
+                          float *qdc, float *velc, float *depthc, float *ck, float *cn, float *X);
+
+/* returns the number of segment-timesteps routed */
+long cpu_baseline_route(kernel_fn kernel, int nsteps, int qts, int short_ts, long norders,
+                        const long *order_ptr, /* [norders + 1] jobs of every order, deepest order first          */
+                        const long *job_ptr,   /* [njobs + 1] rows of every job                                    */
+                        const long *rows,      /* rows of the jobs, topological order inside a job                 */
+                        const long *up_ptr, const long *up_idx, /* upstream rows of every row, summation order     */
+                        const float *params,   /* [nseg][9] dt dx bw tw twcc n ncc cs s0                           */
+                        const float *qlat, long nq, float *q, float *d, int nthreads)
+{
+    long done = 0;
+    const long stride = (long)nsteps + 1;
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    for (long o = 0; o < norders; ++o) {
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : done)
+        for (long j = order_ptr[o]; j < order_ptr[o + 1]; ++j) {
+            const long r0 = job_ptr[j], r1 = job_ptr[j + 1];
+            for (int t = 1; t <= nsteps; ++t) {
+                const long col = (t - 1) / qts;
+                for (long k = r0; k < r1; ++k) {
+                    const long s = rows[k];
+                    float qup = 0.0f, quc = 0.0f;
+                    for (long e = up_ptr[s]; e < up_ptr[s + 1]; ++e) {
+                        const float *qu = q + up_idx[e] * stride;
+                        qup += qu[t - 1];
+                        quc += qu[t];
+                    }
+                    if (short_ts) quc = qup;
+                    const float *p = params + 9 * s;
+                    const float velp = 0.0f, depthp = d[s];
+                    float qdc = 0.0f, velc = 0.0f, depthc = 0.0f, ck = 0.0f, cn = 0.0f, X = 0.0f;
+                    kernel(&p[0], &qup, &quc, &q[s * stride + t - 1], &qlat[s * nq + col], &p[1], &p[2], &p[3], &p[4],
+                           &p[5], &p[6], &p[7], &p[8], &velp, &depthp, &qdc, &velc, &depthc, &ck, &cn, &X);
+                    q[s * stride + t] = qdc;
+                    d[s] = depthc;
+                }
+            }
+            done += (r1 - r0) * (long)nsteps;
+        }
+    }
+    return done;
+}
+
+int cpu_baseline_max_threads(void) { return omp_get_max_threads(); }

@@ -76,3 +76,17 @@ void mc_oracle_wrf_segments_f32(wrf_fn f, long n, const float *in, float *out)
           &a[8], &a[10], &a[14], &o[0], &o[1], &o[2]);
     }
 }
+
+/* The restated fp32 segment step behind the reference's bind(c) signature (pyMCsingleSegStime_NoLoop.f90:8-21), so that
+ * drivers written for the reference symbol (oracle/cpu_baseline.c) can run the port where oracle/_ref is absent. */
+void mc_oracle_kernel_f32(const float *dt, const float *qup, const float *quc, const float *qdp, const float *ql,
+                          const float *dx, const float *bw, const float *tw, const float *twcc, const float *n,
+                          const float *ncc, const float *cs, const float *s0, const float *velp, const float *depthp,
+                          float *qdc, float *velc, float *depthc, float *ck, float *cn, float *X)
+{
+    const float in[15] = {*dt, *qup, *quc, *qdp, *ql, *dx, *bw, *tw, *twcc, *n, *ncc, *cs, *s0, *velp, *depthp};
+    float out[6];
+    int iters;
+    mc_oracle_segment_f32(in, *qdc, out, &iters);
+    *qdc = out[0]; *velc = out[1]; *depthc = out[2]; *ck = out[3]; *cn = out[4]; *X = out[5];
+}

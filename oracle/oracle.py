@@ -300,3 +300,89 @@ def network_by_segment(nsteps, qts_subdivisions, up_ptr, up_idx, level, params, 
     r_up_idx = up_idx[np.arange(r_up_ptr[-1]) + rep] if r_up_ptr[-1] else np.zeros(0, np.int64)
     return network_arrays(nsteps, qts_subdivisions, reach_ptr, order, r_up_ptr, r_up_idx, params, q0, qlat,
                           assume_short_ts, **kw)
+
+
+# ---- bench.py's CPU baseline: the reference's ordered sub-network decomposition, C + OpenMP (oracle/cpu_baseline.c) ----
+def ordered_subnetworks(to, target=10000):
+    """Cut a forest (``to[row]`` = downstream row, -1 at outlets) the way the reference's by-subnetwork methods do
+    (build_subnetworks, nhd_network.py:691-771: sub-networks of about ``target`` segments, in orders that are routed one
+    after the other, deepest first): a sub-network is a maximal sub-tree of at most ``target`` remaining segments; what
+    is left after an order (the rows more than ``target`` segments drain through) is cut again.  Returns
+    (order_ptr [norders+1], job_ptr [njobs+1], rows) with the rows of a job in topological order."""
+    to = np.asarray(to, dtype=np.int64)
+    n = to.shape[0]
+    # distance to the outlet, groups from the outlets upward
+    idx = np.arange(n, dtype=np.int64)
+    anc = np.where(to >= 0, to, idx)
+    dist = (to >= 0).astype(np.int64)
+    while True:
+        nxt = anc[anc]
+        dist = dist + dist[anc]
+        if np.array_equal(nxt, anc):
+            break
+        anc = nxt
+    by_dist = np.argsort(dist, kind="stable")
+    cuts = np.flatnonzero(np.diff(dist[by_dist])) + 1
+    groups = np.split(by_dist, cuts)                       # outlets first
+    alive = np.ones(n, dtype=bool)
+    order_of = np.full(n, -1, dtype=np.int64)
+    root_of = np.full(n, -1, dtype=np.int64)
+    order = 0
+    while alive.any():
+        size = alive.astype(np.int64)                      # alive rows draining through each row
+        for g in groups[::-1]:
+            g = g[alive[g]]
+            t = to[g]
+            ok = t >= 0
+            np.add.at(size, t[ok], size[g[ok]])
+        small = alive & (size <= target)
+        down_big = np.where(to >= 0, ~small[np.maximum(to, 0)] | ~alive[np.maximum(to, 0)], True)
+        is_root = small & down_big
+        for g in groups:                                   # roots hand their label upstream
+            g = g[small[g]]
+            t = np.maximum(to[g], 0)
+            root_of[g] = np.where(is_root[g], g, root_of[t])
+        order_of[small] = order
+        alive &= ~small
+        order += 1
+    key = np.lexsort((-dist, root_of, order_of))           # by order, job, upstream rows first
+    rows = key.astype(np.int64)
+    jobs = root_of[rows]
+    job_start = np.flatnonzero(np.concatenate([[True], jobs[1:] != jobs[:-1]]))
+    job_ptr = np.concatenate([job_start, [n]]).astype(np.int64)
+    job_order = order_of[rows[job_start]]
+    order_ptr = np.concatenate([[0], np.flatnonzero(np.diff(job_order)) + 1, [job_start.shape[0]]]).astype(np.int64)
+    return order_ptr, job_ptr, rows
+
+
+_CPU = None
+
+
+def cpu_baseline_route(nsteps, qts, short_ts, order_ptr, job_ptr, rows, up_ptr, up_idx, params, qlat, q0,
+                       ref_name=None, nthreads=0):
+    """One routing window over ordered sub-networks in C + OpenMP (oracle/cpu_baseline.c); the kernel is the reference
+    Fortran symbol of oracle/_ref/<ref_name>, or the oracle's restatement when ref_name is None.
+    Returns (flows [nseg, nsteps+1], depths [nseg], segment-timesteps routed, threads)."""
+    global _CPU
+    if _CPU is None:
+        _CPU = C.CDLL(os.path.join(_HERE, "libcpu_baseline.so"))
+        _CPU.cpu_baseline_route.restype = C.c_long
+    kern = ref_symbol(ref_name, F32_SYMBOL) if ref_name else C.cast(lib().mc_oracle_kernel_f32, C.c_void_p)
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    qlat = np.ascontiguousarray(qlat, dtype=np.float32)
+    n = params.shape[0]
+    q = np.zeros((n, nsteps + 1), dtype=np.float32)
+    q[:, 0] = q0[:, 0]
+    d = np.ascontiguousarray(q0[:, 2], dtype=np.float32).copy()
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)  # noqa: E731
+    order_ptr, job_ptr, rows, up_ptr, up_idx = map(i64, (order_ptr, job_ptr, rows, up_ptr, up_idx))
+    import time as _time
+    q[:, 1:] = 0                                        # every page touched before the clock starts
+    t_c = _time.perf_counter()
+    done = _CPU.cpu_baseline_route(kern, C.c_int(nsteps), C.c_int(qts), C.c_int(int(bool(short_ts))),
+                                   C.c_long(order_ptr.shape[0] - 1), _ptr(order_ptr, C.c_long), _ptr(job_ptr, C.c_long),
+                                   _ptr(rows, C.c_long), _ptr(up_ptr, C.c_long), _ptr(up_idx, C.c_long),
+                                   _ptr(params, C.c_float), _ptr(qlat, C.c_float), C.c_long(qlat.shape[1]),
+                                   _ptr(q, C.c_float), _ptr(d, C.c_float), C.c_int(int(nthreads)))
+    cpu_baseline_route.last_seconds = _time.perf_counter() - t_c    # the C call alone
+    return q, d, int(done), int(nthreads) if nthreads else int(_CPU.cpu_baseline_max_threads())

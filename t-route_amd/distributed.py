@@ -13,6 +13,16 @@ The compute backend is injected (``plan_factory``): the product passes
 oracle-backed stand-in with the same interface so the partition / exchange /
 gather logic is exercised with world_size 2 on gloo without a GPU.
 """
+import os as _os
+
+# Before any HIP runtime is loaded by this process: at most two hardware queues for ordinary-priority streams (the
+# exchange stream, RCCL's).  With the ROCm 7.2 default of four, a stream of another hardware queue waiting on events of a
+# plan's stream intermittently put that stream's launches in a slow mode (17 ms instead of 6.4 ms per 340 k-row rank,
+# depending on which queue the waiting stream happened to get; DESIGN.md section 7); one or two queues never did.  The
+# variable is read when the runtime initialises, so it is set at import -- a caller that has already initialised HIP
+# should export it itself.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import numpy as np
 
 from . import sharding
@@ -196,7 +206,7 @@ class ShardedRouter:
     def upload_trunk(self):
         """Stage the trunk's forcing once (its boundary hydrographs arrive per route via the exchange)."""
         if self.plan1 is not None:
-            self.plan1.upload_forcing(self.nsteps, self._qlat[self.rows1], self._q0[self.rows1], None)
+            self.plan1.upload_forcing(self.nsteps, self._qlat[self.rows1], self._q0_of(self.rows1), None)
 
     def _exchange_buffers(self, bounds):
         """Send/receive blocks of every time chunk and the stream/row-set handles, made once per window shape."""
@@ -271,7 +281,7 @@ class ShardedRouter:
             self._rsM_cut = self.planM.rowset(self.my_cut_local)
             self._rsM_out0 = self.planM.rowset(self.my_out0_local)
             self._rsM_out1 = self.planM.rowset(n0 + self.my_out1_local) if self.my_out1_global.size else None
-        self.planM.upload_forcing(self.nsteps, self._qlat[self._rowsM], self._q0[self._rowsM], None)
+        self.planM.upload_forcing(self.nsteps, self._qlat[self._rowsM], self._q0_of(self._rowsM), None)
         self._planM_upload = self._qlat
         return self.planM
 
@@ -422,11 +432,16 @@ class ShardedRouter:
         if self.plan1 is not None:
             self.plan1.close()
 
+    def _q0_of(self, rows):
+        return None if self._q0 is None else self._q0[rows]
+
     def upload(self, nsteps, qlat, q0):
-        """Stage this rank's slice of the forcing (global arrays in, local slices uploaded)."""
+        """Stage this rank's slice of the forcing (global arrays in, local slices uploaded).  q0 = None: every plan
+        continues from the state its last window left in HBM (the reference's new_q0 warm start between windows,
+        AbstractNetwork.py:177-191, without the host round trip)."""
         self.nsteps = nsteps
         self._qlat, self._q0 = qlat, q0
-        self.plan0.upload_forcing(nsteps, qlat[self.rows0], q0[self.rows0])
+        self.plan0.upload_forcing(nsteps, qlat[self.rows0], self._q0_of(self.rows0))
 
     def route_resident(self, qts_subdivisions, assume_short_ts):
         """Single-rank form that leaves the outlet hydrographs in HBM (throughput mode): returns the
@@ -458,7 +473,7 @@ class ShardedRouter:
         if self.plan1 is not None:
             bf = np.zeros((int(self.boundary1.sum()), nsteps, 3), dtype=self.dtype)
             bf[:, :, 0] = cut_q[self.b_cut_index]
-            self.plan1.upload_forcing(nsteps, self._qlat[self.rows1], self._q0[self.rows1], bf)
+            self.plan1.upload_forcing(nsteps, self._qlat[self.rows1], self._q0_of(self.rows1), bf)
             stats["phase1"] = self.plan1.route_device(nsteps, qts_subdivisions, assume_short_ts)
             if self.my_out1_global.size:
                 out1 = self.plan1.gather_flow_rows(self.my_out1_local)

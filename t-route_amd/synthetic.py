@@ -179,6 +179,28 @@ def generate(nseg=CONUS_NSEG, nnet=CONUS_NNET, seed=DEFAULT_SEED, nq=25, cache_d
     return out
 
 
+def forcing(nseg, nq=25, seed=DEFAULT_SEED + 1, previous=None, sigma=0.7, redraw=0.2):
+    """Another day of lateral inflow with the statistics of ``generate``'s (11 % zeros, else lognormal with
+    median 2.3e-4 m3/s, sigma 2.3, clipped at 1, times a smooth diurnal factor 1 +- 0.2) under its own seed -- the
+    window a plan is TIMED on after it was tuned on another one.
+    previous = None: an independent draw (no row keeps its magnitude: the hardest case for a plan tuned the day before).
+    previous = the forcing of the day before [nseg, nq]: the next day of the SAME basin -- every row's daily mean times
+    a lognormal factor (sigma), ``redraw`` of the rows drawn anew, new diurnal phases: lateral inflow is mostly
+    baseflow, whose spatial pattern persists from day to day."""
+    rng = np.random.default_rng(seed)
+    fresh = np.minimum(rng.lognormal(np.log(2.3e-4), 2.3, nseg), 1.0) * (rng.random(nseg) > 0.11)
+    if previous is None:
+        base_q = fresh
+    else:
+        mean_prev = np.asarray(previous, dtype=np.float64).mean(axis=1)
+        base_q = np.minimum(mean_prev * rng.lognormal(0.0, sigma, nseg), 1.0)
+        anew = rng.random(nseg) < redraw
+        base_q[anew] = fresh[anew]
+    hours = np.arange(nq)
+    diurnal = 1.0 + 0.2 * np.sin(2 * np.pi * (hours[None, :] / 24.0 + rng.random(nseg)[:, None]))
+    return (base_q[:, None] * diurnal).astype(np.float32)
+
+
 def _dist_to_root(parent):
     """Edges from each node to its root (pointer doubling: log2(height) vectorised sweeps)."""
     n = parent.shape[0]

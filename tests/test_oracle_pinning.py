@@ -183,3 +183,40 @@ def test_full_timestep_mode_is_chaotic_from_cold_start():
     b = O.network(24, lc.qts, reaches, ups, p, lc.q0, ql * (1 + 1e-13), True)
     rel = np.abs(a - b)[:, 1:, 0] / np.maximum(np.abs(a[:, 1:, 0]), 1e-9)
     assert rel.max() < 1e-9
+
+
+def test_cpu_baseline_driver_equals_the_network_loop():
+    """bench.py's CPU baseline (oracle/cpu_baseline.c: ordered sub-networks, C + OpenMP around a kernel symbol) routes
+    the same flows and depths as the restated reference loop -- with the reference Fortran kernel where oracle/_ref is
+    built, and with the restatement behind the same signature."""
+    import helpers as H
+    from troute_amd.synthetic import upstream_csr
+    rng = np.random.default_rng(3)
+    n = 5000
+    to = np.array([rng.integers(i + 1, min(n, i + 60)) if (i + 1 < n and rng.random() > 0.002) else -1 for i in range(n)])
+    perm = rng.permutation(n)
+    to_r = np.full(n, -1, np.int64)
+    to_r[perm] = np.where(to >= 0, perm[np.maximum(to, 0)], -1)
+    up_ptr, up_idx = upstream_csr(to_r)
+    p = np.stack([np.full(n, 300.0), rng.uniform(300, 3000, n), rng.uniform(1, 9, n), np.zeros(n), np.zeros(n),
+                  np.full(n, 0.06), np.full(n, 0.12), rng.uniform(0.2, 1.5, n), rng.uniform(1e-3, 2e-2, n)], 1)
+    p[:, 3] = p[:, 2] * 5 / 3
+    p[:, 4] = 3 * p[:, 3]
+    p = p.astype(np.float32)
+    qlat = rng.uniform(0, 0.05, (n, 2)).astype(np.float32)
+    q0 = np.zeros((n, 3), np.float32)
+    nsteps, qts = 18, 12
+    order_ptr, job_ptr, rows = O.ordered_subnetworks(to_r, target=400)
+    assert sorted(rows.tolist()) == list(range(n)) and order_ptr[-1] == job_ptr.shape[0] - 1 and order_ptr.shape[0] > 2
+    assert (np.diff(job_ptr) <= 400).all()
+    from troute_amd.plan import topology_levels
+    lvl, _, _ = topology_levels(up_ptr, up_idx)
+    for short in (True, False):
+        want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, p, q0, qlat, short)
+        names = [None] + (["libmc_ref_qj0_f32.so"] if O.have_ref("libmc_ref_qj0_f32.so") else [])
+        for name in names:
+            q, d, done, nthreads = O.cpu_baseline_route(nsteps, qts, short, order_ptr, job_ptr, rows, up_ptr, up_idx, p, qlat,
+                                                        q0, ref_name=name, nthreads=4)
+            assert done == n * nsteps
+            assert np.array_equal(q.view(np.uint32), np.ascontiguousarray(want[:, :, 0]).view(np.uint32)), (short, name)
+            assert np.array_equal(d.view(np.uint32), np.ascontiguousarray(want[:, -1, 2]).view(np.uint32))
