@@ -39,6 +39,9 @@ import time
 # depending on which queue the waiting stream happened to get: tools/sim_ranks.py); one or two
 # queues never did, and the single-GPU path (priority streams only) is unaffected either way.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# the CPU baseline's OpenMP threads: one per physical core, spread over the sockets (read when libgomp initialises)
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 
@@ -86,14 +89,17 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     from troute_amd.synthetic import upstream_csr
 
     kind, ref_name = "port", None
-    if O.have_ref("libmc_ref_f32.so"):
+    if O.have_ref("libmc_ref_f32.so") and not os.environ.get("TRMC_CPU_PORT"):
         kind, ref_name = "reference", "libmc_ref_f32.so"
-    threads = cpu_threads or os.cpu_count() or 1
     try:
         import psutil
-        physical = psutil.cpu_count(logical=False) or threads
+        physical = psutil.cpu_count(logical=False) or os.cpu_count() or 1
     except Exception:
-        physical = threads
+        physical = os.cpu_count() or 1
+    # one thread per physical core: on the 2 x 64-core host of the GPU box 256 hardware threads were SLOWER than 128
+    # (6.7e7 against 9.4e7 segment-timesteps/s) and 64 as fast as 128 -- above ~32 threads the makespan of an order is
+    # bounded by its largest jobs (10 000 segments x 288 steps cannot be split) and by the memory system, not by cores
+    threads = cpu_threads or physical
     to = net["to"]
     nseg = to.shape[0]
     ns = int(max(qts, min(nsteps, target_s * threads * 1.5e6 / nseg)))
@@ -114,6 +120,7 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
                   f"reference decomposition by-subnetwork-jit: {int(job_ptr.shape[0] - 1)} sub-networks of <= 10000 segments in "
                   f"{int(order_ptr.shape[0] - 1)} orders ({', '.join(str(int(j)) for j in jobs)} jobs), OpenMP dynamic, "
                   f"C loop around the reference Fortran kernel; decomposition prepared in {t_prep:.1f} s outside the clock",
+        "order_seconds": [round(x, 2) for x in O.cpu_baseline_route.order_seconds],
         "_check": (q[:, ns], d),
     }
 

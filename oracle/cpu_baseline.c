@@ -15,7 +15,7 @@
  *     segment and timestep (reach.pyx:37-94 zero-initialises the outputs first).
  * Threads: OpenMP, one job at a time per thread, dynamic schedule (the reference's loky pool takes jobs as they come).
  *
- * Flows live in q[row][0..nsteps] (column 0 = initial flow), depths in d[row] (updated in place).
+ * Depths live in d[row] (updated in place); flows in per-job time-major blocks, see cpu_baseline_route.
  */
 #include <omp.h>
 #include <stdlib.h>
@@ -25,44 +25,62 @@ typedef void (*kernel_fn)(const float *dt, const float *qup, const float *quc, c
                           const float *ncc, const float *cs, const float *s0, const float *velp, const float *depthp,
                           float *qdc, float *velc, float *depthc, float *ck, float *cn, float *X);
 
-/* returns the number of segment-timesteps routed */
+/* returns the number of segment-timesteps routed.
+ * Rows arrive in JOB ORDER (row k belongs to the job whose range [job_ptr[j], job_ptr[j+1]) holds k; the rows of a job
+ * in topological order) and every job keeps its flows TIME-MAJOR in a block of its own:
+ *     q[job_ptr[j] * (nsteps + 1) + t * m + (k - job_ptr[j])],  m = rows of the job
+ * so that a timestep of a job reads one contiguous run and writes the next -- the reference hands every job its own
+ * sliced copies of the tables too (compute.py:741-760).  job_of_row[k] names the job of row k (for upstream rows that
+ * belong to a job of an earlier order: the hand-over of flowveldepth_interorder, compute.py:882-897). */
 long cpu_baseline_route(kernel_fn kernel, int nsteps, int qts, int short_ts, long norders,
                         const long *order_ptr, /* [norders + 1] jobs of every order, deepest order first          */
                         const long *job_ptr,   /* [njobs + 1] rows of every job                                    */
-                        const long *rows,      /* rows of the jobs, topological order inside a job                 */
+                        const long *job_of_row,
                         const long *up_ptr, const long *up_idx, /* upstream rows of every row, summation order     */
                         const float *params,   /* [nseg][9] dt dx bw tw twcc n ncc cs s0                           */
-                        const float *qlat, long nq, float *q, float *d, int nthreads)
+                        const float *qlat, long nq, float *q, float *d, int nthreads,
+                        double *order_seconds /* [norders] wall time of every order, or NULL */)
 {
     long done = 0;
     const long stride = (long)nsteps + 1;
     if (nthreads > 0) omp_set_num_threads(nthreads);
     for (long o = 0; o < norders; ++o) {
+        const double t_o = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : done)
         for (long j = order_ptr[o]; j < order_ptr[o + 1]; ++j) {
-            const long r0 = job_ptr[j], r1 = job_ptr[j + 1];
+            const long r0 = job_ptr[j], r1 = job_ptr[j + 1], m = r1 - r0;
+            float *qj = q + r0 * stride;
             for (int t = 1; t <= nsteps; ++t) {
                 const long col = (t - 1) / qts;
-                for (long k = r0; k < r1; ++k) {
-                    const long s = rows[k];
+                const float *q_prev = qj + (long)(t - 1) * m;
+                float *q_curr = qj + (long)t * m;
+                for (long s = r0; s < r1; ++s) {
                     float qup = 0.0f, quc = 0.0f;
                     for (long e = up_ptr[s]; e < up_ptr[s + 1]; ++e) {
-                        const float *qu = q + up_idx[e] * stride;
-                        qup += qu[t - 1];
-                        quc += qu[t];
+                        const long u = up_idx[e];
+                        if (u >= r0 && u < r1) {
+                            qup += q_prev[u - r0];
+                            quc += q_curr[u - r0];
+                        } else { /* a tailwater of an earlier order */
+                            const long ju = job_of_row[u], u0 = job_ptr[ju], mu = job_ptr[ju + 1] - u0;
+                            const float *qu = q + u0 * stride + (u - u0);
+                            qup += qu[(long)(t - 1) * mu];
+                            quc += qu[(long)t * mu];
+                        }
                     }
                     if (short_ts) quc = qup;
                     const float *p = params + 9 * s;
                     const float velp = 0.0f, depthp = d[s];
                     float qdc = 0.0f, velc = 0.0f, depthc = 0.0f, ck = 0.0f, cn = 0.0f, X = 0.0f;
-                    kernel(&p[0], &qup, &quc, &q[s * stride + t - 1], &qlat[s * nq + col], &p[1], &p[2], &p[3], &p[4],
+                    kernel(&p[0], &qup, &quc, &q_prev[s - r0], &qlat[s * nq + col], &p[1], &p[2], &p[3], &p[4],
                            &p[5], &p[6], &p[7], &p[8], &velp, &depthp, &qdc, &velc, &depthc, &ck, &cn, &X);
-                    q[s * stride + t] = qdc;
+                    q_curr[s - r0] = qdc;
                     d[s] = depthc;
                 }
             }
-            done += (r1 - r0) * (long)nsteps;
+            done += m * (long)nsteps;
         }
+        if (order_seconds) order_seconds[o] = omp_get_wtime() - t_o;
     }
     return done;
 }

@@ -345,7 +345,9 @@ def ordered_subnetworks(to, target=10000):
         order_of[small] = order
         alive &= ~small
         order += 1
-    key = np.lexsort((-dist, root_of, order_of))           # by order, job, upstream rows first
+    # by order; inside an order the largest jobs first (they bound the makespan of a dynamic schedule); upstream rows first
+    job_size = np.bincount(root_of, minlength=n)
+    key = np.lexsort((-dist, root_of, -job_size[root_of], order_of))
     rows = key.astype(np.int64)
     jobs = root_of[rows]
     job_start = np.flatnonzero(np.concatenate([[True], jobs[1:] != jobs[:-1]]))
@@ -368,21 +370,49 @@ def cpu_baseline_route(nsteps, qts, short_ts, order_ptr, job_ptr, rows, up_ptr, 
         _CPU = C.CDLL(os.path.join(_HERE, "libcpu_baseline.so"))
         _CPU.cpu_baseline_route.restype = C.c_long
     kern = ref_symbol(ref_name, F32_SYMBOL) if ref_name else C.cast(lib().mc_oracle_kernel_f32, C.c_void_p)
-    params = np.ascontiguousarray(params, dtype=np.float32)
-    qlat = np.ascontiguousarray(qlat, dtype=np.float32)
-    n = params.shape[0]
-    q = np.zeros((n, nsteps + 1), dtype=np.float32)
-    q[:, 0] = q0[:, 0]
-    d = np.ascontiguousarray(q0[:, 2], dtype=np.float32).copy()
     i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)  # noqa: E731
     order_ptr, job_ptr, rows, up_ptr, up_idx = map(i64, (order_ptr, job_ptr, rows, up_ptr, up_idx))
+    n = rows.shape[0]
+    # The tables are handed over in JOB ORDER (row k of the C side = rows[k]): what a job reads and writes is then one
+    # contiguous range of every array -- the reference gives each job its own sliced copies (compute.py:741-760); with
+    # the caller's row order the depths of neighbouring rows, written at every step by different threads, would share
+    # cache lines (measured on 2 x 64 cores: 256 threads slower than 32).
+    inv = np.empty(n, dtype=np.int64)
+    inv[rows] = np.arange(n, dtype=np.int64)
+    cnt = (up_ptr[1:] - up_ptr[:-1])[rows]
+    up_ptr_j = np.zeros(n + 1, dtype=np.int64)
+    up_ptr_j[1:] = np.cumsum(cnt)
+    rep = np.repeat(up_ptr[:-1][rows] - up_ptr_j[:-1], cnt)
+    up_idx_j = inv[up_idx[np.arange(up_ptr_j[-1]) + rep]] if up_ptr_j[-1] else np.zeros(0, np.int64)
+    caller_rows, rows = rows, np.arange(n, dtype=np.int64)
+    up_ptr, up_idx = up_ptr_j, np.ascontiguousarray(up_idx_j)
+    params = np.ascontiguousarray(np.asarray(params, dtype=np.float32)[caller_rows])
+    qlat = np.ascontiguousarray(np.asarray(qlat, dtype=np.float32)[caller_rows])
+    # flows: one time-major block per job, q[job_ptr[j] * (nsteps + 1) + t * m + k]
+    m_of_job = np.diff(job_ptr)
+    job_of_row = np.repeat(np.arange(m_of_job.shape[0], dtype=np.int64), m_of_job)
+    k_in_job = np.arange(n, dtype=np.int64) - job_ptr[:-1][job_of_row]
+    slot0 = job_ptr[:-1][job_of_row] * (nsteps + 1) + k_in_job          # element of (row, t = 0)
+    q = np.zeros(n * (nsteps + 1), dtype=np.float32)
+    q[slot0] = q0[caller_rows, 0]
+    d = np.ascontiguousarray(q0[caller_rows, 2], dtype=np.float32).copy()
     import time as _time
-    q[:, 1:] = 0                                        # every page touched before the clock starts
+    order_s = np.zeros(order_ptr.shape[0] - 1, dtype=np.float64)
+    q += 0                                              # every page touched before the clock starts
     t_c = _time.perf_counter()
     done = _CPU.cpu_baseline_route(kern, C.c_int(nsteps), C.c_int(qts), C.c_int(int(bool(short_ts))),
                                    C.c_long(order_ptr.shape[0] - 1), _ptr(order_ptr, C.c_long), _ptr(job_ptr, C.c_long),
-                                   _ptr(rows, C.c_long), _ptr(up_ptr, C.c_long), _ptr(up_idx, C.c_long),
+                                   _ptr(job_of_row, C.c_long), _ptr(up_ptr, C.c_long), _ptr(up_idx, C.c_long),
                                    _ptr(params, C.c_float), _ptr(qlat, C.c_float), C.c_long(qlat.shape[1]),
-                                   _ptr(q, C.c_float), _ptr(d, C.c_float), C.c_int(int(nthreads)))
+                                   _ptr(q, C.c_float), _ptr(d, C.c_float), C.c_int(int(nthreads)),
+                                   _ptr(order_s, C.c_double))
+    cpu_baseline_route.order_seconds = order_s.tolist()
     cpu_baseline_route.last_seconds = _time.perf_counter() - t_c    # the C call alone
+    q_j, d_j = q, d                                                  # back to [row][t], the caller's row order
+    q = np.empty((n, nsteps + 1), dtype=np.float32)
+    step = m_of_job[job_of_row]
+    for t in range(nsteps + 1):
+        q[caller_rows, t] = q_j[slot0 + t * step]
+    d = np.empty_like(d_j)
+    d[caller_rows] = d_j
     return q, d, int(done), int(nthreads) if nthreads else int(_CPU.cpu_baseline_max_threads())
