@@ -45,6 +45,6 @@ def summarise(path):
 
 
 if __name__ == "__main__":
-    res = [summarise(p) for p in sys.argv[1:]]
+    res = [summarise(p) for p in sys.argv[1:] if p != "--json"]
     if "--json" in sys.argv:
         print(json.dumps(res))
