@@ -12,8 +12,8 @@ fp32 (the reference's arithmetic type), cold start -- forcing and topology alrea
 resident in HBM when the timed region starts, results (incl. the gathered outlet hydrographs) left in HBM in the reference's
 [segment][timestep][q,v,d] layout.
 
-The plan is tuned on day N (an untimed window) and TIMED on day N+1: the next day's forcing of the same basin, started
-from the state day N leaves in HBM.
+Three consecutive days: day N-1 spins the network up from a cold start, the plan is tuned on day N (untimed) and TIMED on
+day N+1 -- the next day's forcing of the same basin, started from the state day N leaves in HBM.
 
 Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   roofline          dominant kernel against the 8 TB/s HBM roofline, timed with HIP events on the plan's own stream
@@ -23,7 +23,8 @@ Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   untuned           the plan built from the topology alone, day N, cold start
   value_with_d2h    outlet hydrographs + final state copied to the host inside the timed region
   parity_mode       the whole flowveldepth array copied to the host inside the timed region
-  tuned_window_cold / independent_forcing_cold   the tuned plan on the very window it was tuned on / on an unrelated day
+  tuned_window_warm / cold_start / independent_forcing_cold   the tuned plan on the very window it was tuned on, on a
+                    cold start, on an unrelated day
   full_ts           the same workload without the short-timestep assumption (dataflow engine)
   per_rank          (N > 1) every rank's device time
 """
@@ -253,11 +254,13 @@ def main():
     t_gen = time.perf_counter() - t0
     to, params = net["to"], net["params"]
     nseg = to.shape[0]
-    # day N: the window every plan is TUNED on (cold start).  Day N+1: the window that is TIMED -- the next day of the
-    # same basin (synthetic.forcing: yesterday's spatial pattern, row-wise lognormal day-to-day factor, a fifth of the
-    # rows drawn anew), started from the state day N ends in, which stays in HBM.
-    qlat_a = net["qlat"]
-    qlat_b = synthetic.forcing(nseg, qlat_a.shape[1], synthetic.DEFAULT_SEED + 1, previous=qlat_a)
+    # Three consecutive days of the same basin (synthetic.forcing: yesterday's spatial pattern, a row-wise lognormal
+    # day-to-day factor, a fifth of the rows drawn anew).  Day N-1 spins the network up from a cold start; day N, started
+    # from the state day N-1 leaves in HBM, is the window every plan is TUNED on (untimed); day N+1, started from the state
+    # day N leaves, is the window that is TIMED -- an operational sequence: windows follow each other warm.
+    qlat_s = net["qlat"]
+    qlat_a = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 1, previous=qlat_s)
+    qlat_b = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2, previous=qlat_a)
     q0 = np.zeros((nseg, 3), dtype=np.float32)
 
     def all_gather_into(out, t):
@@ -335,32 +338,42 @@ def main():
     def frac(t):
         return t["stats"]["phase0"]["segment_steps"] * bytes_per / (t["ms_main"] * 1e-3) / 1e9 / HBM_PEAK_GBS
 
-    # ---- 1. the plan as it is built from the topology alone: day N, cold start --------------------------------------
+    def spin_up(router, through_day_n):
+        """day N-1 from a cold start, then (optionally) day N from the state it leaves; untimed"""
+        router.upload(a.nsteps, qlat_s, q0)
+        route_once(router, True)
+        if through_day_n:
+            router.upload(a.nsteps, qlat_a, None)
+            route_once(router, True)
+
+    # ---- 1. the plan as it is built from the topology alone; day N doubles as the tuning window ----------------------
     t0 = time.perf_counter()
-    router = make_router(None, True, qlat_a, q0)
+    router = make_router(None, True, qlat_s, q0)
     t_plan = time.perf_counter() - t0
     engine = getattr(router.plan0, "engine", "levels")
     usteps = max(1, min(a.steps, 2))
+    t0 = time.perf_counter()
+    route_once(router, True)                           # day N-1, cold
+    router.upload(a.nsteps, qlat_a, None)              # day N, warm: which rows are cheap (dry channel: one secant
+    router.collect_cost(not a.no_retune)               # iteration), which are not, which go over bank
+    route_once(router, True)
+    hint = None if a.no_retune else router.iteration_hint()
+    router.collect_cost(False)
+    t_tune = time.perf_counter() - t0
+    router.upload(a.nsteps, qlat_b, None)              # day N+1, warm
     unt = timed(router, True, usteps, 1)
     untuned = {"value": rate(unt), "unit": "segment-timesteps/s", "ms_per_step": unt["el"] / usteps * 1e3,
-               "ms_main": unt["ms_main"], "roofline_frac": frac(unt), "window": "day N, cold start"}
+               "ms_main": unt["ms_main"], "roofline_frac": frac(unt),
+               "window": "day N+1, warm start (the headline's window) on the plan built from the topology alone"}
 
-    # ---- 2. tuning, outside every timed region: day N tells which rows are cheap (dry channel: one secant iteration)
-    # and which are not; the plan is rebuilt with that as its cost hint.  Same results (tests/test_gpu_parity.py).
-    t_tune = 0.0
+    # ---- 2. the plan rebuilt with day N's costs as its hint (same results: tests/test_gpu_parity.py), spun up again ----
     if not a.no_retune:
         t0 = time.perf_counter()
-        router.collect_cost(True)
-        route_once(router, True)
-        hint = router.iteration_hint()
         router.close()
-        router = make_router(hint, True, qlat_a, q0)
-        route_once(router, True)                       # day N on the tuned plan: leaves the state day N+1 starts from
-        router.upload(a.nsteps, qlat_b, None)          # day N+1, warm start from the state resident in HBM
-        t_tune = time.perf_counter() - t0
-    else:
-        route_once(router, True)
+        router = make_router(hint, True, qlat_s, q0)
+        spin_up(router, True)
         router.upload(a.nsteps, qlat_b, None)
+        t_tune += time.perf_counter() - t0
 
     # ---- 3. the headline: day N+1 on the plan tuned on day N -----------------------------------------------------------
     head = timed(router, True, a.steps, a.warmup)
@@ -395,13 +408,18 @@ def main():
             extra["parity_mode"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] * 1e3,
                                     "copied": f"full flowveldepth [{nseg} x {a.nsteps} x 3] ({nseg * a.nsteps * 12 / 1e9:.1f} GB), "
                                               "pageable host memory, inside the timed region"}
-        # the window the plan was tuned on, cold start (round 1's headline configuration), and an unrelated day
-        router.upload(a.nsteps, qlat_a, q0)
+        # the window the plan was tuned on (day N, warm), a cold start (round 1's configuration), and an unrelated day
+        spin_up(router, False)
+        router.upload(a.nsteps, qlat_a, None)
         w = timed(router, True, usteps, 1)
-        extra["tuned_window_cold"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / usteps * 1e3,
+        extra["tuned_window_warm"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / usteps * 1e3,
                                       "ms_main": w["ms_main"], "roofline_frac": frac(w),
-                                      "window": "day N itself (the plan was tuned on it), cold start"}
-        router.upload(a.nsteps, synthetic.forcing(nseg, qlat_a.shape[1], synthetic.DEFAULT_SEED + 2), q0)
+                                      "window": "day N itself (the plan was tuned on it), warm start"}
+        router.upload(a.nsteps, qlat_s, q0)
+        w = timed(router, True, usteps, 1)
+        extra["cold_start"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / usteps * 1e3,
+                               "ms_main": w["ms_main"], "roofline_frac": frac(w), "window": "day N-1, cold start"}
+        router.upload(a.nsteps, synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 7), q0)
         w = timed(router, True, usteps, 1)
         extra["independent_forcing_cold"] = {"value": rate(w), "unit": "segment-timesteps/s",
                                              "ms_per_step": w["el"] / usteps * 1e3, "ms_main": w["ms_main"],
@@ -422,7 +440,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(net, qlat_a, a.nsteps, a.qts, True, a.cpu_seconds, a.cpu_threads)
+            cpu = cpu_baseline(net, qlat_s, a.nsteps, a.qts, True, a.cpu_seconds, a.cpu_threads)
             cpu.pop("_check", None)
         except Exception as e:  # the baseline must never take the GPU number down with it
             cpu = {"error": repr(e)}
@@ -454,7 +472,7 @@ def main():
                 "workload": "synthetic CONUS NHDPlus-shaped network, MC-only, 24 h @ 300 s dt (configs[2])",
                 "segments": int(nseg), "networks": int(len(net["net_sizes"])), "timesteps": a.nsteps,
                 "qts_subdivisions": a.qts, "assume_short_ts": True,
-                "timed_window": "day N+1 (next-day forcing of the same basin), warm start from the state day N leaves in HBM",
+                "timed_window": "day N+1 of three consecutive days of the same basin (N-1 spin-up from cold, N tuning, N+1 timed), warm start from the state day N leaves in HBM",
                 "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
                 "engine": engine,

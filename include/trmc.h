@@ -292,7 +292,7 @@ int trmc_download_fvd(trmc_plan *plan, void *fvd_out);
  * (AbstractNetwork.py:182-190): q0_out[nseg][3] = (q_T, q_T, depth_T).  D2H. */
 int trmc_download_final_state(trmc_plan *plan, void *q0_out);
 /* Cost collection for trmc_plan_create_hinted: with it enabled, every routing window also sums, per row,
- * min(secant iterations, 3) over its timesteps (2 more bytes read and written per segment-step); trmc_download_cost
+ * min(secant iterations, 3) (+ 4 in a step that took the compound-channel branch) over its timesteps (2 more bytes read and written per segment-step); trmc_download_cost
  * returns the sums of the last window [nseg] and its length.  Off by default.  No counterpart in the reference. */
 int trmc_plan_collect_cost(trmc_plan *plan, int enable);
 int trmc_download_cost(trmc_plan *plan, uint16_t *cost_out, int32_t *nsteps_out);

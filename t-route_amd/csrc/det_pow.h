@@ -154,6 +154,52 @@ TRMC_DP_FN float trmc_det_powf_from_log(double L, float y, const uint64_t *tab)
     return (float)w;
 }
 
+/* The same two steps for arguments whose range the caller has established, without the range tests (they only select
+ * special values, so the results are the ones above):
+ *   trmc_det_log2_normal          x positive, finite, not subnormal
+ *   trmc_det_powf_from_log_inrange   |y * L| < 126 (neither overflow nor underflow nor NaN)
+ * mc_segment.hpp uses them for the hydraulic radius of a channel whose parameters and depth lie in the ranges of
+ * DevMathF::fast_ok (trmc.hip), where 2**-64 < R < 2**63 is shown. */
+TRMC_DP_FN double trmc_det_log2_normal(float x, const uint64_t *tab)
+{
+    const uint32_t ix = trmc_sp_bits(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int32_t k = (int32_t)top >> 23;
+    const double invc = trmc_dp_from_bits(tab[2 * i]);
+    const double logc = trmc_dp_from_bits(tab[2 * i + 1]);
+    const double z = (double)trmc_sp_from_bits(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double y = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(0x1.71547652ab82bp0, r, y0);
+    q = __builtin_fma(p, r2, q);
+    y = __builtin_fma(y, r4, q);
+    return y;
+}
+TRMC_DP_FN float trmc_det_powf_from_log_inrange(double L, float y, const uint64_t *tab)
+{
+    const double ylogx = (double)y * L;
+    double kd = ylogx + 0x1.8p+47;
+    const uint64_t ki = trmc_dp_bits(kd);
+    kd -= 0x1.8p+47;
+    const double r = ylogx - kd;
+    uint64_t t = tab[32 + (ki & 31u)];
+    t += ki << 47;
+    const double s = trmc_dp_from_bits(t);
+    const double z = __builtin_fma(0x1.c6af84b912394p-5, r, 0x1.ebfce50fac4f3p-3);
+    const double r2 = r * r;
+    double w = __builtin_fma(0x1.62e42ff0c52d6p-1, r, 1.0);
+    w = __builtin_fma(z, r2, w);
+    w = w * s;
+    return (float)w;
+}
+
 TRMC_DP_FN float trmc_det_powf(float x, float y, const uint64_t *tab)
 {
     return trmc_det_powf_from_log(trmc_det_log2(x, tab), y, tab);

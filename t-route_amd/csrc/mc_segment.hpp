@@ -22,15 +22,16 @@
 //
 // Math policy M:  m.sqrt(x); m.pow(x, y); and, so that x**a and x**b can share
 // one logarithm, M::Log, m.log_of(x), m.pow_l(log_of(x), x, y) == m.pow(x, y);
+// m.log_of_r(x, ok) / m.pow_l_r(l, x, y, ok): the same for a hydraulic radius x; with `ok` (see fast_ok) the policy may
+// skip the special-value tests of its power.
 // m.div4(n1, n2, n3, n4, d, q1, q2, q3, q4): qi = ni / d, the four correctly rounded quotients by one
 // divisor (the Muskingum coefficients) -- a policy may share the reciprocal between them;
 // m.fast_ok(h, h_in, h_over) -> ok; m.div2(a1, a2, b, ok, q1, q2): qi = ai / b; m.div1(a, b, ok) = a / b: the
 // divisions of the hydraulic point, for which a policy may use a cheaper exact sequence when `ok` (its own test of
 // the operand ranges) holds.
 //
-// The header is host/device neutral on purpose: tests/host_harness.cpp
-// instantiates it with libm on the CPU to check the logic against the oracle
-// without a GPU.  The shipped library only ever instantiates it in device code.
+// The header is host/device neutral (no HIP construct outside MC_HD); the shipped library only ever instantiates
+// it in device code, and its results are checked against the oracle through the C ABI (tests/test_gpu_parity.py).
 #pragma once
 
 #if defined(__HIPCC__)
@@ -60,6 +61,7 @@ template <class T> struct ChannelConst {
     T s0_ncc;     // sqrt(s0)/ncc
     T two_sq;     // 2*sqrt(1 + z*z)
     T half_dt;    // dt/2
+    T inv_n;      // 1/n, the factor of the velocity formula (f90:169)
     bool fp_ok;   // twcc > 0 && ncc > 0 : flood-plain terms may activate
 };
 
@@ -80,6 +82,7 @@ MC_HD ChannelConst<T> make_const(const ChannelParams<T> &p, const M &m)
     c.s0_ncc = c.sqrt_s0 / p.ncc;
     c.two_sq = T(2) * c.sq1pz2;
     c.half_dt = p.dt / T(2);
+    c.inv_n = T(1) / p.n;
     c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
     return c;
 }
@@ -129,6 +132,7 @@ template <class T> struct HydraulicPoint {
     T denom;       // 2 * width * s0 * Ck * dx, the divisor of the X formula (width = twcc over bank, else twl)
     T q_manning;   // (1/n_composite) * (AREA+AREAC) * R**(2/3) * sqrt(s0); 0-flagged by has_wp
     bool has_wp;   // WP + WPC > 0
+    bool over;     // evaluated with the flood plain active (the compound-channel branch)
 };
 
 template <class T, class M>
@@ -143,17 +147,18 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
     T n_comp;
     m.div2(s.area + s.areac, (s.wp * p.n) + (s.wpc * p.ncc), s.wp + s.wpc, ok, s.R, n_comp);
 
-    // R**(2/3) and R**(5/3) share one logarithm (M::Log), see det_pow.h
-    const typename M::Log lr = m.log_of(s.R);
-    const T r23 = m.pow_l(lr, s.R, c23);
+    // R**(2/3) and R**(5/3) share one logarithm (M::Log), see det_pow.h; `ok` also tells the policy that R is an
+    // ordinary number (DevMathF::fast_ok: 2**-64 < R < 2**63), for which a power needs no special-value tests
+    const typename M::Log lr = m.log_of_r(s.R, ok);
+    const T r23 = m.pow_l_r(lr, s.R, c23, ok);
     if (over) {
-        hp.ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
+        hp.ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, s.R, c53, ok)
                                                      * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
                                   * s.area
                               + (c.s0_ncc * c53 * m.pow(h - c.bfd, c23)) * s.areac)
                                  / (s.area + s.areac));
     } else if (h > T(0)) {
-        hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l(lr, s.R, c53)
+        hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, s.R, c53, ok)
                                                     * m.div1(c.two_sq, p.bw + T(2) * h * c.z, ok))));
     } else {
         hp.ck = T(0);
@@ -161,6 +166,7 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
     hp.km = (hp.ck > T(0)) ? mc_max(p.dt, p.dx / hp.ck) : p.dt;
     hp.denom = T(2) * (over ? p.twcc : s.twl) * p.s0 * hp.ck * p.dx;
     hp.has_wp = (s.wp + s.wpc) > T(0);
+    hp.over = over;
     hp.q_manning = m.div1(T(1), n_comp, ok) * (s.area + s.areac) * r23 * c.sqrt_s0;
     return hp;
 }
@@ -225,6 +231,7 @@ template <class T> struct StepResult {
     T h;                 // depth the iteration ended on (courant uses it even with no flow)
     T X;                 // last weighting factor (0 when nothing was routed)
     int iters;           // secant iterations spent (all retries together)
+    bool over;           // some evaluation of the step took the compound-channel (over-bank) branch: cost diagnostics only
 };
 
 // One segment, one timestep (f90:8-186), with the segment-invariant constants supplied.
@@ -241,6 +248,7 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
 
     if (!(f.ql > T(0) || f.qup > T(0) || f.quc > T(0) || f.qdp > T(0))) {
         out.qdc = T(0); out.velc = T(0); out.depthc = T(0); out.h = h; out.X = T(0); out.iters = 0;
+        out.over = false;
         return out;
     }
 
@@ -251,16 +259,21 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
     T aerror = T(0.01);
     bool rel_open = true;
     int maxiter = 100, tries = 0, total_iter = 0;
+    bool any_over = false;
     for (;;) {
         T qj_0 = T(0);
         int iter = 0;
         // the point of h_0: evaluated here for the bracket a (re)try starts from; inside the loop h_0 <- max(0, h) is h
         // itself (h is never negative), so the point just evaluated for h is carried over instead of being recomputed
         HydraulicPoint<T> at_h0;
-        if (rel_open && aerror >= mindepth && iter <= maxiter) at_h0 = hydraulics_at<T, M>(h_0, p, c, m);
+        if (rel_open && aerror >= mindepth && iter <= maxiter) {
+            at_h0 = hydraulics_at<T, M>(h_0, p, c, m);
+            any_over = any_over || at_h0.over;
+        }
         while (rel_open && aerror >= mindepth && iter <= maxiter) {
             qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k, m);
             const HydraulicPoint<T> at_h = hydraulics_at<T, M>(h, p, c, m);
+            any_over = any_over || at_h.over;
             const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k, m);
             T h_1;
             if (qj_0 - qj != T(0)) {
@@ -312,11 +325,12 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
     const T a = (twl - p.bw) / T(2);
     const bool okv = m.fast_ok(h, h, T(0)); // (numerator in [2**-44, 2**52], denominator in [2**-14, 2**36]: see fast_ok)
     const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), okv);
-    out.velc = m.div1(T(1), p.n, okv) * m.pow(R, T(2) / T(3)) * c.sqrt_s0;
+    out.velc = c.inv_n * m.pow_l_r(m.log_of_r(R, okv), R, T(2) / T(3), okv) * c.sqrt_s0;
     out.depthc = h;
     out.h = h;
     out.X = k.X;
     out.iters = total_iter;
+    out.over = any_over;
     return out;
 }
 

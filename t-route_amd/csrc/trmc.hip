@@ -83,16 +83,26 @@ struct DevMathF {
     __device__ __forceinline__ Log log_of(float x) const { return trmc_det_log2(x, tab); }
     __device__ __forceinline__ float pow_l(Log l, float, float y) const { return trmc_det_powf_from_log(l, y, tab); }
     __device__ __forceinline__ float pow(float x, float y) const { return trmc_det_powf(x, y, tab); }
+    // the hydraulic radius under fast_ok's ranges: the bound is derived at fast_ok
+    __device__ __forceinline__ Log log_of_r(float x, bool ok) const { return ok ? trmc_det_log2_normal(x, tab) : trmc_det_log2(x, tab); }
+    __device__ __forceinline__ float pow_l_r(Log l, float, float y, bool ok) const
+    {
+        return ok ? trmc_det_powf_from_log_inrange(l, y, tab) : trmc_det_powf_from_log(l, y, tab);
+    }
 #elif TRMC_EXPERIMENT_POW == 1
     using Log = float;
     __device__ __forceinline__ Log log_of(float x) const { return x; }
     __device__ __forceinline__ float pow_l(Log, float x, float y) const { return ::powf(x, y); }
     __device__ __forceinline__ float pow(float x, float y) const { return ::powf(x, y); }
+    __device__ __forceinline__ Log log_of_r(float x, bool) const { return x; }
+    __device__ __forceinline__ float pow_l_r(Log, float x, float y, bool) const { return ::powf(x, y); }
 #else
     using Log = float;
     __device__ __forceinline__ Log log_of(float x) const { return __builtin_amdgcn_logf(x); }
     __device__ __forceinline__ float pow_l(Log l, float, float y) const { return __builtin_amdgcn_exp2f(y * l); }
     __device__ __forceinline__ float pow(float x, float y) const { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+    __device__ __forceinline__ Log log_of_r(float x, bool) const { return __builtin_amdgcn_logf(x); }
+    __device__ __forceinline__ float pow_l_r(Log l, float, float y, bool) const { return __builtin_amdgcn_exp2f(y * l); }
 #endif
     __device__ __forceinline__ float sqrt(float x) const { return ::sqrtf(x); }
 
@@ -117,6 +127,13 @@ struct DevMathF {
     // [2**-44, 2**51]; wp*n + wpc*ncc in [2**-28, 2**54]; the composite n in [2**-64, 2**18]; bw + 2hz in
     // [2**-14, 2**36] under 2*sqrt(1 + z*z) in [2, 2**19] -- all normal, no pair more than 2**80 apart, every quotient
     // normal: the scaling and fix-up instructions are the identity, and the refinement below IS the division.
+    // The hydraulic radius under the same conditions (log_of_r / pow_l_r skip the power's special-value tests): R is
+    // the mediant of the in-bank and the over-bank quotient area / wetted perimeter, so it lies between them.  In bank,
+    // A/WP = (bw + h z) h / (bw + 2 h sq), sq = sqrt(1 + z*z) >= 1: since bw + 2 h sq <= 2 sq (bw + h) and
+    // (bw + h z) / (bw + h) >= min(1, z), A/WP >= h min(1, z) / (2 sq) >= 2**-30 * 2**-17 / 2**15.1 > 2**-63, and
+    // A/WP <= h (1 + h z / bw) <= 2**17 (1 + 2**17 2**14 2**14) < 2**63; over bank, twcc h / (twcc + 2 h) lies between
+    // min(h, twcc) / 3 and h.  With one rounding of the quotient: 2**-64 < R < 2**63, a positive normal float whose
+    // logarithm times 5/3 stays within +-107 -- inside the +-126 where glibc's powf takes its ordinary path.
     bool sane;
     __device__ __forceinline__ bool fast_ok(float h, float h_in, float h_over) const
     {
@@ -197,6 +214,8 @@ struct DevMathD {
     __device__ __forceinline__ Log log_of(double x) const { return x; }
     __device__ __forceinline__ double pow_l(Log, double x, double y) const { return ::pow(x, y); }
     __device__ __forceinline__ double pow(double x, double y) const { return ::pow(x, y); }
+    __device__ __forceinline__ Log log_of_r(double x, bool) const { return x; }
+    __device__ __forceinline__ double pow_l_r(Log, double x, double y, bool) const { return ::pow(x, y); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     bool coef_ok; // unused
     bool sane;    // unused
@@ -249,7 +268,7 @@ template <class T> __device__ __forceinline__ const T &at(const T *base, uint32_
 // ---------------------------------------------------------------- kernels
 template <class T> struct StepArgs {
     const T *dx, *bw, *twcc, *n, *ncc, *s0;            // raw channel parameters the step still reads
-    const T *z, *bfd, *sqrt_s0, *sq1pz2, *s0_n, *s0_ncc; // segment-invariant constants formed at plan time (k_make_const)
+    const T *z, *bfd, *sqrt_s0, *sq1pz2, *s0_n, *s0_ncc, *inv_n; // segment-invariant constants formed at plan time (k_make_const)
     const T *dt_col; // nullptr -> uniform dt
     T dt;
     const int32_t *up_ptr, *up_idx, *level;
@@ -415,6 +434,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         c.sq1pz2 = at(a.sq1pz2, ob);
         c.s0_n = at(a.s0_n, ob);
         c.s0_ncc = at(a.s0_ncc, ob);
+        c.inv_n = at(a.inv_n, ob);
         c.two_sq = T(2) * c.sq1pz2;
         c.half_dt = p.dt / T(2);
         c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
@@ -502,14 +522,16 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // (the partition reads it on the next step; without the partition only trmc_download_iterations does, after
         // the window: one byte-masked store per row and step is 3 % of the launch)
         if (a.partition || t == a.nsteps) a.it_prev[su] = (uint8_t)min(r.iters, 255);
-        if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + min(r.iters, 3));
+        // cost of the step for the plan's cost hint: the iteration class, plus 4 where the compound-channel branch ran
+        // (a wavefront pays that branch -- two more divisions, one more power per evaluation -- as soon as one lane takes it)
+        if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + min(r.iters, 3) + (r.over ? 4 : 0));
     }
 }
 
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
 // written as six more SoA columns behind the nine parameter columns (same device arithmetic the
 // step kernel would otherwise repeat every timestep: 4 divisions and 2 square roots per segment-step)
-constexpr int kConstCols = 6, kTotalCols = TRMC_NPARAM + kConstCols;
+constexpr int kConstCols = 7, kTotalCols = TRMC_NPARAM + kConstCols;
 template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_make_const(T *cols, int32_t nseg, int64_t nseg_pad)
@@ -536,6 +558,7 @@ k_make_const(T *cols, int32_t nseg, int64_t nseg_pad)
     o[3 * nseg_pad] = c.sq1pz2;
     o[4 * nseg_pad] = c.s0_n;
     o[5 * nseg_pad] = c.s0_ncc;
+    o[6 * nseg_pad] = c.inv_n;
 }
 
 // forcing: in[row][nq] (caller order) -> qlat_tm[j][pos]; LDS tile of 64 positions x 32 columns
@@ -807,7 +830,7 @@ constexpr int kFlowStage = TRMC_FLOW_STAGE; // steps staged per thread before th
 
 struct FlowArgs {
     const float *dx, *bw, *twcc, *n, *ncc, *s0;
-    const float *z, *bfd, *sqrt_s0, *sq1pz2, *s0_n, *s0_ncc;
+    const float *z, *bfd, *sqrt_s0, *sq1pz2, *s0_n, *s0_ncc, *inv_n;
     const float *dt_col;
     float dt;
     const int32_t *up_ptr, *up_idx;
@@ -979,6 +1002,7 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
     c.sq1pz2 = at(a.sq1pz2, ob);
     c.s0_n = at(a.s0_n, ob);
     c.s0_ncc = at(a.s0_ncc, ob);
+    c.inv_n = at(a.inv_n, ob);
     c.two_sq = 2.0f * c.sq1pz2;
     c.half_dt = p.dt / 2.0f;
     c.fp_ok = (p.twcc > 0.0f) && (p.ncc > 0.0f);
@@ -1099,7 +1123,7 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
             v_new = r.velc;
             d_new = r.depthc;
             it_last = min(r.iters, 255);
-            it_acc += min(r.iters, 3);
+            it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
             if (gi >= 0) { // streamflow nudging, mc_reach.pyx:761-796 / simple_da.pyx:47-76 (see k_mc_step)
                 const size_t e = (size_t)gi * (size_t)a.nsteps + (size_t)(t - 1);
                 const uint8_t mode = a.da_mode[e];
@@ -1175,7 +1199,7 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
 #define TRMC_LEAN_WAVES 6
 #endif
 constexpr int kLeanRing = 2;
-constexpr int kLeanCols = 12;
+constexpr int kLeanCols = 13;
 
 __device__ __forceinline__ float lean_edge_get(int32_t u, int32_t l, uint32_t &flags, uint32_t ahead_bit, uint32_t never_bit,
                                                const unsigned long long *plane_row, const unsigned long long *ring, int32_t ws,
@@ -1238,6 +1262,7 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
         sp[9 * kFlowBlock] = at(a.sq1pz2, ob);
         sp[10 * kFlowBlock] = at(a.s0_n, ob);
         sp[11 * kFlowBlock] = at(a.s0_ncc, ob);
+        sp[12 * kFlowBlock] = at(a.inv_n, ob);
     }
     const float dt = a.dt_col ? a.dt_col[su] : a.dt;
     const int32_t lag = LAG ? a.lag[su] : 0;
@@ -1315,6 +1340,7 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
             c.sq1pz2 = sp[9 * kFlowBlock];
             c.s0_n = sp[10 * kFlowBlock];
             c.s0_ncc = sp[11 * kFlowBlock];
+            c.inv_n = sp[12 * kFlowBlock];
             c.two_sq = 2.0f * c.sq1pz2;
             c.half_dt = p.dt / 2.0f;
             c.fp_ok = (p.twcc > 0.0f) && (p.ncc > 0.0f);
@@ -1328,7 +1354,7 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
             q_new = r.qdc;
             v_new = r.velc;
             d_new = r.depthc;
-            its = ((its + (uint32_t)min(r.iters, 3)) & 0x00ffffffu) | ((uint32_t)min(r.iters, 255) << 24);
+            its = ((its + (uint32_t)min(r.iters, 3) + (r.over ? 4u : 0u)) & 0x00ffffffu) | ((uint32_t)min(r.iters, 255) << 24);
             if (flags & 64u) { // streamflow nudging (see k_mc_step)
                 const size_t e = (size_t)a.gage_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1);
                 const uint8_t mode = a.da_mode[e];
@@ -1550,6 +1576,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.sq1pz2 = col<T>(pl, TRMC_NPARAM + 3);
     a.s0_n = col<T>(pl, TRMC_NPARAM + 4);
     a.s0_ncc = col<T>(pl, TRMC_NPARAM + 5);
+    a.inv_n = col<T>(pl, TRMC_NPARAM + 6);
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.up2 = (const int2 *)pl->up2.p;
@@ -1792,6 +1819,7 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     a.sq1pz2 = col<float>(pl, TRMC_NPARAM + 3);
     a.s0_n = col<float>(pl, TRMC_NPARAM + 4);
     a.s0_ncc = col<float>(pl, TRMC_NPARAM + 5);
+    a.inv_n = col<float>(pl, TRMC_NPARAM + 6);
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.up2 = (const int2 *)pl->up2.p;

@@ -179,14 +179,17 @@ def generate(nseg=CONUS_NSEG, nnet=CONUS_NNET, seed=DEFAULT_SEED, nq=25, cache_d
     return out
 
 
-def forcing(nseg, nq=25, seed=DEFAULT_SEED + 1, previous=None, sigma=0.7, redraw=0.2):
+def forcing(nseg, nq=25, seed=DEFAULT_SEED + 1, previous=None, sigma=0.06, redraw=0.001):
     """Another day of lateral inflow with the statistics of ``generate``'s (11 % zeros, else lognormal with
     median 2.3e-4 m3/s, sigma 2.3, clipped at 1, times a smooth diurnal factor 1 +- 0.2) under its own seed -- the
     window a plan is TIMED on after it was tuned on another one.
     previous = None: an independent draw (no row keeps its magnitude: the hardest case for a plan tuned the day before).
     previous = the forcing of the day before [nseg, nq]: the next day of the SAME basin -- every row's daily mean times
     a lognormal factor (sigma), ``redraw`` of the rows drawn anew, new diurnal phases: lateral inflow is mostly
-    baseflow, whose spatial pattern persists from day to day."""
+    baseflow, whose spatial pattern persists from day to day.  The defaults are what the reference's own forcing files
+    show one day apart (test/LowerColorado_TX/channel_forcing, 2021-08-23 13:00-16:00 against 2021-08-24 13:00-16:00,
+    qBucket + qSfcLatRunoff of the 11 248 segments): standard deviation of the log ratio 0.056, rank correlation 0.9998,
+    0.05 % of the rows switch between zero and non-zero inflow."""
     rng = np.random.default_rng(seed)
     fresh = np.minimum(rng.lognormal(np.log(2.3e-4), 2.3, nseg), 1.0) * (rng.random(nseg) > 0.11)
     if previous is None:

@@ -420,7 +420,7 @@ def test_cost_hinted_plan_order_changes_nothing(short):
         assert_bit_identical(got, base, f"hinted plan short={short}")
     with pytest.raises(ValueError):
         RoutingPlan(up_ptr, up_idx, params, cost_hint=np.zeros(3, np.uint8))
-    # cost collection: per row the sum over the window of min(iterations, 3); same flows with it on
+    # cost collection: per row the sum over the window of min(iterations, 3) (+ 4 per over-bank step); same flows with it on
     with RoutingPlan(up_ptr, up_idx, params) as plan:
         with pytest.raises(RuntimeError):
             plan.download_cost()
@@ -432,7 +432,7 @@ def test_cost_hinted_plan_order_changes_nothing(short):
         with pytest.raises(RuntimeError):
             plan.download_cost()
     assert_bit_identical(got, base, "cost collection on")
-    assert n == nsteps and cost.dtype == np.uint16 and cost.max() <= 3 * nsteps
+    assert n == nsteps and cost.dtype == np.uint16 and cost.max() <= 7 * nsteps
     assert (cost >= np.minimum(last, 3)).all() and (cost[last >= 2] >= 2).all() and (cost == 0).any()
 
 
@@ -498,7 +498,8 @@ def test_conus_cost_hint_from_a_tuning_window(conus):
     a = r.outlet_hydrographs()
     hint = r.iteration_hint()
     r.close()
-    assert hint.shape == (nseg,) and 32 <= hint.max() <= 48 and len(np.unique(hint)) > 8
+    # sixteenths of the mean of min(iterations, 3) + 4 * (over-bank step): at most 16 * 7
+    assert hint.shape == (nseg,) and 32 <= hint.max() <= 112 and len(np.unique(hint)) > 8
     r = ShardedRouter(to, params, cost_hint=hint)
     r.upload(nsteps, qlat, q0)
     rows2 = r.route_resident(qts, True)
