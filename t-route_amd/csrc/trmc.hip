@@ -39,6 +39,7 @@
 
 #include "../../include/trmc.h"
 #include "det_pow.h"
+#include "det_pow64.h"
 #include "mc_segment.hpp"
 #include "levelpool.hpp"
 #include "topology.hpp"
@@ -207,15 +208,17 @@ struct DevMathF {
     }
 #endif
 };
-// fp64: device libm pow (about 1 ulp; not bit-reproducible against glibc)
+// fp64: the bit-reproducible double power of det_pow64.h (glibc 2.35 pow restated, the one the reference links when it
+// is built with -fdefault-real-8: oracle/_ref/libmc_ref_qj0_f64.so), so that the fp64 path -- BASELINE configs[1] -- is
+// bit-comparable with the reference too, not merely close; / and sqrt are the correctly rounded forms.
 struct DevMathD {
     const uint64_t *tab; // unused
     using Log = double;
     __device__ __forceinline__ Log log_of(double x) const { return x; }
-    __device__ __forceinline__ double pow_l(Log, double x, double y) const { return ::pow(x, y); }
-    __device__ __forceinline__ double pow(double x, double y) const { return ::pow(x, y); }
+    __device__ __forceinline__ double pow_l(Log, double x, double y) const { return det_pow64(x, y); }
+    __device__ __forceinline__ double pow(double x, double y) const { return det_pow64(x, y); }
     __device__ __forceinline__ Log log_of_r(double x, bool) const { return x; }
-    __device__ __forceinline__ double pow_l_r(Log, double x, double y, bool) const { return ::pow(x, y); }
+    __device__ __forceinline__ double pow_l_r(Log, double x, double y, bool) const { return det_pow64(x, y); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     bool coef_ok; // unused
     bool sane;    // unused
