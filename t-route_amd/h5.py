@@ -61,6 +61,7 @@ def lib():
             "H5Sclose": (C.c_int, [hid_t]),
             "H5Tget_class": (C.c_int, [hid_t]),
             "H5Tget_size": (C.c_size_t, [hid_t]),
+            "H5Tis_variable_str": (C.c_int, [hid_t]),
             "H5Tget_sign": (C.c_int, [hid_t]),
             "H5Tcopy": (hid_t, [hid_t]),
             "H5Tset_size": (C.c_int, [hid_t, C.c_size_t]),
@@ -199,7 +200,14 @@ class File:
         try:
             dt = _np_dtype_of(t)
             if dt.kind == "S":
-                raise TypeError(f"{name!r} is a string dataset")
+                # fixed-length strings (netCDF char arrays such as RouteLink's gages [link][15] or a TimeSlice's
+                # stationId: HDF5 strings of size 1 per element) come back as bytes, read with their own type
+                if h.H5Tis_variable_str(t) > 0:
+                    raise TypeError(f"{name!r} is a variable-length string dataset")
+                out = np.zeros(_dims(s), dtype=dt)
+                if out.size and h.H5Dread(d, t, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.ctypes.data_as(C.c_void_p)) < 0:
+                    raise OSError(f"H5Dread({name!r}) failed")
+                return out
             out = np.empty(_dims(s), dtype=dt)
             if out.size and h.H5Dread(d, _native(_NP_TO_H5[dt]), H5S_ALL, H5S_ALL, H5P_DEFAULT,
                                       out.ctypes.data_as(C.c_void_p)) < 0:

@@ -1,0 +1,167 @@
+"""The reference's SHIPPED LowerColorado configuration as one thing (test/LowerColorado_TX/test_AnA.yaml): streamflow
+nudging at the real USGS gages with the real observation and last-observation records (:71-93), the LAKEPARM level-pool
+waterbodies (:17) and the hybrid diffusive domain (:46) switched on TOGETHER -- GPU against the oracle, bit for bit.
+
+Fixtures (data read out of the reference's own files; generators committed next to them):
+  tests/golden/lowercolorado_gages.npz        make_shipped_config_fixture.py (RouteLink gages, usgs_TimeSlice, lastobs)
+  tests/golden/lowercolorado_waterbodies.npz  make_fixtures.py (LAKEPARM, waterbody crosswalk)
+  tests/golden/diffusive_lowercolorado.npz    make_diffusive_fixtures.py (coastal diffusive domain)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import oracle as O
+from troute_amd import nhd_network as nn
+
+GAGES = np.load(os.path.join(H.GOLDEN, "lowercolorado_gages.npz"))
+
+
+def test_gage_fixture_is_the_reference_data():
+    """56 of RouteLink's 76 gaged segments report on 2021-08-23; observations cover 13:00-23:45 on the routing grid."""
+    g = GAGES
+    assert g["gage_ids"].shape == (56,) and (np.diff(g["gage_ids"]) > 0).all()
+    lc = H.LowerColorado()
+    assert np.isin(g["gage_ids"], lc.ids).all()
+    u = g["usgs"]
+    assert u.shape == (56, 289) and u.dtype == np.float32
+    has = ~np.isnan(u)
+    assert has[:, :130].mean() > 0.8 and not has[:, 130:].any()       # nothing after 23:45: the decay branch takes over
+    assert (u[has] > 0).all()
+    assert (g["time_since_lastobs"] <= 0).all() and np.isfinite(g["lastobs_discharge"]).all()
+
+
+def shipped_case(nts):
+    """Tables of the shipped configuration: waterbodies collapsed to nodes, reaches split at waterbodies AND gages."""
+    import test_reservoirs as TR
+    lc, conn, wbody_map, conn_wb, link_lake = TR.collapsed_network()
+    lakes, wbody_cols = TR.lake_tables()
+    lakeset = set(lakes.tolist())
+    gage_ids = [int(s) for s in GAGES["gage_ids"] if int(s) in conn_wb]        # (none of them lies inside a lake)
+    assert len(gage_ids) == 56
+    ind, reaches_bytw, rconn = nn.organize_independent_networks(conn_wb, lakeset, set(gage_ids))
+    assert len(reaches_bytw) == 1
+    tw = next(iter(reaches_bytw))
+    reaches, net = reaches_bytw[tw], ind[tw]
+    reach_end = {r[-1] for r in reaches}
+    assert all(g in reach_end for g in gage_ids)                     # every gage ends its reach (nhd_network.py:319-338)
+    segs = sorted(s for r in reaches for s in r if s not in lakeset)
+    ids = np.array(sorted(segs + lakes.tolist()), np.int64)
+    row_old = {int(s): i for i, s in enumerate(lc.ids)}
+    is_lake = np.isin(ids, lakes)
+    dv = np.full((len(ids), lc.data_values.shape[1]), np.nan, np.float32)
+    ql = np.zeros((len(ids), lc.qlat.shape[1]), np.float32)
+    sel = np.array([row_old[int(s)] for s in ids[~is_lake]])
+    dv[~is_lake] = lc.data_values[sel]
+    ql[~is_lake] = lc.qlat[sel] * 40.0            # wetter than the fixture's forcing so that pools spill and gages see flow
+    q0 = np.zeros((len(ids), 3), np.float32)
+    return dict(lc=lc, conn_wb=conn_wb, wbody_map=wbody_map, rconn=rconn, ind=ind, reaches_bytw=reaches_bytw, tw=tw,
+                reaches=reaches, net=net, ids=ids, is_lake=is_lake, dv=dv, ql=ql, q0=q0, lakes=lakes, wbody_cols=wbody_cols,
+                lakeset=lakeset, gage_ids=gage_ids, nts=nts)
+
+
+def oracle_shipped(c, short):
+    """The restated reference loop with the nudging hook and the level-pool branch both active."""
+    lc, ids, reaches, net, lakes, nts = c["lc"], c["ids"], c["reaches"], c["net"], c["lakes"], c["nts"]
+    row = {int(s): i for i, s in enumerate(ids)}
+    rl = [np.array([row[s] for s in rr], dtype=np.int64) for rr in reaches]
+    ul = [np.array([row[s] for s in net.get(rr[0], [])], dtype=np.int64) for rr in reaches]
+    lake_pos = {int(l): k for k, l in enumerate(lakes)}
+    res_of_reach = np.array([lake_pos.get(rr[0], -1) if rr[0] in c["lakeset"] else -1 for rr in reaches], np.int64)
+    a = c["wbody_cols"].astype(np.float32)
+    par = np.concatenate([a[:, :8], np.full((len(lakes), 1), 10.0, np.float32)], 1)
+    h0 = (a[:, 4] + ((a[:, 1] - a[:, 4]).astype(np.float32) * a[:, 8]).astype(np.float32)).astype(np.float32)
+    res = dict(res_of_reach=res_of_reach, par=par, water_elevation=h0, routing_period=lc.dt)
+    reach_of = {r[-1]: i for i, r in enumerate(reaches)}
+    gage_of_reach = np.full(len(reaches), -1, np.int64)
+    for gi, g in enumerate(c["gage_ids"]):
+        gage_of_reach[reach_of[g]] = gi
+    da = dict(usgs_values=GAGES["usgs"], gage_row=np.array([row[g] for g in c["gage_ids"]], np.int64),
+              gage_of_reach=gage_of_reach, decay_coeff=120.0, routing_period=lc.dt,
+              lastobs_time=GAGES["time_since_lastobs"], lastobs_val=GAGES["lastobs_discharge"])
+    params9 = c["dv"][:, [H.DATA_COLS.index(k) for k in ("dt", "dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0")]]
+    q0 = c["q0"].copy()
+    usgs0 = GAGES["usgs"][:, 0]                   # initial flow <- first observation (mc_reach.pyx:404-411)
+    ok = ~np.isnan(usgs0)
+    q0[da["gage_row"][ok], 0] = usgs0[ok]
+    fvd = O.network(nts, lc.qts, rl, ul, params9, q0, c["ql"], short, det=True, da=da, res=res)
+    return fvd, da, res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("short", [True, False])
+def test_gpu_shipped_configuration_nudging_reservoirs_and_diffusive_together(short, monkeypatch):
+    import pandas as pd
+    import test_diffusive as TD
+    from troute_amd.routing import compute as RC
+    from troute_amd.routing.fast_reach import diffusive as DIFF
+    nts = 48 if short else 24
+    c = shipped_case(nts)
+    lc, ids, is_lake, lakes = c["lc"], c["ids"], c["is_lake"], c["lakes"]
+    cols = list(lc.data_cols)
+    param_df = pd.DataFrame(c["dv"][~is_lake], index=ids[~is_lake], columns=cols).drop(columns=["dt"])
+    z = np.load(os.path.join(H.GOLDEN, "diffusive_lowercolorado.npz"))
+    alt = pd.Series(z["alt"], index=lc.ids)
+    param_df["alt"] = alt.reindex(param_df.index).values
+    q0_df = pd.DataFrame(c["q0"][~is_lake], index=ids[~is_lake], columns=["qu0", "qd0", "h0"])
+    ql_df = pd.DataFrame(c["ql"][~is_lake], index=ids[~is_lake])
+    wb_df = pd.DataFrame(c["wbody_cols"], index=lakes, columns=["LkArea", "LkMxE", "OrificeA", "OrificeC", "OrificeE",
+                                                                 "WeirC", "WeirE", "WeirL", "ifd", "qd0", "h0"])
+    usgs_df = pd.DataFrame(GAGES["usgs"], index=c["gage_ids"])
+    lastobs_df = pd.DataFrame({"time_since_lastobs": GAGES["time_since_lastobs"],
+                               "lastobs_discharge": GAGES["lastobs_discharge"]}, index=c["gage_ids"])
+    e = pd.DataFrame()
+    t0 = pd.Timestamp("2021-08-23 13:00")
+    out = RC.compute_nhd_routing_v02(
+        c["conn_wb"], c["rconn"], c["wbody_map"], c["reaches_bytw"], "V02-structured", "by-network", 10000, 4, t0, lc.dt,
+        nts, lc.qts, c["ind"], param_df, q0_df, ql_df, usgs_df, lastobs_df, e, e, e, e, e, e, e, e, e,
+        {"da_decay_coefficient": 120.0}, short, False, wb_df, {}, e, False, [{}, {}])
+    results = out[0]                                           # nwm_route's unpacking, nwm_routing/__main__.py:1256-1257
+    assert len(results) == 1 and np.array_equal(results[0][0], ids)
+    r = results[0]
+    fvd = r[1].reshape(len(ids), nts, 3)
+
+    # ---- Muskingum-Cunge + nudging + level pools against the oracle ------------------------------------------------
+    want, da, res = oracle_shipped(c, short)
+    assert np.array_equal(fvd.view(np.uint32), np.ascontiguousarray(want[:, 1:, :]).view(np.uint32))
+    assert np.array_equal(r[3][0], np.array(c["gage_ids"]))
+    assert np.array_equal(r[8].view(np.uint32), da["nudge"].view(np.uint32)) and np.abs(r[8]).max() > 0
+    assert np.array_equal(r[3][1].view(np.uint32), da["lastobs_time"].view(np.uint32))
+    assert np.array_equal(r[3][2].view(np.uint32), da["lastobs_val"].view(np.uint32))
+    row = {int(s): i for i, s in enumerate(ids)}
+    lake_rows = np.array([row[int(l)] for l in lakes])
+    assert np.array_equal(r[6][lake_rows].view(np.uint32), res["inflow"][:, 1:].view(np.uint32))
+    assert np.array_equal(fvd[lake_rows, -1, 2], res["water_elevation"])
+    g_rows = da["gage_row"]
+    ok = ~np.isnan(GAGES["usgs"][:, 10])
+    assert ok.sum() > 40 and np.array_equal(fvd[g_rows[ok], 9, 0], GAGES["usgs"][ok, 10])   # a valid observation replaces
+
+    # ---- the hybrid hand-over: diffusive mainstem fed by THESE (nudged, reservoir-routed) tributary flows -----------
+    zz, _lc, tw, dn, _ql, _q0 = TD.lowercolorado_diffusive_network()
+    dn = dict(dn)
+    full_q0 = pd.DataFrame(np.zeros((lc.nseg, 3), np.float32), index=lc.ids, columns=["qu0", "qd0", "h0"])
+    full_ql = pd.DataFrame(lc.qlat * 40.0, index=lc.ids)
+    dsteps = 12
+    short_results = [(r[0], r[1][:, :3 * dsteps]) + tuple(r[2:])]
+    got = RC.compute_diffusive_routing(short_results, {tw: dn}, 1, t0, lc.dt, dsteps, full_q0, full_ql, lc.qts, e, e, {}, e,
+                                       e, None, None, e, e)
+    host = TD.host_oracle()
+
+    def host_batch(inputs, device=0):
+        outs = []
+        for ins in inputs:
+            rc, o = TD.call_c(host, "dw_oracle_diffnw", ins)
+            assert rc == 0
+            outs.append(tuple(np.ascontiguousarray(x) for x in o))
+        return outs
+    monkeypatch.setattr(DIFF, "compute_diffusive_batch", host_batch)
+    oracle_results = [(ids.astype(np.intp), np.ascontiguousarray(want[:, 1:dsteps + 1, :]).reshape(len(ids), -1))]
+    ref = RC.compute_diffusive_routing(oracle_results, {tw: dn}, 1, t0, lc.dt, dsteps, full_q0, full_ql, lc.qts, e, e, {}, e,
+                                       e, None, None, e, e)
+    assert len(got) == len(ref) == 1
+    assert np.array_equal(got[0][0], ref[0][0]) and got[0][1].shape == ref[0][1].shape
+    assert np.array_equal(got[0][1].view(np.uint64) if got[0][1].dtype == np.float64 else got[0][1].view(np.uint32),
+                          ref[0][1].view(np.uint64) if ref[0][1].dtype == np.float64 else ref[0][1].view(np.uint32))
+    assert np.nanmax(np.abs(got[0][1])) > 0.1
