@@ -90,6 +90,31 @@ def lib():
     raise RuntimeError(f"libhdf5 not found ({err}); set TRMC_HDF5_LIB to its path")
 
 
+_HL = None
+
+
+def hl():
+    """libhdf5_hl (dimension scales: how NetCDF-4 stores its dimensions), loaded beside libhdf5."""
+    global _HL
+    if _HL is not None:
+        return _HL
+    lib()
+    err = None
+    for n in ("/opt/conda/lib/libhdf5_hl.so", "libhdf5_hl.so", "libhdf5_serial_hl.so", ctypes.util.find_library("hdf5_hl")):
+        if not n:
+            continue
+        try:
+            h = C.CDLL(n)
+        except OSError as e:
+            err = e
+            continue
+        h.H5DSset_scale.restype, h.H5DSset_scale.argtypes = C.c_int, [hid_t, C.c_char_p]
+        h.H5DSattach_scale.restype, h.H5DSattach_scale.argtypes = C.c_int, [hid_t, hid_t, C.c_uint]
+        _HL = h
+        return h
+    raise RuntimeError(f"libhdf5_hl not found ({err})")
+
+
 def _native(name):
     return hid_t.in_dll(lib(), name).value
 
@@ -139,6 +164,7 @@ class File:
             raise ValueError("mode must be 'r' or 'w'")
         if self._id < 0:
             raise OSError(f"cannot open {self.path!r} as HDF5 ({'read' if mode == 'r' else 'write'})")
+        self._dims = {}            # NetCDF-4 dimensions created in this file: name -> size
 
     def close(self):
         if getattr(self, "_id", -1) >= 0:
@@ -218,6 +244,17 @@ class File:
             h.H5Sclose(s)
             h.H5Dclose(d)
 
+    def has_attr(self, name, attr):
+        """Does dataset `name` (the file when None) carry attribute `attr`?  (Also for attribute types ``attr`` cannot
+        return, such as the object-reference lists of dimension scales.)"""
+        h = lib()
+        obj = self._id if name is None else self._open(name)
+        try:
+            return h.H5Aexists(obj, attr.encode()) > 0
+        finally:
+            if name is not None:
+                h.H5Dclose(obj)
+
     def attr(self, name, attr, default=None):
         """One attribute of dataset `name` (or of the file when name is None): numpy array / bytes."""
         h = lib()
@@ -265,14 +302,37 @@ class File:
                 "fills": fills, "vmin": lo, "vmax": hi}
 
     # ---- writing -------------------------------------------------------------------------------------
-    def write(self, name, array, attrs=None):
-        """Create dataset `name` from a numeric numpy array; attrs: {name: number | numpy array | str}."""
+    def dimension(self, name, size):
+        """A NetCDF-4 dimension that is not a variable: an HDF5 dimension scale of `size` elements whose NAME says so
+        (the convention the netCDF-4 library writes and expects, e.g. /string15 in the reference's lastobs files)."""
+        h = lib()
+        dims = (hsize_t * 1)(size)
+        sp = h.H5Screate_simple(1, dims, None)
+        t = _native("H5T_NATIVE_FLOAT_g")
+        d = h.H5Dcreate2(self._id, name.encode(), t, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+        h.H5Sclose(sp)
+        if d < 0:
+            raise OSError(f"cannot create dimension {name!r}")
+        try:
+            if hl().H5DSset_scale(d, ("This is a netCDF dimension but not a netCDF variable.%10d" % size).encode()) < 0:
+                raise OSError(f"H5DSset_scale({name!r}) failed")
+            _write_attr(d, "_Netcdf4Dimid", np.int32(len(self._dims)))
+        finally:
+            h.H5Dclose(d)
+        self._dims[name] = size
+
+    def write(self, name, array, attrs=None, dims=None):
+        """Create dataset `name` from a numeric numpy array; attrs: {name: number | numpy array | str}.
+        dims: names of the NetCDF-4 dimensions of its axes.  A dimension of the dataset's own name makes it a coordinate
+        variable (the dataset becomes the dimension scale); other names must exist (``dimension`` or an earlier
+        coordinate variable) and are attached as scales (DIMENSION_LIST / REFERENCE_LIST), so that netCDF-4 readers see
+        named, shared dimensions instead of anonymous ones."""
         h = lib()
         a = np.ascontiguousarray(array)
         if a.dtype not in _NP_TO_H5:
             raise TypeError(f"unsupported dtype {a.dtype}")
-        dims = (hsize_t * max(1, a.ndim))(*(a.shape if a.ndim else (1,)))
-        s = h.H5Screate_simple(max(1, a.ndim), dims, None)
+        extent = (hsize_t * max(1, a.ndim))(*(a.shape if a.ndim else (1,)))
+        s = h.H5Screate_simple(max(1, a.ndim), extent, None)
         t = _native(_NP_TO_H5[a.dtype])
         d = h.H5Dcreate2(self._id, name.encode(), t, s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
         if d < 0:
@@ -283,8 +343,58 @@ class File:
                 raise OSError(f"H5Dwrite({name!r}) failed")
             for k, v in (attrs or {}).items():
                 _write_attr(d, k, v)
+            if dims is not None:
+                if len(dims) != a.ndim:
+                    raise ValueError(f"{name!r}: {a.ndim} axes but {len(dims)} dimension names")
+                if len(dims) == 1 and dims[0] == name:          # coordinate variable: it IS the dimension
+                    if hl().H5DSset_scale(d, name.encode()) < 0:
+                        raise OSError(f"H5DSset_scale({name!r}) failed")
+                    _write_attr(d, "_Netcdf4Dimid", np.int32(len(self._dims)))
+                    self._dims[name] = a.shape[0]
+                else:
+                    for ax, dn in enumerate(dims):
+                        if dn not in self._dims or self._dims[dn] != a.shape[ax]:
+                            raise ValueError(f"{name!r}: axis {ax} does not match dimension {dn!r}")
+                        sc = h.H5Dopen2(self._id, dn.encode(), H5P_DEFAULT)
+                        rc = hl().H5DSattach_scale(d, sc, ax)
+                        h.H5Dclose(sc)
+                        if rc < 0:
+                            raise OSError(f"H5DSattach_scale({name!r}, {dn!r}) failed")
         finally:
             h.H5Sclose(s)
+            h.H5Dclose(d)
+
+    def write_chars(self, name, rows, width, attrs=None, dims=None):
+        """A NetCDF char array [len(rows)][width] (HDF5 strings of size 1, null-terminated padding: what the netCDF-4
+        library writes for NC_CHAR, e.g. RouteLink's gages) from byte strings of exactly `width` bytes."""
+        h = lib()
+        raw = np.frombuffer(b"".join(rows), dtype="S1").reshape(len(rows), width) if rows else np.zeros((0, width), "S1")
+        t = h.H5Tcopy(_native("H5T_C_S1_g"))
+        h.H5Tset_size(t, 1)
+        shape = (hsize_t * 2)(len(rows), width)
+        sp = h.H5Screate_simple(2, shape, None)
+        d = h.H5Dcreate2(self._id, name.encode(), t, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+        if d < 0:
+            h.H5Sclose(sp)
+            h.H5Tclose(t)
+            raise OSError(f"cannot create dataset {name!r}")
+        try:
+            buf = np.ascontiguousarray(raw)
+            if buf.size and h.H5Dwrite(d, t, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.ctypes.data_as(C.c_void_p)) < 0:
+                raise OSError(f"H5Dwrite({name!r}) failed")
+            for k, v in (attrs or {}).items():
+                _write_attr(d, k, v)
+            for ax, dn in enumerate(dims or []):
+                if dn not in self._dims or self._dims[dn] != raw.shape[ax]:
+                    raise ValueError(f"{name!r}: axis {ax} does not match dimension {dn!r}")
+                sc = h.H5Dopen2(self._id, dn.encode(), H5P_DEFAULT)
+                rc = hl().H5DSattach_scale(d, sc, ax)
+                h.H5Dclose(sc)
+                if rc < 0:
+                    raise OSError(f"H5DSattach_scale({name!r}, {dn!r}) failed")
+        finally:
+            h.H5Sclose(sp)
+            h.H5Tclose(t)
             h.H5Dclose(d)
 
     def set_attr(self, key, value):

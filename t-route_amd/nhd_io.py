@@ -241,20 +241,23 @@ def write_flowveldepth_netcdf(stream_output_directory, file_name, flow, velocity
         typ = ["ch"] * len(fid)
     path = os.path.join(os.fspath(stream_output_directory), file_name)
     with h5.File(path, "w") as f:
+        # dimensions feature_id, time, type_strlen (nhd_io.py:2100-2104) as HDF5 dimension scales: feature_id and time
+        # are coordinate variables, type_strlen a bare dimension; every variable has them attached
+        f.write("feature_id", fid, {"long_name": "Segment ID"}, dims=["feature_id"])
         f.write("time", np.asarray(timestamps, dtype=np.float64),
                 {"long_name": "valid output time", "standard_name": "time",
                  "units": f"seconds since {t0.strftime('%Y-%m-%d %H:%M:%S')}", "missing_value": np.float64(-9999.0),
-                 "_FillValue": np.float64(-9999.0)})
-        f.write("feature_id", fid, {"long_name": "Segment ID"})
+                 "_FillValue": np.float64(-9999.0)}, dims=["time"])
         width = max([len(t) for t in typ] + [1])
-        f.write("type", np.frombuffer(b"".join(t.encode().ljust(width, b"\0") for t in typ), dtype=np.uint8)
-                .reshape(len(typ), width), {"long_name": "Type"})
+        f.dimension("type_strlen", width)
+        f.write_chars("type", [t.encode().ljust(width, b"\0") for t in typ], width, {"long_name": "Type"},
+                      dims=["feature_id", "type_strlen"])
         for name, frame, long_name, units in (("flow", flow, "Flow", "m3 s-1"), ("velocity", velocity, "Velocity", "m/s"),
                                               ("depth", depth, "Depth", "m"),
                                               ("nudge", nudge_df, "Streamflow Nudge Value", "m3 s-1")):
             f.write(name, np.asarray(frame, dtype=np.float32),
                     {"long_name": long_name, "units": units, "missing_value": np.float32(-9999.0),
-                     "_FillValue": np.float32(-9999.0)})
+                     "_FillValue": np.float32(-9999.0)}, dims=["feature_id", "time"])
         f.set_attr("TITLE", "OUTPUT FROM T-ROUTE")
         f.set_attr("file_reference_time", t0.strftime("%Y-%m-%d_%H:%M:%S"))
         f.set_attr("code_version", "")

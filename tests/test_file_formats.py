@@ -88,22 +88,82 @@ def test_restart_readers_and_writers(tmp_path):
 
 
 def test_write_flowveldepth_netcdf_layout(tmp_path):
+    """Variables, attributes and fill values of the reference's writer (nhd_io.py:2089-2235), in a NetCDF-4 container:
+    the dimensions feature_id, time and type_strlen (:2100-2104) exist as HDF5 dimension scales and are attached to
+    every variable -- the structure the netCDF-4 library writes, read off the reference's own NetCDF files below."""
     n, nt = 7, 5
     rng = np.random.default_rng(0)
     idx = pd.MultiIndex.from_arrays([np.arange(100, 100 + n), ["ch"] * (n - 1) + ["wb"]], names=["featureID", "Type"])
     fr = [pd.DataFrame(rng.random((n, nt)).astype(np.float32), index=idx) for _ in range(4)]
     t0 = datetime.datetime(2021, 8, 23, 13, 0)
     path = nhd_io.write_flowveldepth_netcdf(tmp_path, "fvd.nc", fr[0], fr[1], fr[2], fr[3], np.arange(nt) * 300.0, t0)
+    # the reference writer's variables and their attributes, name for name
+    want_attrs = {"time": {"long_name", "standard_name", "units", "missing_value", "_FillValue"},
+                  "feature_id": {"long_name"}, "type": {"long_name"}}
+    for v in ("flow", "velocity", "depth", "nudge"):
+        want_attrs[v] = {"long_name", "units", "missing_value", "_FillValue"}
     with h5.File(path) as f:
-        assert {"time", "feature_id", "type", "flow", "velocity", "depth", "nudge"} <= set(f.names())
+        assert set(f.names()) == set(want_attrs) | {"type_strlen"}
+        for v, names in want_attrs.items():
+            for a in names:
+                assert f.has_attr(v, a), (v, a)
         assert f.shape("flow") == (n, nt) and f.read("flow").dtype == np.float32
         for name, frame in zip(("flow", "velocity", "depth", "nudge"), fr):
             assert np.array_equal(f.read(name), frame.values)
         assert np.array_equal(f.read("feature_id"), np.arange(100, 100 + n))
         assert f.attr("flow", "units") == b"m3 s-1" and f.attr("time", "units") == b"seconds since 2021-08-23 13:00:00"
-        assert f.attr("flow", "_FillValue")[0] == np.float32(-9999.0)
-        assert f.attr(None, "TITLE") == b"OUTPUT FROM T-ROUTE"
-        assert bytes(f.read("type")[-1]).rstrip(b"\0") == b"wb"
+        assert f.attr("flow", "long_name") == b"Flow" and f.attr("nudge", "long_name") == b"Streamflow Nudge Value"
+        assert f.attr("velocity", "units") == b"m/s" and f.attr("depth", "units") == b"m"
+        assert f.attr("flow", "_FillValue")[0] == np.float32(-9999.0) and f.attr("flow", "missing_value")[0] == np.float32(-9999.0)
+        assert f.attr("time", "_FillValue")[0] == -9999.0 and f.attr("time", "standard_name") == b"time"
+        assert f.attr(None, "TITLE") == b"OUTPUT FROM T-ROUTE" and f.attr(None, "file_reference_time") == b"2021-08-23_13:00:00"
+        assert f.has_attr(None, "code_version")
+        assert b"".join(f.read("type")[-1].tolist()) == b"wb" and f.shape("type") == (n, 2)
+        # NetCDF-4 structure: dimensions are dimension scales, variables reference them
+        for dim in ("feature_id", "time", "type_strlen"):
+            assert f.attr(dim, "CLASS") == b"DIMENSION_SCALE" and f.has_attr(dim, "NAME") and f.has_attr(dim, "_Netcdf4Dimid")
+        assert f.attr("type_strlen", "NAME").startswith(b"This is a netCDF dimension but not a netCDF variable.")
+        for v in ("flow", "velocity", "depth", "nudge", "type"):
+            assert f.has_attr(v, "DIMENSION_LIST")
+        for dim in ("feature_id", "time"):
+            assert f.has_attr(dim, "REFERENCE_LIST")
+    # the same structural attributes on a file the netCDF-4 library itself wrote (the reference's CHRTOUT)
+    with h5.File(CHRT[0]) as f:
+        assert f.attr("feature_id", "CLASS") == b"DIMENSION_SCALE" and f.has_attr("feature_id", "NAME")
+        assert f.has_attr("feature_id", "_Netcdf4Dimid") and f.has_attr("feature_id", "REFERENCE_LIST")
+        assert f.has_attr("streamflow", "DIMENSION_LIST")
+
+
+def test_decoding_of_planted_fill_and_out_of_range_cells_against_h5dump(tmp_path):
+    """A packed variable written with cells planted at _FillValue, at missing_value, below valid_min and above valid_max:
+    h5dump's independent view of the bytes and attributes on disk, decoded by the CF rule the forcing ingest implements
+    (masked -> 0, else raw * scale_factor + add_offset in double), equals the reader + decoder of this package.  (The
+    rule itself is netCDF4-python's documented default; that library is not in the image, so this pins everything BUT
+    the library's own behaviour -- DESIGN.md states it.)"""
+    import subprocess
+    raw = np.array([7, -999900000, -888800000, -1, 2000000001, 0, 2000000000, 123456], dtype=np.int32)
+    path = os.path.join(tmp_path, "packed.nc")
+    with h5.File(path, "w") as f:
+        f.write("feature_id", np.arange(raw.shape[0], dtype=np.int64), {}, dims=["feature_id"])
+        f.write("qBucket", raw, {"scale_factor": np.float32(1e-5), "add_offset": np.float32(0.0),
+                                 "_FillValue": np.int32(-999900000), "missing_value": np.int32(-888800000),
+                                 "valid_range": np.array([0, 2000000000], np.int32)}, dims=["feature_id"])
+    dump = os.path.join(tmp_path, "q.bin")
+    h5dump = "/opt/conda/bin/h5dump"
+    if not os.path.exists(h5dump):
+        pytest.skip("h5dump not available")
+    subprocess.run([h5dump, "-d", "/qBucket", "-b", "LE", "-o", dump, path], check=True, stdout=subprocess.DEVNULL)
+    on_disk = np.fromfile(dump, dtype="<i4")
+    assert np.array_equal(on_disk, raw)
+    txt = subprocess.run([h5dump, "-A", "-d", "/qBucket", path], check=True, capture_output=True, text=True).stdout
+    assert "-999900000" in txt and "-888800000" in txt and "2000000000" in txt and "1e-05" in txt
+    masked = (on_disk == -999900000) | (on_disk == -888800000) | (on_disk < 0) | (on_disk > 2000000000)
+    want = np.where(masked, 0.0, on_disk.astype(np.float64) * np.float64(np.float32(1e-5)) + 0.0)
+    with h5.File(path) as f:
+        pk = f.packing("qBucket")
+        got, m = h5.unpack(f.read("qBucket"), pk, 0.0)
+    assert m.tolist() == masked.tolist() and np.array_equal(got, want)
+    assert sorted(int(x) for x in pk["fills"]) == [-999900000, -888800000] and (pk["vmin"], pk["vmax"]) == (0, 2000000000)
 
 
 def test_chrtout_packed_host_rule():
