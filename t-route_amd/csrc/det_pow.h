@@ -36,6 +36,11 @@
  *
  * Requires -ffp-contract=off (every fused operation is explicit) and
  * round-to-nearest.  Plain C99 / C++ / HIP.
+ *
+ * Provenance and licence of the restated third-party material: the algorithm and the table / coefficient values are
+ * those of the GNU C Library 2.35 (LGPL-2.1-or-later), whose powf / pow are the ARM Optimized Routines implementations
+ * (math/powf.c, math/pow.c and their data files; Copyright (c) 2017-2018 Arm Limited; SPDX MIT OR Apache-2.0 WITH
+ * LLVM-exception).  Nothing here comes from the T-Route tree.
  */
 #ifndef TRMC_DET_POW_H
 #define TRMC_DET_POW_H

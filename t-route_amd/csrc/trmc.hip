@@ -2211,6 +2211,9 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
     if ((rc = upload_i32(pl->up_idx, pl->topo.up_idx, 1))) return bail(rc);
     {
         if (nseg >= (int64_t)1 << 30) return bail(fail(TRMC_EINVAL, "more than 2**30 segments in one plan"));
+        // (the step kernels address a column with a 32-bit BYTE offset: position * element size)
+        if ((uint64_t)pl->nseg_pad * pl->esz >= (1ull << 32))
+            return bail(fail(TRMC_EINVAL, "too many segments for one plan at this precision (column size reaches 4 GiB)"));
         std::vector<int32_t> up2((size_t)pl->nseg_pad * 2, -1);
         for (int64_t p = 0; p < nseg; ++p) {
             const int32_t k0 = pl->topo.up_ptr[p], k1 = pl->topo.up_ptr[p + 1];
@@ -2467,10 +2470,18 @@ int trmc_set_nudging(trmc_plan *pl, int nsteps, int64_t ngage, const int64_t *ga
     if (!gage_rows || !mode || !a || !w) return fail(TRMC_EINVAL, "nudging table pointer is NULL");
     if (int rc = use_device(pl)) return rc;
     std::vector<int32_t> g_of_pos((size_t)pl->nseg_pad, -1);
+    std::vector<int32_t> res_of_pos;
+    if (pl->nres > 0) {
+        res_of_pos.resize((size_t)pl->nseg_pad);
+        HIP_TRY(hipMemcpy(res_of_pos.data(), pl->res_of_pos.p, (size_t)pl->nseg_pad * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     for (int64_t g = 0; g < ngage; ++g) {
         const int64_t r = gage_rows[g];
         if (r < 0 || r >= pl->nseg) return fail(TRMC_EINVAL, "gage row out of range");
         if (pl->topo.level_of_row[r] < 0) return fail(TRMC_EINVAL, "gage on a boundary row");
+        // (the reservoir branch of the kernels ends a row's step before the nudging hook)
+        if (!res_of_pos.empty() && res_of_pos[(size_t)pl->topo.pos_of_row[r]] >= 0)
+            return fail(TRMC_EINVAL, "a gage on a reservoir row is not supported (row " + std::to_string(r) + ")");
         g_of_pos[pl->topo.pos_of_row[r]] = (int32_t)g; // one gage per segment: the last listed wins, as reach_has_gage does
     }
     const size_t n = (size_t)ngage * nsteps, e = pl->esz;
