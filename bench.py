@@ -233,7 +233,7 @@ def main():
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
-    from troute_amd import _lib, synthetic
+    from troute_amd import _lib, sharding, synthetic
     from troute_amd.distributed import ShardedRouter
 
     if _lib.device_count() < 1:
@@ -276,8 +276,10 @@ def main():
             out.copy_(torch.stack(parts).to(out.device))
 
     def make_router(hint, short_ts, qlat, state):
+        # with a hint (the measured cost of every row on the tuning day) the partition is packed by cost as well
+        part = sharding.partition(to, world, row_cost=hint) if (hint is not None and world > 1) else None
         r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint,
-                          assume_short_ts=short_ts)
+                          assume_short_ts=short_ts, partition=part)
         r.upload(a.nsteps, qlat, state)
         if use_dist:
             import torch

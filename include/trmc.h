@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 5
+#define TRMC_ABI_VERSION 6
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -274,6 +274,11 @@ int trmc_gather_flow_range(trmc_plan *plan, int32_t rowset, int t_begin, int t_e
  * (t_begin, t_end]; ranges must be supplied in order, t_begin = end of the previous one (0 first). */
 int trmc_set_boundary_flow_range(trmc_plan *plan, int t_begin, int t_end, const void *q_dev, int64_t src_stride,
                                  void *stream /* hipStream_t to queue the copy on; NULL = the plan's */);
+/* The same with a gather: boundary row b takes the source row src_index_dev[b] (device int64 [nboundary]) of q_dev --
+ * e.g. its cut row's place in the block an all-gather delivered -- so that no separate gather kernel sits between the
+ * collective and the boundary rows.  NULL = the identity. */
+int trmc_set_boundary_flow_range_indexed(trmc_plan *plan, int t_begin, int t_end, const void *q_dev,
+                                         int64_t src_stride, const int64_t *src_index_dev, void *stream);
 /*
  * Time-skewed rows (assume_short_ts only).  lag_of_row[nseg] holds 0 or one common value L: launch d of the
  * window routes the rows without lag at step d and the lagged rows at step d - L, so a window takes

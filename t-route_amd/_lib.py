@@ -62,6 +62,7 @@ SIGNATURES = {
     "trmc_rowset_create": (_int, [_vp, _vp, _i64, _P(_i32)]),
     "trmc_gather_flow_range": (_int, [_vp, _i32, _int, _int, _vp, _i64]),
     "trmc_set_boundary_flow_range": (_int, [_vp, _int, _int, _vp, _i64, _vp]),
+    "trmc_set_boundary_flow_range_indexed": (_int, [_vp, _int, _int, _vp, _i64, _vp, _vp]),
     "trmc_plan_set_lag": (_int, [_vp, _vp]),
     "trmc_download_fvd": (_int, [_vp, _vp]),
     "trmc_download_final_state": (_int, [_vp, _vp]),

@@ -163,7 +163,7 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
     } else {
         hp.ck = T(0);
     }
-    hp.km = (hp.ck > T(0)) ? mc_max(p.dt, p.dx / hp.ck) : p.dt;
+    hp.km = (hp.ck > T(0)) ? mc_max(p.dt, m.divx(p.dx, hp.ck)) : p.dt;
     hp.denom = T(2) * (over ? p.twcc : s.twl) * p.s0 * hp.ck * p.dx;
     hp.has_wp = (s.wp + s.wpc) > T(0);
     hp.over = over;
@@ -188,12 +188,12 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
             if (qj_prev == T(0) && (denom > T(0) || denom < T(0)))
                 x = T(0.5);
             else
-                x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - (qj_prev / denom))));
+                x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - m.divx(qj_prev, denom))));
         } else
             x = mc_min(T(0.5),
                        mc_max(T(0.25),
-                              T(0.5) * (T(1) - (((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4)
-                                                / denom))));
+                              T(0.5) * (T(1) - m.divx(((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4),
+                                                       denom))));
     } else {
         x = T(0.5);
     }
@@ -277,7 +277,7 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
             const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k, m);
             T h_1;
             if (qj_0 - qj != T(0)) {
-                h_1 = h - ((qj * (h_0 - h)) / (qj_0 - qj));
+                h_1 = h - m.divx(qj * (h_0 - h), qj_0 - qj);
                 if (h_1 < T(0)) h_1 = h;
             } else {
                 h_1 = h;

@@ -138,7 +138,7 @@ struct DevMathF {
     bool sane;
     __device__ __forceinline__ bool fast_ok(float h, float h_in, float h_over) const
     {
-#if TRMC_EXPERIMENT_DIV == 0
+#if TRMC_EXPERIMENT_DIV != 1
         return sane && h_in >= 0x1p-30f && h <= 0x1p17f && (h_over == 0.0f || h_over >= 0x1p-30f);
 #else
         return false;
@@ -165,13 +165,22 @@ struct DevMathF {
         if (ok) return quot(a, b, refined_rcp(b));
         return a / b;
     }
+    // the remaining divisions of a secant iteration (weighting factor, K = dx / celerity, secant update): IEEE
+    __device__ __forceinline__ float divx(float a, float b) const
+    {
+#if TRMC_EXPERIMENT_DIV == 2 // timing experiment only: what would range proofs for these four divisions buy?
+        return quot(a, b, refined_rcp(b));
+#else
+        return a / b;
+#endif
+    }
     __device__ __forceinline__ static float quot(float a, float b, float y1)
     {
         const float q0 = a * y1;
         const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y1, q0);
         return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y1, q1);
     }
-#if TRMC_EXPERIMENT_DIV == 0
+#if TRMC_EXPERIMENT_DIV != 1
     bool coef_ok;
     __device__ __forceinline__ static float refined_quot(float a, float b, float y1)
     {
@@ -229,6 +238,7 @@ struct DevMathD {
         q2 = a2 / b;
     }
     __device__ __forceinline__ double div1(double a, double b, bool) const { return a / b; }
+    __device__ __forceinline__ double divx(double a, double b) const { return a / b; }
     __device__ __forceinline__ void div4(double n1, double n2, double n3, double n4, double d, double &q1, double &q2,
                                          double &q3, double &q4) const
     {
@@ -761,14 +771,14 @@ k_gather_range(const T *__restrict__ q_tm, const int32_t *__restrict__ pos, T *_
 template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_fill_boundary_range(const T *__restrict__ q, T *q_tm, T *v_tm, T *d_tm, int32_t nboundary, int64_t nseg_pad,
-                      int32_t t_begin, int32_t t_end, int64_t stride)
+                      int32_t t_begin, int32_t t_end, int64_t stride, const int64_t *__restrict__ src_index)
 {
     const int32_t w = t_end - t_begin;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= (int64_t)nboundary * w) return;
     const int32_t b = (int32_t)(i / w), k = (int32_t)(i % w);
     const size_t dst = (size_t)(t_begin + 1 + k) * nseg_pad + b;
-    q_tm[dst] = q[(size_t)b * stride + k];
+    q_tm[dst] = q[(size_t)(src_index ? src_index[b] : b) * stride + k]; // (src_index: which source row feeds boundary row b)
     v_tm[dst] = T(0);
     d_tm[dst] = T(0);
 }
@@ -1300,7 +1310,6 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     float ql = 0.0f;
     uint32_t its = 0; // iterations: low 24 bits the sum of min(iterations, 3), high 8 bits those of the last step
-
     for (int32_t t = t_lo; t <= t_hi && !dead; ++t) {
         const uint32_t tag_p = a.tag_base + (uint32_t)(t - 1);
         const unsigned long long *g_prev = a.gran + (size_t)(t - 1) * np;
@@ -1412,13 +1421,14 @@ k_flow_init(const float *__restrict__ q0, const int32_t *__restrict__ row_of_pos
 __global__ void __launch_bounds__(kBlock)
 k_flow_boundary(const float *__restrict__ src, unsigned long long *gran, float *__restrict__ out,
                 const int32_t *__restrict__ row_of_pos, int32_t nboundary, int32_t nsteps, int64_t nseg_pad, int32_t t_begin,
-                int32_t t_end, int64_t stride_b, int32_t stride_t, int32_t ncomp, uint32_t tag_base)
+                int32_t t_end, int64_t stride_b, int32_t stride_t, int32_t ncomp, uint32_t tag_base,
+                const int64_t *__restrict__ src_index)
 {
     const int32_t w = t_end - t_begin;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= (int64_t)nboundary * w) return;
     const int32_t b = (int32_t)(i / w), k = (int32_t)(i % w), t = t_begin + 1 + k;
-    const float *v = src + (size_t)b * stride_b + (size_t)k * stride_t;
+    const float *v = src + (size_t)(src_index ? src_index[b] : b) * stride_b + (size_t)k * stride_t;
     const float q = v[0];
     gran[(size_t)t * nseg_pad + b] = ((unsigned long long)(tag_base + (uint32_t)t) << 32) | (unsigned long long)__float_as_uint(q);
     float *o = out + ((size_t)row_of_pos[b] * nsteps + (t - 1)) * 3;
@@ -1912,7 +1922,7 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     if (tp.nboundary > 0 && pl->have_boundary) {
         hipLaunchKernelGGL(k_flow_boundary, dim3(blocks_for(tp.nboundary * (int64_t)nsteps)), dim3(kBlock), 0, st,
                            (const float *)pl->in_bfvd.p, (unsigned long long *)pl->tm.p, (float *)pl->out.p, row_of_pos,
-                           (int32_t)tp.nboundary, nsteps, np, 0, nsteps, (int64_t)nsteps * 3, 3, 3, pl->tag_base);
+                           (int32_t)tp.nboundary, nsteps, np, 0, nsteps, (int64_t)nsteps * 3, 3, 3, pl->tag_base, (const int64_t *)nullptr);
         r.boundary_through = nsteps;
     }
     HIP_TRY(hipEventRecord(pl->ev[1], st));
@@ -2697,6 +2707,12 @@ int trmc_gather_flow_range(trmc_plan *pl, int32_t rowset, int t_begin, int t_end
 int trmc_set_boundary_flow_range(trmc_plan *pl, int t_begin, int t_end, const void *q_dev, int64_t src_stride,
                                  void *stream)
 {
+    return trmc_set_boundary_flow_range_indexed(pl, t_begin, t_end, q_dev, src_stride, nullptr, stream);
+}
+
+int trmc_set_boundary_flow_range_indexed(trmc_plan *pl, int t_begin, int t_end, const void *q_dev, int64_t src_stride,
+                                         const int64_t *src_index_dev, void *stream)
+{
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (!pl->run.active) return fail(TRMC_ESTATE, "trmc_route_begin must precede trmc_set_boundary_flow_range");
     RouteRun &r = pl->run;
@@ -2716,15 +2732,15 @@ int trmc_set_boundary_flow_range(trmc_plan *pl, int t_begin, int t_end, const vo
     if (pl->flow) {
         hipLaunchKernelGGL(k_flow_boundary, dim3(blocks_for(work)), dim3(kBlock), 0, st, (const float *)q_dev,
                            (unsigned long long *)pl->tm.p, (float *)pl->out.p, (const int32_t *)pl->row_of_pos.p, (int32_t)nb,
-                           r.nsteps, pl->nseg_pad, t_begin, t_end, src_stride, 1, 1, pl->tag_base);
+                           r.nsteps, pl->nseg_pad, t_begin, t_end, src_stride, 1, 1, pl->tag_base, src_index_dev);
     } else if (pl->precision == 32) {
         float *q = (float *)pl->tm.p;
         hipLaunchKernelGGL((k_fill_boundary_range<float>), dim3(blocks_for(work)), dim3(kBlock), 0, st, (const float *)q_dev,
-                           q, q + plane, q + 2 * plane, (int32_t)nb, pl->nseg_pad, t_begin, t_end, src_stride);
+                           q, q + plane, q + 2 * plane, (int32_t)nb, pl->nseg_pad, t_begin, t_end, src_stride, src_index_dev);
     } else {
         double *q = (double *)pl->tm.p;
         hipLaunchKernelGGL((k_fill_boundary_range<double>), dim3(blocks_for(work)), dim3(kBlock), 0, st, (const double *)q_dev,
-                           q, q + plane, q + 2 * plane, (int32_t)nb, pl->nseg_pad, t_begin, t_end, src_stride);
+                           q, q + plane, q + 2 * plane, (int32_t)nb, pl->nseg_pad, t_begin, t_end, src_stride, src_index_dev);
     }
     HIP_TRY(hipGetLastError());
     r.boundary_through = t_end;

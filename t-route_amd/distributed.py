@@ -243,7 +243,12 @@ class ShardedRouter:
         assume_short_ts: the trunk rides in the launches of this rank's sub-basins, `2 * chunk` steps behind
         them (`_route_skewed`); otherwise sub-basins first, trunk after the exchange (`_route_phased`)."""
         if assume_short_ts:
-            return self._route_skewed(qts_subdivisions, all_gather_into, 24 if nchunks is None else nchunks)
+            # time chunks of the hand-off pipeline: a launch per chunk.  The level engine launches per timestep anyway
+            # and wants the trunk's skew (two chunks) short; the dataflow engine runs a chunk as one persistent launch
+            # and wants few of them (8 chunks of 36 steps: 4.9 ms per 349 k-row rank against 5.7 ms with 24)
+            if nchunks is None:
+                nchunks = 8 if getattr(self.plan0, "engine", "levels") == "flow" else 24
+            return self._route_skewed(qts_subdivisions, all_gather_into, nchunks)
         return self._route_phased(qts_subdivisions, assume_short_ts, all_gather_into, nchunks)
 
     # ---- short-timestep path: one plan, trunk time-skewed -----------------------------------------------
@@ -340,10 +345,10 @@ class ShardedRouter:
                 sc.wait_event(ev)
                 with torch.cuda.stream(sc):
                     all_gather_into(x["recv"][c], x["send"][c])
-                    if self.plan1 is not None:
-                        torch.index_select(x["recv"][c].view(-1, w), 0, self._t_b_index, out=x["bq"][c])
                 if self.plan1 is not None:
-                    P.set_boundary_flow_range(tb, te, x["bq"][c].data_ptr(), w, stream=sc.cuda_stream)
+                    # straight from the all-gathered block into the boundary rows: the fill kernel gathers by index
+                    P.set_boundary_flow_range(tb, te, x["recv"][c].data_ptr(), w, stream=sc.cuda_stream,
+                                              index_ptr=self._t_b_index.data_ptr())
                     filled[c] = torch.cuda.Event()
                     filled[c].record(sc)
             if d_end >= last:
@@ -395,9 +400,8 @@ class ShardedRouter:
                     ev2 = torch.cuda.Event()
                     ev2.record(sc)
                     s1.wait_event(ev2)
-                    with torch.cuda.stream(s1):
-                        torch.index_select(x["recv"][c].view(-1, w), 0, self._t_b_index, out=x["bq"][c])
-                    self.plan1.set_boundary_flow_range(tb, te, x["bq"][c].data_ptr(), w)
+                    self.plan1.set_boundary_flow_range(tb, te, x["recv"][c].data_ptr(), w,
+                                                       index_ptr=self._t_b_index.data_ptr())
             if self.plan1 is not None:
                 if not self._max_cut:
                     self.plan1.set_boundary_flow_range(tb, te, 0, w)

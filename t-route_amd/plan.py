@@ -250,10 +250,12 @@ class RoutingPlan:
         _lib.check(_lib.lib().trmc_gather_flow_range(self._h, rowset, int(t_begin), int(t_end),
                                                      C.c_void_p(device_ptr), int(stride)))
 
-    def set_boundary_flow_range(self, t_begin, t_end, device_ptr, stride, stream=None):
-        _lib.check(_lib.lib().trmc_set_boundary_flow_range(self._h, int(t_begin), int(t_end),
-                                                           C.c_void_p(device_ptr), int(stride),
-                                                           C.c_void_p(stream) if stream else None))
+    def set_boundary_flow_range(self, t_begin, t_end, device_ptr, stride, stream=None, index_ptr=None):
+        """index_ptr: device int64 [nboundary], the source row of every boundary row (None: row b <- source row b)"""
+        _lib.check(_lib.lib().trmc_set_boundary_flow_range_indexed(self._h, int(t_begin), int(t_end),
+                                                                   C.c_void_p(device_ptr), int(stride),
+                                                                   C.c_void_p(index_ptr) if index_ptr else None,
+                                                                   C.c_void_p(stream) if stream else None))
 
     def set_lag(self, lag_of_row):
         """Rows with lag L are routed L launches behind the others (include/trmc.h trmc_plan_set_lag)."""

@@ -62,8 +62,13 @@ def lpt_assign(sizes, nparts, initial_load=None):
     return part, load
 
 
-def partition(to, nparts, max_piece_frac=None):
+def partition(to, nparts, max_piece_frac=None, row_cost=None):
     """Split rows into pieces for `nparts` workers.
+
+    row_cost: optional [nseg] measured cost of every row (e.g. ``ShardedRouter.iteration_hint()`` of a tuning window:
+    the secant iterations a row needs per step, over-bank steps weighted) -- the pieces are then packed by the cost they
+    carry instead of by their row counts, and a trunk weighs what its rows were measured to cost.  Without it (the first
+    window of a network) rows count equally and a trunk is weighted by constants fitted on timings (below).
 
     Returns dict:
       piece     int32 [nseg]  piece id of every row
@@ -112,6 +117,29 @@ def partition(to, nparts, max_piece_frac=None):
     npieces = phase.shape[0]
     sizes = np.bincount(piece, minlength=npieces)
     owner = np.zeros(npieces, dtype=np.int32)
+    if row_cost is not None and nparts > 1:
+        # measured costs: a piece weighs the cost of its rows (in thousandths of the mean row, so that the integer
+        # packing below keeps its resolution).  What a trunk costs its owner is NOT the arithmetic of its rows alone: they
+        # are the deepest, most tightly coupled rows of the network (every step of theirs waits for the step before, with
+        # little else to fill the device), and the time-skewed trunk drains for two time chunks after the rank's other
+        # rows are done.  Timed rank by rank (tools/sim_ranks.py, 8-, 4- and 2-way CONUS partitions, both engines) the
+        # owner needs to be spared about five times the trunk's measured cost plus 2/15 of a rank's share -- with the
+        # trunk weighed at its measured cost only, the owner was the slowest rank by 15-20 % at every N.
+        c = np.maximum(np.asarray(row_cost, dtype=np.float64), 1.0)
+        c = c * (1000.0 / c.mean())
+        weight = np.bincount(piece, weights=c, minlength=npieces).astype(np.int64)
+        bias = np.zeros(nparts, dtype=np.int64)
+        p1 = np.flatnonzero(phase == 1)
+        if p1.size:
+            owner[p1], trunk_load = lpt_assign(weight[p1], nparts)
+            bias = 5 * trunk_load + np.where(trunk_load > 0, int(2 * weight.sum() / (15 * nparts)), 0)
+        p0 = np.flatnonzero(phase == 0)
+        owner[p0], _ = lpt_assign(weight[p0], nparts, bias)
+        return {
+            "piece": piece.astype(np.int32), "phase": phase, "owner": owner,
+            "cut_rows": cut_rows, "cut_into": to[cut_rows] if cut_rows.size else np.zeros(0, np.int64),
+            "piece_sizes": sizes, "owner_bias": bias, "piece_cost": weight,
+        }
     # trunks first; their owners then take fewer sub-basin rows.  What a trunk costs its owner, in rows of sub-basin it
     # should be spared (fitted on ranks of an 8-, 4- and 2-way CONUS partition timed one by one): its own rows,
     # deep in the network and among the costly ones, five times over, plus the launches that drain the time-skewed trunk

@@ -104,3 +104,28 @@ def test_world2_gloo_equals_single_process(tmp_path, short):
     for o in outs:                                                  # every rank ends with the full gather
         assert np.array_equal(o["rows"], rows1)
         assert np.array_equal(o["hyd"].view(np.uint32), hyd1.view(np.uint32))
+
+
+def test_partition_by_measured_cost_balances_cost_not_rows():
+    """sharding.partition(row_cost=...): pieces are packed by the cost their rows were measured to need."""
+    from troute_amd import sharding, synthetic
+    net = synthetic.generate(nseg=60000, nnet=300, seed=5)
+    to = net["to"]
+    rng = np.random.default_rng(0)
+    sub = sharding.subtree_sizes(to)
+    cost = np.where(sub > 20, 40, 16).astype(np.uint8)           # wet downstream rows cost 2.5 x the dry headwaters
+    cost[rng.random(to.shape[0]) < 0.01] = 112
+    for nparts in (2, 4, 8):
+        plain = sharding.partition(to, nparts)
+        byc = sharding.partition(to, nparts, row_cost=cost)
+        assert np.array_equal(plain["cut_rows"], byc["cut_rows"]) and np.array_equal(plain["piece"], byc["piece"])
+        def loads(p):
+            own = p["owner"][p["piece"]]
+            return np.bincount(own, weights=cost.astype(np.float64), minlength=nparts)
+        lp, lc = loads(plain), loads(byc)
+        # workers that own no trunk carry equal COST (a trunk's owner is spared some on purpose, see partition)
+        free = np.setdiff1d(np.arange(nparts), byc["owner"][byc["phase"] == 1])
+        if free.size > 1:
+            assert lc[free].max() / lc[free].min() < 1.05
+            assert lc[free].max() / lc[free].min() <= lp[free].max() / lp[free].min() + 0.02
+        assert (lc[np.setdiff1d(np.arange(nparts), free)] <= lc[free].max() if free.size else True)
