@@ -128,4 +128,5 @@ def test_partition_by_measured_cost_balances_cost_not_rows():
         if free.size > 1:
             assert lc[free].max() / lc[free].min() < 1.05
             assert lc[free].max() / lc[free].min() <= lp[free].max() / lp[free].min() + 0.02
-        assert (lc[np.setdiff1d(np.arange(nparts), free)] <= lc[free].max() if free.size else True)
+        if free.size:
+            assert (lc[np.setdiff1d(np.arange(nparts), free)] <= lc[free].max()).all()
