@@ -360,6 +360,13 @@ def main():
     router.collect_cost(not a.no_retune)               # iteration), which are not, which go over bank
     route_once(router, True)
     hint = None if a.no_retune else router.iteration_hint()
+    if hint is not None and dist is not None:   # every rank measured its own rows: all of them need the whole vector
+        import torch
+        h = torch.from_numpy(hint.astype(np.int32))
+        if backend == "nccl":
+            h = h.cuda()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        hint = h.cpu().numpy().astype(np.uint8)
     router.collect_cost(False)
     t_tune = time.perf_counter() - t0
     router.upload(a.nsteps, qlat_b, None)              # day N+1, warm

@@ -899,6 +899,18 @@ __device__ __forceinline__ bool flow_watchdog(uint32_t &polls, uint64_t &t_start
     }
     return false;
 }
+// what the first row to give up was waiting for, for the host's error message: ticket[2..5] = {granule index in the
+// plane (low, high word), wanted tag, tag found}
+__device__ __forceinline__ void flow_report(const FlowArgs &a, const unsigned long long *g, uint32_t want, unsigned long long v)
+{
+    if (atomicCAS(a.ticket + 6, 0, 1) == 0) {
+        const unsigned long long idx = (unsigned long long)(g - a.gran);
+        a.ticket[2] = (int32_t)(idx & 0xffffffffull);
+        a.ticket[3] = (int32_t)(idx >> 32);
+        a.ticket[4] = (int32_t)want;
+        a.ticket[5] = (int32_t)(v >> 32);
+    }
+}
 __device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t want, const FlowArgs &a, bool &dead)
 {
     unsigned long long v = gran_load(g);
@@ -911,7 +923,10 @@ __device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t
         do {
             __builtin_amdgcn_s_sleep(TRMC_FLOW_SLEEP);
             v = gran_load(g);
-            if (flow_watchdog(polls, t_start, a)) dead = true;
+            if (flow_watchdog(polls, t_start, a)) {
+                dead = true;
+                flow_report(a, g, want, v);
+            }
         } while ((uint32_t)(v >> 32) != want && !dead);
     }
     return __uint_as_float((uint32_t)v);
@@ -1451,7 +1466,11 @@ struct DevBuf {
         if (e != hipSuccess) return fail(TRMC_ENOMEM, std::string("hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
         bytes = need;
         if (zero_new && need) { // (granule planes: recycled memory must not hold a tag that could pass for a live one)
+            // (hipMemset of device memory may return before it has run, on the null stream -- which the plans'
+            // non-blocking streams do not wait for: without the synchronisation the fill can land AFTER the first
+            // kernels of a window have written into the buffer; seen with two processes sharing one GPU)
             e = hipMemset(p, 0, need);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) return fail(TRMC_EHIP, std::string("hipMemset: ") + hipGetErrorString(e));
         }
         return 0;
@@ -1879,10 +1898,10 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     hipStream_t st = pl->stream;
     if (int rc = pl->tm.ensure((size_t)(nsteps + 1) * np * sizeof(unsigned long long), true)) return rc;
     if (int rc = pl->d_state.ensure((size_t)np * sizeof(float))) return rc;
-    if (int rc = pl->ticket.ensure(2 * sizeof(int32_t))) return rc;
+    if (int rc = pl->ticket.ensure(8 * sizeof(int32_t))) return rc;
     if (std::getenv("TRMC_FLOW_DEBUG")) {
         if (int rc = pl->dbg.ensure((size_t)(tp.nblocks + 1) * 2 * sizeof(unsigned long long))) return rc;
-        HIP_TRY(hipMemset(pl->dbg.p, 0, pl->dbg.bytes));
+        HIP_TRY(hipMemsetAsync(pl->dbg.p, 0, pl->dbg.bytes, st));
     }
     if (int rc = pl->qlat_tm.ensure((size_t)pl->nq * np * sizeof(float))) return rc;
     if (int rc = pl->out.ensure((size_t)pl->nseg * nsteps * 3 * sizeof(float))) return rc;
@@ -1903,7 +1922,7 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
     HIP_TRY(hipEventRecord(pl->ev[0], st));
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st));
-    HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, 2 * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, 8 * sizeof(int32_t), st));
     if (pl->collect_cost) HIP_TRY(hipMemsetAsync(pl->it_sum.p, 0, (size_t)np * sizeof(uint16_t), st));
     if (n > 0) {
         if (!pl->qlat_direct)
@@ -1972,12 +1991,17 @@ int flow_route_end(trmc_plan *pl)
     HIP_TRY(hipEventRecord(pl->ev[2], st));
     HIP_TRY(hipEventRecord(pl->ev[3], st));
     HIP_TRY(hipStreamSynchronize(st));
-    int32_t flags[2] = {0, 0};
+    int32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(flags, pl->ticket.p, sizeof flags, hipMemcpyDeviceToHost));
     if (flags[1] != 0) {
         r.active = false;
+        const uint64_t idx = ((uint64_t)(uint32_t)flags[3] << 32) | (uint32_t)flags[2];
+        const uint64_t np = (uint64_t)pl->nseg_pad;
         return fail(TRMC_EHIP, "dataflow engine: a row waited longer than the watchdog allows for an upstream flow "
-                               "(boundary hydrographs missing for the steps routed, or an internal error); window abandoned");
+                               "(boundary hydrographs missing for the steps routed, or an internal error); window abandoned"
+                               " [waited for position " + std::to_string(idx % np) + " (" + (idx % np < (uint64_t)pl->topo.nboundary ? "a boundary row" : "a routed row")
+                               + ") at step " + std::to_string(idx / np) + ", tag " + std::to_string((uint32_t)flags[4]) + ", found tag "
+                               + std::to_string((uint32_t)flags[5]) + ", window tag base " + std::to_string(pl->tag_base) + "]");
     }
     if (std::getenv("TRMC_FLOW_DEBUG") && pl->topo.nblocks > 0) { // developer aid: when did every block run?
         const int32_t nb = pl->topo.nblocks;
@@ -2503,7 +2527,7 @@ int trmc_set_nudging(trmc_plan *pl, int nsteps, int64_t ngage, const int64_t *ga
     HIP_TRY(hipMemcpy(pl->da_mode.p, mode, n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pl->da_a.p, a, n * e, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pl->da_w.p, w, n * e, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(pl->da_nudge.p, 0, n * e));
+    HIP_TRY(hipMemsetAsync(pl->da_nudge.p, 0, n * e, pl->stream)); // (on the plan's stream: ordered before its kernels)
     pl->ngage = ngage;
     pl->da_nsteps = nsteps;
     pl->routed_nsteps = -1;

@@ -249,6 +249,9 @@ class ShardedRouter:
             if nchunks is None:
                 nchunks = 8 if getattr(self.plan0, "engine", "levels") == "flow" else 24
             return self._route_skewed(qts_subdivisions, all_gather_into, nchunks)
+        if not getattr(self, "_plan0_staged", True):
+            raise RuntimeError("this router continued from the state of its merged (short-timestep) plan; upload() the "
+                               "forcing with an explicit q0 before routing in the general mode")
         return self._route_phased(qts_subdivisions, assume_short_ts, all_gather_into, nchunks)
 
     # ---- short-timestep path: one plan, trunk time-skewed -----------------------------------------------
@@ -445,7 +448,13 @@ class ShardedRouter:
         AbstractNetwork.py:177-191, without the host round trip)."""
         self.nsteps = nsteps
         self._qlat, self._q0 = qlat, q0
+        if q0 is None and self.planM is not None:
+            # the windows so far ran on the merged plan (sub-basins + time-skewed trunk, the short-timestep device path):
+            # that is where the resident state lives; _merged_plan() stages the new forcing there
+            self._plan0_staged = False
+            return
         self.plan0.upload_forcing(nsteps, qlat[self.rows0], self._q0_of(self.rows0))
+        self._plan0_staged = True
 
     def route_resident(self, qts_subdivisions, assume_short_ts):
         """Single-rank form that leaves the outlet hydrographs in HBM (throughput mode): returns the
