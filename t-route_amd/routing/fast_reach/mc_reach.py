@@ -273,7 +273,9 @@ def compute_network_structured(
                 boundary_fvd[k] = bvals[r]
 
     nudge = np.zeros((gages_size, nsteps + 1), dtype="float32")
-    with RoutingPlan(up_ptr, up_idx, params, boundary if brow.size else None, precision, device) as plan:
+    # (the timestep mode is known here: the plan picks the engine and the row order that suit it, trmc_plan_create_ex)
+    with RoutingPlan(up_ptr, up_idx, params, boundary if brow.size else None, precision, device,
+                     assume_short_ts=bool(assume_short_ts)) as plan:
         if res_rows:
             plan.set_reservoirs(res_rows, np.asarray(res_par, dtype=dtype), dt)
         plan.upload_forcing(nsteps, qlat_values, q0, boundary_fvd)
