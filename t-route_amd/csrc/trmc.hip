@@ -853,6 +853,8 @@ struct FlowArgs {
     const float *qlat_tm;
     unsigned long long *gran;      // [nsteps + 1][nseg_pad] granules
     float *d_state;                // [nseg_pad] depth at the last step each row has completed
+    unsigned long long *d_gran;    // [nseg_pad] the same as a granule {depth bits, tag of that step}: hand-over between
+                                   // consecutive launches of one window that overlap in time (k_mc_flow_lean)
     float *out;                    // [nseg][nsteps][3]
     const int32_t *row_of_pos;
     uint8_t *it_prev;
@@ -1318,8 +1320,10 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
     const uint32_t out_idx = (uint32_t)a.row_of_pos[su] * (uint32_t)a.nsteps * 3u; // (the host checks nseg * nsteps * 3 < 2**32)
     bool dead = false;
     if (t_lo > t_hi) return;
+    // the state this row was left in -- possibly by a launch that is still running (consecutive time chunks of a window
+    // overlap on two streams): its own flow granule of step t_lo - 1 and the depth granule tagged with the same step
     float q_prev = flow_wait(a.gran + (size_t)(t_lo - 1) * np + su, a.tag_base + (uint32_t)(t_lo - 1), a, dead);
-    float d_prev = a.d_state[su];
+    float d_prev = flow_wait(a.d_gran + su, a.tag_base + (uint32_t)(t_lo - 1), a, dead);
     __hip_atomic_store(s_ring + (size_t)((t_lo - 1) & (kLeanRing - 1)) * kFlowBlock + threadIdx.x,
                        ((unsigned long long)(a.tag_base + (uint32_t)(t_lo - 1)) << 32) | (unsigned long long)__float_as_uint(q_prev),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1404,6 +1408,9 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
         }
         q_prev = q_new;
         d_prev = d_new;
+        if (t == t_hi) // hand the depth over to the next launch of the window
+            __hip_atomic_store(a.d_gran + su, ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(d_new),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifndef TRMC_FLOW_EXP_NOOUT
         {
             float *o = a.out + (size_t)(out_idx + (uint32_t)(t - 1) * 3u);
@@ -1422,13 +1429,14 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
 // initial state of the dataflow engine: granule row 0 <- qu0 (mc_reach.pyx:361), depth column <- h0
 __global__ void __launch_bounds__(kBlock)
 k_flow_init(const float *__restrict__ q0, const int32_t *__restrict__ row_of_pos, unsigned long long *gran, float *d_state,
-            int32_t nseg, uint32_t tag_base)
+            unsigned long long *d_gran, int32_t nseg, uint32_t tag_base)
 {
     const int32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= nseg) return;
     const size_t r = (size_t)row_of_pos[p] * 3;
     gran[p] = ((unsigned long long)tag_base << 32) | (unsigned long long)__float_as_uint(q0[r + 0]);
     d_state[p] = q0[r + 2];
+    d_gran[p] = ((unsigned long long)tag_base << 32) | (unsigned long long)__float_as_uint(q0[r + 2]);
 }
 // boundary rows of the dataflow engine: hydrographs -> granules of the steps (t_begin, t_end] and the rows' result.
 // src[b * stride_b + (t - 1 - t_begin) * stride_t + c]: bfvd[b][t-1][c] (stride_t = 3, ncomp = 3) or a flow block
@@ -1536,6 +1544,12 @@ struct trmc_plan {
     uint32_t tag_base = 1;               // tag of step 0 of the current window (0 is never a live tag)
     int32_t tag_span = 0;                // tags the current window may use (nsteps + 1)
     DevBuf prio;                         // issue priority per wavefront
+    DevBuf d_gran;                       // depth hand-over granules (k_mc_flow_lean)
+    hipStream_t fstream = nullptr;       // second compute stream: consecutive time chunks of a resident window overlap
+    hipEvent_t ev_chunk[2] = {nullptr, nullptr}; // the last launch queued on {stream, fstream}
+    hipEvent_t ev_ctl = nullptr;         // ordering of the two compute streams against each other
+    int flow_next = 0;                   // which of the two the next trmc_route_advance uses (only toggles in overlap mode)
+    int flow_last = 0;                   // ... and which one the last launch went to
     DevBuf d_state, ticket, rank, dbg;   // depth column; {block ticket, abort flag}; level rank of a position inside its block
     uint64_t watchdog_ticks = 300000000; // 3 s of wall_clock64 (100 MHz)
     trmc_stats stats{};
@@ -1861,6 +1875,7 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     a.qlat_tm = (const float *)pl->qlat_tm.p;
     a.gran = (unsigned long long *)pl->tm.p;
     a.d_state = (float *)pl->d_state.p;
+    a.d_gran = (unsigned long long *)pl->d_gran.p;
     a.out = (float *)pl->out.p;
     a.row_of_pos = (const int32_t *)pl->row_of_pos.p;
     a.it_prev = (uint8_t *)pl->it_prev.p;
@@ -1898,7 +1913,8 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     hipStream_t st = pl->stream;
     if (int rc = pl->tm.ensure((size_t)(nsteps + 1) * np * sizeof(unsigned long long), true)) return rc;
     if (int rc = pl->d_state.ensure((size_t)np * sizeof(float))) return rc;
-    if (int rc = pl->ticket.ensure(8 * sizeof(int32_t))) return rc;
+    if (int rc = pl->d_gran.ensure((size_t)np * sizeof(unsigned long long), true)) return rc;
+    if (int rc = pl->ticket.ensure(16 * sizeof(int32_t))) return rc; // one set of 8 per compute stream
     if (std::getenv("TRMC_FLOW_DEBUG")) {
         if (int rc = pl->dbg.ensure((size_t)(tp.nblocks + 1) * 2 * sizeof(unsigned long long))) return rc;
         HIP_TRY(hipMemsetAsync(pl->dbg.p, 0, pl->dbg.bytes, st));
@@ -1914,6 +1930,7 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     // a fresh range of tags for this window: nothing an earlier window left in the plane can pass for a live granule
     if ((uint64_t)pl->tag_base + (uint64_t)pl->tag_span + (uint64_t)nsteps + 2 >= 0xffffffffull) {
         HIP_TRY(hipMemsetAsync(pl->tm.p, 0, pl->tm.bytes, st));
+        HIP_TRY(hipMemsetAsync(pl->d_gran.p, 0, pl->d_gran.bytes, st));
         pl->tag_base = 1;
         pl->tag_span = 0;
     }
@@ -1922,14 +1939,16 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
     HIP_TRY(hipEventRecord(pl->ev[0], st));
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st));
-    HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, 8 * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, 16 * sizeof(int32_t), st));
+    pl->flow_next = pl->flow_last = 0;
     if (pl->collect_cost) HIP_TRY(hipMemsetAsync(pl->it_sum.p, 0, (size_t)np * sizeof(uint16_t), st));
     if (n > 0) {
         if (!pl->qlat_direct)
             hipLaunchKernelGGL((k_prep_qlat<float>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
                                (const float *)pl->in_qlat.p, row_of_pos, (float *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);
         hipLaunchKernelGGL(k_flow_init, dim3(blocks_for(n)), dim3(kBlock), 0, st, (const float *)pl->in_q0.p, row_of_pos,
-                           (unsigned long long *)pl->tm.p, (float *)pl->d_state.p, n, pl->tag_base);
+                           (unsigned long long *)pl->tm.p, (float *)pl->d_state.p, (unsigned long long *)pl->d_gran.p, n,
+                           pl->tag_base);
     }
     RouteRun &r = pl->run;
     r = RouteRun{};
@@ -1945,38 +1964,59 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
         r.boundary_through = nsteps;
     }
     HIP_TRY(hipEventRecord(pl->ev[1], st));
+    HIP_TRY(hipStreamWaitEvent(pl->fstream, pl->ev[1], 0)); // the second compute stream starts behind the window's set-up
     HIP_TRY(hipGetLastError());
     pl->routed_nsteps = -1;
     return 0;
 }
 
+// Which form of the short-timestep kernel a window uses, and whether consecutive launches of it may overlap.
+// The lean form pays where every block of the launch is resident at once (6 workgroups per compute unit: one rank of a
+// multi-GPU job, a regional network) -- there the pace is set by latency and by the slowest wavefront, and occupancy plus
+// wavefront priorities win (349 k rows, 288 steps: 4.8 ms against 6.1 ms).  Where blocks run in many rounds (CONUS on one
+// GPU: 10 661 blocks) throughput counts and the staged form, which spills nothing and writes whole sectors, is ahead
+// (25.4 ms against 30.5 ms).
+static bool flow_lean(const trmc_plan *pl, int nsteps)
+{
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+    const char *force = std::getenv("TRMC_FLOW_LEAN"); // "0" / "1": A/B measurements
+    return (uint64_t)pl->nseg * (uint64_t)nsteps * 3ull < (1ull << 32)
+           && (force ? force[0] == '1' : pl->topo.nblocks <= TRMC_LEAN_WAVES * ncu);
+}
+// Consecutive launches of a short-timestep window on the lean kernel alternate between two compute streams: rows hand their
+// state from launch to launch through granules (flow plane, d_gran), so launch c+1 needs no kernel boundary behind launch
+// c -- its cheap blocks take the slots launch c's cheap blocks have left while c's costly blocks are still finishing.  Safe
+// because every block of a launch is resident (flow_lean): launch c+2, behind c on its stream, starts when all of c+1 is.
+static bool flow_overlap(const trmc_plan *pl)
+{
+    return pl->run.short_ts && flow_lean(pl, pl->run.nsteps) && !std::getenv("TRMC_FLOW_NOOVERLAP");
+}
+static hipStream_t flow_stream(const trmc_plan *pl, int which) { return which ? pl->fstream : pl->stream; }
+
 // one launch routes every row through the launches / steps (t_done, t_end]
 int flow_route_advance(trmc_plan *pl, int t_end)
 {
     RouteRun &r = pl->run;
-    hipStream_t st = pl->stream;
     if (pl->nrouted > 0 && t_end > r.t_done) {
-        const FlowArgs a = flow_args(pl, r.nsteps, r.qts, r.short_ts != 0);
-        HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, sizeof(int32_t), st)); // block tickets restart; the abort flag stays
+        const bool lean = r.short_ts && flow_lean(pl, r.nsteps);
+        const int which = flow_overlap(pl) ? pl->flow_next : 0;
+        hipStream_t st = flow_stream(pl, which);
+        FlowArgs a = flow_args(pl, r.nsteps, r.qts, r.short_ts != 0);
+        a.ticket += 8 * which;                                       // every compute stream has its own block tickets
+        HIP_TRY(hipMemsetAsync(a.ticket, 0, sizeof(int32_t), st));   // they restart; the abort flag stays
         const dim3 grid((unsigned)pl->topo.nblocks), block(kFlowBlock);
-        // The lean form pays where every block of the launch is resident at once (6 workgroups per compute unit: one rank
-        // of a multi-GPU job, a regional network) -- there the pace is set by latency and by the slowest wavefront, and
-        // occupancy plus wavefront priorities win (349 k rows, 288 steps: 4.8 ms against 6.1 ms).  Where blocks run in many
-        // rounds (CONUS on one GPU: 10 661 blocks) throughput counts and the staged form, which spills nothing and writes
-        // whole sectors, is ahead (25.4 ms against 30.5 ms).
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
-        const char *force = std::getenv("TRMC_FLOW_LEAN"); // "0" / "1": A/B measurements
-        const bool lean = (uint64_t)pl->nseg * (uint64_t)r.nsteps * 3ull < (1ull << 32)
-                          && (force ? force[0] == '1' : pl->topo.nblocks <= TRMC_LEAN_WAVES * ncu);
-        if (r.short_ts && lean && a.lag)
+        if (lean && a.lag)
             hipLaunchKernelGGL((k_mc_flow_lean<true>), grid, block, 0, st, a, r.t_done, t_end);
-        else if (r.short_ts && lean)
+        else if (lean)
             hipLaunchKernelGGL((k_mc_flow_lean<false>), grid, block, 0, st, a, r.t_done, t_end);
         else if (r.short_ts)
             hipLaunchKernelGGL((k_mc_flow<true>), grid, block, 0, st, a, r.t_done, t_end);
         else
             hipLaunchKernelGGL((k_mc_flow<false>), grid, block, 0, st, a, r.t_done, t_end);
+        HIP_TRY(hipEventRecord(pl->ev_chunk[which], st));
+        pl->flow_last = which;
+        if (flow_overlap(pl)) pl->flow_next = 1 - which;
         ++r.launches;
     }
     HIP_TRY(hipGetLastError());
@@ -1988,11 +2028,17 @@ int flow_route_end(trmc_plan *pl)
 {
     RouteRun &r = pl->run;
     hipStream_t st = pl->stream;
+    if (r.launches > 0) { // whatever the second compute stream still runs belongs to the window
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_chunk[0], 0));
+        if (flow_overlap(pl) && r.launches > 1) HIP_TRY(hipStreamWaitEvent(st, pl->ev_chunk[1], 0));
+    }
     HIP_TRY(hipEventRecord(pl->ev[2], st));
     HIP_TRY(hipEventRecord(pl->ev[3], st));
     HIP_TRY(hipStreamSynchronize(st));
-    int32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(flags, pl->ticket.p, sizeof flags, hipMemcpyDeviceToHost));
+    pl->flow_next = pl->flow_last = 0;
+    int32_t both[16] = {0};
+    HIP_TRY(hipMemcpy(both, pl->ticket.p, sizeof both, hipMemcpyDeviceToHost));
+    const int32_t *flags = both[1] != 0 ? both : both + 8;
     if (flags[1] != 0) {
         r.active = false;
         const uint64_t idx = ((uint64_t)(uint32_t)flags[3] << 32) | (uint32_t)flags[2];
@@ -2233,6 +2279,11 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&pl->stream, hipStreamNonBlocking, prio_hi);
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&pl->stream2, hipStreamNonBlocking, prio_lo);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_emit, hipEventDisableTiming);
+        if (e == hipSuccess && pl->flow) {
+            e = hipStreamCreateWithPriority(&pl->fstream, hipStreamNonBlocking, prio_hi);
+            for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&pl->ev_chunk[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_ctl, hipEventDisableTiming);
+        }
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
         if (e != hipSuccess) return bail(fail(TRMC_EHIP, std::string("stream/event setup: ") + hipGetErrorString(e)));
     }
@@ -2275,7 +2326,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->d_gran, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
@@ -2285,6 +2336,10 @@ void trmc_plan_destroy(trmc_plan *pl)
         if (e) (void)hipEventDestroy(e);
     if (pl->ev_emit) (void)hipEventDestroy(pl->ev_emit);
     if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
+    if (pl->fstream) (void)hipStreamDestroy(pl->fstream);
+    for (auto &e : pl->ev_chunk)
+        if (e) (void)hipEventDestroy(e);
+    if (pl->ev_ctl) (void)hipEventDestroy(pl->ev_ctl);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
     delete pl;
 }
@@ -2629,6 +2684,7 @@ int trmc_route_end(trmc_plan *pl)
         // abandon the window: drain the queue so the plan can be reused
         (void)hipStreamSynchronize(pl->stream);
         (void)hipStreamSynchronize(pl->stream2);
+        if (pl->fstream) (void)hipStreamSynchronize(pl->fstream);
         pl->run.active = false;
         return fail(TRMC_ESTATE, "trmc_route_end before every timestep was queued; window abandoned");
     }
@@ -2641,7 +2697,9 @@ int trmc_route_end(trmc_plan *pl)
 int trmc_plan_stream(trmc_plan *pl, void **stream_out)
 {
     if (!pl || !stream_out) return fail(TRMC_EINVAL, "plan/stream_out is NULL");
-    *stream_out = (void *)pl->stream;
+    // inside a window of the dataflow engine whose launches alternate between two compute streams: the stream the NEXT
+    // trmc_route_advance uses (afterwards: the one it used, on which trmc_gather_flow_range is queued as well)
+    *stream_out = (void *)((pl->flow && pl->run.active && flow_overlap(pl)) ? flow_stream(pl, pl->flow_next) : pl->stream);
     return 0;
 }
 
@@ -2717,8 +2775,14 @@ int trmc_gather_flow_range(trmc_plan *pl, int32_t rowset, int t_begin, int t_end
     if (!dst_dev || dst_stride < t_end - t_begin) return fail(TRMC_EINVAL, "dst_dev is NULL or dst_stride too small");
     if (int rc = use_device(pl)) return rc;
     const int64_t work = nrows * (t_end - t_begin);
+    hipStream_t gst = pl->stream;
+    if (pl->flow && pl->run.active && flow_overlap(pl) && pl->run.launches > 0) {
+        // on the stream of the last launch, and behind the last launch of the other one (which holds the steps before)
+        gst = flow_stream(pl, pl->flow_last);
+        if (pl->run.launches > 1) HIP_TRY(hipStreamWaitEvent(gst, pl->ev_chunk[1 - pl->flow_last], 0));
+    }
     if (pl->precision == 32)
-        hipLaunchKernelGGL((k_gather_range<float>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const float *)pl->tm.p,
+        hipLaunchKernelGGL((k_gather_range<float>), dim3(blocks_for(work)), dim3(kBlock), 0, gst, (const float *)pl->tm.p,
                            (const int32_t *)pl->rowsets[rowset].p, (float *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride,
                            pl->flow ? 2 : 1);
     else
@@ -2753,6 +2817,15 @@ int trmc_set_boundary_flow_range_indexed(trmc_plan *pl, int t_begin, int t_end, 
     const size_t plane = (size_t)(r.nsteps + 1) * pl->nseg_pad;
     const int64_t work = nb * (t_end - t_begin);
     hipStream_t st = stream ? (hipStream_t)stream : pl->stream;
+    if (!stream && pl->flow && flow_overlap(pl)) {
+        // no stream given: before the next launch, and behind whatever was queued after the last one (a gather that
+        // produced q_dev, typically)
+        st = flow_stream(pl, pl->flow_next);
+        if (r.launches > 0 && pl->flow_next != pl->flow_last) {
+            HIP_TRY(hipEventRecord(pl->ev_ctl, flow_stream(pl, pl->flow_last)));
+            HIP_TRY(hipStreamWaitEvent(st, pl->ev_ctl, 0));
+        }
+    }
     if (pl->flow) {
         hipLaunchKernelGGL(k_flow_boundary, dim3(blocks_for(work)), dim3(kBlock), 0, st, (const float *)q_dev,
                            (unsigned long long *)pl->tm.p, (float *)pl->out.p, (const int32_t *)pl->row_of_pos.p, (int32_t)nb,

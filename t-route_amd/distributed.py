@@ -334,8 +334,15 @@ class ShardedRouter:
         filled = [None] * C
         last = nsteps + lag
         c = 0
+        ext = {}
         while True:
             d_end = min((c + 1) * K, last)
+            # the stream this chunk's launch goes to (the dataflow engine alternates between two, so that consecutive
+            # chunks overlap: trmc_plan_stream); the gather below is queued behind it
+            h = P.stream()
+            if h not in ext:
+                ext[h] = torch.cuda.ExternalStream(h, device=self._tdev)
+            sP = ext[h]
             if lag and c >= 2 and filled[min(c - 2, C - 1)] is not None:
                 sP.wait_event(filled[min(c - 2, C - 1)])   # boundary values of chunk c-2: queued a chunk ago
             P.route_advance(d_end)

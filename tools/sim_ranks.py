@@ -83,7 +83,8 @@ def main():
                 idx[m] = np.arange(int(m.sum()))
             peers[torch.from_numpy(r.cut_owner.astype(np.int64)).to(dev), torch.from_numpy(idx).to(dev)] = \
                 torch.from_numpy(cut_q).to(dev)
-        nchunks_eff = (a.chunks if a.chunks else 24) if short else (a.chunks if a.chunks else 1)
+        default_chunks = 8 if getattr(r.plan0, "engine", "levels") == "flow" else 24     # route_on_device's defaults
+        nchunks_eff = (a.chunks if a.chunks else default_chunks) if short else (a.chunks if a.chunks else 1)
         state = {"t": 0, "call": 0}
 
         def all_gather_into(out, t):
