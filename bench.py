@@ -34,12 +34,11 @@ import os
 import sys
 import time
 
-# Before any HIP runtime is loaded: at most two hardware queues for ordinary-priority streams (the exchange stream,
-# RCCL's).  With the ROCm 7.2 default of four, a stream of another hardware queue waiting on events of the plan's
-# stream intermittently put that stream's launches in a slow mode (17 ms instead of 6.4 ms per 340 k-row rank,
-# depending on which queue the waiting stream happened to get: tools/sim_ranks.py); one or two
-# queues never did, and the single-GPU path (priority streams only) is unaffected either way.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# Before any HIP runtime is loaded: one hardware queue per stream priority (the same setting troute_amd.distributed makes
+# at import, where the why is written down: with several queues per priority, some assignments of the streams to them put
+# the plan stream's launches in a slow mode whenever another stream waits on its events -- DESIGN.md section 7b).  The
+# single-GPU path (one plan, priority streams only) is unaffected either way.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 # the CPU baseline's OpenMP threads: one per physical core, spread over the sockets (read when libgomp initialises)
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")

@@ -262,10 +262,11 @@ int trmc_route_device(trmc_plan *plan, int nsteps, int qts_subdivisions, int ass
 int trmc_route_begin(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_short_ts);
 int trmc_route_advance(trmc_plan *plan, int t_end);
 int trmc_route_end(trmc_plan *plan);
-/* The plan's HIP stream (hipStream_t as void*), for ordering foreign work (RCCL) against the plan's.  Inside a window of
- * the dataflow engine whose launches are all resident (one rank of a multi-GPU job), consecutive trmc_route_advance calls
- * alternate between two compute streams so that time chunks overlap: the call then returns the stream the NEXT advance
- * uses -- ask again before every advance; trmc_gather_flow_range is queued behind the launches that hold its steps. */
+/* The plan's HIP stream (hipStream_t as void*), for ordering foreign work (RCCL) against the plan's.  With
+ * TRMC_FLOW_OVERLAP=1 in the environment (off by default: no gain measured), a window of the dataflow engine whose
+ * launches are all resident alternates consecutive trmc_route_advance calls between two compute streams so that time
+ * chunks overlap: the call then returns the stream the NEXT advance uses -- ask again before every advance;
+ * trmc_gather_flow_range is queued behind the launches that hold its steps. */
 int trmc_plan_stream(trmc_plan *plan, void **stream_out);
 /* Register a set of rows once (their plan positions are kept in HBM); *id_out names it. */
 int trmc_rowset_create(trmc_plan *plan, const int64_t *rows, int64_t nrows, int32_t *id_out);

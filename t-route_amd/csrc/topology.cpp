@@ -2,6 +2,9 @@
 #include "topology.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <string>
+#include <cstdlib>
 #include <limits>
 #include <utility>
 
@@ -241,11 +244,34 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             const int64_t span = std::max<int64_t>(1, hi - lo + 1);
             const int64_t nw = (nrouted + 63) / 64;
             t.prio_of_wave.assign((size_t)nw, 0);
-            for (int64_t w = 0; w < nw; ++w) {
-                int64_t mx = lo;
+            std::vector<int64_t> wcost((size_t)nw, lo);
+            for (int64_t w = 0; w < nw; ++w)
                 for (int64_t p = t.nboundary + w * 64; p < std::min<int64_t>(nseg, t.nboundary + (w + 1) * 64); ++p)
-                    mx = std::max(mx, cost_of(t.row_of_pos[p]));
-                t.prio_of_wave[(size_t)w] = (uint8_t)std::min<int64_t>(3, (mx - lo) * 4 / span);
+                    wcost[(size_t)w] = std::max(wcost[(size_t)w], cost_of(t.row_of_pos[p]));
+            const char *pm = std::getenv("TRMC_FLOW_PRIO_MODE"); // developer A/B: "linear", "block"; default by wavefront
+            const std::string mode = pm ? pm : "wave";
+            if (mode == "linear") {
+                for (int64_t w = 0; w < nw; ++w) t.prio_of_wave[(size_t)w] = (uint8_t)std::min<int64_t>(3, (wcost[(size_t)w] - lo) * 4 / span);
+            } else if (nw > 0) {
+                // By rank, not by value: a handful of rows with a hint far above the rest would compress everybody else into
+                // priorities 0 and 1.  Equal costs get equal priorities.  (One priority per block -- its wavefronts exchange
+                // flows every step -- measured worse on the ranks of an 8-way partition: 5.3 ms against 4.65 ms.)
+                const int64_t wpb = std::max<int64_t>(1, block_rows / 64);
+                if (mode != "wave")
+                    for (int64_t w0 = 0; w0 < nw; w0 += wpb) {
+                        int64_t mx = lo;
+                        for (int64_t w = w0; w < std::min(nw, w0 + wpb); ++w) mx = std::max(mx, wcost[(size_t)w]);
+                        for (int64_t w = w0; w < std::min(nw, w0 + wpb); ++w) wcost[(size_t)w] = mx;
+                    }
+                std::vector<int64_t> sorted(wcost);
+                std::sort(sorted.begin(), sorted.end());
+                const int pc[3] = {60, 84, 94};
+                const int64_t q1 = sorted[(size_t)((nw - 1) * pc[0] / 100)], q2 = sorted[(size_t)((nw - 1) * pc[1] / 100)],
+                              q3 = sorted[(size_t)((nw - 1) * pc[2] / 100)];
+                for (int64_t w = 0; w < nw; ++w) {
+                    const int64_t c = wcost[(size_t)w];
+                    t.prio_of_wave[(size_t)w] = (uint8_t)((c > q1) + (c > q2) + (c > q3));
+                }
             }
         }
         // Rank of a position inside its block: 0 for a row none of whose upstream rows shares its block, else one more

@@ -875,6 +875,7 @@ struct FlowArgs {
     uint64_t watchdog_ticks;       // wall_clock64 ticks (100 MHz) a row may wait for one granule
     const uint8_t *prio;           // issue priority 0..3 of every wavefront of the block order (topology.cpp)
     unsigned long long *dbg;       // nullptr, or [nblocks][2]: wall clock at the start and the end of every block (TRMC_FLOW_DEBUG)
+    int32_t nblocks_dbg;
 };
 
 __device__ __forceinline__ unsigned long long gran_load(const unsigned long long *g)
@@ -913,6 +914,12 @@ __device__ __forceinline__ void flow_report(const FlowArgs &a, const unsigned lo
         a.ticket[5] = (int32_t)(v >> 32);
     }
 }
+#ifdef TRMC_FLOW_DEBUG_WAITS // developer build: polls of the granule plane / of the LDS ring, per thread
+__device__ uint32_t g_dbg_polls_plane, g_dbg_polls_ring;
+#define TRMC_DBG_COUNT(var) (++(var))
+static __device__ __forceinline__ uint32_t &dbg_plane() { __shared__ uint32_t c[1024]; return c[threadIdx.x]; }
+static __device__ __forceinline__ uint32_t &dbg_ring() { __shared__ uint32_t c[1024]; return c[threadIdx.x]; }
+#endif
 __device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t want, const FlowArgs &a, bool &dead)
 {
     unsigned long long v = gran_load(g);
@@ -925,6 +932,9 @@ __device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t
         do {
             __builtin_amdgcn_s_sleep(TRMC_FLOW_SLEEP);
             v = gran_load(g);
+#ifdef TRMC_FLOW_DEBUG_WAITS
+            ++dbg_plane();
+#endif
             if (flow_watchdog(polls, t_start, a)) {
                 dead = true;
                 flow_report(a, g, want, v);
@@ -1238,12 +1248,18 @@ __device__ __forceinline__ float lean_edge_get(int32_t u, int32_t l, uint32_t &f
     if (!(flags & (ahead_bit | never_bit))) {
         const unsigned long long *slot = ring + (size_t)(ws & (kLeanRing - 1)) * kFlowBlock + l;
         unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef TRMC_FLOW_EXP_NOWAIT
+        return __uint_as_float((uint32_t)v);
+#endif
         if ((int32_t)((uint32_t)(v >> 32) - want) < 0) { // not produced yet: the producer is a wave of this block
             uint32_t polls = 0;
             uint64_t t_start = 0;
             do {
                 __builtin_amdgcn_s_sleep(2);
                 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef TRMC_FLOW_DEBUG_WAITS
+                ++dbg_ring();
+#endif
                 if (flow_watchdog(polls, t_start, a)) dead = true;
             } while ((int32_t)((uint32_t)(v >> 32) - want) < 0 && !dead);
         }
@@ -1269,6 +1285,10 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
     m.sane = a.sane;
     const int32_t blk_base = a.first + s_blk * kFlowBlock;
     if (a.dbg && threadIdx.x == 0) a.dbg[2 * s_blk] = wall_clock64();
+#ifdef TRMC_FLOW_DEBUG_WAITS
+    dbg_plane() = 0;
+    dbg_ring() = 0;
+#endif
     if (a.prio) { // the costlier a wavefront, the higher its issue priority (topology.cpp)
         const int pr = __builtin_amdgcn_readfirstlane((int)a.prio[(s_blk * kFlowBlock + (int32_t)threadIdx.x) >> 6]);
         if (pr == 1) __builtin_amdgcn_s_setprio(1);
@@ -1421,6 +1441,15 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
 #endif
     }
     if (a.dbg) atomicMax(a.dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
+#ifdef TRMC_FLOW_DEBUG_WAITS
+    if (a.dbg) { // [2 * (nblocks + 1) ...]: per block {max plane polls of a thread, max ring polls, iteration sum of the block}
+        unsigned long long *x = a.dbg + 2 * (size_t)(a.nblocks_dbg + 1) + 4 * (size_t)s_blk;
+        atomicMax(x + 0, (unsigned long long)dbg_plane());
+        atomicMax(x + 1, (unsigned long long)dbg_ring());
+        atomicAdd(x + 2, (unsigned long long)(its & 0x00ffffffu));
+        atomicMax(x + 3, (unsigned long long)(its & 0x00ffffffu));
+    }
+#endif
     a.d_state[su] = d_prev;
     if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)(its >> 24);
     if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535u, (uint32_t)a.it_sum[su] + (its & 0x00ffffffu));
@@ -1901,6 +1930,7 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     a.ticket = (int32_t *)pl->ticket.p;
     a.watchdog_ticks = pl->watchdog_ticks;
     a.dbg = std::getenv("TRMC_FLOW_DEBUG") ? (unsigned long long *)pl->dbg.p : nullptr;
+    a.nblocks_dbg = pl->topo.nblocks;
     a.prio = std::getenv("TRMC_FLOW_NOPRIO") ? nullptr : (const uint8_t *)pl->prio.p;
     return a;
 }
@@ -1916,7 +1946,7 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     if (int rc = pl->d_gran.ensure((size_t)np * sizeof(unsigned long long), true)) return rc;
     if (int rc = pl->ticket.ensure(16 * sizeof(int32_t))) return rc; // one set of 8 per compute stream
     if (std::getenv("TRMC_FLOW_DEBUG")) {
-        if (int rc = pl->dbg.ensure((size_t)(tp.nblocks + 1) * 2 * sizeof(unsigned long long))) return rc;
+        if (int rc = pl->dbg.ensure((size_t)(tp.nblocks + 1) * 6 * sizeof(unsigned long long))) return rc;
         HIP_TRY(hipMemsetAsync(pl->dbg.p, 0, pl->dbg.bytes, st));
     }
     if (int rc = pl->qlat_tm.ensure((size_t)pl->nq * np * sizeof(float))) return rc;
@@ -1982,15 +2012,19 @@ static bool flow_lean(const trmc_plan *pl, int nsteps)
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
     const char *force = std::getenv("TRMC_FLOW_LEAN"); // "0" / "1": A/B measurements
     return (uint64_t)pl->nseg * (uint64_t)nsteps * 3ull < (1ull << 32)
-           && (force ? force[0] == '1' : pl->topo.nblocks <= TRMC_LEAN_WAVES * ncu);
+           && (force ? force[0] == '1' : pl->topo.nblocks <= TRMC_LEAN_WAVES * (256 / kFlowBlock) * ncu);
 }
-// Consecutive launches of a short-timestep window on the lean kernel alternate between two compute streams: rows hand their
-// state from launch to launch through granules (flow plane, d_gran), so launch c+1 needs no kernel boundary behind launch
-// c -- its cheap blocks take the slots launch c's cheap blocks have left while c's costly blocks are still finishing.  Safe
-// because every block of a launch is resident (flow_lean): launch c+2, behind c on its stream, starts when all of c+1 is.
+// Optional (TRMC_FLOW_OVERLAP=1; off by default): consecutive launches of a short-timestep window on the lean kernel
+// alternate between two compute streams.  Rows hand their state from launch to launch through granules (flow plane,
+// d_gran), so launch c+1 needs no kernel boundary behind launch c -- its cheap blocks take the slots launch c's cheap blocks
+// have left while c's costly blocks are still finishing.  Safe because every block of a launch is resident (flow_lean):
+// launch c+2, behind c on its stream, starts when all of c+1 is.  Measured on 349 k-row ranks (8 chunks per window): no
+// gain -- 4.9 ms either way once both streams have a hardware queue each, and the two streams share one under
+// GPU_MAX_HW_QUEUES=1, which troute_amd.distributed sets -- hence opt-in.
 static bool flow_overlap(const trmc_plan *pl)
 {
-    return pl->run.short_ts && flow_lean(pl, pl->run.nsteps) && !std::getenv("TRMC_FLOW_NOOVERLAP");
+    const char *on = std::getenv("TRMC_FLOW_OVERLAP");
+    return on && on[0] == '1' && pl->run.short_ts && flow_lean(pl, pl->run.nsteps);
 }
 static hipStream_t flow_stream(const trmc_plan *pl, int which) { return which ? pl->fstream : pl->stream; }
 
@@ -2068,6 +2102,31 @@ int flow_route_end(trmc_plan *pl)
             std::fprintf(stderr, "   %6d  %9.3f %9.3f %9.3f\n", b, (d[2 * b] - t_min) * 1e-5, (d[2 * b + 1] - t_min) * 1e-5,
                          (d[2 * b + 1] - d[2 * b]) * 1e-5);
         }
+#ifdef TRMC_FLOW_DEBUG_WAITS
+        {
+            std::vector<unsigned long long> w((size_t)nb * 4);
+            HIP_TRY(hipMemcpy(w.data(), (unsigned long long *)pl->dbg.p + 2 * (size_t)(nb + 1), w.size() * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "   by twentieth of the block order: mean end ms, mean max-plane-polls, mean max-ring-polls, mean its/row, max its, mean prio\n");
+            std::vector<int8_t> prio((size_t)nb * (kFlowBlock / 64), 0);
+            for (size_t q = 0; q < prio.size() && q < pl->topo.prio_of_wave.size(); ++q) prio[q] = (int8_t)pl->topo.prio_of_wave[q];
+            for (int k = 0; k < 20; ++k) {
+                const int32_t b0 = (int32_t)((int64_t)nb * k / 20), b1 = (int32_t)((int64_t)nb * (k + 1) / 20);
+                double e = 0, p0 = 0, p1 = 0, it = 0, mx = 0, pr = 0;
+                for (int32_t b = b0; b < b1; ++b) {
+                    e += (d[2 * b + 1] - t_min) * 1e-5;
+                    p0 += (double)w[4 * b];
+                    p1 += (double)w[4 * b + 1];
+                    it += (double)w[4 * b + 2] / kFlowBlock;
+                    mx += (double)w[4 * b + 3];
+                    for (int q = 0; q < kFlowBlock / 64; ++q) pr += prio[(size_t)b * (kFlowBlock / 64) + q] / (double)(kFlowBlock / 64);
+                }
+                const double n = b1 - b0 > 0 ? b1 - b0 : 1;
+                std::fprintf(stderr, "   %2d  end %7.3f  plane %8.0f  ring %8.0f  its %7.1f  max %7.1f  prio %4.2f\n", k, e / n, p0 / n, p1 / n, it / n,
+                             mx / n, pr / n);
+            }
+        }
+#endif
         // how many blocks are running at a few instants
         for (int k = 1; k <= 10; ++k) {
             const unsigned long long tt = t_min + (t_max - t_min) * k / 11;

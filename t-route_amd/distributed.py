@@ -15,13 +15,17 @@ gather logic is exercised with world_size 2 on gloo without a GPU.
 """
 import os as _os
 
-# Before any HIP runtime is loaded by this process: at most two hardware queues for ordinary-priority streams (the
-# exchange stream, RCCL's).  With the ROCm 7.2 default of four, a stream of another hardware queue waiting on events of a
-# plan's stream intermittently put that stream's launches in a slow mode (17 ms instead of 6.4 ms per 340 k-row rank,
-# depending on which queue the waiting stream happened to get); one or two queues never did.  The
-# variable is read when the runtime initialises, so it is set at import -- a caller that has already initialised HIP
+# Before any HIP runtime is loaded by this process: ONE hardware queue per stream priority.  A plan's compute stream
+# (high priority), its transpose stream (low) and the exchange stream (ordinary: torch's, RCCL's) then sit on three
+# hardware queues whatever else the process has created.  With more queues per priority the runtime spreads streams over
+# them in creation order, and for some assignments a stream waiting on events of the plan's stream puts that stream's
+# launches in a slow mode -- 67 us instead of 25 us per step launch of a 600 k-row rank, for the whole window.  Which
+# assignments depends on the number of streams created before: round 1 saw it with 3 and 4 queues and never with 2; with
+# one more stream per plan (round 2) it is 2 queues that trigger it (N = 2 and N = 4 owners of the trunk: 21 ms instead
+# of 12.4 / 8.2 ms) and 3 and 4 that do not.  One queue per priority has no assignment to get wrong.
+# The variable is read when the runtime initialises, so it is set at import -- a caller that has already initialised HIP
 # should export it itself.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 
 import numpy as np
 
