@@ -11,6 +11,7 @@
 //                       the 501-row tables -- with ballots and lane shuffles (WaveScan).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -265,12 +266,408 @@ __global__ void __launch_bounds__(64) k_dw_solve(const BatchItem *items)
     trdw::solve<WaveScan>(p, *items[blockIdx.x].min_dx, scan);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The time loop in parallel form (k_dw_solve_par): one workgroup of kParThreads threads per tailwater domain.
+//
+// Of a sub-step of diffnw only one thing is a recurrence from node to node: the depth solve of the corrector sweep, where
+// node i needs the new depth of node i+1 (and, across a junction, the top node of the reach below).  Everything else
+// depends on the old time level or on the node's own new state:
+//   * predictor: the Crank-Nicolson coefficients of a node (forward_coef) -- one thread per node; the Thomas recurrences
+//     and the back-substitution run along a REACH and never cross a junction (the upstream boundary of a reach enters its
+//     first node only, forward()) -- one thread per reach; junction inflows -- one thread per reach;
+//   * corrector, before the chain: the bracket of the depth solve and the table look-ups of its first three function
+//     evaluations (depth_pre) -- one thread per node;
+//   * the chain itself: one wavefront, from the domain's outlet upstream, everything it reads in LDS -- per node a record of
+//     12 doubles from depth_pre and a window of kWinRows rows of the four table columns the iteration reads, centred on the
+//     row the node's water surface was found in a sub-step ago (a water surface moves by a fraction of a table row per
+//     sub-step); an abscissa outside the window takes the search over the whole column in global memory instead;
+//   * corrector, after the chain: area, top width, roughness, celerity and diffusivity of a node (backward_node_post) and
+//     the refresh of its window -- one thread per node; reach means -- one thread per reach.
+// The arithmetic of every piece is the function the serial solver calls (diffusive_core.hpp), so the bits are the same.
+constexpr int kParThreads = 512;
+constexpr int kWinRows = 6;
+constexpr int kRecDoubles = 12;
+
+// one thread, its own searches (bisection on an ascending column), tables in global memory
+struct LaneScan {
+    __device__ static double *state(double *g) { return g; }
+    __device__ const double *table(const trdw::Problem &p, int i, int j) const { return trdw::node_block(p, i, j); }
+    __device__ int locate_row(const double *xx, int n, double x) const { return trdw::locate(xx, n, x); }
+    template <bool STRICT, bool SQ> __device__ static int count_below(const double *x, double zz, int kk, double v)
+    {
+        int lo = 0, hi = kk; // first index whose entry is not below v
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const double e = SQ ? (x[mid] - zz) * (x[mid] - zz) : x[mid];
+            if (STRICT ? e < v : e <= v) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    }
+    __device__ trdw::Bracket bracket(const double *x, bool squared, double zz, int kk, double xrt) const
+    {
+        auto at = [&](int k) { return squared ? (x[k] - zz) * (x[k] - zz) : x[k]; };
+        const double xmin = at(0), xmax = at(kk - 1);
+        trdw::Bracket b;
+        if (xrt <= xmax && xrt >= xmin) {
+            const int c = squared ? count_below<true, true>(x, zz, kk, xrt) : count_below<true, false>(x, zz, kk, xrt);
+            b.mode = 0;
+            b.k = c > 0 ? c - 1 : 0;
+            b.xk = at(b.k);
+            b.xk1 = at(b.k + 1);
+        } else if (xrt >= xmax) {
+            b.mode = 1;
+            b.k = kk - 2;
+            b.xk = at(kk - 2);
+            b.xk1 = at(kk - 1);
+        } else {
+            b.mode = 2;
+            b.k = 0;
+            b.xk = b.xk1 = 0.0;
+        }
+        return b;
+    }
+    __device__ double apply(const trdw::Bracket &b, const double *y, int kk, double xrt) const
+    {
+        if (b.mode <= 1) return (xrt - b.xk) / (b.xk1 - b.xk) * (y[b.k + 1] - y[b.k]) + y[b.k];
+        double ym = y[0];
+        for (int k = 1; k < kk; ++k) ym = trdw::dmin(ym, y[k]);
+        return ym;
+    }
+};
+
+struct ParItem {
+    trdw::Problem p;
+    double *min_dx;
+    const int32_t *nk, *nj;      // node n -> (node i, reach j), mainstem reaches in routing order, nodes 1..ncomp
+    const int32_t *rbase;        // [nmstem + 1] first node of the m-th mainstem reach
+    const int32_t *m_of_reach;   // [nrch] reach j (1-based) -> m, -1 for tributaries
+    double *scratch;             // [nnodes][12]: forward coefficients, recurrence lines, node contributions
+    int nnodes;
+};
+
+// the chain's view of a node: record + window in LDS
+struct ChainLds {
+    double *rec;    // [nnodes][kRecDoubles]: 0 y_norm 1 x1 2 x2 3..5 sf 6 df_mid 7 slope 8 dxi 9 z 10 Q 11 -
+    double *win;    // [nnodes][4][kWinRows]: elevation, conveyance, dK/dA, top width
+    int32_t *w0;    // [nnodes] first table row of the window (0-based), -1: none
+    double *newY;   // [nnodes]
+};
+
+// conveyance (and optionally dK/dA, top width) of node n at water elevation elv: from the node's window, else from its
+// table in global memory with the wavefront's search
+template <bool ALL>
+__device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const ChainLds &L, const WaveScan &ws, int n, int i, int j, double elv,
+                                             double &conv, double &dKdA, double &topw)
+{
+    const double *w = L.win + (size_t)n * 4 * kWinRows;
+    if (L.w0[n] >= 0 && w[0] < elv && elv < w[kWinRows - 1]) {
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < kWinRows; ++r) c += w[r] <= elv ? 1 : 0;
+        const double xa = w[c - 1], xb = w[c];
+        conv = trdw::linterpol(xa, w[kWinRows + c - 1], xb, w[kWinRows + c], elv);
+        if (ALL) {
+            dKdA = trdw::linterpol(xa, w[2 * kWinRows + c - 1], xb, w[2 * kWinRows + c], elv);
+            topw = trdw::linterpol(xa, w[3 * kWinRows + c - 1], xb, w[3 * kWinRows + c], elv);
+        }
+        return;
+    }
+    const double *tb = trdw::node_block(p, i, j);
+    const int irow = trdw::row_blk(ws, tb, trdw::C_ELEV, elv);
+    conv = trdw::at_row(tb, trdw::C_ELEV, trdw::C_CONV, irow, elv);
+    if (ALL) {
+        dKdA = trdw::at_row(tb, trdw::C_ELEV, trdw::C_DKDA, irow, elv);
+        topw = trdw::at_row(tb, trdw::C_ELEV, trdw::C_TOPW, irow, elv);
+    }
+}
+
+__global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *items)
+{
+    using namespace trdw;
+    typedef LaneScan Scan; // (DW_S / DW_L: the sweep state stays in global memory; flat pointers)
+    const ParItem &it = items[blockIdx.x];
+    Problem p = it.p;
+    p.dtini = p.timestep_ar[0];
+    p.dtini_min = p.dtini / p.timestep_ar[9];
+    p.cfl = p.para_ar[0]; p.C_llm = p.para_ar[1]; p.D_llm = p.para_ar[2]; p.D_ulm = p.para_ar[3];
+    p.q_llm = p.para_ar[7]; p.so_llm = p.para_ar[8]; p.theta = p.para_ar[9];
+    p.dsbc_option = (int)p.para_ar[10];
+    const int tid = threadIdx.x, nnodes = it.nnodes, nmstem = p.nmstem;
+    const int32_t *nk = it.nk, *nj = it.nj, *rbase = it.rbase, *m_of_reach = it.m_of_reach;
+    double *scr = it.scratch;
+    HIP_DYNAMIC_SHARED(double, s_mem)
+    ChainLds L;
+    L.rec = s_mem;
+    L.win = L.rec + (size_t)nnodes * kRecDoubles;
+    L.newY = L.win + (size_t)nnodes * 4 * kWinRows;
+    L.w0 = (int32_t *)(L.newY + nnodes);
+    __shared__ double s_red[kParThreads / 64];
+    __shared__ double s_elev[2 * kNel]; // the serial prologue's two elevation columns (WaveScan)
+    WaveScan ws;
+    ws.lds = s_elev;
+    ws.gcol[0] = ws.gcol[1] = nullptr;
+    LaneScan ls;
+
+    // ---- prologue: the serial code, one wavefront (a few hundred node sweeps, once)
+    if (tid < 64) solve_prologue<WaveScan>(p, ws);
+    ws.gcol[0] = ws.gcol[1] = nullptr; // the chain's fall-back searches read the columns where they are
+    __threadfence_block();
+    __syncthreads();
+
+    const double TOL = (double)1e-8f;
+    const double mindepth_nstab = (double)0.1f;
+    const double t0 = p.timestep_ar[1], tfin = p.timestep_ar[2], saveInterval = p.timestep_ar[3];
+    const int nts_ql = p.nts_ql, nts_qtrib = p.nts_qtrib, nts_db = p.nts_db;
+
+    // windows around the initial water surface
+    for (int n = tid; n < nnodes; n += kParThreads) {
+        const int i = nk[n], j = nj[n];
+        const double *tb = node_block(p, i, j);
+        const Bracket be = ls.bracket(tb + C_ELEV * kNel, false, 0.0, kNel, DW_S(p.oldY, i, j));
+        int w0 = be.k - (kWinRows / 2 - 1);
+        w0 = w0 < 0 ? 0 : (w0 > kNel - kWinRows ? kNel - kWinRows : w0);
+        double *w = L.win + (size_t)n * 4 * kWinRows;
+        for (int r = 0; r < kWinRows; ++r) {
+            w[r] = tb[C_ELEV * kNel + w0 + r];
+            w[kWinRows + r] = tb[C_CONV * kNel + w0 + r];
+            w[2 * kWinRows + r] = tb[C_DKDA * kNel + w0 + r];
+            w[3 * kWinRows + r] = tb[C_TOPW * kNel + w0 + r];
+        }
+        L.w0[n] = w0;
+    }
+    __syncthreads();
+
+    double maxCelDx = 1.0 / *it.min_dx;
+    int ts_ev = 1;
+    double t = t0 * 60.0;
+    while (t < tfin * 60.) {
+        // ---- predictor ------------------------------------------------------------------------------------------
+        int ql_row = locate(p.tarr_ql, nts_ql + 1, t);
+        if (ql_row == 0) ql_row = 1;
+        if (ql_row == nts_ql + 1) ql_row = nts_ql;
+        calculate_dt(p, t0, t, saveInterval, tfin, maxCelDx);
+        for (int n = tid; n < nnodes; n += kParThreads) { // lateral inflow and Crank-Nicolson coefficients of a node
+            const int i = nk[n], j = nj[n], ncomp = DW_FRNW(j, 1);
+            if (i <= ncomp - 1) {
+                const double *ql = p.qlat + (int64_t)nts_ql * ((i - 1) + (int64_t)p.mxncomp * (j - 1));
+                const double y1 = ql_row == 1 ? ql[0] : ql[ql_row - 2], y2 = ql[ql_row - 1];
+                DW_G(p.lateralFlow, i, j) = linterpol(p.tarr_ql[ql_row - 1], y1, p.tarr_ql[ql_row], y2, t);
+            }
+            if (i >= 2) {
+                const FwdCoef c = forward_coef<Scan>(p, i, j, ncomp);
+                double *q = scr + (size_t)n * 12;
+                q[0] = c.ppi; q[1] = c.qqi; q[2] = c.rri; q[3] = c.ssi; q[4] = c.sxi;
+            }
+        }
+        __syncthreads();
+        for (int m = tid; m < nmstem; m += kParThreads) { // the recurrences of a reach; new flows of its nodes 2..ncomp
+            const int j = p.mstem_frj[m], ncomp = DW_FRNW(j, 1), n0 = rbase[m];
+            double allqlat = 0.0;
+            for (int i = 2; i <= ncomp - 1; ++i) allqlat = allqlat + DW_G(p.lateralFlow, i, j) * DW_S(p.dx, i, j);
+            double e = 1.0, f = 0.0, ex = 0.0, fx = 0.0;
+            { double *q = scr + (size_t)n0 * 12; q[5] = e; q[6] = f; q[7] = ex; q[8] = fx; }
+            for (int i = 2; i <= ncomp; ++i) {
+                double *q = scr + (size_t)(n0 + i - 1) * 12;
+                const double ppi = q[0], qqi = q[1], rri = q[2], ssi = q[3], sxi = q[4];
+                const double e1 = -1.0 * rri / (ppi * e + qqi);
+                const double f1 = (ssi - ppi * f) / (ppi * e + qqi);
+                const double ex1 = -1.0 * rri / (ppi * ex + qqi);
+                const double fx1 = (sxi - ppi * fx) / (ppi * ex + qqi);
+                e = e1; f = f1; ex = ex1; fx = fx1;
+                q[5] = e; q[6] = f; q[7] = ex; q[8] = fx;
+            }
+            const double qp_ghost = DW_S(p.oldQ, ncomp - 1, j), qpx_ghost = 0.0;
+            DW_S(p.qp, ncomp, j) = e * qp_ghost + f;
+            DW_S(p.qpx, ncomp, j) = ex * qpx_ghost + fx;
+            for (int i = ncomp - 1; i >= 1; --i) {
+                const double *q = scr + (size_t)(n0 + i - 1) * 12;
+                DW_S(p.qp, i, j) = q[5] * DW_S(p.qp, i + 1, j) + q[6];
+                DW_S(p.qpx, i, j) = q[7] * DW_S(p.qpx, i + 1, j) + q[8];
+            }
+            for (int i = 2; i <= ncomp; ++i) {
+                if (fabs(DW_S(p.qp, i, j)) < p.q_llm) DW_S(p.qp, i, j) = p.q_llm;
+                DW_S(p.newQ, i, j) = DW_S(p.qp, i, j);
+            }
+            scr[(size_t)n0 * 12 + 9] = allqlat;
+        }
+        __syncthreads();
+        for (int m = tid; m < nmstem; m += kParThreads) { // junction inflow -> first node of the reach
+            const int j = p.mstem_frj[m], n0 = rbase[m];
+            double q1 = 0.0;
+            if (DW_FRNW(j, 3) > 0) {
+                for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
+                    const int usrchj = DW_FRNW(j, 3 + k);
+                    double q_usrch;
+                    if (is_mainstem(p, usrchj)) {
+                        q_usrch = DW_S(p.newQ, DW_FRNW(usrchj, 1), usrchj);
+                    } else {
+                        const double tf0 = t + p.dtini / 60.;
+                        q_usrch = intp_y(nts_qtrib, p.tarr_qtrib, p.qtrib + (int64_t)(usrchj - 1) * nts_qtrib, tf0);
+                    }
+                    q1 = q1 + q_usrch;
+                }
+            }
+            q1 = q1 + DW_G(p.lateralFlow, 1, j) * DW_S(p.dx, 1, j);
+            double qp1 = q1;
+            qp1 = qp1 + scr[(size_t)n0 * 12 + 9];
+            if (fabs(qp1) < p.q_llm) qp1 = p.q_llm;
+            DW_S(p.qp, 1, j) = qp1;
+            DW_S(p.newQ, 1, j) = qp1;
+        }
+        __syncthreads();
+        // ---- corrector ------------------------------------------------------------------------------------------
+        for (int m = tid; m < nmstem; m += kParThreads) { // water surface at the domain's outlet(s)
+            const int j = p.mstem_frj[m], ncomp = DW_FRNW(j, 1), n0 = rbase[m];
+            if (DW_FRNW(j, 2) >= 0) continue;
+            double y = DW_S(p.newY, ncomp, j);
+            if (p.dsbc_option == 1) {
+                y = intp_y(nts_db, p.tarr_db, p.varr_db, t + p.dtini / 60.);
+                if ((y - DW_S(p.z, ncomp, j)) < mindepth_nstab) y = mindepth_nstab + DW_S(p.z, ncomp, j);
+            } else if (p.dsbc_option == 2) {
+                y = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, fabs(DW_S(p.newQ, ncomp, j)));
+            }
+            L.newY[n0 + ncomp - 1] = y;
+        }
+        for (int n = tid; n < nnodes; n += kParThreads) { // what the depth solve of a node needs besides the node below
+            const int i = nk[n], j = nj[n], ncomp = DW_FRNW(j, 1);
+            double *r = L.rec + (size_t)n * kRecDoubles;
+            const double z_cur = DW_S(p.z, i, j), Q_cur = DW_S(p.qp, i, j);
+            r[9] = z_cur;
+            r[10] = Q_cur;
+            if (i <= ncomp - 1) {
+                const DepthPre d = depth_pre(p, ls, node_block(p, i, j), i, j, Q_cur, z_cur);
+                r[0] = d.y_norm; r[1] = d.x1; r[2] = d.x2; r[3] = d.sf[0]; r[4] = d.sf[1]; r[5] = d.sf[2];
+                r[6] = d.df_mid; r[7] = d.slope; r[8] = d.dxi;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) { // the chain: one wavefront, outlet first
+            for (int jm = nmstem; jm >= 1; --jm) {
+                const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1), n0 = rbase[jm - 1];
+                if (DW_FRNW(j, 2) >= 0) L.newY[n0 + ncomp - 1] = L.newY[rbase[m_of_reach[DW_FRNW(j, 2) - 1]]];
+                for (int i = ncomp; i >= 2; --i) {
+                    const int nd = n0 + i - 1, nc = nd - 1;
+                    const double *rd = L.rec + (size_t)nd * kRecDoubles, *rc = L.rec + (size_t)nc * kRecDoubles;
+                    const double zz = rd[9], Q_ds = rd[10];
+                    double y_ds = L.newY[nd] - zz;
+                    y_ds = dmax(y_ds, (double)0.005f);
+                    const double elv_ds = y_ds + zz;
+                    double conv_ds, u0, u1;
+                    chain_lookup<false>(p, L, ws, nd, i, j, elv_ds, conv_ds, u0, u1);
+                    const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
+                    DepthPre d;
+                    d.y_norm = rc[0]; d.x1 = rc[1]; d.x2 = rc[2]; d.sf[0] = rc[3]; d.sf[1] = rc[4]; d.sf[2] = rc[5];
+                    d.df_mid = rc[6]; d.slope = rc[7]; d.dxi = rc[8]; d.z_cur = rc[9];
+                    const double Q_cur = rc[10], z_cur = rc[9];
+                    const double y_cur = depth_solve(d, sf_ds, y_ds, [&](double yc) {
+                        double conv, dKdA, topw;
+                        chain_lookup<true>(p, L, ws, nc, i - 1, j, yc + z_cur, conv, dKdA, topw);
+                        return funcd_arith(Q_cur, sf_ds, conv, dKdA, topw, d.slope, d.dxi, yc, y_ds);
+                    });
+                    double ny = y_cur + z_cur;
+                    if (ny > 100000.0) ny = 100000.0;
+                    L.newY[nc] = ny;
+                }
+            }
+        }
+        __syncthreads();
+        for (int n = tid; n < nnodes; n += kParThreads) { // the node's own new state, its window for the next sub-step
+            const int i = nk[n], j = nj[n];
+            const double xt = L.newY[n];
+            DW_S(p.newY, i, j) = xt;
+            const NodePost np = backward_node_post(p, i, j, ls);
+            double *q = scr + (size_t)n * 12;
+            q[10] = np.celerity2;
+            q[11] = np.diffusivity2;
+            const double *tb = node_block(p, i, j);
+            const int k = LaneScan::count_below<true, false>(tb + C_ELEV * kNel, 0.0, kNel, xt) - 1; // interval of xt
+            const int w0_old = L.w0[n];
+            if (w0_old < 0 || k < w0_old + 1 || k > w0_old + kWinRows - 3) {
+                int w0 = k - (kWinRows / 2 - 1);
+                w0 = w0 < 0 ? 0 : (w0 > kNel - kWinRows ? kNel - kWinRows : w0);
+                double *w = L.win + (size_t)n * 4 * kWinRows;
+                for (int r = 0; r < kWinRows; ++r) {
+                    w[r] = tb[C_ELEV * kNel + w0 + r];
+                    w[kWinRows + r] = tb[C_CONV * kNel + w0 + r];
+                    w[2 * kWinRows + r] = tb[C_DKDA * kNel + w0 + r];
+                    w[3 * kWinRows + r] = tb[C_TOPW * kNel + w0 + r];
+                }
+                L.w0[n] = w0;
+            }
+        }
+        __syncthreads();
+        double my_max = 0.;
+        for (int m = tid; m < nmstem; m += kParThreads) { // reach means of celerity and diffusivity
+            const int j = p.mstem_frj[m], ncomp = DW_FRNW(j, 1), n0 = rbase[m];
+            double cs = 0.0, ds = 0.0;
+            for (int i = 1; i <= ncomp; ++i) { cs = cs + scr[(size_t)(n0 + i - 1) * 12 + 10]; ds = ds + scr[(size_t)(n0 + i - 1) * 12 + 11]; }
+            double cel = cs / ncomp;
+            if (cel < p.C_llm) cel = p.C_llm;
+            const double dif = ds / ncomp;
+            for (int i = 1; i <= ncomp; ++i) {
+                DW_S(p.celerity, i, j) = cel;
+                double d = dif;
+                if (d > p.D_ulm) d = p.D_ulm;
+                if (d < p.D_llm) d = p.D_llm;
+                DW_S(p.diffusivity, i, j) = d;
+            }
+            for (int kkk = 1; kkk <= ncomp - 1; ++kkk) my_max = dmax(my_max, cel / DW_S(p.dx, kkk, j));
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) my_max = dmax(my_max, __shfl_xor(my_max, d));
+        if ((tid & 63) == 0) s_red[tid >> 6] = my_max;
+        __syncthreads();
+        maxCelDx = 0.;
+        for (int w = 0; w < kParThreads / 64; ++w) maxCelDx = dmax(maxCelDx, s_red[w]);
+        t = t + p.dtini / 60.;
+        // ---- results at the recording instants (:787-810), the initial state after the first sub-step (:813-832)
+        const bool rec_now = fmod((t - t0 * 60.) * 60., saveInterval) <= TOL || t == tfin * 60.;
+        const bool first = t == t0 + p.dtini / 60.;
+        if ((rec_now && ts_ev + 1 <= p.ntss_ev) || first) {
+            for (int n = tid; n < nnodes; n += kParThreads) {
+                const int i = nk[n], j = nj[n];
+                if (rec_now && ts_ev + 1 <= p.ntss_ev) {
+                    DW_EV(p.q_ev, ts_ev + 1, i, j) = DW_S(p.newQ, i, j);
+                    DW_EV(p.elv_ev, ts_ev + 1, i, j) = DW_S(p.newY, i, j);
+                    DW_EV(p.depth_ev, ts_ev + 1, i, j) = DW_EV(p.elv_ev, ts_ev + 1, i, j) - DW_S(p.z, i, j);
+                }
+                if (first) {
+                    DW_EV(p.q_ev, 1, i, j) = DW_S(p.oldQ, i, j);
+                    DW_EV(p.elv_ev, 1, i, j) = DW_S(p.oldY, i, j);
+                    DW_EV(p.depth_ev, 1, i, j) = DW_EV(p.elv_ev, 1, i, j) - DW_S(p.z, i, j);
+                }
+            }
+            for (int m = tid; m < nmstem; m += kParThreads) {
+                const int j = p.mstem_frj[m];
+                for (int k = 1; k <= DW_FRNW(j, 3); ++k) {
+                    const int usrchj = DW_FRNW(j, 3 + k);
+                    if (is_mainstem(p, usrchj)) continue;
+                    if (rec_now && ts_ev + 1 <= p.ntss_ev) {
+                        DW_EV(p.elv_ev, ts_ev + 1, DW_FRNW(usrchj, 1), usrchj) = DW_S(p.newY, 1, j);
+                        DW_EV(p.depth_ev, ts_ev + 1, DW_FRNW(usrchj, 1), usrchj) = DW_S(p.newY, 1, j) - DW_S(p.z, 1, j);
+                    }
+                    if (first) {
+                        DW_EV(p.elv_ev, 1, DW_FRNW(usrchj, 1), usrchj) = DW_S(p.oldY, 1, j);
+                        DW_EV(p.depth_ev, 1, DW_FRNW(usrchj, 1), usrchj) = DW_S(p.oldY, 1, j) - DW_S(p.z, 1, j);
+                    }
+                }
+            }
+        }
+        if (rec_now) ts_ev = ts_ev + 1;
+        __syncthreads();
+        { double *sw = p.oldY; p.oldY = p.newY; p.newY = sw; }
+        { double *sw = p.oldQ; p.oldQ = p.newQ; p.newQ = sw; }
+    }
+}
+
 // host side of one domain: device copies of its inputs, its work space, its node list
 struct Domain {
     std::vector<void *> ptrs;
     trdw::Problem p;
     double *d_out = nullptr, *d_min = nullptr;
-    int32_t *d_nk = nullptr, *d_nj = nullptr;
+    int32_t *d_nk = nullptr, *d_nj = nullptr, *d_rbase = nullptr, *d_mof = nullptr;
+    double *d_scratch = nullptr;
+    size_t par_lds = 0;       // dynamic LDS of the parallel time loop (0: does not fit, serial kernel)
     int nnodes = 0;
     size_t nout = 0;
     int64_t lds_state = 0;
@@ -321,6 +718,13 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
     }
     dom.nnodes = (int)node_k.size();
     if (dom.nnodes == 0) return dw_fail(TRDW_EINVAL, "no mainstem reach (flag 555) in frnw_ar_g");
+    std::vector<int32_t> rbase, m_of((size_t)nr, -1);
+    for (int n_ = 0; n_ < dom.nnodes; ++n_)
+        if (node_k[n_] == 1) {
+            m_of[(size_t)node_j[n_] - 1] = (int32_t)rbase.size();
+            rbase.push_back(n_);
+        }
+    rbase.push_back(dom.nnodes);
     const size_t nn = (size_t)mx * nr;
     trdw::Problem &p = dom.p;
     std::memset(&p, 0, sizeof p);
@@ -368,6 +772,13 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
     if (dom.up(nullptr, (2 * (size_t)nr + 2) * sizeof(int32_t), (void **)&d_frj, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     if (dom.up(node_k.data(), (size_t)dom.nnodes * sizeof(int32_t), (void **)&dom.d_nk, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     if (dom.up(node_j.data(), (size_t)dom.nnodes * sizeof(int32_t), (void **)&dom.d_nj, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    if (dom.up(rbase.data(), rbase.size() * sizeof(int32_t), (void **)&dom.d_rbase, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    if (dom.up(m_of.data(), m_of.size() * sizeof(int32_t), (void **)&dom.d_mof, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    if (dom.up(nullptr, (size_t)dom.nnodes * 12 * sizeof(double), (void **)&dom.d_scratch, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
+    {
+        const size_t need = (size_t)dom.nnodes * ((kRecDoubles + 4 * kWinRows + 1) * sizeof(double) + sizeof(int32_t));
+        dom.par_lds = need + 2 * trdw::kNel * sizeof(double) + 1024 <= 160 * 1024 ? need : 0;
+    }
     DW_TRY(hipStreamSynchronize(st)); // node_k / node_j are about to go out of scope
     DW_TRY(hipMemsetAsync(dom.d_out, 0, 3 * dom.nout * sizeof(double), st));
     DW_TRY(hipMemsetAsync(d_work, 0, (size_t)nwork * sizeof(double), st));
@@ -398,13 +809,14 @@ int run_batch(const trdw_args *args, int n)
     struct Run {
         hipStream_t st = nullptr;
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-        void *d_items = nullptr;
+        void *d_items = nullptr, *d_pitems = nullptr;
         std::vector<Domain> doms;
         ~Run()
         {
             if (st) (void)hipStreamSynchronize(st);
             doms.clear();
             if (d_items) (void)hipFree(d_items);
+            if (d_pitems) (void)hipFree(d_pitems);
             for (auto &e : ev)
                 if (e) (void)hipEventDestroy(e);
             if (st) (void)hipStreamDestroy(st);
@@ -442,9 +854,37 @@ int run_batch(const trdw_args *args, int n)
         hipLaunchKernelGGL(k_dw_tables_finish, dim3(rows), dim3(256), 0, st, dm.p, dm.d_nk, dm.d_nj, dm.nnodes);
     }
     DW_TRY(hipEventRecord(run.ev[1], st));
-    if (lds_max > 64 * 1024)
-        DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    hipLaunchKernelGGL(k_dw_solve, dim3(n), dim3(64), lds_max, st, (const BatchItem *)run.d_items);
+    // the parallel time loop when every domain's chain state fits LDS (TRDW_SOLVER=serial: the one-wavefront kernel)
+    const char *solver = std::getenv("TRDW_SOLVER");
+    bool par = !(solver && std::string(solver) == "serial");
+    size_t par_lds = 0;
+    for (int b = 0; b < n; ++b) {
+        par = par && run.doms[b].par_lds > 0;
+        par_lds = par_lds > run.doms[b].par_lds ? par_lds : run.doms[b].par_lds;
+    }
+    if (par) {
+        std::vector<ParItem> pitems((size_t)n);
+        for (int b = 0; b < n; ++b) {
+            Domain &dm = run.doms[b];
+            pitems[b].p = dm.p;
+            pitems[b].min_dx = dm.d_min;
+            pitems[b].nk = dm.d_nk;
+            pitems[b].nj = dm.d_nj;
+            pitems[b].rbase = dm.d_rbase;
+            pitems[b].m_of_reach = dm.d_mof;
+            pitems[b].scratch = dm.d_scratch;
+            pitems[b].nnodes = dm.nnodes;
+        }
+        DW_TRY(hipMalloc(&run.d_pitems, (size_t)n * sizeof(ParItem)));
+        DW_TRY(hipMemcpyAsync(run.d_pitems, pitems.data(), (size_t)n * sizeof(ParItem), hipMemcpyHostToDevice, st));
+        DW_TRY(hipStreamSynchronize(st)); // pitems is about to go out of scope
+        DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve_par), hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds));
+        hipLaunchKernelGGL(k_dw_solve_par, dim3(n), dim3(kParThreads), par_lds, st, (const ParItem *)run.d_pitems);
+    } else {
+        if (lds_max > 64 * 1024)
+            DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        hipLaunchKernelGGL(k_dw_solve, dim3(n), dim3(64), lds_max, st, (const BatchItem *)run.d_items);
+    }
     DW_TRY(hipEventRecord(run.ev[2], st));
     DW_TRY(hipGetLastError());
     for (int b = 0; b < n; ++b) {

@@ -583,34 +583,43 @@ DW_HD inline double setup_scalars(Problem &p)
 struct Depth {  // funcd_diffdepth (:1664-1711): f and df/dy at depth y_cur of node i
     double f, df;
 };
-// sf_ds, the energy slope at the node below, does not depend on y_cur: rtsafe forms it once (same operations)
-template <class Scan>
-DW_HD inline Depth funcd(const Problem &p, const Scan &scan, const double *tb, int i, int j, double Q_cur, double sf_ds,
-                         double z_cur, double y_cur, double y_ds)
+// rtsafe (:1555-1662): Newton-Raphson safeguarded by bisection for the depth of node i given node i+1 -- in two parts.
+// Everything that does not depend on the node below (the bracket from the normal depth and the old depth, the table
+// look-ups of the three evaluations the iteration starts with) is DepthPre; depth_solve() is what is left of the
+// recurrence from node to node.  The host runs one after the other; the device forms DepthPre for all nodes of a
+// sub-step at once, one node per thread, and walks the chain with one wavefront (diffusive.hip).
+struct DepthPre {
+    double y_norm, x1, x2;   // normal depth for Q_cur, the bracket 0.05 (y_norm + y_old) .. (y_norm + y_old)
+    double sf[3];            // |Q| Q / K**2 at x1, x2 and the midpoint
+    double df_mid;           // df/dy at the midpoint
+    double qq;               // |Q_cur| Q_cur
+    double slope, dxi, z_cur;
+};
+// f and df/dy from the table values at y_cur (funcd_diffdepth's arithmetic)
+DW_HD inline Depth funcd_arith(double Q_cur, double sf_ds, double conv_cur, double dKdA, double topw, double slope, double dxi,
+                               double y_cur, double y_ds)
 {
-    if (p.counters) p.counters[2] += 1;
-    const double elv_cur = y_cur + z_cur;
-    const int irow = row_blk(scan, tb, C_ELEV, elv_cur);       // one search: conveyance, dK/dA and top width
-    const double conv_cur = at_row(tb, C_ELEV, C_CONV, irow, elv_cur);
     const double sf_cur = fabs(Q_cur) * Q_cur / (conv_cur * conv_cur);
-    double slope = (DW_S(p.z, i, j) - DW_S(p.z, i + 1, j)) / DW_S(p.dx, i, j);
-    slope = dmax(slope, p.so_llm);
     Depth r;
-    r.f = y_cur - y_ds + slope * DW_S(p.dx, i, j) - 0.50 * (sf_cur + sf_ds) * DW_S(p.dx, i, j);
-    const double dKdA = at_row(tb, C_ELEV, C_DKDA, irow, elv_cur);
-    const double topw = at_row(tb, C_ELEV, C_TOPW, irow, elv_cur);
-    r.df = 1.0 + (fabs(Q_cur) * Q_cur / (conv_cur * conv_cur * conv_cur)) * DW_S(p.dx, i, j) * topw * dKdA;
+    r.f = y_cur - y_ds + slope * dxi - 0.50 * (sf_cur + sf_ds) * dxi;
+    r.df = 1.0 + (fabs(Q_cur) * Q_cur / (conv_cur * conv_cur * conv_cur)) * dxi * topw * dKdA;
     return r;
 }
-// The same function at three depths at once, stage by stage (searches, then table rows, then arithmetic): the three
-// evaluations rtsafe starts with -- both ends of its bracket and the midpoint -- do not depend on each other, and a
-// lone wavefront that runs them one after the other waits for every search and every table row three times.
-// Per depth the operations are those of funcd, so the bits are too.
 template <class Scan>
-DW_HD inline void funcd3(const Problem &p, const Scan &scan, const double *tb, int i, int j, double Q_cur, double sf_ds,
-                         double z_cur, const double (&y)[3], double y_ds, Depth (&out)[3])
+DW_HD inline DepthPre depth_pre(const Problem &p, const Scan &scan, const double *tb, int i, int j, double Q_cur, double z_cur)
 {
     if (p.counters) p.counters[2] += 3;
+    DepthPre d;
+    const int row_norm = row_blk(scan, tb, C_UNIF, fabs(Q_cur));
+    const double elv_norm = at_row(tb, C_UNIF, C_ELEV, row_norm, fabs(Q_cur));
+    d.y_norm = elv_norm - DW_S(p.z, i, j);
+    const double y_old = DW_S(p.oldY, i, j) - DW_S(p.z, i, j);
+    d.x1 = 0.5 * (d.y_norm + y_old) * (double)0.1f;
+    d.x2 = 0.5 * (d.y_norm + y_old) * 2.0;
+    const double rt = 0.50 * (d.x1 + d.x2);
+    // the three evaluations rtsafe starts with -- both ends of its bracket and the midpoint -- stage by stage
+    // (searches, then table rows, then arithmetic): they do not depend on each other
+    const double y[3] = {d.x1, d.x2, rt};
     double elv[3], conv[3], dKdA[3], topw[3];
     int irow[3];
     for (int k = 0; k < 3; ++k) elv[k] = y[k] + z_cur;
@@ -620,109 +629,127 @@ DW_HD inline void funcd3(const Problem &p, const Scan &scan, const double *tb, i
         dKdA[k] = at_row(tb, C_ELEV, C_DKDA, irow[k], elv[k]);
         topw[k] = at_row(tb, C_ELEV, C_TOPW, irow[k], elv[k]);
     }
-    const double dxi = DW_S(p.dx, i, j);
-    double slope = (DW_S(p.z, i, j) - DW_S(p.z, i + 1, j)) / dxi;
-    slope = dmax(slope, p.so_llm);
-    for (int k = 0; k < 3; ++k) {
-        const double sf_cur = fabs(Q_cur) * Q_cur / (conv[k] * conv[k]);
-        out[k].f = y[k] - y_ds + slope * dxi - 0.50 * (sf_cur + sf_ds) * dxi;
-        out[k].df = 1.0 + (fabs(Q_cur) * Q_cur / (conv[k] * conv[k] * conv[k])) * dxi * topw[k] * dKdA[k];
-    }
+    d.dxi = DW_S(p.dx, i, j);
+    double slope = (DW_S(p.z, i, j) - DW_S(p.z, i + 1, j)) / d.dxi;
+    d.slope = dmax(slope, p.so_llm);
+    d.z_cur = z_cur;
+    d.qq = fabs(Q_cur) * Q_cur;
+    for (int k = 0; k < 3; ++k) d.sf[k] = fabs(Q_cur) * Q_cur / (conv[k] * conv[k]);
+    d.df_mid = 1.0 + (fabs(Q_cur) * Q_cur / (conv[2] * conv[2] * conv[2])) * d.dxi * topw[2] * dKdA[2];
+    return d;
 }
-// rtsafe (:1555-1662): Newton-Raphson safeguarded by bisection for the depth of node i given node i+1
-template <class Scan>
-DW_HD inline double rtsafe(const Problem &p, const Scan &scan, const double *tb, const double *tb_ds, int i, int j, double Q_cur,
-                          double Q_ds, double z_cur, double z_ds, double y_ds)
+// F: (y_cur) -> Depth, the function evaluation of an iteration (a table search and three rows)
+template <class F> DW_HD inline double depth_solve(const DepthPre &d, double sf_ds, double y_ds, const F &eval)
 {
     const int maxit = 40;
     const double xacc = (double)1e-4f;
-    const double elv_ds = y_ds + z_ds;
-    // the two look-ups that set the problem up, their searches first, then their rows
-    const int row_ds = row_blk(scan, tb_ds, C_ELEV, elv_ds);
-    const int row_norm = row_blk(scan, tb, C_UNIF, fabs(Q_cur));
-    const double conv_ds = at_row(tb_ds, C_ELEV, C_CONV, row_ds, elv_ds);
-    const double elv_norm = at_row(tb, C_UNIF, C_ELEV, row_norm, fabs(Q_cur));
-    const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
-    const double y_norm = elv_norm - DW_S(p.z, i, j);
-    const double y_old = DW_S(p.oldY, i, j) - DW_S(p.z, i, j);
-    const double x1 = 0.5 * (y_norm + y_old) * (double)0.1f;
-    const double x2 = 0.5 * (y_norm + y_old) * 2.0;
+    const double x1 = d.x1, x2 = d.x2;
     double rt = 0.50 * (x1 + x2);
-    // f at both ends of the bracket and (f, df) at the midpoint the iteration starts from, together (the reference
-    // evaluates the midpoint only when the bracket holds; its value is not used otherwise)
-    const double y3[3] = {x1, x2, rt};
-    Depth d3[3];
-    funcd3(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, y3, y_ds, d3);
-    const double fl = d3[0].f, fh = d3[1].f;
-    if ((fl > 0.0 && fh > 0.0) || (fl < 0.0 && fh < 0.0)) return y_norm;
+    // f at both ends of the bracket and (f, df) at the midpoint the iteration starts from (the reference evaluates the
+    // midpoint only when the bracket holds; its value is not used otherwise)
+    const double fl = x1 - y_ds + d.slope * d.dxi - 0.50 * (d.sf[0] + sf_ds) * d.dxi;
+    const double fh = x2 - y_ds + d.slope * d.dxi - 0.50 * (d.sf[1] + sf_ds) * d.dxi;
+    if ((fl > 0.0 && fh > 0.0) || (fl < 0.0 && fh < 0.0)) return d.y_norm;
     if (fl == 0.0) return x1;
     if (fh == 0.0) return x2;
     double xl, xh;
     if (fl < 0.0) { xl = x1; xh = x2; } else { xh = x1; xl = x2; }
     double dxold = fabs(x2 - x1), dxx = dxold;
-    Depth d = d3[2];
+    Depth dd;
+    dd.f = rt - y_ds + d.slope * d.dxi - 0.50 * (d.sf[2] + sf_ds) * d.dxi;
+    dd.df = d.df_mid;
     for (int iter = 1; iter <= maxit; ++iter) {
-        if (((rt - xh) * d.df - d.f) * ((rt - xl) * d.df - d.f) > 0.0 || fabs(2.0 * d.f) > fabs(dxold * d.df)) {
+        if (((rt - xh) * dd.df - dd.f) * ((rt - xl) * dd.df - dd.f) > 0.0 || fabs(2.0 * dd.f) > fabs(dxold * dd.df)) {
             dxold = dxx;
             dxx = 0.50 * (xh - xl);
             rt = xl + dxx;
             if (xl == rt) return rt;
         } else {
             dxold = dxx;
-            dxx = d.f / d.df;
+            dxx = dd.f / dd.df;
             const double temp = rt;
             rt = rt - dxx;
             if (temp == rt) return rt;
         }
         if (fabs(dxx) < xacc) return rt;
-        d = funcd(p, scan, tb, i, j, Q_cur, sf_ds, z_cur, rt, y_ds);
-        if (d.f < 0.0) xl = rt; else xh = rt;
+        dd = eval(rt);
+        if (dd.f < 0.0) xl = rt; else xh = rt;
     }
-    return y_norm;
+    return d.y_norm;
+}
+template <class Scan>
+DW_HD inline double rtsafe(const Problem &p, const Scan &scan, const double *tb, const double *tb_ds, int i, int j, double Q_cur,
+                          double Q_ds, double z_cur, double z_ds, double y_ds)
+{
+    const double elv_ds = y_ds + z_ds;
+    const int row_ds = row_blk(scan, tb_ds, C_ELEV, elv_ds);
+    const double conv_ds = at_row(tb_ds, C_ELEV, C_CONV, row_ds, elv_ds);
+    const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
+    const DepthPre d = depth_pre(p, scan, tb, i, j, Q_cur, z_cur);
+    return depth_solve(d, sf_ds, y_ds, [&](double y_cur) {
+        if (p.counters) p.counters[2] += 1;
+        const double elv_cur = y_cur + z_cur;
+        const int irow = row_blk(scan, tb, C_ELEV, elv_cur);       // one search: conveyance, dK/dA and top width
+        const double conv_cur = at_row(tb, C_ELEV, C_CONV, irow, elv_cur);
+        const double dKdA = at_row(tb, C_ELEV, C_DKDA, irow, elv_cur);
+        const double topw = at_row(tb, C_ELEV, C_TOPW, irow, elv_cur);
+        return funcd_arith(Q_cur, sf_ds, conv_cur, dKdA, topw, d.slope, d.dxi, y_cur, y_ds);
+    });
 }
 
-// mesh_diffusive_forward (:1108-1355): Crank-Nicolson flow along reach j (Thomas recurrences eei/ffi, exi/fxi)
+// mesh_diffusive_forward (:1108-1355): Crank-Nicolson flow along reach j (Thomas recurrences eei/ffi, exi/fxi).
+// The coefficients of node i (2..ncomp) depend on the old time level only: FwdCoef, one node at a time.
+struct FwdCoef {
+    double ppi, qqi, rri, ssi, sxi;
+};
+template <class Scan> DW_HD inline FwdCoef forward_coef(const Problem &p, int i, int j, int ncomp)
+{
+    const double dtini = p.dtini, theta = p.theta;
+    const double dxm = DW_S(p.dx, i - 1, j);
+    const double cour = dtini / dxm;
+    const double cour2 = fabs(DW_S(p.celerity, i, j)) * cour;
+    const double c2 = cour2 * cour2, c3 = cour2 * cour2 * cour2;
+    const double a1 = 3.0 * c2 - 2.0 * c3;
+    const double a2 = 1 - a1;
+    const double a3 = (c2 - c3) * dxm;
+    const double a4 = (-1.0 * cour2 + 2.0 * c2 - c3) * dxm;
+    const double b1 = (6.0 * cour2 - 6.0 * c2) / (-1.0 * dxm);
+    const double b2 = -b1;
+    const double b3 = (2.0 * cour2 - 3.0 * c2) * (-1.0);
+    const double b4 = (-1.0 + 4.0 * cour2 - 3.0 * c2) * (-1.0);
+    const double dd1 = (6.0 - 12.0 * cour2) / (dxm * dxm);
+    const double dd2 = -dd1;
+    const double dd3 = (2.0 - 6.0 * cour2) / dxm;
+    const double dd4 = (4.0 - 6.0 * cour2) / dxm;
+    const double h1 = 12.0 / (dxm * dxm * dxm);
+    const double h2 = -h1;
+    const double h3 = 6.0 / (dxm * dxm);
+    const double h4 = h3;
+    const double alpha = (i == ncomp) ? 1.0 : DW_S(p.dx, i, j) / DW_S(p.dx, i - 1, j);
+    const double qa = DW_S(p.oldQ, i - 1, j), qb = DW_S(p.oldQ, i, j);
+    const double xa = DW_S(p.qpx, i - 1, j), xb = DW_S(p.qpx, i, j);
+    const double qy = a1 * qa + a2 * qb + a3 * xa + a4 * xb;
+    const double qxy = b1 * qa + b2 * qb + b3 * xa + b4 * xb;
+    const double qxxy = dd1 * qa + dd2 * qb + dd3 * xa + dd4 * xb;
+    const double qxxxy = h1 * qa + h2 * qb + h3 * xa + h4 * xb;
+    const double dif = DW_S(p.diffusivity, i, j);
+    FwdCoef c;
+    c.ppi = -theta * dif * dtini / (dxm * dxm) * 2.0 / (alpha * (alpha + 1.0)) * alpha;
+    c.qqi = 1.0 - c.ppi * (alpha + 1.0) / alpha;
+    c.rri = c.ppi / alpha;
+    c.ssi = qy + dtini * dif * (1.0 - theta) * qxxy;
+    c.sxi = qxy + dtini * dif * (1.0 - theta) * qxxxy;
+    return c;
+}
 template <class Scan> DW_HD inline void forward(Problem &p, int j)
 {
     const int ncomp = DW_FRNW(j, 1);
-    const double dtini = p.dtini, theta = p.theta;
     DW_L(p.eei)[0] = 1.0; DW_L(p.ffi)[0] = 0.0; DW_L(p.exi)[0] = 0.0; DW_L(p.fxi)[0] = 0.0;
     double allqlat = 0.0;
     for (int i = 2; i <= ncomp - 1; ++i) allqlat = allqlat + DW_G(p.lateralFlow, i, j) * DW_S(p.dx, i, j);
     for (int i = 2; i <= ncomp; ++i) {
-        const double dxm = DW_S(p.dx, i - 1, j);
-        const double cour = dtini / dxm;
-        const double cour2 = fabs(DW_S(p.celerity, i, j)) * cour;
-        const double c2 = cour2 * cour2, c3 = cour2 * cour2 * cour2;
-        const double a1 = 3.0 * c2 - 2.0 * c3;
-        const double a2 = 1 - a1;
-        const double a3 = (c2 - c3) * dxm;
-        const double a4 = (-1.0 * cour2 + 2.0 * c2 - c3) * dxm;
-        const double b1 = (6.0 * cour2 - 6.0 * c2) / (-1.0 * dxm);
-        const double b2 = -b1;
-        const double b3 = (2.0 * cour2 - 3.0 * c2) * (-1.0);
-        const double b4 = (-1.0 + 4.0 * cour2 - 3.0 * c2) * (-1.0);
-        const double dd1 = (6.0 - 12.0 * cour2) / (dxm * dxm);
-        const double dd2 = -dd1;
-        const double dd3 = (2.0 - 6.0 * cour2) / dxm;
-        const double dd4 = (4.0 - 6.0 * cour2) / dxm;
-        const double h1 = 12.0 / (dxm * dxm * dxm);
-        const double h2 = -h1;
-        const double h3 = 6.0 / (dxm * dxm);
-        const double h4 = h3;
-        const double alpha = (i == ncomp) ? 1.0 : DW_S(p.dx, i, j) / DW_S(p.dx, i - 1, j);
-        const double qa = DW_S(p.oldQ, i - 1, j), qb = DW_S(p.oldQ, i, j);
-        const double xa = DW_S(p.qpx, i - 1, j), xb = DW_S(p.qpx, i, j);
-        const double qy = a1 * qa + a2 * qb + a3 * xa + a4 * xb;
-        const double qxy = b1 * qa + b2 * qb + b3 * xa + b4 * xb;
-        const double qxxy = dd1 * qa + dd2 * qb + dd3 * xa + dd4 * xb;
-        const double qxxxy = h1 * qa + h2 * qb + h3 * xa + h4 * xb;
-        const double dif = DW_S(p.diffusivity, i, j);
-        const double ppi = -theta * dif * dtini / (dxm * dxm) * 2.0 / (alpha * (alpha + 1.0)) * alpha;
-        const double qqi = 1.0 - ppi * (alpha + 1.0) / alpha;
-        const double rri = ppi / alpha;
-        const double ssi = qy + dtini * dif * (1.0 - theta) * qxxy;
-        const double sxi = qxy + dtini * dif * (1.0 - theta) * qxxxy;
+        const FwdCoef c = forward_coef<Scan>(p, i, j, ncomp);
+        const double ppi = c.ppi, qqi = c.qqi, rri = c.rri, ssi = c.ssi, sxi = c.sxi;
         DW_L(p.eei)[i - 1] = -1.0 * rri / (ppi * DW_L(p.eei)[i - 2] + qqi);
         DW_L(p.ffi)[i - 1] = (ssi - ppi * DW_L(p.ffi)[i - 2]) / (ppi * DW_L(p.eei)[i - 2] + qqi);
         DW_L(p.exi)[i - 1] = -1.0 * rri / (ppi * DW_L(p.exi)[i - 2] + qqi);
@@ -744,7 +771,35 @@ template <class Scan> DW_HD inline void forward(Problem &p, int j)
     for (int i = 1; i <= ncomp; ++i) DW_S(p.newQ, i, j) = DW_S(p.qp, i, j);
 }
 
-// mesh_diffusive_backward (:1357-1553): water surface along reach j from its bottom node upwards
+// mesh_diffusive_backward (:1357-1553): water surface along reach j from its bottom node upwards.
+// What a node contributes once its water surface is known -- area, perimeter, top width, roughness, and the celerity and
+// diffusivity its reach averages -- depends on that node alone: NodePost.
+struct NodePost {
+    double co, celerity2, diffusivity2;
+};
+template <class Scan> DW_HD inline NodePost backward_node_post(Problem &p, int i, int j, const Scan &scan)
+{
+    const double *tb = scan.table(p, i, j);
+    const double *elevT = tb + C_ELEV * kNel;
+    const double xt = DW_S(p.newY, i, j);
+    const double zz = DW_S(p.z, i, j);
+    const double sq = (xt - zz) * (xt - zz);
+    NodePost r;
+    r.co = 1.0 * scan.apply(scan.bracket(elevT, true, zz, kNel, sq), tb + C_CONV * kNel, kNel, sq);
+    const Bracket be = scan.bracket(elevT, false, 0.0, kNel, xt); // one search for the four columns at xt
+    DW_G(p.newArea, i, j) = scan.apply(be, tb + C_AREA * kNel, kNel, xt);
+    DW_G(p.pere, i, j) = scan.apply(be, tb + C_PERI * kNel, kNel, xt);
+    DW_G(p.bo, i, j) = scan.apply(be, tb + C_TOPW * kNel, kNel, xt);
+    DW_G(p.sk, i, j) = scan.apply(be, tb + C_SKK * kNel, kNel, xt);
+    const double qpi = DW_S(p.qp, i, j);
+    const double sfi = qpi * fabs(qpi) / (r.co * r.co);
+    r.celerity2 = (double)(5.0f / 3.0f) * DW_POW(fabs(sfi), (double)0.3f) * DW_POW(fabs(qpi), (double)0.4f)
+                  / DW_POW(DW_G(p.bo, i, j), (double)0.4f) / DW_POW(1. / (DW_G(p.sk, i, j) * 1.0), (double)0.6f);
+    const double C_ulm = (i > 1) ? p.cfl * DW_S(p.dx, i - 1, j) / p.dtini_min : p.cfl * DW_S(p.dx, i, j) / p.dtini_min;
+    if (r.celerity2 > C_ulm) r.celerity2 = C_ulm;
+    r.diffusivity2 = fabs(qpi) / 2.0 / DW_G(p.bo, i, j) / fabs(sfi);
+    return r;
+}
 template <class Scan> DW_HD inline void backward(Problem &p, int j, Scan &scan)
 {
     const int ncomp = DW_FRNW(j, 1);
@@ -760,25 +815,13 @@ template <class Scan> DW_HD inline void backward(Problem &p, int j, Scan &scan)
         scan.begin_node(p, i, j);               // node i (and i-1, which the depth solve reads) become resident
         if (p.counters) p.counters[1] += 1;
         const double *tb = scan.table(p, i, j);
-        const double *elevT = tb + C_ELEV * kNel;
-        const double xt = DW_S(p.newY, i, j);
-        const double zz = DW_S(p.z, i, j);
-        const double sq = (xt - zz) * (xt - zz);
-        DW_L(p.co)[i - 1] = 1.0 * scan.apply(scan.bracket(elevT, true, zz, kNel, sq), tb + C_CONV * kNel, kNel, sq);
-        const Bracket be = scan.bracket(elevT, false, 0.0, kNel, xt); // one search for the four columns at xt
-        DW_G(p.newArea, i, j) = scan.apply(be, tb + C_AREA * kNel, kNel, xt);
-        DW_G(p.pere, i, j) = scan.apply(be, tb + C_PERI * kNel, kNel, xt);
-        DW_G(p.bo, i, j) = scan.apply(be, tb + C_TOPW * kNel, kNel, xt);
-        DW_G(p.sk, i, j) = scan.apply(be, tb + C_SKK * kNel, kNel, xt);
-        const double qpi = DW_S(p.qp, i, j);
-        const double sfi = qpi * fabs(qpi) / (DW_L(p.co)[i - 1] * DW_L(p.co)[i - 1]);
-        DW_L(p.celerity2)[i - 1] = (double)(5.0f / 3.0f) * DW_POW(fabs(sfi), (double)0.3f) * DW_POW(fabs(qpi), (double)0.4f)
-                             / DW_POW(DW_G(p.bo, i, j), (double)0.4f) / DW_POW(1. / (DW_G(p.sk, i, j) * 1.0), (double)0.6f);
-        const double C_ulm = (i > 1) ? p.cfl * DW_S(p.dx, i - 1, j) / p.dtini_min : p.cfl * DW_S(p.dx, i, j) / p.dtini_min;
-        if (DW_L(p.celerity2)[i - 1] > C_ulm) DW_L(p.celerity2)[i - 1] = C_ulm;
-        DW_L(p.diffusivity2)[i - 1] = fabs(qpi) / 2.0 / DW_G(p.bo, i, j) / fabs(sfi);
+        const NodePost np = backward_node_post(p, i, j, scan);
+        DW_L(p.co)[i - 1] = np.co;
+        DW_L(p.celerity2)[i - 1] = np.celerity2;
+        DW_L(p.diffusivity2)[i - 1] = np.diffusivity2;
         if (i > 1) {
-            const double Q_cur = DW_S(p.qp, i - 1, j), Q_ds = qpi;
+            const double zz = DW_S(p.z, i, j);
+            const double Q_cur = DW_S(p.qp, i - 1, j), Q_ds = DW_S(p.qp, i, j);
             const double z_cur = DW_S(p.z, i - 1, j), z_ds = zz;
             double y_ds = DW_S(p.newY, i, j) - zz;
             y_ds = dmax(y_ds, (double)0.005f);
@@ -811,14 +854,14 @@ DW_HD inline void calculate_dt(Problem &p, double initialTime, double time, doub
     if (time + p.dtini / 60. > tfin * 60.) p.dtini = (tfin * 60. - time) * 60.;
 }
 
-// Everything of diffnw after the tables exist (:488-870), in one thread.
-template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &scan)
+// What diffnw does between the tables and its time loop (:488-607), in one thread: time axes, the initial water
+// surface, the tributary hydrographs in the output arrays.
+template <class Scan> DW_HD inline void solve_prologue(Problem &p, Scan &scan)
 {
     const double TOL = (double)1e-8f;
     const double mindepth_nstab = (double)0.1f;
     const double t0 = p.timestep_ar[1], tfin = p.timestep_ar[2], saveInterval = p.timestep_ar[3];
     const double dt_ql = p.timestep_ar[4], dt_db = p.timestep_ar[6], dt_qtrib = p.timestep_ar[7];
-    const double dtini_given = p.timestep_ar[0];
     const int nts_ql = p.nts_ql, nts_qtrib = p.nts_qtrib, nts_db = p.nts_db, nlinks = p.nrch;
     // ---- time axes (:491-530)
     for (int n = 1; n <= nts_ql; ++n) p.tarr_ql[n] = t0 * 60.0 + dt_ql * (double)n / 60.0;
@@ -870,10 +913,21 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
         }
         t = t + p.dtini / 60.;
     }
+}
+
+// Everything of diffnw after the tables exist (:488-870), in one thread.
+template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &scan)
+{
+    const double TOL = (double)1e-8f;
+    const double mindepth_nstab = (double)0.1f;
+    const double t0 = p.timestep_ar[1], tfin = p.timestep_ar[2], saveInterval = p.timestep_ar[3];
+    const double dtini_given = p.timestep_ar[0];
+    const int nts_ql = p.nts_ql, nts_qtrib = p.nts_qtrib, nts_db = p.nts_db;
+    solve_prologue(p, scan);
     // ---- the ordered time loop (:612-870)
     double maxCelDx = 1.0 / minDx;
-    ts_ev = 1;
-    t = t0 * 60.0;
+    int ts_ev = 1;
+    double t = t0 * 60.0;
     while (t < tfin * 60.) {
         if (p.counters) p.counters[0] += 1;
         // predictor: flow, upstream to downstream
