@@ -11,6 +11,7 @@
 //                       the 501-row tables -- with ballots and lane shuffles (WaveScan).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -285,7 +286,8 @@ __global__ void __launch_bounds__(64) k_dw_solve(const BatchItem *items)
 //     the refresh of its window -- one thread per node; reach means -- one thread per reach.
 // The arithmetic of every piece is the function the serial solver calls (diffusive_core.hpp), so the bits are the same.
 constexpr int kParThreads = 512;
-constexpr int kWinRows = 6;
+constexpr int kWinRows = 5;                       // table rows of a window: 4 intervals
+constexpr int kWinDoubles = kWinRows + 3 * 2 * (kWinRows - 1); // elevations; per interval and column {ordinate, slope}
 constexpr int kRecDoubles = 12;
 
 // one thread, its own searches (bisection on an ascending column), tables in global memory
@@ -342,36 +344,101 @@ struct ParItem {
     const int32_t *rbase;        // [nmstem + 1] first node of the m-th mainstem reach
     const int32_t *m_of_reach;   // [nrch] reach j (1-based) -> m, -1 for tributaries
     double *scratch;             // [nnodes][12]: forward coefficients, recurrence lines, node contributions
+    unsigned long long *phase_ticks; // developer aid (TRDW_PHASES=1): [8] wall-clock ticks per phase, [8] window misses
     int nnodes;
 };
 
 // the chain's view of a node: record + window in LDS
 struct ChainLds {
     double *rec;    // [nnodes][kRecDoubles]: 0 y_norm 1 x1 2 x2 3..5 sf 6 df_mid 7 slope 8 dxi 9 z 10 Q 11 -
-    double *win;    // [nnodes][4][kWinRows]: elevation, conveyance, dK/dA, top width
-    int32_t *w0;    // [nnodes] first table row of the window (0-based), -1: none
+    double *win;    // [nnodes][kWinDoubles]: elevations of the rows, then per column (conveyance, dK/dA, top width) and
+                    // interval {ordinate at its lower row, (y2 - y1) / (x2 - x1)} -- linterpol's quotient, formed ahead
+    int32_t *w0;    // [nnodes][2]: first table row of the window (0-based; -1: none); interval of the last look-up |
+                    // (intervals narrower than linterpol's 1e-4 as a bit mask) << 8
     double *newY;   // [nnodes]
+    unsigned long long *misses; // developer aid: look-ups that left the window
 };
 
-// conveyance (and optionally dK/dA, top width) of node n at water elevation elv: from the node's window, else from its
-// table in global memory with the wavefront's search
+// (re)load the window of node n so that interval k of its table sits in the middle
+__device__ __forceinline__ void window_load(const ChainLds &L, int n, const double *tb, int k)
+{
+    int w0 = k - (kWinRows - 1) / 2 + ((kWinRows - 1) % 2 == 0 ? 1 : 0);
+    w0 = w0 < 0 ? 0 : (w0 > trdw::kNel - kWinRows ? trdw::kNel - kWinRows : w0);
+    double *w = L.win + (size_t)n * kWinDoubles;
+    const double *xe = tb + trdw::C_ELEV * trdw::kNel + w0;
+    for (int r = 0; r < kWinRows; ++r) w[r] = xe[r];
+    int tiny = 0;
+    for (int r = 0; r < kWinRows - 1; ++r)
+        if (fabs(xe[r + 1] - xe[r]) < (double)0.0001f) tiny |= 1 << r;
+    const int cols[3] = {trdw::C_CONV, trdw::C_DKDA, trdw::C_TOPW};
+    for (int c = 0; c < 3; ++c) {
+        const double *y = tb + cols[c] * trdw::kNel + w0;
+        double *o = w + kWinRows + c * 2 * (kWinRows - 1);
+        for (int r = 0; r < kWinRows - 1; ++r) {
+            // linterpol: (y2 - y1) / (x2 - x1) * (x - x1) + y1, or the mean of the ordinates on a degenerate interval
+            const bool deg = (tiny >> r) & 1;
+            o[2 * r] = deg ? 0.5 * (y[r] + y[r + 1]) : y[r];
+            o[2 * r + 1] = deg ? 0.0 : (y[r + 1] - y[r]) / (xe[r + 1] - xe[r]);
+        }
+    }
+    L.w0[2 * n] = w0;
+    int g = k - w0;
+    g = g < 0 ? 0 : (g > kWinRows - 2 ? kWinRows - 2 : g);
+    L.w0[2 * n + 1] = g | (tiny << 8);
+}
+// A node's window as the chain holds it in registers: the row elevations and the interval of the last look-up (the
+// guess); the other intervals stay in LDS.  The chain fetches a node's window while it is still solving the node before,
+// so a look-up that falls into the guessed interval -- nearly all do: the iterates of one node lie within centimetres of
+// each other -- costs compares, selects and a multiply-add, no memory access.
+struct WinRegs {
+    int n, w0, g, tiny;
+    double xe[kWinRows];
+    double yc, qc, yd, qd, yt, qt;
+};
+__device__ __forceinline__ void win_fetch_interval(const ChainLds &L, WinRegs &W, int g)
+{
+    const double *oc = L.win + (size_t)W.n * kWinDoubles + kWinRows;
+    W.g = g;
+    W.yc = oc[2 * g]; W.qc = oc[2 * g + 1];
+    W.yd = oc[2 * (kWinRows - 1) + 2 * g]; W.qd = oc[2 * (kWinRows - 1) + 2 * g + 1];
+    W.yt = oc[4 * (kWinRows - 1) + 2 * g]; W.qt = oc[4 * (kWinRows - 1) + 2 * g + 1];
+}
+__device__ __forceinline__ WinRegs win_fetch(const ChainLds &L, int n)
+{
+    WinRegs W;
+    W.n = n;
+    const double *w = L.win + (size_t)n * kWinDoubles;
+    W.w0 = L.w0[2 * n];
+    const int meta = L.w0[2 * n + 1];
+    W.tiny = meta >> 8;
+#pragma unroll
+    for (int r = 0; r < kWinRows; ++r) W.xe[r] = w[r];
+    win_fetch_interval(L, W, meta & 0xff);
+    return W;
+}
+// conveyance (and optionally dK/dA, top width) of the window's node (i, j) at water elevation elv; an elevation outside the
+// window takes the wavefront's search over the node's table in global memory
 template <bool ALL>
-__device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const ChainLds &L, const WaveScan &ws, int n, int i, int j, double elv,
+__device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const ChainLds &L, const WaveScan &ws, WinRegs &W, int i, int j, double elv,
                                              double &conv, double &dKdA, double &topw)
 {
-    const double *w = L.win + (size_t)n * 4 * kWinRows;
-    if (L.w0[n] >= 0 && w[0] < elv && elv < w[kWinRows - 1]) {
+    if (W.w0 >= 0 && W.xe[0] < elv && elv < W.xe[kWinRows - 1]) {
         int c = 0;
 #pragma unroll
-        for (int r = 0; r < kWinRows; ++r) c += w[r] <= elv ? 1 : 0;
-        const double xa = w[c - 1], xb = w[c];
-        conv = trdw::linterpol(xa, w[kWinRows + c - 1], xb, w[kWinRows + c], elv);
+        for (int r = 0; r < kWinRows; ++r) c += W.xe[r] <= elv ? 1 : 0;
+        if (c - 1 != W.g) win_fetch_interval(L, W, c - 1); // the look-up moved to another interval of the window
+        double x1 = W.xe[0];
+#pragma unroll
+        for (int r = 1; r < kWinRows - 1; ++r) x1 = W.g == r ? W.xe[r] : x1;
+        const bool deg = (W.tiny >> W.g) & 1;
+        conv = deg ? W.yc : W.qc * (elv - x1) + W.yc;
         if (ALL) {
-            dKdA = trdw::linterpol(xa, w[2 * kWinRows + c - 1], xb, w[2 * kWinRows + c], elv);
-            topw = trdw::linterpol(xa, w[3 * kWinRows + c - 1], xb, w[3 * kWinRows + c], elv);
+            dKdA = deg ? W.yd : W.qd * (elv - x1) + W.yd;
+            topw = deg ? W.yt : W.qt * (elv - x1) + W.yt;
         }
         return;
     }
+    if (L.misses && (threadIdx.x & 63) == 0) ++*L.misses;
     const double *tb = trdw::node_block(p, i, j);
     const int irow = trdw::row_blk(ws, tb, trdw::C_ELEV, elv);
     conv = trdw::at_row(tb, trdw::C_ELEV, trdw::C_CONV, irow, elv);
@@ -399,12 +466,12 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
     ChainLds L;
     L.rec = s_mem;
     L.win = L.rec + (size_t)nnodes * kRecDoubles;
-    L.newY = L.win + (size_t)nnodes * 4 * kWinRows;
+    L.newY = L.win + (size_t)nnodes * kWinDoubles;
     L.w0 = (int32_t *)(L.newY + nnodes);
+    L.misses = it.phase_ticks ? it.phase_ticks + 8 : nullptr;
     __shared__ double s_red[kParThreads / 64];
-    __shared__ double s_elev[2 * kNel]; // the serial prologue's two elevation columns (WaveScan)
     WaveScan ws;
-    ws.lds = s_elev;
+    ws.lds = s_mem; // the serial prologue's two elevation columns, where the records and windows will be (host: >= 8 KB)
     ws.gcol[0] = ws.gcol[1] = nullptr;
     LaneScan ls;
 
@@ -423,23 +490,22 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
     for (int n = tid; n < nnodes; n += kParThreads) {
         const int i = nk[n], j = nj[n];
         const double *tb = node_block(p, i, j);
-        const Bracket be = ls.bracket(tb + C_ELEV * kNel, false, 0.0, kNel, DW_S(p.oldY, i, j));
-        int w0 = be.k - (kWinRows / 2 - 1);
-        w0 = w0 < 0 ? 0 : (w0 > kNel - kWinRows ? kNel - kWinRows : w0);
-        double *w = L.win + (size_t)n * 4 * kWinRows;
-        for (int r = 0; r < kWinRows; ++r) {
-            w[r] = tb[C_ELEV * kNel + w0 + r];
-            w[kWinRows + r] = tb[C_CONV * kNel + w0 + r];
-            w[2 * kWinRows + r] = tb[C_DKDA * kNel + w0 + r];
-            w[3 * kWinRows + r] = tb[C_TOPW * kNel + w0 + r];
-        }
-        L.w0[n] = w0;
+        const int k = LaneScan::count_below<true, false>(tb + C_ELEV * kNel, 0.0, kNel, DW_S(p.oldY, i, j)) - 1;
+        window_load(L, n, tb, k);
     }
     __syncthreads();
 
     double maxCelDx = 1.0 / *it.min_dx;
     int ts_ev = 1;
     double t = t0 * 60.0;
+    unsigned long long *ticks = it.phase_ticks;
+    unsigned long long tk = ticks ? wall_clock64() : 0;
+#define DW_PHASE(k)                                        \
+    if (ticks && tid == 0) {                               \
+        const unsigned long long now_ = wall_clock64();    \
+        ticks[k] += now_ - tk;                             \
+        tk = now_;                                         \
+    }
     while (t < tfin * 60.) {
         // ---- predictor ------------------------------------------------------------------------------------------
         int ql_row = locate(p.tarr_ql, nts_ql + 1, t);
@@ -460,6 +526,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
             }
         }
         __syncthreads();
+        DW_PHASE(0)
         for (int m = tid; m < nmstem; m += kParThreads) { // the recurrences of a reach; new flows of its nodes 2..ncomp
             const int j = p.mstem_frj[m], ncomp = DW_FRNW(j, 1), n0 = rbase[m];
             double allqlat = 0.0;
@@ -491,6 +558,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
             scr[(size_t)n0 * 12 + 9] = allqlat;
         }
         __syncthreads();
+        DW_PHASE(1)
         for (int m = tid; m < nmstem; m += kParThreads) { // junction inflow -> first node of the reach
             const int j = p.mstem_frj[m], n0 = rbase[m];
             double q1 = 0.0;
@@ -515,6 +583,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
             DW_S(p.newQ, 1, j) = qp1;
         }
         __syncthreads();
+        DW_PHASE(2)
         // ---- corrector ------------------------------------------------------------------------------------------
         for (int m = tid; m < nmstem; m += kParThreads) { // water surface at the domain's outlet(s)
             const int j = p.mstem_frj[m], ncomp = DW_FRNW(j, 1), n0 = rbase[m];
@@ -541,19 +610,26 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
             }
         }
         __syncthreads();
+        DW_PHASE(3)
         if (tid < 64) { // the chain: one wavefront, outlet first
             for (int jm = nmstem; jm >= 1; --jm) {
                 const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1), n0 = rbase[jm - 1];
                 if (DW_FRNW(j, 2) >= 0) L.newY[n0 + ncomp - 1] = L.newY[rbase[m_of_reach[DW_FRNW(j, 2) - 1]]];
+                WinRegs Wd = win_fetch(L, n0 + ncomp - 1);
+                WinRegs Wc = win_fetch(L, n0 + ncomp - 2);
+                double y_below = L.newY[n0 + ncomp - 1];
                 for (int i = ncomp; i >= 2; --i) {
                     const int nd = n0 + i - 1, nc = nd - 1;
+                    // the node after this one: its window and record are on their way while this node is solved
+                    const int nn = nc >= 1 ? nc - 1 : 0;
+                    const WinRegs Wn = win_fetch(L, nn);
                     const double *rd = L.rec + (size_t)nd * kRecDoubles, *rc = L.rec + (size_t)nc * kRecDoubles;
                     const double zz = rd[9], Q_ds = rd[10];
-                    double y_ds = L.newY[nd] - zz;
+                    double y_ds = y_below - zz;
                     y_ds = dmax(y_ds, (double)0.005f);
                     const double elv_ds = y_ds + zz;
                     double conv_ds, u0, u1;
-                    chain_lookup<false>(p, L, ws, nd, i, j, elv_ds, conv_ds, u0, u1);
+                    chain_lookup<false>(p, L, ws, Wd, i, j, elv_ds, conv_ds, u0, u1);
                     const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
                     DepthPre d;
                     d.y_norm = rc[0]; d.x1 = rc[1]; d.x2 = rc[2]; d.sf[0] = rc[3]; d.sf[1] = rc[4]; d.sf[2] = rc[5];
@@ -561,16 +637,20 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
                     const double Q_cur = rc[10], z_cur = rc[9];
                     const double y_cur = depth_solve(d, sf_ds, y_ds, [&](double yc) {
                         double conv, dKdA, topw;
-                        chain_lookup<true>(p, L, ws, nc, i - 1, j, yc + z_cur, conv, dKdA, topw);
+                        chain_lookup<true>(p, L, ws, Wc, i - 1, j, yc + z_cur, conv, dKdA, topw);
                         return funcd_arith(Q_cur, sf_ds, conv, dKdA, topw, d.slope, d.dxi, yc, y_ds);
                     });
                     double ny = y_cur + z_cur;
                     if (ny > 100000.0) ny = 100000.0;
                     L.newY[nc] = ny;
+                    y_below = ny;
+                    Wd = Wc;
+                    Wc = Wn;
                 }
             }
         }
         __syncthreads();
+        DW_PHASE(4)
         for (int n = tid; n < nnodes; n += kParThreads) { // the node's own new state, its window for the next sub-step
             const int i = nk[n], j = nj[n];
             const double xt = L.newY[n];
@@ -581,21 +661,11 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
             q[11] = np.diffusivity2;
             const double *tb = node_block(p, i, j);
             const int k = LaneScan::count_below<true, false>(tb + C_ELEV * kNel, 0.0, kNel, xt) - 1; // interval of xt
-            const int w0_old = L.w0[n];
-            if (w0_old < 0 || k < w0_old + 1 || k > w0_old + kWinRows - 3) {
-                int w0 = k - (kWinRows / 2 - 1);
-                w0 = w0 < 0 ? 0 : (w0 > kNel - kWinRows ? kNel - kWinRows : w0);
-                double *w = L.win + (size_t)n * 4 * kWinRows;
-                for (int r = 0; r < kWinRows; ++r) {
-                    w[r] = tb[C_ELEV * kNel + w0 + r];
-                    w[kWinRows + r] = tb[C_CONV * kNel + w0 + r];
-                    w[2 * kWinRows + r] = tb[C_DKDA * kNel + w0 + r];
-                    w[3 * kWinRows + r] = tb[C_TOPW * kNel + w0 + r];
-                }
-                L.w0[n] = w0;
-            }
+            const int w0_old = L.w0[2 * n];
+            if (w0_old < 0 || k < w0_old + 1 || k > w0_old + kWinRows - 3) window_load(L, n, tb, k);
         }
         __syncthreads();
+        DW_PHASE(5)
         double my_max = 0.;
         for (int m = tid; m < nmstem; m += kParThreads) { // reach means of celerity and diffusivity
             const int j = p.mstem_frj[m], ncomp = DW_FRNW(j, 1), n0 = rbase[m];
@@ -657,7 +727,9 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
         __syncthreads();
         { double *sw = p.oldY; p.oldY = p.newY; p.newY = sw; }
         { double *sw = p.oldQ; p.oldQ = p.newQ; p.newQ = sw; }
+        DW_PHASE(6)
     }
+#undef DW_PHASE
 }
 
 // host side of one domain: device copies of its inputs, its work space, its node list
@@ -776,8 +848,9 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
     if (dom.up(m_of.data(), m_of.size() * sizeof(int32_t), (void **)&dom.d_mof, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     if (dom.up(nullptr, (size_t)dom.nnodes * 12 * sizeof(double), (void **)&dom.d_scratch, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     {
-        const size_t need = (size_t)dom.nnodes * ((kRecDoubles + 4 * kWinRows + 1) * sizeof(double) + sizeof(int32_t));
-        dom.par_lds = need + 2 * trdw::kNel * sizeof(double) + 1024 <= 160 * 1024 ? need : 0;
+        size_t need = (size_t)dom.nnodes * ((kRecDoubles + kWinDoubles + 1) * sizeof(double) + 2 * sizeof(int32_t));
+        need = need < 2 * trdw::kNel * sizeof(double) ? 2 * trdw::kNel * sizeof(double) : need; // (the prologue's two columns)
+        dom.par_lds = need + 1024 <= 160 * 1024 ? need : 0;
     }
     DW_TRY(hipStreamSynchronize(st)); // node_k / node_j are about to go out of scope
     DW_TRY(hipMemsetAsync(dom.d_out, 0, 3 * dom.nout * sizeof(double), st));
@@ -809,7 +882,7 @@ int run_batch(const trdw_args *args, int n)
     struct Run {
         hipStream_t st = nullptr;
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-        void *d_items = nullptr, *d_pitems = nullptr;
+        void *d_items = nullptr, *d_pitems = nullptr, *d_ticks = nullptr;
         std::vector<Domain> doms;
         ~Run()
         {
@@ -817,6 +890,7 @@ int run_batch(const trdw_args *args, int n)
             doms.clear();
             if (d_items) (void)hipFree(d_items);
             if (d_pitems) (void)hipFree(d_pitems);
+            if (d_ticks) (void)hipFree(d_ticks);
             for (auto &e : ev)
                 if (e) (void)hipEventDestroy(e);
             if (st) (void)hipStreamDestroy(st);
@@ -874,6 +948,12 @@ int run_batch(const trdw_args *args, int n)
             pitems[b].m_of_reach = dm.d_mof;
             pitems[b].scratch = dm.d_scratch;
             pitems[b].nnodes = dm.nnodes;
+            pitems[b].phase_ticks = nullptr;
+        }
+        if (std::getenv("TRDW_PHASES")) {
+            DW_TRY(hipMalloc(&run.d_ticks, 16 * sizeof(unsigned long long)));
+            DW_TRY(hipMemsetAsync(run.d_ticks, 0, 16 * sizeof(unsigned long long), st));
+            pitems[0].phase_ticks = (unsigned long long *)run.d_ticks;
         }
         DW_TRY(hipMalloc(&run.d_pitems, (size_t)n * sizeof(ParItem)));
         DW_TRY(hipMemcpyAsync(run.d_pitems, pitems.data(), (size_t)n * sizeof(ParItem), hipMemcpyHostToDevice, st));
@@ -899,6 +979,13 @@ int run_batch(const trdw_args *args, int n)
     DW_TRY(hipEventElapsedTime(&t12, run.ev[1], run.ev[2]));
     g_dw_tables_ms = t01;
     g_dw_solve_ms = t12;
+    if (run.d_ticks) {
+        unsigned long long tk[16];
+        DW_TRY(hipMemcpy(tk, run.d_ticks, sizeof tk, hipMemcpyDeviceToHost));
+        static const char *name[7] = {"coefficients", "recurrences", "junctions", "depth_pre", "chain", "node_post", "means+output"};
+        for (int k = 0; k < 7; ++k) std::fprintf(stderr, "[trdw phases] %-14s %9.3f ms\n", name[k], tk[k] * 1e-5);
+        std::fprintf(stderr, "[trdw phases] chain look-ups outside the window: %llu\n", tk[8]);
+    }
     return 0;
 }
 
