@@ -286,9 +286,14 @@ __global__ void __launch_bounds__(64) k_dw_solve(const BatchItem *items)
 //     the refresh of its window -- one thread per node; reach means -- one thread per reach.
 // The arithmetic of every piece is the function the serial solver calls (diffusive_core.hpp), so the bits are the same.
 constexpr int kParThreads = 512;
-constexpr int kWinRows = 5;                       // table rows of a window: 4 intervals
-constexpr int kWinDoubles = kWinRows + 3 * 2 * (kWinRows - 1); // elevations; per interval and column {ordinate, slope}
-constexpr int kRecDoubles = 12;
+// table rows of a window (WR, a template parameter of the kernel: the host takes the widest of 7 / 6 / 5 whose chain state
+// fits LDS); doubles of a window: the row elevations, then per column and interval {ordinate, quotient}
+constexpr int win_doubles(int wr) { return wr + 3 * 2 * (wr - 1); }
+constexpr int kRecDoubles = 12;                   // (the last one is the node's new water surface)
+constexpr size_t par_lds_bytes(int nnodes, int wr)
+{
+    return (size_t)nnodes * ((kRecDoubles + win_doubles(wr)) * sizeof(double) + 2 * sizeof(int32_t));
+}
 
 // one thread, its own searches (bisection on an ascending column), tables in global memory
 struct LaneScan {
@@ -351,30 +356,30 @@ struct ParItem {
 // the chain's view of a node: record + window in LDS
 struct ChainLds {
     double *rec;    // [nnodes][kRecDoubles]: 0 y_norm 1 x1 2 x2 3..5 sf 6 df_mid 7 slope 8 dxi 9 z 10 Q 11 -
-    double *win;    // [nnodes][kWinDoubles]: elevations of the rows, then per column (conveyance, dK/dA, top width) and
+    double *win;    // [nnodes][win_doubles(WR)]: elevations of the rows, then per column (conveyance, dK/dA, top width) and
                     // interval {ordinate at its lower row, (y2 - y1) / (x2 - x1)} -- linterpol's quotient, formed ahead
     int32_t *w0;    // [nnodes][2]: first table row of the window (0-based; -1: none); interval of the last look-up |
                     // (intervals narrower than linterpol's 1e-4 as a bit mask) << 8
-    double *newY;   // [nnodes]
+    __device__ double &newY(int n) const { return rec[(size_t)n * kRecDoubles + 11]; }
     unsigned long long *misses; // developer aid: look-ups that left the window
 };
 
 // (re)load the window of node n so that interval k of its table sits in the middle
-__device__ __forceinline__ void window_load(const ChainLds &L, int n, const double *tb, int k)
+template <int WR> __device__ __forceinline__ void window_load(const ChainLds &L, int n, const double *tb, int k)
 {
-    int w0 = k - (kWinRows - 1) / 2 + ((kWinRows - 1) % 2 == 0 ? 1 : 0);
-    w0 = w0 < 0 ? 0 : (w0 > trdw::kNel - kWinRows ? trdw::kNel - kWinRows : w0);
-    double *w = L.win + (size_t)n * kWinDoubles;
+    int w0 = k - (WR - 1) / 2 + ((WR - 1) % 2 == 0 ? 1 : 0);
+    w0 = w0 < 0 ? 0 : (w0 > trdw::kNel - WR ? trdw::kNel - WR : w0);
+    double *w = L.win + (size_t)n * win_doubles(WR);
     const double *xe = tb + trdw::C_ELEV * trdw::kNel + w0;
-    for (int r = 0; r < kWinRows; ++r) w[r] = xe[r];
+    for (int r = 0; r < WR; ++r) w[r] = xe[r];
     int tiny = 0;
-    for (int r = 0; r < kWinRows - 1; ++r)
+    for (int r = 0; r < WR - 1; ++r)
         if (fabs(xe[r + 1] - xe[r]) < (double)0.0001f) tiny |= 1 << r;
     const int cols[3] = {trdw::C_CONV, trdw::C_DKDA, trdw::C_TOPW};
     for (int c = 0; c < 3; ++c) {
         const double *y = tb + cols[c] * trdw::kNel + w0;
-        double *o = w + kWinRows + c * 2 * (kWinRows - 1);
-        for (int r = 0; r < kWinRows - 1; ++r) {
+        double *o = w + WR + c * 2 * (WR - 1);
+        for (int r = 0; r < WR - 1; ++r) {
             // linterpol: (y2 - y1) / (x2 - x1) * (x - x1) + y1, or the mean of the ordinates on a degenerate interval
             const bool deg = (tiny >> r) & 1;
             o[2 * r] = deg ? 0.5 * (y[r] + y[r + 1]) : y[r];
@@ -383,53 +388,61 @@ __device__ __forceinline__ void window_load(const ChainLds &L, int n, const doub
     }
     L.w0[2 * n] = w0;
     int g = k - w0;
-    g = g < 0 ? 0 : (g > kWinRows - 2 ? kWinRows - 2 : g);
+    g = g < 0 ? 0 : (g > WR - 2 ? WR - 2 : g);
     L.w0[2 * n + 1] = g | (tiny << 8);
 }
 // A node's window as the chain holds it in registers: the row elevations and the interval of the last look-up (the
 // guess); the other intervals stay in LDS.  The chain fetches a node's window while it is still solving the node before,
 // so a look-up that falls into the guessed interval -- nearly all do: the iterates of one node lie within centimetres of
 // each other -- costs compares, selects and a multiply-add, no memory access.
-struct WinRegs {
+template <int WR> struct WinRegs {
     int n, w0, g, tiny;
-    double xe[kWinRows];
+    double xe[WR];
+    double xa, xb;           // the guessed interval [xa, xb)
     double yc, qc, yd, qd, yt, qt;
 };
-__device__ __forceinline__ void win_fetch_interval(const ChainLds &L, WinRegs &W, int g)
+template <int WR> __device__ __forceinline__ void win_fetch_interval(const ChainLds &L, WinRegs<WR> &W, int g)
 {
-    const double *oc = L.win + (size_t)W.n * kWinDoubles + kWinRows;
+    const double *oc = L.win + (size_t)W.n * win_doubles(WR) + WR;
     W.g = g;
+    W.xa = W.xe[0];
+    W.xb = W.xe[1];
+#pragma unroll
+    for (int r = 1; r < WR - 1; ++r) {
+        W.xa = g == r ? W.xe[r] : W.xa;
+        W.xb = g == r ? W.xe[r + 1] : W.xb;
+    }
     W.yc = oc[2 * g]; W.qc = oc[2 * g + 1];
-    W.yd = oc[2 * (kWinRows - 1) + 2 * g]; W.qd = oc[2 * (kWinRows - 1) + 2 * g + 1];
-    W.yt = oc[4 * (kWinRows - 1) + 2 * g]; W.qt = oc[4 * (kWinRows - 1) + 2 * g + 1];
+    W.yd = oc[2 * (WR - 1) + 2 * g]; W.qd = oc[2 * (WR - 1) + 2 * g + 1];
+    W.yt = oc[4 * (WR - 1) + 2 * g]; W.qt = oc[4 * (WR - 1) + 2 * g + 1];
 }
-__device__ __forceinline__ WinRegs win_fetch(const ChainLds &L, int n)
+template <int WR> __device__ __forceinline__ WinRegs<WR> win_fetch(const ChainLds &L, int n)
 {
-    WinRegs W;
+    WinRegs<WR> W;
     W.n = n;
-    const double *w = L.win + (size_t)n * kWinDoubles;
+    const double *w = L.win + (size_t)n * win_doubles(WR);
     W.w0 = L.w0[2 * n];
     const int meta = L.w0[2 * n + 1];
     W.tiny = meta >> 8;
 #pragma unroll
-    for (int r = 0; r < kWinRows; ++r) W.xe[r] = w[r];
-    win_fetch_interval(L, W, meta & 0xff);
+    for (int r = 0; r < WR; ++r) W.xe[r] = w[r];
+    win_fetch_interval<WR>(L, W, meta & 0xff);
     return W;
 }
 // conveyance (and optionally dK/dA, top width) of the window's node (i, j) at water elevation elv; an elevation outside the
 // window takes the wavefront's search over the node's table in global memory
-template <bool ALL>
-__device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const ChainLds &L, const WaveScan &ws, WinRegs &W, int i, int j, double elv,
+template <bool ALL, int WR>
+__device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const ChainLds &L, const WaveScan &ws, WinRegs<WR> &W, int i, int j, double elv,
                                              double &conv, double &dKdA, double &topw)
 {
-    if (W.w0 >= 0 && W.xe[0] < elv && elv < W.xe[kWinRows - 1]) {
-        int c = 0;
+    if (W.w0 >= 0 && W.xe[0] < elv && elv < W.xe[WR - 1]) {
+        if (!(W.xa <= elv && elv < W.xb)) { // the look-up moved to another interval of the window
+            int c = 0;
 #pragma unroll
-        for (int r = 0; r < kWinRows; ++r) c += W.xe[r] <= elv ? 1 : 0;
-        if (c - 1 != W.g) win_fetch_interval(L, W, c - 1); // the look-up moved to another interval of the window
-        double x1 = W.xe[0];
-#pragma unroll
-        for (int r = 1; r < kWinRows - 1; ++r) x1 = W.g == r ? W.xe[r] : x1;
+            for (int r = 0; r < WR; ++r) c += W.xe[r] <= elv ? 1 : 0;
+            win_fetch_interval<WR>(L, W, c - 1);
+        }
+        const double x1 = W.xa;
         const bool deg = (W.tiny >> W.g) & 1;
         conv = deg ? W.yc : W.qc * (elv - x1) + W.yc;
         if (ALL) {
@@ -448,7 +461,7 @@ __device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const Chain
     }
 }
 
-__global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *items)
+template <int WR> __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *items)
 {
     using namespace trdw;
     typedef LaneScan Scan; // (DW_S / DW_L: the sweep state stays in global memory; flat pointers)
@@ -466,8 +479,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
     ChainLds L;
     L.rec = s_mem;
     L.win = L.rec + (size_t)nnodes * kRecDoubles;
-    L.newY = L.win + (size_t)nnodes * kWinDoubles;
-    L.w0 = (int32_t *)(L.newY + nnodes);
+    L.w0 = (int32_t *)(L.win + (size_t)nnodes * win_doubles(WR));
     L.misses = it.phase_ticks ? it.phase_ticks + 8 : nullptr;
     __shared__ double s_red[kParThreads / 64];
     WaveScan ws;
@@ -491,7 +503,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
         const int i = nk[n], j = nj[n];
         const double *tb = node_block(p, i, j);
         const int k = LaneScan::count_below<true, false>(tb + C_ELEV * kNel, 0.0, kNel, DW_S(p.oldY, i, j)) - 1;
-        window_load(L, n, tb, k);
+        window_load<WR>(L, n, tb, k);
     }
     __syncthreads();
 
@@ -595,7 +607,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
             } else if (p.dsbc_option == 2) {
                 y = intp_tab(p, ncomp, j, C_UNIF, C_ELEV, fabs(DW_S(p.newQ, ncomp, j)));
             }
-            L.newY[n0 + ncomp - 1] = y;
+            L.newY(n0 + ncomp - 1) = y;
         }
         for (int n = tid; n < nnodes; n += kParThreads) { // what the depth solve of a node needs besides the node below
             const int i = nk[n], j = nj[n], ncomp = DW_FRNW(j, 1);
@@ -614,35 +626,37 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
         if (tid < 64) { // the chain: one wavefront, outlet first
             for (int jm = nmstem; jm >= 1; --jm) {
                 const int j = p.mstem_frj[jm - 1], ncomp = DW_FRNW(j, 1), n0 = rbase[jm - 1];
-                if (DW_FRNW(j, 2) >= 0) L.newY[n0 + ncomp - 1] = L.newY[rbase[m_of_reach[DW_FRNW(j, 2) - 1]]];
-                WinRegs Wd = win_fetch(L, n0 + ncomp - 1);
-                WinRegs Wc = win_fetch(L, n0 + ncomp - 2);
-                double y_below = L.newY[n0 + ncomp - 1];
+                if (DW_FRNW(j, 2) >= 0) L.newY(n0 + ncomp - 1) = L.newY(rbase[m_of_reach[DW_FRNW(j, 2) - 1]]);
+                WinRegs<WR> Wd = win_fetch<WR>(L, n0 + ncomp - 1);
+                WinRegs<WR> Wc = win_fetch<WR>(L, n0 + ncomp - 2);
+                double y_below = L.newY(n0 + ncomp - 1);
                 for (int i = ncomp; i >= 2; --i) {
                     const int nd = n0 + i - 1, nc = nd - 1;
                     // the node after this one: its window and record are on their way while this node is solved
                     const int nn = nc >= 1 ? nc - 1 : 0;
-                    const WinRegs Wn = win_fetch(L, nn);
+                    const WinRegs<WR> Wn = win_fetch<WR>(L, nn);
                     const double *rd = L.rec + (size_t)nd * kRecDoubles, *rc = L.rec + (size_t)nc * kRecDoubles;
                     const double zz = rd[9], Q_ds = rd[10];
                     double y_ds = y_below - zz;
                     y_ds = dmax(y_ds, (double)0.005f);
                     const double elv_ds = y_ds + zz;
                     double conv_ds, u0, u1;
-                    chain_lookup<false>(p, L, ws, Wd, i, j, elv_ds, conv_ds, u0, u1);
+                    chain_lookup<false, WR>(p, L, ws, Wd, i, j, elv_ds, conv_ds, u0, u1);
                     const double sf_ds = fabs(Q_ds) * Q_ds / (conv_ds * conv_ds);
                     DepthPre d;
                     d.y_norm = rc[0]; d.x1 = rc[1]; d.x2 = rc[2]; d.sf[0] = rc[3]; d.sf[1] = rc[4]; d.sf[2] = rc[5];
                     d.df_mid = rc[6]; d.slope = rc[7]; d.dxi = rc[8]; d.z_cur = rc[9];
                     const double Q_cur = rc[10], z_cur = rc[9];
+                    if (L.misses && tid == 0) ++L.misses[2];
                     const double y_cur = depth_solve(d, sf_ds, y_ds, [&](double yc) {
                         double conv, dKdA, topw;
-                        chain_lookup<true>(p, L, ws, Wc, i - 1, j, yc + z_cur, conv, dKdA, topw);
+                        if (L.misses && tid == 0) ++L.misses[1];
+                        chain_lookup<true, WR>(p, L, ws, Wc, i - 1, j, yc + z_cur, conv, dKdA, topw);
                         return funcd_arith(Q_cur, sf_ds, conv, dKdA, topw, d.slope, d.dxi, yc, y_ds);
                     });
                     double ny = y_cur + z_cur;
                     if (ny > 100000.0) ny = 100000.0;
-                    L.newY[nc] = ny;
+                    L.newY(nc) = ny;
                     y_below = ny;
                     Wd = Wc;
                     Wc = Wn;
@@ -653,7 +667,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
         DW_PHASE(4)
         for (int n = tid; n < nnodes; n += kParThreads) { // the node's own new state, its window for the next sub-step
             const int i = nk[n], j = nj[n];
-            const double xt = L.newY[n];
+            const double xt = L.newY(n);
             DW_S(p.newY, i, j) = xt;
             const NodePost np = backward_node_post(p, i, j, ls);
             double *q = scr + (size_t)n * 12;
@@ -662,7 +676,7 @@ __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *ite
             const double *tb = node_block(p, i, j);
             const int k = LaneScan::count_below<true, false>(tb + C_ELEV * kNel, 0.0, kNel, xt) - 1; // interval of xt
             const int w0_old = L.w0[2 * n];
-            if (w0_old < 0 || k < w0_old + 1 || k > w0_old + kWinRows - 3) window_load(L, n, tb, k);
+            if (w0_old < 0 || k < w0_old + 1 || k > w0_old + WR - 3) window_load<WR>(L, n, tb, k);
         }
         __syncthreads();
         DW_PHASE(5)
@@ -739,7 +753,7 @@ struct Domain {
     double *d_out = nullptr, *d_min = nullptr;
     int32_t *d_nk = nullptr, *d_nj = nullptr, *d_rbase = nullptr, *d_mof = nullptr;
     double *d_scratch = nullptr;
-    size_t par_lds = 0;       // dynamic LDS of the parallel time loop (0: does not fit, serial kernel)
+    int par_rows = 0;         // window rows of the parallel time loop (0: its chain state does not fit LDS, serial kernel)
     int nnodes = 0;
     size_t nout = 0;
     int64_t lds_state = 0;
@@ -848,9 +862,10 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
     if (dom.up(m_of.data(), m_of.size() * sizeof(int32_t), (void **)&dom.d_mof, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     if (dom.up(nullptr, (size_t)dom.nnodes * 12 * sizeof(double), (void **)&dom.d_scratch, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     {
-        size_t need = (size_t)dom.nnodes * ((kRecDoubles + kWinDoubles + 1) * sizeof(double) + 2 * sizeof(int32_t));
-        need = need < 2 * trdw::kNel * sizeof(double) ? 2 * trdw::kNel * sizeof(double) : need; // (the prologue's two columns)
-        dom.par_lds = need + 1024 <= 160 * 1024 ? need : 0;
+        // widest window whose chain state fits beside the kernel's static LDS (and the prologue's two columns)
+        dom.par_rows = 0;
+        for (int wr = 7; wr >= 5 && !dom.par_rows; --wr)
+            if (par_lds_bytes(dom.nnodes, wr) + 1024 <= 160 * 1024) dom.par_rows = wr;
     }
     DW_TRY(hipStreamSynchronize(st)); // node_k / node_j are about to go out of scope
     DW_TRY(hipMemsetAsync(dom.d_out, 0, 3 * dom.nout * sizeof(double), st));
@@ -931,10 +946,15 @@ int run_batch(const trdw_args *args, int n)
     // the parallel time loop when every domain's chain state fits LDS (TRDW_SOLVER=serial: the one-wavefront kernel)
     const char *solver = std::getenv("TRDW_SOLVER");
     bool par = !(solver && std::string(solver) == "serial");
-    size_t par_lds = 0;
+    int par_rows = 7, nn_max = 0;
     for (int b = 0; b < n; ++b) {
-        par = par && run.doms[b].par_lds > 0;
-        par_lds = par_lds > run.doms[b].par_lds ? par_lds : run.doms[b].par_lds;
+        par_rows = par_rows < run.doms[b].par_rows ? par_rows : run.doms[b].par_rows;
+        nn_max = nn_max > run.doms[b].nnodes ? nn_max : run.doms[b].nnodes;
+    }
+    par = par && par_rows >= 5;
+    if (const char *e = std::getenv("TRDW_WINDOW_ROWS")) { // developer A/B
+        const int wr = std::atoi(e);
+        if (wr >= 5 && wr <= par_rows) par_rows = wr;
     }
     if (par) {
         std::vector<ParItem> pitems((size_t)n);
@@ -958,8 +978,17 @@ int run_batch(const trdw_args *args, int n)
         DW_TRY(hipMalloc(&run.d_pitems, (size_t)n * sizeof(ParItem)));
         DW_TRY(hipMemcpyAsync(run.d_pitems, pitems.data(), (size_t)n * sizeof(ParItem), hipMemcpyHostToDevice, st));
         DW_TRY(hipStreamSynchronize(st)); // pitems is about to go out of scope
-        DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve_par), hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds));
-        hipLaunchKernelGGL(k_dw_solve_par, dim3(n), dim3(kParThreads), par_lds, st, (const ParItem *)run.d_pitems);
+        size_t par_lds = par_lds_bytes(nn_max, par_rows);
+        par_lds = par_lds < 2 * trdw::kNel * sizeof(double) ? 2 * trdw::kNel * sizeof(double) : par_lds; // (the prologue's two columns)
+        auto launch = [&](auto kernel) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kernel, dim3(n), dim3(kParThreads), par_lds, st, (const ParItem *)run.d_pitems);
+            return hipSuccess;
+        };
+        if (par_rows == 7) DW_TRY(launch(k_dw_solve_par<7>));
+        else if (par_rows == 6) DW_TRY(launch(k_dw_solve_par<6>));
+        else DW_TRY(launch(k_dw_solve_par<5>));
     } else {
         if (lds_max > 64 * 1024)
             DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -984,7 +1013,8 @@ int run_batch(const trdw_args *args, int n)
         DW_TRY(hipMemcpy(tk, run.d_ticks, sizeof tk, hipMemcpyDeviceToHost));
         static const char *name[7] = {"coefficients", "recurrences", "junctions", "depth_pre", "chain", "node_post", "means+output"};
         for (int k = 0; k < 7; ++k) std::fprintf(stderr, "[trdw phases] %-14s %9.3f ms\n", name[k], tk[k] * 1e-5);
-        std::fprintf(stderr, "[trdw phases] chain look-ups outside the window: %llu\n", tk[8]);
+        std::fprintf(stderr, "[trdw phases] chain: %llu depth solves, %llu function evaluations inside them, %llu look-ups outside the window\n",
+                     tk[10], tk[9], tk[8]);
     }
     return 0;
 }
