@@ -349,6 +349,7 @@ struct ParItem {
     const int32_t *rbase;        // [nmstem + 1] first node of the m-th mainstem reach
     const int32_t *m_of_reach;   // [nrch] reach j (1-based) -> m, -1 for tributaries
     double *scratch;             // [nnodes][12]: forward coefficients, recurrence lines, node contributions
+    double *chain_state;         // records and windows of the chain in global memory, for a domain too long for LDS
     unsigned long long *phase_ticks; // developer aid (TRDW_PHASES=1): [8] wall-clock ticks per phase, [8] window misses
     int nnodes;
 };
@@ -461,7 +462,7 @@ __device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const Chain
     }
 }
 
-template <int WR> __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *items)
+template <int WR, bool IN_LDS> __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(const ParItem *items)
 {
     using namespace trdw;
     typedef LaneScan Scan; // (DW_S / DW_L: the sweep state stays in global memory; flat pointers)
@@ -477,7 +478,7 @@ template <int WR> __global__ void __launch_bounds__(kParThreads) k_dw_solve_par(
     double *scr = it.scratch;
     HIP_DYNAMIC_SHARED(double, s_mem)
     ChainLds L;
-    L.rec = s_mem;
+    L.rec = IN_LDS ? s_mem : it.chain_state;
     L.win = L.rec + (size_t)nnodes * kRecDoubles;
     L.w0 = (int32_t *)(L.win + (size_t)nnodes * win_doubles(WR));
     L.misses = it.phase_ticks ? it.phase_ticks + 8 : nullptr;
@@ -752,7 +753,7 @@ struct Domain {
     trdw::Problem p;
     double *d_out = nullptr, *d_min = nullptr;
     int32_t *d_nk = nullptr, *d_nj = nullptr, *d_rbase = nullptr, *d_mof = nullptr;
-    double *d_scratch = nullptr;
+    double *d_scratch = nullptr, *d_chain = nullptr;
     int par_rows = 0;         // window rows of the parallel time loop (0: its chain state does not fit LDS, serial kernel)
     int nnodes = 0;
     size_t nout = 0;
@@ -866,6 +867,8 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
         dom.par_rows = 0;
         for (int wr = 7; wr >= 5 && !dom.par_rows; --wr)
             if (par_lds_bytes(dom.nnodes, wr) + 1024 <= 160 * 1024) dom.par_rows = wr;
+        // a longer mainstem keeps the same state in global memory (windows and records are fetched a node ahead)
+        if (dom.up(nullptr, par_lds_bytes(dom.nnodes, 7), (void **)&dom.d_chain, st)) return dw_fail(TRDW_ENOMEM, "device allocation failed");
     }
     DW_TRY(hipStreamSynchronize(st)); // node_k / node_j are about to go out of scope
     DW_TRY(hipMemsetAsync(dom.d_out, 0, 3 * dom.nout * sizeof(double), st));
@@ -951,7 +954,7 @@ int run_batch(const trdw_args *args, int n)
         par_rows = par_rows < run.doms[b].par_rows ? par_rows : run.doms[b].par_rows;
         nn_max = nn_max > run.doms[b].nnodes ? nn_max : run.doms[b].nnodes;
     }
-    par = par && par_rows >= 5;
+    if (std::getenv("TRDW_CHAIN_GLOBAL")) par_rows = 0; // developer A/B: chain state in global memory
     if (const char *e = std::getenv("TRDW_WINDOW_ROWS")) { // developer A/B
         const int wr = std::atoi(e);
         if (wr >= 5 && wr <= par_rows) par_rows = wr;
@@ -967,6 +970,7 @@ int run_batch(const trdw_args *args, int n)
             pitems[b].rbase = dm.d_rbase;
             pitems[b].m_of_reach = dm.d_mof;
             pitems[b].scratch = dm.d_scratch;
+            pitems[b].chain_state = dm.d_chain;
             pitems[b].nnodes = dm.nnodes;
             pitems[b].phase_ticks = nullptr;
         }
@@ -978,7 +982,7 @@ int run_batch(const trdw_args *args, int n)
         DW_TRY(hipMalloc(&run.d_pitems, (size_t)n * sizeof(ParItem)));
         DW_TRY(hipMemcpyAsync(run.d_pitems, pitems.data(), (size_t)n * sizeof(ParItem), hipMemcpyHostToDevice, st));
         DW_TRY(hipStreamSynchronize(st)); // pitems is about to go out of scope
-        size_t par_lds = par_lds_bytes(nn_max, par_rows);
+        size_t par_lds = par_rows >= 5 ? par_lds_bytes(nn_max, par_rows) : 0;
         par_lds = par_lds < 2 * trdw::kNel * sizeof(double) ? 2 * trdw::kNel * sizeof(double) : par_lds; // (the prologue's two columns)
         auto launch = [&](auto kernel) -> hipError_t {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds);
@@ -986,9 +990,10 @@ int run_batch(const trdw_args *args, int n)
             hipLaunchKernelGGL(kernel, dim3(n), dim3(kParThreads), par_lds, st, (const ParItem *)run.d_pitems);
             return hipSuccess;
         };
-        if (par_rows == 7) DW_TRY(launch(k_dw_solve_par<7>));
-        else if (par_rows == 6) DW_TRY(launch(k_dw_solve_par<6>));
-        else DW_TRY(launch(k_dw_solve_par<5>));
+        if (par_rows == 7) DW_TRY(launch(k_dw_solve_par<7, true>));
+        else if (par_rows == 6) DW_TRY(launch(k_dw_solve_par<6, true>));
+        else if (par_rows == 5) DW_TRY(launch(k_dw_solve_par<5, true>));
+        else DW_TRY(launch(k_dw_solve_par<7, false>));
     } else {
         if (lds_max > 64 * 1024)
             DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));

@@ -304,6 +304,23 @@ def test_gpu_equals_reference_fortran_bitwise_lowercolorado():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"TRDW_SOLVER": "serial"}, {"TRDW_CHAIN_GLOBAL": "1"}, {"TRDW_WINDOW_ROWS": "5"}],
+                         ids=["one-wavefront kernel", "chain state in global memory", "5-row windows"])
+def test_gpu_solver_variants_give_the_same_bits(env, monkeypatch):
+    """The parallel time loop's other forms -- the serial kernel it replaced, the chain state in global memory (domains
+    too long for LDS), narrow windows (look-ups that leave the window take the full-column search) -- on the
+    LowerColorado golden and a small natural-section case: bit for bit the reference Fortran."""
+    from troute_amd.routing.fast_reach import diffusive as D
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ins, want = load_lowercolorado(6)
+    check_window(D.compute_diffusive(ins), want)
+    ins, want = load_small("comb_nat")
+    for g, w in zip(D.compute_diffusive(ins), want):
+        assert same_bits(g, w)
+
+
+@pytest.mark.gpu
 def test_gpu_equals_reference_fortran_bitwise_natural_sections_and_coastal_depth():
     from troute_amd.routing.fast_reach import diffusive as D
     ins, want = load_lowercolorado(12, "diffusive_lowercolorado_nat.npz")
