@@ -12,10 +12,11 @@
  * (Fortran order) in double / int32 -- a Fortran or Cython caller can bind it in place of c_diffnw.  The only
  * additions are the int return value (0, or a negative status with the text in trdw_last_error()) and
  * trdw_select_device().  One call = one tailwater domain: the cross-section tables are built by one thread per
- * (node, water level); the ordered time loop runs in one wavefront whose lanes share every table scan.
+ * (node, water level); the ordered time loop runs in one workgroup per domain -- per-node and per-reach phases on 512
+ * threads, the depth-solve chain from node to node on one wavefront.
  * Covered: synthetic (RouteLink) and natural (bathymetry, mxnbathy_g > 0) cross sections, both
- * downstream-boundary options.  Refused with TRDW_EUNSUPPORTED: the refactored-hydrofabric crosswalk
- * (cwnrow_g > 0).  No CPU fallback: without a HIP device the call fails with TRDW_ENODEVICE.
+ * downstream-boundary options, and the mapping of results from a refactored hydrofabric back to the original one
+ * (cwnrow_g > 0, diffusive.f90:849-920).  No CPU fallback: without a HIP device the call fails with TRDW_ENODEVICE.
  */
 #ifndef TRDW_H
 #define TRDW_H

@@ -19,11 +19,10 @@ extern "C" int dw_oracle_diffnw(
     const double *rdx_ar_g, const int *cwnrow_g, const int *cwncol_g, const double *crosswalk_g, const double *z_thalweg_g,
     double *q_ev_g, double *elv_ev_g, double *depth_ev_g)
 {
-    (void)nts_da_g; (void)so_ar_g; (void)ubcd_g; (void)paradim; (void)usgs_da_g; (void)usgs_da_reach_g; (void)rdx_ar_g; (void)cwncol_g; (void)crosswalk_g;
-    (void)z_thalweg_g;
-    if (*cwnrow_g != 0) return -1; // crosswalk: not covered
+    (void)nts_da_g; (void)so_ar_g; (void)ubcd_g; (void)paradim; (void)usgs_da_g; (void)usgs_da_reach_g;
     trdw::Problem p;
     memset(&p, 0, sizeof p);
+    p.rdx_ar = rdx_ar_g; p.crosswalk = crosswalk_g; p.z_thalweg = z_thalweg_g; p.cwnrow = *cwnrow_g; p.cwncol = *cwncol_g;
     p.timestep_ar = timestep_ar_g;
     p.nts_ql = *nts_ql_g; p.nts_ub = *nts_ub_g; p.nts_db = *nts_db_g; p.ntss_ev = *ntss_ev_g; p.nts_qtrib = *nts_qtrib_g;
     p.nts_da = *nts_da_g; p.mxncomp = *mxncomp_g; p.nrch = *nrch_g;
@@ -72,6 +71,18 @@ extern "C" int dw_oracle_diffnw(
     p.counters = (int64_t *)counters;
     trdw::SerialScan scan;
     trdw::solve(p, minDx, scan);
+    if (p.cwnrow > 0) { // results back onto the original hydrofabric (diffnw :849-920)
+        const long long nn = (long long)p.mxncomp * p.nrch;
+        double *tq = (double *)malloc((size_t)nout * sizeof(double)), *te = (double *)malloc((size_t)nout * sizeof(double));
+        double *used = (double *)malloc((size_t)nn * sizeof(double));
+        int32_t *flag = (int32_t *)malloc((size_t)nn * sizeof(int32_t));
+        if (!tq || !te || !used || !flag) return -2;
+        memcpy(tq, q_ev_g, (size_t)nout * sizeof(double));
+        memcpy(te, elv_ev_g, (size_t)nout * sizeof(double));
+        for (long long e = 0; e < nout; ++e) q_ev_g[e] = elv_ev_g[e] = 0.0;
+        for (int ts = 1; ts <= p.ntss_ev; ++ts) trdw::crosswalk_instant(p, ts, tq, te, used, flag);
+        free(tq); free(te); free(used); free(flag);
+    }
     free(w);
     free(frj);
     if (getenv("DW_ORACLE_COUNTERS")) fprintf(stderr, "sub-steps %lld node sweeps %lld funcd %lld\n", counters[0], counters[1], counters[2]);

@@ -747,6 +747,16 @@ template <int WR, bool IN_LDS> __global__ void __launch_bounds__(kParThreads) k_
 #undef DW_PHASE
 }
 
+// results of the recording instants back onto the original hydrofabric: one thread per instant (the links of an
+// instant are visited in crosswalk order, the fractions accumulate)
+__global__ void __launch_bounds__(64) k_dw_crosswalk(trdw::Problem p, const double *tq, const double *te, double *used, int32_t *flag)
+{
+    const int ts = blockIdx.x * 64 + threadIdx.x + 1;
+    if (ts > p.ntss_ev) return;
+    const int64_t nn = (int64_t)p.mxncomp * p.nrch;
+    trdw::crosswalk_instant(p, ts, tq, te, used + (int64_t)(ts - 1) * nn, flag + (int64_t)(ts - 1) * nn);
+}
+
 // host side of one domain: device copies of its inputs, its work space, its node list
 struct Domain {
     std::vector<void *> ptrs;
@@ -782,7 +792,9 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
     if (*a.mxnbathy_g < 0) return dw_fail(TRDW_EINVAL, "mxnbathy_g is negative");
     if (*a.mxnbathy_g > 0 && (!a.x_bathy_g || !a.z_bathy_g || !a.mann_bathy_g || !a.size_bathy_g))
         return dw_fail(TRDW_EINVAL, "bathymetry arrays are NULL although mxnbathy_g > 0");
-    if (*a.cwnrow_g != 0) return dw_fail(TRDW_EUNSUPPORTED, "the refactored-hydrofabric crosswalk (cwnrow_g > 0) is not covered");
+    if (*a.cwnrow_g < 0) return dw_fail(TRDW_EINVAL, "cwnrow_g is negative");
+    if (*a.cwnrow_g > 0 && (!a.cwncol_g || !a.crosswalk_g || !a.rdx_ar_g || !a.z_thalweg_g))
+        return dw_fail(TRDW_EINVAL, "crosswalk arrays are NULL although cwnrow_g > 0");
     if (*a.paradim < 11) return dw_fail(TRDW_EINVAL, "para_ar_g needs 11 entries");
     const int mx = *a.mxncomp_g, nr = *a.nrch_g, nql = *a.nts_ql_g, nqt = *a.nts_qtrib_g, ndb = *a.nts_db_g, nev = *a.ntss_ev_g,
               fc = *a.frnw_col;
@@ -847,6 +859,24 @@ int prepare(const trdw_args &a, Domain &dom, hipStream_t st)
         DW_UP(z_bathy, a.z_bathy_g, (size_t)p.mxnbathy * nn, double)
         DW_UP(mann_bathy, a.mann_bathy_g, (size_t)p.mxnbathy * nn, double)
         DW_UP(size_bathy, a.size_bathy_g, nn, int32_t)
+    }
+    p.cwnrow = *a.cwnrow_g;
+    p.cwncol = p.cwnrow > 0 ? *a.cwncol_g : 0;
+    if (p.cwnrow > 0) { // results are mapped back from the refactored to the original hydrofabric (diffnw :849-920)
+        if (p.cwncol < 6) return dw_fail(TRDW_EINVAL, "crosswalk_g needs at least 6 columns");
+        for (int r = 0; r < p.cwnrow; ++r) {
+            auto cw = [&](int c) { return a.crosswalk_g[r + (size_t)(c - 1) * p.cwnrow]; };
+            const int ri = (int)cw(1), rj = (int)cw(2), nlnk = (int)cw(3);
+            if (ri < 1 || ri + 1 > mx || rj < 1 || rj > nr || nlnk < 0 || 3 + 3 * nlnk > p.cwncol)
+                return dw_fail(TRDW_EINVAL, "crosswalk_g: a row's refactored segment or link count is out of range");
+            for (int l = 0; l < nlnk; ++l) {
+                const int oi = (int)cw(4 + 3 * l), oj = (int)cw(5 + 3 * l);
+                if (oi < 1 || oi + 1 > mx || oj < 1 || oj > nr) return dw_fail(TRDW_EINVAL, "crosswalk_g: an original link is out of range");
+            }
+        }
+        DW_UP(rdx_ar, a.rdx_ar_g, nn, double)
+        DW_UP(crosswalk, a.crosswalk_g, (size_t)p.cwnrow * p.cwncol, double)
+        DW_UP(z_thalweg, a.z_thalweg_g, nn, double)
     }
 #undef DW_UP
     dom.nout = (size_t)nev * nn;
@@ -998,6 +1028,20 @@ int run_batch(const trdw_args *args, int n)
         if (lds_max > 64 * 1024)
             DW_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dw_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         hipLaunchKernelGGL(k_dw_solve, dim3(n), dim3(64), lds_max, st, (const BatchItem *)run.d_items);
+    }
+    for (int b = 0; b < n; ++b) {
+        Domain &dm = run.doms[b];
+        if (dm.p.cwnrow <= 0) continue;
+        const size_t nn = (size_t)dm.p.mxncomp * dm.p.nrch, nev = (size_t)dm.p.ntss_ev;
+        double *tq = nullptr, *used = nullptr;
+        int32_t *flag = nullptr;
+        if (dm.up(nullptr, 2 * dm.nout * sizeof(double), (void **)&tq, st) || dm.up(nullptr, nev * nn * sizeof(double), (void **)&used, st)
+            || dm.up(nullptr, nev * nn * sizeof(int32_t), (void **)&flag, st))
+            return dw_fail(TRDW_ENOMEM, "device allocation failed: crosswalk scratch");
+        DW_TRY(hipMemcpyAsync(tq, dm.d_out, 2 * dm.nout * sizeof(double), hipMemcpyDeviceToDevice, st)); // q_ev, elv_ev
+        DW_TRY(hipMemsetAsync(dm.d_out, 0, 2 * dm.nout * sizeof(double), st));
+        hipLaunchKernelGGL(k_dw_crosswalk, dim3((unsigned)((nev + 63) / 64)), dim3(64), 0, st, dm.p, (const double *)tq,
+                           (const double *)(tq + dm.nout), used, flag);
     }
     DW_TRY(hipEventRecord(run.ev[2], st));
     DW_TRY(hipGetLastError());

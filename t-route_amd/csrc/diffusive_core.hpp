@@ -11,7 +11,8 @@
 // Fortran (column-major) arrays.
 //
 // Natural cross sections (mxnbathy_g > 0, readXsection_natural_mann_vertices :1756-2091) are covered as well.
-// Not covered (the entry point refuses it): the refactored-hydrofabric crosswalk (cwnrow_g > 0, :873-925).
+// The mapping of results from a refactored hydrofabric back to the original one (cwnrow_g > 0, :849-920) is
+// crosswalk_instant() at the end of this file.
 // The streamflow-DA branch is commented out in the reference itself (:1301-1327).
 //
 // Layout of the computation (not of the reference's call tree):
@@ -62,6 +63,9 @@ struct Problem {
     const int32_t *size_bathy;                  // [mxncomp][nrch]
     double *nat_v;                              // work: vertex lists [mxncomp*nrch][3][mxnbathy + 2]
     const double *para_ar;
+    // refactored hydrofabric: results are mapped back to the original one at the end (cwnrow > 0)
+    const double *rdx_ar, *crosswalk, *z_thalweg; // [mxncomp][nrch], [cwnrow][cwncol], [mxncomp][nrch]
+    int cwnrow, cwncol;
     double *q_ev, *elv_ev, *depth_ev;
     // ---- work space (caller allocated; sizes in work_doubles()) ---------------------------------------------
     double *tab;            // [nrch*mxncomp][kCols][kNel]
@@ -1037,6 +1041,52 @@ template <class Scan> DW_HD inline void solve(Problem &p, double minDx, Scan &sc
         { double *sw = p.oldQ; p.oldQ = p.newQ; p.newQ = sw; }
     }
     (void)dtini_given;
+}
+
+// Results of one recording instant mapped from the refactored hydrofabric the domain was routed on to the original one
+// (diffnw :849-920): every crosswalk row is a refactored segment (ri, rj) and the original links (oi, oj) it covers, each
+// with the fraction of the link's length; flow and depth are interpolated linearly along the refactored segment, the
+// water elevation is the depth over the original thalweg.  tq / te: the routed flows and elevations; used / flag:
+// [mxncomp * nrch] scratch of this instant (length fraction of a link covered so far, partial covers seen).
+DW_HD inline void crosswalk_instant(const Problem &p, int ts, const double *tq, const double *te, double *used, int32_t *flag)
+{
+    const double equiv_one = (double)0.99f;
+    const int64_t nn = (int64_t)p.mxncomp * p.nrch;
+    for (int64_t e = 0; e < nn; ++e) { used[e] = 0.0; flag[e] = 0; }
+    for (int cwrow = 1; cwrow <= p.cwnrow; ++cwrow) {
+        auto cw = [&](int c) { return p.crosswalk[(cwrow - 1) + (int64_t)(c - 1) * p.cwnrow]; };
+        const int ri = (int)cw(1), rj = (int)cw(2), nlnk = (int)cw(3);
+        const double rdx = DW_G(p.rdx_ar, ri, rj);
+        const double slopeQ = (DW_EV(tq, ts, ri + 1, rj) - DW_EV(tq, ts, ri, rj)) / rdx;
+        const double intcQ = DW_EV(tq, ts, ri, rj);
+        const double slopeD = ((DW_EV(te, ts, ri + 1, rj) - DW_G(p.z, ri + 1, rj)) - (DW_EV(te, ts, ri, rj) - DW_G(p.z, ri, rj))) / rdx;
+        const double intcD = DW_EV(te, ts, ri, rj) - DW_G(p.z, ri, rj);
+        double dst_lnk = 0.0;
+        for (int lnk = 1; lnk <= nlnk; ++lnk) {
+            const int oi = (int)cw(4 + 3 * (lnk - 1)), oj = (int)cw(5 + 3 * (lnk - 1));
+            const double lfrac = cw(6 + 3 * (lnk - 1));
+            const double dst_top = dst_lnk;
+            dst_lnk = dst_lnk + DW_G(p.dx_ar, oi, oj) * lfrac;
+            const double dst_btm = dst_lnk;
+            DW_G(used, oi, oj) = DW_G(used, oi, oj) + lfrac;
+            if (DW_G(used, oi, oj) < equiv_one) DW_G(flag, oi, oj) = DW_G(flag, oi, oj) + 1;
+            const double u = DW_G(used, oi, oj);
+            const int fl = DW_G(flag, oi, oj);
+            if (u >= equiv_one && fl == 0) {
+                DW_EV(p.q_ev, ts, oi, oj) = intcQ + slopeQ * dst_top;
+                DW_EV(p.q_ev, ts, oi + 1, oj) = intcQ + slopeQ * dst_btm;
+                DW_EV(p.elv_ev, ts, oi, oj) = intcD + slopeD * dst_top + DW_G(p.z_thalweg, oi, oj);
+                DW_EV(p.elv_ev, ts, oi + 1, oj) = intcD + slopeD * dst_btm + DW_G(p.z_thalweg, oi + 1, oj);
+            } else if (u < equiv_one && fl == 1) {
+                DW_EV(p.q_ev, ts, oi, oj) = intcQ + slopeQ * dst_top;
+                DW_EV(p.elv_ev, ts, oi, oj) = intcD + slopeD * dst_top + DW_G(p.z_thalweg, oi, oj);
+            } else if (u >= equiv_one && fl >= 1) {
+                DW_EV(p.q_ev, ts, oi + 1, oj) = intcQ + slopeQ * dst_btm;
+                DW_EV(p.elv_ev, ts, oi + 1, oj) = intcD + slopeD * dst_btm + DW_G(p.z_thalweg, oi + 1, oj);
+                DW_G(flag, oi, oj) = 0;
+            }
+        }
+    }
 }
 
 } // namespace trdw

@@ -165,7 +165,8 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
     def empty(df):
         return df is None or getattr(df, "empty", True)
     if refactored_diffusive_domain:
-        raise NotImplementedError("the refactored hydrofabric (crosswalk) is not covered by the device solver")
+        raise NotImplementedError("marshalling of a refactored hydrofabric: the reference keeps empty placeholders for the crosswalk "
+                                  "arguments itself (diffusive_utils_v02.py:1033-1038); the solver accepts them (trdw_diffnw, cwnrow_g > 0)")
     if not empty(usgs_df):
         raise NotImplementedError("gage data for diffusive nudging: the branch is disabled in the reference solver itself")
 

@@ -263,8 +263,42 @@ def small_cases():
     return cases
 
 
+def crosswalk_cases():
+    """The small mainstems routed as a REFACTORED hydrofabric whose results are mapped back to an original one
+    (diffnw :849-920; the reference's own Python never builds these arguments any more -- diffusive_utils_v02.py:1033-1038
+    keeps empty placeholders -- so the crosswalk is hand-made).  Rows: refactored segment (ri, rj), number of original links,
+    then (oi, oj, fraction of the link's length) per link.  Together they take every branch of the mapping: a link covered
+    at once, in two parts, in three parts (the middle part writes nothing), a segment over two links, the 0.99 threshold."""
+    base = {name: d for name, d in small_cases()}
+    rows = [[1, 3, 1, 1, 3, 1.0], [2, 3, 1, 2, 3, 0.4], [3, 3, 1, 2, 3, 0.6], [4, 3, 2, 3, 3, 1.0, 4, 3, 0.5],
+            [1, 4, 2, 4, 3, 0.5, 1, 4, 1.0], [2, 4, 1, 2, 4, 0.3], [3, 4, 1, 2, 4, 0.3], [4, 4, 1, 2, 4, 0.4],
+            [5, 4, 1, 3, 4, 0.995], [6, 4, 1, 5, 4, 1.0]]
+    cases = []
+    for name in ("y3", "y3_nat"):
+        d = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in base[name].items()}
+        rng = np.random.default_rng(77)
+        cw = np.zeros((len(rows), 9))
+        for r, row in enumerate(rows):
+            cw[r, :len(row)] = row
+        mx, nrch = int(d["mxncomp_g"]), int(d["nrch_g"])
+        d.update({"rdx_ar_g": d["dx_ar_g"] * rng.uniform(0.8, 1.25, (mx, nrch)), "cwnrow_g": cw.shape[0], "cwncol_g": cw.shape[1],
+                  "crosswalk_g": cw, "z_thalweg_g": d["z_ar_g"] - rng.uniform(0.0, 0.4, (mx, nrch))})
+        cases.append((name + "_cw", d))
+    return cases
+
+
 if __name__ == "__main__":
     O.build()
+    if "--crosswalk" in sys.argv:       # only the crosswalk fixture (the others are unchanged)
+        cwz = {}
+        for name, d in crosswalk_cases():
+            outs = call_reference(d)
+            assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1.0 and (outs[1] != 0).any(), name
+            for k, v in pack(d, outs).items():
+                cwz[f"{name}__{k}"] = v
+            print(name, "mapped cells", int((outs[0] != 0).sum()), "q max", outs[0].max())
+        np.savez_compressed(os.path.join(HERE, "diffusive_crosswalk.npz"), **cwz)
+        sys.exit(0)
     nn = import_ref_nhd_network()
     du = import_ref_diffusive_utils(nn)
     small = {}

@@ -31,6 +31,14 @@ def load_small(name):
     return {k[3:]: v for k, v in d.items() if k.startswith("in_")}, (d["out_q"], d["out_elv"], d["out_depth"])
 
 
+def load_crosswalk(name):
+    """refactored-hydrofabric cases: results mapped back through a crosswalk (tests/golden/make_diffusive_fixtures.py
+    --crosswalk; outputs of the reference Fortran)"""
+    z = np.load(os.path.join(H.GOLDEN, "diffusive_crosswalk.npz"))
+    d = {k.split("__", 1)[1]: z[k] for k in z.files if k.startswith(name + "__")}
+    return {k[3:]: v for k, v in d.items() if k.startswith("in_")}, (d["out_q"], d["out_elv"], d["out_depth"])
+
+
 def load_lowercolorado(nsteps=None, fixture="diffusive_lowercolorado.npz"):
     z = np.load(os.path.join(H.GOLDEN, fixture))
     ins = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
@@ -271,13 +279,42 @@ def test_python_mirror_refuses_what_is_not_covered_and_has_no_cpu_fallback():
     with pytest.raises(ValueError, match="fewer than two bathymetry stations"):
         D.compute_diffusive(bad)
     bad = dict(ins)
-    bad["cwnrow_g"] = np.array(2)
-    with pytest.raises(NotImplementedError, match="crosswalk"):
+    bad["cwnrow_g"] = np.array(2)                      # crosswalk rows announced, none supplied
+    with pytest.raises(ValueError, match="crosswalk"):
+        D.compute_diffusive(bad)
+    bad = dict(load_crosswalk("y3_cw")[0])
+    bad["crosswalk_g"] = bad["crosswalk_g"].copy()
+    bad["crosswalk_g"][3, 3] = 99                      # an original link outside the arrays
+    with pytest.raises(ValueError, match="out of range"):
         D.compute_diffusive(bad)
     bad = dict(ins)
     bad["frnw_g"] = np.where(ins["frnw_g"] == 555, -555, ins["frnw_g"])
     with pytest.raises(ValueError, match="no mainstem"):
         D.compute_diffusive(bad)
+
+
+@pytest.mark.parametrize("name", ("y3_cw", "y3_nat_cw"))
+def test_host_restatement_crosswalk_equals_reference_fortran_bitwise(name):
+    """diffnw :849-920: results of a refactored hydrofabric mapped back to the original links -- every branch of the
+    mapping (links covered at once, in two and in three parts, a segment over two links, the 0.99 threshold)."""
+    ins, want = load_crosswalk(name)
+    rc, got = call_c(host_oracle(), "dw_oracle_diffnw", ins)
+    assert rc == 0
+    for g, w in zip(got, want):
+        assert same_bits(np.asarray(g), w)
+    assert (want[0] != 0).sum() == 11 * want[0].shape[0]      # 11 mapped node cells per recording instant, the rest zeroed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ("y3_cw", "y3_nat_cw"))
+def test_gpu_crosswalk_equals_reference_fortran_bitwise(name):
+    from troute_amd.routing.fast_reach import diffusive as D
+    ins, want = load_crosswalk(name)
+    got = D.compute_diffusive(ins)
+    for g, w in zip(got, want):
+        assert same_bits(g, w)
+    many = D.compute_diffusive_batch([ins, load_small("y3")[0], ins])    # mapped and unmapped domains in one launch
+    assert all(same_bits(g, w) for g, w in zip(many[2], want)) and same_bits(many[1][0], load_small("y3")[1][0])
 
 
 @pytest.mark.gpu
@@ -403,7 +440,7 @@ def test_gpu_batch_of_domains_in_one_launch():
     assert D.compute_diffusive_batch([]) == []
     bad = dict(cases[1][0])
     bad["cwnrow_g"] = np.array(1)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         D.compute_diffusive_batch([cases[0][0], bad])
 
 
