@@ -130,3 +130,17 @@ def test_partition_by_measured_cost_balances_cost_not_rows():
             assert lc[free].max() / lc[free].min() <= lp[free].max() / lp[free].min() + 0.02
         if free.size:
             assert (lc[np.setdiff1d(np.arange(nparts), free)] <= lc[free].max()).all()
+
+
+def test_import_pins_one_hardware_queue_per_stream_priority():
+    """troute_amd.distributed sets GPU_MAX_HW_QUEUES before any HIP runtime loads (with several queues per
+    priority some stream-to-queue assignments put a plan's launches in a slow mode); a caller's own setting wins."""
+    import subprocess
+    import sys
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import troute_amd.distributed; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    env = dict(os.environ, PYTHONPATH=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "t-route_amd", ".."))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and out.stdout.strip() == "1", out.stderr
+    code2 = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '4'; import troute_amd.distributed; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and out.stdout.strip() == "4", out.stderr

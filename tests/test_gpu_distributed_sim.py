@@ -38,6 +38,18 @@ class ThreadAllGather:
                                                   (False, None, False), (False, 3, False), (True, None, True),
                                                   (False, None, True)])
 def test_two_ranks_device_exchange_equals_single_rank(short, nchunks, retune):
+    _two_ranks(short, nchunks, retune)
+
+
+def test_two_ranks_with_chunk_overlap_on_two_streams(monkeypatch):
+    """TRMC_FLOW_OVERLAP=1 (opt-in): consecutive time chunks of a resident window alternate between two compute streams,
+    flow and depth handed over through granules -- the same bits."""
+    monkeypatch.setenv("TRMC_FLOW_OVERLAP", "1")
+    _two_ranks(True, 5, False)
+    _two_ranks(True, None, True)
+
+
+def _two_ranks(short, nchunks, retune):
     import torch
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
