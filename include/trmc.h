@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 6
+#define TRMC_ABI_VERSION 7
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -297,6 +297,12 @@ int trmc_plan_set_lag(trmc_plan *plan, const int32_t *lag_of_row);
 /* Full result, row order: fvd_out[nseg][nsteps][3] = (q, vel, depth) per step,
  * i.e. flowveldepth[:, 1:, :] of [R1] (mc_reach.pyx:807-813).  D2H. */
 int trmc_download_fvd(trmc_plan *plan, void *fvd_out);
+/* Page-locked host memory for result arrays: a D2H copy into it runs at the speed of the link instead of through the
+ * driver's staging buffers (the 9.4 GB flowveldepth array of a CONUS day: 0.2 s instead of 0.8 s).  The Python host side
+ * keeps a small pool of these behind download_fvd(); a C caller may use them for any *_out argument.  Plain memory to the
+ * host; release with trmc_host_free, not free(). */
+int trmc_host_alloc(size_t bytes, void **ptr_out);
+int trmc_host_free(void *ptr);
 /* Final state in the reference's q0 layout, new_q0 = fvd[:, [-3,-3,-1]]
  * (AbstractNetwork.py:182-190): q0_out[nseg][3] = (q_T, q_T, depth_T).  D2H. */
 int trmc_download_final_state(trmc_plan *plan, void *q0_out);

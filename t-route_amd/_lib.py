@@ -65,6 +65,8 @@ SIGNATURES = {
     "trmc_set_boundary_flow_range_indexed": (_int, [_vp, _int, _int, _vp, _i64, _vp, _vp]),
     "trmc_plan_set_lag": (_int, [_vp, _vp]),
     "trmc_download_fvd": (_int, [_vp, _vp]),
+    "trmc_host_alloc": (_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "trmc_host_free": (_int, [_vp]),
     "trmc_download_final_state": (_int, [_vp, _vp]),
     "trmc_download_iterations": (_int, [_vp, _vp]),
     "trmc_plan_collect_cost": (_int, [_vp, _int]),
@@ -119,6 +121,54 @@ def check(rc):
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- page-locked result arrays ----------------------------------------------------------------------------------
+# A result array the size of a CONUS day (9.4 GB) crosses PCIe four times faster into page-locked memory than into
+# pageable memory, but locking that many pages costs more than one copy saves -- so the buffers are pooled: the array
+# handed out owns its buffer, and when the caller drops it the buffer goes back to the pool for the next window
+# (TRMC_PINNED_RESULTS=0 switches the pool off; an allocation that fails falls back to ordinary memory).
+_PINNED_MIN = 8 << 20
+_PINNED_KEEP = 2          # free buffers kept per size
+_pinned_free = {}
+
+
+def _pinned_release(address, nbytes):
+    try:
+        pool = _pinned_free.setdefault(nbytes, [])
+        if len(pool) < _PINNED_KEEP:
+            pool.append(address)
+        elif _LIB is not None:
+            _LIB.trmc_host_free(C.c_void_p(address))
+    except Exception:        # interpreter shutdown
+        pass
+
+
+def result_empty(shape, dtype):
+    """An uninitialised array for a device-to-host copy: page-locked when it is large, ordinary memory otherwise."""
+    import weakref
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes < _PINNED_MIN or os.environ.get("TRMC_PINNED_RESULTS", "1") == "0":
+        return np.empty(shape, dtype=dtype)
+    pool = _pinned_free.get(nbytes)
+    if pool:
+        address = pool.pop()
+    else:
+        p = C.c_void_p(0)
+        if lib().trmc_host_alloc(nbytes, C.byref(p)) != TRMC_OK or not p.value:
+            return np.empty(shape, dtype=dtype)
+        address = p.value
+    buf = (C.c_char * nbytes).from_address(address)
+    weakref.finalize(buf, _pinned_release, address, nbytes)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+def pinned_pool_clear():
+    """Free the page-locked buffers that are not in use."""
+    for nbytes, pool in list(_pinned_free.items()):
+        while pool:
+            lib().trmc_host_free(C.c_void_p(pool.pop()))
 
 
 def device_count():

@@ -2914,6 +2914,28 @@ int trmc_download_fvd(trmc_plan *pl, void *fvd_out)
     return 0;
 }
 
+int trmc_host_alloc(size_t bytes, void **ptr_out)
+{
+    if (!ptr_out) return fail(TRMC_EINVAL, "ptr_out is NULL");
+    *ptr_out = nullptr;
+    if (bytes == 0) return 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(TRMC_ENODEVICE, "no HIP device available");
+    const hipError_t e = hipHostMalloc(ptr_out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *ptr_out = nullptr;
+        (void)hipGetLastError();
+        return fail(TRMC_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int trmc_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
 int trmc_plan_collect_cost(trmc_plan *pl, int enable)
 {
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");

@@ -266,12 +266,12 @@ class RoutingPlan:
         self.maxlag = 0 if lag is None else int(lag.max(initial=0))
 
     def download_fvd(self):
-        out = np.empty((self.nseg, self._nsteps, 3), dtype=self.dtype)
+        out = _lib.result_empty((self.nseg, self._nsteps, 3), self.dtype)
         _lib.check(_lib.lib().trmc_download_fvd(self._h, _lib.ptr(out)))
         return out
 
     def download_final_state(self):
-        out = np.empty((self.nseg, 3), dtype=self.dtype)
+        out = _lib.result_empty((self.nseg, 3), self.dtype)
         _lib.check(_lib.lib().trmc_download_final_state(self._h, _lib.ptr(out)))
         return out
 
@@ -300,7 +300,7 @@ class RoutingPlan:
         _lib.check(_lib.lib().trmc_gather_flow_rows(self._h, _lib.ptr(rows), rows.shape[0], None, 1))
 
     def download_gathered(self):
-        out = np.empty(self._gathered_shape, dtype=self.dtype)
+        out = _lib.result_empty(self._gathered_shape, self.dtype)
         if out.size:
             _lib.check(_lib.lib().trmc_download_gathered(self._h, _lib.ptr(out)))
         return out

@@ -167,3 +167,40 @@ def test_packed_forcing_argument_errors():
         rc = lib.trmc_upload_forcing_packed(plan._h, 12, 2, 60, _lib.ptr(raw), _lib.ptr(raw), _lib.ptr(pk), None,
                                             _lib.ptr(np.arange(50, dtype=np.int64)), _lib.ptr(q0), None)
         assert rc == _lib.TRMC_EINVAL and b"pack_b" in lib.trmc_last_error()
+
+
+def test_large_results_come_in_pooled_page_locked_arrays(monkeypatch):
+    """download_fvd() hands out an array backed by page-locked memory when the result is large (trmc_host_alloc); the
+    buffer returns to a pool when the array is dropped and is the same memory the next window's result arrives in;
+    TRMC_PINNED_RESULTS=0 gives ordinary arrays; the values are the same either way."""
+    import gc
+    from troute_amd import _lib, synthetic
+    from troute_amd.distributed import ShardedRouter
+    net = synthetic.generate(nseg=60000, nnet=150, seed=5, nq=3)
+    n = net["to"].shape[0]
+    r = ShardedRouter(net["to"], net["params"])
+    r.upload(24, net["qlat"], np.zeros((n, 3), np.float32))
+    r.route_resident(12, True)
+    assert n * 24 * 3 * 4 >= _lib._PINNED_MIN
+    _lib.pinned_pool_clear()
+    a = r.plan0.download_fvd()
+    addr = a.ctypes.data
+    assert not a.flags["OWNDATA"] and a.flags["WRITEABLE"] and a.shape == (n, 24, 3)
+    keep = a.copy()
+    view = a[5:9]                     # a view keeps the buffer alive
+    del a
+    gc.collect()
+    assert not _lib._pinned_free.get(keep.nbytes)
+    del view
+    gc.collect()
+    assert _lib._pinned_free.get(keep.nbytes) == [addr]
+    b = r.plan0.download_fvd()        # the pooled buffer again
+    assert b.ctypes.data == addr and np.array_equal(b.view(np.uint32), keep.view(np.uint32))
+    monkeypatch.setenv("TRMC_PINNED_RESULTS", "0")
+    c = r.plan0.download_fvd()
+    assert c.flags["OWNDATA"] and np.array_equal(c.view(np.uint32), keep.view(np.uint32))
+    del b
+    gc.collect()
+    _lib.pinned_pool_clear()
+    assert not _lib._pinned_free.get(keep.nbytes)
+    r.close()
