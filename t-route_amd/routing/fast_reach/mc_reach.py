@@ -289,11 +289,14 @@ def compute_network_structured(
         stats = plan.stats()
 
     out_dtype = np.float32 if precision == 32 else np.float64
-    flowveldepth = fvd.reshape(nseg, nsteps * 3).astype(out_dtype, copy=False)[fill_index_mask]
+    flowveldepth = fvd.reshape(nseg, nsteps * 3).astype(out_dtype, copy=False)
+    if not fill_index_mask.all():          # (no copy of the result when no off-network upstream rows were spliced in)
+        flowveldepth = flowveldepth[fill_index_mask]
     upstream = np.zeros((nseg, nsteps), dtype="float32")  # np.empty in the reference (:487), reservoir rows filled (:710)
     if res_rows:
         upstream[res_rows] = res_inflow
-    upstream = upstream[fill_index_mask]
+    if not fill_index_mask.all():
+        upstream = upstream[fill_index_mask]
     t_end = nsteps * dt
     f32 = lambda a: np.asarray(a, dtype="float32")  # noqa: E731
     i32 = lambda a: np.asarray(a, dtype="int32")  # noqa: E731
