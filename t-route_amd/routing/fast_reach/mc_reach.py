@@ -36,6 +36,88 @@ def binary_find(arr, els):
     return idx_c.tolist()
 
 
+class _PlanCache:
+    """Plans of the networks this process has routed, by content (``nwm_route`` calls the kernel callable once per loop
+    with the same network: topology, order and device copies of the parameters are built once instead of per call).
+    The first window of a short-timestep fp32 network is routed on a plan built from the topology alone while its
+    secant-iteration costs are collected; the second call rebuilds the plan ONCE with those costs as the row-order hint
+    (results do not depend on the order), and later calls reuse it.  ``TRMC_PLAN_CACHE=<n>`` sets the number of plans
+    kept (default 2; 0: a fresh plan per call, as the reference's callable is stateless)."""
+
+    def __init__(self):
+        import collections
+        import threading
+        self._d = collections.OrderedDict()
+        self._lock = threading.RLock()
+
+    def _key(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows):
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        for a in (up_ptr, up_idx, params, boundary):
+            if a is None:
+                h.update(b"-")
+            else:
+                a = np.ascontiguousarray(a)
+                h.update(str((a.shape, a.dtype.str)).encode())
+                h.update(a.view(np.uint8).reshape(-1).data)
+        h.update(repr((precision, device, short_ts, res_rows)).encode())
+        return h.digest()
+
+    def lease(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows):
+        import contextlib
+        import os
+        keep = int(os.environ.get("TRMC_PLAN_CACHE", "2"))
+
+        def build(hint=None):
+            return RoutingPlan(up_ptr, up_idx, params, boundary, precision, device, cost_hint=hint, assume_short_ts=short_ts)
+
+        @contextlib.contextmanager
+        def fresh():
+            with build() as plan:
+                yield plan
+
+        if keep <= 0:
+            return fresh()
+
+        @contextlib.contextmanager
+        def cached():
+            with self._lock:
+                key = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows)
+                e = self._d.pop(key, None)
+                tune = short_ts and precision == 32
+                if e is None:
+                    e = {"plan": build(), "stage": 0 if tune else 2}
+                    if tune:
+                        e["plan"].collect_cost(True)
+                elif e["stage"] == 1:                          # costs of the first window -> the tuned plan, once
+                    cost, n = e["plan"].download_cost()
+                    hint = np.minimum((cost.astype(np.int64) * 16 + n - 1) // max(n, 1), 255).astype(np.uint8)
+                    e["plan"].close()
+                    e = {"plan": build(hint), "stage": 2}
+                ok = False
+                try:
+                    yield e["plan"]
+                    ok = True
+                finally:
+                    if ok:
+                        if e["stage"] == 0:
+                            e["stage"] = 1
+                        self._d[key] = e
+                        while len(self._d) > keep:
+                            self._d.popitem(last=False)[1]["plan"].close()
+                    else:
+                        e["plan"].close()
+        return cached()
+
+    def clear(self):
+        with self._lock:
+            while self._d:
+                self._d.popitem()[1]["plan"].close()
+
+
+_PLANS = _PlanCache()
+
+
 def column_mapper(src_cols):
     """Map source columns to the kernel's column order (mc_reach.pyx:150-162)."""
     index = {label: i for i, label in enumerate(src_cols)}
@@ -73,8 +155,11 @@ def _flatten_network(reaches_wTypes, upstream_connections, data_idx):
     is_head[np.asarray(starts, dtype=np.int64)] = True
     counts[rows[~is_head]] = 1
     head_rows = rows[is_head]
-    up_rows_of_head = [binary_find(data_idx, u) for u in head_ups]
-    counts[head_rows] = [len(u) for u in up_rows_of_head]
+    # the upstream ids of all reach heads in one look-up (one searchsorted instead of one per reach)
+    n_up = np.fromiter((len(u) for u in head_ups), dtype=np.int64, count=len(head_ups))
+    all_ups = np.fromiter((x for u in head_ups for x in u), dtype=np.int64, count=int(n_up.sum()))
+    all_up_rows = np.asarray(binary_find(data_idx, all_ups), dtype=np.int64)
+    counts[head_rows] = n_up
     up_ptr = np.zeros(nseg + 1, dtype=np.int64)
     up_ptr[1:] = np.cumsum(counts)
     up_idx = np.empty(up_ptr[-1], dtype=np.int64)
@@ -82,8 +167,12 @@ def _flatten_network(reaches_wTypes, upstream_connections, data_idx):
     prev = np.empty_like(rows)
     prev[1:] = rows[:-1]
     up_idx[up_ptr[rows[~is_head]]] = prev[~is_head]
-    for r, ups in zip(head_rows.tolist(), up_rows_of_head):
-        up_idx[up_ptr[r]:up_ptr[r] + len(ups)] = ups
+    # heads: their upstream rows in dict-list order, written at up_ptr[head] + 0, 1, ...
+    if all_up_rows.size:
+        first = np.zeros(n_up.shape[0] + 1, dtype=np.int64)
+        first[1:] = np.cumsum(n_up)
+        within = np.arange(all_up_rows.size, dtype=np.int64) - np.repeat(first[:-1], n_up)
+        up_idx[np.repeat(up_ptr[head_rows], n_up) + within] = all_up_rows
     return up_ptr, up_idx, in_reach
 
 
@@ -274,8 +363,8 @@ def compute_network_structured(
 
     nudge = np.zeros((gages_size, nsteps + 1), dtype="float32")
     # (the timestep mode is known here: the plan picks the engine and the row order that suit it, trmc_plan_create_ex)
-    with RoutingPlan(up_ptr, up_idx, params, boundary if brow.size else None, precision, device,
-                     assume_short_ts=bool(assume_short_ts)) as plan:
+    with _PLANS.lease(up_ptr, up_idx, params, boundary if brow.size else None, precision, device,
+                      bool(assume_short_ts), tuple(res_rows)) as plan:
         if res_rows:
             plan.set_reservoirs(res_rows, np.asarray(res_par, dtype=dtype), dt)
         plan.upload_forcing(nsteps, qlat_values, q0, boundary_fvd)

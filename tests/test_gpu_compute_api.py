@@ -184,3 +184,34 @@ def test_upstream_results_of_a_waterbody_seed_its_outflow_not_the_nan_initial_co
     want = O.network(nts, qts, [np.array([1, 2, 3])], [np.array([0])], dv, q0o, qlat, True, det=True,
                      prefilled=np.array([1, 0, 0, 0], np.uint8), fvd_init=init)[1:, 1:, :]
     assert np.array_equal(r[1].reshape(3, nts, 3).view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+
+
+def test_kernel_callable_reuses_and_tunes_its_plan_without_changing_results(monkeypatch):
+    """The drop-in callable keeps the plan of a network it has routed (by content) -- the second call rebuilds it once with
+    the first window's iteration costs as the row-order hint, later calls reuse it -- and every call returns the bits a
+    fresh, untuned plan returns, also for another window's forcing and state."""
+    from troute_amd.routing.fast_reach import mc_reach as M
+    lc = H.LowerColorado()
+    rng = np.random.default_rng(3)
+    windows = [(lc.qlat, lc.q0),
+               (lc.qlat * rng.uniform(0.5, 1.5, lc.qlat.shape).astype(np.float32), lc.q0),
+               (lc.qlat, np.abs(rng.normal(1.0, 0.5, lc.q0.shape)).astype(np.float32))]
+    nts = 48
+
+    def call(ql, q0):
+        args = M.mc_only_args(nts, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, q0, ql,
+                              assume_short_ts=True)
+        return M.compute_network_structured(*args)
+
+    monkeypatch.setenv("TRMC_PLAN_CACHE", "0")
+    want = [call(ql, q0)[1].copy() for ql, q0 in windows]
+    monkeypatch.setenv("TRMC_PLAN_CACHE", "2")
+    M._PLANS.clear()
+    stages = []
+    for k in (0, 1, 2, 0, 1):                                   # untuned, tuning rebuild, tuned, tuned, tuned
+        got = call(*windows[k])[1]
+        assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), k
+        stages.append([e["stage"] for e in M._PLANS._d.values()])
+    assert stages == [[1], [2], [2], [2], [2]]
+    M._PLANS.clear()
+    assert not M._PLANS._d
