@@ -25,3 +25,37 @@ pr.enable()
 compute_network_structured(*args)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+
+# ---- the top-level seam: compute_nhd_routing_v02 with DataFrames (what nwm_route calls) --------------------------------
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+from troute_amd import nhd_network as nn  # noqa: E402
+from troute_amd.routing.compute import compute_nhd_routing_v02  # noqa: E402
+
+conn = {int(s): ([int(t)] if t != 0 else []) for s, t in zip(lc.ids, lc.to)}
+cols = ["dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0"]
+param_df = pd.DataFrame(lc.params9[:, 1:], index=lc.ids, columns=cols)
+param_df["alt"] = 0.0
+q0_df = pd.DataFrame(lc.q0, index=lc.ids, columns=["qu0", "qd0", "h0"])
+qlat_df = pd.DataFrame(lc.qlat, index=lc.ids)
+t0 = time.perf_counter()
+ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
+print(f"organize_independent_networks: {1e3 * (time.perf_counter() - t0):.1f} ms")
+e = pd.DataFrame()
+
+
+def top():
+    return compute_nhd_routing_v02(conn, rconn, {}, reaches_bytw, "V02-structured", "by-network", 10000, 4, None, 300.0, lc.nts,
+                                   lc.qts, ind, param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, e, {},
+                                   e, False, [{}, {}])
+
+
+for k in range(4):
+    t0 = time.perf_counter()
+    top()
+    print(f"compute_nhd_routing_v02 call {k}: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+pr = cProfile.Profile()
+pr.enable()
+top()
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(16)
