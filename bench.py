@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-retune", action="store_true",
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: all hardware threads)")
     return ap.parse_args()
@@ -500,7 +501,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": kernel,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(engine),
+                "traffic": pmc_traffic(engine, a) if rank == 0 else None,
                 "launches_per_step": head["launches"], "avg_launch_ms": head["ms_main"] / max(head["launches"], 1),
                 "alg_bytes_per_launch": seg0 / max(head["launches"], 1) * bytes_per,
                 "ms_main": head["ms_main"], "ms_total_device": head["ms_total"],
@@ -518,22 +519,58 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(engine):
-    """HBM bytes per launch of the dominant kernel from the round's counter passes (profiles/pmc_traffic.json, written by
-    tools/profile_round.sh) -- reported only while the kernels are the ones the counters were taken on (the file records
-    a digest of the device sources); otherwise null rather than a stale figure."""
-    import hashlib
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def pmc_traffic(engine, args):
+    """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two counter-only rocprofv3 passes (FETCH_SIZE, then
+    WRITE_SIZE; --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a one-window child run of this script on the
+    same plan order, per dispatch of the dominant routing kernel; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950:
+    FETCH_SIZE counts half of the streamed reads; units of KB).  null when the profiler is not available, when this
+    process is itself a profiled child or one rank of several, or on any failure -- never a figure from a file."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if args.no_traffic or os.environ.get("TRMC_BENCH_CHILD") or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return None
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None                                     # this process is being profiled itself
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    pat = "k_mc_step" if engine == "levels" else "k_mc_flow"
+    vals = {}
     try:
-        rec = json.load(open(path))
-        h = hashlib.sha256()
-        for f in ("trmc.hip", "mc_segment.hpp", "det_pow.h", "levelpool.hpp"):
-            h.update(open(os.path.join(ROOT, "t-route_amd", "csrc", f), "rb").read())
-        if rec.get("source_sha256") == h.hexdigest() and rec.get("engine") == engine:
-            return rec.get("hbm_bytes_per_launch")
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, counter)
+                cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "c", "--", sys.executable,
+                       os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-full-ts",
+                       "--no-diffusive", "--no-parity-mode", "--no-traffic", "--nsteps", str(args.nsteps), "--qts", str(args.qts),
+                       "--precision", str(args.precision)]
+                if args.nseg:
+                    cmd += ["--nseg", str(args.nseg)]
+                if args.nnet:
+                    cmd += ["--nnet", str(args.nnet)]
+                if args.no_retune:
+                    cmd += ["--no-retune"]
+                env = dict(os.environ, TRMC_BENCH_CHILD="1", TMPDIR="/tmp")
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+                dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+                con = sqlite3.connect(dbs[0])
+                rows = con.execute(
+                    "select s.kernel_name, count(distinct d.id), sum(d.end - d.start) from rocpd_kernel_dispatch d "
+                    "join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name").fetchall()
+                rows = [r for r in rows if pat in r[0]]
+                name = max(rows, key=lambda r: r[2])[0]
+                per = con.execute(
+                    "select sum(e.value) / count(distinct d.id) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+                    "join rocpd_kernel_dispatch d on d.event_id = e.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+                    "where s.kernel_name = ? and p.name = ?", (name, counter)).fetchone()[0]
+                con.close()
+                vals[counter] = float(per)
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except Exception:
-        pass
-    return None
+        return None
 
 
 if __name__ == "__main__":
