@@ -554,7 +554,7 @@ def pmc_traffic(engine, args):
                 if args.no_retune:
                     cmd += ["--no-retune"]
                 env = dict(os.environ, TRMC_BENCH_CHILD="1", TMPDIR="/tmp")
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
                 dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
                 con = sqlite3.connect(dbs[0])
                 rows = con.execute(
