@@ -335,10 +335,15 @@ def compute_network_structured(
         for gi in range(gages_size):
             reach_gage[int(upr[gi])] = int(upg[gi])
         active = sorted(set(reach_gage.values()))
-        for ri, gi in reach_gage.items():
+        # With assume_short_ts a segment only ever reads STORED flows of the step before (mc_reach.pyx:133-137: qup = qdp,
+        # quc = qup), so it does not matter where in its reach the gage sits.  Without it the segment below a gage inside
+        # a reach reads the gage segment's un-nudged flow of the current step (the nudge is applied after the whole reach,
+        # :761-796) while everything else sees the nudged one -- two values for one segment-step, which the engine does
+        # not carry: the gage then has to end its reach, as the reference's own network builders arrange.
+        for ri, gi in ({} if assume_short_ts else reach_gage).items():
             last_row = binary_find(data_idx, [reaches_wTypes[ri][0][-1]])[0]
             if last_row != int(usgs_positions[gi]):
-                raise NotImplementedError("a gage segment that is not the last segment of its reach")
+                raise NotImplementedError("a gage segment that is not the last segment of its reach (assume_short_ts=False)")
         mode, a_tab, w_tab, lt_fin, lv_fin = _da.resolve_tables(
             nsteps, dt, da_decay_coefficient, usgs_values, lastobs_values_init, time_since_lastobs_init)
         act = np.asarray(active, dtype=np.int64)

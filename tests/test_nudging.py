@@ -120,11 +120,46 @@ def test_gpu_nudging_bit_identical_to_oracle(short):
 
 
 @pytest.mark.gpu
-def test_gpu_nudging_rejects_gage_inside_reach():
+def test_gpu_nudging_gages_inside_reaches_short_timestep_mode():
+    """A caller whose reaches were NOT split at the gages: with assume_short_ts the result is still the reference's
+    (a segment reads only stored flows of the step before) -- gages at random positions of 40 reaches of the unsplit
+    LowerColorado decomposition, GPU == oracle bit for bit."""
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+    lc = H.LowerColorado()
+    rng = np.random.default_rng(21)
+    long_reaches = [i for i, r in enumerate(lc.reaches) if len(r) >= 3]
+    pick = rng.choice(long_reaches, 40, replace=False)
+    row = {int(s): i for i, s in enumerate(lc.ids)}
+    ngage, gmax, nts = len(pick), 120, 96
+    inside = [int(rng.integers(0, len(lc.reaches[i]) - 1)) for i in pick]          # never the last segment
+    upos = np.array([row[lc.reaches[i][k]] for i, k in zip(pick, inside)], np.int32)
+    upr, upg = np.asarray(pick, np.int32), np.arange(ngage, dtype=np.int32)
+    usgs = rng.lognormal(np.log(0.05), 1.0, (ngage, gmax)).astype(np.float32)
+    usgs[rng.random((ngage, gmax)) < 0.25] = np.nan
+    lv0 = rng.lognormal(np.log(0.05), 1.0, ngage).astype(np.float32)
+    lt0 = (-rng.uniform(0, 7200, ngage)).astype(np.float32)
+    args = mc_only_args(nts, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, lc.q0, lc.qlat,
+                        assume_short_ts=True)
+    args[16], args[17], args[18], args[19] = usgs, upos, upr, upg
+    args[20], args[21], args[22] = lv0, lt0, 120.0
+    r = compute_network_structured(*args)
+    rl, ul = lc.row_lists()
+    gage_of_reach = np.full(len(lc.reaches), -1, np.int64)
+    gage_of_reach[upr] = upg
+    da = dict(usgs_values=usgs, gage_row=upos, gage_of_reach=gage_of_reach, decay_coeff=120.0, routing_period=lc.dt,
+              lastobs_time=lt0, lastobs_val=lv0)
+    want = O.network(nts, lc.qts, rl, ul, lc.params9, lc.q0, lc.qlat, True, det=True, da=da)
+    assert np.array_equal(r[1].reshape(lc.nseg, nts, 3).view(np.uint32), np.ascontiguousarray(want[:, 1:, :]).view(np.uint32))
+    assert np.array_equal(r[8].view(np.uint32), da["nudge"].view(np.uint32)) and np.abs(r[8]).max() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_nudging_rejects_gage_inside_reach_without_the_short_timestep_assumption():
     from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
     lc = H.LowerColorado()
     long_reach = next(i for i, r in enumerate(lc.reaches) if len(r) >= 3)
-    args = mc_only_args(12, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, lc.q0, lc.qlat)
+    args = mc_only_args(12, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, lc.q0, lc.qlat,
+                        assume_short_ts=False)
     row = {int(s): i for i, s in enumerate(lc.ids)}
     args[16] = np.ones((1, 5), np.float32)
     args[17] = np.array([row[lc.reaches[long_reach][0]]], np.int32)
