@@ -71,8 +71,25 @@ def parse():
     ap.add_argument("--no-diffusive", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: all hardware threads)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: one per CPU the cgroup grants, at most the physical cores)")
     return ap.parse_args()
+
+
+def cpu_quota():
+    """CPUs of run time the cgroup of this process grants (cgroup v2 cpu.max, v1 cfs quota), None when unlimited/unknown."""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            return float(txt[0]) / float(txt[1])
+        return None
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except Exception:
+        return None
 
 
 def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
@@ -84,7 +101,7 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     dominant basin (half of all segments) gets more than one core.  The time x segment loop and the job scheduling are
     C + OpenMP (oracle/cpu_baseline.c) around the reference Fortran kernel symbol (oracle/_ref, amdflang -O2), so no
     Python sits inside the clock.  Bounded sample: all segments, the first `ns` timesteps of the window, `ns` sized for
-    about `target_s` seconds at 1.5e6 segment-timesteps/s per thread.
+    about `target_s` seconds at 3e6 segment-timesteps/s per thread (the box runs 6e6 per core; SURVEY section 6 measured 1.6e6 here).
     """
     from oracle import oracle as O
     from troute_amd.synthetic import upstream_csr
@@ -97,13 +114,16 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
         physical = psutil.cpu_count(logical=False) or os.cpu_count() or 1
     except Exception:
         physical = os.cpu_count() or 1
-    # one thread per physical core: on the 2 x 64-core host of the GPU box 256 hardware threads were SLOWER than 128
-    # (6.7e7 against 9.4e7 segment-timesteps/s) and 64 as fast as 128 -- above ~32 threads the makespan of an order is
-    # bounded by its largest jobs (10 000 segments x 288 steps cannot be split) and by the memory system, not by cores
-    threads = cpu_threads or physical
+    # The cores this process may actually use: the container of the GPU box shows 256 hardware threads (2 x 64 cores) but
+    # its cgroup grants 16 CPUs of run time (cpu.max = 1600000 100000) -- which is why 64, 128 and 256 threads all gave
+    # 9.4e7 segment-timesteps/s or less while 8 threads gave 6.3e6 each: beyond the quota, threads are throttled, not run.
+    # One thread per granted CPU (never more than the physical cores).
+    quota = cpu_quota()
+    usable = physical if quota is None else max(1, min(physical, int(quota + 0.5)))
+    threads = cpu_threads or usable
     to = net["to"]
     nseg = to.shape[0]
-    ns = int(max(qts, min(nsteps, target_s * threads * 1.5e6 / nseg)))
+    ns = int(max(qts, min(nsteps, target_s * threads * 3.0e6 / nseg)))
     t0 = time.perf_counter()
     order_ptr, job_ptr, rows = O.ordered_subnetworks(to, 10000)
     up_ptr, up_idx = upstream_csr(to)
@@ -115,6 +135,7 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     jobs = np.diff(order_ptr)
     return {
         "value": done / dt, "unit": "segment-timesteps/s", "cores": int(nthreads), "physical_cores": int(physical),
+        "cpu_quota": None if quota is None else round(float(quota), 2),
         "kind": kind,
         "per_thread": done / dt / max(nthreads, 1),
         "sample": f"all {nseg} segments x the first {ns} of {nsteps} timesteps ({done} segment-timesteps), {dt:.1f} s wall; "
