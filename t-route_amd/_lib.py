@@ -136,7 +136,7 @@ _pinned_free = {}
 def _pinned_release(address, nbytes):
     try:
         pool = _pinned_free.setdefault(nbytes, [])
-        if len(pool) < _PINNED_KEEP:
+        if len(pool) < (_PINNED_KEEP if nbytes <= (4 << 30) else 1):     # (one spare only of the multi-gigabyte buffers)
             pool.append(address)
         elif _LIB is not None:
             _LIB.trmc_host_free(C.c_void_p(address))
