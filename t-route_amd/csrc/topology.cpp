@@ -130,10 +130,6 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
         for (int64_t o = 0; o < nseg; ++o)
             if (!is_b(o) && down_ptr[o + 1] == down_ptr[o]) outlets.push_back((int32_t)o);
         std::stable_sort(outlets.begin(), outlets.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
-        // experiment (general-mode plans): the DEEPEST tributary of a junction first, so that the blocks of the longest chains
-        // of dependent rows get their tickets early
-        const char *df_env = std::getenv("TRMC_FLOW_DEEP_FIRST");
-        const bool deep_first = !cost_tiers && df_env && df_env[0] == '1';
         std::vector<int32_t> post; // routed rows, every row after all rows draining into it
         post.reserve(nrouted);
         {
@@ -162,10 +158,7 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                     }
                     // visited in ascending size (the largest tributary last, right before its junction): pushed in
                     // descending order of visit
-                    if (deep_first)
-                        std::stable_sort(kids.begin(), kids.end(), [&](int32_t a, int32_t b) { return t.level_of_row[a] < t.level_of_row[b]; });
-                    else
-                        std::stable_sort(kids.begin(), kids.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
+                    std::stable_sort(kids.begin(), kids.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
                     for (const int32_t u : kids) stack.emplace_back(u, 0);
                 }
             }
