@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 7
+#define TRMC_ABI_VERSION 8
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -233,6 +233,12 @@ int trmc_download_reservoir_inflow(trmc_plan *plan, void *inflow_out);
  */
 int trmc_set_nudging(trmc_plan *plan, int nsteps, int64_t ngage, const int64_t *gage_rows,
                      const uint8_t *mode, const void *a, const void *w);
+/* Gages INSIDE a reach when the window is routed WITHOUT assume_short_ts (with it nothing is needed: a segment then reads
+ * only stored flows of the step before).  successor_rows[g] = the row directly below gage g in its reach, or -1 when the
+ * gage ends its reach.  The reference nudges after the whole reach has been routed (mc_reach.pyx:133-137, :761-796), so
+ * that one row reads the gage segment's flow of the current step as it was BEFORE the nudge while every other reader gets
+ * the nudged value.  Level engine only (TRMC_ESTATE on a dataflow plan); after trmc_set_nudging, per window. */
+int trmc_set_nudging_successors(trmc_plan *plan, int64_t ngage, const int64_t *successor_rows);
 /* nudge_out[ngage][nsteps]: the nudge applied at every gage and step (mc_reach.pyx:793). D2H. */
 int trmc_download_nudge(trmc_plan *plan, void *nudge_out);
 

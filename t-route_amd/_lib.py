@@ -53,6 +53,7 @@ SIGNATURES = {
     "trmc_set_reservoirs": (_int, [_vp, _i64, _vp, _vp, C.c_double]),
     "trmc_download_reservoir_inflow": (_int, [_vp, _vp]),
     "trmc_set_nudging": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp]),
+    "trmc_set_nudging_successors": (_int, [_vp, C.c_int64, _vp]),
     "trmc_download_nudge": (_int, [_vp, _vp]),
     "trmc_route_device": (_int, [_vp, _int, _int, _int]),
     "trmc_route_begin": (_int, [_vp, _int, _int, _int]),

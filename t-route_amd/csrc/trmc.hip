@@ -304,6 +304,11 @@ template <class T> struct StepArgs {
     const uint8_t *da_mode;
     const T *da_a, *da_w;
     T *da_nudge;
+    // gages INSIDE a reach, general mode only (trmc_set_nudging_successors): the segment below such a gage reads the gage
+    // segment's flow of the current step as it was BEFORE the nudge (the reference nudges after the whole reach,
+    // mc_reach.pyx:133-137,:761-796): raw_of_pos = gage whose raw flow a position reads (-1 = none), da_raw [gage][nsteps]
+    const int32_t *raw_of_pos;
+    T *da_raw;
     int64_t nseg_pad;
     int32_t nsteps, qts;
 };
@@ -482,6 +487,10 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 }
             }
         }
+        if (!SHORT && a.raw_of_pos) {
+            const int32_t g = a.raw_of_pos[s];
+            if (g >= 0) quc = a.da_raw[(size_t)g * (size_t)a.nsteps + (size_t)(t - 1)]; // (its one upstream row is that gage)
+        }
         f.qup = qup;
         f.quc = SHORT ? qup : quc;
 
@@ -518,6 +527,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 const size_t e = (size_t)g * (size_t)a.nsteps + (size_t)(t - 1);
                 const uint8_t mode = a.da_mode[e];
                 T nudge = T(0);
+                if (!SHORT && a.da_raw) a.da_raw[e] = q_new;
                 if (mode == 1) {            // valid observation: replace
                     nudge = a.da_a[e] - q_new;
                     q_new = a.da_a[e];
@@ -1559,6 +1569,8 @@ struct trmc_plan {
     int64_t nres = 0;
     double res_dt = 0.0;
     int64_t ngage = 0;
+    int64_t nraw = 0;                    // gages inside a reach whose successor reads the un-nudged flow (general mode)
+    DevBuf raw_of_pos, da_raw;
     int32_t da_nsteps = -1;
     // per window
     DevBuf in_qlat, in_q0, in_bfvd, qlat_tm, tm, out, scratch, gathered;
@@ -1671,6 +1683,8 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.da_a = (const T *)pl->da_a.p;
     a.da_w = (const T *)pl->da_w.p;
     a.da_nudge = (T *)pl->da_nudge.p;
+    a.raw_of_pos = da && pl->nraw > 0 ? (const int32_t *)pl->raw_of_pos.p : nullptr;
+    a.da_raw = da && pl->nraw > 0 ? (T *)pl->da_raw.p : nullptr;
     a.qlat_tm = (const T *)pl->qlat_tm.p;
     const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
     a.q_tm = (T *)pl->tm.p;
@@ -2385,7 +2399,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->d_gran, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();
@@ -2468,6 +2482,7 @@ static int stage_state(trmc_plan *pl, int nsteps, int64_t nq, const void *q0, co
     pl->nq = nq;
     pl->have_boundary = pl->topo.nboundary == 0 || boundary_fvd != nullptr;
     pl->ngage = 0; // nudging tables belong to one window: trmc_set_nudging() after each upload
+    pl->nraw = 0;
     pl->staged_nsteps = nsteps;
     pl->routed_nsteps = -1;
     return 0;
@@ -2643,8 +2658,42 @@ int trmc_set_nudging(trmc_plan *pl, int nsteps, int64_t ngage, const int64_t *ga
     HIP_TRY(hipMemcpy(pl->da_w.p, w, n * e, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(pl->da_nudge.p, 0, n * e, pl->stream)); // (on the plan's stream: ordered before its kernels)
     pl->ngage = ngage;
+    pl->nraw = 0;
     pl->da_nsteps = nsteps;
     pl->routed_nsteps = -1;
+    return 0;
+}
+
+int trmc_set_nudging_successors(trmc_plan *pl, int64_t ngage, const int64_t *successor_rows)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->ngage == 0 || ngage != pl->ngage) return fail(TRMC_ESTATE, "trmc_set_nudging (same ngage) must precede trmc_set_nudging_successors");
+    if (!successor_rows) return fail(TRMC_EINVAL, "successor_rows is NULL");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
+    pl->nraw = 0;
+    int64_t n = 0;
+    for (int64_t g = 0; g < ngage; ++g) n += successor_rows[g] >= 0;
+    if (n == 0) return 0;
+    if (pl->flow)
+        return fail(TRMC_ESTATE, "gages inside a reach without assume_short_ts need the level engine (create the plan with "
+                                       "TRMC_ENGINE_LEVELS)");
+    if (int rc = use_device(pl)) return rc;
+    std::vector<int32_t> g_of_pos((size_t)pl->nseg_pad, -1), raw((size_t)pl->nseg_pad, -1);
+    HIP_TRY(hipMemcpy(g_of_pos.data(), pl->gage_of_pos.p, (size_t)pl->nseg_pad * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t g = 0; g < ngage; ++g) {
+        const int64_t r = successor_rows[g];
+        if (r < 0) continue;
+        if (r >= pl->nseg || pl->topo.level_of_row[r] < 0) return fail(TRMC_EINVAL, "successor row out of range or a boundary row");
+        const int32_t p = pl->topo.pos_of_row[r];
+        // the segment below a gage inside a reach has exactly one upstream row: that gage's segment
+        if (pl->topo.up_ptr[p + 1] - pl->topo.up_ptr[p] != 1 || g_of_pos[(size_t)pl->topo.up_idx[pl->topo.up_ptr[p]]] != (int32_t)g)
+            return fail(TRMC_EINVAL, "successor row " + std::to_string(r) + " is not the segment directly below gage " + std::to_string(g));
+        raw[(size_t)p] = (int32_t)g;
+    }
+    if (int rc = upload_i32(pl->raw_of_pos, raw, 1)) return rc;
+    if (int rc = pl->da_raw.ensure((size_t)ngage * pl->da_nsteps * pl->esz)) return rc;
+    HIP_TRY(hipMemsetAsync(pl->da_raw.p, 0, (size_t)ngage * pl->da_nsteps * pl->esz, pl->stream));
+    pl->nraw = n;
     return 0;
 }
 

@@ -212,6 +212,12 @@ class RoutingPlan:
         _lib.check(_lib.lib().trmc_set_nudging(self._h, nsteps, ng, _lib.ptr(gage_rows), _lib.ptr(mode),
                                                _lib.ptr(a), _lib.ptr(w)))
 
+    def set_nudging_successors(self, successor_rows):
+        """Rows directly below gages that sit INSIDE their reach (-1: the gage ends its reach), for a window routed without
+        assume_short_ts on a level-engine plan (include/trmc.h trmc_set_nudging_successors)."""
+        succ = np.ascontiguousarray(successor_rows, dtype=np.int64)
+        _lib.check(_lib.lib().trmc_set_nudging_successors(self._h, succ.shape[0], _lib.ptr(succ)))
+
     def download_nudge(self):
         out = np.zeros((getattr(self, "_ngage", 0), self._nsteps), dtype=self.dtype)
         _lib.check(_lib.lib().trmc_download_nudge(self._h, _lib.ptr(out)))

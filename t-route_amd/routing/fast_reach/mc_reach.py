@@ -50,7 +50,7 @@ class _PlanCache:
         self._d = collections.OrderedDict()
         self._lock = threading.RLock()
 
-    def _key(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows):
+    def _key(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine):
         import hashlib
         h = hashlib.blake2b(digest_size=16)
         for a in (up_ptr, up_idx, params, boundary):
@@ -60,16 +60,17 @@ class _PlanCache:
                 a = np.ascontiguousarray(a)
                 h.update(str((a.shape, a.dtype.str)).encode())
                 h.update(a.view(np.uint8).reshape(-1).data)
-        h.update(repr((precision, device, short_ts, res_rows)).encode())
+        h.update(repr((precision, device, short_ts, res_rows, engine)).encode())
         return h.digest()
 
-    def lease(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows):
+    def lease(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine="auto"):
         import contextlib
         import os
         keep = int(os.environ.get("TRMC_PLAN_CACHE", "2"))
 
         def build(hint=None):
-            return RoutingPlan(up_ptr, up_idx, params, boundary, precision, device, cost_hint=hint, assume_short_ts=short_ts)
+            return RoutingPlan(up_ptr, up_idx, params, boundary, precision, device, cost_hint=hint, assume_short_ts=short_ts,
+                               engine=engine)
 
         @contextlib.contextmanager
         def fresh():
@@ -82,7 +83,7 @@ class _PlanCache:
         @contextlib.contextmanager
         def cached():
             with self._lock:
-                key = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows)
+                key = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine)
                 e = self._d.pop(key, None)
                 tune = short_ts and precision == 32
                 if e is None:
@@ -339,17 +340,24 @@ def compute_network_structured(
         # quc = qup), so it does not matter where in its reach the gage sits.  Without it the segment below a gage inside
         # a reach reads the gage segment's un-nudged flow of the current step (the nudge is applied after the whole reach,
         # :761-796) while everything else sees the nudged one -- two values for one segment-step, which the engine does
-        # not carry: the gage then has to end its reach, as the reference's own network builders arrange.
+        # not carry in one array
+        # -- a second value per gage and step, which the level engine carries (trmc_set_nudging_successors).
+        successors = None
         for ri, gi in ({} if assume_short_ts else reach_gage).items():
-            last_row = binary_find(data_idx, [reaches_wTypes[ri][0][-1]])[0]
-            if last_row != int(usgs_positions[gi]):
-                raise NotImplementedError("a gage segment that is not the last segment of its reach (assume_short_ts=False)")
+            reach_rows = binary_find(data_idx, reaches_wTypes[ri][0])
+            if reach_rows[-1] != int(usgs_positions[gi]):
+                if int(usgs_positions[gi]) not in reach_rows:
+                    raise ValueError("a gage that is not a segment of the reach it is listed for")
+                if successors is None:
+                    successors = np.full(gages_size, -1, dtype=np.int64)
+                successors[gi] = reach_rows[reach_rows.index(int(usgs_positions[gi])) + 1]
         mode, a_tab, w_tab, lt_fin, lv_fin = _da.resolve_tables(
             nsteps, dt, da_decay_coefficient, usgs_values, lastobs_values_init, time_since_lastobs_init)
         act = np.asarray(active, dtype=np.int64)
         if precision != 32:
             a_tab, w_tab = a_tab.astype(dtype), w_tab.astype(dtype)
-        nudging = (usgs_positions[act], mode[act], a_tab[act], w_tab[act], act)
+        nudging = (usgs_positions[act], mode[act], a_tab[act], w_tab[act], act,
+                   None if successors is None else successors[act])
         # gages that own no reach are never visited by the loop: their lastobs stay at the initial values
         idle = np.setdiff1d(np.arange(gages_size), act)
         lt_fin[idle] = np.asarray(time_since_lastobs_init, dtype=np.float32)[idle]
@@ -368,13 +376,17 @@ def compute_network_structured(
 
     nudge = np.zeros((gages_size, nsteps + 1), dtype="float32")
     # (the timestep mode is known here: the plan picks the engine and the row order that suit it, trmc_plan_create_ex)
+    # (gages inside a reach in the general mode need the level engine: it carries the un-nudged flow beside the nudged one)
+    engine = "levels" if nudging is not None and nudging[5] is not None else "auto"
     with _PLANS.lease(up_ptr, up_idx, params, boundary if brow.size else None, precision, device,
-                      bool(assume_short_ts), tuple(res_rows)) as plan:
+                      bool(assume_short_ts), tuple(res_rows), engine) as plan:
         if res_rows:
             plan.set_reservoirs(res_rows, np.asarray(res_par, dtype=dtype), dt)
         plan.upload_forcing(nsteps, qlat_values, q0, boundary_fvd)
         if nudging is not None:
             plan.set_nudging(nsteps, nudging[0], nudging[1], nudging[2], nudging[3])
+            if nudging[5] is not None:
+                plan.set_nudging_successors(nudging[5])
         plan.route_device(nsteps, qts_subdivisions, assume_short_ts)
         fvd = plan.download_fvd()
         if nudging is not None:
