@@ -464,3 +464,105 @@ def test_gpu_given_depth_boundary_equals_host_restatement():
     for g, w in zip(got, want):
         assert same_bits(g, w)
     assert np.isfinite(got[2]).all() and got[2].max() > 0.3
+
+
+def long_mainstem(nmain=220, seed=4):
+    """A synthetic domain much longer than anything that fits a compute unit's LDS: `nmain` mainstem reaches in series
+    (6-8 nodes each, about 1 500 nodes) with a tributary hydrograph at every fifth junction and a mainstem side branch of
+    three reaches joining half-way down -- the layout fp_network_map produces (reaches upstream first)."""
+    rng = np.random.default_rng(seed)
+    layout = []                      # dicts n, up (1-based reach ids), ds, main
+    # side branch (mainstem): reaches 1..3
+    for k in range(3):
+        layout.append(dict(n=int(rng.integers(4, 7)), up=[k] if k else [], ds=None, main=True))
+    join = nmain // 2
+    first_main = len(layout) + 1
+    trib_of = {}
+    for k in range(nmain):
+        up = [len(layout)] if k else []
+        if k == join:
+            up = up + [3]
+        if k and k % 5 == 0:
+            trib_of[k] = None
+        layout.append(dict(n=int(rng.integers(6, 9)), up=up, ds=None, main=True))
+    # tributaries (two nodes), appended where the reference lists them: anywhere before their junction is fine for frnw
+    for k in sorted(trib_of):
+        layout.insert(0, dict(n=2, up=[], ds=None, main=False))
+        for r in layout[1:]:
+            r["up"] = [u + 1 for u in r["up"]]
+        first_main += 1
+    ntrib = len(trib_of)
+    for idx, k in enumerate(sorted(trib_of)):
+        layout[first_main - 1 + k]["up"].append(ntrib - idx)
+    nrch = len(layout)
+    for j, r in enumerate(layout):
+        for u in r["up"]:
+            layout[u - 1]["ds"] = j + 1
+    layout[-1]["ds"] = -99
+    mx = max(r["n"] for r in layout)
+    nsteps, dt = 4, 300.0
+    tfin = dt * nsteps / 3600.0
+    ts = np.zeros(10)
+    ts[[0, 1, 2, 3, 4, 5, 7, 8, 9]] = [dt, 0.0, tfin, dt, 3600.0, dt, dt, dt, 10.0]
+    para = np.array([0.95, 0.5, 10.0, 10000.0, -15.0, -10.0, 1.0, 0.02831, 0.0001, 1.0, 2.0])
+    frnw = np.zeros((nrch, 20), np.int32)
+    geo = {k: np.zeros((mx, nrch)) for k in ("z", "bo", "traps", "tw", "twcc", "mann", "manncc", "so", "dx")}
+    iniq = np.zeros((mx, nrch))
+    zbot = {}
+    for j in reversed(range(nrch)):
+        r = layout[j]
+        n = r["n"]
+        frnw[j, 0], frnw[j, 1], frnw[j, 2] = n, r["ds"], len(r["up"])
+        frnw[j, 3:3 + len(r["up"])] = r["up"]
+        frnw[j, 3 + len(r["up"])] = 555 if r["main"] else -555
+        dx = rng.uniform(300.0, 1200.0, n)
+        so = rng.uniform(2e-4, 1.5e-3, n)
+        z = np.zeros(n)
+        z[n - 1] = 2.0 if r["ds"] < 0 else zbot[r["ds"] - 1]
+        for i in range(n - 2, -1, -1):
+            z[i] = z[i + 1] + so[i] * dx[i]
+        zbot[j] = z[0]
+        bw = rng.uniform(10.0, 40.0)
+        geo["z"][:n, j], geo["dx"][:n, j], geo["so"][:n, j] = z, dx, so
+        geo["bo"][:n, j] = bw
+        geo["traps"][:n, j] = rng.uniform(1.0, 3.0)
+        geo["tw"][:n, j] = bw * 2.0
+        geo["twcc"][:n, j] = bw * 6.0
+        geo["mann"][:n, j] = 0.035
+        geo["manncc"][:n, j] = 0.07
+        iniq[:n, j] = rng.uniform(2.0, 6.0)
+    nts_ql = max(1, int(np.ceil(tfin)))
+    qlat = rng.uniform(0.0, 2e-4, (nts_ql, mx, nrch))
+    nts_qtrib = nsteps + 1
+    qtrib = np.zeros((nts_qtrib, nrch))
+    for j, r in enumerate(layout):
+        if not r["main"]:
+            qtrib[:, j] = 2.0 + np.sin(np.arange(nts_qtrib) / 3.0 + j) ** 2
+    return {"timestep_ar_g": ts, "nts_ql_g": nts_ql, "nts_ub_g": nsteps, "nts_db_g": 1, "ntss_ev_g": nsteps + 1,
+            "nts_qtrib_g": nts_qtrib, "nts_da_g": 1, "mxncomp_g": mx, "nrch_g": nrch,
+            "z_ar_g": geo["z"], "bo_ar_g": geo["bo"], "traps_ar_g": geo["traps"], "tw_ar_g": geo["tw"],
+            "twcc_ar_g": geo["twcc"], "mann_ar_g": geo["mann"], "manncc_ar_g": geo["manncc"], "so_ar_g": geo["so"],
+            "dx_ar_g": geo["dx"], "iniq": iniq, "frnw_col": 20, "frnw_g": frnw, "qlat_g": qlat,
+            "ubcd_g": np.zeros((nsteps, nrch)), "dbcd_g": np.zeros(1), "qtrib_g": qtrib, "paradim": 11, "para_ar_g": para,
+            "mxnbathy_g": 0, "x_bathy_g": np.zeros((0, mx, nrch)), "z_bathy_g": np.zeros((0, mx, nrch)),
+            "mann_bathy_g": np.zeros((0, mx, nrch)), "size_bathy_g": np.zeros((mx, nrch), np.int32),
+            "usgs_da_g": np.full((1, nrch), -4444.0), "usgs_da_reach_g": np.zeros(nrch, np.int32),
+            "rdx_ar_g": np.zeros((0, 0)), "cwnrow_g": 0, "cwncol_g": 0, "crosswalk_g": np.zeros((0, 0)),
+            "z_thalweg_g": np.zeros((0, 0))}
+
+
+@pytest.mark.gpu
+def test_gpu_long_mainstem_with_a_side_branch_equals_host_restatement():
+    """~1 500 mainstem nodes in 223 reaches (the chain state does not fit LDS: records and windows in global memory, the
+    per-node phases in three passes of the 512 threads), a mainstem junction of two mainstem reaches, tributaries at 43
+    junctions: the parallel time loop against the host instantiation (itself pinned to the reference Fortran on the
+    goldens), bit for bit; the one-wavefront kernel gives the same."""
+    from troute_amd.routing.fast_reach import diffusive as D
+    ins = long_mainstem()
+    nodes = int(ins["frnw_g"][ins["frnw_g"][np.arange(ins["nrch_g"]), 3 + ins["frnw_g"][:, 2]] == 555, 0].sum())
+    assert nodes > 1400
+    rc, want = call_c(host_oracle(), "dw_oracle_diffnw", ins)
+    assert rc == 0 and np.isfinite(want[0]).all() and np.abs(want[0]).max() > 1.0
+    got = D.compute_diffusive(ins)
+    for g, w in zip(got, want):
+        assert same_bits(g, w)
