@@ -26,6 +26,7 @@
 // skip the special-value tests of its power.
 // m.div4(n1, n2, n3, n4, d, q1, q2, q3, q4): qi = ni / d, the four correctly rounded quotients by one
 // divisor (the Muskingum coefficients) -- a policy may share the reciprocal between them;
+// (a policy whose fast_ok can be true promises with it: h > 0 and a positive wetted perimeter)
 // m.fast_ok(h, h_in, h_over) -> ok; m.div2(a1, a2, b, ok, q1, q2): qi = ai / b; m.div1(a, b, ok) = a / b: the
 // divisions of the hydraulic point, for which a policy may use a cheaper exact sequence when `ok` (its own test of
 // the operand ranges) holds.
@@ -135,15 +136,16 @@ template <class T> struct HydraulicPoint {
     bool over;     // evaluated with the flood plain active (the compound-channel branch)
 };
 
-template <class T, class M>
-MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
+// (OK: the policy's fast_ok() verdict as a compile-time constant -- the point is evaluated by one of two straight-line
+// bodies chosen by ONE branch, instead of testing the same flag at each of its six divisions and powers)
+template <class T, class M, bool OK>
+MC_HD HydraulicPoint<T> hydraulics_core(T h, Section<T> &s, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
 {
     const T c23 = T(2) / T(3), c53 = T(5) / T(3);
-    Section<T> s = section_at<T, M, false>(h, p, c, m);
     HydraulicPoint<T> hp;
     const bool over = (h > c.bfd) && c.fp_ok;
     // the hydraulic radius and the composite Manning n are quotients by the same wetted perimeter (f90:417, :329)
-    const bool ok = m.fast_ok(h, s.h_in, s.h_over);
+    const bool ok = OK;
     T n_comp;
     m.div2(s.area + s.areac, (s.wp * p.n) + (s.wpc * p.ncc), s.wp + s.wpc, ok, s.R, n_comp);
 
@@ -157,7 +159,7 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
                                   * s.area
                               + (c.s0_ncc * c53 * m.pow(h - c.bfd, c23)) * s.areac)
                                  / (s.area + s.areac));
-    } else if (h > T(0)) {
+    } else if (OK || h > T(0)) { // (fast_ok: the in-bank depth is at least 2**-30, the bottom width at least 2**-14)
         hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, s.R, c53, ok)
                                                     * m.div1(c.two_sq, p.bw + T(2) * h * c.z, ok))));
     } else {
@@ -165,10 +167,17 @@ MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const Chan
     }
     hp.km = (hp.ck > T(0)) ? mc_max(p.dt, m.divx(p.dx, hp.ck)) : p.dt;
     hp.denom = T(2) * (over ? p.twcc : s.twl) * p.s0 * hp.ck * p.dx;
-    hp.has_wp = (s.wp + s.wpc) > T(0);
+    hp.has_wp = OK || (s.wp + s.wpc) > T(0);
     hp.over = over;
     hp.q_manning = m.div1(T(1), n_comp, ok) * (s.area + s.areac) * r23 * c.sqrt_s0;
     return hp;
+}
+template <class T, class M>
+MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
+{
+    Section<T> s = section_at<T, M, false>(h, p, c, m);
+    if (m.fast_ok(h, s.h_in, s.h_over)) return hydraulics_core<T, M, true>(h, s, p, c, m);
+    return hydraulics_core<T, M, false>(h, s, p, c, m);
 }
 
 // Residual Q_mc(h) - Q_manning(h) at the hydraulic point of depth h (f90:277-332).
@@ -323,9 +332,14 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
 
     const T twl = p.bw + T(2) * c.z * h;
     const T a = (twl - p.bw) / T(2);
-    const bool okv = m.fast_ok(h, h, T(0)); // (numerator in [2**-44, 2**52], denominator in [2**-14, 2**36]: see fast_ok)
-    const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), okv);
-    out.velc = c.inv_n * m.pow_l_r(m.log_of_r(R, okv), R, T(2) / T(3), okv) * c.sqrt_s0;
+    // (numerator in [2**-44, 2**52], denominator in [2**-14, 2**36]: see fast_ok; one branch, two straight-line bodies)
+    if (m.fast_ok(h, h, T(0))) {
+        const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), true);
+        out.velc = c.inv_n * m.pow_l_r(m.log_of_r(R, true), R, T(2) / T(3), true) * c.sqrt_s0;
+    } else {
+        const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), false);
+        out.velc = c.inv_n * m.pow_l_r(m.log_of_r(R, false), R, T(2) / T(3), false) * c.sqrt_s0;
+    }
     out.depthc = h;
     out.h = h;
     out.X = k.X;
