@@ -136,6 +136,14 @@ template <class T> struct HydraulicPoint {
     bool over;     // evaluated with the flood plain active (the compound-channel branch)
 };
 
+// (h - bfd)**(2/3) of the over-bank celerity.  Under fast_ok the over-bank depth is h - bfd itself (the branch is only taken
+// with a flood plain, so the NWM-3.0 exception has not zeroed it) and lies in [2**-30, 2**17]: an ordinary number like the
+// hydraulic radius, for which the policy's power needs no special-value tests.
+template <class T, class M, bool OK> MC_HD T over_bank_pow(T x, T y, const M &m)
+{
+    if (OK) return m.pow_l_r(m.log_of_r(x, true), x, y, true);
+    return m.pow(x, y);
+}
 // (OK: the policy's fast_ok() verdict as a compile-time constant -- the point is evaluated by one of two straight-line
 // bodies chosen by ONE branch, instead of testing the same flag at each of its six divisions and powers)
 template <class T, class M, bool OK>
@@ -157,7 +165,7 @@ MC_HD HydraulicPoint<T> hydraulics_core(T h, Section<T> &s, const ChannelParams<
         hp.ck = mc_max(T(0), (c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, s.R, c53, ok)
                                                      * (c.two_sq / (p.bw + T(2) * c.bfd * c.z))))
                                   * s.area
-                              + (c.s0_ncc * c53 * m.pow(h - c.bfd, c23)) * s.areac)
+                              + (c.s0_ncc * c53 * over_bank_pow<T, M, OK>(h - c.bfd, c23, m)) * s.areac)
                                  / (s.area + s.areac));
     } else if (OK || h > T(0)) { // (fast_ok: the in-bank depth is at least 2**-30, the bottom width at least 2**-14)
         hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, s.R, c53, ok)
