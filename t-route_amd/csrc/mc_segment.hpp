@@ -173,7 +173,10 @@ MC_HD HydraulicPoint<T> hydraulics_core(T h, Section<T> &s, const ChannelParams<
     } else {
         hp.ck = T(0);
     }
-    hp.km = (hp.ck > T(0)) ? mc_max(p.dt, m.divx(p.dx, hp.ck)) : p.dt;
+    {
+        const T kq = mc_max(p.dt, m.divx(p.dx, hp.ck)); // (a zero celerity: inf or NaN, discarded)
+        hp.km = (hp.ck > T(0)) ? kq : p.dt;
+    }
     hp.denom = T(2) * (over ? p.twcc : s.twl) * p.s0 * hp.ck * p.dx;
     hp.has_wp = OK || (s.wp + s.wpc) > T(0);
     hp.over = over;
@@ -197,22 +200,23 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
 {
     const T km = hp.km;
     T x;
-    if (hp.ck > T(0)) {
+    {
+        // The weighting factor is formed whether or not the celerity is positive and selected afterwards (a zero celerity
+        // has a zero `denom`: the quotient is NaN or inf and is discarded) -- a guarded division is a divergent branch,
+        // and the guard nearly always holds.  Same for K = dx / celerity and the secant update below.
         const T denom = hp.denom;
+        T xv;
         if (!LOWER) {
-            // every solve starts with Qj_0 = 0: 0 / denom is a zero for any non-zero denom (inf included), 1 - (+-0) = 1,
-            // x = 0.5 -- no division.  (A zero or NaN denom makes the quotient NaN and takes the arithmetic below.)
             if (qj_prev == T(0) && (denom > T(0) || denom < T(0)))
-                x = T(0.5);
+                xv = T(0.5);
             else
-                x = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - m.divx(qj_prev, denom))));
+                xv = mc_min(T(0.5), mc_max(T(0), T(0.5) * (T(1) - m.divx(qj_prev, denom))));
         } else
-            x = mc_min(T(0.5),
-                       mc_max(T(0.25),
-                              T(0.5) * (T(1) - m.divx(((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4),
-                                                       denom))));
-    } else {
-        x = T(0.5);
+            xv = mc_min(T(0.5),
+                        mc_max(T(0.25),
+                               T(0.5) * (T(1) - m.divx(((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4),
+                                                        denom))));
+        x = (hp.ck > T(0)) ? xv : T(0.5);
     }
 
     const T d = (km * (T(1) - x) + c.half_dt);
@@ -224,8 +228,8 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
         if ((k.C4 < T(0)) && (mc_abs(k.C4) > w)) k.C4 = -w;
     }
 
-    if (hp.has_wp) return ((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4) - hp.q_manning;
-    return T(0);
+    const T res = ((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4) - hp.q_manning;
+    return hp.has_wp ? res : T(0);
 }
 
 // Kinematic celerity and Courant number at depth h (f90:342-367; unguarded).
@@ -293,11 +297,10 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
             any_over = any_over || at_h.over;
             const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k, m);
             T h_1;
-            if (qj_0 - qj != T(0)) {
-                h_1 = h - m.divx(qj * (h_0 - h), qj_0 - qj);
-                if (h_1 < T(0)) h_1 = h;
-            } else {
-                h_1 = h;
+            {
+                const T hq = h - m.divx(qj * (h_0 - h), qj_0 - qj); // (equal residuals: NaN or inf, discarded)
+                h_1 = (qj_0 - qj != T(0)) ? hq : h;
+                h_1 = (h_1 < T(0)) ? h : h_1;
             }
             if (h > T(0)) {
                 const T dh = mc_abs(h_1 - h);
