@@ -100,9 +100,10 @@ MC_HD Section<T> section_at(T h, const ChannelParams<T> &p, const ChannelConst<T
     s.twl = p.bw + T(2) * c.z * h;
     s.h_over = mc_max(h - c.bfd, T(0));
     s.h_in = mc_min(c.bfd, h);
-    if (s.h_over > T(0) && p.twcc <= T(0)) { // NWM 3.0: no flood plain -> extend trapezoid
-        s.h_over = T(0);
-        s.h_in = h;
+    {
+        const bool extend = s.h_over > T(0) && p.twcc <= T(0); // NWM 3.0: no flood plain -> extend trapezoid
+        s.h_over = extend ? T(0) : s.h_over;
+        s.h_in = extend ? h : s.h_in;
     }
     s.area = (p.bw + s.h_in * c.z) * s.h_in;
     s.wp = p.bw + T(2) * s.h_in * c.sq1pz2;
@@ -225,7 +226,7 @@ MC_HD T secant_residual(const HydraulicPoint<T> &hp, T qj_prev, const ChannelPar
     k.X = x;
     if (LOWER) {
         const T w = (k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp);
-        if ((k.C4 < T(0)) && (mc_abs(k.C4) > w)) k.C4 = -w;
+        k.C4 = ((k.C4 < T(0)) && (mc_abs(k.C4) > w)) ? -w : k.C4;
     }
 
     const T res = ((k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp) + k.C4) - hp.q_manning;
@@ -302,18 +303,13 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
                 h_1 = (qj_0 - qj != T(0)) ? hq : h;
                 h_1 = (h_1 < T(0)) ? h : h_1;
             }
-            if (h > T(0)) {
+            {
                 const T dh = mc_abs(h_1 - h);
-                aerror = dh;
-                if (dh > T(0.010001) * h)
-                    rel_open = true;
-                else if (dh < T(0.009999) * h)
-                    rel_open = false;
-                else
-                    rel_open = mc_abs((h_1 - h) / h) > T(0.01);
-            } else {
-                rel_open = false; // rerror = 0
-                aerror = T(0.9);
+                const bool hi = dh > T(0.010001) * h, lo = dh < T(0.009999) * h;
+                bool open = hi;
+                if (!hi && !lo) open = mc_abs((h_1 - h) / h) > T(0.01); // (the band around the threshold, or a NaN: rare)
+                rel_open = (h > T(0)) ? open : false;                     // h = 0: rerror = 0
+                aerror = (h > T(0)) ? dh : T(0.9);
             }
             at_h0 = at_h;
             h_0 = mc_max(T(0), h);
@@ -332,13 +328,10 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
     }
 
     const T w3 = (k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp);
-    if ((w3 + k.C4) < T(0)) {
-        if ((k.C4 < T(0)) && (mc_abs(k.C4) > w3))
-            out.qdc = T(0);
-        else
-            out.qdc = mc_max(((k.C1 * f.qup) + (k.C2 * f.quc) + k.C4), ((k.C1 * f.qup) + (k.C3 * f.qdp) + k.C4));
-    } else {
-        out.qdc = w3 + k.C4;
+    {   // (f90:126-141; all three candidates are a few additions: formed, then selected)
+        const T q_neg = mc_max(((k.C1 * f.qup) + (k.C2 * f.quc) + k.C4), ((k.C1 * f.qup) + (k.C3 * f.qdp) + k.C4));
+        const T q_lo = ((k.C4 < T(0)) && (mc_abs(k.C4) > w3)) ? T(0) : q_neg;
+        out.qdc = ((w3 + k.C4) < T(0)) ? q_lo : w3 + k.C4;
     }
 
     const T twl = p.bw + T(2) * c.z * h;
