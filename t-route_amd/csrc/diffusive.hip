@@ -436,8 +436,8 @@ template <bool ALL, int WR>
 __device__ __forceinline__ void chain_lookup(const trdw::Problem &p, const ChainLds &L, const WaveScan &ws, WinRegs<WR> &W, int i, int j, double elv,
                                              double &conv, double &dKdA, double &topw)
 {
-    if (W.w0 >= 0 && W.xe[0] < elv && elv < W.xe[WR - 1]) {
-        if (!(W.xa <= elv && elv < W.xb)) { // the look-up moved to another interval of the window
+    if (DW_UNIFORM(W.w0 >= 0 && W.xe[0] < elv && elv < W.xe[WR - 1])) {
+        if (DW_UNIFORM(!(W.xa <= elv && elv < W.xb))) { // the look-up moved to another interval of the window
             int c = 0;
 #pragma unroll
             for (int r = 0; r < WR; ++r) c += W.xe[r] <= elv ? 1 : 0;

@@ -642,6 +642,14 @@ DW_HD inline DepthPre depth_pre(const Problem &p, const Scan &scan, const double
     d.df_mid = 1.0 + (fabs(Q_cur) * Q_cur / (conv[2] * conv[2] * conv[2])) * d.dxi * topw[2] * dKdA[2];
     return d;
 }
+// A condition every lane of the wavefront agrees on (depth_solve is only ever run by all lanes in step: the serial host
+// loop, the one-wavefront kernel, the chain of the parallel kernel): on the device it is made a SCALAR condition, so that the
+// branch is a scalar branch instead of an exec-mask region.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DW_UNIFORM(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#else
+#define DW_UNIFORM(c) (c)
+#endif
 // F: (y_cur) -> Depth, the function evaluation of an iteration (a table search and three rows)
 template <class F> DW_HD inline double depth_solve(const DepthPre &d, double sf_ds, double y_ds, const F &eval)
 {
@@ -653,31 +661,29 @@ template <class F> DW_HD inline double depth_solve(const DepthPre &d, double sf_
     // midpoint only when the bracket holds; its value is not used otherwise)
     const double fl = x1 - y_ds + d.slope * d.dxi - 0.50 * (d.sf[0] + sf_ds) * d.dxi;
     const double fh = x2 - y_ds + d.slope * d.dxi - 0.50 * (d.sf[1] + sf_ds) * d.dxi;
-    if ((fl > 0.0 && fh > 0.0) || (fl < 0.0 && fh < 0.0)) return d.y_norm;
-    if (fl == 0.0) return x1;
-    if (fh == 0.0) return x2;
-    double xl, xh;
-    if (fl < 0.0) { xl = x1; xh = x2; } else { xh = x1; xl = x2; }
+    if (DW_UNIFORM((fl > 0.0 && fh > 0.0) || (fl < 0.0 && fh < 0.0))) return d.y_norm;
+    if (DW_UNIFORM(fl == 0.0)) return x1;
+    if (DW_UNIFORM(fh == 0.0)) return x2;
+    const bool up = fl < 0.0;
+    double xl = up ? x1 : x2, xh = up ? x2 : x1;
     double dxold = fabs(x2 - x1), dxx = dxold;
     Depth dd;
     dd.f = rt - y_ds + d.slope * d.dxi - 0.50 * (d.sf[2] + sf_ds) * d.dxi;
     dd.df = d.df_mid;
     for (int iter = 1; iter <= maxit; ++iter) {
-        if (((rt - xh) * dd.df - dd.f) * ((rt - xl) * dd.df - dd.f) > 0.0 || fabs(2.0 * dd.f) > fabs(dxold * dd.df)) {
-            dxold = dxx;
-            dxx = 0.50 * (xh - xl);
-            rt = xl + dxx;
-            if (xl == rt) return rt;
-        } else {
-            dxold = dxx;
-            dxx = dd.f / dd.df;
-            const double temp = rt;
-            rt = rt - dxx;
-            if (temp == rt) return rt;
-        }
-        if (fabs(dxx) < xacc) return rt;
+        // bisection step or Newton step: both candidates are formed (the quotient is needed nearly every time), one selected
+        const bool bis = ((rt - xh) * dd.df - dd.f) * ((rt - xl) * dd.df - dd.f) > 0.0 || fabs(2.0 * dd.f) > fabs(dxold * dd.df);
+        const double dx_b = 0.50 * (xh - xl), dx_n = dd.f / dd.df;
+        dxold = dxx;
+        dxx = bis ? dx_b : dx_n;
+        const double rt_new = bis ? xl + dxx : rt - dxx;
+        const bool stuck = bis ? xl == rt_new : rt == rt_new;
+        rt = rt_new;
+        if (DW_UNIFORM(stuck || fabs(dxx) < xacc)) return rt;
         dd = eval(rt);
-        if (dd.f < 0.0) xl = rt; else xh = rt;
+        const bool neg = dd.f < 0.0;
+        xl = neg ? rt : xl;
+        xh = neg ? xh : rt;
     }
     return d.y_norm;
 }
