@@ -1089,7 +1089,7 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
     float *const out_row = a.out + (size_t)a.row_of_pos[su] * (size_t)a.nsteps * 3;
 
     float q_prev = 0.0f, d_prev = 0.0f, ql = 0.0f, xp0 = 0.0f, xp1 = 0.0f;
-    int32_t ql_col = -1, staged = 0, it_acc = 0, it_last = 0;
+    int32_t ql_col = -1, ql_left = 0, staged = 0, it_acc = 0, it_last = 0;
     bool have_state = false, dead = false;
 
     for (int32_t k = 0;; ++k) {
@@ -1109,13 +1109,18 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
                 if (e0.u >= 0) xp0 = flow_wait(g_prev + e0.u, tag_p, a, dead);
                 if (e1.u >= 0) xp1 = flow_wait(g_prev + e1.u, tag_p, a, dead);
             }
+            // the lateral-inflow column of step t is (t - 1) / qts: found by division once, by a counter from then on
+            ql_col = (t - 1) / a.qts;
+            ql_left = a.qts - (t - 1) % a.qts;
+            ql = a.qlat_tm[(size_t)ql_col * np + su];
             have_state = true;
         }
-        const int32_t col = (t - 1) / a.qts;
-        if (col != ql_col) {
-            ql = a.qlat_tm[(size_t)col * np + su];
-            ql_col = col;
+        if (ql_left == 0) {
+            ++ql_col;
+            ql = a.qlat_tm[(size_t)ql_col * np + su];
+            ql_left = a.qts;
         }
+        --ql_left;
         // junction sums in the reference's order (mc_reach.pyx:499-502): with assume_short_ts the upstream flows of
         // step t - 1 (they are also `quc`, :504-505), without it those of step t and -- kept from the round before --
         // of step t - 1
@@ -1357,12 +1362,21 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
     __hip_atomic_store(s_ring + (size_t)((t_lo - 1) & (kLeanRing - 1)) * kFlowBlock + threadIdx.x,
                        ((unsigned long long)(a.tag_base + (uint32_t)(t_lo - 1)) << 32) | (unsigned long long)__float_as_uint(q_prev),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    float ql = 0.0f;
+    // the lateral-inflow column of step t is (t - 1) / qts: the first one is read now, the next ones as the counter runs out
+    int32_t ql_col = (t_lo - 1) / a.qts;
+    int32_t ql_left = a.qts - (t_lo - 1) % a.qts;
+    float ql = a.qlat_tm[(size_t)ql_col * np + su];
+    ++ql_col;
     uint32_t its = 0; // iterations: low 24 bits the sum of min(iterations, 3), high 8 bits those of the last step
     for (int32_t t = t_lo; t <= t_hi && !dead; ++t) {
         const uint32_t tag_p = a.tag_base + (uint32_t)(t - 1);
         const unsigned long long *g_prev = a.gran + (size_t)(t - 1) * np;
-        if (t == t_lo || (t - 1) % a.qts == 0) ql = a.qlat_tm[(size_t)((t - 1) / a.qts) * np + su];
+        if (ql_left == 0) { // (a counter, not (t - 1) % qts and (t - 1) / qts: two integer divisions per step otherwise)
+            ql = a.qlat_tm[(size_t)ql_col * np + su];
+            ql_left = a.qts;
+            ++ql_col;
+        }
+        --ql_left;
         if ((t & 15) == 0) flags &= ~5u; // a producer that ran ahead may have been caught up with: try the ring again
         // junction sum in the reference's order (mc_reach.pyx:499-505)
         float qup = 0.0f;
