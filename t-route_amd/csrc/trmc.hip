@@ -340,8 +340,9 @@ constexpr int kStepBlock = TRMC_STEP_BLOCK;
 #endif
 template <class T, bool SHORT, int IPT, bool SORT = true, bool LAG = false>
 __global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES)
-k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag)
-{
+k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag, const int32_t ql_col)
+{   // ql_col: the lateral-inflow column (diag - 1) / qts of a launch whose rows are all at step diag (SHORT, no lag) -- formed
+    // by the host: an integer division by a run-time divisor is some 35 instructions per thread
     using M = typename DevMath<T>::type;
     constexpr int kChunk = IPT * kStepBlock;
     constexpr int kWaves = kStepBlock / 64;
@@ -460,7 +461,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         trmc::Inflow<T> f;
         f.qdp = at(q_prev, ob);
         const T depthp = at(a.d_tm + row_p, ob);
-        f.ql = at(a.qlat_tm + (size_t)((t - 1) / a.qts) * (size_t)a.nseg_pad, ob);
+        f.ql = at(a.qlat_tm + (size_t)((SHORT && !LAG) ? ql_col : (t - 1) / a.qts) * (size_t)a.nseg_pad, ob);
 
         // junction sums in the reference's order (mc_reach.pyx:499-502).  The first two upstream positions of a row
         // sit in a table of their own (-1 = none; bit 30 of the second = "the CSR list has more"): one load beside
@@ -1731,13 +1732,13 @@ inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_
     const bool sort = a.partition && n >= TRMC_SORT_MIN;
     if (SHORT && a.lag) {
         if (sort)
-            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, true, SHORT>), grid, block, 0, st, a, s0, s1, d);
+            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, true, SHORT>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
         else
-            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false, SHORT>), grid, block, 0, st, a, s0, s1, d);
+            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false, SHORT>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
     } else if (sort)
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), grid, block, 0, st, a, s0, s1, d);
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
     else
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), grid, block, 0, st, a, s0, s1, d);
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
 }
 
 // A routing window runs in three parts so that a caller can interleave other device work (the multi-GPU
