@@ -361,9 +361,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // narrow slices (a few blocks per launch) are latency-bound: the partition's loads and barriers
         // would only lengthen the critical path, so positions are visited in plan order
         static_assert(SORT || IPT == 1, "the unsorted form handles one position per thread");
-        s_perm[threadIdx.x] = (uint16_t)threadIdx.x;
-        n_work = min(kChunk, s_end - base);
-        __syncthreads();
+        n_work = min(kChunk, s_end - base); // (no permutation to publish: thread w takes position base + w)
     } else {
     // ---- class of my IPT items, per-wave counts -------------------------------------------------
     int32_t cls[IPT], rank[IPT];
@@ -421,7 +419,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     for (int pass = 0; pass < IPT; ++pass) {
         const int32_t w = pass * kStepBlock + (int32_t)threadIdx.x;
         if (w >= n_work) break;
-        const int32_t s = base + (int32_t)s_perm[w];
+        const int32_t s = base + (SORT ? (int32_t)s_perm[w] : w);
         const int32_t t = SHORT ? (LAG ? diag - a.lag[s] : diag) : diag - a.level[s];
         if ((!SORT || LAG) && (t < 1 || t > a.nsteps)) continue;
 
