@@ -1684,7 +1684,13 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.lag = pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr;
     a.it_prev = (uint8_t *)pl->it_prev.p;
     a.it_sum = pl->collect_cost ? (uint16_t *)pl->it_sum.p : nullptr;
-    a.partition = !pl->hinted;
+    // The per-block partition by iteration class used to pay on a plan without a cost hint (round 1: 26.1 ms against more
+    // without it); since the step got cheaper in its control flow (round 2) its 60 instructions and three barriers cost
+    // more than the mixed wavefronts they avoid: CONUS day 23.0 ms with it, 21.7 ms in plain plan order.  Off unless asked for.
+    {
+        static const bool want = [] { const char *e = std::getenv("TRMC_STEP_PARTITION"); return e && e[0] == '1'; }();
+        a.partition = want && !pl->hinted;
+    }
     a.sane = pl->params_sane;
     a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
     a.res_par = (const T *)pl->res_par.p;
