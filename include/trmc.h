@@ -115,7 +115,7 @@ int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *
  *                                wavefront diagonal (k_mc_step); the only engine of precision-64 plans
  *           TRMC_ENGINE_FLOW     dataflow engine (precision 32): rows in block order, one persistent launch per window,
  *                                rows exchange flows through tagged granules (k_mc_flow)
- *           TRMC_ENGINE_AUTO     flow, except for a precision-32 plan of 500 000 routed rows or more that is meant for
+ *           TRMC_ENGINE_AUTO     flow, except for a precision-32 plan of 1 000 000 routed rows or more that is meant for
  *                                assume_short_ts: there every launch fills the device many times over and wavefronts
  *                                that are uniform in cost across a whole level outweigh the launch boundaries
  *   mode    TRMC_PLAN_SHORT_TS / TRMC_PLAN_FULL_TS: the assume_short_ts value the plan will be routed with, if the caller

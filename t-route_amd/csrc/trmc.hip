@@ -2329,7 +2329,7 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
             else {
                 int64_t nb = 0;
                 for (int64_t r = 0; boundary && r < nseg; ++r) nb += boundary[r] != 0;
-                engine = ((flags & TRMC_PLAN_SHORT_TS) && nseg - nb >= 500000) ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
+                engine = ((flags & TRMC_PLAN_SHORT_TS) && nseg - nb >= 1000000) ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
             }
         }
         pl->flow = engine == TRMC_ENGINE_FLOW;

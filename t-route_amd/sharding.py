@@ -11,6 +11,8 @@ nhd_network.py:691-771; hand-off compute.py:882-897): sub-basins run first
 (phase 0), their outlet hydrographs become prescribed boundary rows of the
 trunk (phase 1).  No collective is needed inside a phase.
 """
+import os
+
 import numpy as np
 
 
@@ -60,6 +62,16 @@ def lpt_assign(sizes, nparts, initial_load=None):
         part[i] = p
         load[p] += sizes[i]
     return part, load
+
+
+def _trunk_share(nseg, nparts):
+    """Fraction of a rank's share a trunk's owner is spared beyond the trunk itself: 2/15 where the ranks run the dataflow
+    engine (under a million rows each: balanced at N = 4 and 8), 0.23 where they run the level engine, whose owner also pays
+    the draining launches of the skewed trunk at full width (N = 2: the owner was 8 % slower than its peer with 2/15)."""
+    env = os.environ.get("TRMC_TRUNK_SHARE")
+    if env:
+        return float(env)
+    return 0.23 if nseg / max(nparts, 1) >= 1.0e6 else 2.0 / 15.0
 
 
 def partition(to, nparts, max_piece_frac=None, row_cost=None):
@@ -132,7 +144,7 @@ def partition(to, nparts, max_piece_frac=None, row_cost=None):
         p1 = np.flatnonzero(phase == 1)
         if p1.size:
             owner[p1], trunk_load = lpt_assign(weight[p1], nparts)
-            bias = 5 * trunk_load + np.where(trunk_load > 0, int(2 * weight.sum() / (15 * nparts)), 0)
+            bias = 5 * trunk_load + np.where(trunk_load > 0, int(_trunk_share(nseg, nparts) * weight.sum() / nparts), 0)
         p0 = np.flatnonzero(phase == 0)
         owner[p0], _ = lpt_assign(weight[p0], nparts, bias)
         return {
@@ -149,7 +161,7 @@ def partition(to, nparts, max_piece_frac=None, row_cost=None):
     p1 = np.flatnonzero(phase == 1)
     if p1.size:
         owner[p1], trunk_load = lpt_assign(sizes[p1], nparts)
-        bias = 5 * trunk_load + np.where(trunk_load > 0, 2 * nseg // (15 * nparts), 0)
+        bias = 5 * trunk_load + np.where(trunk_load > 0, int(_trunk_share(nseg, nparts) * nseg / nparts), 0)
     p0 = np.flatnonzero(phase == 0)
     owner[p0], load0 = lpt_assign(sizes[p0], nparts, bias)
     return {
