@@ -249,9 +249,10 @@ class ShardedRouter:
         if assume_short_ts:
             # time chunks of the hand-off pipeline: a launch per chunk.  The level engine launches per timestep anyway
             # and wants the trunk's skew (two chunks) short; the dataflow engine runs a chunk as one persistent launch
-            # and wants few of them (8 chunks of 36 steps: 4.9 ms per 349 k-row rank against 5.7 ms with 24)
+            # and wants few of them (349 k-row ranks: 5.7 ms with 24 chunks, 4.5 with 8, 4.3 with 4 of 72 steps -- every
+            # launch ends in a drain; with 2 or 3 the trunk's owner, who trails by two chunks, is the slowest rank again)
             if nchunks is None:
-                nchunks = 8 if getattr(self.plan0, "engine", "levels") == "flow" else 24
+                nchunks = 4 if getattr(self.plan0, "engine", "levels") == "flow" else 24
             return self._route_skewed(qts_subdivisions, all_gather_into, nchunks)
         if not getattr(self, "_plan0_staged", True):
             raise RuntimeError("this router continued from the state of its merged (short-timestep) plan; upload() the "

@@ -65,13 +65,17 @@ def lpt_assign(sizes, nparts, initial_load=None):
 
 
 def _trunk_share(nseg, nparts):
-    """Fraction of a rank's share a trunk's owner is spared beyond the trunk itself: 2/15 where the ranks run the dataflow
-    engine (under a million rows each: balanced at N = 4 and 8), 0.23 where they run the level engine, whose owner also pays
-    the draining launches of the skewed trunk at full width (N = 2: the owner was 8 % slower than its peer with 2/15)."""
+    """Fraction of a rank's share a trunk's owner is spared beyond the trunk itself, fitted on the ranks of 8-, 4- and 2-way
+    CONUS partitions timed one by one (tools/sim_ranks.py).  Ranks on the dataflow engine (under a million rows each) route a
+    window in four time chunks and the owner's skewed trunk drains for two of them: 0.3 where a rank's blocks are all
+    resident (under 400 k rows, N = 8: with 0.18 the owner was the slowest rank by 10 %), 0.2 where they run in rounds
+    (N = 4: with 0.3 the owner finished 0.6 ms ahead of peers that carried its rows).  0.23 on the level engine, whose
+    owner also pays the draining launches of the skewed trunk at full width (N = 2)."""
     env = os.environ.get("TRMC_TRUNK_SHARE")
     if env:
         return float(env)
-    return 0.23 if nseg / max(nparts, 1) >= 1.0e6 else 2.0 / 15.0
+    per_rank = nseg / max(nparts, 1)
+    return 0.23 if per_rank >= 1.0e6 else (0.2 if per_rank >= 4.0e5 else 0.3)
 
 
 def partition(to, nparts, max_piece_frac=None, row_cost=None):
@@ -135,7 +139,7 @@ def partition(to, nparts, max_piece_frac=None, row_cost=None):
         # are the deepest, most tightly coupled rows of the network (every step of theirs waits for the step before, with
         # little else to fill the device), and the time-skewed trunk drains for two time chunks after the rank's other
         # rows are done.  Timed rank by rank (tools/sim_ranks.py, 8-, 4- and 2-way CONUS partitions, both engines) the
-        # owner needs to be spared about five times the trunk's measured cost plus 2/15 of a rank's share -- with the
+        # owner needs to be spared about five times the trunk's measured cost plus a fraction of a rank's share (_trunk_share) -- with the
         # trunk weighed at its measured cost only, the owner was the slowest rank by 15-20 % at every N.
         c = np.maximum(np.asarray(row_cost, dtype=np.float64), 1.0)
         c = c * (1000.0 / c.mean())
@@ -156,7 +160,7 @@ def partition(to, nparts, max_piece_frac=None, row_cost=None):
     # should be spared (fitted on ranks of an 8-, 4- and 2-way CONUS partition timed one by one): its own rows,
     # deep in the network and among the costly ones, five times over, plus the launches that drain the time-skewed trunk
     # at the end of a window (2 of the default 24 chunks; a partly filled GPU gains less than proportionally from
-    # having fewer rows, hence 2/15 of the rank's share rather than 1/12).
+    # having fewer rows; the fraction of a rank's share is _trunk_share, refitted when the chunk counts changed).
     bias = np.zeros(nparts, dtype=np.int64)
     p1 = np.flatnonzero(phase == 1)
     if p1.size:

@@ -147,12 +147,12 @@ def test_import_pins_one_hardware_queue_per_stream_priority():
 
 
 def test_trunk_owner_share_follows_the_engine_of_the_ranks(monkeypatch):
-    """What a trunk's owner is spared beyond the trunk itself (sharding._trunk_share): 2/15 of a share where ranks hold
-    fewer than a million rows (dataflow engine, TRMC_ENGINE_AUTO), 0.23 where they hold more (level engine);
+    """What a trunk's owner is spared beyond the trunk itself (sharding._trunk_share): 0.3 / 0.2 of a share where ranks hold
+    fewer than 400 k / a million rows (dataflow engine, TRMC_ENGINE_AUTO), 0.23 where they hold more (level engine);
     TRMC_TRUNK_SHARE overrides; the bias a partition reports is built from it."""
     monkeypatch.delenv("TRMC_TRUNK_SHARE", raising=False)
-    assert sharding._trunk_share(2_729_077, 8) == pytest.approx(2.0 / 15.0)
-    assert sharding._trunk_share(2_729_077, 4) == pytest.approx(2.0 / 15.0)
+    assert sharding._trunk_share(2_729_077, 8) == pytest.approx(0.3)
+    assert sharding._trunk_share(2_729_077, 4) == pytest.approx(0.2)
     assert sharding._trunk_share(2_729_077, 2) == pytest.approx(0.23)
     net = synthetic.generate(nseg=60000, nnet=300, seed=5)
     to = net["to"]
@@ -160,7 +160,7 @@ def test_trunk_owner_share_follows_the_engine_of_the_ranks(monkeypatch):
     owners = np.unique(part["owner"][part["phase"] == 1])
     assert owners.size >= 1
     trunk_rows = np.bincount(part["owner"][part["phase"] == 1], weights=part["piece_sizes"][part["phase"] == 1], minlength=4)
-    want = 5 * trunk_rows + np.where(trunk_rows > 0, int(2.0 / 15.0 * to.shape[0] / 4), 0)
+    want = 5 * trunk_rows + np.where(trunk_rows > 0, int(0.3 * to.shape[0] / 4), 0)
     assert np.array_equal(part["owner_bias"], want.astype(np.int64))
     monkeypatch.setenv("TRMC_TRUNK_SHARE", "0.5")
     assert sharding._trunk_share(10, 2) == 0.5

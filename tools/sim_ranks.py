@@ -5,7 +5,7 @@ The cut-edge hydrographs a rank would receive from its peers are taken from a co
 (so the trunk sees its true inflows); the collective is an in-process copy.  Reports, per rank, the wall
 time of route_on_device -- the job time of the real N-GPU run is about the maximum (plus RCCL latency).
 
-    python tools/sim_ranks.py --world 8 [--chunks 8] [--full-ts]
+    python tools/sim_ranks.py --world 8 [--chunks 4] [--full-ts]
 """
 import argparse
 import os
@@ -83,7 +83,7 @@ def main():
                 idx[m] = np.arange(int(m.sum()))
             peers[torch.from_numpy(r.cut_owner.astype(np.int64)).to(dev), torch.from_numpy(idx).to(dev)] = \
                 torch.from_numpy(cut_q).to(dev)
-        default_chunks = 8 if getattr(r.plan0, "engine", "levels") == "flow" else 24     # route_on_device's defaults
+        default_chunks = 4 if getattr(r.plan0, "engine", "levels") == "flow" else 24     # route_on_device's defaults
         nchunks_eff = (a.chunks if a.chunks else default_chunks) if short else (a.chunks if a.chunks else 1)
         state = {"t": 0, "call": 0}
 
