@@ -8,8 +8,8 @@ One "step" = one pass of the hot path over one batch of synthetic input: routing
 whole seeded synthetic CONUS network (2 729 077 segments, 14 713 independent networks,
 troute_amd/synthetic.py) for one forcing window of 288 x 300 s timesteps with the
 reference's configured assume_short_ts=True (test/LowerColorado_TX/test_AnA.yaml:32),
-fp32 (the reference's arithmetic type), cold start -- forcing and topology already
-resident in HBM when the timed region starts, results (incl. the gathered outlet hydrographs) left in HBM in the reference's
+fp32 (the reference's arithmetic type), warm start from the state the day before leaves in HBM -- forcing and topology
+already resident in HBM when the timed region starts, results (incl. the gathered outlet hydrographs) left in HBM in the reference's
 [segment][timestep][q,v,d] layout.
 
 Three consecutive days: day N-1 spins the network up from a cold start, the plan is tuned on day N (untimed) and TIMED on
@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-retune", action="store_true",
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
+    ap.add_argument("--no-parity-sample", action="store_true", help="skip the post-timing oracle check of sampled networks")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: one per CPU the cgroup grants, at most the physical cores)")
@@ -145,6 +146,50 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
         "order_seconds": [round(x, 2) for x in O.cpu_baseline_route.order_seconds],
         "_check": (q[:, ns], d),
     }
+
+
+def parity_sample(net, router, days, q0, nsteps, qts, n_networks=50, seed=20250930):
+    """Checker, run AFTER the timed region: ~50 whole independent networks of the workload (10-3 000 segments each) are
+    routed alone by the oracle (oracle/, the CPU restatement pinned to the reference Fortran) through the same sequence
+    of windows the router has been through -- `days`: the forcing of day N-1 (cold start from q0), day N, day N+1 -- and
+    compared bit for bit with what the timed plan holds for them after the LAST timed window: the hydrograph of every
+    sampled row and the final state.  Independent networks do not interact, so the sub-collection's result inside the
+    2.7 M-row run must equal its result alone."""
+    from oracle import oracle as O
+    from troute_amd import sharding
+    from troute_amd.distributed import restrict_csr
+    from troute_amd.plan import topology_levels
+    from troute_amd.synthetic import upstream_csr
+    to, params = net["to"], net["params"]
+    nseg = to.shape[0]
+    rng = np.random.default_rng(seed)
+    outlet = sharding.outlet_of(to)
+    _, lab = np.unique(outlet, return_inverse=True)
+    sizes = np.bincount(lab)
+    cand = np.flatnonzero((sizes >= 10) & (sizes <= 3000))
+    pick = rng.choice(cand, min(n_networks, cand.size), replace=False)
+    rows = np.flatnonzero(np.isin(lab, pick))
+    t0 = time.perf_counter()
+    hyd = router.plan0.gather_flow_rows(rows)           # (world == 1: the plan's rows are the network's rows)
+    final = router.plan0.download_final_state()[rows]
+    up_ptr, up_idx = upstream_csr(to)
+    g2l = np.full(nseg, -1, np.int64)
+    g2l[rows] = np.arange(rows.size)
+    lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)
+    lvl, _, _ = topology_levels(lp, li)
+    state = np.ascontiguousarray(q0[rows])
+    want = None
+    for ql in days:
+        want = O.network_by_segment(nsteps, qts, lp, li, lvl, params[rows], state, np.ascontiguousarray(ql[rows]), True, det=True)
+        state = np.ascontiguousarray(want[:, -1, :][:, [0, 0, 2]])
+    u32 = lambda x: np.ascontiguousarray(x).view(np.uint32)   # noqa: E731
+    same_h = bool(np.array_equal(u32(hyd), u32(want[:, 1:, 0])))
+    same_s = bool(np.array_equal(u32(final), u32(state)))
+    return {"networks": int(pick.size), "segments": int(rows.size), "windows": len(days), "timesteps": int(nsteps),
+            "bit_identical": same_h and same_s, "hydrographs_identical": same_h, "final_state_identical": same_s,
+            "differing_values": int((u32(hyd) != u32(want[:, 1:, 0])).sum() + (u32(final) != u32(state)).sum()),
+            "checker": "oracle/ (C restatement pinned to the reference Fortran), det_pow instantiation",
+            "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def _diffusive_inputs(gold, nsteps):
@@ -414,6 +459,12 @@ def main():
     else:
         hyd = hyd.cpu().numpy()
     assert np.isfinite(hyd).all()
+    parity = None
+    if rank == 0 and world == 1 and not a.no_parity_sample and a.precision == 32:
+        try:      # what the timed plan holds after the last timed window, against the oracle (checker use, outside the clock)
+            parity = parity_sample(net, router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts)
+        except Exception as e:
+            parity = {"error": repr(e)}
     value = rate(head)
     info = router.plan0.info()
     stats = head["stats"]
@@ -528,6 +579,7 @@ def main():
                 "ms_main": head["ms_main"], "ms_total_device": head["ms_total"],
             },
             "cpu_baseline": cpu,
+            "parity_sample": parity,
             "untuned": untuned,
             "full_ts": full,
             "per_rank": per_rank,
@@ -566,7 +618,7 @@ def pmc_traffic(engine, args):
                 out = os.path.join(td, counter)
                 cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "c", "--", sys.executable,
                        os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-full-ts",
-                       "--no-diffusive", "--no-parity-mode", "--no-traffic", "--nsteps", str(args.nsteps), "--qts", str(args.qts),
+                       "--no-diffusive", "--no-parity-mode", "--no-traffic", "--no-parity-sample", "--nsteps", str(args.nsteps), "--qts", str(args.qts),
                        "--precision", str(args.precision)]
                 if args.nseg:
                     cmd += ["--nseg", str(args.nseg)]

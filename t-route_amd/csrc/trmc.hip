@@ -289,9 +289,8 @@ template <class T> struct StepArgs {
     const int32_t *lag; // LAG form of the short-timestep kernel: position s is at step diag - lag[s]
     const T *qlat_tm;
     T *q_tm, *v_tm, *d_tm;
-    uint8_t *it_prev; // secant iterations each position needed on its previous step
+    uint8_t *it_prev; // secant iterations each position needed on the LAST step of the window (trmc_download_iterations)
     uint16_t *it_sum; // nullptr, or: sum over the window of min(iterations, 3) per position (trmc_plan_collect_cost)
-    bool partition;   // blocks partition their rows by iteration class (off when the plan order already groups them)
     bool sane;        // every channel parameter of the plan lies in the range DevMathF::fast_ok's argument needs
     // level-pool reservoirs (nullptr = none): reservoir index of a position, parameters [nres][9],
     // inflow series [nres][nsteps] (the reference's upstream_array rows), routing period
@@ -314,20 +313,17 @@ template <class T> struct StepArgs {
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
-// positions [s_begin, s_end).
+// positions [s_begin, s_end); thread w of the launch takes position s_begin + w.
 //
-// Divergence control.  The secant loop runs 0 (no flow), 1 (depth below the 1 cm floor: early
-// exit, f90:120-122), 2 (wet channel) or, rarely, 3+ iterations per segment-step, and a segment
-// repeats its count from one step to the next 99.3 % of the time.  In plan order a 64-lane wave
-// nearly always holds a 2-iteration lane (mean wave cost 2.5 iterations against a lane mean of
-// 1.44).  Each block therefore owns IPT*256 consecutive positions, reads the iteration count
-// every one of them needed on its previous step (one byte, `it_prev`), and stably partitions its
-// items by that class in LDS before touching anything else; wave-pass p then works on items
-// perm[p*256 + tid], which are of one class except at class boundaries.  Results do not depend on
-// the order items are visited in.
-#ifndef TRMC_STEP_BLOCK // threads per block of the step kernel = positions partitioned together (measured on MI355X,
-// CONUS: 64 -> 100.4 us per launch, 128 -> 97.2, 192 -> 99.1, 256 -> 100.2, 512 -> 115.5, 1024 -> 132: small blocks
-// free their wave slots sooner once the partition has made wave run times unequal)
+// Divergence control is the PLAN's business, not the kernel's: the secant loop runs 0 (no flow), 1 (depth below
+// the 1 cm floor: early exit, f90:120-122), 2 (wet channel) or, rarely, 3+ iterations per segment-step, a segment
+// repeats its count from one step to the next 99.3 % of the time, and a plan built with a cost hint
+// (trmc_plan_create_hinted) stores the rows of a level grouped by that cost, so that a wavefront holds rows of one
+// class.  (Rounds 1-2 also carried a per-block partition by the previous step's class for plans without a hint --
+// ballots, a shuffle scan and three barriers; since the step's control flow got cheaper it cost more than the mixed
+// wavefronts it avoided, 23.0 against 21.7 ms per CONUS day, and it is gone.)
+#ifndef TRMC_STEP_BLOCK // threads per block of the step kernel (measured on MI355X, CONUS: 64 -> 100.4 us per launch,
+// 128 -> 97.2, 192 -> 99.1, 256 -> 100.2, 512 -> 115.5, 1024 -> 132: small blocks free their wave slots sooner)
 #define TRMC_STEP_BLOCK 128
 #endif
 constexpr int kStepBlock = TRMC_STEP_BLOCK;
@@ -338,90 +334,21 @@ constexpr int kStepBlock = TRMC_STEP_BLOCK;
 #ifndef TRMC_EXPERIMENT_WAVES
 #define TRMC_EXPERIMENT_WAVES 1
 #endif
-template <class T, bool SHORT, int IPT, bool SORT = true, bool LAG = false>
+template <class T, bool SHORT, bool LAG = false>
 __global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES)
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag, const int32_t ql_col)
 {   // ql_col: the lateral-inflow column (diag - 1) / qts of a launch whose rows are all at step diag (SHORT, no lag) -- formed
     // by the host: an integer division by a run-time divisor is some 35 instructions per thread
     using M = typename DevMath<T>::type;
-    constexpr int kChunk = IPT * kStepBlock;
-    constexpr int kWaves = kStepBlock / 64;
-    constexpr int kClasses = 5; // 0, 1, 2, 3+ iterations, and "nothing to do" (out of range)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
-    __shared__ uint16_t s_perm[kChunk];
-    __shared__ int32_t s_cnt[kClasses][IPT][kWaves];
     M m{stage_pow_tables(s_tab), false};
     m.sane = a.sane;
 
-    const int32_t base = s_begin + (int32_t)blockIdx.x * kChunk;
-    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    int32_t n_work;
-    if (!SORT) {
-        // narrow slices (a few blocks per launch) are latency-bound: the partition's loads and barriers
-        // would only lengthen the critical path, so positions are visited in plan order
-        static_assert(SORT || IPT == 1, "the unsorted form handles one position per thread");
-        n_work = min(kChunk, s_end - base); // (no permutation to publish: thread w takes position base + w)
-    } else {
-    // ---- class of my IPT items, per-wave counts -------------------------------------------------
-    int32_t cls[IPT], rank[IPT];
-#pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const int32_t s = base + j * kStepBlock + (int32_t)threadIdx.x;
-        int32_t c = kClasses - 1;
-        if (s < s_end) {
-            const int32_t t = SHORT ? (LAG ? diag - a.lag[s] : diag) : diag - a.level[s];
-#ifdef TRMC_EXPERIMENT_NOSORT // timing experiment: keep plan order
-            if (t >= 1 && t <= a.nsteps) c = 0;
-#else
-            if (t >= 1 && t <= a.nsteps) c = min((int32_t)a.it_prev[s], 3);
-#endif
-        }
-        cls[j] = c;
-#pragma unroll
-        for (int b = 0; b < kClasses; ++b) {
-            const unsigned long long mask = __ballot(c == b);
-            if (c == b) rank[j] = __popcll(mask & ((1ull << lane) - 1ull));
-            if (lane == 0) s_cnt[b][j][wave] = __popcll(mask);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the IPT*kWaves*kClasses counts (class-major: stable by item index inside a
-    // class), done by wave 0 with lane shuffles: entry e = lane and e = lane + 64
-    if (wave == 0) {
-        constexpr int kEntries = kClasses * IPT * kWaves;
-        static_assert(kEntries <= 128, "scan handles two entries per lane");
-        int32_t *flat = &s_cnt[0][0][0];
-        const int32_t v0 = lane < kEntries ? flat[lane] : 0;
-        const int32_t v1 = lane + 64 < kEntries ? flat[lane + 64] : 0;
-        int32_t i0 = v0, i1 = v1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int32_t t0 = __shfl_up(i0, d), t1 = __shfl_up(i1, d);
-            if (lane >= d) {
-                i0 += t0;
-                i1 += t1;
-            }
-        }
-        const int32_t total0 = __shfl(i0, 63);
-        if (lane < kEntries) flat[lane] = i0 - v0;
-        if (lane + 64 < kEntries) flat[lane + 64] = total0 + i1 - v1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < IPT; ++j)
-        s_perm[s_cnt[cls[j]][j][wave] + rank[j]] = (uint16_t)(j * kStepBlock + (int32_t)threadIdx.x);
-    __syncthreads();
-    n_work = s_cnt[kClasses - 1][0][0]; // items of classes 0..3 come first
-    }
-
-    // ---- the segment steps, one class-sorted wave-pass at a time ---------------------------------
-    for (int pass = 0; pass < IPT; ++pass) {
-        const int32_t w = pass * kStepBlock + (int32_t)threadIdx.x;
-        if (w >= n_work) break;
-        const int32_t s = base + (SORT ? (int32_t)s_perm[w] : w);
+    {
+        const int32_t s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
+        if (s >= s_end) return;
         const int32_t t = SHORT ? (LAG ? diag - a.lag[s] : diag) : diag - a.level[s];
-        if ((!SORT || LAG) && (t < 1 || t > a.nsteps)) continue;
+        if (t < 1 || t > a.nsteps) return;
 
         // 32-bit unsigned position: with uniform (SGPR) array bases every load below is
         // `global_load v, v_off, s[base]` with ONE shared byte offset instead of a 64-bit add per array
@@ -504,8 +431,8 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 a.v_tm[row_c + s] = T(0);
                 a.d_tm[row_c + s] = H;
                 a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
-                if (a.partition || t == a.nsteps) a.it_prev[s] = 0;
-                continue;
+                if (t == a.nsteps) a.it_prev[s] = 0;
+                return;
             }
         }
 
@@ -541,9 +468,9 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         at(a.q_tm + row_c, ob) = q_new;
         at(a.v_tm + row_c, ob) = r.velc;
         at(a.d_tm + row_c, ob) = r.depthc;
-        // (the partition reads it on the next step; without the partition only trmc_download_iterations does, after
-        // the window: one byte-masked store per row and step is 3 % of the launch)
-        if (a.partition || t == a.nsteps) a.it_prev[su] = (uint8_t)min(r.iters, 255);
+        // (only trmc_download_iterations reads it, after the window: one byte-masked store per row and step would be
+        // 3 % of the launch)
+        if (t == a.nsteps) a.it_prev[su] = (uint8_t)min(r.iters, 255);
         // cost of the step for the plan's cost hint: the iteration class, plus 4 where the compound-channel branch ran
         // (a wavefront pays that branch -- two more divisions, one more power per evaluation -- as soon as one lane takes it)
         if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + min(r.iters, 3) + (r.over ? 4 : 0));
@@ -1684,13 +1611,6 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.lag = pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr;
     a.it_prev = (uint8_t *)pl->it_prev.p;
     a.it_sum = pl->collect_cost ? (uint16_t *)pl->it_sum.p : nullptr;
-    // The per-block partition by iteration class used to pay on a plan without a cost hint (round 1: 26.1 ms against more
-    // without it); since the step got cheaper in its control flow (round 2) its 60 instructions and three barriers cost
-    // more than the mixed wavefronts they avoid: CONUS day 23.0 ms with it, 21.7 ms in plain plan order.  Off unless asked for.
-    {
-        static const bool want = [] { const char *e = std::getenv("TRMC_STEP_PARTITION"); return e && e[0] == '1'; }();
-        a.partition = want && !pl->hinted;
-    }
     a.sane = pl->params_sane;
     a.res_of_pos = pl->nres > 0 ? (const int32_t *)pl->res_of_pos.p : nullptr;
     a.res_par = (const T *)pl->res_par.p;
@@ -1717,32 +1637,15 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// wide slices are class-partitioned per block; narrow slices (latency-bound) are not
-
 template <class T, bool SHORT>
 inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d)
 {
     const int64_t n = (int64_t)s1 - s0;
     const dim3 grid((unsigned)((n + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
-    // (1024-position chunks handled as four serial passes per block sort better -- fewer VALU
-    // instructions -- but measured 14 % slower on MI355X because every block gets four times longer;
-    // the kernel keeps its IPT parameter, the launcher uses one position per thread)
-#ifndef TRMC_SORT_MIN // positions per launch from which blocks partition their rows by class (A/B builds override it)
-#define TRMC_SORT_MIN ((int64_t)kStepBlock * 512)
-#endif
-    // fewer than two blocks per CU: latency-bound, skip the class partition; a plan built with a cost hint has its
-    // rows grouped by cost already (the partition's 60 instructions and three barriers then only cost: 23.7 ms per
-    // CONUS day with it, 22.3 ms without)
-    const bool sort = a.partition && n >= TRMC_SORT_MIN;
-    if (SHORT && a.lag) {
-        if (sort)
-            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, true, SHORT>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
-        else
-            hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false, SHORT>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
-    } else if (sort)
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
+    if (SHORT && a.lag)
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, SHORT>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
     else
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, 1, false>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, false>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
 }
 
 // A routing window runs in three parts so that a caller can interleave other device work (the multi-GPU

@@ -221,9 +221,14 @@ def run_both(ups, params, qlat, q0, nsteps, qts, short):
     return got, want
 
 
+ENGINES = ["flow", "levels"]   # TRMC_ENGINE: the dataflow engine (k_mc_flow*) and the level engine (k_mc_step)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("nseg", [1, 2, 63, 64, 65, 1000, 6000])
 @pytest.mark.parametrize("short", [True, False])
-def test_random_forests_bit_identical(nseg, short):
+def test_random_forests_bit_identical(nseg, short, engine, monkeypatch):
+    monkeypatch.setenv("TRMC_ENGINE", engine)
     rng = np.random.default_rng(1000 + nseg)
     to = H.random_network(rng, nseg)
     _, _, ups = H.reaches_from_to(to)
@@ -332,27 +337,35 @@ def conus():
     return net, up_ptr, up_idx
 
 
-@pytest.mark.parametrize("short", [True, False])
-def test_conus_full_size_samples_bit_identical_to_oracle(conus, short):
+def conus_sample_rows(to, rng, n_mid=80, n_small=200, lo=50, hi=20000):
+    """rows of a random sub-collection of whole independent networks"""
+    from troute_amd import sharding
+    outlet = sharding.outlet_of(to)
+    _, lab = np.unique(outlet, return_inverse=True)
+    sizes = np.bincount(lab)
+    cand = np.flatnonzero((sizes >= lo) & (sizes <= hi))
+    pick = np.concatenate([rng.choice(cand, n_mid, replace=False), rng.choice(np.flatnonzero(sizes < lo), n_small, replace=False)])
+    return np.flatnonzero(np.isin(lab, pick))
+
+
+@pytest.mark.parametrize("short,plan_mode,engine", [(True, None, "flow"), (False, None, "flow"), (True, True, "levels"),
+                                                    (False, False, "flow")])
+def test_conus_full_size_samples_bit_identical_to_oracle(conus, short, plan_mode, engine):
     """Size-independent property at full size: independent networks do not interact, so any
     sub-collection of them routed ALONE by the oracle must equal -- bit for bit -- what the GPU
-    produced for them inside the 2.7 M-segment run (outlet and interior hydrographs, final state)."""
-    from troute_amd import sharding
+    produced for them inside the 2.7 M-segment run (outlet and interior hydrographs, final state).
+    plan_mode: the timestep mode the plan is told it is for (RoutingPlan assume_short_ts) -- None: unknown, the dataflow
+    engine; True at this size: TRMC_ENGINE_AUTO picks the LEVEL engine, k_mc_step at 2.7 M rows, the kernel bench.py times."""
     from troute_amd.distributed import restrict_csr
     net, up_ptr, up_idx = conus
     to = net["to"]
     nseg = to.shape[0]
     nsteps, qts = 288, 12
     q0 = np.zeros((nseg, 3), np.float32)
-    rng = np.random.default_rng(77)
-    outlet = sharding.outlet_of(to)
-    uniq, lab = np.unique(outlet, return_inverse=True)
-    sizes = np.bincount(lab)
-    cand = np.flatnonzero((sizes >= 50) & (sizes <= 20000))
-    pick = np.concatenate([rng.choice(cand, 80, replace=False), rng.choice(np.flatnonzero(sizes < 50), 200, replace=False)])
-    rows = np.flatnonzero(np.isin(lab, pick))
+    rows = conus_sample_rows(to, np.random.default_rng(77))
     assert 10000 < rows.size < 400000
-    with RoutingPlan(up_ptr, up_idx, net["params"]) as plan:
+    with RoutingPlan(up_ptr, up_idx, net["params"], assume_short_ts=plan_mode) as plan:
+        assert plan.engine == engine
         plan.upload_forcing(nsteps, net["qlat"], q0)
         st = plan.route_device(nsteps, qts, short)
         hyd = plan.gather_flow_rows(rows)
@@ -367,6 +380,64 @@ def test_conus_full_size_samples_bit_identical_to_oracle(conus, short):
     assert_bit_identical(hyd, want[:, 1:, 0], f"CONUS sample hydrographs short={short}")
     assert_bit_identical(final[rows], want[:, -1, :][:, [0, 0, 2]], "CONUS sample final state")
     assert np.isfinite(final).all() and (final[:, 0] >= 0).all()
+
+
+def test_conus_bench_sequence_day_n_plus_1_bit_identical_to_oracle(conus):
+    """The configuration bench.py TIMES, replayed step for step at full size and checked against the oracle where the
+    bench is timed: day N-1 from a cold start on the plan built from the topology alone -> day N warm, with cost
+    collection -> the plan rebuilt with that hint (assume_short_ts plan at 2.7 M rows: the level engine, k_mc_step, rows
+    of a level grouped by cost) -> spun up again through days N-1 and N -> day N+1, warm.  A sub-collection of whole
+    networks routed alone by the oracle through the same three days must equal what the GPU holds for them on day N+1:
+    hydrographs of every sampled row, final state (reference loop semantics: mc_reach.pyx:492-505,:719-750; warm start
+    between windows AbstractNetwork.py:177-191)."""
+    from troute_amd import synthetic
+    from troute_amd.distributed import ShardedRouter, restrict_csr
+    net, up_ptr, up_idx = conus
+    to, params = net["to"], net["params"]
+    nseg = to.shape[0]
+    nsteps, qts = 288, 12
+    qlat_s = net["qlat"]
+    qlat_a = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 1, previous=qlat_s)
+    qlat_b = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2, previous=qlat_a)
+    q0 = np.zeros((nseg, 3), np.float32)
+    rows = conus_sample_rows(to, np.random.default_rng(78), n_mid=80, n_small=120, hi=10000)
+    assert 3000 < rows.size < 120000
+
+    def make(hint):
+        r = ShardedRouter(to, params, cost_hint=hint, assume_short_ts=True)
+        assert r.plan0.engine == "levels"
+        return r
+    r = make(None)
+    r.upload(nsteps, qlat_s, q0)
+    r.route_resident(qts, True)                      # day N-1, cold
+    r.upload(nsteps, qlat_a, None)                   # day N, warm, cost collection on
+    r.collect_cost(True)
+    r.route_resident(qts, True)
+    hint = r.iteration_hint()
+    r.close()
+    r = make(hint)
+    r.upload(nsteps, qlat_s, q0)
+    r.route_resident(qts, True)
+    r.upload(nsteps, qlat_a, None)
+    r.route_resident(qts, True)
+    r.upload(nsteps, qlat_b, None)                   # day N+1: the timed window
+    for _ in range(2):                               # (the bench routes it several times: warm-up, then the timed steps)
+        r.route_resident(qts, True)
+    hyd = r.plan0.gather_flow_rows(rows)
+    final = r.plan0.download_final_state()
+    r.close()
+
+    g2l = np.full(nseg, -1, np.int64)
+    g2l[rows] = np.arange(rows.size)
+    lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)
+    lvl, _, _ = topology_levels(lp, li)
+    state = q0[rows]
+    for ql in (qlat_s, qlat_a, qlat_b):
+        want = O.network_by_segment(nsteps, qts, lp, li, lvl, params[rows], state, ql[rows], True, det=True)
+        state = np.ascontiguousarray(want[:, -1, :][:, [0, 0, 2]])
+    assert_bit_identical(hyd, want[:, 1:, 0], "day N+1 hydrographs on the tuned plan")
+    assert_bit_identical(final[rows], state, "day N+1 final state on the tuned plan")
+    assert (hyd > 0).mean() > 0.5
 
 
 def test_conus_row_relabelling_invariance(conus):
@@ -394,11 +465,13 @@ def test_conus_row_relabelling_invariance(conus):
     assert_bit_identical(a, b[perm], "relabelled CONUS")
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("short", [True, False])
-def test_cost_hinted_plan_order_changes_nothing(short):
-    """A plan built with a cost hint (rows of a level grouped by the secant iterations they needed in an earlier
-    window) visits the rows in another order and must produce the same bits: random hints, the plan's own iteration
-    counts as hint, a forest wide enough for the per-block class partition (> 65 536 rows)."""
+def test_cost_hinted_plan_order_changes_nothing(short, engine, monkeypatch):
+    """A plan built with a cost hint (rows of a level -- or of a block, on the dataflow engine -- grouped by the secant
+    iterations they needed in an earlier window) visits the rows in another order and must produce the same bits, which
+    are the ORACLE's: random hints, the plan's own iteration counts as hint; both engines."""
+    monkeypatch.setenv("TRMC_ENGINE", engine)
     rng = np.random.default_rng(4242)
     nseg = 90000
     to = H.random_network(rng, nseg)
@@ -406,12 +479,16 @@ def test_cost_hinted_plan_order_changes_nothing(short):
     up_ptr, up_idx = csr_from_lists(ups)
     params, qlat, q0 = synth_inputs(rng, nseg, 4)
     nsteps, qts = 24, 6
+    lvl, _, _ = topology_levels(up_ptr, up_idx)
+    want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params, q0, qlat, short, det=True)[:, 1:, :]
     with RoutingPlan(up_ptr, up_idx, params) as plan:
         base = plan.route(nsteps, qts, short, qlat, q0)
         own = plan.download_iterations()
+    assert_bit_identical(base, want, f"unhinted plan vs oracle short={short} engine={engine}")
     assert own.max() >= 2 and (own == 0).any()
     for hint in (rng.integers(0, 4, nseg).astype(np.uint8), np.minimum(own, 3)):
-        with RoutingPlan(up_ptr, up_idx, params, cost_hint=hint) as plan:
+        # (assume_short_ts given: the dataflow engine then sorts its block order by cost tiers as well)
+        with RoutingPlan(up_ptr, up_idx, params, cost_hint=hint, assume_short_ts=short) as plan:
             got = plan.route(nsteps, qts, short, qlat, q0)
             assert np.array_equal(plan.download_iterations(), own)
         assert_bit_identical(got, base, f"hinted plan short={short}")
@@ -433,13 +510,15 @@ def test_cost_hinted_plan_order_changes_nothing(short):
     assert (cost >= np.minimum(last, 3)).all() and (cost[last >= 2] >= 2).all() and (cost == 0).any()
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("short", [True, False])
-def test_extreme_parameters_and_depths_around_the_fast_division_guard(short):
+def test_extreme_parameters_and_depths_around_the_fast_division_guard(short, engine, monkeypatch):
     """The hydraulic point drops the scaling / fix-up steps of its divisions when a plan-wide parameter check and a
     per-call depth test hold (DevMathF::fast_ok, trmc.hip); the oracle always divides plainly.  Forests with parameters
     log-uniform over the whole admitted range [2**-14, 2**17] (twcc / ncc sometimes 0) and initial depths from 1e-12 to
     1e4 -- on both sides of the depth test -- must agree bit for bit; one parameter outside the range switches the
-    plan to plain divisions, same results."""
+    plan to plain divisions, same results.  Both engines."""
+    monkeypatch.setenv("TRMC_ENGINE", engine)
     rng = np.random.default_rng(77)
     nseg = 70000
     to = H.random_network(rng, nseg)

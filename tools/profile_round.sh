@@ -15,7 +15,7 @@ sum=gpurun_out/${tag}_summary.txt
 : > "$sum"
 lean="--no-cpu-baseline --no-full-ts --no-diffusive --no-parity-mode --no-traffic"
 timeout 900 rocprofv3 --kernel-trace -d "$out/trace" -o trace -- python bench.py --steps 3 --warmup 1 $lean > "$out/trace.log" 2>&1
-tail -1 "$out/trace.log" > "gpurun_out/${tag}_bench_under_trace.json"
+grep "^{\"metric\"" "$out/trace.log" | tail -1 > "gpurun_out/${tag}_bench_under_trace.json"
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace -d "$out/$c" -o $c -- python bench.py --steps 2 --warmup 0 $lean > "$out/$c.log" 2>&1
 done
