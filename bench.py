@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: Muskingum-Cunge routing of a CONUS-scale network on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one process per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks from RANK/WORLD_SIZE)
+
+N > 1: one process per GPU; the ranks exchange cut-edge hydrographs and gather the outlet hydrographs through the engine's own
+communicator (include/trmc.h: RCCL over xGMI bound through the C ABI -- no PyTorch anywhere on the path; with fewer devices
+than ranks, e.g. `--gpus 2` on a one-GPU box, the ranks share devices and the shared-memory transport stands in: a rehearsal
+of the control flow, not a measurement).
 
 One "step" = one pass of the hot path over one batch of synthetic input: routing the
 whole seeded synthetic CONUS network (2 729 077 segments, 14 713 independent networks,
@@ -276,34 +281,49 @@ def diffusive_leg(nsteps=12):
     return out
 
 
+def spawn_ranks(a):
+    """`--gpus N` without a launcher: start the N ranks as N copies of this script (RANK / LOCAL_RANK / WORLD_SIZE in their
+    environment, one communicator key for the launch); rank 0 prints the JSON line on our stdout."""
+    import subprocess
+    import uuid
+    key = f"bench{os.getpid()}_{uuid.uuid4().hex[:8]}"
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), TRMC_COMM_KEY=key,
+                   MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    use_dist = world > 1 or bool(os.environ.get("TRMC_FORCE_DIST"))   # the env var exercises the RCCL path at N=1
-    # TRMC_BENCH_BACKEND=gloo: a rehearsal of the multi-rank control flow on a box with ONE GPU -- every rank on device
-    # 0, the collectives through host memory.  Not a measurement.
-    backend = os.environ.get("TRMC_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = 0
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     from troute_amd import _lib, sharding, synthetic
+    from troute_amd import comm as X
     from troute_amd.distributed import ShardedRouter
 
-    if _lib.device_count() < 1:
+    ndev = _lib.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a GPU: libtrmc.so has no CPU fallback")
+    use_dist = world > 1 or bool(os.environ.get("TRMC_FORCE_DIST"))   # the env var exercises the communicator path at N=1
+    # the communicator: RCCL over xGMI when every rank has a device of its own; with fewer devices than ranks the ranks
+    # share them and the shared-memory transport stands in (TRMC_BENCH_BACKEND=rccl|shm overrides).  Not a measurement then.
+    device = local_rank % ndev
+    comm = None
+    if use_dist:
+        comm = X.Comm(rank, world, device, backend=os.environ.get("TRMC_BENCH_BACKEND", "auto"))
+    local_rank = device
 
     kw = {}
     if a.nseg:
@@ -313,8 +333,8 @@ def main():
     t0 = time.perf_counter()
     if rank == 0:
         net = synthetic.generate(cache_dir=cache, **kw)
-    if dist is not None:
-        dist.barrier()
+    if comm is not None:
+        comm.barrier()
     if rank != 0:
         net = synthetic.generate(cache_dir=cache, **kw)
     t_gen = time.perf_counter() - t0
@@ -329,18 +349,6 @@ def main():
     qlat_b = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2, previous=qlat_a)
     q0 = np.zeros((nseg, 3), dtype=np.float32)
 
-    def all_gather_into(out, t):
-        """out[world, *t.shape] <- every rank's t, over RCCL (xGMI), ordered against the current stream"""
-        if backend == "nccl":
-            dist.all_gather_into_tensor(out, t)
-        else:
-            import torch
-            torch.cuda.current_stream().synchronize()
-            mine = t.cpu()
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            out.copy_(torch.stack(parts).to(out.device))
-
     def make_router(hint, short_ts, qlat, state):
         # with a hint (the measured cost of every row on the tuning day) the partition is packed by cost as well
         part = sharding.partition(to, world, row_cost=hint) if (hint is not None and world > 1) else None
@@ -348,21 +356,19 @@ def main():
                           assume_short_ts=short_ts, partition=part)
         r.upload(a.nsteps, qlat, state)
         if use_dist:
-            import torch
-            r.enable_device_exchange(torch, torch.device("cuda", local_rank))
+            r.enable_device_exchange(comm)
             r.upload_trunk()
         return r
 
     def route_once(router, short_ts):
-        if use_dist:   # every hand-off stays in HBM: gather kernels -> RCCL all-gather -> boundary rows
-            return router.route_on_device(a.qts, short_ts, all_gather_into, a.chunks)
+        if use_dist:   # every hand-off stays in HBM: gather kernels -> all-gather (RCCL over xGMI) -> boundary rows
+            return router.route_on_device(a.qts, short_ts, a.chunks)
         return router.route_resident(a.qts, short_ts), None   # outlet hydrographs stay in HBM
 
     def sync():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            X.device_synchronize(local_rank)
+            comm.barrier()
 
     def timed(router, short_ts, steps, warmup, d2h=None):
         """EXACTLY `steps` routing windows between barriers; max over ranks.  d2h: None (results stay in HBM), "state"
@@ -370,7 +376,7 @@ def main():
         consumes) or "full" (the whole flowveldepth array: parity mode)."""
         def fetch(hyd):
             if d2h == "state":
-                hyd = router.outlet_hydrographs() if hyd is None else hyd.cpu().numpy()
+                hyd = router.outlet_hydrographs() if hyd is None else hyd.numpy()
                 router.plan0.download_final_state()
             elif d2h == "full":
                 router.plan0.download_fvd()
@@ -390,11 +396,8 @@ def main():
             hyd = fetch(hyd)
         sync()
         el = time.perf_counter() - t0
-        if dist is not None:
-            import torch
-            t = torch.tensor([el], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+        if comm is not None:
+            el = float(comm.all_reduce_max_host(np.array([el], dtype=np.float64))[0])
         return {"el": el, "ms_main": float(np.mean(mains)), "ms_total": float(np.mean(totals)), "launches": launches,
                 "stats": router.last_stats, "hyd": hyd, "steps": steps}
 
@@ -427,13 +430,8 @@ def main():
     router.collect_cost(not a.no_retune)               # iteration), which are not, which go over bank
     route_once(router, True)
     hint = None if a.no_retune else router.iteration_hint()
-    if hint is not None and dist is not None:   # every rank measured its own rows: all of them need the whole vector
-        import torch
-        h = torch.from_numpy(hint.astype(np.int32))
-        if backend == "nccl":
-            h = h.cuda()
-        dist.all_reduce(h, op=dist.ReduceOp.MAX)
-        hint = h.cpu().numpy().astype(np.uint8)
+    if hint is not None and comm is not None:   # every rank measured its own rows: all of them need the whole vector
+        hint = comm.all_reduce_max_host(hint)
     router.collect_cost(False)
     t_tune = time.perf_counter() - t0
     router.upload(a.nsteps, qlat_b, None)              # day N+1, warm
@@ -456,8 +454,8 @@ def main():
     hyd = head["hyd"]
     if hyd is None:
         hyd = router.outlet_hydrographs()          # one D2H after the timed region, to report/check
-    else:
-        hyd = hyd.cpu().numpy()
+    elif not isinstance(hyd, np.ndarray):
+        hyd = hyd.numpy()
     assert np.isfinite(hyd).all()
     parity = None
     if rank == 0 and world == 1 and not a.no_parity_sample and a.precision == 32:
@@ -471,11 +469,8 @@ def main():
     seg0 = stats["phase0"]["segment_steps"]
     achieved = seg0 * bytes_per / (head["ms_main"] * 1e-3) / 1e9
     per_rank = None
-    if dist is not None:                            # every rank's device time, so that a scaling run can be diagnosed
-        import torch
-        mine = torch.tensor([head["ms_main"], float(seg0)], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+    if comm is not None:                            # every rank's device time, so that a scaling run can be diagnosed
+        allr = comm.all_gather_host(np.array([head["ms_main"], float(seg0)], dtype=np.float64))
         per_rank = [{"rank": i, "ms_main": float(t[0]), "segment_steps": int(t[1])} for i, t in enumerate(allr)]
 
     extra = {}
@@ -565,6 +560,7 @@ def main():
                 "timed_window": "day N+1 of three consecutive days of the same basin (N-1 spin-up from cold, N tuning, N+1 timed), warm start from the state day N leaves in HBM",
                 "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
+                "transport": None if comm is None else comm.backend,
                 "engine": engine,
                 "generate_s": round(t_gen, 2), "plan_s": round(t_plan, 2),
                 "plan_order": "rows grouped by their secant-iteration cost over day N (untimed tuning window); timed on day N+1"
@@ -588,8 +584,9 @@ def main():
         }
         line.update(extra)
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 def pmc_traffic(engine, args):

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 8
+#define TRMC_ABI_VERSION 9
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -349,6 +349,56 @@ int trmc_route(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_sho
  * as reach.pyx:55 passes it.
  */
 int trmc_segments(int device, int precision, int64_t n, const void *in, void *out);
+
+/*
+ * ---- communicator: the ranks of a multi-GPU job on one node (one process, or thread, per rank) ------------------
+ * What ranks exchange on this path is what the reference hands from one sub-network order to the next as
+ * flowveldepth_interorder (src/troute-routing/troute/routing/compute.py:882-897, consumed mc_reach.pyx:458-469):
+ * hydrographs of the rows where the partition cuts a basin, and at the end the outlet hydrographs -- an all-gather of
+ * equal-sized blocks.  Two transports behind one handle:
+ *   trmc_comm_init      RCCL over xGMI (librccl.so is loaded when the first communicator is made, never by the
+ *                       single-GPU path): rank 0 obtains an id with trmc_comm_unique_id and hands its
+ *                       TRMC_COMM_ID_BYTES bytes to the other ranks by any means (a file, a socket); collectives on
+ *                       device pointers are asynchronous on the caller's stream, like ncclAllGather.
+ *   trmc_comm_init_shm  a POSIX shared-memory segment `name` ("/something", unique to the job) of `capacity_bytes`
+ *                       (0: 64 MiB): blocks are staged through host memory, calls are synchronous.  For ranks that
+ *                       share a device (RCCL refuses that) and, with device < 0, for hosts without a GPU, where only
+ *                       the *_host collectives work.
+ * Every rank makes the same sequence of collective calls.
+ */
+#define TRMC_COMM_ID_BYTES 128
+typedef struct trmc_comm trmc_comm;
+int trmc_comm_unique_id(void *id_out /* [TRMC_COMM_ID_BYTES] */);
+int trmc_comm_init(int rank, int world, const void *id, int device, trmc_comm **out);
+int trmc_comm_init_shm(int rank, int world, const char *name, int device, int64_t capacity_bytes, trmc_comm **out);
+int trmc_comm_info(const trmc_comm *comm, int32_t *rank, int32_t *world, int32_t *is_rccl);
+/* recv_dev[world][bytes] <- every rank's send_dev[bytes]; device pointers on the communicator's device; ordered on
+ * `stream` (a hipStream_t; NULL = the null stream) */
+int trmc_comm_all_gather(trmc_comm *comm, const void *send_dev, void *recv_dev, int64_t bytes, void *stream);
+/* the same for host memory (small control data: a timing, a cost hint); returns when recv is complete */
+int trmc_comm_all_gather_host(trmc_comm *comm, const void *send, void *recv, int64_t bytes);
+int trmc_comm_barrier(trmc_comm *comm);
+void trmc_comm_destroy(trmc_comm *comm);
+
+/* Device buffers, streams and events for the hand-off between a plan's stream (trmc_plan_stream) and the collectives:
+ * thin, typed-by-convention wrappers of hipMalloc / hipStream* / hipEvent* so that a host language needs no other GPU
+ * library in the process.  `stream` / `event` are hipStream_t / hipEvent_t values. */
+int trmc_dev_alloc(int device, int64_t bytes, void **ptr_out); /* zero-filled */
+int trmc_dev_free(int device, void *ptr);
+int trmc_dev_upload(int device, void *dst_dev, const void *src_host, int64_t bytes);
+int trmc_dev_download(int device, void *dst_host, const void *src_dev, int64_t bytes, void *stream); /* waits for `stream` */
+/* dst_dev[i][row_bytes] <- src_dev[index_dev[i]][row_bytes], i < nrows (row_bytes a multiple of 4): picks the outlet
+ * rows out of an all-gathered block */
+int trmc_dev_gather_rows(int device, const void *src_dev, const int64_t *index_dev, int64_t nrows, int64_t row_bytes,
+                         void *dst_dev, void *stream);
+int trmc_stream_create(int device, void **stream_out);
+int trmc_stream_destroy(int device, void *stream);
+int trmc_stream_synchronize(int device, void *stream);
+int trmc_device_synchronize(int device);
+int trmc_event_create(int device, void **event_out);
+int trmc_event_destroy(int device, void *event);
+int trmc_event_record(int device, void *event, void *stream);
+int trmc_stream_wait_event(int device, void *stream, void *event);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,28 @@ SIGNATURES = {
     "trmc_get_stats": (_int, [_vp, _P(Stats)]),
     "trmc_route": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "trmc_segments": (_int, [_int, _int, _i64, _vp, _vp]),
+    # communicator + device plumbing of the multi-GPU path (csrc/comm.hip)
+    "trmc_comm_unique_id": (_int, [_vp]),
+    "trmc_comm_init": (_int, [_int, _int, _vp, _int, _P(_vp)]),
+    "trmc_comm_init_shm": (_int, [_int, _int, C.c_char_p, _int, _i64, _P(_vp)]),
+    "trmc_comm_info": (_int, [_vp, _P(_i32), _P(_i32), _P(_i32)]),
+    "trmc_comm_all_gather": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "trmc_comm_all_gather_host": (_int, [_vp, _vp, _vp, _i64]),
+    "trmc_comm_barrier": (_int, [_vp]),
+    "trmc_comm_destroy": (None, [_vp]),
+    "trmc_dev_alloc": (_int, [_int, _i64, _P(_vp)]),
+    "trmc_dev_free": (_int, [_int, _vp]),
+    "trmc_dev_upload": (_int, [_int, _vp, _vp, _i64]),
+    "trmc_dev_download": (_int, [_int, _vp, _vp, _i64, _vp]),
+    "trmc_dev_gather_rows": (_int, [_int, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "trmc_stream_create": (_int, [_int, _P(_vp)]),
+    "trmc_stream_destroy": (_int, [_int, _vp]),
+    "trmc_stream_synchronize": (_int, [_int, _vp]),
+    "trmc_device_synchronize": (_int, [_int]),
+    "trmc_event_create": (_int, [_int, _P(_vp)]),
+    "trmc_event_destroy": (_int, [_int, _vp]),
+    "trmc_event_record": (_int, [_int, _vp, _vp]),
+    "trmc_stream_wait_event": (_int, [_int, _vp, _vp]),
 }
 
 # include/trdw.h (the diffusive-wave mainstem solver, same shared library)

@@ -14,8 +14,13 @@
 //   * ChannelConst   everything that depends only on the channel parameters is
 //                    formed once per segment-step (side distance z, bankfull
 //                    depth, sqrt(s0), sqrt(1+z^2), the two Manning factors);
-//   * SecantPoint    one evaluation of the residual  Q_mc(h) - Q_manning(h);
-//   * mc_segment_step the bracketed secant iteration, outflow, velocity, depth.
+//   * HydraulicPoint everything a residual evaluation needs that depends on the depth alone;
+//   * step_pre       the two points the secant iteration starts from -- they depend on the row's OWN depth of the step
+//                    before only, never on what flows in, so a row that waits for its upstream rows (the dataflow
+//                    engine) evaluates them while it waits;
+//   * step_solve     the bracketed secant iteration and the outflow (what the row below waits for);
+//   * step_velocity  the velocity of the result row, which no other row reads;
+//   * mc_segment_step = the three in sequence.
 // The same operations, in the same order and rounding as the reference, so the
 // fp32 instantiation is bit-comparable with the fp32 Fortran wherever pow()
 // agrees; compile with -ffp-contract=off.
@@ -30,6 +35,8 @@
 // m.fast_ok(h, h_in, h_over) -> ok; m.div2(a1, a2, b, ok, q1, q2): qi = ai / b; m.div1(a, b, ok) = a / b: the
 // divisions of the hydraulic point, for which a policy may use a cheaper exact sequence when `ok` (its own test of
 // the operand ranges) holds.
+// m.all(pred): true when `pred` holds for every row that is evaluated together with this one (a wavefront's active
+// lanes) -- a scalar condition: the in-bank body of the hydraulic point is chosen by ONE uniform branch per wavefront.
 //
 // The header is host/device neutral (no HIP construct outside MC_HD); the shipped library only ever instantiates
 // it in device code, and its results are checked against the oracle through the C ABI (tests/test_gpu_parity.py).
@@ -39,6 +46,10 @@
 #define MC_HD __host__ __device__ __forceinline__
 #else
 #define MC_HD inline
+#endif
+
+#ifndef TRMC_INBANK_BODY // 0: the general body of the hydraulic point everywhere (A/B measurements)
+#define TRMC_INBANK_BODY 1
 #endif
 
 namespace trmc {
@@ -63,8 +74,19 @@ template <class T> struct ChannelConst {
     T two_sq;     // 2*sqrt(1 + z*z)
     T half_dt;    // dt/2
     T inv_n;      // 1/n, the factor of the velocity formula (f90:169)
+    T z2;         // 2*z
     bool fp_ok;   // twcc > 0 && ncc > 0 : flood-plain terms may activate
 };
+
+// the constants that are one operation away from the stored ones (the kernels load z, bfd, sqrt_s0, sq1pz2, s0_n, s0_ncc,
+// inv_n from the plan's columns and form these per row)
+template <class T> MC_HD void derive_const(ChannelConst<T> &c, const ChannelParams<T> &p)
+{
+    c.two_sq = T(2) * c.sq1pz2;
+    c.z2 = T(2) * c.z;
+    c.half_dt = p.dt / T(2);
+    c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
+}
 
 template <class T, class M>
 MC_HD ChannelConst<T> make_const(const ChannelParams<T> &p, const M &m)
@@ -81,10 +103,8 @@ MC_HD ChannelConst<T> make_const(const ChannelParams<T> &p, const M &m)
     c.sq1pz2 = m.sqrt(T(1) + c.z * c.z);
     c.s0_n = c.sqrt_s0 / p.n;
     c.s0_ncc = c.sqrt_s0 / p.ncc;
-    c.two_sq = T(2) * c.sq1pz2;
-    c.half_dt = p.dt / T(2);
     c.inv_n = T(1) / p.n;
-    c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
+    derive_const(c, p);
     return c;
 }
 
@@ -185,11 +205,55 @@ MC_HD HydraulicPoint<T> hydraulics_core(T h, Section<T> &s, const ChannelParams<
     return hp;
 }
 template <class T, class M>
-MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
+MC_HD HydraulicPoint<T> hydraulics_general(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
 {
     Section<T> s = section_at<T, M, false>(h, p, c, m);
     if (m.fast_ok(h, s.h_in, s.h_over)) return hydraulics_core<T, M, true>(h, s, p, c, m);
     return hydraulics_core<T, M, false>(h, s, p, c, m);
+}
+
+// The point of a depth that lies in the channel (h <= bfd) and in the range of the policy's fast_ok: what
+// hydraulics_core<OK = true> computes there, with everything the flood plain contributes written out of it.  With
+// h <= bfd: h_over = max(h - bfd, 0) = 0 and h_in = min(bfd, h) = h; the NWM-3.0 exception needs h_over > 0; areac =
+// twcc * 0 = +0 and wpc = 0 (twcc, ncc finite: the policy's parameter check), so area + areac = area, wp*n + wpc*ncc =
+// wp*n and wp + wpc = wp bit for bit (x + 0 = x for x > 0); `over` is false.  Three products are taken in another
+// association that rounds the same because a factor of two is exact:  (2 z) h = (2 h) z  and  (2 h) sq = h (2 sq) --
+// so the top width term of the celerity, bw + 2 h z, IS twl.  Same bits as the general body, some forty instructions
+// fewer, most of them compares and selects.
+template <class T, class M> MC_HD bool inbank_fast(T h, const ChannelConst<T> &c, const M &m)
+{
+    return m.fast_ok(h, h, T(0)) && h <= c.bfd;
+}
+template <class T, class M>
+MC_HD HydraulicPoint<T> hydraulics_inbank(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
+{
+    const T c23 = T(2) / T(3), c53 = T(5) / T(3);
+    HydraulicPoint<T> hp;
+    const T twl = p.bw + c.z2 * h;
+    const T area = (p.bw + h * c.z) * h;
+    const T wp = p.bw + h * c.two_sq;
+    T R, n_comp;
+    m.div2(area, wp * p.n, wp, true, R, n_comp);
+    const typename M::Log lr = m.log_of_r(R, true);
+    const T r23 = m.pow_l_r(lr, R, c23, true);
+    hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, R, c53, true) * m.div1(c.two_sq, twl, true))));
+    {
+        const T kq = mc_max(p.dt, m.divx(p.dx, hp.ck));
+        hp.km = (hp.ck > T(0)) ? kq : p.dt;
+    }
+    hp.denom = T(2) * twl * p.s0 * hp.ck * p.dx;
+    hp.has_wp = true;
+    hp.over = false;
+    hp.q_manning = m.div1(T(1), n_comp, true) * area * r23 * c.sqrt_s0;
+    return hp;
+}
+
+// one point: the in-bank body when every row evaluated together is in bank (one uniform branch), else the general one
+template <class T, class M>
+MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
+{
+    if (TRMC_INBANK_BODY && m.all(inbank_fast<T, M>(h, c, m))) return hydraulics_inbank<T, M>(h, p, c, m);
+    return hydraulics_general<T, M>(h, p, c, m);
 }
 
 // Residual Q_mc(h) - Q_manning(h) at the hydraulic point of depth h (f90:277-332).
@@ -256,23 +320,59 @@ template <class T> struct StepResult {
     bool over;           // some evaluation of the step took the compound-channel (over-bank) branch: cost diagnostics only
 };
 
-// One segment, one timestep (f90:8-186), with the segment-invariant constants supplied.
+// ---- the step in three parts -------------------------------------------------------------------------------------
+// The bracket the iteration starts from and its two hydraulic points (f90:69-71, first pass of :83-95): functions of
+// the depth at the previous time level and the channel alone.
+template <class T> struct StepPre {
+    T h, h_0;
+    HydraulicPoint<T> at_h0, at_h;
+    bool have; // the two points have been evaluated
+};
+template <class T> MC_HD void step_bracket(T depthp, T &h, T &h_0)
+{
+    const T depth0 = mc_max(depthp, T(0));
+    h = (depth0 * T(1.33)) + T(0.01);
+    h_0 = (depth0 * T(0.67));
+}
 template <class T, class M>
-MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelConst<T> &c, const Inflow<T> &f,
-                                    T depthp, const M &m)
+MC_HD StepPre<T> step_pre(const ChannelParams<T> &p, const ChannelConst<T> &c, T depthp, const M &m)
+{
+    StepPre<T> s;
+    step_bracket(depthp, s.h, s.h_0);
+    // (0 <= h_0 <= h: the lower bound of the range is tested on h_0, the upper bound and the bank on h)
+    if (TRMC_INBANK_BODY && m.all(m.fast_ok(s.h, s.h_0, T(0)) && s.h <= c.bfd)) {
+        s.at_h0 = hydraulics_inbank<T, M>(s.h_0, p, c, m);
+        s.at_h = hydraulics_inbank<T, M>(s.h, p, c, m);
+    } else {
+        s.at_h0 = hydraulics_general<T, M>(s.h_0, p, c, m);
+        s.at_h = hydraulics_general<T, M>(s.h, p, c, m);
+    }
+    s.have = true;
+    return s;
+}
+// whether anything is routed at all (f90:73-74; the caller passes qdc = 0, reach.pyx:55)
+template <class T> MC_HD bool step_has_flow(const Inflow<T> &f)
+{
+    return f.ql > T(0) || f.qup > T(0) || f.quc > T(0) || f.qdp > T(0);
+}
+// ... and whether that is already certain from the row's own state
+template <class T> MC_HD bool step_has_own_flow(T ql, T qdp) { return ql > T(0) || qdp > T(0); }
+
+template <class T> struct StepSolve {
+    T qdc, h, X;
+    int iters;
+    bool over;
+};
+// The secant iteration (f90:83-134) and the outflow (f90:149-161).  `pre` = step_pre of the same row and depth (evaluated
+// here when it has not been); requires step_has_flow(f).
+template <class T, class M>
+MC_HD StepSolve<T> step_solve(const ChannelParams<T> &p, const ChannelConst<T> &c, const Inflow<T> &f, T depthp,
+                              const StepPre<T> &pre_in, const M &m)
 {
     const T mindepth = T(0.01);
-    StepResult<T> out;
-
-    const T depth0 = mc_max(depthp, T(0));
-    T h = (depth0 * T(1.33)) + mindepth;
-    T h_0 = (depth0 * T(0.67));
-
-    if (!(f.ql > T(0) || f.qup > T(0) || f.quc > T(0) || f.qdp > T(0))) {
-        out.qdc = T(0); out.velc = T(0); out.depthc = T(0); out.h = h; out.X = T(0); out.iters = 0;
-        out.over = false;
-        return out;
-    }
+    StepSolve<T> out;
+    const StepPre<T> pre = pre_in.have ? pre_in : step_pre<T, M>(p, c, depthp, m);
+    T h = pre.h, h_0 = pre.h_0;
 
     MuskCoef<T> k{T(0), T(0), T(0), T(0), T(0)};
     // The relative error |(h_1 - h) / h| (f90:108) is only ever compared with 0.01 (f90:83): `rel_open` is that
@@ -281,21 +381,25 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
     T aerror = T(0.01);
     bool rel_open = true;
     int maxiter = 100, tries = 0, total_iter = 0;
-    bool any_over = false;
+    bool any_over = pre.at_h0.over || pre.at_h.over;
+    bool first = true;
     for (;;) {
         T qj_0 = T(0);
         int iter = 0;
-        // the point of h_0: evaluated here for the bracket a (re)try starts from; inside the loop h_0 <- max(0, h) is h
-        // itself (h is never negative), so the point just evaluated for h is carried over instead of being recomputed
-        HydraulicPoint<T> at_h0;
-        if (rel_open && aerror >= mindepth && iter <= maxiter) {
+        // the point of h_0: evaluated for the bracket a (re)try starts from (the first pass takes both of its points from
+        // `pre`); inside the loop h_0 <- max(0, h) is h itself (h is never negative), so the point just evaluated for h is
+        // carried over instead of being recomputed
+        HydraulicPoint<T> at_h0 = pre.at_h0, at_h = pre.at_h;
+        if (!first && rel_open && aerror >= mindepth && iter <= maxiter) {
             at_h0 = hydraulics_at<T, M>(h_0, p, c, m);
             any_over = any_over || at_h0.over;
         }
         while (rel_open && aerror >= mindepth && iter <= maxiter) {
             qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k, m);
-            const HydraulicPoint<T> at_h = hydraulics_at<T, M>(h, p, c, m);
-            any_over = any_over || at_h.over;
+            if (!(first && iter == 0)) {
+                at_h = hydraulics_at<T, M>(h, p, c, m);
+                any_over = any_over || at_h.over;
+            }
             const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k, m);
             T h_1;
             {
@@ -318,6 +422,7 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
             ++total_iter;
             if (h < mindepth) break;
         }
+        first = false;
         if (iter >= maxiter && ++tries <= 4) { // widen the bracket and retry
             h = h * T(1.33);
             h_0 = h_0 * T(0.67);
@@ -333,22 +438,51 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
         const T q_lo = ((k.C4 < T(0)) && (mc_abs(k.C4) > w3)) ? T(0) : q_neg;
         out.qdc = ((w3 + k.C4) < T(0)) ? q_lo : w3 + k.C4;
     }
-
-    const T twl = p.bw + T(2) * c.z * h;
-    const T a = (twl - p.bw) / T(2);
-    // (numerator in [2**-44, 2**52], denominator in [2**-14, 2**36]: see fast_ok; one branch, two straight-line bodies)
-    if (m.fast_ok(h, h, T(0))) {
-        const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), true);
-        out.velc = c.inv_n * m.pow_l_r(m.log_of_r(R, true), R, T(2) / T(3), true) * c.sqrt_s0;
-    } else {
-        const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), false);
-        out.velc = c.inv_n * m.pow_l_r(m.log_of_r(R, false), R, T(2) / T(3), false) * c.sqrt_s0;
-    }
-    out.depthc = h;
     out.h = h;
     out.X = k.X;
     out.iters = total_iter;
     out.over = any_over;
+    return out;
+}
+
+// velocity at the depth the iteration ended on, from the trapezoid-only hydraulic radius (f90:163-169)
+template <class T, class M>
+MC_HD T step_velocity(const ChannelParams<T> &p, const ChannelConst<T> &c, T h, const M &m)
+{
+    const T twl = p.bw + T(2) * c.z * h;
+    const T a = (twl - p.bw) / T(2);
+    // (numerator in [2**-44, 2**52], denominator in [2**-14, 2**36]: see fast_ok; one uniform branch, two straight-line bodies)
+    if (m.all(m.fast_ok(h, h, T(0)))) {
+        const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), true);
+        return c.inv_n * m.pow_l_r(m.log_of_r(R, true), R, T(2) / T(3), true) * c.sqrt_s0;
+    }
+    const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), false);
+    return c.inv_n * m.pow_l_r(m.log_of_r(R, false), R, T(2) / T(3), false) * c.sqrt_s0;
+}
+
+// One segment, one timestep (f90:8-186), with the segment-invariant constants supplied.
+template <class T, class M>
+MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelConst<T> &c, const Inflow<T> &f,
+                                    T depthp, const M &m)
+{
+    StepResult<T> out;
+    if (!step_has_flow(f)) {
+        T h, h_0;
+        step_bracket(depthp, h, h_0);
+        out.qdc = T(0); out.velc = T(0); out.depthc = T(0); out.h = h; out.X = T(0); out.iters = 0;
+        out.over = false;
+        return out;
+    }
+    StepPre<T> none;
+    none.have = false;
+    const StepSolve<T> s = step_solve<T, M>(p, c, f, depthp, none, m);
+    out.qdc = s.qdc;
+    out.velc = step_velocity<T, M>(p, c, s.h, m);
+    out.depthc = s.h;
+    out.h = s.h;
+    out.X = s.X;
+    out.iters = s.iters;
+    out.over = s.over;
     return out;
 }
 

@@ -43,6 +43,7 @@
 #include "mc_segment.hpp"
 #include "levelpool.hpp"
 #include "topology.hpp"
+#include "internal.hpp"
 
 namespace {
 
@@ -53,6 +54,12 @@ int fail(int code, const std::string &msg)
     g_err = msg;
     return code;
 }
+
+} // namespace
+namespace trmc {
+int fail_with(int code, const std::string &msg) { return fail(code, msg); }
+} // namespace trmc
+namespace {
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -106,6 +113,8 @@ struct DevMathF {
     __device__ __forceinline__ float pow_l_r(Log l, float, float y, bool) const { return __builtin_amdgcn_exp2f(y * l); }
 #endif
     __device__ __forceinline__ float sqrt(float x) const { return ::sqrtf(x); }
+    // wave-wide AND over the active lanes: a scalar, so the branch on it is a uniform one
+    __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
 
     // The four Muskingum coefficients C1..C4 = n_i / D (f90:303-312) with ONE reciprocal.
     // hipcc expands an fp32 division into  v_div_scale x2, v_rcp, the refinement
@@ -229,6 +238,7 @@ struct DevMathD {
     __device__ __forceinline__ Log log_of_r(double x, bool) const { return x; }
     __device__ __forceinline__ double pow_l_r(Log, double x, double y, bool) const { return det_pow64(x, y); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
     bool coef_ok; // unused
     bool sane;    // unused
     __device__ __forceinline__ bool fast_ok(double, double, double) const { return false; }
@@ -379,9 +389,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         c.s0_n = at(a.s0_n, ob);
         c.s0_ncc = at(a.s0_ncc, ob);
         c.inv_n = at(a.inv_n, ob);
-        c.two_sq = T(2) * c.sq1pz2;
-        c.half_dt = p.dt / T(2);
-        c.fp_ok = (p.twcc > T(0)) && (p.ncc > T(0));
+        trmc::derive_const(c, p);
 
         trmc::Inflow<T> f;
         f.qdp = at(q_prev, ob);
@@ -475,6 +483,138 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // (a wavefront pays that branch -- two more divisions, one more power per evaluation -- as soon as one lane takes it)
         if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + min(r.iters, 3) + (r.over ? 4 : 0));
     }
+}
+
+// The WIDE levels of a short-timestep window, K timesteps per launch, a row in ONE thread for all of them.
+//
+// With assume_short_ts a row at step t reads flows of step t - 1 only (mc_reach.pyx:504-505, :135-136).  So if level l
+// of the network runs K steps BEHIND level l - 1, every flow a row reads during a tile of K steps was written by an
+// EARLIER launch: launch `tile` routes level l through the steps ((tile - l) K, (tile - l + 1) K], and a row of that level
+// reads its upstream rows (levels < l, hence at least K steps ahead) at steps it finds complete.  No flag, no poll, no
+// barrier -- the kernel boundary is the only synchronisation -- and inside a launch a thread keeps its row's thirteen
+// parameter / constant columns and its state (flow, depth) in registers, reads the forcing once per column and its
+// upstream flows once per step, and writes (q, v, d) per step: 12 + 8 bytes of traffic per segment-step after the first
+// instead of the 94 the one-step kernel moves, and no memory phase that the arithmetic of a 70-microsecond launch cannot hide.
+// The level skew costs `wide - 1` partly filled launches at either end of the window; only levels wide enough to fill the
+// device by themselves are routed this way (route_advance_t picks them), the narrow tail of the level order keeps the
+// one-step launches of k_mc_step, trailing the last wide level.  Results are the same bits: the same segment steps on the
+// same inputs, visited in another order (tests run both paths against the oracle).
+#ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow (1: as many registers as it likes)
+#define TRMC_TILE_WAVES 1
+#endif
+template <class T>
+__global__ void __launch_bounds__(kStepBlock, TRMC_TILE_WAVES)
+k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t tile, const int32_t K)
+{
+    using M = typename DevMath<T>::type;
+    __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    M m{stage_pow_tables(s_tab), false};
+    m.sane = a.sane;
+
+    const int32_t s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
+    if (s >= s_end) return;
+    const int32_t behind = tile - a.level[s];
+    if (behind < 0) return;
+    const int32_t t_lo = behind * K + 1, t_hi = min(behind * K + K, a.nsteps);
+    if (t_lo > t_hi) return;
+
+    const uint32_t su = (uint32_t)s;
+    uint32_t ob = su * (uint32_t)sizeof(T);
+    const size_t np = (size_t)a.nseg_pad;
+    trmc::ChannelParams<T> p;
+    p.dt = a.dt_col ? at(a.dt_col, ob) : a.dt;
+    asm volatile("" : "+v"(ob));
+    p.dx = at(a.dx, ob);
+    p.bw = at(a.bw, ob);
+    p.twcc = at(a.twcc, ob);
+    p.n = at(a.n, ob);
+    p.ncc = at(a.ncc, ob);
+    p.s0 = at(a.s0, ob);
+    p.tw = p.cs = T(0);
+    trmc::ChannelConst<T> c;
+    c.z = at(a.z, ob);
+    c.bfd = at(a.bfd, ob);
+    c.sqrt_s0 = at(a.sqrt_s0, ob);
+    c.sq1pz2 = at(a.sq1pz2, ob);
+    c.s0_n = at(a.s0_n, ob);
+    c.s0_ncc = at(a.s0_ncc, ob);
+    c.inv_n = at(a.inv_n, ob);
+    trmc::derive_const(c, p);
+    const int2 u = a.up2[su];
+    const int32_t ri = a.res_of_pos ? a.res_of_pos[s] : -1;
+    const int32_t gi = a.gage_of_pos ? a.gage_of_pos[s] : -1;
+
+    T q_prev = at(a.q_tm + (size_t)(t_lo - 1) * np, ob);
+    T d_prev = at(a.d_tm + (size_t)(t_lo - 1) * np, ob);
+    // the lateral-inflow column of step t is (t - 1) / qts: found by division once, by a counter from then on
+    int32_t ql_col = (t_lo - 1) / a.qts, ql_left = a.qts - (t_lo - 1) % a.qts;
+    T ql = at(a.qlat_tm + (size_t)ql_col * np, ob);
+    int32_t it_acc = 0, it_last = 0;
+    for (int32_t t = t_lo; t <= t_hi; ++t) {
+        if (ql_left == 0) {
+            ++ql_col;
+            ql = at(a.qlat_tm + (size_t)ql_col * np, ob);
+            ql_left = a.qts;
+        }
+        --ql_left;
+        const T *const q_up = a.q_tm + (size_t)(t - 1) * np; // upstream flows of the step before (complete: earlier launches)
+        // junction sum in the reference's order (mc_reach.pyx:499-502); see k_mc_step for the table of the first two
+        T qup = T(0);
+        if (u.x >= 0) qup += at(q_up, (uint32_t)u.x * (uint32_t)sizeof(T));
+        if (u.y >= 0) {
+            qup += at(q_up, (uint32_t)(u.y & 0x3fffffff) * (uint32_t)sizeof(T));
+            if (u.y & 0x40000000) {
+                const int32_t k1 = a.up_ptr[su + 1];
+                for (int32_t k = a.up_ptr[su] + 2; k < k1; ++k) qup += at(q_up, (uint32_t)a.up_idx[k] * (uint32_t)sizeof(T));
+            }
+        }
+        T q_new, v_new, d_new;
+        if (ri >= 0) { // level-pool reservoir row (see k_mc_step)
+            const T *rp = a.res_par + (size_t)ri * 9;
+            const trmc::LevelPoolParams<T> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
+            T H = d_prev;
+            q_new = trmc::levelpool_step<T, M>(qup, T(0), a.res_dt, H, lp, m);
+            v_new = T(0);
+            d_new = H;
+            a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = qup;
+            it_last = 0;
+        } else {
+            trmc::Inflow<T> f;
+            f.qup = qup;
+            f.quc = qup;
+            f.qdp = q_prev;
+            f.ql = ql;
+            m.coef_ok = coef_guard(p.dt, f.ql);
+            const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, c, f, d_prev, m);
+            q_new = r.qdc;
+            v_new = r.velc;
+            d_new = r.depthc;
+            it_last = min(r.iters, 255);
+            it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
+            if (gi >= 0) { // streamflow nudging (see k_mc_step)
+                const size_t e = (size_t)gi * (size_t)a.nsteps + (size_t)(t - 1);
+                const uint8_t mode = a.da_mode[e];
+                T nudge = T(0);
+                if (mode == 1) {
+                    nudge = a.da_a[e] - q_new;
+                    q_new = a.da_a[e];
+                } else if (mode == 2) {
+                    nudge = (a.da_a[e] - q_new) * a.da_w[e];
+                    q_new = q_new + nudge;
+                }
+                a.da_nudge[e] = nudge;
+            }
+        }
+        const size_t row_c = (size_t)t * np;
+        asm volatile("" : "+v"(ob));
+        at(a.q_tm + row_c, ob) = q_new;
+        at(a.v_tm + row_c, ob) = v_new;
+        at(a.d_tm + row_c, ob) = d_new;
+        q_prev = q_new;
+        d_prev = d_new;
+    }
+    if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)it_last;
+    if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + it_acc);
 }
 
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
@@ -979,9 +1119,7 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
     c.s0_n = at(a.s0_n, ob);
     c.s0_ncc = at(a.s0_ncc, ob);
     c.inv_n = at(a.inv_n, ob);
-    c.two_sq = 2.0f * c.sq1pz2;
-    c.half_dt = p.dt / 2.0f;
-    c.fp_ok = (p.twcc > 0.0f) && (p.ncc > 0.0f);
+    trmc::derive_const(c, p);
     const int2 up = a.up2[su];
     const bool more = up.y >= 0 && (up.y & 0x40000000);
     FlowEdge e0, e1;
@@ -1047,6 +1185,15 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
             ql_left = a.qts;
         }
         --ql_left;
+        // What the step needs of the row's OWN state only -- the bracket of the secant iteration and its first two
+        // hydraulic points (mc_segment.hpp step_pre: half of the arithmetic of a two-iteration step) -- is evaluated
+        // BEFORE the row looks for what its upstream rows hand down: off the dependence chain that links a row to the row
+        // above it (f90:69-71 and the first pass of :83-95 read depthp and the channel only).  In the general mode, that
+        // is: with assume_short_ts a row reads flows of the step BEFORE, which its upstream rows published a step ago --
+        // there is no chain to shorten, and holding the two points across the look-up would only cost registers.
+        trmc::StepPre<float> pre;
+        pre.have = false;
+        if (!SHORT && ri < 0 && trmc::step_has_own_flow(ql, q_prev)) pre = trmc::step_pre<float, M>(p, c, d_prev, m);
         // junction sums in the reference's order (mc_reach.pyx:499-502): with assume_short_ts the upstream flows of
         // step t - 1 (they are also `quc`, :504-505), without it those of step t and -- kept from the round before --
         // of step t - 1
@@ -1087,24 +1234,29 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
         f.qdp = q_prev;
         f.ql = ql;
 
-        float q_new, v_new, d_new;
+        float q_new, v_new = 0.0f, d_new;
+        bool routed = false;
         if (ri >= 0) { // level-pool reservoir row, mc_reach.pyx:507-510,:551-553,:706-710 (see k_mc_step)
             const float *rp = a.res_par + (size_t)ri * 9;
             const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
             float H = d_prev;
             q_new = trmc::levelpool_step<float, M>(f.quc, 0.0f, a.res_dt, H, lp, m);
-            v_new = 0.0f;
             d_new = H;
             a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
             it_last = 0;
         } else {
-            m.coef_ok = coef_guard(p.dt, f.ql);
-            const trmc::StepResult<float> r = trmc::mc_segment_step<float, M>(p, c, f, d_prev, m);
-            q_new = r.qdc;
-            v_new = r.velc;
-            d_new = r.depthc;
-            it_last = min(r.iters, 255);
-            it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
+            q_new = 0.0f;
+            d_new = 0.0f;
+            it_last = 0;
+            if (trmc::step_has_flow(f)) {
+                m.coef_ok = coef_guard(p.dt, f.ql);
+                const trmc::StepSolve<float> r = trmc::step_solve<float, M>(p, c, f, d_prev, pre, m);
+                q_new = r.qdc;
+                d_new = r.h;
+                routed = true;
+                it_last = min(r.iters, 255);
+                it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
+            }
             if (gi >= 0) { // streamflow nudging, mc_reach.pyx:761-796 / simple_da.pyx:47-76 (see k_mc_step)
                 const size_t e = (size_t)gi * (size_t)a.nsteps + (size_t)(t - 1);
                 const uint8_t mode = a.da_mode[e];
@@ -1119,13 +1271,16 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
                 a.da_nudge[e] = nudge;
             }
         }
-        // publish the flow: the block's ring, and one 8-byte agent-scope store into the plane; tag in the high word
+        // publish the flow as soon as it exists -- the block's ring, and one 8-byte agent-scope store into the plane; tag
+        // in the high word -- and only then form the velocity (a power, a square root, a division: f90:163-169), which no
+        // other row reads
         {
             const unsigned long long g = ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(q_new);
             __hip_atomic_store(s_ring + (size_t)(t & (kFlowRing - 1)) * kFlowBlock + threadIdx.x, g, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(g_curr + su, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (routed) v_new = trmc::step_velocity<float, M>(p, c, d_new, m);
         q_prev = q_new;
         d_prev = d_new;
         // stage (q, v, d) of step t; a run ends at every 8th step of the window and at the last step of the launch
@@ -1312,50 +1467,58 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
             const int32_t k1 = a.up_ptr[su + 1];
             for (int32_t e = a.up_ptr[su] + 2; e < k1; ++e) qup += flow_wait(g_prev + a.up_idx[e], tag_p, a, dead);
         }
-        float q_new, v_new, d_new;
+        float q_new = 0.0f, v_new = 0.0f, d_new = 0.0f;
+        bool routed = false;
+        trmc::ChannelParams<float> p;
+        trmc::ChannelConst<float> c;
         if (flags & 32u) { // level-pool reservoir row (see k_mc_step)
             const int32_t ri = a.res_of_pos[su];
             const float *rp = a.res_par + (size_t)ri * 9;
             const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
             float H = d_prev;
             q_new = trmc::levelpool_step<float, M>(qup, 0.0f, a.res_dt, H, lp, m);
-            v_new = 0.0f;
             d_new = H;
             a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = qup;
             its &= 0x00ffffffu;
         } else {
-            const float *sp = s_par + threadIdx.x;
-            trmc::ChannelParams<float> p;
-            p.dt = dt;
-            p.dx = sp[0 * kFlowBlock];
-            p.bw = sp[1 * kFlowBlock];
-            p.twcc = sp[2 * kFlowBlock];
-            p.n = sp[3 * kFlowBlock];
-            p.ncc = sp[4 * kFlowBlock];
-            p.s0 = sp[5 * kFlowBlock];
-            p.tw = p.cs = 0.0f;
-            trmc::ChannelConst<float> c;
-            c.z = sp[6 * kFlowBlock];
-            c.bfd = sp[7 * kFlowBlock];
-            c.sqrt_s0 = sp[8 * kFlowBlock];
-            c.sq1pz2 = sp[9 * kFlowBlock];
-            c.s0_n = sp[10 * kFlowBlock];
-            c.s0_ncc = sp[11 * kFlowBlock];
-            c.inv_n = sp[12 * kFlowBlock];
-            c.two_sq = 2.0f * c.sq1pz2;
-            c.half_dt = p.dt / 2.0f;
-            c.fp_ok = (p.twcc > 0.0f) && (p.ncc > 0.0f);
             trmc::Inflow<float> f;
             f.qup = qup;
             f.quc = qup;
             f.qdp = q_prev;
             f.ql = ql;
-            m.coef_ok = coef_guard(p.dt, f.ql);
-            const trmc::StepResult<float> r = trmc::mc_segment_step<float, M>(p, c, f, d_prev, m);
-            q_new = r.qdc;
-            v_new = r.velc;
-            d_new = r.depthc;
-            its = ((its + (uint32_t)min(r.iters, 3) + (r.over ? 4u : 0u)) & 0x00ffffffu) | ((uint32_t)min(r.iters, 255) << 24);
+            uint32_t it_now = 0, it_cost = 0;
+            if (trmc::step_has_flow(f)) {
+                // (with assume_short_ts a row reads flows its upstream rows published a step ago: no dependence chain runs
+                // through the step, so nothing of it is hoisted above the look-up -- see k_mc_flow -- and the two points of
+                // the bracket are formed inside step_solve)
+                const float *sp = s_par + threadIdx.x;
+                p.dt = dt;
+                p.dx = sp[0 * kFlowBlock];
+                p.bw = sp[1 * kFlowBlock];
+                p.twcc = sp[2 * kFlowBlock];
+                p.n = sp[3 * kFlowBlock];
+                p.ncc = sp[4 * kFlowBlock];
+                p.s0 = sp[5 * kFlowBlock];
+                p.tw = p.cs = 0.0f;
+                c.z = sp[6 * kFlowBlock];
+                c.bfd = sp[7 * kFlowBlock];
+                c.sqrt_s0 = sp[8 * kFlowBlock];
+                c.sq1pz2 = sp[9 * kFlowBlock];
+                c.s0_n = sp[10 * kFlowBlock];
+                c.s0_ncc = sp[11 * kFlowBlock];
+                c.inv_n = sp[12 * kFlowBlock];
+                trmc::derive_const(c, p);
+                trmc::StepPre<float> pre;
+                pre.have = false;
+                m.coef_ok = coef_guard(p.dt, f.ql);
+                const trmc::StepSolve<float> r = trmc::step_solve<float, M>(p, c, f, d_prev, pre, m);
+                q_new = r.qdc;
+                d_new = r.h;
+                routed = true;
+                it_now = (uint32_t)min(r.iters, 255);
+                it_cost = (uint32_t)min(r.iters, 3) + (r.over ? 4u : 0u);
+            }
+            its = ((its + it_cost) & 0x00ffffffu) | (it_now << 24);
             if (flags & 64u) { // streamflow nudging (see k_mc_step)
                 const size_t e = (size_t)a.gage_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1);
                 const uint8_t mode = a.da_mode[e];
@@ -1370,12 +1533,15 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
                 a.da_nudge[e] = nudge;
             }
         }
+        // the flow goes out as soon as it exists; the velocity (a power, a square root, a division no other row waits for)
+        // is formed after the granule is on its way
         {
             const unsigned long long g = ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(q_new);
             __hip_atomic_store(s_ring + (size_t)(t & (kLeanRing - 1)) * kFlowBlock + threadIdx.x, g, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(a.gran + (size_t)t * np + su, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (routed) v_new = trmc::step_velocity<float, M>(p, c, d_new, m);
         q_prev = q_new;
         d_prev = d_new;
         if (t == t_hi) // hand the depth over to the next launch of the window
@@ -1479,6 +1645,8 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
                                   // lagged rows at step t_done - maxlag; the window ends at nsteps + maxlag
     int32_t boundary_through = 0; // boundary rows hold their hydrographs for steps 1..boundary_through
     int32_t tiles_done = 0, launches = 0;
+    // wide levels routed K steps per launch with a skew of K steps per level (k_mc_tile); 0 = every level one step per launch
+    int32_t wide = 0, wide_k = 0, wide_next = 0, wide_through = 0; // levels; K; next tile; step every wide level has completed
 };
 
 struct trmc_plan {
@@ -1729,6 +1897,25 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
                            (const T *)pl->in_bfvd.p, a.q_tm, a.v_tm, a.d_tm, (int32_t)tp.nboundary, nsteps, np);
         r.boundary_through = nsteps;
     }
+    // Short-timestep windows of a wide network: the leading levels that can fill the device by themselves are routed K
+    // steps per launch (k_mc_tile), the rest one step per launch behind them.  Needs every boundary hydrograph up front
+    // (wide rows run ahead of the window's progress) and no lagged rows (the multi-GPU trunk has its own skew).
+    // TRMC_WIDE_MIN_ROWS (rows a level must have, default 32768; 0 switches the path off), TRMC_WIDE_LEVELS (at most,
+    // default 16) and TRMC_WIDE_K (steps per launch, default 12) are measurement / test knobs.
+    if (short_ts && pl->maxlag == 0 && r.boundary_through == nsteps && pl->nrouted > 0) {
+        auto env_int = [](const char *name, long dflt) {
+            const char *e = std::getenv(name);
+            return e && *e ? std::atol(e) : dflt;
+        };
+        const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 32768), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
+        int32_t W = 0;
+        if (min_rows > 0)
+            while (W < tp.nlevels && W < max_levels && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows) ++W;
+        if (W > 0) {
+            r.wide = W;
+            r.wide_k = (int32_t)std::max(1L, std::min((long)nsteps, env_int("TRMC_WIDE_K", std::max(1, std::min(12, nsteps / 8)))));
+        }
+    }
     HIP_TRY(hipEventRecord(pl->ev[1], st));
     HIP_TRY(hipGetLastError());
     pl->routed_nsteps = -1;
@@ -1745,7 +1932,29 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     hipStream_t st = pl->stream;
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
-        if (r.short_ts) {
+        if (r.short_ts && r.wide > 0) {
+            // wide levels: K steps per launch, level l trailing level l - 1 by K steps (k_mc_tile); the narrow tail of the
+            // level order: one step per launch, behind the last wide level.  A wide tile is queued when the tail needs it.
+            const int32_t K = r.wide_k, W = r.wide;
+            const int32_t w0 = tp.lvl_ptr[0], w1 = tp.lvl_ptr[W], s1 = tp.lvl_ptr[L];
+            const int32_t ntile = (nsteps + K - 1) / K + W - 1;
+            for (int32_t t = t0 + 1; t <= t_end; ++t) {
+                while (r.wide_through < t && r.wide_next < ntile) {
+                    const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
+                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, 0, st, a, w0, w1, r.wide_next, K);
+                    ++r.launches;
+                    ++r.wide_next;
+                    const int32_t done_tiles = r.wide_next - (W - 1); // tiles the LAST wide level has been through
+                    r.wide_through = done_tiles <= 0 ? 0 : std::min(nsteps, done_tiles * K);
+                }
+                if (s1 > w1) {
+                    launch_step<T, true>(st, a, w1, s1, t);
+                    ++r.launches;
+                }
+                if (t % kTile == 0 && t < nsteps)
+                    if (int rc = emit_tiles_through<T>(pl, t)) return rc;
+            }
+        } else if (r.short_ts) {
             const int32_t s0 = tp.lvl_ptr[0], s1 = tp.lvl_ptr[L];
             const int32_t lagmax = pl->maxlag;
             for (int32_t t = t0 + 1; t <= t_end; ++t) { // launch t: rows at step t, lagged rows at step t - lagmax

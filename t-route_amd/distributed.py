@@ -1,8 +1,8 @@
 """One-process-per-GPU routing of a partitioned network (see sharding.py).
 
 Phase 0: every rank routes the sub-basins / small networks it owns (one plan).
-Exchange: outlet hydrographs of the cut sub-basins are all-gathered (RCCL over
-xGMI when the process group is NCCL; gloo in the CPU tests) -- the data the
+Exchange: outlet hydrographs of the cut sub-basins are all-gathered (troute_amd.comm.Comm:
+RCCL over xGMI bound through the C ABI, or its shared-memory transport) -- the data the
 reference hands from one sub-network order to the next as
 ``flowveldepth_interorder`` (compute.py:882-897, consumed mc_reach.pyx:458-469).
 Phase 1: the rank that owns a trunk routes it with those hydrographs as
@@ -16,7 +16,7 @@ gather logic is exercised with world_size 2 on gloo without a GPU.
 import os as _os
 
 # Before any HIP runtime is loaded by this process: ONE hardware queue per stream priority.  A plan's compute stream
-# (high priority), its transpose stream (low) and the exchange stream (ordinary: torch's, RCCL's) then sit on three
+# (high priority), its transpose stream (low) and the exchange stream (ordinary: the communicator's, RCCL's) then sit on three
 # hardware queues whatever else the process has created.  With more queues per priority the runtime spreads streams over
 # them in creation order, and for some assignments a stream waiting on events of the plan's stream puts that stream's
 # launches in a slow mode -- 67 us instead of 25 us per step launch of a 600 k-row rank, for the whole window.  Which
@@ -57,8 +57,10 @@ class ShardedRouter:
         if plan_factory is None:
             from .plan import RoutingPlan  # the HIP engine; no fallback
 
-            def plan_factory(lp, li, par, boundary, prec, dev, **kw):
-                return RoutingPlan(lp, li, par, boundary, prec, dev, assume_short_ts=assume_short_ts, engine=engine, **kw)
+            def plan_factory(lp, li, par, boundary, prec, dev, short=None, **kw):
+                # short: the merged plan of the short-timestep device path is built for that mode whatever the caller said
+                return RoutingPlan(lp, li, par, boundary, prec, dev,
+                                   assume_short_ts=assume_short_ts if short is None else short, engine=engine, **kw)
         from .synthetic import upstream_csr
         self._hint = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
         if self._hint is not None:
@@ -66,13 +68,13 @@ class ShardedRouter:
                 raise ValueError("cost_hint shape mismatch")
             base_factory = plan_factory
 
-            def plan_factory(lp, li, par, boundary, prec, dev, rows=None):   # noqa: F811 - the hinted factory
-                return base_factory(lp, li, par, boundary, prec, dev, cost_hint=self._hint[rows])
+            def plan_factory(lp, li, par, boundary, prec, dev, rows=None, **kw):   # noqa: F811 - the hinted factory
+                return base_factory(lp, li, par, boundary, prec, dev, cost_hint=self._hint[rows], **kw)
         else:
             base_factory = plan_factory
 
-            def plan_factory(lp, li, par, boundary, prec, dev, rows=None):   # noqa: F811
-                return base_factory(lp, li, par, boundary, prec, dev)
+            def plan_factory(lp, li, par, boundary, prec, dev, rows=None, **kw):   # noqa: F811
+                return base_factory(lp, li, par, boundary, prec, dev, **kw)
         self.rank, self.world = rank, world
         self.nseg = to.shape[0]
         self.dtype = np.float32 if precision == 32 else np.float64
@@ -169,20 +171,24 @@ class ShardedRouter:
             take(self.plan1, self.rows1)
         return hint
 
-    # ---- device-resident exchange (torch tensors; NCCL = RCCL over xGMI on the GPU box) --------------
-    def enable_device_exchange(self, torch, device):
+    # ---- device-resident exchange (HIP buffers, streams and events through the C ABI; RCCL = troute_amd.comm.Comm) ----
+    def enable_device_exchange(self, comm, device=None):
         """Precompute the index maps for route_on_device(): every rank knows the whole partition, so the
-        position of every cut row / outlet row inside the all-gathered buffers is known up front."""
-        self._torch, self._tdev = torch, device
+        position of every cut row / outlet row inside the all-gathered buffers is known up front.
+        comm: a troute_amd.comm.Comm of this job's ranks (its all_gather is ncclAllGather over xGMI, or the
+        shared-memory transport when ranks share a device)."""
+        from . import comm as X
+        self._X, self._comm = X, comm
+        self._dev = self._mk["device"] if device is None else int(device)
         world = self.world
         part = self.part
         piece, phase, owner = part["piece"], part["phase"], part["owner"]
         row_phase, row_owner = phase[piece], owner[piece]
-        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
-        self._tdt = tdt
+        self._esz = np.dtype(self.dtype).itemsize
         # cut rows: slot (owner, index within the owner's ascending list)
         ncut = self.cut_rows.shape[0]
         self._max_cut = 0
+        self._d_b_index = None
         if ncut:
             counts = np.bincount(self.cut_owner, minlength=world)
             self._max_cut = int(counts.max())
@@ -192,7 +198,8 @@ class ShardedRouter:
                 idx_in_owner[m] = np.arange(int(m.sum()))
             flat = self.cut_owner.astype(np.int64) * self._max_cut + idx_in_owner
             if self.plan1 is not None:
-                self._t_b_index = torch.from_numpy(flat[self.b_cut_index]).to(device)
+                self._n_b_index = int(self.b_cut_index.shape[0])
+                self._d_b_index = X.DeviceBuffer.from_array(self._dev, flat[self.b_cut_index].astype(np.int64))
         # outlets: per rank, phase-0 outlets (ascending) followed by trunk outlets (ascending)
         outlets = self.outlets
         per_rank = []
@@ -205,72 +212,66 @@ class ShardedRouter:
         slot = np.concatenate([r * self._max_out + np.arange(len(x)) for r, x in enumerate(per_rank)])
         order = np.argsort(rows, kind="stable")
         self._out_rows = rows[order]
-        self._t_out_index = torch.from_numpy(slot[order].astype(np.int64)).to(device)
+        self._d_out_index = X.DeviceBuffer.from_array(self._dev, slot[order].astype(np.int64))
+        self._sc = X.stream_create(self._dev)          # exchange stream: the collectives are ordered on it
+        self._events = []
+
+    def _event(self):
+        e = self._X.event_create(self._dev)
+        self._events.append(e)
+        return e
 
     def upload_trunk(self):
         """Stage the trunk's forcing once (its boundary hydrographs arrive per route via the exchange)."""
         if self.plan1 is not None:
             self.plan1.upload_forcing(self.nsteps, self._qlat[self.rows1], self._q0_of(self.rows1), None)
 
-    def _exchange_buffers(self, bounds):
-        """Send/receive blocks of every time chunk and the stream/row-set handles, made once per window shape."""
-        key = tuple(int(x) for x in bounds)
+    def _window_buffers(self, widths, nsteps):
+        """Send / receive blocks of every time chunk, the outlet blocks and one event per hand-off, made once per window
+        shape (zero-filled device memory from the library)."""
+        key = (tuple(int(w) for w in widths), int(nsteps))
         if getattr(self, "_xbuf_key", None) == key:
             return self._xbuf
-        torch, dev, tdt, world = self._torch, self._tdev, self._tdt, self.world
-        if not hasattr(self, "_s0"):
-            self._s0 = torch.cuda.ExternalStream(self.plan0.stream(), device=dev)
-            self._s1 = torch.cuda.ExternalStream(self.plan1.stream(), device=dev) if self.plan1 is not None else None
-            self._sc = torch.cuda.Stream(device=dev)          # exchange stream: RCCL is ordered against it
-            self._rs_cut = self.plan0.rowset(self.my_cut_local)
-            self._rs_out0 = self.plan0.rowset(self.my_out0_local)
-            self._rs_out1 = self.plan1.rowset(self.my_out1_local) if self.plan1 is not None else None
-        x = {"send": [], "recv": [], "bq": []}
-        for c in range(len(key) - 1):
-            w = key[c + 1] - key[c]
+        X, dev, world, e = self._X, self._dev, self.world, self._esz
+        x = {"send": [], "recv": [], "ev_sent": [], "ev_filled": []}
+        for w in key[0]:
             if self._max_cut:
-                x["send"].append(torch.zeros((self._max_cut, w), dtype=tdt, device=dev))
-                x["recv"].append(torch.zeros((world, self._max_cut, w), dtype=tdt, device=dev))
-                x["bq"].append(torch.zeros((int(self._t_b_index.shape[0]), w), dtype=tdt, device=dev)
-                               if self.plan1 is not None else None)
-        x["send_o"] = torch.zeros((self._max_out, key[-1]), dtype=tdt, device=dev)
-        x["recv_o"] = torch.zeros((world, self._max_out, key[-1]), dtype=tdt, device=dev)
-        torch.cuda.synchronize(dev)
+                x["send"].append(X.DeviceBuffer(dev, self._max_cut * w * e))
+                x["recv"].append(X.DeviceBuffer(dev, world * self._max_cut * w * e))
+                x["ev_sent"].append(self._event())
+                x["ev_filled"].append(self._event())
+        x["send_o"] = X.DeviceBuffer(dev, self._max_out * nsteps * e)
+        x["recv_o"] = X.DeviceBuffer(dev, world * self._max_out * nsteps * e)
+        x["hyd"] = X.DeviceBuffer(dev, max(1, self._out_rows.shape[0]) * nsteps * e)
+        x["ev_out"] = self._event()
+        x["ev_out1"] = self._event()
         self._xbuf_key, self._xbuf = key, x
         return x
 
-    def route_on_device(self, qts_subdivisions, assume_short_ts, all_gather_into, nchunks=None):
-        """One routing window with every hand-off in HBM; returns (outlet_rows, hydrographs tensor on device).
-        ``all_gather_into(out[world, *in.shape], in)`` = torch.distributed.all_gather_into_tensor (RCCL over
-        xGMI), ordered against the current torch stream.
+    def route_on_device(self, qts_subdivisions, assume_short_ts, nchunks=None):
+        """One routing window with every hand-off in HBM; returns (outlet_rows, hydrographs as a comm.DeviceArray).
+        The collectives go through the communicator given to enable_device_exchange().
 
         assume_short_ts: the trunk rides in the launches of this rank's sub-basins, `2 * chunk` steps behind
         them (`_route_skewed`); otherwise sub-basins first, trunk after the exchange (`_route_phased`)."""
         if assume_short_ts:
-            # time chunks of the hand-off pipeline: a launch per chunk.  The level engine launches per timestep anyway
-            # and wants the trunk's skew (two chunks) short; the dataflow engine runs a chunk as one persistent launch
-            # and wants few of them (349 k-row ranks: 5.7 ms with 24 chunks, 4.5 with 8, 4.3 with 4 of 72 steps -- every
-            # launch ends in a drain; with 2 or 3 the trunk's owner, who trails by two chunks, is the slowest rank again)
-            if nchunks is None:
-                nchunks = 4 if getattr(self.plan0, "engine", "levels") == "flow" else 24
-            return self._route_skewed(qts_subdivisions, all_gather_into, nchunks)
+            return self._route_skewed(qts_subdivisions, nchunks)
         if not getattr(self, "_plan0_staged", True):
             raise RuntimeError("this router continued from the state of its merged (short-timestep) plan; upload() the "
                                "forcing with an explicit q0 before routing in the general mode")
-        return self._route_phased(qts_subdivisions, assume_short_ts, all_gather_into, nchunks)
+        return self._route_phased(qts_subdivisions, assume_short_ts, nchunks)
 
     # ---- short-timestep path: one plan, trunk time-skewed -----------------------------------------------
     def _merged_plan(self, lag):
         """plan0's table followed by the trunk table (trunk rows + boundary copies of the cut rows that feed
         it); trunk rows carry `lag`.  Built once per lag, forcing staged once per upload()."""
         if self.plan1 is None:                      # nothing to merge: plan0 itself, forcing staged by upload()
-            if not hasattr(self, "_sM"):
-                self._sM = self._torch.cuda.ExternalStream(self.plan0.stream(), device=self._tdev)
+            if not hasattr(self, "_rsM_cut"):
                 self._rsM_cut = self.plan0.rowset(self.my_cut_local)
                 self._rsM_out0 = self.plan0.rowset(self.my_out0_local)
                 self._rsM_out1 = None
             return self.plan0
-        if self.planM is not None and self._planM_lag == lag and self._planM_upload is self._qlat:
+        if self.planM is not None and self._planM_lag == lag and self._planM_upload == self._upload_gen:
             return self.planM
         mk = self._mk
         n0 = self.rows0.shape[0]
@@ -285,42 +286,28 @@ class ShardedRouter:
             boundary = np.concatenate([np.zeros(n0, np.uint8), self.boundary1.astype(np.uint8)])
             lagv = np.concatenate([np.zeros(n0, np.int32), np.where(self.boundary1, 0, lag).astype(np.int32)])
             self._rowsM = rows
-            self.planM = mk["factory"](up_ptr, up_idx, mk["params"][rows], boundary, mk["precision"], mk["device"], rows=rows)
+            self.planM = mk["factory"](up_ptr, up_idx, mk["params"][rows], boundary, mk["precision"], mk["device"], rows=rows,
+                                       short=True)
             self.planM.set_lag(lagv)
             if self._collect:
                 self.planM.collect_cost(True)
             self._planM_lag = lag
-            self._sM = self._torch.cuda.ExternalStream(self.planM.stream(), device=self._tdev)
             self._rsM_cut = self.planM.rowset(self.my_cut_local)
             self._rsM_out0 = self.planM.rowset(self.my_out0_local)
             self._rsM_out1 = self.planM.rowset(n0 + self.my_out1_local) if self.my_out1_global.size else None
         self.planM.upload_forcing(self.nsteps, self._qlat[self._rowsM], self._q0_of(self._rowsM), None)
-        self._planM_upload = self._qlat
+        self._planM_upload = self._upload_gen
         return self.planM
 
-    def _skew_buffers(self, nsteps, K):
-        key = ("skew", nsteps, K)
-        if getattr(self, "_sbuf_key", None) == key:
-            return self._sbuf
-        torch, dev, tdt, world = self._torch, self._tdev, self._tdt, self.world
-        if not hasattr(self, "_sc"):
-            self._sc = torch.cuda.Stream(device=dev)          # exchange stream: RCCL is ordered against it
-        C = -(-nsteps // K)
-        x = {"send": [], "recv": [], "bq": []}
-        for c in range(C):
-            w = min(nsteps, (c + 1) * K) - c * K
-            if self._max_cut:
-                x["send"].append(torch.zeros((self._max_cut, w), dtype=tdt, device=dev))
-                x["recv"].append(torch.zeros((world, self._max_cut, w), dtype=tdt, device=dev))
-                x["bq"].append(torch.zeros((int(self._t_b_index.shape[0]), w), dtype=tdt, device=dev)
-                               if self.plan1 is not None else None)
-        x["send_o"] = torch.zeros((self._max_out, nsteps), dtype=tdt, device=dev)
-        x["recv_o"] = torch.zeros((world, self._max_out, nsteps), dtype=tdt, device=dev)
-        torch.cuda.synchronize(dev)
-        self._sbuf_key, self._sbuf = key, x
-        return x
+    def _default_chunks(self, plan):
+        """time chunks of the hand-off pipeline: a launch per chunk.  The level engine launches per timestep anyway and
+        wants the trunk's skew (two chunks) short; the dataflow engine runs a chunk as one persistent launch and wants
+        few of them (349 k-row ranks: 5.7 ms with 24 chunks, 4.5 with 8, 4.3 with 4 of 72 steps -- every launch ends in
+        a drain; with 2 or 3 the trunk's owner, who trails by two chunks, is the slowest rank again).  Decided from the
+        engine of the plan that actually runs the window."""
+        return 4 if getattr(plan, "engine", "levels") == "flow" else 24
 
-    def _route_skewed(self, qts_subdivisions, all_gather_into, nchunks):
+    def _route_skewed(self, qts_subdivisions, nchunks):
         """assume_short_ts: a row at step t reads its upstream rows at step t-1 only.  The window is cut into
         chunks of K steps.  After this rank's sub-basins have been queued through chunk c, the chunk's
         cut-edge hydrographs are gathered (plan stream), all-gathered and written into the trunk's boundary
@@ -328,95 +315,95 @@ class ShardedRouter:
         when a launch needs chunk c's boundary values, their exchange was queued a whole chunk of launches
         earlier, so the plan stream's wait on it never stalls, and the trunk costs no launches of its own
         except the 2K that drain it at the end.  The host never waits inside the window."""
-        torch, nsteps = self._torch, self.nsteps
+        X, dev, comm, e = self._X, self._dev, self._comm, self._esz
+        nsteps = self.nsteps
+        if nchunks is None:
+            # (the merged plan has the same engine as plan0 would be given for the same rows plus the trunk: ask plan0 first,
+            # re-derive below once the merged plan exists)
+            nchunks = self._default_chunks(self.planM if self.planM is not None else self.plan0)
         K = max(1, -(-nsteps // max(1, int(nchunks))))
         C = -(-nsteps // K)
         lag = 2 * K if self.plan1 is not None else 0
         P = self._merged_plan(lag)
-        x = self._skew_buffers(nsteps, K)
-        sP, sc = self._sM, self._sc
+        x = self._window_buffers([min(nsteps, (c + 1) * K) - c * K for c in range(C)], nsteps)
+        sc = self._sc
         P.route_begin(nsteps, qts_subdivisions, True)
-        filled = [None] * C
+        filled = [False] * C
         last = nsteps + lag
         c = 0
-        ext = {}
+        sP = P.stream()
         while True:
             d_end = min((c + 1) * K, last)
-            # the stream this chunk's launch goes to (the dataflow engine alternates between two, so that consecutive
+            # the stream this chunk's launch goes to (the dataflow engine may alternate between two, so that consecutive
             # chunks overlap: trmc_plan_stream); the gather below is queued behind it
-            h = P.stream()
-            if h not in ext:
-                ext[h] = torch.cuda.ExternalStream(h, device=self._tdev)
-            sP = ext[h]
-            if lag and c >= 2 and filled[min(c - 2, C - 1)] is not None:
-                sP.wait_event(filled[min(c - 2, C - 1)])   # boundary values of chunk c-2: queued a chunk ago
+            sP = P.stream()
+            if lag and c >= 2 and filled[min(c - 2, C - 1)]:
+                X.stream_wait_event(dev, sP, x["ev_filled"][min(c - 2, C - 1)])   # boundary values of chunk c-2: queued a chunk ago
             P.route_advance(d_end)
             if c < C and self._max_cut:
                 tb, te = c * K, min(nsteps, (c + 1) * K)
                 w = te - tb
-                P.gather_flow_range(self._rsM_cut, tb, te, x["send"][c].data_ptr(), w)
-                ev = torch.cuda.Event()
-                ev.record(sP)
-                sc.wait_event(ev)
-                with torch.cuda.stream(sc):
-                    all_gather_into(x["recv"][c], x["send"][c])
+                P.gather_flow_range(self._rsM_cut, tb, te, x["send"][c].ptr, w)
+                X.event_record(dev, x["ev_sent"][c], sP)
+                X.stream_wait_event(dev, sc, x["ev_sent"][c])
+                comm.all_gather(x["send"][c].ptr, x["recv"][c].ptr, self._max_cut * w * e, sc)
                 if self.plan1 is not None:
                     # straight from the all-gathered block into the boundary rows: the fill kernel gathers by index
-                    P.set_boundary_flow_range(tb, te, x["recv"][c].data_ptr(), w, stream=sc.cuda_stream,
-                                              index_ptr=self._t_b_index.data_ptr())
-                    filled[c] = torch.cuda.Event()
-                    filled[c].record(sc)
+                    P.set_boundary_flow_range(tb, te, x["recv"][c].ptr, w, stream=sc, index_ptr=self._d_b_index.ptr)
+                    X.event_record(dev, x["ev_filled"][c], sc)
+                    filled[c] = True
             if d_end >= last:
                 break
             c += 1
         # network outlets: phase-0 outlets then trunk outlets in this rank's slot of the final all-gather
         send_o, recv_o = x["send_o"], x["recv_o"]
         n0 = self.my_out0_local.shape[0]
-        P.gather_flow_range(self._rsM_out0, 0, nsteps, send_o.data_ptr(), nsteps)
+        P.gather_flow_range(self._rsM_out0, 0, nsteps, send_o.ptr, nsteps)
         if self._rsM_out1 is not None:
-            P.gather_flow_range(self._rsM_out1, 0, nsteps, send_o[n0:].data_ptr(), nsteps)
-        ev = torch.cuda.Event()
-        ev.record(sP)
-        sc.wait_event(ev)
-        with torch.cuda.stream(sc):
-            all_gather_into(recv_o, send_o)
-            hyd = recv_o.view(-1, nsteps).index_select(0, self._t_out_index)
+            P.gather_flow_range(self._rsM_out1, 0, nsteps, send_o.ptr + n0 * nsteps * e, nsteps)
+        X.event_record(dev, x["ev_out"], sP)
+        X.stream_wait_event(dev, sc, x["ev_out"])
+        comm.all_gather(send_o.ptr, recv_o.ptr, self._max_out * nsteps * e, sc)
+        X.gather_rows(dev, recv_o.ptr, self._d_out_index.ptr, self._out_rows.shape[0], nsteps * e, x["hyd"].ptr, sc)
         self.last_stats = {"phase0": P.route_end()}
-        sc.synchronize()
-        return self._out_rows, hyd
+        X.stream_synchronize(dev, sc)
+        return self._out_rows, X.DeviceArray(x["hyd"], (self._out_rows.shape[0], nsteps), self.dtype, sc)
 
     # ---- general path: sub-basins, exchange, trunk (optionally pipelined in time chunks) ---------------------
-    def _route_phased(self, qts_subdivisions, assume_short_ts, all_gather_into, nchunks=None):
+    def _route_phased(self, qts_subdivisions, assume_short_ts, nchunks=None):
         """Sub-basins on plan0's stream, trunk on plan1's, the exchange between them on a third stream; with
         nchunks > 1 the three are pipelined in time (the level wavefront of the general mode restarts per
         chunk, so the default keeps the window whole)."""
-        torch, nsteps = self._torch, self.nsteps
+        X, dev, comm, e = self._X, self._dev, self._comm, self._esz
+        nsteps = self.nsteps
         if nchunks is None:
             nchunks = 1
         nchunks = max(1, min(int(nchunks), nsteps))
         bounds = np.round(np.linspace(0, nsteps, nchunks + 1)).astype(np.int64)
-        x = self._exchange_buffers(bounds)
-        s0, s1, sc = self._s0, self._s1, self._sc
+        x = self._window_buffers(np.diff(bounds), nsteps)
+        if not hasattr(self, "_rs_cut"):
+            self._rs_cut = self.plan0.rowset(self.my_cut_local)
+            self._rs_out0 = self.plan0.rowset(self.my_out0_local)
+            self._rs_out1 = self.plan1.rowset(self.my_out1_local) if self.plan1 is not None else None
+        sc = self._sc
         self.plan0.route_begin(nsteps, qts_subdivisions, assume_short_ts)
         if self.plan1 is not None:
             self.plan1.route_begin(nsteps, qts_subdivisions, assume_short_ts)
+        s0 = self.plan0.stream()
+        s1 = self.plan1.stream() if self.plan1 is not None else 0
         for c in range(nchunks):
             tb, te = int(bounds[c]), int(bounds[c + 1])
             w = te - tb
             self.plan0.route_advance(te)
             if self._max_cut:
-                self.plan0.gather_flow_range(self._rs_cut, tb, te, x["send"][c].data_ptr(), w)
-                ev = torch.cuda.Event()
-                ev.record(s0)
-                sc.wait_event(ev)
-                with torch.cuda.stream(sc):
-                    all_gather_into(x["recv"][c], x["send"][c])
+                self.plan0.gather_flow_range(self._rs_cut, tb, te, x["send"][c].ptr, w)
+                X.event_record(dev, x["ev_sent"][c], s0)
+                X.stream_wait_event(dev, sc, x["ev_sent"][c])
+                comm.all_gather(x["send"][c].ptr, x["recv"][c].ptr, self._max_cut * w * e, sc)
                 if self.plan1 is not None:
-                    ev2 = torch.cuda.Event()
-                    ev2.record(sc)
-                    s1.wait_event(ev2)
-                    self.plan1.set_boundary_flow_range(tb, te, x["recv"][c].data_ptr(), w,
-                                                       index_ptr=self._t_b_index.data_ptr())
+                    X.event_record(dev, x["ev_filled"][c], sc)
+                    X.stream_wait_event(dev, s1, x["ev_filled"][c])
+                    self.plan1.set_boundary_flow_range(tb, te, x["recv"][c].ptr, w, index_ptr=self._d_b_index.ptr)
             if self.plan1 is not None:
                 if not self._max_cut:
                     self.plan1.set_boundary_flow_range(tb, te, 0, w)
@@ -424,25 +411,22 @@ class ShardedRouter:
         # network outlets: phase-0 outlets then trunk outlets in this rank's slot of the final all-gather
         send_o, recv_o = x["send_o"], x["recv_o"]
         n0 = self.my_out0_local.shape[0]
-        self.plan0.gather_flow_range(self._rs_out0, 0, nsteps, send_o.data_ptr(), nsteps)
-        ev = torch.cuda.Event()
-        ev.record(s0)
-        sc.wait_event(ev)
+        self.plan0.gather_flow_range(self._rs_out0, 0, nsteps, send_o.ptr, nsteps)
+        X.event_record(dev, x["ev_out"], s0)
+        X.stream_wait_event(dev, sc, x["ev_out"])
         if self.plan1 is not None:
             if self.my_out1_global.size:
-                self.plan1.gather_flow_range(self._rs_out1, 0, nsteps, send_o[n0:].data_ptr(), nsteps)
-            ev1 = torch.cuda.Event()
-            ev1.record(s1)
-            sc.wait_event(ev1)
-        with torch.cuda.stream(sc):
-            all_gather_into(recv_o, send_o)
-            hyd = recv_o.view(-1, nsteps).index_select(0, self._t_out_index)
+                self.plan1.gather_flow_range(self._rs_out1, 0, nsteps, send_o.ptr + n0 * nsteps * e, nsteps)
+            X.event_record(dev, x["ev_out1"], s1)
+            X.stream_wait_event(dev, sc, x["ev_out1"])
+        comm.all_gather(send_o.ptr, recv_o.ptr, self._max_out * nsteps * e, sc)
+        X.gather_rows(dev, recv_o.ptr, self._d_out_index.ptr, self._out_rows.shape[0], nsteps * e, x["hyd"].ptr, sc)
         stats = {"phase0": self.plan0.route_end()}
         if self.plan1 is not None:
             stats["phase1"] = self.plan1.route_end()
-        sc.synchronize()
+        X.stream_synchronize(dev, sc)
         self.last_stats = stats
-        return self._out_rows, hyd
+        return self._out_rows, X.DeviceArray(x["hyd"], (self._out_rows.shape[0], nsteps), self.dtype, sc)
 
     def close(self):
         if self.planM is not None:
@@ -450,6 +434,21 @@ class ShardedRouter:
         self.plan0.close()
         if self.plan1 is not None:
             self.plan1.close()
+        if getattr(self, "_X", None) is not None:          # exchange stream, events and buffers of route_on_device()
+            for ev in getattr(self, "_events", []):
+                self._X.event_destroy(self._dev, ev)
+            self._events = []
+            if getattr(self, "_sc", 0):
+                self._X.stream_destroy(self._dev, self._sc)
+                self._sc = 0
+            for b in list(getattr(self, "_xbuf", {}).values()):
+                for bb in (b if isinstance(b, list) else [b]):
+                    if hasattr(bb, "free"):
+                        bb.free()
+            self._xbuf, self._xbuf_key = {}, None
+            for name in ("_d_b_index", "_d_out_index"):
+                if getattr(self, name, None) is not None:
+                    getattr(self, name).free()
 
     def _q0_of(self, rows):
         return None if self._q0 is None else self._q0[rows]
@@ -460,6 +459,9 @@ class ShardedRouter:
         AbstractNetwork.py:177-191, without the host round trip)."""
         self.nsteps = nsteps
         self._qlat, self._q0 = qlat, q0
+        # every upload() re-stages the merged plan too, whether or not the caller reuses its arrays (a forcing buffer
+        # refilled in place is a new window all the same)
+        self._upload_gen = getattr(self, "_upload_gen", 0) + 1
         if q0 is None and self.planM is not None:
             # the windows so far ran on the merged plan (sub-basins + time-skewed trunk, the short-timestep device path):
             # that is where the resident state lives; _merged_plan() stages the new forcing there

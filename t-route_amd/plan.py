@@ -241,7 +241,7 @@ class RoutingPlan:
         return self.stats()
 
     def stream(self):
-        """hipStream_t of the plan as an integer (wrap with torch.cuda.ExternalStream to order RCCL against it)."""
+        """hipStream_t of the plan as an integer (what troute_amd.comm's event / stream calls and the collectives take)."""
         s = C.c_void_p(0)
         _lib.check(_lib.lib().trmc_plan_stream(self._h, C.byref(s)))
         return s.value or 0

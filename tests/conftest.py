@@ -10,15 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The simulated multi-rank GPU test carries its hand-off buffers in torch tensors.  torch bundles
-    # its own HIP runtime, which must be the first one loaded into the process: import it before any
-    # test loads libtrmc.so (linked against /opt/rocm) when GPU tests are selected.
-    expr = config.getoption("-m") or ""
-    if "gpu" in expr and "not gpu" not in expr:
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -106,6 +106,79 @@ def test_world2_gloo_equals_single_process(tmp_path, short):
         assert np.array_equal(o["hyd"].view(np.uint32), hyd1.view(np.uint32))
 
 
+def _shm_worker(rank, world, key, tmp, short):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_plan import OraclePlan
+    from troute_amd.comm import Comm
+    from troute_amd.distributed import ShardedRouter
+    comm = Comm(rank, world, device=-1, backend="shm", key=key)
+    net = small_conus()
+    router = ShardedRouter(net["to"], net["params"], rank=rank, world=world, plan_factory=OraclePlan)
+    q0 = np.zeros((net["to"].shape[0], 3), np.float32)
+    router.upload(24, net["qlat"], q0)
+    rows, hyd = router.route(12, short, comm.all_gather_rows_host)
+    t = comm.all_reduce_max_host(np.array([float(rank + 1)]))
+    np.savez(os.path.join(tmp, f"out_{rank}.npz"), rows=rows, hyd=hyd, ncut=router.cut_rows.shape[0],
+             has_trunk=router.plan1 is not None, tmax=t)
+    comm.barrier()
+    comm.close()
+
+
+@pytest.mark.parametrize("short", [True, False])
+def test_world2_own_communicator_equals_single_process(tmp_path, short):
+    """The same job with the product's OWN communicator (troute_amd.comm.Comm over the C ABI, shared-memory transport,
+    no device: host-pointer collectives) instead of gloo: two processes, hand-off of the cut-edge hydrographs and the
+    final outlet gather through trmc_comm_all_gather_host."""
+    import multiprocessing as mp
+    from oracle_plan import OraclePlan
+    from troute_amd.distributed import ShardedRouter
+    net = small_conus()
+    q0 = np.zeros((net["to"].shape[0], 3), np.float32)
+    single = ShardedRouter(net["to"], net["params"], plan_factory=OraclePlan)
+    single.upload(24, net["qlat"], q0)
+    rows1, hyd1 = single.route(12, short)
+    ctx = mp.get_context("spawn")
+    key = f"t{os.getpid()}_{int(short)}"
+    ps = [ctx.Process(target=_shm_worker, args=(r, 2, key, str(tmp_path), short)) for r in range(2)]
+    [p.start() for p in ps]
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    outs = [np.load(tmp_path / f"out_{r}.npz") for r in range(2)]
+    assert int(outs[0]["ncut"]) > 0 and (bool(outs[0]["has_trunk"]) or bool(outs[1]["has_trunk"]))
+    for o in outs:
+        assert np.array_equal(o["rows"], rows1)
+        assert np.array_equal(o["hyd"].view(np.uint32), hyd1.view(np.uint32))
+        assert float(o["tmax"][0]) == 2.0
+
+
+def test_communicator_chunks_blocks_larger_than_its_segment():
+    """all_gather_host of blocks larger than the shared segment goes through it a slice at a time (two threads of this
+    process as the two ranks)."""
+    import threading
+    from troute_amd.comm import Comm
+    key = f"c{os.getpid()}"
+    rng = np.random.default_rng(3)
+    data = [rng.integers(0, 255, 300_000, dtype=np.uint8) for _ in range(2)]
+    got, errs = [None, None], []
+
+    def run(r):
+        try:
+            c = Comm(r, 2, device=-1, backend="shm", key=key, shm_bytes=64 * 1024)
+            got[r] = c.all_gather_host(data[r])
+            parts = c.all_gather_rows_host(data[r][: 1000 * (r + 1)].reshape(-1, 10))
+            assert [p.shape for p in parts] == [(100, 10), (200, 10)]
+            c.close()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert not errs, errs
+    for r in range(2):
+        assert np.array_equal(got[r][0], data[0]) and np.array_equal(got[r][1], data[1])
+
+
 def test_partition_by_measured_cost_balances_cost_not_rows():
     """sharding.partition(row_cost=...): pieces are packed by the cost their rows were measured to need."""
     from troute_amd import sharding, synthetic

@@ -1,37 +1,20 @@
 """Device-resident, time-pipelined multi-rank path (ShardedRouter.route_on_device) on ONE GPU: two ranks run as two
-threads of this process and exchange through an in-process stand-in for
-torch.distributed.all_gather_into_tensor.  Checks that the HBM-to-HBM hand-off (sub-basin outlets ->
-trunk boundary rows, final outlet gather) reproduces the single-rank result bit for bit."""
+threads of this process, each with its own communicator handle (troute_amd.comm.Comm over the C ABI; the shared-memory
+transport, because RCCL refuses two ranks on one device -- the calls, buffers, streams and events are the ones the RCCL
+transport gets).  Checks that the HBM-to-HBM hand-off (sub-basin outlets -> trunk boundary rows, final outlet gather)
+reproduces the single-rank result bit for bit."""
+import os
 import threading
 
 import numpy as np
 import pytest
 
 from troute_amd import synthetic
+from troute_amd.comm import Comm
 from troute_amd.distributed import ShardedRouter
 
 pytestmark = pytest.mark.gpu
-
-
-class ThreadAllGather:
-    def __init__(self, world):
-        self.world = world
-        self.slots = [None] * world
-        self.barrier = threading.Barrier(world)
-
-    def for_rank(self, rank):
-        def all_gather_into(out, t):
-            """torch.distributed.all_gather_into_tensor for threads of one process: ordered against the
-            caller's current stream like the real collective (waits for it, leaves the result on it)"""
-            import torch
-            torch.cuda.current_stream().synchronize()
-            self.slots[rank] = t
-            self.barrier.wait()
-            for r in range(self.world):
-                out[r].copy_(self.slots[r])
-            torch.cuda.current_stream().synchronize()
-            self.barrier.wait()
-        return all_gather_into
+_serial = [0]
 
 
 @pytest.mark.parametrize("short,nchunks,retune", [(True, None, False), (True, 1, False), (True, 5, False),
@@ -50,7 +33,6 @@ def test_two_ranks_with_chunk_overlap_on_two_streams(monkeypatch):
 
 
 def _two_ranks(short, nchunks, retune):
-    import torch
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
     q0 = np.zeros((nseg, 3), np.float32)
@@ -62,33 +44,35 @@ def _two_ranks(short, nchunks, retune):
     single.close()
 
     world = 2
-    ag = ThreadAllGather(world)
+    _serial[0] += 1
+    key = f"sim{os.getpid()}_{_serial[0]}"
     results = [None] * world
     errors = []
 
     def run(rank):
         try:
+            comm = Comm(rank, world, device=0, backend="shm", key=key)
             r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0)
-            r.enable_device_exchange(torch, torch.device("cuda", 0))
+            r.enable_device_exchange(comm)
             r.upload(nsteps, net["qlat"], q0)
             r.upload_trunk()
             if retune:                                  # every rank rebuilds its plans from its own tuning window
                 r.collect_cost(True)
-                r.route_on_device(qts, short, ag.for_rank(rank), nchunks)
-                hint = r.iteration_hint()
+                r.route_on_device(qts, short, nchunks)
+                hint = comm.all_reduce_max_host(r.iteration_hint())   # every rank measured its own rows
                 assert hint.max() > 0
                 r.close()
                 r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0, cost_hint=hint)
-                r.enable_device_exchange(torch, torch.device("cuda", 0))
+                r.enable_device_exchange(comm)
                 r.upload(nsteps, net["qlat"], q0)
                 r.upload_trunk()
             for _ in range(2):                          # twice: the staged buffers must be reusable
-                rows, hyd = r.route_on_device(qts, short, ag.for_rank(rank), nchunks)
-            results[rank] = (rows, hyd.cpu().numpy(), r.cut_rows.shape[0], r.plan1 is not None)
+                rows, hyd = r.route_on_device(qts, short, nchunks)
+            results[rank] = (rows, hyd.numpy(), r.cut_rows.shape[0], r.plan1 is not None)
             r.close()
+            comm.close()
         except Exception as e:                          # pragma: no cover
             errors.append(e)
-            ag.barrier.abort()
 
     ts = [threading.Thread(target=run, args=(k,)) for k in range(world)]
     [t.start() for t in ts]

@@ -113,13 +113,17 @@ def test_lowercolorado_return_tuple_shape(lc):
     assert r[6].shape == (lc.nseg, lc.nts) and len(r[7]) == 3 and r[8].shape == (0, lc.nts + 1) and len(r[9]) == 4
 
 
-@pytest.mark.parametrize("engine", ["flow", "levels"])
+@pytest.mark.parametrize("engine", ["flow", "levels", "levels-wide"])
 @pytest.mark.parametrize("short", [True, False])
 def test_lowercolorado_fp32_bit_identical_to_reference_golden(lc, short, engine, monkeypatch):
     """Golden = reference Fortran kernel symbol driven through the restated loop (make_fixtures.py):
     12 time slices x every segment and 100 probe segments x every step, both timestep modes, on BOTH engines
-    (the dataflow engine k_mc_flow and the level engine k_mc_step)."""
-    monkeypatch.setenv("TRMC_ENGINE", engine)
+    (the dataflow engine k_mc_flow and the level engine k_mc_step), the level engine also with its wide levels several
+    steps per launch (k_mc_tile)."""
+    monkeypatch.setenv("TRMC_ENGINE", engine.split("-")[0])
+    if engine.endswith("-wide"):
+        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
+        monkeypatch.setenv("TRMC_WIDE_K", "5")
     _, fvd = route_lc(lc, short)
     g = lc.golden()
     tag = "shortts" if short else "fullts"
@@ -221,14 +225,26 @@ def run_both(ups, params, qlat, q0, nsteps, qts, short):
     return got, want
 
 
-ENGINES = ["flow", "levels"]   # TRMC_ENGINE: the dataflow engine (k_mc_flow*) and the level engine (k_mc_step)
+# TRMC_ENGINE: the dataflow engine (k_mc_flow*), the level engine one step per launch (k_mc_step), and the level engine
+# with its wide levels routed several steps per launch under a level skew (k_mc_tile; at its default thresholds only
+# networks of CONUS width take that path -- here every level of 32 rows or more does, five steps per launch)
+ENGINES = ["flow", "levels", "levels-wide"]
+
+
+def set_engine(monkeypatch, engine):
+    monkeypatch.setenv("TRMC_ENGINE", engine.split("-")[0])
+    if engine.endswith("-wide"):
+        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
+        monkeypatch.setenv("TRMC_WIDE_K", "5")
+    else:
+        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
 
 
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("nseg", [1, 2, 63, 64, 65, 1000, 6000])
 @pytest.mark.parametrize("short", [True, False])
 def test_random_forests_bit_identical(nseg, short, engine, monkeypatch):
-    monkeypatch.setenv("TRMC_ENGINE", engine)
+    set_engine(monkeypatch, engine)
     rng = np.random.default_rng(1000 + nseg)
     to = H.random_network(rng, nseg)
     _, _, ups = H.reaches_from_to(to)
@@ -471,7 +487,7 @@ def test_cost_hinted_plan_order_changes_nothing(short, engine, monkeypatch):
     """A plan built with a cost hint (rows of a level -- or of a block, on the dataflow engine -- grouped by the secant
     iterations they needed in an earlier window) visits the rows in another order and must produce the same bits, which
     are the ORACLE's: random hints, the plan's own iteration counts as hint; both engines."""
-    monkeypatch.setenv("TRMC_ENGINE", engine)
+    set_engine(monkeypatch, engine)
     rng = np.random.default_rng(4242)
     nseg = 90000
     to = H.random_network(rng, nseg)
@@ -518,7 +534,7 @@ def test_extreme_parameters_and_depths_around_the_fast_division_guard(short, eng
     log-uniform over the whole admitted range [2**-14, 2**17] (twcc / ncc sometimes 0) and initial depths from 1e-12 to
     1e4 -- on both sides of the depth test -- must agree bit for bit; one parameter outside the range switches the
     plan to plain divisions, same results.  Both engines."""
-    monkeypatch.setenv("TRMC_ENGINE", engine)
+    set_engine(monkeypatch, engine)
     rng = np.random.default_rng(77)
     nseg = 70000
     to = H.random_network(rng, nseg)
