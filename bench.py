@@ -26,7 +26,8 @@ Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   cpu_baseline      the reference Fortran kernel (oracle/_ref, amdflang -O2) over every segment, decomposed like the
                     reference's by-subnetwork-jit method, C + OpenMP, bounded sample of the timesteps
   untuned           the plan built from the topology alone, day N, cold start
-  value_with_d2h    outlet hydrographs + final state copied to the host inside the timed region
+  value             INCLUDES the copy of what a throughput-mode caller consumes -- outlet hydrographs + final state -- to the
+                    host, made on a copy stream beside the next window;  value_resident: everything left in HBM
   parity_mode       the whole flowveldepth array copied to the host inside the timed region
   tuned_window_warm / cold_start / independent_forcing_cold   the tuned plan on the very window it was tuned on, on a
                     cold start, on an unrelated day
@@ -75,7 +76,8 @@ def parse():
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
     ap.add_argument("--no-parity-sample", action="store_true", help="skip the post-timing oracle check of sampled networks")
-    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic / roofline.valu = null)")
+    ap.add_argument("--headline-only", action="store_true", help="stop after the headline's timed windows (what the counter passes run)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: one per CPU the cgroup grants, at most the physical cores)")
     return ap.parse_args()
@@ -153,13 +155,14 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     }
 
 
-def parity_sample(net, router, days, q0, nsteps, qts, n_networks=50, seed=20250930):
+def parity_sample(net, router, days, q0, nsteps, qts, n_networks=50, seed=20250930, outlets=None):
     """Checker, run AFTER the timed region: ~50 whole independent networks of the workload (10-3 000 segments each) are
     routed alone by the oracle (oracle/, the CPU restatement pinned to the reference Fortran) through the same sequence
     of windows the router has been through -- `days`: the forcing of day N-1 (cold start from q0), day N, day N+1 -- and
     compared bit for bit with what the timed plan holds for them after the LAST timed window: the hydrograph of every
     sampled row and the final state.  Independent networks do not interact, so the sub-collection's result inside the
-    2.7 M-row run must equal its result alone."""
+    2.7 M-row run must equal its result alone.  outlets = (rows, hydrographs): the multi-GPU job's product, the gathered
+    outlet hydrographs of EVERY network -- then those of the sampled networks are what is compared."""
     from oracle import oracle as O
     from troute_amd import sharding
     from troute_amd.distributed import restrict_csr
@@ -175,8 +178,9 @@ def parity_sample(net, router, days, q0, nsteps, qts, n_networks=50, seed=202509
     pick = rng.choice(cand, min(n_networks, cand.size), replace=False)
     rows = np.flatnonzero(np.isin(lab, pick))
     t0 = time.perf_counter()
-    hyd = router.plan0.gather_flow_rows(rows)           # (world == 1: the plan's rows are the network's rows)
-    final = router.plan0.download_final_state()[rows]
+    if outlets is None:
+        hyd = router.plan0.gather_flow_rows(rows)           # (world == 1: the plan's rows are the network's rows)
+        final = router.plan0.download_final_state()[rows]
     up_ptr, up_idx = upstream_csr(to)
     g2l = np.full(nseg, -1, np.int64)
     g2l[rows] = np.arange(rows.size)
@@ -188,6 +192,17 @@ def parity_sample(net, router, days, q0, nsteps, qts, n_networks=50, seed=202509
         want = O.network_by_segment(nsteps, qts, lp, li, lvl, params[rows], state, np.ascontiguousarray(ql[rows]), True, det=True)
         state = np.ascontiguousarray(want[:, -1, :][:, [0, 0, 2]])
     u32 = lambda x: np.ascontiguousarray(x).view(np.uint32)   # noqa: E731
+    if outlets is not None:
+        o_rows, o_hyd = outlets
+        mine = np.flatnonzero(to[rows] < 0)                   # the sampled networks' outlets, as local rows
+        at = np.searchsorted(o_rows, rows[mine])
+        assert np.array_equal(o_rows[at], rows[mine])
+        same_h = bool(np.array_equal(u32(o_hyd[at]), u32(want[mine, 1:, 0])))
+        return {"networks": int(pick.size), "segments": int(rows.size), "windows": len(days), "timesteps": int(nsteps),
+                "bit_identical": same_h, "compared": "outlet hydrographs of the sampled networks out of the job's all-gathered block",
+                "differing_values": int((u32(o_hyd[at]) != u32(want[mine, 1:, 0])).sum()),
+                "checker": "oracle/ (C restatement pinned to the reference Fortran), det_pow instantiation",
+                "seconds": round(time.perf_counter() - t0, 1)}
     same_h = bool(np.array_equal(u32(hyd), u32(want[:, 1:, 0])))
     same_s = bool(np.array_equal(u32(final), u32(state)))
     return {"networks": int(pick.size), "segments": int(rows.size), "windows": len(days), "timesteps": int(nsteps),
@@ -372,30 +387,48 @@ def main():
 
     def timed(router, short_ts, steps, warmup, d2h=None):
         """EXACTLY `steps` routing windows between barriers; max over ranks.  d2h: None (results stay in HBM), "state"
-        (outlet hydrographs + final state copied to the host inside the clock: what a caller of the throughput mode
-        consumes) or "full" (the whole flowveldepth array: parity mode)."""
-        def fetch(hyd):
+        (outlet hydrographs + final state on the host inside the clock: what a caller of the throughput mode consumes,
+        SURVEY 8d -- copied on a copy stream beside the NEXT window, the last copy waited for before the clock stops) or
+        "full" (the whole flowveldepth array, synchronously: parity mode)."""
+        def one():
             if d2h == "state":
-                hyd = router.outlet_hydrographs() if hyd is None else hyd.numpy()
-                router.plan0.download_final_state()
-            elif d2h == "full":
+                if use_dist:
+                    rows, hyd = route_once(router, short_ts)
+                    got = router.fetch_wait()                     # window k - 1, copied beside window k
+                    router.fetch_begin(hyd, want_hyd=(rank == 0))
+                    return got[0]
+                return router.route_and_fetch(a.qts, short_ts)[0]
+            rows, hyd = route_once(router, short_ts)
+            if d2h == "full":
                 router.plan0.download_fvd()
             return hyd
 
+        def drain():
+            return router.fetch_wait()[0] if d2h == "state" else None
+
         for _ in range(warmup):
-            fetch(route_once(router, short_ts)[1])   # (the page-locked result buffers are taken from the pool and given back)
+            one()                                    # (the page-locked result buffers are taken from the pool and given back)
+        drain()
         sync()
         t0 = time.perf_counter()
         mains, totals, launches, hyd = [], [], 0, None
+        dbg = []
         for _ in range(steps):
-            rows, hyd = route_once(router, short_ts)
+            td = time.perf_counter()
+            hyd = one()
+            dbg.append((time.perf_counter() - td) * 1e3)
             st = router.last_stats["phase0"]
             mains.append(st["ms_main"])
             totals.append(st["ms_total"])
             launches = st["main_launches"]
-            hyd = fetch(hyd)
+        td = time.perf_counter()
+        last = drain()
+        hyd = last if last is not None else hyd
         sync()
         el = time.perf_counter() - t0
+        if os.environ.get("TRMC_BENCH_DEBUG"):
+            print(f"[timed d2h={d2h}] per-step wall ms {[round(x, 2) for x in dbg]} drain {(time.perf_counter() - td) * 1e3:.2f} "
+                  f"device ms_total {[round(x, 2) for x in totals]}", file=sys.stderr)
         if comm is not None:
             el = float(comm.all_reduce_max_host(np.array([el], dtype=np.float64))[0])
         return {"el": el, "ms_main": float(np.mean(mains)), "ms_total": float(np.mean(totals)), "launches": launches,
@@ -449,18 +482,24 @@ def main():
         router.upload(a.nsteps, qlat_b, None)
         t_tune += time.perf_counter() - t0
 
-    # ---- 3. the headline: day N+1 on the plan tuned on day N -----------------------------------------------------------
-    head = timed(router, True, a.steps, a.warmup)
+    # ---- 3. the headline: day N+1 on the plan tuned on day N; every window's outlet hydrographs and final state arrive on
+    # the host inside the clock (SURVEY 8d's throughput mode), copied beside the next window ---------------------------
+    head = timed(router, True, a.steps, a.warmup, d2h="state")
     hyd = head["hyd"]
-    if hyd is None:
-        hyd = router.outlet_hydrographs()          # one D2H after the timed region, to report/check
-    elif not isinstance(hyd, np.ndarray):
-        hyd = hyd.numpy()
+    if hyd is None:                                 # (a rank other than 0 of a multi-GPU job does not fetch the outlet block)
+        hyd = np.zeros((0, a.nsteps), np.float32)
     assert np.isfinite(hyd).all()
+    if a.headline_only:            # (a counter pass of pmc_counters(): the last windows of the process are the headline's)
+        router.close()
+        if comm is not None:
+            comm.close()
+        return
+    resident = timed(router, True, max(1, min(a.steps, 3)), 1)
     parity = None
-    if rank == 0 and world == 1 and not a.no_parity_sample and a.precision == 32:
+    if rank == 0 and not a.no_parity_sample and a.precision == 32:
         try:      # what the timed plan holds after the last timed window, against the oracle (checker use, outside the clock)
-            parity = parity_sample(net, router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts)
+            parity = parity_sample(net, router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
+                                   outlets=(router._out_rows, hyd) if use_dist else None)
         except Exception as e:
             parity = {"error": repr(e)}
     value = rate(head)
@@ -473,13 +512,12 @@ def main():
         allr = comm.all_gather_host(np.array([head["ms_main"], float(seg0)], dtype=np.float64))
         per_rank = [{"rank": i, "ms_main": float(t[0]), "segment_steps": int(t[1])} for i, t in enumerate(allr)]
 
-    extra = {}
+    extra = {"value_resident": {"value": rate(resident), "unit": "segment-timesteps/s",
+                                "ms_per_step": resident["el"] / resident["steps"] * 1e3, "ms_main": resident["ms_main"],
+                                "what": "the same windows with every result left in HBM (no copy to the host in the clock)"},
+             "copied_per_step": f"outlet hydrographs [{len(net['net_sizes'])} x {a.nsteps}] + final state [{nseg} x 3] into page-locked "
+                                "host arrays on a copy stream beside the next window; the last window's copy is waited for inside the clock"}
     if not use_dist:
-        dsteps = max(1, min(a.steps, 3))
-        w = timed(router, True, dsteps, 1, d2h="state")
-        extra["value_with_d2h"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / dsteps * 1e3,
-                                   "copied": f"outlet hydrographs [{hyd.shape[0]} x {hyd.shape[1]}] + final state [{nseg} x 3], "
-                                             "page-locked arrays from the library's pool, inside the timed region"}
         if not a.no_parity_mode:
             w = timed(router, True, 2, 1, d2h="full")
             extra["parity_mode"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / 2 * 1e3,
@@ -538,8 +576,38 @@ def main():
             diffusive = {"error": repr(e)}
 
     if rank == 0:
-        kernel = {"levels": "k_mc_step<float,true>" if a.precision == 32 else "k_mc_step<double,true>",
-                  "flow": "k_mc_flow_lean / k_mc_flow<true>"}[engine]
+        tname = "float" if a.precision == 32 else "double"
+        st0 = stats["phase0"]
+        launches = max(head["launches"], 1)
+        if engine == "levels" and st0.get("wide_launches", 0) > 0:
+            # the window has two kernels: the wide levels K steps per launch (k_mc_tile, the dominant one: most of the rows,
+            # most of the time) and the narrow tail one step per launch beside it.  achieved / frac are the dominant
+            # kernel's -- its algorithmic bytes per launch over its average launch duration, HIP events around every one of
+            # its launches -- and `window` is the same arithmetic for the window as a whole (every kernel, ms_main).
+            wl, wss = st0["wide_launches"], st0["wide_segment_steps"]
+            kernel, pat = f"k_mc_tile<{tname}>", "k_mc_tile"
+            k_ms, k_launches, k_bytes = st0["ms_wide"], wl, wss * bytes_per / wl
+            tail = {"kernel": f"k_mc_step<{tname},true>", "launches_per_step": launches - wl,
+                    "segment_steps": int(seg0 - wss), "runs": "on the tail stream, beside the wide launches"}
+        else:
+            kernel = {"levels": f"k_mc_step<{tname},true>", "flow": "k_mc_flow_lean / k_mc_flow<true>"}[engine]
+            pat = "k_mc_step" if engine == "levels" else "k_mc_flow"
+            k_ms, k_launches, k_bytes = head["ms_main"], launches, seg0 * bytes_per / launches
+            tail = None
+        k_achieved = k_bytes * k_launches / (k_ms * 1e-3) / 1e9
+        pmc = pmc_counters(pat, k_launches, a) if rank == 0 else {}
+        roof = {
+            "bound": "hbm", "kernel": kernel,
+            "achieved": k_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_achieved / HBM_PEAK_GBS,
+            "traffic": pmc.get("traffic"),
+            "launches_per_step": k_launches, "avg_launch_ms": k_ms / k_launches, "alg_bytes_per_launch": k_bytes,
+            "valu": pmc.get("valu"),
+            "window": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "ms_main": head["ms_main"],
+                       "launches": launches, "what": "all segment-steps of the window x 64 B over the device time of all its kernels"},
+            "tail": tail,
+            "wide_levels": st0.get("wide_levels", 0), "wide_k": st0.get("wide_k", 0),
+            "ms_main": head["ms_main"], "ms_total_device": head["ms_total"],
+        }
         line = {
             "metric": "segment-timesteps/sec, CONUS NHD 2.7M-seg MC",
             "value": value,
@@ -566,14 +634,7 @@ def main():
                 "plan_order": "rows grouped by their secant-iteration cost over day N (untimed tuning window); timed on day N+1"
                 if not a.no_retune else "topological only", "tune_s": round(t_tune, 2),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": kernel,
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(engine, a) if rank == 0 else None,
-                "launches_per_step": head["launches"], "avg_launch_ms": head["ms_main"] / max(head["launches"], 1),
-                "alg_bytes_per_launch": seg0 / max(head["launches"], 1) * bytes_per,
-                "ms_main": head["ms_main"], "ms_total_device": head["ms_total"],
-            },
+            "roofline": roof,
             "cpu_baseline": cpu,
             "parity_sample": parity,
             "untuned": untuned,
@@ -589,34 +650,40 @@ def main():
         comm.close()
 
 
-def pmc_traffic(engine, args):
-    """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two counter-only rocprofv3 passes (FETCH_SIZE, then
-    WRITE_SIZE; --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a one-window child run of this script on the
-    same plan order, per dispatch of the dominant routing kernel; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950:
-    FETCH_SIZE counts half of the streamed reads; units of KB).  null when the profiler is not available, when this
-    process is itself a profiled child or one rank of several, or on any failure -- never a figure from a file."""
+def pmc_counters(pattern, launches_per_window, args):
+    """Hardware counters of the dominant kernel, MEASURED IN THIS RUN: three counter-only rocprofv3 passes (--kernel-trace
+    only, as MI355X_MICROARCH.md prescribes: FETCH_SIZE; WRITE_SIZE; the SQ instruction / cycle counters) over a child run of
+    this script that stops after one headline window (--headline-only), read per dispatch for the LAST window's launches of
+    the kernel -- the timed configuration, not an average over tuning and warm-up windows.
+      traffic  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of the streamed
+               reads; units of KB)
+      valu     instructions_per_wave_step (SQ_INSTS_VALU / SQ_WAVES / timesteps a launch routes), cycles_per_instruction
+               (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU: the counter is in quad-cycles), busy_frac (VALU-active cycles per
+               SIMD over the busy cycles of a shader engine: 4 x SQ_ACTIVE_INST_VALU / nSIMD  /  SQ_BUSY_CYCLES / nSE)
+    {} when the profiler is not available, when this process is itself a profiled child or one rank of several, or on any
+    failure -- never a figure from a file."""
     import glob
     import shutil
     import sqlite3
     import subprocess
     import tempfile
     if args.no_traffic or os.environ.get("TRMC_BENCH_CHILD") or int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        return None
+        return {}
     if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
-        return None                                     # this process is being profiled itself
+        return {}                                       # this process is being profiled itself
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return None
-    pat = "k_mc_step" if engine == "levels" else "k_mc_flow"
-    vals = {}
+        return {}
+    vals, out = {}, {}
+    passes = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"))
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                out = os.path.join(td, counter)
-                cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "c", "--", sys.executable,
-                       os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-full-ts",
-                       "--no-diffusive", "--no-parity-mode", "--no-traffic", "--no-parity-sample", "--nsteps", str(args.nsteps), "--qts", str(args.qts),
-                       "--precision", str(args.precision)]
+            for i, counters in enumerate(passes):
+                d = os.path.join(td, f"p{i}")
+                cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "c", "--", sys.executable,
+                       os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--headline-only", "--no-cpu-baseline",
+                       "--no-full-ts", "--no-diffusive", "--no-parity-mode", "--no-traffic", "--no-parity-sample",
+                       "--nsteps", str(args.nsteps), "--qts", str(args.qts), "--precision", str(args.precision)]
                 if args.nseg:
                     cmd += ["--nseg", str(args.nseg)]
                 if args.nnet:
@@ -624,23 +691,41 @@ def pmc_traffic(engine, args):
                 if args.no_retune:
                     cmd += ["--no-retune"]
                 env = dict(os.environ, TRMC_BENCH_CHILD="1", TMPDIR="/tmp")
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
-                dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+                dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
                 con = sqlite3.connect(dbs[0])
-                rows = con.execute(
-                    "select s.kernel_name, count(distinct d.id), sum(d.end - d.start) from rocpd_kernel_dispatch d "
-                    "join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name").fetchall()
-                rows = [r for r in rows if pat in r[0]]
-                name = max(rows, key=lambda r: r[2])[0]
-                per = con.execute(
-                    "select sum(e.value) / count(distinct d.id) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
-                    "join rocpd_kernel_dispatch d on d.event_id = e.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
-                    "where s.kernel_name = ? and p.name = ?", (name, counter)).fetchone()[0]
+                disp = con.execute(
+                    "select d.id, d.event_id, d.end - d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                    "on d.kernel_id = s.id where s.kernel_name like ? order by d.start", (f"%{pattern}%",)).fetchall()
+                last = disp[-int(launches_per_window):]
+                ev = [x[1] for x in last]
+                q = ",".join("?" * len(ev))
+                for name, total, ninst in con.execute(
+                        f"select p.name, sum(e.value), count(*) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+                        f"where e.event_id in ({q}) group by p.name", ev):
+                    vals[name] = total / len(last)                    # per launch, summed over the hardware instances
+                    vals[name + "#inst"] = ninst / len(last)          # hardware instances that report the counter
+                vals["avg_us_" + str(i)] = sum(x[2] for x in last) / len(last) / 1e3
                 con.close()
-                vals[counter] = float(per)
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
+        out["traffic"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        steps_per_launch = float(args.nsteps) / float(launches_per_window) if "k_mc_tile" in pattern else 1.0
+        waves, insts, active = vals["SQ_WAVES"], vals["SQ_INSTS_VALU"], vals["SQ_ACTIVE_INST_VALU"]
+        n_simd = 256 * 4
+        n_se = max(vals.get("SQ_BUSY_CYCLES#inst", 32.0), 1.0)
+        out["valu"] = {
+            "instructions_per_wave_step": insts / waves / steps_per_launch,
+            "instructions_per_launch": insts, "wavefronts_per_launch": waves,
+            "cycles_per_instruction": 4.0 * active / insts,
+            "busy_frac": (4.0 * active / n_simd) / (vals["SQ_BUSY_CYCLES"] / n_se),
+            "launch_us_under_counters": vals["avg_us_2"],
+            "how": "SQ_INSTS_VALU / SQ_WAVES / steps per launch; 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU; (4 x SQ_ACTIVE_INST_VALU / "
+                   f"{n_simd} SIMDs) / (SQ_BUSY_CYCLES / {int(n_se)} instances); last window's launches of {pattern}",
+        }
+        return out
+    except Exception as e:
+        out.setdefault("traffic", None)
+        out["error"] = repr(e)
+        return out
 
 
 if __name__ == "__main__":

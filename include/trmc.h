@@ -76,6 +76,13 @@ typedef struct trmc_stats {
     double ms_main;          /* all launches of the segment-step kernel        */
     double ms_emit;          /* [t][seg] -> [row][t][q,v,d] transpose          */
     double ms_total;         /* prep + main + emit                             */
+    /* short-timestep windows of a wide network: the leading `wide_levels` levels are routed `wide_k` timesteps per
+     * launch by k_mc_tile (0: every level one step per launch) */
+    int32_t wide_levels, wide_k;
+    int32_t wide_launches;   /* launches of k_mc_tile (part of main_launches)  */
+    int32_t reserved_;
+    int64_t wide_segment_steps; /* segment-steps routed by those launches     */
+    double ms_wide;          /* summed duration of those launches (they run beside the tail's, so this is not a share of ms_main) */
 } trmc_stats;
 
 const char *trmc_last_error(void);
@@ -332,6 +339,15 @@ int trmc_gather_flow_rows(trmc_plan *plan, const int64_t *rows, int64_t nrows, v
  * device-resident); this copies it to the host later: out[nrows][nsteps] of that gather. */
 int trmc_download_gathered(trmc_plan *plan, void *out);
 
+/* Throughput mode, copy hidden: what a caller consumes of a window -- the flow hydrographs of a registered row set (the
+ * network outlets) and the final state (new_q0, AbstractNetwork.py:182-190) -- is gathered on the plan's stream into
+ * plan-owned HBM and copied to the host on a SEPARATE copy stream, so the copy of window k runs beside the kernels of
+ * window k + 1 (the planes the gathers read are only overwritten by kernels queued after them).  hyd_host
+ * [rows of the set][nsteps] and q0_host [nseg][3] should be page-locked (trmc_host_alloc); either may be NULL.
+ * trmc_fetch_wait returns when both arrays are complete; one fetch in flight per plan. */
+int trmc_fetch_begin(trmc_plan *plan, int32_t rowset, void *hyd_host, void *q0_host);
+int trmc_fetch_wait(trmc_plan *plan);
+
 int trmc_get_stats(const trmc_plan *plan, trmc_stats *stats);
 
 /* Convenience: upload + route + download in one call (what the drop-in
@@ -387,6 +403,8 @@ int trmc_dev_alloc(int device, int64_t bytes, void **ptr_out); /* zero-filled */
 int trmc_dev_free(int device, void *ptr);
 int trmc_dev_upload(int device, void *dst_dev, const void *src_host, int64_t bytes);
 int trmc_dev_download(int device, void *dst_host, const void *src_dev, int64_t bytes, void *stream); /* waits for `stream` */
+/* ... and without waiting: complete after trmc_stream_synchronize(stream); dst_host should be page-locked (trmc_host_alloc) */
+int trmc_dev_download_async(int device, void *dst_host, const void *src_dev, int64_t bytes, void *stream);
 /* dst_dev[i][row_bytes] <- src_dev[index_dev[i]][row_bytes], i < nrows (row_bytes a multiple of 4): picks the outlet
  * rows out of an all-gathered block */
 int trmc_dev_gather_rows(int device, const void *src_dev, const int64_t *index_dev, int64_t nrows, int64_t row_bytes,

@@ -24,6 +24,8 @@ class Stats(C.Structure):
         ("nseg", C.c_int64), ("nseg_routed", C.c_int64), ("nlevels", C.c_int32), ("nsteps", C.c_int32),
         ("assume_short_ts", C.c_int32), ("main_launches", C.c_int32), ("segment_steps", C.c_int64),
         ("ms_prep", C.c_double), ("ms_main", C.c_double), ("ms_emit", C.c_double), ("ms_total", C.c_double),
+        ("wide_levels", C.c_int32), ("wide_k", C.c_int32), ("wide_launches", C.c_int32), ("reserved_", C.c_int32),
+        ("wide_segment_steps", C.c_int64), ("ms_wide", C.c_double),
     ]
 
     def as_dict(self):
@@ -74,6 +76,8 @@ SIGNATURES = {
     "trmc_download_cost": (_int, [_vp, _vp, _P(_i32)]),
     "trmc_gather_flow_rows": (_int, [_vp, _vp, _i64, _vp, _int]),
     "trmc_download_gathered": (_int, [_vp, _vp]),
+    "trmc_fetch_begin": (_int, [_vp, _i32, _vp, _vp]),
+    "trmc_fetch_wait": (_int, [_vp]),
     "trmc_get_stats": (_int, [_vp, _P(Stats)]),
     "trmc_route": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "trmc_segments": (_int, [_int, _int, _i64, _vp, _vp]),
@@ -90,6 +94,7 @@ SIGNATURES = {
     "trmc_dev_free": (_int, [_int, _vp]),
     "trmc_dev_upload": (_int, [_int, _vp, _vp, _i64]),
     "trmc_dev_download": (_int, [_int, _vp, _vp, _i64, _vp]),
+    "trmc_dev_download_async": (_int, [_int, _vp, _vp, _i64, _vp]),
     "trmc_dev_gather_rows": (_int, [_int, _vp, _vp, _i64, _i64, _vp, _vp]),
     "trmc_stream_create": (_int, [_int, _P(_vp)]),
     "trmc_stream_destroy": (_int, [_int, _vp]),
@@ -122,7 +127,10 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C t-route_amd/csrc).  There is no CPU fallback.")
         h = C.CDLL(LIB_PATH)
+        lenient = bool(os.environ.get("TRMC_LIB_PATH")) and os.environ.get("TRMC_LIB_LENIENT") == "1"   # A/B against an older build
         for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_DW.items()):
+            if lenient and not hasattr(h, name):
+                continue
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
@@ -153,31 +161,54 @@ def ptr(a):
 # (TRMC_PINNED_RESULTS=0 switches the pool off; an allocation that fails falls back to ordinary memory).
 _PINNED_MIN = 8 << 20
 _PINNED_KEEP = 2          # free buffers kept per size
-_pinned_free = {}
+_PINNED_CAP = int(os.environ.get("TRMC_PINNED_POOL_MB", "24576")) << 20   # free page-locked memory kept in all, bytes
+_pinned_free = {}         # nbytes -> [addresses]; guarded by _pinned_lock
+_pinned_order = []        # sizes in the order they were last given back (oldest first): what goes when the pool is full
+import threading as _threading
+_pinned_lock = _threading.Lock()
 
 
 def _pinned_release(address, nbytes):
     try:
-        pool = _pinned_free.setdefault(nbytes, [])
-        if len(pool) < (_PINNED_KEEP if nbytes <= (4 << 30) else 1):     # (one spare only of the multi-gigabyte buffers)
-            pool.append(address)
-        elif _LIB is not None:
-            _LIB.trmc_host_free(C.c_void_p(address))
+        drop = []
+        with _pinned_lock:
+            pool = _pinned_free.setdefault(nbytes, [])
+            if len(pool) < (_PINNED_KEEP if nbytes <= (4 << 30) else 1):     # (one spare only of the multi-gigabyte buffers)
+                pool.append(address)
+                if nbytes in _pinned_order:
+                    _pinned_order.remove(nbytes)
+                _pinned_order.append(nbytes)
+            else:
+                drop.append(address)
+            # a process that routes windows of many sizes must not keep page-locked memory of every one of them: beyond
+            # the cap the sizes given back longest ago are released first
+            total = sum(k * len(v) for k, v in _pinned_free.items())
+            while total > _PINNED_CAP and _pinned_order:
+                k = _pinned_order[0]
+                if _pinned_free.get(k):
+                    drop.append(_pinned_free[k].pop())
+                    total -= k
+                if not _pinned_free.get(k):
+                    _pinned_order.pop(0)
+        if _LIB is not None:
+            for a in drop:
+                _LIB.trmc_host_free(C.c_void_p(a))
     except Exception:        # interpreter shutdown
         pass
 
 
-def result_empty(shape, dtype):
-    """An uninitialised array for a device-to-host copy: page-locked when it is large, ordinary memory otherwise."""
+def result_empty(shape, dtype, always_pinned=False):
+    """An uninitialised array for a device-to-host copy: page-locked when it is large (or when an asynchronous copy needs
+    it to be: always_pinned), ordinary memory otherwise."""
     import weakref
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-    if nbytes < _PINNED_MIN or os.environ.get("TRMC_PINNED_RESULTS", "1") == "0":
+    if nbytes == 0 or ((nbytes < _PINNED_MIN and not always_pinned) or os.environ.get("TRMC_PINNED_RESULTS", "1") == "0"):
         return np.empty(shape, dtype=dtype)
-    pool = _pinned_free.get(nbytes)
-    if pool:
-        address = pool.pop()
-    else:
+    with _pinned_lock:
+        pool = _pinned_free.get(nbytes)
+        address = pool.pop() if pool else None
+    if address is None:
         p = C.c_void_p(0)
         if lib().trmc_host_alloc(nbytes, C.byref(p)) != TRMC_OK or not p.value:
             return np.empty(shape, dtype=dtype)
@@ -189,9 +220,12 @@ def result_empty(shape, dtype):
 
 def pinned_pool_clear():
     """Free the page-locked buffers that are not in use."""
-    for nbytes, pool in list(_pinned_free.items()):
-        while pool:
-            lib().trmc_host_free(C.c_void_p(pool.pop()))
+    with _pinned_lock:
+        addrs = [a for pool in _pinned_free.values() for a in pool]
+        _pinned_free.clear()
+        del _pinned_order[:]
+    for a in addrs:
+        lib().trmc_host_free(C.c_void_p(a))
 
 
 def device_count():

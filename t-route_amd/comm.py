@@ -70,6 +70,15 @@ class DeviceArray:
     def numpy(self):
         return self.buf.download(self.shape, self.dtype, self.stream)
 
+    def download_async(self, stream, out=None):
+        """start the copy into a page-locked array on `stream`; complete after stream_synchronize(device, stream)"""
+        if out is None:
+            out = _lib.result_empty(self.shape, self.dtype, always_pinned=True)
+        if out.nbytes:
+            _check(_lib.lib().trmc_dev_download_async(self.buf.device, _lib.ptr(out), C.c_void_p(self.ptr), out.nbytes,
+                                                      C.c_void_p(stream) if stream else None))
+        return out
+
 
 def stream_create(device):
     s = C.c_void_p(0)

@@ -415,6 +415,15 @@ int trmc_dev_download(int device, void *dst_host, const void *src_dev, int64_t b
     return 0;
 }
 
+int trmc_dev_download_async(int device, void *dst_host, const void *src_dev, int64_t bytes, void *stream)
+{
+    if (bytes == 0) return 0;
+    if (!dst_host || !src_dev || bytes < 0) return fail_with(TRMC_EINVAL, "bad download arguments");
+    COMM_HIP_TRY(hipSetDevice(device));
+    COMM_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
 int trmc_dev_gather_rows(int device, const void *src_dev, const int64_t *index_dev, int64_t nrows, int64_t row_bytes,
                          void *dst_dev, void *stream)
 {

@@ -102,6 +102,20 @@ TRMC_DP_FN float trmc_sp_from_bits(uint32_t u)
     return x;
 }
 
+/* 2**(k/32) with the exponent of k added in: the double whose bits are  t + (ki << 47)  (glibc: `t += ki << 47`).  The
+ * shifted term has no bits below 2**47, so the sum is an addition into the HIGH word alone; on the device that is ONE
+ * 32-bit shift-add (the compiler makes a shift, a move and a 64-bit add of the plain form). */
+TRMC_DP_FN double trmc_dp_exp2_scale(uint64_t t, uint64_t ki)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t hi;
+    asm("v_lshl_add_u32 %0, %1, 15, %2" : "=v"(hi) : "v"((uint32_t)ki), "v"((uint32_t)(t >> 32)));
+    return __hiloint2double((int)hi, (int)(uint32_t)t);
+#else
+    return trmc_dp_from_bits(t + (ki << 47));
+#endif
+}
+
 /* log2(x) as glibc's powf forms it, plus the special values its callers rely on:
  * NaN or finite x < 0 -> NaN ; +-0 -> -inf ; +-inf -> +inf (y is a positive non-integer). */
 TRMC_DP_FN double trmc_det_log2(float x, const uint64_t *tab)
@@ -148,9 +162,7 @@ TRMC_DP_FN float trmc_det_powf_from_log(double L, float y, const uint64_t *tab)
     const uint64_t ki = trmc_dp_bits(kd);
     kd -= 0x1.8p+47;
     const double r = ylogx - kd;
-    uint64_t t = tab[32 + (ki & 31u)];
-    t += ki << 47;
-    const double s = trmc_dp_from_bits(t);
+    const double s = trmc_dp_exp2_scale(tab[32 + (ki & 31u)], ki);
     const double z = __builtin_fma(0x1.c6af84b912394p-5, r, 0x1.ebfce50fac4f3p-3);
     const double r2 = r * r;
     double w = __builtin_fma(0x1.62e42ff0c52d6p-1, r, 1.0);
@@ -194,9 +206,7 @@ TRMC_DP_FN float trmc_det_powf_from_log_inrange(double L, float y, const uint64_
     const uint64_t ki = trmc_dp_bits(kd);
     kd -= 0x1.8p+47;
     const double r = ylogx - kd;
-    uint64_t t = tab[32 + (ki & 31u)];
-    t += ki << 47;
-    const double s = trmc_dp_from_bits(t);
+    const double s = trmc_dp_exp2_scale(tab[32 + (ki & 31u)], ki);
     const double z = __builtin_fma(0x1.c6af84b912394p-5, r, 0x1.ebfce50fac4f3p-3);
     const double r2 = r * r;
     double w = __builtin_fma(0x1.62e42ff0c52d6p-1, r, 1.0);

@@ -320,6 +320,10 @@ template <class T> struct StepArgs {
     T *da_raw;
     int64_t nseg_pad;
     int32_t nsteps, qts;
+    // k_mc_tile writes its rows' results straight into the caller's layout out[row][step][q,v,d]
+    T *out;
+    const int32_t *row_of_pos;
+    bool out_vec; // the runs it writes are 16-byte aligned (float, nsteps % 4 == 0, K % 4 == 0)
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -499,6 +503,12 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 // device by themselves are routed this way (route_advance_t picks them), the narrow tail of the level order keeps the
 // one-step launches of k_mc_step, trailing the last wide level.  Results are the same bits: the same segment steps on the
 // same inputs, visited in another order (tests run both paths against the oracle).
+// Results go straight into the caller's layout out[row][step][q,v,d]: a thread stages kTileStage steps in LDS (lane-
+// contiguous columns: conflict-free) and writes them as one 96-byte run -- three whole 32-byte sectors -- so these rows
+// need no transposing pass (k_emit skips them) and no velocity plane at all; of the time-major planes only the flow row
+// of every step (what downstream rows and the gathers read) and the depth row of a tile's last step (where the row's next
+// tile, or the final state, picks it up) are written.
+constexpr int kTileStage = 8;
 #ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow (1: as many registers as it likes)
 #define TRMC_TILE_WAVES 1
 #endif
@@ -508,6 +518,7 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 {
     using M = typename DevMath<T>::type;
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    __shared__ T s_out[3 * kTileStage * kStepBlock]; // [step slot * 3 + c][thread]
     M m{stage_pow_tables(s_tab), false};
     m.sane = a.sane;
 
@@ -546,10 +557,11 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 
     T q_prev = at(a.q_tm + (size_t)(t_lo - 1) * np, ob);
     T d_prev = at(a.d_tm + (size_t)(t_lo - 1) * np, ob);
+    T *const out_row = a.out + (size_t)a.row_of_pos[su] * (size_t)a.nsteps * 3;
     // the lateral-inflow column of step t is (t - 1) / qts: found by division once, by a counter from then on
     int32_t ql_col = (t_lo - 1) / a.qts, ql_left = a.qts - (t_lo - 1) % a.qts;
     T ql = at(a.qlat_tm + (size_t)ql_col * np, ob);
-    int32_t it_acc = 0, it_last = 0;
+    int32_t it_acc = 0, it_last = 0, staged = 0;
     for (int32_t t = t_lo; t <= t_hi; ++t) {
         if (ql_left == 0) {
             ++ql_col;
@@ -608,10 +620,33 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         const size_t row_c = (size_t)t * np;
         asm volatile("" : "+v"(ob));
         at(a.q_tm + row_c, ob) = q_new;
-        at(a.v_tm + row_c, ob) = v_new;
-        at(a.d_tm + row_c, ob) = d_new;
+        if (t == t_hi) at(a.d_tm + row_c, ob) = d_new;
         q_prev = q_new;
         d_prev = d_new;
+        {   // stage (q, v, d) of step t; a run ends when kTileStage steps are staged and at the tile's last step
+            T *so = s_out + (size_t)(staged * 3) * kStepBlock + threadIdx.x;
+            so[0] = q_new;
+            so[kStepBlock] = v_new;
+            so[2 * kStepBlock] = d_new;
+            ++staged;
+            if (staged == kTileStage || t == t_hi) {
+                T *dst = out_row + (size_t)(t - staged) * 3;
+                const T *si = s_out + threadIdx.x;
+                if (a.out_vec && (staged & 3) == 0) { // (float: 3 * staged values = 3 * staged / 4 pieces of 16 bytes)
+                    for (int j = 0; j < 3 * staged / 4; ++j) {
+                        float4 v;
+                        v.x = (float)si[(4 * j + 0) * kStepBlock];
+                        v.y = (float)si[(4 * j + 1) * kStepBlock];
+                        v.z = (float)si[(4 * j + 2) * kStepBlock];
+                        v.w = (float)si[(4 * j + 3) * kStepBlock];
+                        reinterpret_cast<float4 *>(dst)[j] = v;
+                    }
+                } else {
+                    for (int32_t e = 0; e < 3 * staged; ++e) dst[e] = si[e * kStepBlock];
+                }
+                staged = 0;
+            }
+        }
     }
     if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)it_last;
     if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + it_acc);
@@ -752,18 +787,20 @@ template <class T>
 __global__ void __launch_bounds__(kBlock)
 k_emit(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restrict__ d_tm,
        const int32_t *__restrict__ row_of_pos, T *__restrict__ out, int32_t nseg, int64_t nseg_pad,
-       int32_t nsteps, int32_t t_begin, int32_t t_end)
-{
+       int32_t nsteps, int32_t t_begin, int32_t t_end, int32_t shift_from, int32_t shift, int32_t skip_lo, int32_t skip_hi)
+{   // positions [skip_lo, skip_hi) have written their results themselves (k_mc_tile): they are passed over, and the whole
+    // 64-position blocks inside that range are not launched at all (blocks from position shift_from on move up by `shift`)
     static_assert(kBlock == 256 && kEmitSteps % 4 == 0, "the passes below assume 4 waves and whole groups of 4 steps");
     constexpr int kRow = 3 * kEmitSteps + 4; // row stride in elements: a multiple of 4, so that 16-byte reads are aligned
     __shared__ __attribute__((aligned(16))) T tile[64][kRow]; // [position][step*3 + c]
-    const int32_t p0 = blockIdx.x * 64;
+    int32_t p0 = (int32_t)blockIdx.x * 64;
+    if (p0 >= shift_from) p0 += shift;
     const int32_t t0 = t_begin + (int32_t)blockIdx.y * kEmitSteps; // zero-based output step
     const int32_t nt = min(kEmitSteps, t_end - t0);
     const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     {
         const int32_t p = p0 + lane;
-        if (p < nseg) {
+        if (p < nseg && !(p >= skip_lo && p < skip_hi)) {
             size_t src = (size_t)(t0 + 1 + wave) * (size_t)nseg_pad + (size_t)p;
             T *dst = &tile[lane][wave * 3];
             for (int32_t tl = wave; tl < nt; tl += 4) {
@@ -785,6 +822,7 @@ k_emit(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restri
             for (int32_t pl = wave * 16 + half; pl < wave * 16 + 16; pl += 2) {
                 const int32_t p = p0 + pl;
                 if (p >= nseg) break;
+                if (p >= skip_lo && p < skip_hi) continue;
                 const float4 v = *reinterpret_cast<const float4 *>(&tile[pl][4 * j]);
                 float4 *dst = reinterpret_cast<float4 *>(out + ((size_t)row_of_pos[p] * nsteps + t0) * 3);
                 dst[j] = v;
@@ -794,6 +832,7 @@ k_emit(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restri
         for (int32_t pl = wave; pl < 64; pl += kBlock / 64) {
             const int32_t p = p0 + pl;
             if (p >= nseg) break;
+            if (p >= skip_lo && p < skip_hi) continue;
             T *dst = out + ((size_t)row_of_pos[p] * nsteps + t0) * 3;
             for (int32_t e = lane; e < nt * 3; e += 64) dst[e] = tile[pl][e];
         }
@@ -1647,6 +1686,7 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     int32_t tiles_done = 0, launches = 0;
     // wide levels routed K steps per launch with a skew of K steps per level (k_mc_tile); 0 = every level one step per launch
     int32_t wide = 0, wide_k = 0, wide_next = 0, wide_through = 0; // levels; K; next tile; step every wide level has completed
+    bool tail_active = false;     // the tail launches of this window go to the tail stream
 };
 
 struct trmc_plan {
@@ -1660,6 +1700,12 @@ struct trmc_plan {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;       // result transpose, overlapped with the step launches
+    hipStream_t wstream = nullptr;       // the wide tiles (k_mc_tile), ordinary priority: the narrow tail of the level order runs one
+                                         // step per launch on the plan's own high-priority stream BESIDE them -- the tail's 288
+                                         // dependent launches are the latency-critical part, the tiles fill whatever they leave
+    std::vector<hipEvent_t> wide_ev;     // "wide tile k is complete" (tile stream -> plan stream), a ring
+    hipEvent_t ev_tail = nullptr;        // "every tile queued so far is complete" (tile stream -> plan stream)
+    std::vector<hipEvent_t> wide_t0, wide_t1; // timing events around the wide launches of the window (trmc_stats.ms_wide)
     std::vector<hipEvent_t> tile_ev;     // "time tile b is complete" (main stream -> stream2)
     hipEvent_t ev_emit = nullptr;        // "all tiles emitted" (stream2 -> main stream)
     // static, plan order
@@ -1700,9 +1746,14 @@ struct trmc_plan {
     int flow_next = 0;                   // which of the two the next trmc_route_advance uses (only toggles in overlap mode)
     int flow_last = 0;                   // ... and which one the last launch went to
     DevBuf d_state, ticket, rank, dbg;   // depth column; {block ticket, abort flag}; level rank of a position inside its block
-    uint64_t watchdog_ticks = 300000000; // 3 s of wall_clock64 (100 MHz)
+    uint64_t watchdog_ticks = 3000000000ull; // 30 s of wall_clock64 (100 MHz): long enough for a device that is shared or profiled (TRMC_FLOW_WATCHDOG_MS)
     trmc_stats stats{};
     RouteRun run;
+    // asynchronous fetch of what a throughput-mode caller consumes (trmc_fetch_begin / trmc_fetch_wait)
+    DevBuf fetch_hyd, fetch_q0;
+    hipStream_t cstream = nullptr;       // copy stream: D2H of window k runs beside the kernels of window k + 1
+    hipEvent_t ev_fetch_ready = nullptr, ev_fetch_done = nullptr;
+    bool fetch_pending = false;
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
     std::vector<int32_t> rowset_lag;
@@ -1800,6 +1851,9 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.nseg_pad = pl->nseg_pad;
     a.nsteps = nsteps;
     a.qts = qts;
+    a.out = (T *)pl->out.p;
+    a.row_of_pos = (const int32_t *)pl->row_of_pos.p;
+    a.out_vec = sizeof(T) == 4 && nsteps % 4 == 0 && pl->run.wide_k % 4 == 0;
     return a;
 }
 
@@ -1833,13 +1887,20 @@ template <class T> int emit_tiles_through(trmc_plan *pl, int32_t t_complete) // 
     const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
     const T *q_tm = (const T *)pl->tm.p;
     while (r.tiles_done < ntiles && ((r.tiles_done + 1) * kTile <= t_complete || t_complete >= nsteps)) {
-        HIP_TRY(hipEventRecord(pl->tile_ev[r.tiles_done], pl->stream));
+        // (with wide tiles: the tail, on the plan's stream, trails them -- its progress is everybody's; without a tail the
+        // tile stream's is)
+        HIP_TRY(hipEventRecord(pl->tile_ev[r.tiles_done], (r.wide > 0 && !r.tail_active) ? pl->wstream : pl->stream));
         HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->tile_ev[r.tiles_done], 0));
-        if (n > 0) {
+        // (rows of the wide levels wrote their results themselves, k_mc_tile: their positions are left out)
+        const int32_t skip_lo = r.wide > 0 ? pl->topo.lvl_ptr[0] : 0, skip_hi = r.wide > 0 ? pl->topo.lvl_ptr[r.wide] : 0;
+        const int32_t shift_from = (skip_lo + 63) / 64 * 64, shift = std::max(0, (skip_hi - shift_from) / 64 * 64);
+        const int32_t n_emit = n - shift;
+        if (n_emit > 0) {
             const int32_t tb = r.tiles_done * kTile, te = min(nsteps, tb + kTile);
-            hipLaunchKernelGGL((k_emit<T>), dim3((n + 63) / 64, (unsigned)((te - tb + kEmitSteps - 1) / kEmitSteps)),
+            hipLaunchKernelGGL((k_emit<T>), dim3((n_emit + 63) / 64, (unsigned)((te - tb + kEmitSteps - 1) / kEmitSteps)),
                                dim3(kBlock), 0, pl->stream2, q_tm, q_tm + plane, q_tm + 2 * plane,
-                               (const int32_t *)pl->row_of_pos.p, (T *)pl->out.p, n, pl->nseg_pad, nsteps, tb, te);
+                               (const int32_t *)pl->row_of_pos.p, (T *)pl->out.p, n, pl->nseg_pad, nsteps, tb, te, shift_from, shift,
+                               skip_lo, skip_hi);
         }
         ++r.tiles_done;
     }
@@ -1897,6 +1958,7 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
                            (const T *)pl->in_bfvd.p, a.q_tm, a.v_tm, a.d_tm, (int32_t)tp.nboundary, nsteps, np);
         r.boundary_through = nsteps;
     }
+    HIP_TRY(hipEventRecord(pl->ev[1], st));
     // Short-timestep windows of a wide network: the leading levels that can fill the device by themselves are routed K
     // steps per launch (k_mc_tile), the rest one step per launch behind them.  Needs every boundary hydrograph up front
     // (wide rows run ahead of the window's progress) and no lagged rows (the multi-GPU trunk has its own skew).
@@ -1914,9 +1976,24 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         if (W > 0) {
             r.wide = W;
             r.wide_k = (int32_t)std::max(1L, std::min((long)nsteps, env_int("TRMC_WIDE_K", std::max(1, std::min(12, nsteps / 8)))));
+            if (!pl->wstream) {
+                // ordinary priority: between the tail's step launches (high) and the result transpose (low); one hardware queue each
+                HIP_TRY(hipStreamCreateWithFlags(&pl->wstream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&pl->ev_tail, hipEventDisableTiming));
+                pl->wide_ev.assign(8, nullptr);
+                for (auto &e : pl->wide_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            HIP_TRY(hipStreamWaitEvent(pl->wstream, pl->ev[1], 0)); // the tiles start behind the window's set-up
+            const size_t ntile = (size_t)((nsteps + r.wide_k - 1) / r.wide_k + W - 1);
+            while (pl->wide_t0.size() < std::min<size_t>(ntile, 256)) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                pl->wide_t0.push_back(e0);
+                pl->wide_t1.push_back(e1);
+            }
         }
     }
-    HIP_TRY(hipEventRecord(pl->ev[1], st));
     HIP_TRY(hipGetLastError());
     pl->routed_nsteps = -1;
     return 0;
@@ -1933,27 +2010,48 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
         if (r.short_ts && r.wide > 0) {
-            // wide levels: K steps per launch, level l trailing level l - 1 by K steps (k_mc_tile); the narrow tail of the
-            // level order: one step per launch, behind the last wide level.  A wide tile is queued when the tail needs it.
+            // wide levels: K steps per launch, level l trailing level l - 1 by K steps (k_mc_tile), on the TILE stream
+            // (ordinary priority); the narrow tail of the level order: one step per launch (k_mc_step) on the plan's own
+            // high-priority stream, behind the last wide level (an event per tile).  The tail is what the window waits for
+            // -- 288 launches that depend on each other -- so it gets the issue slots first and the tiles, which are pure
+            // throughput, fill the rest; with the priorities the other way round the tail fell 140 steps behind and ran
+            // 2.4 ms past the last tile.  A tile is queued when the tail needs it; at the end of the call the plan's stream
+            // waits for the tiles queued so far, so whatever the caller queues next (a gather, the next window) sees every
+            // row at t_end.
             const int32_t K = r.wide_k, W = r.wide;
             const int32_t w0 = tp.lvl_ptr[0], w1 = tp.lvl_ptr[W], s1 = tp.lvl_ptr[L];
             const int32_t ntile = (nsteps + K - 1) / K + W - 1;
+            const bool tail = s1 > w1;
+            hipStream_t ws = pl->wstream;
+            r.tail_active = tail;
             for (int32_t t = t0 + 1; t <= t_end; ++t) {
+                bool fresh = false;
                 while (r.wide_through < t && r.wide_next < ntile) {
                     const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
-                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, 0, st, a, w0, w1, r.wide_next, K);
+                    const size_t slot = (size_t)r.wide_next;
+                    if (slot < pl->wide_t0.size()) HIP_TRY(hipEventRecord(pl->wide_t0[slot], ws));
+                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, 0, ws, a, w0, w1, r.wide_next, K);
+                    if (slot < pl->wide_t1.size()) HIP_TRY(hipEventRecord(pl->wide_t1[slot], ws));
                     ++r.launches;
                     ++r.wide_next;
                     const int32_t done_tiles = r.wide_next - (W - 1); // tiles the LAST wide level has been through
                     r.wide_through = done_tiles <= 0 ? 0 : std::min(nsteps, done_tiles * K);
+                    fresh = true;
                 }
-                if (s1 > w1) {
+                if (tail) {
+                    if (fresh) { // the tail's next steps read what the tile just queued completes
+                        hipEvent_t e = pl->wide_ev[(size_t)r.wide_next % pl->wide_ev.size()];
+                        HIP_TRY(hipEventRecord(e, ws));
+                        HIP_TRY(hipStreamWaitEvent(st, e, 0));
+                    }
                     launch_step<T, true>(st, a, w1, s1, t);
                     ++r.launches;
                 }
                 if (t % kTile == 0 && t < nsteps)
                     if (int rc = emit_tiles_through<T>(pl, t)) return rc;
             }
+            HIP_TRY(hipEventRecord(pl->ev_tail, ws));
+            HIP_TRY(hipStreamWaitEvent(st, pl->ev_tail, 0));
         } else if (r.short_ts) {
             const int32_t s0 = tp.lvl_ptr[0], s1 = tp.lvl_ptr[L];
             const int32_t lagmax = pl->maxlag;
@@ -2016,6 +2114,21 @@ template <class T> int route_end_t(trmc_plan *pl)
     s.ms_main = ms12;
     s.ms_emit = ms23;
     s.ms_total = (double)ms01 + ms12 + ms23;
+    s.wide_levels = r.wide;
+    s.wide_k = r.wide_k;
+    s.wide_launches = r.wide_next;
+    s.reserved_ = 0;
+    s.wide_segment_steps = r.wide > 0 ? (int64_t)(tp.lvl_ptr[r.wide] - tp.lvl_ptr[0]) * nsteps : 0;
+    s.ms_wide = 0.0;
+    {
+        const size_t timed_n = std::min<size_t>((size_t)r.wide_next, pl->wide_t0.size());
+        for (size_t i = 0; i < timed_n; ++i) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, pl->wide_t0[i], pl->wide_t1[i]));
+            s.ms_wide += ms;
+        }
+        if (timed_n > 0 && timed_n < (size_t)r.wide_next) s.ms_wide *= (double)r.wide_next / (double)timed_n;
+    }
     pl->routed_nsteps = nsteps;
     r.active = false;
     return 0;
@@ -2530,6 +2643,11 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (!pl) return;
     (void)hipSetDevice(pl->device);
     for (DevBuf &b : pl->rowsets) b.release();
+    pl->fetch_hyd.release();
+    pl->fetch_q0.release();
+    if (pl->cstream) (void)hipStreamDestroy(pl->cstream);
+    if (pl->ev_fetch_ready) (void)hipEventDestroy(pl->ev_fetch_ready);
+    if (pl->ev_fetch_done) (void)hipEventDestroy(pl->ev_fetch_done);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
@@ -2540,6 +2658,13 @@ void trmc_plan_destroy(trmc_plan *pl)
         if (e) (void)hipEventDestroy(e);
     if (pl->ev_emit) (void)hipEventDestroy(pl->ev_emit);
     if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
+    if (pl->wstream) (void)hipStreamDestroy(pl->wstream);
+    for (auto &e : pl->wide_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto *v : {&pl->wide_t0, &pl->wide_t1})
+        for (auto &e : *v)
+            if (e) (void)hipEventDestroy(e);
+    if (pl->ev_tail) (void)hipEventDestroy(pl->ev_tail);
     if (pl->fstream) (void)hipStreamDestroy(pl->fstream);
     for (auto &e : pl->ev_chunk)
         if (e) (void)hipEventDestroy(e);
@@ -3161,6 +3286,54 @@ int trmc_download_final_state(trmc_plan *pl, void *q0_out)
     if (int rc = final_state_into(pl, pl->scratch.p)) return rc;
     HIP_TRY(hipMemcpyAsync(q0_out, pl->scratch.p, bytes, hipMemcpyDeviceToHost, pl->stream));
     HIP_TRY(hipStreamSynchronize(pl->stream));
+    return 0;
+}
+
+int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_host)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (pl->fetch_pending) return fail(TRMC_ESTATE, "a fetch is in flight (trmc_fetch_wait it first)");
+    if (hyd_host && (rowset < 0 || rowset >= (int32_t)pl->rowsets.size())) return fail(TRMC_EINVAL, "unknown row set");
+    if (int rc = use_device(pl)) return rc;
+    if (!pl->cstream) {
+        HIP_TRY(hipStreamCreateWithFlags(&pl->cstream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_done, hipEventDisableTiming));
+    }
+    const int32_t T_ = pl->routed_nsteps;
+    const int64_t nrows = hyd_host ? pl->rowset_n[rowset] : 0;
+    const size_t hb = (size_t)nrows * T_ * pl->esz, qb = q0_host ? (size_t)pl->nseg * 3 * pl->esz : 0;
+    if (hb) {
+        if (int rc = pl->fetch_hyd.ensure(hb)) return rc;
+        if (pl->precision == 32)
+            hipLaunchKernelGGL((k_gather_rows<float>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream, (const float *)pl->tm.p,
+                               (const int32_t *)pl->rowsets[rowset].p, (float *)pl->fetch_hyd.p, nrows, pl->nseg_pad, T_, pl->flow ? 2 : 1);
+        else
+            hipLaunchKernelGGL((k_gather_rows<double>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream, (const double *)pl->tm.p,
+                               (const int32_t *)pl->rowsets[rowset].p, (double *)pl->fetch_hyd.p, nrows, pl->nseg_pad, T_, 1);
+        HIP_TRY(hipGetLastError());
+    }
+    if (qb) {
+        if (int rc = pl->fetch_q0.ensure(qb)) return rc;
+        if (int rc = final_state_into(pl, pl->fetch_q0.p)) return rc;
+    }
+    HIP_TRY(hipEventRecord(pl->ev_fetch_ready, pl->stream));
+    HIP_TRY(hipStreamWaitEvent(pl->cstream, pl->ev_fetch_ready, 0));
+    if (hb) HIP_TRY(hipMemcpyAsync(hyd_host, pl->fetch_hyd.p, hb, hipMemcpyDeviceToHost, pl->cstream));
+    if (qb) HIP_TRY(hipMemcpyAsync(q0_host, pl->fetch_q0.p, qb, hipMemcpyDeviceToHost, pl->cstream));
+    HIP_TRY(hipEventRecord(pl->ev_fetch_done, pl->cstream));
+    pl->fetch_pending = true;
+    return 0;
+}
+
+int trmc_fetch_wait(trmc_plan *pl)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (!pl->fetch_pending) return 0;
+    if (int rc = use_device(pl)) return rc;
+    pl->fetch_pending = false;
+    HIP_TRY(hipEventSynchronize(pl->ev_fetch_done));
     return 0;
 }
 

@@ -242,7 +242,9 @@ class ShardedRouter:
                 x["ev_filled"].append(self._event())
         x["send_o"] = X.DeviceBuffer(dev, self._max_out * nsteps * e)
         x["recv_o"] = X.DeviceBuffer(dev, world * self._max_out * nsteps * e)
-        x["hyd"] = X.DeviceBuffer(dev, max(1, self._out_rows.shape[0]) * nsteps * e)
+        # (two: the block of window k may still be on its way to the host while window k + 1 fills the other one)
+        x["hyd"] = [X.DeviceBuffer(dev, max(1, self._out_rows.shape[0]) * nsteps * e) for _ in range(2)]
+        x["flip"] = 0
         x["ev_out"] = self._event()
         x["ev_out1"] = self._event()
         self._xbuf_key, self._xbuf = key, x
@@ -364,10 +366,13 @@ class ShardedRouter:
         X.event_record(dev, x["ev_out"], sP)
         X.stream_wait_event(dev, sc, x["ev_out"])
         comm.all_gather(send_o.ptr, recv_o.ptr, self._max_out * nsteps * e, sc)
-        X.gather_rows(dev, recv_o.ptr, self._d_out_index.ptr, self._out_rows.shape[0], nsteps * e, x["hyd"].ptr, sc)
+        x["flip"] ^= 1
+        hyd = x["hyd"][x["flip"]]
+        X.gather_rows(dev, recv_o.ptr, self._d_out_index.ptr, self._out_rows.shape[0], nsteps * e, hyd.ptr, sc)
         self.last_stats = {"phase0": P.route_end()}
         X.stream_synchronize(dev, sc)
-        return self._out_rows, X.DeviceArray(x["hyd"], (self._out_rows.shape[0], nsteps), self.dtype, sc)
+        self._state_plans = [P]
+        return self._out_rows, X.DeviceArray(hyd, (self._out_rows.shape[0], nsteps), self.dtype, sc)
 
     # ---- general path: sub-basins, exchange, trunk (optionally pipelined in time chunks) ---------------------
     def _route_phased(self, qts_subdivisions, assume_short_ts, nchunks=None):
@@ -420,13 +425,16 @@ class ShardedRouter:
             X.event_record(dev, x["ev_out1"], s1)
             X.stream_wait_event(dev, sc, x["ev_out1"])
         comm.all_gather(send_o.ptr, recv_o.ptr, self._max_out * nsteps * e, sc)
-        X.gather_rows(dev, recv_o.ptr, self._d_out_index.ptr, self._out_rows.shape[0], nsteps * e, x["hyd"].ptr, sc)
+        x["flip"] ^= 1
+        hyd = x["hyd"][x["flip"]]
+        X.gather_rows(dev, recv_o.ptr, self._d_out_index.ptr, self._out_rows.shape[0], nsteps * e, hyd.ptr, sc)
         stats = {"phase0": self.plan0.route_end()}
         if self.plan1 is not None:
             stats["phase1"] = self.plan1.route_end()
         X.stream_synchronize(dev, sc)
         self.last_stats = stats
-        return self._out_rows, X.DeviceArray(x["hyd"], (self._out_rows.shape[0], nsteps), self.dtype, sc)
+        self._state_plans = [self.plan0] + ([self.plan1] if self.plan1 is not None else [])
+        return self._out_rows, X.DeviceArray(hyd, (self._out_rows.shape[0], nsteps), self.dtype, sc)
 
     def close(self):
         if self.planM is not None:
@@ -441,6 +449,9 @@ class ShardedRouter:
             if getattr(self, "_sc", 0):
                 self._X.stream_destroy(self._dev, self._sc)
                 self._sc = 0
+            if getattr(self, "_cs", 0):
+                self._X.stream_destroy(self._dev, self._cs)
+                self._cs = 0
             for b in list(getattr(self, "_xbuf", {}).values()):
                 for bb in (b if isinstance(b, list) else [b]):
                     if hasattr(bb, "free"):
@@ -481,6 +492,50 @@ class ShardedRouter:
 
     def outlet_hydrographs(self):
         return self.plan0.download_gathered()
+
+    # ---- what a throughput-mode caller consumes of a window (outlet hydrographs + final state), copied to the
+    # host on a copy stream BESIDE the next window: fetch_begin() after a window, fetch_wait() after the next one is queued
+    def route_and_fetch(self, qts_subdivisions, assume_short_ts):
+        """Single-rank form: route the window, start the asynchronous copy of its outlet hydrographs and final state
+        (page-locked arrays), and hand back the products of the PREVIOUS call (None, None the first time)."""
+        if self.world != 1:
+            raise ValueError("route_and_fetch is the one-GPU path")
+        self.last_stats = {"phase0": self.plan0.route_device(self.nsteps, qts_subdivisions, assume_short_ts)}
+        prev = self.fetch_wait()          # (its copy ran beside the window just routed)
+        if not hasattr(self, "_rs_fetch"):
+            self._rs_fetch = self.plan0.rowset(self.my_out0_local)
+        self.plan0.fetch_begin(self._rs_fetch, True)
+        self._fetching = ("single",)
+        return prev
+
+    def fetch_begin(self, hyd_dev, want_hyd=True):
+        """Multi-rank form, after route_on_device(): this rank's final state (every plan that holds one) and, if wanted,
+        the gathered outlet block start their way to the host."""
+        X = self._X
+        if not hasattr(self, "_cs"):
+            self._cs = X.stream_create(self._dev)
+        for plan in self._state_plans:
+            plan.fetch_begin(None, True)
+        hyd = None
+        if want_hyd:                       # (a ring of three page-locked blocks, made once: no allocation in a steady pipeline)
+            ring = getattr(self, "_hyd_ring", None)
+            if ring is None or ring[0][0].shape != hyd_dev.shape:
+                from . import _lib
+                ring = [[_lib.result_empty(hyd_dev.shape, hyd_dev.dtype, always_pinned=True) for _ in range(3)], 0]
+                self._hyd_ring = ring
+            hyd = hyd_dev.download_async(self._cs, out=ring[0][ring[1] % 3])
+            ring[1] += 1
+        self._fetching = ("dist", hyd)
+
+    def fetch_wait(self):
+        f, self._fetching = getattr(self, "_fetching", None), None
+        if f is None:
+            return None, None
+        if f[0] == "single":
+            return self.plan0.fetch_wait()
+        states = [plan.fetch_wait()[1] for plan in self._state_plans]
+        self._X.stream_synchronize(self._dev, self._cs)
+        return f[1], states
 
     def route(self, qts_subdivisions, assume_short_ts, all_gather=None):
         """One routing window.  ``all_gather(array) -> list of arrays (one per rank)``.

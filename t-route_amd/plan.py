@@ -250,6 +250,9 @@ class RoutingPlan:
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         rid = C.c_int32(-1)
         _lib.check(_lib.lib().trmc_rowset_create(self._h, _lib.ptr(rows), rows.shape[0], C.byref(rid)))
+        if not hasattr(self, "_rowset_n"):
+            self._rowset_n = {}
+        self._rowset_n[rid.value] = int(rows.shape[0])
         return rid.value
 
     def gather_flow_range(self, rowset, t_begin, t_end, device_ptr, stride):
@@ -309,6 +312,30 @@ class RoutingPlan:
         out = _lib.result_empty(self._gathered_shape, self.dtype)
         if out.size:
             _lib.check(_lib.lib().trmc_download_gathered(self._h, _lib.ptr(out)))
+        return out
+
+    def fetch_begin(self, rowset, want_state=True):
+        """Start the asynchronous fetch of a window's products (include/trmc.h trmc_fetch_begin): the hydrographs of a
+        registered row set and / or the final state, into page-locked arrays; returns at once.  ``fetch_wait()`` hands the
+        arrays over when the copy stream is through -- typically after the NEXT window has been queued.  The arrays come
+        from a ring of three sets the plan keeps (all made at the first call: no allocation in a steady pipeline), so what
+        ``fetch_wait()`` returned stays valid until the third fetch_begin() after it."""
+        nrows = 0 if rowset is None else self._rowset_n[rowset]
+        shape = ((nrows, self._nsteps) if rowset is not None else None, (self.nseg, 3) if want_state else None)
+        ring = getattr(self, "_fetch_ring", None)
+        if ring is None or ring["shape"] != shape:
+            ring = {"shape": shape, "k": 0,
+                    "sets": [tuple(None if sh is None else _lib.result_empty(sh, self.dtype, always_pinned=True) for sh in shape)
+                             for _ in range(3)]}
+            self._fetch_ring = ring
+        hyd, q0 = ring["sets"][ring["k"] % 3]
+        ring["k"] += 1
+        _lib.check(_lib.lib().trmc_fetch_begin(self._h, -1 if rowset is None else int(rowset), _lib.ptr(hyd), _lib.ptr(q0)))
+        self._fetch = (hyd, q0)
+
+    def fetch_wait(self):
+        _lib.check(_lib.lib().trmc_fetch_wait(self._h))
+        out, self._fetch = getattr(self, "_fetch", (None, None)), (None, None)
         return out
 
     def gather_flow_rows(self, rows, device_ptr=None):

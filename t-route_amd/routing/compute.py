@@ -239,8 +239,14 @@ def compute_nhd_routing_v02(
     fvd, upstream = r[1], r[6]
     gage_ids, lastobs_times, lastobs_values = r[3]
     nudge = r[8]
-    gage_row = np.searchsorted(ids, table.index.values[np.asarray(da_byseg, dtype=np.int64)]) if ngage else \
-        np.zeros(0, dtype=np.int64)                                     # gage rows in the (masked) result order
+    if ngage:                                                            # gage rows in the (masked) result order
+        gseg = table.index.values[np.asarray(da_byseg, dtype=np.int64)]
+        gage_row = np.minimum(np.searchsorted(ids, gseg), max(nseg - 1, 0))
+        # a gage whose segment is an off-network upstream row (flowveldepth_interorder: masked out of the result,
+        # mc_reach.pyx:451,:812) belongs to no tailwater of this call
+        gage_row = np.where(ids[gage_row] == gseg, gage_row, -1) if nseg else np.full(ngage, -1, dtype=np.int64)
+    else:
+        gage_row = np.zeros(0, dtype=np.int64)
 
     # ---- back to the reference's per-tailwater result list ---------------------------------------------
     owner = np.full(nseg, -1, dtype=np.int64)
@@ -250,7 +256,8 @@ def compute_nhd_routing_v02(
     results = []
     for k in range(len(tws)):
         sel = np.flatnonzero(owner == k)
-        gk = np.flatnonzero(owner[gage_row] == k) if ngage else np.zeros(0, dtype=np.int64)   # this network's gages
+        gk = (np.flatnonzero((gage_row >= 0) & (owner[np.maximum(gage_row, 0)] == k)) if ngage
+              else np.zeros(0, dtype=np.int64))                                                # this network's gages
         results.append((
             ids[sel].astype(np.intp),
             fvd[sel],

@@ -235,7 +235,7 @@ def set_engine(monkeypatch, engine):
     monkeypatch.setenv("TRMC_ENGINE", engine.split("-")[0])
     if engine.endswith("-wide"):
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
-        monkeypatch.setenv("TRMC_WIDE_K", "5")
+        monkeypatch.setenv("TRMC_WIDE_K", "8")        # (a multiple of 4: the 16-byte result stores where nsteps allows them)
     else:
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
 

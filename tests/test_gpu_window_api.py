@@ -4,14 +4,10 @@ reported as RuntimeError / ValueError instead of undefined behaviour."""
 import numpy as np
 import pytest
 
-try:                      # before libtrmc.so is loaded: torch ships its own HIP runtime (see conftest.py)
-    import torch
-except Exception:         # pragma: no cover
-    torch = None
-
 import helpers as H
 from helpers import flow_engine
 from troute_amd import _lib
+from troute_amd.comm import DeviceBuffer
 from troute_amd.plan import RoutingPlan, csr_from_lists
 
 pytestmark = pytest.mark.gpu
@@ -41,17 +37,18 @@ def test_window_in_parts_equals_one_call(short):
         plan.route_begin(nsteps, qts, short)
         rows = np.array([5, 17, 2999, 0], np.int64)
         rs = plan.rowset(rows)
-        buf = torch.zeros((4, nsteps), dtype=torch.float32, device="cuda")
+        buf = DeviceBuffer(0, 4 * nsteps * 4)               # [4][nsteps] float32 in HBM (the library's own allocator)
         done = 0
         for t_end in (1, 1, 7, 23, 40):                      # uneven chunks, one empty
             plan.route_advance(t_end)
-            plan.gather_flow_range(rs, done, t_end, buf[:, done:].data_ptr(), nsteps)
+            plan.gather_flow_range(rs, done, t_end, buf.ptr + done * 4, nsteps)
             done = t_end
         st = plan.route_end()
         assert st["nsteps"] == nsteps and st["main_launches"] >= (4 if flow_engine() else nsteps)
         got = plan.download_fvd()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-        assert np.array_equal(buf.cpu().numpy().view(np.uint32), want[rows, :, 0].view(np.uint32))
+        assert np.array_equal(buf.download((4, nsteps), np.float32).view(np.uint32), want[rows, :, 0].view(np.uint32))
+        buf.free()
 
 
 def test_call_order_errors():
@@ -139,9 +136,9 @@ def test_time_skewed_rows_equal_two_phase_routing():
             plan.route_advance(d_end)
             if c < C_:
                 tb, te = c * K, min(nsteps, (c + 1) * K)
-                b = torch.zeros((1, te - tb), dtype=torch.float32, device="cuda")
-                plan.gather_flow_range(rs, tb, te, b.data_ptr(), te - tb)
-                plan.set_boundary_flow_range(tb, te, b.data_ptr(), te - tb)
+                b = DeviceBuffer(0, (te - tb) * 4)
+                plan.gather_flow_range(rs, tb, te, b.ptr, te - tb)
+                plan.set_boundary_flow_range(tb, te, b.ptr, te - tb)
                 bufs.append(b)
             if d_end >= last:
                 break

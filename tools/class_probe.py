@@ -19,7 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1 << 20)
 ap.add_argument("--nsteps", type=int, default=48)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--classes", default="dry,trickle,wet,flood,mixed")
+ap.add_argument("--classes", default="dry,trickle,wet,wet2,flood,mixed,sorted2,inter2,inter2w")
 a = ap.parse_args()
 net = synthetic.generate(cache_dir=os.environ.get("TRMC_CACHE", "/tmp/trmc_cache"))
 rng = np.random.default_rng(1)
@@ -28,16 +28,30 @@ FORCING = {   # lateral inflow per row [m3/s]
     "trickle": lambda n: np.exp(rng.uniform(np.log(1e-8), np.log(2e-6), n)).astype(np.float32),
     "wet": lambda n: np.exp(rng.uniform(np.log(0.02), np.log(0.8), n)).astype(np.float32),
     "flood": lambda n: np.exp(rng.uniform(np.log(300.0), np.log(3000.0), n)).astype(np.float32),
+    "wet2": lambda n: np.exp(rng.uniform(np.log(0.05), np.log(0.12), n)).astype(np.float32),   # typical channel: all rows 2 iterations
     "mixed": None,
+    # half the rows two-iteration, half one-iteration: the two classes one after the other (the order a cost-sorted level
+    # has), dealt out in turn by blocks of 128 rows (a step-kernel workgroup), by wavefronts of 64
+    "sorted2": None, "inter2": None, "inter2w": None,
 }
+TYPICAL = np.array([300.0, 1500.0, 3.0, 5.0, 15.0, 0.06, 0.12, 0.6, 0.006], np.float32)
 for k, name in enumerate(a.classes.split(",")):
     n = a.rows + 4096 * k
     rows = rng.integers(0, net["params"].shape[0], n)
     params = net["params"][rows].copy()
     if name == "mixed":      # the bench network's own forcing on unconnected rows: classes as they come, unsorted
         ql = net["qlat"][rows, 3].copy()
+    elif name in ("sorted2", "inter2", "inter2w"):
+        params[:] = TYPICAL
+        wet = FORCING["wet2"](n)
+        tri = FORCING["trickle"](n)
+        chunk = {"sorted2": n // 2, "inter2": 128, "inter2w": 64}[name]
+        pick = (np.arange(n) // chunk) % 2 == 0
+        ql = np.where(pick, wet, tri)
     else:
         ql = FORCING[name](n)
+        if name == "wet2":
+            params[:] = TYPICAL
     nq = (a.nsteps - 1) // 12 + 1
     qlat = np.repeat(ql[:, None], nq, axis=1) * (1.0 + 0.05 * np.sin(np.arange(nq)))[None, :].astype(np.float32)
     up_ptr = np.zeros(n + 1, np.int64)

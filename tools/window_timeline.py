@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Timeline of the LAST routing window in a rocprofv3 --kernel-trace database: per kernel the launches, summed and mean
+duration, the span they cover, how much of the wide tiles' time the tail launches overlap, and the gaps of each stream.
+    python tools/window_timeline.py results.db [first-kernel-of-a-window pattern, default k_prep_qlat|k_init_state]"""
+import sqlite3
+import sys
+
+con = sqlite3.connect(sys.argv[1])
+rows = con.execute(
+    "select s.kernel_name, d.start, d.end, d.queue_id, d.stream_id from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+    "on d.kernel_id = s.id order by d.start").fetchall()
+
+
+def short(n):
+    for k in ("k_mc_tile", "k_mc_step", "k_emit", "k_init_state", "k_prep_qlat", "k_gather_rows", "k_final_state", "k_mc_flow"):
+        if k in n:
+            return k
+    return n[:24]
+
+
+rows = [(short(n), s, e, q, st) for n, s, e, q, st in rows]
+starts = [i for i, r in enumerate(rows) if r[0] == "k_init_state"]
+if not starts:
+    sys.exit("no window found")
+i0 = starts[-1]
+win = rows[i0:]
+t0 = win[0][1]
+print(f"last window: {len(win)} dispatches, span {(max(r[2] for r in win) - t0) / 1e6:.3f} ms")
+by = {}
+for n, s, e, q, st in win:
+    by.setdefault(n, []).append((s - t0, e - t0, q, st))
+for n, v in by.items():
+    dur = [b - a for a, b, _, _ in v]
+    print(f"  {n:14s} launches {len(v):4d}  sum {sum(dur) / 1e6:8.3f} ms  mean {sum(dur) / len(v) / 1e3:8.1f} us  first start {v[0][0] / 1e6:7.3f}  last end {v[-1][1] / 1e6:7.3f} ms"
+          f"  queue/stream {sorted(set((q, st) for _, _, q, st in v))}")
+if "k_mc_tile" in by and "k_mc_step" in by:
+    tiles = by["k_mc_tile"]
+    ov = 0
+    for a, b, _, _ in by["k_mc_step"]:
+        for c, d, _, _ in tiles:
+            ov += max(0, min(b, d) - max(a, c))
+    tot = sum(b - a for a, b, _, _ in by["k_mc_step"])
+    print(f"  tail launches: {ov / max(tot, 1):.2f} of their time lies inside a wide tile's; idle between wide tiles "
+          f"{sum(max(0, tiles[i + 1][0] - tiles[i][1]) for i in range(len(tiles) - 1)) / 1e6:.3f} ms")
+    k = by["k_mc_step"]
+    for j in (0, len(k) // 4, len(k) // 2, 3 * len(k) // 4, len(k) - 1):
+        print(f"    tail launch {j:3d}: start {k[j][0] / 1e6:7.3f} dur {(k[j][1] - k[j][0]) / 1e3:7.1f} us")
+    for j in (0, len(tiles) // 2, len(tiles) - 1):
+        print(f"    wide tile  {j:3d}: start {tiles[j][0] / 1e6:7.3f} dur {(tiles[j][1] - tiles[j][0]) / 1e3:7.1f} us")
