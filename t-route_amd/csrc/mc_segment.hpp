@@ -35,6 +35,8 @@
 // m.fast_ok(h, h_in, h_over) -> ok; m.div2(a1, a2, b, ok, q1, q2): qi = ai / b; m.div1(a, b, ok) = a / b: the
 // divisions of the hydraulic point, for which a policy may use a cheaper exact sequence when `ok` (its own test of
 // the operand ranges) holds.
+// M::kPacked, M::V2 and m.v2 / m.v2s / m.vx / m.vy / m.div2v / m.div1v: optional two-element vectors whose arithmetic is one
+// packed instruction (hydraulics_inbank2).
 // m.all(pred): true when `pred` holds for every row that is evaluated together with this one (a wavefront's active
 // lanes) -- a scalar condition: the in-bank body of the hydraulic point is chosen by ONE uniform branch per wavefront.
 //
@@ -248,6 +250,44 @@ MC_HD HydraulicPoint<T> hydraulics_inbank(T h, const ChannelParams<T> &p, const 
     return hp;
 }
 
+// The same body for TWO depths of one channel at once -- the bracket (h_0, h) a step starts from -- on a policy that has
+// two-element vectors (M::kPacked, M::V2): every float addition, multiplication and fused multiply-add of the two points
+// is then ONE packed instruction for both (gfx950: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, IEEE per element: the same
+// bits as the scalar operations), which is where half of the body's instructions are; reciprocals' seeds, the powers
+// (double precision) and the compare-selects stay per element.
+template <class T, class M>
+MC_HD void hydraulics_inbank2(T h_a, T h_b, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m,
+                              HydraulicPoint<T> &o_a, HydraulicPoint<T> &o_b)
+{
+    using V = typename M::V2;
+    const T c23 = T(2) / T(3), c53 = T(5) / T(3);
+    const V h = m.v2(h_a, h_b), bw = m.v2s(p.bw);
+    const V twl = bw + m.v2s(c.z2) * h;
+    const V area = (bw + h * m.v2s(c.z)) * h;
+    const V wp = bw + h * m.v2s(c.two_sq);
+    V R, n_comp;
+    m.div2v(area, wp * m.v2s(p.n), wp, R, n_comp);
+    const typename M::Log lr_a = m.log_of_r(m.vx(R), true), lr_b = m.log_of_r(m.vy(R), true);
+    const V r23 = m.v2(m.pow_l_r(lr_a, m.vx(R), c23, true), m.pow_l_r(lr_b, m.vy(R), c23, true));
+    const V r53 = m.v2(m.pow_l_r(lr_a, m.vx(R), c53, true), m.pow_l_r(lr_b, m.vy(R), c53, true));
+    const V ckv = m.v2s(c.s0_n) * (m.v2s(c53) * r23 - (m.v2s(c23) * r53 * m.div1v(m.v2s(c.two_sq), twl)));
+    o_a.ck = mc_max(T(0), m.vx(ckv));
+    o_b.ck = mc_max(T(0), m.vy(ckv));
+    {
+        const T kq_a = mc_max(p.dt, m.divx(p.dx, o_a.ck)), kq_b = mc_max(p.dt, m.divx(p.dx, o_b.ck));
+        o_a.km = (o_a.ck > T(0)) ? kq_a : p.dt;
+        o_b.km = (o_b.ck > T(0)) ? kq_b : p.dt;
+    }
+    const V dn = m.v2s(T(2)) * twl * m.v2s(p.s0) * m.v2(o_a.ck, o_b.ck) * m.v2s(p.dx);
+    o_a.denom = m.vx(dn);
+    o_b.denom = m.vy(dn);
+    const V qm = m.div1v(m.v2s(T(1)), n_comp) * area * r23 * m.v2s(c.sqrt_s0);
+    o_a.q_manning = m.vx(qm);
+    o_b.q_manning = m.vy(qm);
+    o_a.has_wp = o_b.has_wp = true;
+    o_a.over = o_b.over = false;
+}
+
 // one point: the in-bank body when every row evaluated together is in bank (one uniform branch), else the general one
 template <class T, class M>
 MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
@@ -341,8 +381,12 @@ MC_HD StepPre<T> step_pre(const ChannelParams<T> &p, const ChannelConst<T> &c, T
     step_bracket(depthp, s.h, s.h_0);
     // (0 <= h_0 <= h: the lower bound of the range is tested on h_0, the upper bound and the bank on h)
     if (TRMC_INBANK_BODY && m.all(m.fast_ok(s.h, s.h_0, T(0)) && s.h <= c.bfd)) {
-        s.at_h0 = hydraulics_inbank<T, M>(s.h_0, p, c, m);
-        s.at_h = hydraulics_inbank<T, M>(s.h, p, c, m);
+        if constexpr (M::kPacked) {
+            hydraulics_inbank2<T, M>(s.h_0, s.h, p, c, m, s.at_h0, s.at_h);
+        } else {
+            s.at_h0 = hydraulics_inbank<T, M>(s.h_0, p, c, m);
+            s.at_h = hydraulics_inbank<T, M>(s.h, p, c, m);
+        }
     } else {
         s.at_h0 = hydraulics_general<T, M>(s.h_0, p, c, m);
         s.at_h = hydraulics_general<T, M>(s.h, p, c, m);
@@ -363,8 +407,48 @@ template <class T> struct StepSolve {
     int iters;
     bool over;
 };
+// what a secant iteration carries to the next one (f90:92-117; the coefficients and both residual slots live on through
+// the reference's intent(out) dummies)
+template <class T> struct SecantState {
+    T h, h_0, qj_0, aerror;
+    bool rel_open;
+    MuskCoef<T> k;
+    HydraulicPoint<T> at_h0; // the point of h_0: after an iteration, the one just evaluated for h (h_0 <- h)
+};
+// one iteration, the hydraulic point of the current h supplied (f90:92-117)
+template <class T, class M>
+MC_HD void secant_iterate(SecantState<T> &s, const HydraulicPoint<T> &at_h, const ChannelParams<T> &p, const ChannelConst<T> &c,
+                          const Inflow<T> &f, const M &m)
+{
+    s.qj_0 = secant_residual<T, M, false>(s.at_h0, s.qj_0, p, c, f, s.k, m);
+    const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, s.k, m);
+    const T h = s.h, h_0 = s.h_0;
+    T h_1;
+    {
+        const T hq = h - m.divx(qj * (h_0 - h), s.qj_0 - qj); // (equal residuals: NaN or inf, discarded)
+        h_1 = (s.qj_0 - qj != T(0)) ? hq : h;
+        h_1 = (h_1 < T(0)) ? h : h_1;
+    }
+    {
+        // The relative error |(h_1 - h) / h| (f90:108) is only ever compared with 0.01 (f90:83): `rel_open` is that
+        // comparison, decided without the division whenever the ratio is clearly on one side (a band of 1e-4 around the
+        // threshold against a rounding error of 6e-8; a NaN fails both tests and takes the division).
+        const T dh = mc_abs(h_1 - h);
+        const bool hi = dh > T(0.010001) * h, lo = dh < T(0.009999) * h;
+        bool open = hi;
+        if (!hi && !lo) open = mc_abs((h_1 - h) / h) > T(0.01); // (the band around the threshold, or a NaN: rare)
+        s.rel_open = (h > T(0)) ? open : false;                   // h = 0: rerror = 0
+        s.aerror = (h > T(0)) ? dh : T(0.9);
+    }
+    s.at_h0 = at_h;
+    s.h_0 = mc_max(T(0), h);
+    s.h = mc_max(T(0), h_1);
+}
 // The secant iteration (f90:83-134) and the outflow (f90:149-161).  `pre` = step_pre of the same row and depth (evaluated
-// here when it has not been); requires step_has_flow(f).
+// here when it has not been); requires step_has_flow(f).  The first iteration of the first pass is written out on its
+// own: it is always entered (rerror = 1, aerror = 0.01, iter = 0), both of its points come from `pre`, and its first
+// residual starts from Qj_0 = 0 -- the compiler folds that; 40 % of the CONUS segment-steps are done after it (depth under
+// the 1 cm floor).  Retries (f90:126-134: more than 100 iterations, never seen on a river network) go round the same loop.
 template <class T, class M>
 MC_HD StepSolve<T> step_solve(const ChannelParams<T> &p, const ChannelConst<T> &c, const Inflow<T> &f, T depthp,
                               const StepPre<T> &pre_in, const M &m)
@@ -372,73 +456,51 @@ MC_HD StepSolve<T> step_solve(const ChannelParams<T> &p, const ChannelConst<T> &
     const T mindepth = T(0.01);
     StepSolve<T> out;
     const StepPre<T> pre = pre_in.have ? pre_in : step_pre<T, M>(p, c, depthp, m);
-    T h = pre.h, h_0 = pre.h_0;
-
-    MuskCoef<T> k{T(0), T(0), T(0), T(0), T(0)};
-    // The relative error |(h_1 - h) / h| (f90:108) is only ever compared with 0.01 (f90:83): `rel_open` is that
-    // comparison, decided without the division whenever the ratio is clearly on one side (a band of 1e-4 around the
-    // threshold against a rounding error of 6e-8; a NaN fails both tests and takes the division).
-    T aerror = T(0.01);
-    bool rel_open = true;
-    int maxiter = 100, tries = 0, total_iter = 0;
+    SecantState<T> s;
+    s.h = pre.h;
+    s.h_0 = pre.h_0;
+    s.qj_0 = T(0);
+    s.k = MuskCoef<T>{T(0), T(0), T(0), T(0), T(0)};
+    s.at_h0 = pre.at_h0;
     bool any_over = pre.at_h0.over || pre.at_h.over;
-    bool first = true;
+    int maxiter = 100, tries = 0, iter = 1, total_iter = 1;
+    secant_iterate<T, M>(s, pre.at_h, p, c, f, m);
+    bool skip = s.h < mindepth; // (f90:120-122 after the first iteration)
     for (;;) {
-        T qj_0 = T(0);
-        int iter = 0;
-        // the point of h_0: evaluated for the bracket a (re)try starts from (the first pass takes both of its points from
-        // `pre`); inside the loop h_0 <- max(0, h) is h itself (h is never negative), so the point just evaluated for h is
-        // carried over instead of being recomputed
-        HydraulicPoint<T> at_h0 = pre.at_h0, at_h = pre.at_h;
-        if (!first && rel_open && aerror >= mindepth && iter <= maxiter) {
-            at_h0 = hydraulics_at<T, M>(h_0, p, c, m);
-            any_over = any_over || at_h0.over;
-        }
-        while (rel_open && aerror >= mindepth && iter <= maxiter) {
-            qj_0 = secant_residual<T, M, false>(at_h0, qj_0, p, c, f, k, m);
-            if (!(first && iter == 0)) {
-                at_h = hydraulics_at<T, M>(h, p, c, m);
+        if (!skip) {
+            while (s.rel_open && s.aerror >= mindepth && iter <= maxiter) {
+                const HydraulicPoint<T> at_h = hydraulics_at<T, M>(s.h, p, c, m);
                 any_over = any_over || at_h.over;
+                secant_iterate<T, M>(s, at_h, p, c, f, m);
+                ++iter;
+                ++total_iter;
+                if (s.h < mindepth) break;
             }
-            const T qj = secant_residual<T, M, true>(at_h, T(0), p, c, f, k, m);
-            T h_1;
-            {
-                const T hq = h - m.divx(qj * (h_0 - h), qj_0 - qj); // (equal residuals: NaN or inf, discarded)
-                h_1 = (qj_0 - qj != T(0)) ? hq : h;
-                h_1 = (h_1 < T(0)) ? h : h_1;
-            }
-            {
-                const T dh = mc_abs(h_1 - h);
-                const bool hi = dh > T(0.010001) * h, lo = dh < T(0.009999) * h;
-                bool open = hi;
-                if (!hi && !lo) open = mc_abs((h_1 - h) / h) > T(0.01); // (the band around the threshold, or a NaN: rare)
-                rel_open = (h > T(0)) ? open : false;                     // h = 0: rerror = 0
-                aerror = (h > T(0)) ? dh : T(0.9);
-            }
-            at_h0 = at_h;
-            h_0 = mc_max(T(0), h);
-            h = mc_max(T(0), h_1);
-            ++iter;
-            ++total_iter;
-            if (h < mindepth) break;
         }
-        first = false;
+        skip = false;
         if (iter >= maxiter && ++tries <= 4) { // widen the bracket and retry
-            h = h * T(1.33);
-            h_0 = h_0 * T(0.67);
+            s.h = s.h * T(1.33);
+            s.h_0 = s.h_0 * T(0.67);
             maxiter += 25;
+            s.qj_0 = T(0);
+            iter = 0;
+            if (s.rel_open && s.aerror >= mindepth && iter <= maxiter) {
+                s.at_h0 = hydraulics_at<T, M>(s.h_0, p, c, m);
+                any_over = any_over || s.at_h0.over;
+            }
             continue;
         }
         break;
     }
 
+    const MuskCoef<T> &k = s.k;
     const T w3 = (k.C1 * f.qup) + (k.C2 * f.quc) + (k.C3 * f.qdp);
     {   // (f90:126-141; all three candidates are a few additions: formed, then selected)
         const T q_neg = mc_max(((k.C1 * f.qup) + (k.C2 * f.quc) + k.C4), ((k.C1 * f.qup) + (k.C3 * f.qdp) + k.C4));
         const T q_lo = ((k.C4 < T(0)) && (mc_abs(k.C4) > w3)) ? T(0) : q_neg;
         out.qdc = ((w3 + k.C4) < T(0)) ? q_lo : w3 + k.C4;
     }
-    out.h = h;
+    out.h = s.h;
     out.X = k.X;
     out.iters = total_iter;
     out.over = any_over;

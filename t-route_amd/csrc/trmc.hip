@@ -115,6 +115,36 @@ struct DevMathF {
     __device__ __forceinline__ float sqrt(float x) const { return ::sqrtf(x); }
     // wave-wide AND over the active lanes: a scalar, so the branch on it is a uniform one
     __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
+    // two floats whose + - * fma are one packed instruction (v_pk_*_f32: IEEE per element, the same bits as the scalar forms)
+#ifndef TRMC_PACKED_PAIR
+#define TRMC_PACKED_PAIR 0 // measured: 671 instead of 701 instructions per wavefront-step and SLOWER (a packed instruction issues for two passes)
+#endif
+    static constexpr bool kPacked = TRMC_PACKED_PAIR != 0;
+    typedef float V2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ static V2 v2(float a, float b) { return V2{a, b}; }
+    __device__ __forceinline__ static V2 v2s(float a) { return V2{a, a}; }
+    __device__ __forceinline__ static float vx(V2 v) { return v.x; }
+    __device__ __forceinline__ static float vy(V2 v) { return v.y; }
+    __device__ __forceinline__ static V2 vfma(V2 a, V2 b, V2 c) { return __builtin_elementwise_fma(a, b, c); }
+    __device__ __forceinline__ static V2 refined_rcp_v(V2 b)
+    {
+        const V2 y0 = V2{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+        return vfma(vfma(-b, y0, v2s(1.0f)), y0, y0);
+    }
+    __device__ __forceinline__ static V2 quot_v(V2 a, V2 b, V2 y1)
+    {
+        const V2 q0 = a * y1;
+        const V2 q1 = vfma(vfma(-b, q0, a), y1, q0);
+        return vfma(vfma(-b, q1, a), y1, q1);
+    }
+    // (the packed forms of div2 / div1 under `ok`: the same refined-reciprocal sequences, see below)
+    __device__ __forceinline__ void div2v(V2 a1, V2 a2, V2 b, V2 &q1, V2 &q2) const
+    {
+        const V2 y1 = refined_rcp_v(b);
+        q1 = quot_v(a1, b, y1);
+        q2 = quot_v(a2, b, y1);
+    }
+    __device__ __forceinline__ V2 div1v(V2 a, V2 b) const { return quot_v(a, b, refined_rcp_v(b)); }
 
     // The four Muskingum coefficients C1..C4 = n_i / D (f90:303-312) with ONE reciprocal.
     // hipcc expands an fp32 division into  v_div_scale x2, v_rcp, the refinement
@@ -239,6 +269,7 @@ struct DevMathD {
     __device__ __forceinline__ double pow_l_r(Log, double x, double y, bool) const { return det_pow64(x, y); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
+    static constexpr bool kPacked = false;
     bool coef_ok; // unused
     bool sane;    // unused
     __device__ __forceinline__ bool fast_ok(double, double, double) const { return false; }
@@ -509,11 +540,12 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 // of every step (what downstream rows and the gathers read) and the depth row of a tile's last step (where the row's next
 // tile, or the final state, picks it up) are written.
 constexpr int kTileStage = 8;
-#ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow (1: as many registers as it likes)
-#define TRMC_TILE_WAVES 1
+#ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow (4: at most 128 registers; left to itself the
+// compiler takes 129 and the kernel drops to three)
+#define TRMC_TILE_WAVES 4
 #endif
 template <class T>
-__global__ void __launch_bounds__(kStepBlock, TRMC_TILE_WAVES)
+__global__ void __launch_bounds__(kStepBlock, sizeof(T) == 4 ? TRMC_TILE_WAVES : 1)
 k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t tile, const int32_t K)
 {
     using M = typename DevMath<T>::type;
@@ -561,11 +593,14 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     // the lateral-inflow column of step t is (t - 1) / qts: found by division once, by a counter from then on
     int32_t ql_col = (t_lo - 1) / a.qts, ql_left = a.qts - (t_lo - 1) % a.qts;
     T ql = at(a.qlat_tm + (size_t)ql_col * np, ob);
+    m.coef_ok = coef_guard(p.dt, ql); // (depends on the forcing column only: formed when that changes, not every step)
+    const bool count_cost = a.it_sum != nullptr;
     int32_t it_acc = 0, it_last = 0, staged = 0;
     for (int32_t t = t_lo; t <= t_hi; ++t) {
         if (ql_left == 0) {
             ++ql_col;
             ql = at(a.qlat_tm + (size_t)ql_col * np, ob);
+            m.coef_ok = coef_guard(p.dt, ql);
             ql_left = a.qts;
         }
         --ql_left;
@@ -596,13 +631,12 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             f.quc = qup;
             f.qdp = q_prev;
             f.ql = ql;
-            m.coef_ok = coef_guard(p.dt, f.ql);
             const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, c, f, d_prev, m);
             q_new = r.qdc;
             v_new = r.velc;
             d_new = r.depthc;
-            it_last = min(r.iters, 255);
-            it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
+            it_last = r.iters;
+            if (count_cost) it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
             if (gi >= 0) { // streamflow nudging (see k_mc_step)
                 const size_t e = (size_t)gi * (size_t)a.nsteps + (size_t)(t - 1);
                 const uint8_t mode = a.da_mode[e];
@@ -648,8 +682,8 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             }
         }
     }
-    if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)it_last;
-    if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + it_acc);
+    if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)min(it_last, 255);
+    if (count_cost) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + it_acc);
 }
 
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
