@@ -37,6 +37,8 @@
 // the operand ranges) holds.
 // M::kPacked, M::V2 and m.v2 / m.v2s / m.vx / m.vy / m.div2v / m.div1v: optional two-element vectors whose arithmetic is one
 // packed instruction (hydraulics_inbank2).
+// M::kInbank: whether the policy wants the in-bank body of the hydraulic point at all (hydraulics_inbank: fewer instructions,
+// more code and registers -- the level kernels take it, the dataflow kernels, whose pace is one wavefront's latency, do not).
 // m.all(pred): true when `pred` holds for every row that is evaluated together with this one (a wavefront's active
 // lanes) -- a scalar condition: the in-bank body of the hydraulic point is chosen by ONE uniform branch per wavefront.
 //
@@ -48,10 +50,6 @@
 #define MC_HD __host__ __device__ __forceinline__
 #else
 #define MC_HD inline
-#endif
-
-#ifndef TRMC_INBANK_BODY // 0: the general body of the hydraulic point everywhere (A/B measurements)
-#define TRMC_INBANK_BODY 1
 #endif
 
 namespace trmc {
@@ -292,7 +290,7 @@ MC_HD void hydraulics_inbank2(T h_a, T h_b, const ChannelParams<T> &p, const Cha
 template <class T, class M>
 MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
 {
-    if (TRMC_INBANK_BODY && m.all(inbank_fast<T, M>(h, c, m))) return hydraulics_inbank<T, M>(h, p, c, m);
+    if (M::kInbank && m.all(inbank_fast<T, M>(h, c, m))) return hydraulics_inbank<T, M>(h, p, c, m);
     return hydraulics_general<T, M>(h, p, c, m);
 }
 
@@ -380,7 +378,7 @@ MC_HD StepPre<T> step_pre(const ChannelParams<T> &p, const ChannelConst<T> &c, T
     StepPre<T> s;
     step_bracket(depthp, s.h, s.h_0);
     // (0 <= h_0 <= h: the lower bound of the range is tested on h_0, the upper bound and the bank on h)
-    if (TRMC_INBANK_BODY && m.all(m.fast_ok(s.h, s.h_0, T(0)) && s.h <= c.bfd)) {
+    if (M::kInbank && m.all(m.fast_ok(s.h, s.h_0, T(0)) && s.h <= c.bfd)) {
         if constexpr (M::kPacked) {
             hydraulics_inbank2<T, M>(s.h_0, s.h, p, c, m, s.at_h0, s.at_h);
         } else {

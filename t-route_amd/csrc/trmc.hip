@@ -120,6 +120,7 @@ struct DevMathF {
 #define TRMC_PACKED_PAIR 0 // measured: 671 instead of 701 instructions per wavefront-step and SLOWER (a packed instruction issues for two passes)
 #endif
     static constexpr bool kPacked = TRMC_PACKED_PAIR != 0;
+    static constexpr bool kInbank = true;
     typedef float V2 __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ static V2 v2(float a, float b) { return V2{a, b}; }
     __device__ __forceinline__ static V2 v2s(float a) { return V2{a, a}; }
@@ -256,6 +257,12 @@ struct DevMathF {
     }
 #endif
 };
+// The same arithmetic for the dataflow kernels, without the in-bank body: there a wavefront steps through time by itself
+// and what counts is the latency of ITS step -- registers and code size -- not the instruction count of a full device
+// (measured: a lone 4 096-row chain 6.6 us per step against 7.3 with the in-bank body, the general-mode CONUS day the same).
+struct DevMathFlow : DevMathF {
+    static constexpr bool kInbank = false;
+};
 // fp64: the bit-reproducible double power of det_pow64.h (glibc 2.35 pow restated, the one the reference links when it
 // is built with -fdefault-real-8: oracle/_ref/libmc_ref_qj0_f64.so), so that the fp64 path -- BASELINE configs[1] -- is
 // bit-comparable with the reference too, not merely close; / and sqrt are the correctly rounded forms.
@@ -270,6 +277,7 @@ struct DevMathD {
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
     static constexpr bool kPacked = false;
+    static constexpr bool kInbank = false;
     bool coef_ok; // unused
     bool sane;    // unused
     __device__ __forceinline__ bool fast_ok(double, double, double) const { return false; }
@@ -1147,7 +1155,7 @@ template <bool SHORT>
 __global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES) TRMC_FLOW_ATTR
 k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the launches / steps (t0, t1] of the window
 {
-    using M = DevMathF;
+    using M = DevMathFlow;
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ float s_out[3 * kFlowStage * kFlowBlock];             // [step slot * 3 + c][thread]
     __shared__ unsigned long long s_ring[kFlowRing * kFlowBlock];    // [step % kFlowRing][thread] granules
@@ -1258,15 +1266,13 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
             ql_left = a.qts;
         }
         --ql_left;
-        // What the step needs of the row's OWN state only -- the bracket of the secant iteration and its first two
-        // hydraulic points (mc_segment.hpp step_pre: half of the arithmetic of a two-iteration step) -- is evaluated
-        // BEFORE the row looks for what its upstream rows hand down: off the dependence chain that links a row to the row
-        // above it (f90:69-71 and the first pass of :83-95 read depthp and the channel only).  In the general mode, that
-        // is: with assume_short_ts a row reads flows of the step BEFORE, which its upstream rows published a step ago --
-        // there is no chain to shorten, and holding the two points across the look-up would only cost registers.
+        // (Evaluating the part of the step that needs the row's OWN state only -- step_pre: the bracket and its two hydraulic
+        // points -- BEFORE the look-up below, off the dependence chain, was built and measured: the general-mode CONUS day
+        // 55 ms instead of 38, a lone chain 8.3 us per row instead of 7.4.  The chain mostly runs through the lanes of ONE
+        // wavefront, which advance a row per round whatever the order inside the round, and the two points held across the
+        // look-up cost registers the kernel does not have.  What stayed: the flow is published before the velocity is formed.)
         trmc::StepPre<float> pre;
         pre.have = false;
-        if (!SHORT && ri < 0 && trmc::step_has_own_flow(ql, q_prev)) pre = trmc::step_pre<float, M>(p, c, d_prev, m);
         // junction sums in the reference's order (mc_reach.pyx:499-502): with assume_short_ts the upstream flows of
         // step t - 1 (they are also `quc`, :504-505), without it those of step t and -- kept from the round before --
         // of step t - 1
@@ -1442,7 +1448,7 @@ template <bool LAG>
 __global__ void __launch_bounds__(kFlowBlock, TRMC_LEAN_WAVES)
 k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
 {
-    using M = DevMathF;
+    using M = DevMathFlow;
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ float s_par[kLeanCols * kFlowBlock];                 // [column][thread]
     __shared__ unsigned long long s_ring[kLeanRing * kFlowBlock];   // [step % 2][thread] granules
