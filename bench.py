@@ -318,6 +318,12 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)
+    # ONE JSON line on stdout, whatever the libraries loaded below print there (RCCL writes a version banner to stdout when a
+    # communicator is made): file descriptor 1 is pointed at stderr for the rest of the process, the line goes out through
+    # a private copy of the original stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -644,7 +650,8 @@ def main():
             "diffusive": diffusive,
         }
         line.update(extra)
-        print(json.dumps(line))
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if comm is not None:
         comm.barrier()
         comm.close()

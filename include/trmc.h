@@ -402,6 +402,7 @@ void trmc_comm_destroy(trmc_comm *comm);
 int trmc_dev_alloc(int device, int64_t bytes, void **ptr_out); /* zero-filled */
 int trmc_dev_free(int device, void *ptr);
 int trmc_dev_upload(int device, void *dst_dev, const void *src_host, int64_t bytes);
+int trmc_dev_copy(int device, void *dst_dev, const void *src_dev, int64_t bytes, void *stream); /* device to device, on `stream` */
 int trmc_dev_download(int device, void *dst_host, const void *src_dev, int64_t bytes, void *stream); /* waits for `stream` */
 /* ... and without waiting: complete after trmc_stream_synchronize(stream); dst_host should be page-locked (trmc_host_alloc) */
 int trmc_dev_download_async(int device, void *dst_host, const void *src_dev, int64_t bytes, void *stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "trmc_dev_alloc": (_int, [_int, _i64, _P(_vp)]),
     "trmc_dev_free": (_int, [_int, _vp]),
     "trmc_dev_upload": (_int, [_int, _vp, _vp, _i64]),
+    "trmc_dev_copy": (_int, [_int, _vp, _vp, _i64, _vp]),
     "trmc_dev_download": (_int, [_int, _vp, _vp, _i64, _vp]),
     "trmc_dev_download_async": (_int, [_int, _vp, _vp, _i64, _vp]),
     "trmc_dev_gather_rows": (_int, [_int, _vp, _vp, _i64, _i64, _vp, _vp]),

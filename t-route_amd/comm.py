@@ -118,6 +118,11 @@ def stream_wait_event(device, stream, event):
     _check(_lib.lib().trmc_stream_wait_event(int(device), C.c_void_p(stream) if stream else None, C.c_void_p(event)))
 
 
+def device_copy(device, dst_ptr, src_ptr, nbytes, stream):
+    _check(_lib.lib().trmc_dev_copy(int(device), C.c_void_p(dst_ptr), C.c_void_p(src_ptr), int(nbytes),
+                                    C.c_void_p(stream) if stream else None))
+
+
 def gather_rows(device, src_ptr, index_ptr, nrows, row_bytes, dst_ptr, stream):
     _check(_lib.lib().trmc_dev_gather_rows(int(device), C.c_void_p(src_ptr), C.c_void_p(index_ptr), int(nrows), int(row_bytes),
                                            C.c_void_p(dst_ptr), C.c_void_p(stream) if stream else None))

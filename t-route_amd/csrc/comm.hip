@@ -415,6 +415,15 @@ int trmc_dev_download(int device, void *dst_host, const void *src_dev, int64_t b
     return 0;
 }
 
+int trmc_dev_copy(int device, void *dst_dev, const void *src_dev, int64_t bytes, void *stream)
+{
+    if (bytes == 0) return 0;
+    if (!dst_dev || !src_dev || bytes < 0) return fail_with(TRMC_EINVAL, "bad copy arguments");
+    COMM_HIP_TRY(hipSetDevice(device));
+    COMM_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 int trmc_dev_download_async(int device, void *dst_host, const void *src_dev, int64_t bytes, void *stream)
 {
     if (bytes == 0) return 0;

@@ -2,7 +2,7 @@
 """Time every rank's share of an N-GPU CONUS run on ONE GPU, one rank after the other.
 
 The cut-edge hydrographs a rank would receive from its peers are taken from a complete single-GPU route
-(so the trunk sees its true inflows); the collective is an in-process copy.  Reports, per rank, the wall
+(so the trunk sees its true inflows); the collective is a device-to-device copy of what the peers would have sent (a stand-in for troute_amd.comm.Comm).  Reports, per rank, the wall
 time of route_on_device -- the job time of the real N-GPU run is about the maximum (plus RCCL latency).
 
     python tools/sim_ranks.py --world 8 [--chunks 4] [--full-ts]
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--ranks", type=str, default=None, help="comma list (default: all)")
     ap.add_argument("--retune", action="store_true", help="rebuild every router with the cost hint of a tuning window")
     a = ap.parse_args()
-    import torch
+    from troute_amd import comm as X
     from troute_amd import sharding, synthetic
     from troute_amd.distributed import ShardedRouter
 
@@ -37,7 +37,7 @@ def main():
     nseg = to.shape[0]
     q0 = np.zeros((nseg, 3), np.float32)
     nsteps, qts, short = 288, 12, not a.full_ts
-    dev = torch.device("cuda", 0)
+    dev = 0
 
     part = sharding.partition(to, a.world)
     # true hydrographs of the cut rows from a whole-network route
@@ -71,69 +71,77 @@ def main():
     for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
         r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
                           assume_short_ts=short, engine=eng)
-        r.enable_device_exchange(torch, dev)
-        r.upload(nsteps, qlat, q0)
-        r.upload_trunk()
-        # what the peers would contribute to each all-gather, laid out [world, max_cut, nsteps]
-        peers = torch.zeros((a.world, max(r._max_cut, 1), nsteps), dtype=torch.float32, device=dev)
-        if cut_rows.size:
-            idx = np.zeros(cut_rows.size, dtype=np.int64)
-            for k in range(a.world):
-                m = r.cut_owner == k
-                idx[m] = np.arange(int(m.sum()))
-            peers[torch.from_numpy(r.cut_owner.astype(np.int64)).to(dev), torch.from_numpy(idx).to(dev)] = \
-                torch.from_numpy(cut_q).to(dev)
         default_chunks = 4 if getattr(r.plan0, "engine", "levels") == "flow" else 24     # route_on_device's defaults
         nchunks_eff = (a.chunks if a.chunks else default_chunks) if short else (a.chunks if a.chunks else 1)
-        state = {"t": 0, "call": 0}
 
-        def all_gather_into(out, t):
-            # the router issues one all-gather per time chunk (when there are cut rows), then the outlet gather
-            is_cut = r._max_cut > 0 and state["call"] < nchunks_eff
-            state["call"] += 1
-            if is_cut:
-                w = out.shape[2]
-                out.copy_(peers[:, :, state["t"]:state["t"] + w])
-                out[rank].copy_(t)
-                state["t"] += w
-            else:
-                out.zero_()
-                out[rank].copy_(t)
+        class SimComm:
+            """the peers of this rank, played back: an all-gather of a time chunk of cut-edge hydrographs hands out what a
+            whole-network route says the other ranks would have sent (device-to-device copies on the caller's stream);
+            the outlet gather returns this rank's own block only"""
+            rank, world, backend = 0, a.world, "sim"
 
+            def __init__(self, router):
+                self.r = router
+                self.call = 0
+                self.blocks = None
+
+            def prepare(self, K, C):
+                mc = max(self.r._max_cut, 1)
+                peers = np.zeros((a.world, mc, nsteps), np.float32)
+                if cut_rows.size:
+                    idx = np.zeros(cut_rows.size, dtype=np.int64)
+                    for k in range(a.world):
+                        m = self.r.cut_owner == k
+                        idx[m] = np.arange(int(m.sum()))
+                    peers[self.r.cut_owner.astype(np.int64), idx] = cut_q
+                self.blocks = [X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, c * K:min(nsteps, (c + 1) * K)]))
+                               for c in range(C)]
+
+            def all_gather(self, send_ptr, recv_ptr, nbytes, stream=0):
+                c = self.call
+                self.call += 1
+                if self.r._max_cut > 0 and c < len(self.blocks):
+                    X.device_copy(dev, recv_ptr, self.blocks[c].ptr, self.blocks[c].nbytes, stream)
+                X.device_copy(dev, recv_ptr + rank * nbytes, send_ptr, nbytes, stream)
+
+            def barrier(self):
+                pass
+
+        sim = SimComm(r)
+        r.enable_device_exchange(sim, dev)
+        r.upload(nsteps, qlat, q0)
+        r.upload_trunk()
+        if short:
+            K = max(1, -(-nsteps // max(1, int(nchunks_eff))))
+            sim.prepare(K, -(-nsteps // K))
+        else:
+            bounds = np.round(np.linspace(0, nsteps, nchunks_eff + 1)).astype(np.int64)
+            sim.blocks = []
+            mc = max(r._max_cut, 1)
+            peers = np.zeros((a.world, mc, nsteps), np.float32)
+            if cut_rows.size:
+                idx = np.zeros(cut_rows.size, dtype=np.int64)
+                for k in range(a.world):
+                    m = r.cut_owner == k
+                    idx[m] = np.arange(int(m.sum()))
+                peers[r.cut_owner.astype(np.int64), idx] = cut_q
+            sim.blocks = [X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, int(bounds[c]):int(bounds[c + 1])]))
+                          for c in range(nchunks_eff)]
         acc = {}
-        if os.environ.get("TRMC_SIM_TRACE"):     # host-side time per call site
-            def wrap(obj, name):
-                fn = getattr(obj, name)
-                def timed(*args, **kw):
-                    t0 = time.perf_counter()
-                    try:
-                        return fn(*args, **kw)
-                    finally:
-                        acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
-                setattr(obj, name, timed)
-            for nm in ("route_begin", "route_advance", "route_end", "gather_flow_range", "set_boundary_flow_range"):
-                wrap(r.plan0, nm)
-                if r.plan1 is not None and short:
-                    wrap(r._merged_plan(2 * -(-nsteps // nchunks_eff)), nm)
-            _ag = all_gather_into
-            def all_gather_into(out, t, _ag=_ag):
-                t0 = time.perf_counter()
-                _ag(out, t)
-                acc["all_gather"] = acc.get("all_gather", 0.0) + time.perf_counter() - t0
         times = []
         for _ in range(a.reps + 1):
-            state["t"], state["call"] = 0, 0
-            torch.cuda.synchronize()
+            sim.call = 0
+            X.device_synchronize(dev)
             t0 = time.perf_counter()
-            rows, hyd = r.route_on_device(qts, short, all_gather_into, a.chunks)
-            torch.cuda.synchronize()
+            rows, hyd = r.route_on_device(qts, short, nchunks_eff)
+            X.device_synchronize(dev)
             times.append(time.perf_counter() - t0)
         t = min(times[1:])
         worst = max(worst, t)
         st = r.last_stats
         # check my own outlets against the single-GPU run
         mine = np.concatenate([r.my_out0_global, r.my_out1_global])
-        h = hyd.cpu().numpy()
+        h = hyd.numpy()
         sel = np.searchsorted(rows, mine)
         ok = np.array_equal(h[sel].view(np.uint32), ref_hyd[np.searchsorted(ref_rows, mine)].view(np.uint32))
         print(f"rank {rank} ({r.plan0.engine}): {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
