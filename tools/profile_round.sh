@@ -1,33 +1,38 @@
 #!/bin/bash
-# The round's profile evidence: rocprofv3 kernel trace of the default bench command, then separate counter-only
-# passes for FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU (never combined with other trace domains), summarised by
-# tools/rocpd_summary.py into gpurun_out/<tag>_summary.txt, plus gpurun_out/<tag>_pmc_traffic.json
-# (copy both into profiles/).   usage: tools/profile_round.sh <tag> <engine: levels|flow> <round>
+# The round's profile evidence, all of the TIMED configuration (bench.py --headline-only: the process ends with the
+# headline's windows): a rocprofv3 kernel trace (every kernel of the process, then the timeline of the last window), and
+# separate counter-only passes -- FETCH_SIZE; WRITE_SIZE; the SQ instruction / cycle counters -- never combined with other
+# trace domains, read for the LAST window's launches.   usage: tools/profile_round.sh <tag>     (copy gpurun_out/<tag>_* into profiles/)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 tag=${1:-r}
-engine=${2:-levels}
-rnd=${3:-0}
 out=gpurun_out/$tag
 mkdir -p "$out"
-sum=gpurun_out/${tag}_summary.txt
-: > "$sum"
-lean="--no-cpu-baseline --no-full-ts --no-diffusive --no-parity-mode --no-traffic"
+lean="--headline-only --no-traffic --no-parity-sample"
 timeout 900 rocprofv3 --kernel-trace -d "$out/trace" -o trace -- python bench.py --steps 3 --warmup 1 $lean > "$out/trace.log" 2>&1
-grep "^{\"metric\"" "$out/trace.log" | tail -1 > "gpurun_out/${tag}_bench_under_trace.json"
-for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace -d "$out/$c" -o $c -- python bench.py --steps 2 --warmup 0 $lean > "$out/$c.log" 2>&1
+sets=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES")
+i=0
+for c in "${sets[@]}"; do
+  i=$((i+1))
+  timeout 900 rocprofv3 --pmc $c --kernel-trace -d "$out/pmc$i" -o p -- python bench.py --steps 1 --warmup 0 $lean > "$out/pmc$i.log" 2>&1
 done
+tdb=$(find "$out/trace" -name '*.db' | head -1)
+sum=gpurun_out/${tag}_rocprofv3_summary.txt
+{
+  echo "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --headline-only   (every kernel of the process: the untuned plan's"
+  echo "# windows, the tuning window, the spin-up of the tuned plan, then warm-up + 3 timed windows of the headline)"
+  python tools/rocpd_summary.py "$tdb" | cut -c1-170
+  echo
+  echo "# the last window of that trace (a timed headline window)"
+  python tools/window_timeline.py "$tdb"
+} > "$sum"
 dbs=""
-for d in trace FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+for d in pmc1 pmc2 pmc3; do
   db=$(find "$out/$d" -name '*.db' | head -1)
   [ -n "$db" ] && dbs="$dbs $db"
 done
-python tools/rocpd_summary.py $dbs --json > "$out/all.txt"
-grep -v '^\[{' "$out/all.txt" > "$sum"
-grep '^\[{' "$out/all.txt" > "$out/summary.json"
-python tools/make_pmc_json.py "$out/summary.json" "$engine" "$rnd" > "gpurun_out/${tag}_pmc_traffic.json"
+python tools/pmc_last_window.py $dbs --json > "gpurun_out/${tag}_pmc_last_window.json"
 find "$out" -name '*.db' -delete
-cut -c1-150 "$sum" | head -60
-cat "gpurun_out/${tag}_pmc_traffic.json"
+cat "$sum" | head -40
+cat "gpurun_out/${tag}_pmc_last_window.json" | head -60
