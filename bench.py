@@ -370,9 +370,13 @@ def main():
     qlat_b = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2, previous=qlat_a)
     q0 = np.zeros((nseg, 3), dtype=np.float32)
 
+    tuned = {"speed": None, "part": None}
+
     def make_router(hint, short_ts, qlat, state):
-        # with a hint (the measured cost of every row on the tuning day) the partition is packed by cost as well
-        part = sharding.partition(to, world, row_cost=hint) if (hint is not None and world > 1) else None
+        # with a hint (the measured cost of every row on the tuning day) the partition is packed by cost as well, and by the
+        # pace every rank was MEASURED to keep on that day (what a trunk does to its owner is in there; sharding.partition)
+        part = (sharding.partition(to, world, row_cost=hint, rank_speed=tuned["speed"], previous=tuned["part"])
+                if (hint is not None and world > 1) else None)
         r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint,
                           assume_short_ts=short_ts, partition=part)
         r.upload(a.nsteps, qlat, state)
@@ -471,6 +475,11 @@ def main():
     hint = None if a.no_retune else router.iteration_hint()
     if hint is not None and comm is not None:   # every rank measured its own rows: all of them need the whole vector
         hint = comm.all_reduce_max_host(hint)
+    if hint is not None and comm is not None:
+        # every rank's pace on the tuning window: the cost its rows were measured to carry over the device time it took
+        cost_mine = float(hint[np.concatenate([router.rows0, router.rows1])].astype(np.float64).sum())
+        lt = comm.all_gather_host(np.array([cost_mine, router.last_stats["phase0"]["ms_main"]], dtype=np.float64))
+        tuned["speed"], tuned["part"] = sharding.rank_speeds(lt[:, 0], lt[:, 1]), router.part
     router.collect_cost(False)
     t_tune = time.perf_counter() - t0
     router.upload(a.nsteps, qlat_b, None)              # day N+1, warm
@@ -496,6 +505,12 @@ def main():
         hyd = np.zeros((0, a.nsteps), np.float32)
     assert np.isfinite(hyd).all()
     if a.headline_only:            # (a counter pass of pmc_counters(): the last windows of the process are the headline's)
+        if rank == 0:
+            json_out.write(json.dumps({"metric": "segment-timesteps/sec, CONUS NHD 2.7M-seg MC", "value": rate(head),
+                                       "unit": "segment-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                                       "ms_per_step": head["el"] / a.steps * 1e3, "ms_main": head["ms_main"],
+                                       "headline_only": True}) + "\n")
+            json_out.flush()
         router.close()
         if comm is not None:
             comm.close()
@@ -635,6 +650,7 @@ def main():
                 "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
                 "transport": None if comm is None else comm.backend,
+                "rank_pace_on_tuning_day": None if tuned["speed"] is None else [round(float(x), 3) for x in tuned["speed"]],
                 "engine": engine,
                 "generate_s": round(t_gen, 2), "plan_s": round(t_plan, 2),
                 "plan_order": "rows grouped by their secant-iteration cost over day N (untimed tuning window); timed on day N+1"

@@ -11,8 +11,6 @@ nhd_network.py:691-771; hand-off compute.py:882-897): sub-basins run first
 (phase 0), their outlet hydrographs become prescribed boundary rows of the
 trunk (phase 1).  No collective is needed inside a phase.
 """
-import os
-
 import numpy as np
 
 
@@ -52,39 +50,45 @@ def subtree_sizes(to):
     return size
 
 
-def lpt_assign(sizes, nparts, initial_load=None):
-    """Longest-processing-time bin packing: part index per item (`initial_load`: what the bins hold already)."""
+def lpt_assign(sizes, nparts, initial_load=None, speed=None):
+    """Longest-processing-time bin packing: part index per item (`initial_load`: what the bins hold already; `speed`: relative
+    pace of every bin -- an item goes where it would be FINISHED first, (load + size) / speed)."""
     sizes = np.asarray(sizes, dtype=np.int64)
     part = np.zeros(sizes.shape[0], dtype=np.int32)
     load = np.zeros(nparts, dtype=np.int64) if initial_load is None else np.asarray(initial_load, dtype=np.int64).copy()
+    inv = None if speed is None else 1.0 / np.maximum(np.asarray(speed, dtype=np.float64), 1e-9)
     for i in np.argsort(-sizes, kind="stable").tolist():
-        p = int(np.argmin(load))
+        p = int(np.argmin(load)) if inv is None else int(np.argmin((load + sizes[i]) * inv))
         part[i] = p
         load[p] += sizes[i]
     return part, load
 
 
-def _trunk_share(nseg, nparts):
-    """Fraction of a rank's share a trunk's owner is spared beyond the trunk itself, fitted on the ranks of 8-, 4- and 2-way
-    CONUS partitions timed one by one (tools/sim_ranks.py).  Ranks on the dataflow engine (under a million rows each) route a
-    window in four time chunks and the owner's skewed trunk drains for two of them: 0.3 where a rank's blocks are all
-    resident (under 400 k rows, N = 8: with 0.18 the owner was the slowest rank by 10 %), 0.2 where they run in rounds
-    (N = 4: with 0.3 the owner finished 0.6 ms ahead of peers that carried its rows).  0.23 on the level engine, whose
-    owner also pays the draining launches of the skewed trunk at full width (N = 2)."""
-    env = os.environ.get("TRMC_TRUNK_SHARE")
-    if env:
-        return float(env)
-    per_rank = nseg / max(nparts, 1)
-    return 0.23 if per_rank >= 1.0e6 else (0.2 if per_rank >= 4.0e5 else 0.3)
+def rank_speeds(loads, times):
+    """Relative pace of every rank from a measured window: (cost it carried) / (time it took), mean 1.  What a trunk does to
+    its owner -- deep, tightly coupled rows, a skewed drain at the end of the window -- shows up here as a lower pace and
+    is handed back to partition(rank_speed=...) instead of being modelled."""
+    loads = np.asarray(loads, dtype=np.float64)
+    times = np.maximum(np.asarray(times, dtype=np.float64), 1e-9)
+    v = np.maximum(loads, 1.0) / times
+    return v / v.mean()
 
 
-def partition(to, nparts, max_piece_frac=None, row_cost=None):
+def partition(to, nparts, max_piece_frac=None, row_cost=None, rank_speed=None, previous=None):
     """Split rows into pieces for `nparts` workers.
 
     row_cost: optional [nseg] measured cost of every row (e.g. ``ShardedRouter.iteration_hint()`` of a tuning window:
     the secant iterations a row needs per step, over-bank steps weighted) -- the pieces are then packed by the cost they
     carry instead of by their row counts, and a trunk weighs what its rows were measured to cost.  Without it (the first
-    window of a network) rows count equally and a trunk is weighted by constants fitted on timings (below).
+    window of a network) rows count equally.
+    rank_speed: optional [nparts] relative pace of the ranks MEASURED on a window routed with an earlier partition of the
+    same network (``rank_speeds``: cost carried / time taken) -- pieces then go where they are finished first.  A trunk's
+    owner is slower than its share of the cost says (deep rows that wait for each other, the drain of the time-skew);
+    how much depends on the engine, the device and the network, so it is measured, not assumed: the first partition of a
+    network counts a trunk at its cost alone, the tuning window every long run starts with times the ranks, and the
+    partition the run continues with is packed by those times (bench.py does exactly that).
+    previous: the partition the speeds were measured with -- its trunks keep their owners (a pace belongs to a rank AS the
+    owner of its trunk), only sub-basins and small networks move.
 
     Returns dict:
       piece     int32 [nseg]  piece id of every row
@@ -93,7 +97,7 @@ def partition(to, nparts, max_piece_frac=None, row_cost=None):
       cut_rows  int64 [ncut]     rows (outlets of phase-0 sub-basins) whose hydrograph is handed
                                  to the trunk they drain into
       cut_into  int64 [ncut]     trunk row each cut row flows into
-      owner_bias int64 [nparts]  rows of sub-basin a worker is spared for the trunks it owns (see below)
+      owner_bias int64 [nparts]  what the trunks a worker owns weigh (rows, or cost units with row_cost)
     With nparts == 1 everything is one phase-0 piece per independent network (no cuts).
     """
     nseg = to.shape[0]
@@ -134,40 +138,35 @@ def partition(to, nparts, max_piece_frac=None, row_cost=None):
     sizes = np.bincount(piece, minlength=npieces)
     owner = np.zeros(npieces, dtype=np.int32)
     if row_cost is not None and nparts > 1:
-        # measured costs: a piece weighs the cost of its rows (in thousandths of the mean row, so that the integer
-        # packing below keeps its resolution).  What a trunk costs its owner is NOT the arithmetic of its rows alone: they
-        # are the deepest, most tightly coupled rows of the network (every step of theirs waits for the step before, with
-        # little else to fill the device), and the time-skewed trunk drains for two time chunks after the rank's other
-        # rows are done.  Timed rank by rank (tools/sim_ranks.py, 8-, 4- and 2-way CONUS partitions, both engines) the
-        # owner needs to be spared about five times the trunk's measured cost plus a fraction of a rank's share (_trunk_share) -- with the
-        # trunk weighed at its measured cost only, the owner was the slowest rank by 15-20 % at every N.
+        # measured costs: a piece weighs the cost of its rows (in thousandths of the mean row, so that the integer packing
+        # below keeps its resolution); trunks first, then the sub-basins and small networks on top of them
         c = np.maximum(np.asarray(row_cost, dtype=np.float64), 1.0)
         c = c * (1000.0 / c.mean())
         weight = np.bincount(piece, weights=c, minlength=npieces).astype(np.int64)
         bias = np.zeros(nparts, dtype=np.int64)
         p1 = np.flatnonzero(phase == 1)
         if p1.size:
-            owner[p1], trunk_load = lpt_assign(weight[p1], nparts)
-            bias = 5 * trunk_load + np.where(trunk_load > 0, int(_trunk_share(nseg, nparts) * weight.sum() / nparts), 0)
+            owner[p1], bias = lpt_assign(weight[p1], nparts)
+            if previous is not None:
+                owner[p1] = previous["owner"][p1]
+                bias = np.bincount(owner[p1], weights=weight[p1], minlength=nparts).astype(np.int64)
         p0 = np.flatnonzero(phase == 0)
-        owner[p0], _ = lpt_assign(weight[p0], nparts, bias)
+        owner[p0], _ = lpt_assign(weight[p0], nparts, bias, speed=rank_speed)
         return {
             "piece": piece.astype(np.int32), "phase": phase, "owner": owner,
             "cut_rows": cut_rows, "cut_into": to[cut_rows] if cut_rows.size else np.zeros(0, np.int64),
             "piece_sizes": sizes, "owner_bias": bias, "piece_cost": weight,
         }
-    # trunks first; their owners then take fewer sub-basin rows.  What a trunk costs its owner, in rows of sub-basin it
-    # should be spared (fitted on ranks of an 8-, 4- and 2-way CONUS partition timed one by one): its own rows,
-    # deep in the network and among the costly ones, five times over, plus the launches that drain the time-skewed trunk
-    # at the end of a window (2 of the default 24 chunks; a partly filled GPU gains less than proportionally from
-    # having fewer rows; the fraction of a rank's share is _trunk_share, refitted when the chunk counts changed).
+    # trunks first (counted at their rows); their owners then take that many fewer sub-basin rows
     bias = np.zeros(nparts, dtype=np.int64)
     p1 = np.flatnonzero(phase == 1)
     if p1.size:
-        owner[p1], trunk_load = lpt_assign(sizes[p1], nparts)
-        bias = 5 * trunk_load + np.where(trunk_load > 0, int(_trunk_share(nseg, nparts) * nseg / nparts), 0)
+        owner[p1], bias = lpt_assign(sizes[p1], nparts)
+        if previous is not None:
+            owner[p1] = previous["owner"][p1]
+            bias = np.bincount(owner[p1], weights=sizes[p1], minlength=nparts).astype(np.int64)
     p0 = np.flatnonzero(phase == 0)
-    owner[p0], load0 = lpt_assign(sizes[p0], nparts, bias)
+    owner[p0], load0 = lpt_assign(sizes[p0], nparts, bias, speed=rank_speed)
     return {
         "piece": piece.astype(np.int32), "phase": phase, "owner": owner,
         "cut_rows": cut_rows, "cut_into": to[cut_rows] if cut_rows.size else np.zeros(0, np.int64),

@@ -219,23 +219,37 @@ def test_import_pins_one_hardware_queue_per_stream_priority():
     assert out.returncode == 0 and out.stdout.strip() == "4", out.stderr
 
 
-def test_trunk_owner_share_follows_the_engine_of_the_ranks(monkeypatch):
-    """What a trunk's owner is spared beyond the trunk itself (sharding._trunk_share): 0.3 / 0.2 of a share where ranks hold
-    fewer than 400 k / a million rows (dataflow engine, TRMC_ENGINE_AUTO), 0.23 where they hold more (level engine);
-    TRMC_TRUNK_SHARE overrides; the bias a partition reports is built from it."""
-    monkeypatch.delenv("TRMC_TRUNK_SHARE", raising=False)
-    assert sharding._trunk_share(2_729_077, 8) == pytest.approx(0.3)
-    assert sharding._trunk_share(2_729_077, 4) == pytest.approx(0.2)
-    assert sharding._trunk_share(2_729_077, 2) == pytest.approx(0.23)
-    net = synthetic.generate(nseg=60000, nnet=300, seed=5)
+@pytest.mark.parametrize("seed,nseg,nnet,nparts", [(5, 60000, 300, 4), (23, 90000, 120, 8), (7, 40000, 500, 2)])
+def test_partition_by_measured_rank_pace(seed, nseg, nnet, nparts):
+    """sharding.partition(rank_speed=..., previous=...): what a trunk costs its owner is MEASURED -- the pace (cost carried /
+    time taken) every rank kept on a window routed with an earlier partition -- not assumed: pieces go where they are
+    finished first, so the predicted finish times (cost / pace) come out equal; trunks keep the owners the paces were
+    measured with.  Several networks and rank counts: nothing here is fitted to one of them."""
+    net = synthetic.generate(nseg=nseg, nnet=nnet, seed=seed)
     to = net["to"]
-    part = sharding.partition(to, 4)
-    owners = np.unique(part["owner"][part["phase"] == 1])
-    assert owners.size >= 1
-    trunk_rows = np.bincount(part["owner"][part["phase"] == 1], weights=part["piece_sizes"][part["phase"] == 1], minlength=4)
-    want = 5 * trunk_rows + np.where(trunk_rows > 0, int(0.3 * to.shape[0] / 4), 0)
-    assert np.array_equal(part["owner_bias"], want.astype(np.int64))
-    monkeypatch.setenv("TRMC_TRUNK_SHARE", "0.5")
-    assert sharding._trunk_share(10, 2) == 0.5
-    part2 = sharding.partition(to, 4)
-    assert (part2["owner_bias"][owners] > part["owner_bias"][owners]).all()
+    rng = np.random.default_rng(seed)
+    cost = rng.choice(np.array([16, 24, 40, 112], np.uint8), size=to.shape[0], p=[0.45, 0.35, 0.19, 0.01])
+    first = sharding.partition(to, nparts, row_cost=cost)
+    own = first["owner"][first["piece"]]
+    loads = np.bincount(own, weights=cost.astype(np.float64), minlength=nparts)
+    assert loads.max() / loads.mean() < 1.03                       # without paces: equal cost everywhere, trunks at their cost
+    owners = np.unique(first["owner"][first["phase"] == 1])
+    # a measured window in which the trunks' owners were 25 % slower than their cost says, another rank 10 % faster
+    pace = np.ones(nparts)
+    pace[owners] = 0.75
+    fast = np.setdiff1d(np.arange(nparts), owners)
+    if fast.size:
+        pace[fast[0]] = 1.10
+    times = loads / pace
+    speed = sharding.rank_speeds(loads, times)
+    assert speed.mean() == pytest.approx(1.0) and np.allclose(speed / speed[0], pace / pace[0])
+    second = sharding.partition(to, nparts, row_cost=cost, rank_speed=speed, previous=first)
+    assert np.array_equal(second["cut_rows"], first["cut_rows"]) and np.array_equal(second["piece"], first["piece"])
+    p1 = first["phase"] == 1
+    assert np.array_equal(second["owner"][p1], first["owner"][p1])                      # trunks stay where they were timed
+    own2 = second["owner"][second["piece"]]
+    loads2 = np.bincount(own2, weights=cost.astype(np.float64), minlength=nparts)
+    finish = loads2 / pace
+    assert finish.max() / finish.min() < 1.05, finish
+    if fast.size:
+        assert (loads2[owners] < loads[owners]).all()                                   # the slow ranks were relieved

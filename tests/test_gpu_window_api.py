@@ -201,3 +201,66 @@ def test_large_results_come_in_pooled_page_locked_arrays(monkeypatch):
     _lib.pinned_pool_clear()
     assert not _lib._pinned_free.get(keep.nbytes)
     r.close()
+
+
+def test_asynchronous_fetch_equals_the_synchronous_downloads():
+    """trmc_fetch_begin / trmc_fetch_wait (outlet hydrographs of a row set + final state, copied on a copy stream beside the
+    NEXT window) hand over exactly what gather_flow_rows / download_final_state return, window after window, and the
+    arrays a wait returned stay intact while the next windows run (a ring of three)."""
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=5000)
+    nsteps, qts = 48, 12
+    rows = np.array([0, 7, 4999, 2500, 31], np.int64)
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as plan:
+        rs = plan.rowset(rows)
+        plan.upload_forcing(nsteps, qlat, q0)
+        kept = []
+        for k in range(4):
+            plan.route_device(nsteps, qts, True)
+            want_h, want_s = plan.gather_flow_rows(rows), plan.download_final_state()
+            prev = plan.fetch_wait()                       # (nothing in flight the first time)
+            assert (prev[0] is None) == (k == 0)
+            plan.fetch_begin(rs, True)
+            kept.append((want_h.copy(), want_s.copy()))
+            plan.upload_forcing(nsteps, qlat * np.float32(1.0 + 0.1 * (k + 1)), None)   # next window: warm start, other forcing
+            if k > 0:
+                assert np.array_equal(prev[0].view(np.uint32), kept[k - 1][0].view(np.uint32))
+                assert np.array_equal(prev[1].view(np.uint32), kept[k - 1][1].view(np.uint32))
+        last = plan.fetch_wait()
+        assert np.array_equal(last[0].view(np.uint32), kept[-1][0].view(np.uint32))
+        assert np.array_equal(last[1].view(np.uint32), kept[-1][1].view(np.uint32))
+        with pytest.raises(RuntimeError, match="fetch is in flight"):
+            plan.fetch_begin(rs, True)
+            plan.fetch_begin(rs, True)
+        plan.fetch_wait()
+
+
+def test_rccl_communicator_single_rank_and_device_plumbing():
+    """The RCCL transport of the package's communicator (librccl.so by dlopen: ncclGetUniqueId / ncclCommInitRank /
+    ncclAllGather through include/trmc.h) at world size 1 -- what one GPU can run of it -- plus the device buffers, streams,
+    events and the indexed row gather of the hand-off."""
+    from troute_amd import comm as X
+    c = X.Comm(0, 1, device=0, backend="rccl", key=f"t{np.random.default_rng().integers(1 << 30)}")
+    assert c.backend == "rccl"
+    src = np.arange(6 * 40, dtype=np.float32).reshape(6, 40)
+    a = X.DeviceBuffer.from_array(0, src)
+    b = X.DeviceBuffer(0, src.nbytes)
+    st = X.stream_create(0)
+    ev = X.event_create(0)
+    c.all_gather(a.ptr, b.ptr, src.nbytes, st)
+    X.event_record(0, ev, st)
+    st2 = X.stream_create(0)
+    X.stream_wait_event(0, st2, ev)
+    idx = X.DeviceBuffer.from_array(0, np.array([5, 0, 3], np.int64))
+    d = X.DeviceBuffer(0, 3 * 40 * 4)
+    X.gather_rows(0, b.ptr, idx.ptr, 3, 40 * 4, d.ptr, st2)
+    got = d.download((3, 40), np.float32, st2)
+    assert np.array_equal(got, src[[5, 0, 3]])
+    assert np.array_equal(c.all_gather_host(np.array([1.5, 2.5]))[0], [1.5, 2.5])
+    assert c.all_reduce_max_host(np.array([3, 1], np.uint8)).tolist() == [3, 1]
+    c.barrier()
+    for x in (a, b, idx, d):
+        x.free()
+    X.event_destroy(0, ev)
+    X.stream_destroy(0, st)
+    X.stream_destroy(0, st2)
+    c.close()

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ranks", type=str, default=None, help="comma list (default: all)")
     ap.add_argument("--retune", action="store_true", help="rebuild every router with the cost hint of a tuning window")
+    ap.add_argument("--rebalance", action="store_true", help="time all ranks, repartition by their measured pace "
+                    "(sharding.partition rank_speed, what bench.py does after its tuning window), time them again")
     a = ap.parse_args()
     from troute_amd import comm as X
     from troute_amd import sharding, synthetic
@@ -67,90 +69,101 @@ def main():
     single.close()
     print(f"single GPU ({single_engine} engine): {t_single * 1e3:.2f} ms   cut rows {cut_rows.size}")
 
-    worst = 0.0
-    for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
-        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
-                          assume_short_ts=short, engine=eng)
-        default_chunks = 4 if getattr(r.plan0, "engine", "levels") == "flow" else 24     # route_on_device's defaults
-        nchunks_eff = (a.chunks if a.chunks else default_chunks) if short else (a.chunks if a.chunks else 1)
+    passes = [part]          # (the partition the cut-edge hydrographs above belong to keeps its cut rows: same trunks)
+    times_of = {}
+    for ipass in range(2 if a.rebalance else 1):
+      if ipass == 1:
+        cost = hint.astype(np.float64) if hint is not None else np.ones(nseg)
+        own = passes[0]["owner"][passes[0]["piece"]]
+        loads = np.bincount(own, weights=cost, minlength=a.world)
+        speed = sharding.rank_speeds(loads, [times_of[k] for k in range(a.world)])
+        print("measured pace of the ranks:", np.round(speed, 3))
+        part = sharding.partition(to, a.world, row_cost=hint, rank_speed=speed, previous=passes[0])
+      worst = 0.0
+      for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
+          r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
+                            assume_short_ts=short, engine=eng)
+          default_chunks = 4 if getattr(r.plan0, "engine", "levels") == "flow" else 24     # route_on_device's defaults
+          nchunks_eff = (a.chunks if a.chunks else default_chunks) if short else (a.chunks if a.chunks else 1)
 
-        class SimComm:
-            """the peers of this rank, played back: an all-gather of a time chunk of cut-edge hydrographs hands out what a
-            whole-network route says the other ranks would have sent (device-to-device copies on the caller's stream);
-            the outlet gather returns this rank's own block only"""
-            rank, world, backend = 0, a.world, "sim"
+          class SimComm:
+              """the peers of this rank, played back: an all-gather of a time chunk of cut-edge hydrographs hands out what a
+              whole-network route says the other ranks would have sent (device-to-device copies on the caller's stream);
+              the outlet gather returns this rank's own block only"""
+              rank, world, backend = 0, a.world, "sim"
 
-            def __init__(self, router):
-                self.r = router
-                self.call = 0
-                self.blocks = None
+              def __init__(self, router):
+                  self.r = router
+                  self.call = 0
+                  self.blocks = None
 
-            def prepare(self, K, C):
-                mc = max(self.r._max_cut, 1)
-                peers = np.zeros((a.world, mc, nsteps), np.float32)
-                if cut_rows.size:
-                    idx = np.zeros(cut_rows.size, dtype=np.int64)
-                    for k in range(a.world):
-                        m = self.r.cut_owner == k
-                        idx[m] = np.arange(int(m.sum()))
-                    peers[self.r.cut_owner.astype(np.int64), idx] = cut_q
-                self.blocks = [X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, c * K:min(nsteps, (c + 1) * K)]))
-                               for c in range(C)]
+              def prepare(self, K, C):
+                  mc = max(self.r._max_cut, 1)
+                  peers = np.zeros((a.world, mc, nsteps), np.float32)
+                  if cut_rows.size:
+                      idx = np.zeros(cut_rows.size, dtype=np.int64)
+                      for k in range(a.world):
+                          m = self.r.cut_owner == k
+                          idx[m] = np.arange(int(m.sum()))
+                      peers[self.r.cut_owner.astype(np.int64), idx] = cut_q
+                  self.blocks = [X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, c * K:min(nsteps, (c + 1) * K)]))
+                                 for c in range(C)]
 
-            def all_gather(self, send_ptr, recv_ptr, nbytes, stream=0):
-                c = self.call
-                self.call += 1
-                if self.r._max_cut > 0 and c < len(self.blocks):
-                    X.device_copy(dev, recv_ptr, self.blocks[c].ptr, self.blocks[c].nbytes, stream)
-                X.device_copy(dev, recv_ptr + rank * nbytes, send_ptr, nbytes, stream)
+              def all_gather(self, send_ptr, recv_ptr, nbytes, stream=0):
+                  c = self.call
+                  self.call += 1
+                  if self.r._max_cut > 0 and c < len(self.blocks):
+                      X.device_copy(dev, recv_ptr, self.blocks[c].ptr, self.blocks[c].nbytes, stream)
+                  X.device_copy(dev, recv_ptr + rank * nbytes, send_ptr, nbytes, stream)
 
-            def barrier(self):
-                pass
+              def barrier(self):
+                  pass
 
-        sim = SimComm(r)
-        r.enable_device_exchange(sim, dev)
-        r.upload(nsteps, qlat, q0)
-        r.upload_trunk()
-        if short:
-            K = max(1, -(-nsteps // max(1, int(nchunks_eff))))
-            sim.prepare(K, -(-nsteps // K))
-        else:
-            bounds = np.round(np.linspace(0, nsteps, nchunks_eff + 1)).astype(np.int64)
-            sim.blocks = []
-            mc = max(r._max_cut, 1)
-            peers = np.zeros((a.world, mc, nsteps), np.float32)
-            if cut_rows.size:
-                idx = np.zeros(cut_rows.size, dtype=np.int64)
-                for k in range(a.world):
-                    m = r.cut_owner == k
-                    idx[m] = np.arange(int(m.sum()))
-                peers[r.cut_owner.astype(np.int64), idx] = cut_q
-            sim.blocks = [X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, int(bounds[c]):int(bounds[c + 1])]))
-                          for c in range(nchunks_eff)]
-        acc = {}
-        times = []
-        for _ in range(a.reps + 1):
-            sim.call = 0
-            X.device_synchronize(dev)
-            t0 = time.perf_counter()
-            rows, hyd = r.route_on_device(qts, short, nchunks_eff)
-            X.device_synchronize(dev)
-            times.append(time.perf_counter() - t0)
-        t = min(times[1:])
-        worst = max(worst, t)
-        st = r.last_stats
-        # check my own outlets against the single-GPU run
-        mine = np.concatenate([r.my_out0_global, r.my_out1_global])
-        h = hyd.numpy()
-        sel = np.searchsorted(rows, mine)
-        ok = np.array_equal(h[sel].view(np.uint32), ref_hyd[np.searchsorted(ref_rows, mine)].view(np.uint32))
-        print(f"rank {rank} ({r.plan0.engine}): {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
-              + (f"  trunk {r.rows1.size} rows" + (f" main {st['phase1']['ms_main']:.2f} ms" if "phase1" in st else " (skewed)") if r.plan1 is not None else "")
-              + f"  outlets bit-identical: {ok}")
-        if acc:
-            print("   host ms (all reps):", {k: round(v * 1e3, 2) for k, v in acc.items()})
-        r.close()
-    print(f"max over ranks {worst * 1e3:.2f} ms -> speed-up vs single {t_single / worst:.2f}x at world {a.world}")
+          sim = SimComm(r)
+          r.enable_device_exchange(sim, dev)
+          r.upload(nsteps, qlat, q0)
+          r.upload_trunk()
+          if short:
+              K = max(1, -(-nsteps // max(1, int(nchunks_eff))))
+              sim.prepare(K, -(-nsteps // K))
+          else:
+              bounds = np.round(np.linspace(0, nsteps, nchunks_eff + 1)).astype(np.int64)
+              sim.blocks = []
+              mc = max(r._max_cut, 1)
+              peers = np.zeros((a.world, mc, nsteps), np.float32)
+              if cut_rows.size:
+                  idx = np.zeros(cut_rows.size, dtype=np.int64)
+                  for k in range(a.world):
+                      m = r.cut_owner == k
+                      idx[m] = np.arange(int(m.sum()))
+                  peers[r.cut_owner.astype(np.int64), idx] = cut_q
+              sim.blocks = [X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, int(bounds[c]):int(bounds[c + 1])]))
+                            for c in range(nchunks_eff)]
+          acc = {}
+          times = []
+          for _ in range(a.reps + 1):
+              sim.call = 0
+              X.device_synchronize(dev)
+              t0 = time.perf_counter()
+              rows, hyd = r.route_on_device(qts, short, nchunks_eff)
+              X.device_synchronize(dev)
+              times.append(time.perf_counter() - t0)
+          t = min(times[1:])
+          worst = max(worst, t)
+          times_of[rank] = t
+          st = r.last_stats
+          # check my own outlets against the single-GPU run
+          mine = np.concatenate([r.my_out0_global, r.my_out1_global])
+          h = hyd.numpy()
+          sel = np.searchsorted(rows, mine)
+          ok = np.array_equal(h[sel].view(np.uint32), ref_hyd[np.searchsorted(ref_rows, mine)].view(np.uint32))
+          print(f"rank {rank} ({r.plan0.engine}): {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
+                + (f"  trunk {r.rows1.size} rows" + (f" main {st['phase1']['ms_main']:.2f} ms" if "phase1" in st else " (skewed)") if r.plan1 is not None else "")
+                + f"  outlets bit-identical: {ok}")
+          if acc:
+              print("   host ms (all reps):", {k: round(v * 1e3, 2) for k, v in acc.items()})
+          r.close()
+      print(f"max over ranks {worst * 1e3:.2f} ms -> speed-up vs single {t_single / worst:.2f}x at world {a.world}")
 
 
 if __name__ == "__main__":
