@@ -228,6 +228,7 @@ def test_asynchronous_fetch_equals_the_synchronous_downloads():
         last = plan.fetch_wait()
         assert np.array_equal(last[0].view(np.uint32), kept[-1][0].view(np.uint32))
         assert np.array_equal(last[1].view(np.uint32), kept[-1][1].view(np.uint32))
+        plan.route_device(nsteps, qts, True)
         with pytest.raises(RuntimeError, match="fetch is in flight"):
             plan.fetch_begin(rs, True)
             plan.fetch_begin(rs, True)
