@@ -174,17 +174,27 @@ class Comm:
         key = key or default_key()
         lib = _lib.lib()
         ndev = _lib.device_count()
-        if backend == "auto":
+        auto = backend == "auto"
+        if auto:
             backend = "rccl" if (ndev >= world and world > 1) else "shm"
-        self.backend = backend
         h = C.c_void_p(0)
         if backend == "rccl":
             def make_id():
                 buf = (C.c_char * ID_BYTES)()
                 _check(lib.trmc_comm_unique_id(buf))
                 return bytes(buf)
-            blob = exchange_id(self.rank, key, make_id)
-            _check(lib.trmc_comm_init(self.rank, self.world, blob, self.device, C.byref(h)))
+            try:
+                blob = exchange_id(self.rank, key, make_id)
+                _check(lib.trmc_comm_init(self.rank, self.world, blob, self.device, C.byref(h)))
+            except Exception:
+                # RCCL missing or unable to start on this node: with "auto" every rank falls back to the shared-memory
+                # transport (the failure is the same on all of them); an explicit "rccl" is an error
+                if not auto:
+                    raise
+                backend, h = "shm", C.c_void_p(0)
+        self.backend = backend
+        if backend == "rccl":
+            pass
         elif backend == "shm":
             name = ("/trmc_" + "".join(ch if ch.isalnum() else "_" for ch in str(key)))[:120]
             _check(lib.trmc_comm_init_shm(self.rank, self.world, name.encode(), self.device, int(shm_bytes), C.byref(h)))

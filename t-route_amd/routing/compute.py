@@ -289,8 +289,6 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
 
     def empty(df):
         return df is None or getattr(df, "empty", True)
-    if refactored_diffusive_domain:
-        raise NotImplementedError("the refactored hydrofabric is not covered by the device solver")
     if da_parameter_dict and "diffusive_streamflow_nudging" in da_parameter_dict and not empty(usgs_df):
         # the reference forwards usgs_df to the solver in this case (compute.py:1799-1803); nudging inside the
         # diffusive solver is not covered here, and dropping it silently would change results
@@ -309,13 +307,22 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
         junction_inflows = pd.DataFrame(data=trib_flow, index=trib_segs)
         coastal = (coastal_boundary_depth_df.loc[tw].to_frame().T
                    if not empty(coastal_boundary_depth_df) and tw in coastal_boundary_depth_df.index else pd.DataFrame())
-        topo = topobathy.loc[dn["mainstem_segs"]] if not empty(topobathy) else pd.DataFrame()      # compute.py:1783-1796
+        if not empty(topobathy):                                                           # compute.py:1783-1796
+            topo = topobathy.loc[refactored_diffusive_domain[tw]["rlinks"] if refactored_diffusive_domain else dn["mainstem_segs"]]
+        else:
+            topo = pd.DataFrame()
+        # the network as refactored for the diffusive solver, by tailwater (compute.py:1805-1812)
+        if refactored_diffusive_domain:
+            rdomain = refactored_diffusive_domain[tw]
+            rreaches = refactored_reaches[rdomain["refac_tw"]]
+        else:
+            rdomain, rreaches = None, None
         dq = qlats.copy()
         dq.columns = range(dq.shape[1])                                       # compute.py:1822-1823
         inputs.append(diff_utils.diffusive_input_data_v02(
             tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
             dn["param_df"], dq, q0, junction_inflows, qts_subdivisions, t0, nts, dt, waterbodies_df, topo,
-            pd.DataFrame(), None, None, coastal, pd.DataFrame()))
+            pd.DataFrame(), rdomain, rreaches, coastal, pd.DataFrame()))
     outs = diffusive.compute_diffusive_batch(inputs, device=device)
     e = np.asarray([])
     results_diffusive = []

@@ -17,8 +17,13 @@ subset against the dictionary the reference itself produced (tests/golden/diffus
 Natural cross sections (``topobathy_bytw``, fp_naturalxsec_map :394-510) and the coastal depth boundary
 (``coastal_boundary_depth_df``, fp_coastal_boundary_input_map :575-657) are marshalled as the reference does.
 
-Not covered (NotImplementedError): the refactored hydrofabric (``refactored_diffusive_domain``) and gage data for
-diffusive nudging (the branch is switched off inside the reference solver).
+Refactored hydrofabric (``refactored_diffusive_domain`` / ``refactored_reaches``): forwarded as the reference forwards them
+(compute.py:1785-1812).  The reference's own v02 marshalling keeps EMPTY placeholders for the crosswalk arguments
+(:1033-1038) and its refactored branch then reads names that are never assigned (``rz_ar_g`` ... :1115-1142), so it
+cannot run; here the solver's crosswalk arguments (``rdx_ar_g``, ``crosswalk_g``, ``z_thalweg_g``: what ``trdw_diffnw``
+maps results back to the original links with, diffusive.f90:849-920) are taken from the domain dictionary when the caller
+supplies them under those names, and without them the call fails with a message that says so.
+Not covered (NotImplementedError): gage data for diffusive nudging (the branch is switched off inside the reference solver).
 """
 import math
 from functools import partial
@@ -164,9 +169,15 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
     """The solver's argument dictionary for the network draining to tailwater `tw` (reference :659-1155)."""
     def empty(df):
         return df is None or getattr(df, "empty", True)
+    crosswalk = None
     if refactored_diffusive_domain:
-        raise NotImplementedError("marshalling of a refactored hydrofabric: the reference keeps empty placeholders for the crosswalk "
-                                  "arguments itself (diffusive_utils_v02.py:1033-1038); the solver accepts them (trdw_diffnw, cwnrow_g > 0)")
+        need = ("rdx_ar_g", "crosswalk_g", "z_thalweg_g")
+        if not all(k in refactored_diffusive_domain for k in need):
+            raise NotImplementedError(
+                "refactored hydrofabric: the reference's own marshalling leaves the crosswalk arguments empty and its refactored "
+                "branch reads unassigned names (diffusive_utils_v02.py:1033-1038, :1115-1142); supply 'rdx_ar_g', 'crosswalk_g' "
+                "and 'z_thalweg_g' in refactored_diffusive_domain (the solver maps results back with them, trdw_diffnw cwnrow_g > 0)")
+        crosswalk = {k: np.asarray(refactored_diffusive_domain[k], dtype=np.float64) for k in need}
     if not empty(usgs_df):
         raise NotImplementedError("gage data for diffusive nudging: the branch is disabled in the reference solver itself")
 
@@ -234,7 +245,7 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
     x_bathy_g, z_bathy_g, mann_bathy_g, size_bathy_g, mxnbathy_g = fp_naturalxsec_map(
         ordered, mainstem_seg_list, topobathy_bytw, param_df, mx_jorder, mxncomp_g, nrch_g, dbfksegID)
     nts_da_g = int(tfin_g * 3600.0 / dt) + 1                        # fp_da_map, empty table (:537-539)
-    return {
+    ins = {
         "timestep_ar_g": timestep_ar_g, "nts_ql_g": nts_ql_g, "nts_ub_g": nts_ub_g, "nts_db_g": nts_db_g,
         "nts_qtrib_g": nts_qtrib_g, "ntss_ev_g": int(tfin_g * 3600.0 / dt) + 1, "nts_da_g": nts_da_g,
         "mxncomp_g": mxncomp_g, "nrch_g": nrch_g, "z_ar_g": z_ar_g, "bo_ar_g": bo_ar_g, "traps_ar_g": traps_ar_g,
@@ -247,6 +258,10 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
         "rdx_ar_g": np.array([]).reshape(0, 0), "cwnrow_g": 0, "cwncol_g": 0, "crosswalk_g": np.array([]).reshape(0, 0),
         "z_thalweg_g": np.array([]).reshape(0, 0),
     }
+    if crosswalk is not None:                                       # results mapped back to the original links by the solver
+        ins.update(crosswalk)
+        ins["cwnrow_g"], ins["cwncol_g"] = (int(x) for x in crosswalk["crosswalk_g"].shape)
+    return ins
 
 
 def unpack_output(pynw, ordered_reaches, out_q, out_elv):

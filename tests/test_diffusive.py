@@ -180,6 +180,17 @@ def test_input_marshalling_equals_reference_dictionary():
                                     dn["tributary_segments"], None, dn["param_df"], qlat_df, q0, junction_inflows, lc.qts,
                                     None, nsteps, lc.dt, pd.DataFrame(), pd.DataFrame(), pd.DataFrame(), {"links": [1]}, None,
                                     pd.DataFrame(), pd.DataFrame())
+    # a refactored domain that brings the solver's crosswalk arguments: forwarded into the dictionary (compute.py:1785-1812
+    # hands the domain over per tailwater; the reference's own marshalling leaves these arguments empty, :1033-1038)
+    cw = np.arange(3 * 18, dtype=np.float64).reshape(3, 18)
+    rdom = {"rlinks": dn["mainstem_segs"], "refac_tw": tw, "rdx_ar_g": np.ones((4, 2)), "crosswalk_g": cw,
+            "z_thalweg_g": np.zeros((4, 2))}
+    ins2 = DU.diffusive_input_data_v02(
+        tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
+        dn["param_df"], qlat_df, q0, junction_inflows, lc.qts, pd.Timestamp("2021-08-23 13:00"), nsteps, lc.dt,
+        pd.DataFrame(), pd.DataFrame(), pd.DataFrame(), rdom, dn["reaches"], pd.DataFrame(), pd.DataFrame())
+    assert ins2["cwnrow_g"] == 3 and ins2["cwncol_g"] == 18 and np.array_equal(ins2["crosswalk_g"], cw)
+    assert ins2["rdx_ar_g"].shape == (4, 2) and np.array_equal(ins2["z_ar_g"], ins["z_ar_g"])
 
 
 def natural_and_coastal_tables(z):
