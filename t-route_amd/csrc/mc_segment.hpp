@@ -35,8 +35,6 @@
 // m.fast_ok(h, h_in, h_over) -> ok; m.div2(a1, a2, b, ok, q1, q2): qi = ai / b; m.div1(a, b, ok) = a / b: the
 // divisions of the hydraulic point, for which a policy may use a cheaper exact sequence when `ok` (its own test of
 // the operand ranges) holds.
-// M::kPacked, M::V2 and m.v2 / m.v2s / m.vx / m.vy / m.div2v / m.div1v: optional two-element vectors whose arithmetic is one
-// packed instruction (hydraulics_inbank2).
 // M::kInbank: whether the policy wants the in-bank body of the hydraulic point at all (hydraulics_inbank: fewer instructions,
 // more code and registers -- the level kernels take it, the dataflow kernels, whose pace is one wavefront's latency, do not).
 // m.all(pred): true when `pred` holds for every row that is evaluated together with this one (a wavefront's active
@@ -248,44 +246,9 @@ MC_HD HydraulicPoint<T> hydraulics_inbank(T h, const ChannelParams<T> &p, const 
     return hp;
 }
 
-// The same body for TWO depths of one channel at once -- the bracket (h_0, h) a step starts from -- on a policy that has
-// two-element vectors (M::kPacked, M::V2): every float addition, multiplication and fused multiply-add of the two points
-// is then ONE packed instruction for both (gfx950: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, IEEE per element: the same
-// bits as the scalar operations), which is where half of the body's instructions are; reciprocals' seeds, the powers
-// (double precision) and the compare-selects stay per element.
-template <class T, class M>
-MC_HD void hydraulics_inbank2(T h_a, T h_b, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m,
-                              HydraulicPoint<T> &o_a, HydraulicPoint<T> &o_b)
-{
-    using V = typename M::V2;
-    const T c23 = T(2) / T(3), c53 = T(5) / T(3);
-    const V h = m.v2(h_a, h_b), bw = m.v2s(p.bw);
-    const V twl = bw + m.v2s(c.z2) * h;
-    const V area = (bw + h * m.v2s(c.z)) * h;
-    const V wp = bw + h * m.v2s(c.two_sq);
-    V R, n_comp;
-    m.div2v(area, wp * m.v2s(p.n), wp, R, n_comp);
-    const typename M::Log lr_a = m.log_of_r(m.vx(R), true), lr_b = m.log_of_r(m.vy(R), true);
-    const V r23 = m.v2(m.pow_l_r(lr_a, m.vx(R), c23, true), m.pow_l_r(lr_b, m.vy(R), c23, true));
-    const V r53 = m.v2(m.pow_l_r(lr_a, m.vx(R), c53, true), m.pow_l_r(lr_b, m.vy(R), c53, true));
-    const V ckv = m.v2s(c.s0_n) * (m.v2s(c53) * r23 - (m.v2s(c23) * r53 * m.div1v(m.v2s(c.two_sq), twl)));
-    o_a.ck = mc_max(T(0), m.vx(ckv));
-    o_b.ck = mc_max(T(0), m.vy(ckv));
-    {
-        const T kq_a = mc_max(p.dt, m.divx(p.dx, o_a.ck)), kq_b = mc_max(p.dt, m.divx(p.dx, o_b.ck));
-        o_a.km = (o_a.ck > T(0)) ? kq_a : p.dt;
-        o_b.km = (o_b.ck > T(0)) ? kq_b : p.dt;
-    }
-    const V dn = m.v2s(T(2)) * twl * m.v2s(p.s0) * m.v2(o_a.ck, o_b.ck) * m.v2s(p.dx);
-    o_a.denom = m.vx(dn);
-    o_b.denom = m.vy(dn);
-    const V qm = m.div1v(m.v2s(T(1)), n_comp) * area * r23 * m.v2s(c.sqrt_s0);
-    o_a.q_manning = m.vx(qm);
-    o_b.q_manning = m.vy(qm);
-    o_a.has_wp = o_b.has_wp = true;
-    o_a.over = o_b.over = false;
-}
-
+// (The same body for the bracket's TWO depths at once on two-element vectors -- v_pk_add / v_pk_mul / v_pk_fma_f32 for both
+// points -- was built and measured in round 3: 671 instead of 701 instructions per wavefront-step and slower, a packed
+// instruction issues for two passes; removed.)
 // one point: the in-bank body when every row evaluated together is in bank (one uniform branch), else the general one
 template <class T, class M>
 MC_HD HydraulicPoint<T> hydraulics_at(T h, const ChannelParams<T> &p, const ChannelConst<T> &c, const M &m)
@@ -379,12 +342,8 @@ MC_HD StepPre<T> step_pre(const ChannelParams<T> &p, const ChannelConst<T> &c, T
     step_bracket(depthp, s.h, s.h_0);
     // (0 <= h_0 <= h: the lower bound of the range is tested on h_0, the upper bound and the bank on h)
     if (M::kInbank && m.all(m.fast_ok(s.h, s.h_0, T(0)) && s.h <= c.bfd)) {
-        if constexpr (M::kPacked) {
-            hydraulics_inbank2<T, M>(s.h_0, s.h, p, c, m, s.at_h0, s.at_h);
-        } else {
-            s.at_h0 = hydraulics_inbank<T, M>(s.h_0, p, c, m);
-            s.at_h = hydraulics_inbank<T, M>(s.h, p, c, m);
-        }
+        s.at_h0 = hydraulics_inbank<T, M>(s.h_0, p, c, m);
+        s.at_h = hydraulics_inbank<T, M>(s.h, p, c, m);
     } else {
         s.at_h0 = hydraulics_general<T, M>(s.h_0, p, c, m);
         s.at_h = hydraulics_general<T, M>(s.h, p, c, m);

@@ -115,37 +115,7 @@ struct DevMathF {
     __device__ __forceinline__ float sqrt(float x) const { return ::sqrtf(x); }
     // wave-wide AND over the active lanes: a scalar, so the branch on it is a uniform one
     __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
-    // two floats whose + - * fma are one packed instruction (v_pk_*_f32: IEEE per element, the same bits as the scalar forms)
-#ifndef TRMC_PACKED_PAIR
-#define TRMC_PACKED_PAIR 0 // measured: 671 instead of 701 instructions per wavefront-step and SLOWER (a packed instruction issues for two passes)
-#endif
-    static constexpr bool kPacked = TRMC_PACKED_PAIR != 0;
     static constexpr bool kInbank = true;
-    typedef float V2 __attribute__((ext_vector_type(2)));
-    __device__ __forceinline__ static V2 v2(float a, float b) { return V2{a, b}; }
-    __device__ __forceinline__ static V2 v2s(float a) { return V2{a, a}; }
-    __device__ __forceinline__ static float vx(V2 v) { return v.x; }
-    __device__ __forceinline__ static float vy(V2 v) { return v.y; }
-    __device__ __forceinline__ static V2 vfma(V2 a, V2 b, V2 c) { return __builtin_elementwise_fma(a, b, c); }
-    __device__ __forceinline__ static V2 refined_rcp_v(V2 b)
-    {
-        const V2 y0 = V2{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
-        return vfma(vfma(-b, y0, v2s(1.0f)), y0, y0);
-    }
-    __device__ __forceinline__ static V2 quot_v(V2 a, V2 b, V2 y1)
-    {
-        const V2 q0 = a * y1;
-        const V2 q1 = vfma(vfma(-b, q0, a), y1, q0);
-        return vfma(vfma(-b, q1, a), y1, q1);
-    }
-    // (the packed forms of div2 / div1 under `ok`: the same refined-reciprocal sequences, see below)
-    __device__ __forceinline__ void div2v(V2 a1, V2 a2, V2 b, V2 &q1, V2 &q2) const
-    {
-        const V2 y1 = refined_rcp_v(b);
-        q1 = quot_v(a1, b, y1);
-        q2 = quot_v(a2, b, y1);
-    }
-    __device__ __forceinline__ V2 div1v(V2 a, V2 b) const { return quot_v(a, b, refined_rcp_v(b)); }
 
     // The four Muskingum coefficients C1..C4 = n_i / D (f90:303-312) with ONE reciprocal.
     // hipcc expands an fp32 division into  v_div_scale x2, v_rcp, the refinement
@@ -276,7 +246,6 @@ struct DevMathD {
     __device__ __forceinline__ double pow_l_r(Log, double x, double y, bool) const { return det_pow64(x, y); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
-    static constexpr bool kPacked = false;
     static constexpr bool kInbank = false;
     bool coef_ok; // unused
     bool sane;    // unused
