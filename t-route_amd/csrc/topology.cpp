@@ -248,6 +248,8 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             for (int64_t w = 0; w < nw; ++w)
                 for (int64_t p = t.nboundary + w * 64; p < std::min<int64_t>(nseg, t.nboundary + (w + 1) * 64); ++p)
                     wcost[(size_t)w] = std::max(wcost[(size_t)w], cost_of(t.row_of_pos[p]));
+            t.cost_of_wave.resize((size_t)nw);
+            for (int64_t w = 0; w < nw; ++w) t.cost_of_wave[(size_t)w] = (uint8_t)std::min<int64_t>(255, wcost[(size_t)w]);
             const char *pm = std::getenv("TRMC_FLOW_PRIO_MODE"); // developer A/B: "linear", "block"; default by wavefront
             const std::string mode = pm ? pm : "wave";
             if (mode == "linear") {

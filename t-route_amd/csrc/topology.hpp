@@ -36,6 +36,7 @@ struct Topology {
     int32_t nblocks = 0;                 // blocks of block_rows consecutive routed positions, from position nboundary
     std::vector<int32_t> rank_of_pos;    // [nseg] dependency depth of a position inside its block (topology.cpp)
     int32_t maxrank = 0;
+    std::vector<uint8_t> cost_of_wave;   // [ceil(routed / 64)] the costliest row's hint (or drainage class) of every wavefront of the block order
     std::vector<uint8_t> prio_of_wave;   // [ceil(routed / 64)] issue priority 0..3 of every wavefront of the block order: by the
                                          // costliest row it holds (cost hint, else drainage size); costlier = higher
 };

@@ -230,8 +230,11 @@ struct DevMathF {
 // The same arithmetic for the dataflow kernels, without the in-bank body: there a wavefront steps through time by itself
 // and what counts is the latency of ITS step -- registers and code size -- not the instruction count of a full device
 // (measured: a lone 4 096-row chain 6.6 us per step against 7.3 with the in-bank body, the general-mode CONUS day the same).
+#ifndef TRMC_FLOW_INBANK
+#define TRMC_FLOW_INBANK 0
+#endif
 struct DevMathFlow : DevMathF {
-    static constexpr bool kInbank = false;
+    static constexpr bool kInbank = TRMC_FLOW_INBANK != 0;
 };
 // fp64: the bit-reproducible double power of det_pow64.h (glibc 2.35 pow restated, the one the reference links when it
 // is built with -fdefault-real-8: oracle/_ref/libmc_ref_qj0_f64.so), so that the fp64 path -- BASELINE configs[1] -- is
@@ -297,6 +300,20 @@ template <class T> __device__ __forceinline__ const T &at(const T *base, uint32_
 }
 
 // ---------------------------------------------------------------- kernels
+// COLD kernel arguments.  hipcc reads the arguments a kernel uses into SGPRs at entry, in tuples of up to sixteen, and when
+// the arithmetic of a step needs those registers (the power's double constants alone take forty) it parks the tuples in
+// VGPR lanes and reads them back WHOLE -- eight v_readlane for one pointer -- wherever a member is used: the lean kernel
+// executed some 120 of them per step (the tables of the rare branches, the watchdog of every poll loop, what the epilogue
+// stores).  What the time loop needs only in rare branches or after its end is therefore read where it is used, through an
+// opaque pointer to the kernel-argument segment: one scalar load from the constant cache, no register held across the loop.
+// (The argument struct is the kernel's first parameter: offset 0 of the segment.)
+template <class A> using ColdArgs = const __attribute__((address_space(4))) A *;
+template <class A> __device__ __forceinline__ ColdArgs<A> cold_args()
+{
+    ColdArgs<A> p = (ColdArgs<A>)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
 template <class T> struct StepArgs {
     const T *dx, *bw, *twcc, *n, *ncc, *s0;            // raw channel parameters the step still reads
     const T *z, *bfd, *sqrt_s0, *sq1pz2, *s0_n, *s0_ncc, *inv_n; // segment-invariant constants formed at plan time (k_make_const)
@@ -517,15 +534,18 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 // of every step (what downstream rows and the gathers read) and the depth row of a tile's last step (where the row's next
 // tile, or the final state, picks it up) are written.
 constexpr int kTileStage = 8;
-#ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow (4: at most 128 registers; left to itself the
-// compiler takes 129 and the kernel drops to three)
-#define TRMC_TILE_WAVES 4
+#ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow.  Measured on the CONUS day by
+// padding the blocks' LDS (TRMC_TILE_LDS_PAD) and by this cap: 1 wavefront per SIMD 36.7 ms, 2: 23.9, 3: 20.7, 3.5: 19.5,
+// 4: 18.45, 5 (95 registers, 4 spilled): 17.9, 6 (80 registers, 27 spilled): 19.4 -- the curve of a kernel that hides its
+// latencies with other wavefronts and is close to its issue limit at four
+#define TRMC_TILE_WAVES 5
 #endif
 template <class T>
 __global__ void __launch_bounds__(kStepBlock, sizeof(T) == 4 ? TRMC_TILE_WAVES : 1)
 k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t tile, const int32_t K)
 {
     using M = typename DevMath<T>::type;
+    const ColdArgs<StepArgs<T>> cold = cold_args<StepArgs<T>>(); // (see cold_args: what the loop rarely needs is not kept in registers)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ T s_out[3 * kTileStage * kStepBlock]; // [step slot * 3 + c][thread]
     M m{stage_pow_tables(s_tab), false};
@@ -573,34 +593,37 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     m.coef_ok = coef_guard(p.dt, ql); // (depends on the forcing column only: formed when that changes, not every step)
     const bool count_cost = a.it_sum != nullptr;
     int32_t it_acc = 0, it_last = 0, staged = 0;
-    for (int32_t t = t_lo; t <= t_hi; ++t) {
+    // flows of the step before (complete: earlier launches); advanced a row per step -- t differs from lane to lane (the
+    // level skew), and (size_t)t * np in vector registers is a 64-bit multiplication per step
+    T *q_up = a.q_tm + (size_t)(t_lo - 1) * np;
+    for (int32_t t = t_lo; t <= t_hi; ++t, q_up += np) {
         if (ql_left == 0) {
             ++ql_col;
-            ql = at(a.qlat_tm + (size_t)ql_col * np, ob);
+            ql = at(cold->qlat_tm + (size_t)ql_col * np, ob);
             m.coef_ok = coef_guard(p.dt, ql);
-            ql_left = a.qts;
+            ql_left = cold->qts;
         }
         --ql_left;
-        const T *const q_up = a.q_tm + (size_t)(t - 1) * np; // upstream flows of the step before (complete: earlier launches)
         // junction sum in the reference's order (mc_reach.pyx:499-502); see k_mc_step for the table of the first two
         T qup = T(0);
         if (u.x >= 0) qup += at(q_up, (uint32_t)u.x * (uint32_t)sizeof(T));
         if (u.y >= 0) {
             qup += at(q_up, (uint32_t)(u.y & 0x3fffffff) * (uint32_t)sizeof(T));
             if (u.y & 0x40000000) {
-                const int32_t k1 = a.up_ptr[su + 1];
-                for (int32_t k = a.up_ptr[su] + 2; k < k1; ++k) qup += at(q_up, (uint32_t)a.up_idx[k] * (uint32_t)sizeof(T));
+                const int32_t *const up_ptr = cold->up_ptr, *const up_idx = cold->up_idx;
+                const int32_t k1 = up_ptr[su + 1];
+                for (int32_t k = up_ptr[su] + 2; k < k1; ++k) qup += at(q_up, (uint32_t)up_idx[k] * (uint32_t)sizeof(T));
             }
         }
         T q_new, v_new, d_new;
         if (ri >= 0) { // level-pool reservoir row (see k_mc_step)
-            const T *rp = a.res_par + (size_t)ri * 9;
+            const T *rp = cold->res_par + (size_t)ri * 9;
             const trmc::LevelPoolParams<T> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
             T H = d_prev;
-            q_new = trmc::levelpool_step<T, M>(qup, T(0), a.res_dt, H, lp, m);
+            q_new = trmc::levelpool_step<T, M>(qup, T(0), cold->res_dt, H, lp, m);
             v_new = T(0);
             d_new = H;
-            a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = qup;
+            cold->res_inflow[(size_t)ri * (size_t)cold->nsteps + (size_t)(t - 1)] = qup;
             it_last = 0;
         } else {
             trmc::Inflow<T> f;
@@ -615,23 +638,23 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             it_last = r.iters;
             if (count_cost) it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
             if (gi >= 0) { // streamflow nudging (see k_mc_step)
-                const size_t e = (size_t)gi * (size_t)a.nsteps + (size_t)(t - 1);
-                const uint8_t mode = a.da_mode[e];
+                const size_t e = (size_t)gi * (size_t)cold->nsteps + (size_t)(t - 1);
+                const T *const da_a = cold->da_a;
+                const uint8_t mode = cold->da_mode[e];
                 T nudge = T(0);
                 if (mode == 1) {
-                    nudge = a.da_a[e] - q_new;
-                    q_new = a.da_a[e];
+                    nudge = da_a[e] - q_new;
+                    q_new = da_a[e];
                 } else if (mode == 2) {
-                    nudge = (a.da_a[e] - q_new) * a.da_w[e];
+                    nudge = (da_a[e] - q_new) * cold->da_w[e];
                     q_new = q_new + nudge;
                 }
-                a.da_nudge[e] = nudge;
+                cold->da_nudge[e] = nudge;
             }
         }
-        const size_t row_c = (size_t)t * np;
         asm volatile("" : "+v"(ob));
-        at(a.q_tm + row_c, ob) = q_new;
-        if (t == t_hi) at(a.d_tm + row_c, ob) = d_new;
+        at(q_up + np, ob) = q_new;
+        if (t == t_hi) at(cold->d_tm + (size_t)t * np, ob) = d_new;
         q_prev = q_new;
         d_prev = d_new;
         {   // stage (q, v, d) of step t; a run ends when kTileStage steps are staged and at the tile's last step
@@ -659,8 +682,8 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             }
         }
     }
-    if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)min(it_last, 255);
-    if (count_cost) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + it_acc);
+    if (t_hi == cold->nsteps) cold->it_prev[su] = (uint8_t)min(it_last, 255);
+    if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535, (int)it_sum[su] + it_acc);
 }
 
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
@@ -1000,10 +1023,25 @@ struct FlowArgs {
     int32_t *ticket;               // [0] block tickets of this launch, [1] abort flag of the window
     uint64_t watchdog_ticks;       // wall_clock64 ticks (100 MHz) a row may wait for one granule
     const uint8_t *prio;           // issue priority 0..3 of every wavefront of the block order (topology.cpp)
+    // blocks dealt to compute units by cost (lean kernels, see flow_place_blocks): queue q holds cuq_blk[cuq_ptr[q] ..
+    // cuq_ptr[q + 1]), cuq_head[q] counts what has been taken, cu_index maps hw_cu_key() to a queue; nullptr = block tickets
+    const int32_t *cuq_ptr, *cuq_blk, *cu_index;
+    const uint8_t *cuq_perm;       // [nblocks] row group of the block for SIMD s: bits 2s+1..2s
+    int32_t *cuq_head;
+    int32_t ncuq;
     unsigned long long *dbg;       // nullptr, or [nblocks][2]: wall clock at the start and the end of every block (TRMC_FLOW_DEBUG)
     int32_t nblocks_dbg;
 };
 
+using FlowCold = ColdArgs<FlowArgs>;
+
+// which compute unit a wavefront runs on: XCC_ID[3:0] | HW_ID {se_id[15:13], sh_id[12], cu_id[11:8]} -> 12 bits
+__device__ __forceinline__ uint32_t hw_cu_key()
+{
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+    return ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+}
 __device__ __forceinline__ unsigned long long gran_load(const unsigned long long *g)
 {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1014,30 +1052,30 @@ __device__ __forceinline__ unsigned long long gran_load(const unsigned long long
 #ifndef TRMC_FLOW_SLEEP
 #define TRMC_FLOW_SLEEP 16 // x 64 clocks between two polls of a granule that is not there yet
 #endif
-__device__ __forceinline__ bool flow_watchdog(uint32_t &polls, uint64_t &t_start, const FlowArgs &a)
+__device__ __forceinline__ bool flow_watchdog(uint32_t &polls, uint64_t &t_start, FlowCold a)
 {
     if ((++polls & 1023u) != 0u) return false;
     if (t_start == 0) {
         t_start = wall_clock64();
         return false;
     }
-    if (wall_clock64() - t_start > a.watchdog_ticks
-        || __hip_atomic_load(a.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        __hip_atomic_store(a.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wall_clock64() - t_start > a->watchdog_ticks
+        || __hip_atomic_load(a->ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(a->ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
     }
     return false;
 }
 // what the first row to give up was waiting for, for the host's error message: ticket[2..5] = {granule index in the
 // plane (low, high word), wanted tag, tag found}
-__device__ __forceinline__ void flow_report(const FlowArgs &a, const unsigned long long *g, uint32_t want, unsigned long long v)
+__device__ __forceinline__ void flow_report(FlowCold a, const unsigned long long *g, uint32_t want, unsigned long long v)
 {
-    if (atomicCAS(a.ticket + 6, 0, 1) == 0) {
-        const unsigned long long idx = (unsigned long long)(g - a.gran);
-        a.ticket[2] = (int32_t)(idx & 0xffffffffull);
-        a.ticket[3] = (int32_t)(idx >> 32);
-        a.ticket[4] = (int32_t)want;
-        a.ticket[5] = (int32_t)(v >> 32);
+    if (atomicCAS(a->ticket + 6, 0, 1) == 0) {
+        const unsigned long long idx = (unsigned long long)(g - a->gran);
+        a->ticket[2] = (int32_t)(idx & 0xffffffffull);
+        a->ticket[3] = (int32_t)(idx >> 32);
+        a->ticket[4] = (int32_t)want;
+        a->ticket[5] = (int32_t)(v >> 32);
     }
 }
 #ifdef TRMC_FLOW_DEBUG_WAITS // developer build: polls of the granule plane / of the LDS ring, per thread
@@ -1046,7 +1084,7 @@ __device__ uint32_t g_dbg_polls_plane, g_dbg_polls_ring;
 static __device__ __forceinline__ uint32_t &dbg_plane() { __shared__ uint32_t c[1024]; return c[threadIdx.x]; }
 static __device__ __forceinline__ uint32_t &dbg_ring() { __shared__ uint32_t c[1024]; return c[threadIdx.x]; }
 #endif
-__device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t want, const FlowArgs &a, bool &dead)
+__device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t want, FlowCold a, bool &dead)
 {
     unsigned long long v = gran_load(g);
 #ifdef TRMC_FLOW_EXP_NOWAIT // timing experiment: no dependence between rows (wrong results)
@@ -1087,7 +1125,7 @@ struct FlowEdge {
 constexpr int kFlowRing = TRMC_FLOW_RING;  // steps the LDS ring of a block holds (a power of two)
 
 __device__ __forceinline__ float flow_edge_get(FlowEdge &e, const unsigned long long *plane_row, unsigned long long *ring,
-                                               int32_t ws, uint32_t want, const FlowArgs &a, bool &dead)
+                                               int32_t ws, uint32_t want, FlowCold a, bool &dead)
 {
     unsigned long long v = e.pre;
     if (!(e.ahead && e.pre_ok && (uint32_t)(v >> 32) == want)) {
@@ -1125,6 +1163,7 @@ __global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES) TRMC_FLOW_ATTR
 k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the launches / steps (t0, t1] of the window
 {
     using M = DevMathFlow;
+    const FlowCold cold = cold_args<FlowArgs>(); // (see cold_args: what the loop rarely needs is not kept in registers)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ float s_out[3 * kFlowStage * kFlowBlock];             // [step slot * 3 + c][thread]
     __shared__ unsigned long long s_ring[kFlowRing * kFlowBlock];    // [step % kFlowRing][thread] granules
@@ -1141,7 +1180,7 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
     const uint32_t su = valid ? (uint32_t)pos : (uint32_t)a.first;
     const uint32_t ob = su * 4u;
     const int32_t lag = a.lag ? a.lag[su] : 0;
-    if (a.dbg && threadIdx.x == 0) a.dbg[2 * s_blk] = wall_clock64();
+    if (cold->dbg && threadIdx.x == 0) cold->dbg[2 * s_blk] = ((unsigned long long)hw_cu_key() << 48) | (wall_clock64() & 0xffffffffffffull);
     // the steps [t_lo, t_hi] this row covers in this launch, and the round it starts in
     const int32_t t_lo = SHORT ? max(t0 - lag, 0) + 1 : t0 + 1;
     const int32_t t_hi = valid ? (SHORT ? min(t1 - lag, a.nsteps) : min(t1, a.nsteps)) : 0;
@@ -1214,25 +1253,26 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
         const unsigned long long *g_prev = a.gran + (size_t)(t - 1) * np;
         unsigned long long *g_curr = a.gran + (size_t)t * np;
         if (!have_state) { // the state this row was left in: its own granule of step t - 1, its depth column
-            q_prev = flow_wait(g_prev + su, tag_p, a, dead);
-            d_prev = a.d_state[su];
+            q_prev = flow_wait(g_prev + su, tag_p, cold, dead);
+            d_prev = cold->d_state[su];
             __hip_atomic_store(s_ring + (size_t)((t - 1) & (kFlowRing - 1)) * kFlowBlock + threadIdx.x,
                                ((unsigned long long)tag_p << 32) | (unsigned long long)__float_as_uint(q_prev),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!SHORT) { // the general mode also needs its upstream rows at the step before its first one
-                if (e0.u >= 0) xp0 = flow_wait(g_prev + e0.u, tag_p, a, dead);
-                if (e1.u >= 0) xp1 = flow_wait(g_prev + e1.u, tag_p, a, dead);
+                if (e0.u >= 0) xp0 = flow_wait(g_prev + e0.u, tag_p, cold, dead);
+                if (e1.u >= 0) xp1 = flow_wait(g_prev + e1.u, tag_p, cold, dead);
             }
             // the lateral-inflow column of step t is (t - 1) / qts: found by division once, by a counter from then on
-            ql_col = (t - 1) / a.qts;
-            ql_left = a.qts - (t - 1) % a.qts;
-            ql = a.qlat_tm[(size_t)ql_col * np + su];
+            const int32_t qts = cold->qts;
+            ql_col = (t - 1) / qts;
+            ql_left = qts - (t - 1) % qts;
+            ql = cold->qlat_tm[(size_t)ql_col * np + su];
             have_state = true;
         }
         if (ql_left == 0) {
             ++ql_col;
-            ql = a.qlat_tm[(size_t)ql_col * np + su];
-            ql_left = a.qts;
+            ql = cold->qlat_tm[(size_t)ql_col * np + su];
+            ql_left = cold->qts;
         }
         --ql_left;
         // (Evaluating the part of the step that needs the row's OWN state only -- step_pre: the bracket and its two hydraulic
@@ -1249,8 +1289,8 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
         const uint32_t want = SHORT ? tag_p : tag_p + 1u;
         const unsigned long long *g_want = SHORT ? g_prev : g_curr;
         float x0 = 0.0f, x1 = 0.0f;
-        if (e0.u >= 0) x0 = flow_edge_get(e0, g_want, s_ring, ws, want, a, dead);
-        if (e1.u >= 0) x1 = flow_edge_get(e1, g_want, s_ring, ws, want, a, dead);
+        if (e0.u >= 0) x0 = flow_edge_get(e0, g_want, s_ring, ws, want, cold, dead);
+        if (e1.u >= 0) x1 = flow_edge_get(e1, g_want, s_ring, ws, want, cold, dead);
         // edges read through the granule plane: next step's granule starts its way here now
         if (t < t_hi) {
             if (e0.u >= 0 && e0.ahead) e0.pre = gran_load(g_want + np + e0.u);
@@ -1267,11 +1307,12 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
             quc += x1;
         }
         if (more) { // fan-in above two (0.2 % of junctions): straight from the granule plane
-            const int32_t k1 = a.up_ptr[su + 1];
-            for (int32_t e = a.up_ptr[su] + 2; e < k1; ++e) {
-                const int32_t ue = a.up_idx[e];
-                qup += flow_wait(g_prev + ue, tag_p, a, dead);
-                if (!SHORT) quc += flow_wait(g_curr + ue, tag_p + 1u, a, dead);
+            const int32_t *const up_ptr = cold->up_ptr, *const up_idx = cold->up_idx;
+            const int32_t k1 = up_ptr[su + 1];
+            for (int32_t e = up_ptr[su] + 2; e < k1; ++e) {
+                const int32_t ue = up_idx[e];
+                qup += flow_wait(g_prev + ue, tag_p, cold, dead);
+                if (!SHORT) quc += flow_wait(g_curr + ue, tag_p + 1u, cold, dead);
             }
         }
         xp0 = x0;
@@ -1285,12 +1326,12 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
         float q_new, v_new = 0.0f, d_new;
         bool routed = false;
         if (ri >= 0) { // level-pool reservoir row, mc_reach.pyx:507-510,:551-553,:706-710 (see k_mc_step)
-            const float *rp = a.res_par + (size_t)ri * 9;
+            const float *rp = cold->res_par + (size_t)ri * 9;
             const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
             float H = d_prev;
-            q_new = trmc::levelpool_step<float, M>(f.quc, 0.0f, a.res_dt, H, lp, m);
+            q_new = trmc::levelpool_step<float, M>(f.quc, 0.0f, cold->res_dt, H, lp, m);
             d_new = H;
-            a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
+            cold->res_inflow[(size_t)ri * (size_t)cold->nsteps + (size_t)(t - 1)] = f.quc;
             it_last = 0;
         } else {
             q_new = 0.0f;
@@ -1306,17 +1347,18 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
                 it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
             }
             if (gi >= 0) { // streamflow nudging, mc_reach.pyx:761-796 / simple_da.pyx:47-76 (see k_mc_step)
-                const size_t e = (size_t)gi * (size_t)a.nsteps + (size_t)(t - 1);
-                const uint8_t mode = a.da_mode[e];
+                const size_t e = (size_t)gi * (size_t)cold->nsteps + (size_t)(t - 1);
+                const float *const da_a = cold->da_a;
+                const uint8_t mode = cold->da_mode[e];
                 float nudge = 0.0f;
                 if (mode == 1) {
-                    nudge = a.da_a[e] - q_new;
-                    q_new = a.da_a[e];
+                    nudge = da_a[e] - q_new;
+                    q_new = da_a[e];
                 } else if (mode == 2) {
-                    nudge = (a.da_a[e] - q_new) * a.da_w[e];
+                    nudge = (da_a[e] - q_new) * cold->da_w[e];
                     q_new = q_new + nudge;
                 }
-                a.da_nudge[e] = nudge;
+                cold->da_nudge[e] = nudge;
             }
         }
         // publish the flow as soon as it exists -- the block's ring, and one 8-byte agent-scope store into the plane; tag
@@ -1363,11 +1405,11 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
             }
         }
     }
-    if (a.dbg) atomicMax(a.dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
+    if (cold->dbg) atomicMax(cold->dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
     if (valid && have_state) {
-        a.d_state[su] = d_prev;
-        if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)it_last;
-        if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + it_acc);
+        cold->d_state[su] = d_prev;
+        if (t_hi == cold->nsteps) cold->it_prev[su] = (uint8_t)it_last;
+        if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535, (int)it_sum[su] + it_acc);
     }
 }
 
@@ -1382,12 +1424,15 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
 #ifndef TRMC_LEAN_WAVES
 #define TRMC_LEAN_WAVES 6
 #endif
+#ifndef TRMC_LEAN_RING_SLEEP // x 64 clocks between two polls of the block's LDS ring
+#define TRMC_LEAN_RING_SLEEP 2
+#endif
 constexpr int kLeanRing = 2;
 constexpr int kLeanCols = 13;
 
 __device__ __forceinline__ float lean_edge_get(int32_t u, int32_t l, uint32_t &flags, uint32_t ahead_bit, uint32_t never_bit,
                                                const unsigned long long *plane_row, const unsigned long long *ring, int32_t ws,
-                                               uint32_t want, const FlowArgs &a, bool &dead)
+                                               uint32_t want, FlowCold a, bool &dead)
 {
     if (!(flags & (ahead_bit | never_bit))) {
         const unsigned long long *slot = ring + (size_t)(ws & (kLeanRing - 1)) * kFlowBlock + l;
@@ -1399,7 +1444,7 @@ __device__ __forceinline__ float lean_edge_get(int32_t u, int32_t l, uint32_t &f
             uint32_t polls = 0;
             uint64_t t_start = 0;
             do {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(TRMC_LEAN_RING_SLEEP);
                 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef TRMC_FLOW_DEBUG_WAITS
                 ++dbg_ring();
@@ -1413,37 +1458,93 @@ __device__ __forceinline__ float lean_edge_get(int32_t u, int32_t l, uint32_t &f
     return flow_wait(plane_row + u, want, a, dead);
 }
 
+// Which block a workgroup of a lean launch routes.  Every block of such a launch is resident at once (flow_lean), each
+// stays on its compute unit for the whole launch, and a SIMD issues for its wavefronts one instruction at a time: the launch
+// lasts as long as the most heavily loaded compute unit needs.  The hardware deals workgroups out by COUNT (5 or 6 per
+// unit for a 340 k-row rank); by block tickets the costliest unit of such a rank carried 1.5 times the mean (measured
+// per-unit end times 0.8 .. 4.5 ms, correlation with the modelled load 0.8).  So the host deals the blocks to per-unit queues
+// by cost (flow_place_blocks), a workgroup finds out where it runs (hw_cu_key) and takes the next block of that unit's
+// queue -- or, when the hardware sent the unit more workgroups than its queue holds, of the nearest queue that has one left.
+// Any assignment is correct: nothing depends on the order blocks start in while all of them are resident.
+__device__ __forceinline__ int32_t lean_pick_block(const FlowArgs &a)
+{
+    if (!a.cuq_blk) return atomicAdd(a.ticket, 1);
+    const int32_t Q = a.ncuq;
+    const uint32_t key = hw_cu_key();
+    int32_t q = a.cu_index[key];
+    if (q < 0) q = (int32_t)(key % (uint32_t)Q);
+    // cuq_head[q]: low half = blocks taken from the front (by workgroups of the unit itself: its costliest first), high half =
+    // blocks taken from the back (by workgroups of other units whose own queue had run out: the cheapest); both only grow,
+    // and a take counts if front + back was below the queue length before it
+    for (int32_t k = 0; k < Q; ++k) {
+        const int32_t qq = q + k < Q ? q + k : q + k - Q;
+        const int32_t lo = a.cuq_ptr[qq], n = a.cuq_ptr[qq + 1] - lo;
+        const uint32_t seen = (uint32_t)__hip_atomic_load(a.cuq_head + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)((seen & 0xffffu) + (seen >> 16)) >= n) continue;
+        const uint32_t was = (uint32_t)atomicAdd(a.cuq_head + qq, k == 0 ? 1 : 0x10000);
+        const int32_t front = (int32_t)(was & 0xffffu), back = (int32_t)(was >> 16);
+        if (front + back < n) return a.cuq_blk[lo + (k == 0 ? front : n - 1 - back)];
+    }
+    return -1; // (cannot happen: as many workgroups as blocks)
+}
+
 template <bool LAG>
 __global__ void __launch_bounds__(kFlowBlock, TRMC_LEAN_WAVES)
 k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
 {
     using M = DevMathFlow;
+    const FlowCold cold = cold_args<FlowArgs>(); // (see cold_args: what the loop rarely needs is not kept in registers)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ float s_par[kLeanCols * kFlowBlock];                 // [column][thread]
     __shared__ unsigned long long s_ring[kLeanRing * kFlowBlock];   // [step % 2][thread] granules
     __shared__ int32_t s_blk;
-    if (threadIdx.x == 0) s_blk = atomicAdd(a.ticket, 1);
+    __shared__ int32_t s_grp[kFlowBlock / 64];
+    if (threadIdx.x == 0) s_blk = lean_pick_block(a);
+    if (threadIdx.x < kFlowBlock / 64) s_grp[threadIdx.x] = -1;
 #pragma unroll
     for (int j = 0; j < kLeanRing; ++j) s_ring[j * kFlowBlock + threadIdx.x] = 0ull;
     M m{stage_pow_tables(s_tab), false}; // (its barrier also publishes s_blk and the cleared ring)
     m.sane = a.sane;
+    if (s_blk < 0) return;
+    // Which 64 rows of the block this wavefront takes.  A block's rows are grouped by descending cost, so its first
+    // wavefront is its costliest (1 010 instructions per step against 730 for the others, 8-way CONUS rank) -- and if that
+    // always lands on the same SIMD of its unit, that SIMD carries 1.3 times the others' load.  The host has matched the
+    // block's four row groups with the four SIMDs of the unit it dealt the block to (costliest group to the SIMD carrying
+    // least, flow_place_blocks); a wavefront reads which SIMD it is on and takes that SIMD's group.  Should two wavefronts
+    // of the workgroup share a SIMD, everybody keeps the plain order.
+    int32_t grp = (int32_t)(threadIdx.x >> 6);
+    uint32_t my_simd = 0;
+    if (a.cuq_perm) {
+        my_simd = (__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) >> 4) & 3u; // HW_REG_HW_ID.simd_id
+        const int32_t g = (int32_t)((a.cuq_perm[s_blk] >> (2u * my_simd)) & 3u);
+        if ((threadIdx.x & 63u) == 0) s_grp[g] = (int32_t)(threadIdx.x >> 6);
+        __syncthreads();
+        bool all_taken = true;
+#pragma unroll
+        for (int j = 0; j < kFlowBlock / 64; ++j) all_taken = all_taken && s_grp[j] >= 0;
+        if (all_taken) grp = g;
+    }
+    const int32_t tix = grp * 64 + (int32_t)(threadIdx.x & 63u); // the row of the block this thread routes
     const int32_t blk_base = a.first + s_blk * kFlowBlock;
-    if (a.dbg && threadIdx.x == 0) a.dbg[2 * s_blk] = wall_clock64();
+    if (cold->dbg && tix == 0) cold->dbg[2 * s_blk] = ((unsigned long long)hw_cu_key() << 48) | (wall_clock64() & 0xffffffffffffull);
 #ifdef TRMC_FLOW_DEBUG_WAITS
     dbg_plane() = 0;
     dbg_ring() = 0;
+#else
+    if (cold->dbg && (threadIdx.x & 63u) == 0) // which SIMD every row group ran on
+        cold->dbg[2 * (size_t)(cold->nblocks_dbg + 1) + 4 * (size_t)s_blk + grp] = 1ull + my_simd + ((unsigned long long)(threadIdx.x >> 6) << 8);
 #endif
     if (a.prio) { // the costlier a wavefront, the higher its issue priority (topology.cpp)
-        const int pr = __builtin_amdgcn_readfirstlane((int)a.prio[(s_blk * kFlowBlock + (int32_t)threadIdx.x) >> 6]);
+        const int pr = __builtin_amdgcn_readfirstlane((int)a.prio[(s_blk * kFlowBlock + tix) >> 6]);
         if (pr == 1) __builtin_amdgcn_s_setprio(1);
         else if (pr == 2) __builtin_amdgcn_s_setprio(2);
         else if (pr == 3) __builtin_amdgcn_s_setprio(3);
     }
-    if (blk_base + (int32_t)threadIdx.x >= a.nseg) return; // (no block-wide barrier below)
-    const uint32_t su = (uint32_t)(blk_base + (int32_t)threadIdx.x);
+    if (blk_base + tix >= a.nseg) return; // (no block-wide barrier below)
+    const uint32_t su = (uint32_t)(blk_base + tix);
     {
         const uint32_t ob = su * 4u;
-        float *sp = s_par + threadIdx.x;
+        float *sp = s_par + tix;
         sp[0 * kFlowBlock] = at(a.dx, ob);
         sp[1 * kFlowBlock] = at(a.bw, ob);
         sp[2 * kFlowBlock] = at(a.twcc, ob);
@@ -1486,9 +1587,9 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
     if (t_lo > t_hi) return;
     // the state this row was left in -- possibly by a launch that is still running (consecutive time chunks of a window
     // overlap on two streams): its own flow granule of step t_lo - 1 and the depth granule tagged with the same step
-    float q_prev = flow_wait(a.gran + (size_t)(t_lo - 1) * np + su, a.tag_base + (uint32_t)(t_lo - 1), a, dead);
-    float d_prev = flow_wait(a.d_gran + su, a.tag_base + (uint32_t)(t_lo - 1), a, dead);
-    __hip_atomic_store(s_ring + (size_t)((t_lo - 1) & (kLeanRing - 1)) * kFlowBlock + threadIdx.x,
+    float q_prev = flow_wait(a.gran + (size_t)(t_lo - 1) * np + su, a.tag_base + (uint32_t)(t_lo - 1), cold, dead);
+    float d_prev = flow_wait(cold->d_gran + su, a.tag_base + (uint32_t)(t_lo - 1), cold, dead);
+    __hip_atomic_store(s_ring + (size_t)((t_lo - 1) & (kLeanRing - 1)) * kFlowBlock + tix,
                        ((unsigned long long)(a.tag_base + (uint32_t)(t_lo - 1)) << 32) | (unsigned long long)__float_as_uint(q_prev),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // the lateral-inflow column of step t is (t - 1) / qts: the first one is read now, the next ones as the counter runs out
@@ -1501,32 +1602,34 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
         const uint32_t tag_p = a.tag_base + (uint32_t)(t - 1);
         const unsigned long long *g_prev = a.gran + (size_t)(t - 1) * np;
         if (ql_left == 0) { // (a counter, not (t - 1) % qts and (t - 1) / qts: two integer divisions per step otherwise)
-            ql = a.qlat_tm[(size_t)ql_col * np + su];
-            ql_left = a.qts;
+            ql = cold->qlat_tm[(size_t)ql_col * np + su];
+            ql_left = cold->qts;
             ++ql_col;
         }
         --ql_left;
         if ((t & 15) == 0) flags &= ~5u; // a producer that ran ahead may have been caught up with: try the ring again
         // junction sum in the reference's order (mc_reach.pyx:499-505)
         float qup = 0.0f;
-        if (u0 >= 0) qup += lean_edge_get(u0, u0 - blk_base, flags, 1u, 2u, g_prev, s_ring, t - 1, tag_p, a, dead);
-        if (u1 >= 0) qup += lean_edge_get(u1, u1 - blk_base, flags, 4u, 8u, g_prev, s_ring, t - 1, tag_p, a, dead);
+        if (u0 >= 0) qup += lean_edge_get(u0, u0 - blk_base, flags, 1u, 2u, g_prev, s_ring, t - 1, tag_p, cold, dead);
+        if (u1 >= 0) qup += lean_edge_get(u1, u1 - blk_base, flags, 4u, 8u, g_prev, s_ring, t - 1, tag_p, cold, dead);
         if (flags & 16u) {
-            const int32_t k1 = a.up_ptr[su + 1];
-            for (int32_t e = a.up_ptr[su] + 2; e < k1; ++e) qup += flow_wait(g_prev + a.up_idx[e], tag_p, a, dead);
+            const int32_t *const up_ptr = cold->up_ptr, *const up_idx = cold->up_idx;
+            const int32_t k1 = up_ptr[su + 1];
+            for (int32_t e = up_ptr[su] + 2; e < k1; ++e) qup += flow_wait(g_prev + up_idx[e], tag_p, cold, dead);
         }
         float q_new = 0.0f, v_new = 0.0f, d_new = 0.0f;
         bool routed = false;
         trmc::ChannelParams<float> p;
         trmc::ChannelConst<float> c;
         if (flags & 32u) { // level-pool reservoir row (see k_mc_step)
-            const int32_t ri = a.res_of_pos[su];
-            const float *rp = a.res_par + (size_t)ri * 9;
+            const int32_t ri = cold->res_of_pos[su];
+            const int32_t nsteps = cold->nsteps;
+            const float *rp = cold->res_par + (size_t)ri * 9;
             const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
             float H = d_prev;
-            q_new = trmc::levelpool_step<float, M>(qup, 0.0f, a.res_dt, H, lp, m);
+            q_new = trmc::levelpool_step<float, M>(qup, 0.0f, cold->res_dt, H, lp, m);
             d_new = H;
-            a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = qup;
+            cold->res_inflow[(size_t)ri * (size_t)nsteps + (size_t)(t - 1)] = qup;
             its &= 0x00ffffffu;
         } else {
             trmc::Inflow<float> f;
@@ -1539,7 +1642,7 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
                 // (with assume_short_ts a row reads flows its upstream rows published a step ago: no dependence chain runs
                 // through the step, so nothing of it is hoisted above the look-up -- see k_mc_flow -- and the two points of
                 // the bracket are formed inside step_solve)
-                const float *sp = s_par + threadIdx.x;
+                const float *sp = s_par + tix;
                 p.dt = dt;
                 p.dx = sp[0 * kFlowBlock];
                 p.bw = sp[1 * kFlowBlock];
@@ -1568,24 +1671,25 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
             }
             its = ((its + it_cost) & 0x00ffffffu) | (it_now << 24);
             if (flags & 64u) { // streamflow nudging (see k_mc_step)
-                const size_t e = (size_t)a.gage_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1);
-                const uint8_t mode = a.da_mode[e];
+                const size_t e = (size_t)cold->gage_of_pos[su] * (size_t)cold->nsteps + (size_t)(t - 1);
+                const float *const da_a = cold->da_a;
+                const uint8_t mode = cold->da_mode[e];
                 float nudge = 0.0f;
                 if (mode == 1) {
-                    nudge = a.da_a[e] - q_new;
-                    q_new = a.da_a[e];
+                    nudge = da_a[e] - q_new;
+                    q_new = da_a[e];
                 } else if (mode == 2) {
-                    nudge = (a.da_a[e] - q_new) * a.da_w[e];
+                    nudge = (da_a[e] - q_new) * cold->da_w[e];
                     q_new = q_new + nudge;
                 }
-                a.da_nudge[e] = nudge;
+                cold->da_nudge[e] = nudge;
             }
         }
         // the flow goes out as soon as it exists; the velocity (a power, a square root, a division no other row waits for)
         // is formed after the granule is on its way
         {
             const unsigned long long g = ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(q_new);
-            __hip_atomic_store(s_ring + (size_t)(t & (kLeanRing - 1)) * kFlowBlock + threadIdx.x, g, __ATOMIC_RELAXED,
+            __hip_atomic_store(s_ring + (size_t)(t & (kLeanRing - 1)) * kFlowBlock + tix, g, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(a.gran + (size_t)t * np + su, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1593,7 +1697,7 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
         q_prev = q_new;
         d_prev = d_new;
         if (t == t_hi) // hand the depth over to the next launch of the window
-            __hip_atomic_store(a.d_gran + su, ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(d_new),
+            __hip_atomic_store(cold->d_gran + su, ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(d_new),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifndef TRMC_FLOW_EXP_NOOUT
         {
@@ -1604,21 +1708,26 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
         }
 #endif
     }
-    if (a.dbg) atomicMax(a.dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
+    if (cold->dbg) atomicMax(cold->dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
 #ifdef TRMC_FLOW_DEBUG_WAITS
-    if (a.dbg) { // [2 * (nblocks + 1) ...]: per block {max plane polls of a thread, max ring polls, iteration sum of the block}
-        unsigned long long *x = a.dbg + 2 * (size_t)(a.nblocks_dbg + 1) + 4 * (size_t)s_blk;
+    if (cold->dbg) { // [2 * (nblocks + 1) ...]: per block {max plane polls of a thread, max ring polls, iteration sum of the block}
+        unsigned long long *x = cold->dbg + 2 * (size_t)(cold->nblocks_dbg + 1) + 4 * (size_t)s_blk;
         atomicMax(x + 0, (unsigned long long)dbg_plane());
         atomicMax(x + 1, (unsigned long long)dbg_ring());
         atomicAdd(x + 2, (unsigned long long)(its & 0x00ffffffu));
         atomicMax(x + 3, (unsigned long long)(its & 0x00ffffffu));
     }
 #endif
-    a.d_state[su] = d_prev;
-    if (t_hi == a.nsteps) a.it_prev[su] = (uint8_t)(its >> 24);
-    if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535u, (uint32_t)a.it_sum[su] + (its & 0x00ffffffu));
+    cold->d_state[su] = d_prev;
+    if (t_hi == cold->nsteps) cold->it_prev[su] = (uint8_t)(its >> 24);
+    if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535u, (uint32_t)it_sum[su] + (its & 0x00ffffffu));
 }
 
+// which compute units exist: every workgroup marks the key of the unit it runs on
+__global__ void __launch_bounds__(64) k_cu_probe(uint8_t *seen)
+{
+    if (threadIdx.x == 0) seen[hw_cu_key()] = 1;
+}
 // initial state of the dataflow engine: granule row 0 <- qu0 (mc_reach.pyx:361), depth column <- h0
 __global__ void __launch_bounds__(kBlock)
 k_flow_init(const float *__restrict__ q0, const int32_t *__restrict__ row_of_pos, unsigned long long *gran, float *d_state,
@@ -1755,6 +1864,8 @@ struct trmc_plan {
     int flow_next = 0;                   // which of the two the next trmc_route_advance uses (only toggles in overlap mode)
     int flow_last = 0;                   // ... and which one the last launch went to
     DevBuf d_state, ticket, rank, dbg;   // depth column; {block ticket, abort flag}; level rank of a position inside its block
+    DevBuf cuq_ptr, cuq_blk, cuq_head, cu_index, cuq_perm; // blocks dealt to compute units by cost (flow_place_blocks); heads: one set per compute stream
+    int32_t ncuq = 0;                    // number of queues (= compute units found), 0 = block tickets
     uint64_t watchdog_ticks = 3000000000ull; // 30 s of wall_clock64 (100 MHz): long enough for a device that is shared or profiled (TRMC_FLOW_WATCHDOG_MS)
     trmc_stats stats{};
     RouteRun run;
@@ -2008,6 +2119,15 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     return 0;
 }
 
+// occupancy experiment (TRMC_TILE_LDS_PAD = bytes of dynamic LDS per block that nobody uses: fewer blocks fit a compute unit)
+static unsigned tile_lds_pad()
+{
+    static const unsigned pad = [] {
+        const char *e = std::getenv("TRMC_TILE_LDS_PAD");
+        return e ? (unsigned)std::atoi(e) : 0u;
+    }();
+    return pad;
+}
 template <class T> int route_advance_t(trmc_plan *pl, int t_end)
 {
     const trmc::Topology &tp = pl->topo;
@@ -2039,7 +2159,7 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
                     const size_t slot = (size_t)r.wide_next;
                     if (slot < pl->wide_t0.size()) HIP_TRY(hipEventRecord(pl->wide_t0[slot], ws));
-                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, 0, ws, a, w0, w1, r.wide_next, K);
+                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, tile_lds_pad(), ws, a, w0, w1, r.wide_next, K);
                     if (slot < pl->wide_t1.size()) HIP_TRY(hipEventRecord(pl->wide_t1[slot], ws));
                     ++r.launches;
                     ++r.wide_next;
@@ -2144,6 +2264,100 @@ template <class T> int route_end_t(trmc_plan *pl)
 }
 
 // ---- dataflow engine, host side (fp32 plans in block order) ------------------------------------------------------
+// Deal the blocks of a dataflow plan to the compute units by cost (see lean_pick_block).  Cost of a wavefront: the
+// instructions of one of its steps by the hint of its costliest row (counters of the lean kernel by iteration class: dry
+// 130, one iteration 600, two 890, three 1 150, over-bank rows about twice that) -- a hint is either the iteration class
+// 0..3 (+ 4 over bank) or its window mean in sixteenths (ShardedRouter.iteration_hint); without one it is the drainage
+// class 0..3, the same scale.  Blocks go out in rounds of one per unit, costliest first, each to the unit that carries least
+// so far: every unit gets as many blocks as the hardware will send it workgroups (it deals those out by count).
+int flow_place_blocks(trmc_plan *pl)
+{
+    pl->ncuq = 0;
+    const char *off = std::getenv("TRMC_FLOW_PLACE");
+    if (off && off[0] == '0') return 0;
+    const int32_t nb = pl->topo.nblocks;
+    if (nb <= 0) return 0;
+    constexpr int kKeys = 4096;
+    // which compute units are there?
+    DevBuf seen;
+    if (int rc = seen.ensure(kKeys)) return rc;
+    HIP_TRY(hipMemset(seen.p, 0, kKeys));
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+    hipLaunchKernelGGL(k_cu_probe, dim3((unsigned)(64 * ncu)), dim3(64), 0, nullptr, (uint8_t *)seen.p);
+    std::vector<uint8_t> hs(kKeys);
+    hipError_t e = hipMemcpy(hs.data(), seen.p, kKeys, hipMemcpyDeviceToHost);
+    seen.release();
+    if (e != hipSuccess) return fail(TRMC_EHIP, std::string("compute-unit probe: ") + hipGetErrorString(e));
+    std::vector<int32_t> cu_index(kKeys, -1);
+    int32_t Q = 0;
+    for (int k = 0; k < kKeys; ++k)
+        if (hs[k]) cu_index[k] = Q++;
+    if (Q < 2) return 0;
+    // cost of every block
+    const std::vector<uint8_t> &wc = pl->topo.cost_of_wave;
+    int hi = 0;
+    for (const uint8_t c : wc) hi = std::max(hi, (int)c);
+    const bool sixteenths = hi > 7;
+    auto units = [&](int hint) {
+        const double c = sixteenths ? hint / 16.0 : (double)hint;
+        static const double x[5] = {0, 1, 2, 3, 7}, y[5] = {130, 600, 890, 1150, 2200};
+        for (int i = 1; i < 5; ++i)
+            if (c <= x[i]) return y[i - 1] + (y[i] - y[i - 1]) * (c - x[i - 1]) / (x[i] - x[i - 1]);
+        return y[4];
+    };
+    constexpr int wpb = kFlowBlock / 64;
+    std::vector<double> cost((size_t)nb, 0.0), wcost((size_t)nb * wpb, 0.0);
+    for (int32_t b = 0; b < nb; ++b)
+        for (int q = 0; q < wpb; ++q) {
+            const size_t w = (size_t)b * wpb + q;
+            if (w < wc.size()) wcost[w] = units(wc[w]);
+            cost[(size_t)b] += wcost[w];
+        }
+    std::vector<int32_t> order((size_t)nb);
+    for (int32_t b = 0; b < nb; ++b) order[(size_t)b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    std::vector<double> load((size_t)Q, 0.0), sload((size_t)Q * 4, 0.0); // per unit; per SIMD of a unit
+    std::vector<std::vector<int32_t>> queue((size_t)Q);
+    std::vector<int32_t> cus((size_t)Q);
+    std::vector<uint8_t> perm((size_t)nb + 4, 0xe4); // identity: group s for SIMD s
+    for (int32_t r = 0; r < nb; r += Q) {
+        for (int32_t c = 0; c < Q; ++c) cus[(size_t)c] = c;
+        std::stable_sort(cus.begin(), cus.end(), [&](int32_t x, int32_t y) { return load[(size_t)x] < load[(size_t)y]; });
+        for (int32_t j = 0; j < std::min(Q, nb - r); ++j) {
+            const int32_t b = order[(size_t)(r + j)], c = cus[(size_t)j];
+            queue[(size_t)c].push_back(b);
+            load[(size_t)c] += cost[(size_t)b];
+            if (wpb == 4) { // the block's row groups by descending cost meet the unit's SIMDs by ascending load
+                int g[4] = {0, 1, 2, 3}, sd[4] = {0, 1, 2, 3};
+                std::stable_sort(g, g + 4, [&](int x, int y) { return wcost[(size_t)b * 4 + x] > wcost[(size_t)b * 4 + y]; });
+                std::stable_sort(sd, sd + 4, [&](int x, int y) { return sload[(size_t)c * 4 + x] < sload[(size_t)c * 4 + y]; });
+                uint8_t pm = 0;
+                for (int i = 0; i < 4; ++i) {
+                    pm |= (uint8_t)(g[i] << (2 * sd[i]));
+                    sload[(size_t)c * 4 + sd[i]] += wcost[(size_t)b * 4 + g[i]];
+                }
+                perm[(size_t)b] = pm;
+            }
+        }
+    }
+    std::vector<int32_t> ptr((size_t)Q + 1, 0), blk;
+    blk.reserve((size_t)nb);
+    for (int32_t c = 0; c < Q; ++c) {
+        // (in the order they were dealt: by descending cost -- a unit's own workgroups take from the front, thieves from the back)
+        for (const int32_t b : queue[(size_t)c]) blk.push_back(b);
+        ptr[(size_t)c + 1] = (int32_t)blk.size();
+    }
+    if (int rc = pl->cuq_perm.ensure(perm.size())) return rc;
+    HIP_TRY(hipMemcpy(pl->cuq_perm.p, perm.data(), perm.size(), hipMemcpyHostToDevice));
+    if (int rc = upload_i32(pl->cuq_ptr, ptr, 1)) return rc;
+    if (int rc = upload_i32(pl->cuq_blk, blk, 1)) return rc;
+    if (int rc = upload_i32(pl->cu_index, cu_index, 1)) return rc;
+    if (int rc = pl->cuq_head.ensure((size_t)Q * 2 * sizeof(int32_t))) return rc;
+    pl->ncuq = Q;
+    return 0;
+}
+
 FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
 {
     FlowArgs a;
@@ -2199,6 +2413,10 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     a.dbg = std::getenv("TRMC_FLOW_DEBUG") ? (unsigned long long *)pl->dbg.p : nullptr;
     a.nblocks_dbg = pl->topo.nblocks;
     a.prio = std::getenv("TRMC_FLOW_NOPRIO") ? nullptr : (const uint8_t *)pl->prio.p;
+    a.cuq_ptr = a.cuq_blk = a.cu_index = nullptr; // (flow_route_advance switches the queues on for lean launches)
+    a.cuq_perm = nullptr;
+    a.cuq_head = nullptr;
+    a.ncuq = 0;
     return a;
 }
 
@@ -2306,6 +2524,15 @@ int flow_route_advance(trmc_plan *pl, int t_end)
         FlowArgs a = flow_args(pl, r.nsteps, r.qts, r.short_ts != 0);
         a.ticket += 8 * which;                                       // every compute stream has its own block tickets
         HIP_TRY(hipMemsetAsync(a.ticket, 0, sizeof(int32_t), st));   // they restart; the abort flag stays
+        if (lean && pl->ncuq > 0) { // blocks by compute unit (lean_pick_block)
+            a.cuq_ptr = (const int32_t *)pl->cuq_ptr.p;
+            a.cuq_blk = (const int32_t *)pl->cuq_blk.p;
+            a.cu_index = (const int32_t *)pl->cu_index.p;
+            a.cuq_perm = std::getenv("TRMC_FLOW_NOPERM") ? nullptr : (const uint8_t *)pl->cuq_perm.p;
+            a.cuq_head = (int32_t *)pl->cuq_head.p + (size_t)pl->ncuq * which;
+            a.ncuq = pl->ncuq;
+            HIP_TRY(hipMemsetAsync(a.cuq_head, 0, (size_t)pl->ncuq * sizeof(int32_t), st));
+        }
         const dim3 grid((unsigned)pl->topo.nblocks), block(kFlowBlock);
         if (lean && a.lag)
             hipLaunchKernelGGL((k_mc_flow_lean<true>), grid, block, 0, st, a, r.t_done, t_end);
@@ -2354,6 +2581,30 @@ int flow_route_end(trmc_plan *pl)
         const int32_t nb = pl->topo.nblocks;
         std::vector<unsigned long long> d((size_t)nb * 2);
         HIP_TRY(hipMemcpy(d.data(), pl->dbg.p, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> cu_key(nb);
+        for (int32_t b = 0; b < nb; ++b) { // (the start word carries the compute unit in its top 16 bits)
+            cu_key[b] = (uint32_t)(d[2 * b] >> 48);
+            d[2 * b] &= 0xffffffffffffull;
+        }
+        std::vector<unsigned long long> dx((size_t)nb * 4, 0ull); // per row group: 1 + SIMD + 256 * wavefront of the workgroup
+        HIP_TRY(hipMemcpy(dx.data(), (unsigned long long *)pl->dbg.p + 2 * (size_t)(nb + 1), dx.size() * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost));
+        if (const char *path = std::getenv("TRMC_FLOW_DEBUG_FILE")) { // one line per block: id, compute unit, start, end (ms)
+            if (FILE *f = std::fopen(path, "a")) {
+                std::fprintf(f, "# launch of %d blocks\n", nb);
+                for (int32_t b = 0; b < nb; ++b)
+                {
+                    std::fprintf(f, "%d %u %.5f %.5f", b, cu_key[b], d[2 * b] * 1e-5, d[2 * b + 1] * 1e-5);
+                    for (int q = 0; q < kFlowBlock / 64; ++q) {
+                        const size_t w = (size_t)b * (kFlowBlock / 64) + q;
+                        std::fprintf(f, " %d", w < pl->topo.cost_of_wave.size() ? (int)pl->topo.cost_of_wave[w] : -1);
+                    }
+                    for (int q = 0; q < kFlowBlock / 64; ++q) std::fprintf(f, " %llu", dx[(size_t)4 * b + q]);
+                    std::fprintf(f, "\n");
+                }
+                std::fclose(f);
+            }
+        }
         unsigned long long t_min = ~0ull, t_max = 0;
         for (int32_t b = 0; b < nb; ++b) {
             t_min = std::min(t_min, d[2 * b]);
@@ -2639,6 +2890,7 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
         if (!pl->topo.prio_of_wave.empty()
             && hipMemcpy(pl->prio.p, pl->topo.prio_of_wave.data(), pl->topo.prio_of_wave.size(), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(TRMC_EHIP, "uploading the wavefront priorities failed"));
+        if ((rc = flow_place_blocks(pl))) return bail(rc);
     }
     if ((rc = upload_i32(pl->row_of_pos, pl->topo.row_of_pos, 1))) return bail(rc);
     if ((rc = upload_i32(pl->pos_of_row, pl->topo.pos_of_row, 1))) return bail(rc);
@@ -2657,7 +2909,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->cstream) (void)hipStreamDestroy(pl->cstream);
     if (pl->ev_fetch_ready) (void)hipEventDestroy(pl->ev_fetch_ready);
     if (pl->ev_fetch_done) (void)hipEventDestroy(pl->ev_fetch_done);
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
         b->release();

@@ -254,6 +254,35 @@ def test_random_forests_bit_identical(nseg, short, engine, monkeypatch):
     assert_bit_identical(got, want, f"forest n={nseg} short={short}")
 
 
+@pytest.mark.parametrize("place", ["tickets", "queues", "queues+simd"])
+def test_flow_engine_block_placement_changes_nothing(place, monkeypatch):
+    """Lean launches of the dataflow engine deal their blocks to the compute units by cost (per-unit queues, row groups
+    matched with SIMDs; trmc.hip lean_pick_block / flow_place_blocks).  Block tickets, queues alone and the default give
+    the same bits -- also with far fewer blocks than units (every workgroup but a few takes from a queue not its own) and
+    with a cost hint that makes the queues uneven."""
+    set_engine(monkeypatch, "flow")
+    if place == "tickets":
+        monkeypatch.setenv("TRMC_FLOW_PLACE", "0")
+    elif place == "queues":
+        monkeypatch.setenv("TRMC_FLOW_NOPERM", "1")
+    for nseg in (700, 40000):
+        rng = np.random.default_rng(77 + nseg)
+        to = H.random_network(rng, nseg)
+        _, _, ups = H.reaches_from_to(to)
+        nsteps, qts = 24, 4
+        params, qlat, q0 = synth_inputs(rng, nseg, 6)
+        up_ptr, up_idx = csr_from_lists(ups)
+        lvl, _, _ = topology_levels(up_ptr, up_idx)
+        hint = rng.integers(0, 8, nseg).astype(np.uint8) * np.uint8(16)
+        with RoutingPlan(up_ptr, up_idx, params, cost_hint=hint, assume_short_ts=True, engine="flow") as plan:
+            assert plan.engine == "flow"
+            got = plan.route(nsteps, qts, True, qlat, q0)
+            again = plan.route(nsteps, qts, True, qlat, q0)
+        want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params, q0, qlat, True, det=True)[:, 1:, :]
+        assert_bit_identical(got, want, f"placement {place} n={nseg}")
+        assert_bit_identical(again, want, f"placement {place} n={nseg}, second window")
+
+
 @pytest.mark.parametrize("nsteps,qts", [(1, 1), (65, 1), (130, 12), (64, 64)])
 def test_timestep_and_forcing_shapes(nsteps, qts):
     """Tile edges of the result transpose (64-step tiles), qts = 1 (one forcing column per step), one
