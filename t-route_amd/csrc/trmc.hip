@@ -373,13 +373,23 @@ constexpr int kStepBlock = TRMC_STEP_BLOCK;
 #ifndef TRMC_EXPERIMENT_WAVES
 #define TRMC_EXPERIMENT_WAVES 1
 #endif
+#ifdef TRMC_STEP_VGPRS // experiment: cap the register allocation of the step kernel
+#define TRMC_STEP_ATTR __attribute__((amdgpu_num_vgpr(TRMC_STEP_VGPRS)))
+#else
+#define TRMC_STEP_ATTR
+#endif
 template <class T, bool SHORT, bool LAG = false>
-__global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES)
+__global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES) TRMC_STEP_ATTR
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag, const int32_t ql_col)
 {   // ql_col: the lateral-inflow column (diag - 1) / qts of a launch whose rows are all at step diag (SHORT, no lag) -- formed
     // by the host: an integer division by a run-time divisor is some 35 instructions per thread
     using M = typename DevMath<T>::type;
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    // Issue priority over whatever else is resident: beside the wide tiles (k_mc_tile) these launches are the narrow tail of
+    // the level order -- 288 launches that wait for each other, the critical path of the window -- and a wavefront of theirs
+    // that shares its SIMD with four tile wavefronts at equal priority needs 43 us for a step it does in 20 us alone.  (Alone
+    // on the device every wavefront has the same priority and nothing changes.)
+    __builtin_amdgcn_s_setprio(3);
     M m{stage_pow_tables(s_tab), false};
     m.sane = a.sane;
 
@@ -1803,7 +1813,7 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     int32_t boundary_through = 0; // boundary rows hold their hydrographs for steps 1..boundary_through
     int32_t tiles_done = 0, launches = 0;
     // wide levels routed K steps per launch with a skew of K steps per level (k_mc_tile); 0 = every level one step per launch
-    int32_t wide = 0, wide_k = 0, wide_next = 0, wide_through = 0; // levels; K; next tile; step every wide level has completed
+    int32_t wide = 0, wide_k = 0, wide_next = 0, wide_through = 0; // levels; K; tiles queued; last tile the tail waits for
     bool tail_active = false;     // the tail launches of this window go to the tail stream
 };
 
@@ -1821,7 +1831,6 @@ struct trmc_plan {
     hipStream_t wstream = nullptr;       // the wide tiles (k_mc_tile), ordinary priority: the narrow tail of the level order runs one
                                          // step per launch on the plan's own high-priority stream BESIDE them -- the tail's 288
                                          // dependent launches are the latency-critical part, the tiles fill whatever they leave
-    std::vector<hipEvent_t> wide_ev;     // "wide tile k is complete" (tile stream -> plan stream), a ring
     hipEvent_t ev_tail = nullptr;        // "every tile queued so far is complete" (tile stream -> plan stream)
     std::vector<hipEvent_t> wide_t0, wide_t1; // timing events around the wide launches of the window (trmc_stats.ms_wide)
     std::vector<hipEvent_t> tile_ev;     // "time tile b is complete" (main stream -> stream2)
@@ -2082,30 +2091,35 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     // Short-timestep windows of a wide network: the leading levels that can fill the device by themselves are routed K
     // steps per launch (k_mc_tile), the rest one step per launch behind them.  Needs every boundary hydrograph up front
     // (wide rows run ahead of the window's progress) and no lagged rows (the multi-GPU trunk has its own skew).
-    // TRMC_WIDE_MIN_ROWS (rows a level must have, default 32768; 0 switches the path off), TRMC_WIDE_LEVELS (at most,
-    // default 16) and TRMC_WIDE_K (steps per launch, default 12) are measurement / test knobs.
+    // TRMC_WIDE_MIN_ROWS (rows a level must have, default 384 per compute unit; 0 switches the path off), TRMC_WIDE_LEVELS (at
+    // most, default 16) and TRMC_WIDE_K (steps per launch, default 16) are measurement / test knobs.
     if (short_ts && pl->maxlag == 0 && r.boundary_through == nsteps && pl->nrouted > 0) {
         auto env_int = [](const char *name, long dflt) {
             const char *e = std::getenv(name);
             return e && *e ? std::atol(e) : dflt;
         };
-        const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 32768), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
+        // (measured on the CONUS day, MI355X, with every tile queued up front: levels of at least 32 768 rows -- eleven of them
+        // -- and K = 12: 17.5 ms; eight levels 16.9; six 16.6; five 16.5 with K = 12 and 16.25 with K = 16; four 16.6; three 16.9;
+        // K = 24: 17.0.  Fewer wide levels shorten the ramps of the level skew and give the tail launches more rows to fill the
+        // device with after the last tile; the threshold that picks five levels there is 30 % of the rows the device holds at
+        // five wavefronts per SIMD.)
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+        const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 384L * ncu), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
         int32_t W = 0;
         if (min_rows > 0)
             while (W < tp.nlevels && W < max_levels && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows) ++W;
         if (W > 0) {
             r.wide = W;
-            r.wide_k = (int32_t)std::max(1L, std::min((long)nsteps, env_int("TRMC_WIDE_K", std::max(1, std::min(12, nsteps / 8)))));
+            r.wide_k = (int32_t)std::max(1L, std::min((long)nsteps, env_int("TRMC_WIDE_K", std::max(1, std::min(16, nsteps / 8)))));
             if (!pl->wstream) {
                 // ordinary priority: between the tail's step launches (high) and the result transpose (low); one hardware queue each
                 HIP_TRY(hipStreamCreateWithFlags(&pl->wstream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&pl->ev_tail, hipEventDisableTiming));
-                pl->wide_ev.assign(8, nullptr);
-                for (auto &e : pl->wide_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
             HIP_TRY(hipStreamWaitEvent(pl->wstream, pl->ev[1], 0)); // the tiles start behind the window's set-up
             const size_t ntile = (size_t)((nsteps + r.wide_k - 1) / r.wide_k + W - 1);
-            while (pl->wide_t0.size() < std::min<size_t>(ntile, 256)) {
+            while (pl->wide_t0.size() < ntile) { // (t0: only the first is used -- a tile starts where the one before it ended)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 HIP_TRY(hipEventCreate(&e0));
                 HIP_TRY(hipEventCreate(&e1));
@@ -2153,25 +2167,31 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             const bool tail = s1 > w1;
             hipStream_t ws = pl->wstream;
             r.tail_active = tail;
-            for (int32_t t = t0 + 1; t <= t_end; ++t) {
-                bool fresh = false;
-                while (r.wide_through < t && r.wide_next < ntile) {
-                    const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
-                    const size_t slot = (size_t)r.wide_next;
-                    if (slot < pl->wide_t0.size()) HIP_TRY(hipEventRecord(pl->wide_t0[slot], ws));
-                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, tile_lds_pad(), ws, a, w0, w1, r.wide_next, K);
-                    if (slot < pl->wide_t1.size()) HIP_TRY(hipEventRecord(pl->wide_t1[slot], ws));
+            // Every tile of the window is queued at once, at the window's first call: the wide path needs all boundary
+            // hydrographs up front (route_begin_t), so a tile depends on nothing but the tile before it.  (Queued one by one
+            // as the tail came to need them, the last tiles of a window were late -- the host runs only a little ahead of the
+            // device once the runtime's pool of dependency signals is in use -- and the tail, the critical path, waited
+            // 1.2 ms for them.)  One event per tile: it ends the tile for the clock (a tile starts where the one before it
+            // ended; the first has a start event of its own) and it is what the tail waits for.
+            if (r.wide_next == 0) {
+                const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
+                HIP_TRY(hipEventRecord(pl->wide_t0[0], ws));
+                for (int32_t j = 0; j < ntile; ++j) {
+                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, tile_lds_pad(), ws, a, w0, w1, j, K);
+                    HIP_TRY(hipEventRecord(pl->wide_t1[(size_t)j], ws));
                     ++r.launches;
-                    ++r.wide_next;
-                    const int32_t done_tiles = r.wide_next - (W - 1); // tiles the LAST wide level has been through
-                    r.wide_through = done_tiles <= 0 ? 0 : std::min(nsteps, done_tiles * K);
-                    fresh = true;
                 }
+                r.wide_next = ntile;
+                r.wide_through = -1; // (from here on: the last tile the tail has been told to wait for)
+            }
+            for (int32_t t = t0 + 1; t <= t_end; ++t) {
                 if (tail) {
-                    if (fresh) { // the tail's next steps read what the tile just queued completes
-                        hipEvent_t e = pl->wide_ev[(size_t)r.wide_next % pl->wide_ev.size()];
-                        HIP_TRY(hipEventRecord(e, ws));
-                        HIP_TRY(hipStreamWaitEvent(st, e, 0));
+                    // the last wide level has completed step t - 1 after tile ceil((t - 1) / K) + W - 2 ... and, with it,
+                    // through step ceil((t - 1) / K) K: the tail waits once per K steps
+                    const int32_t need = t == 1 ? -1 : (t - 2) / K + W - 1; // tile index; none for the first step (state only)
+                    if (need > r.wide_through) {
+                        HIP_TRY(hipStreamWaitEvent(st, pl->wide_t1[(size_t)std::min(need, ntile - 1)], 0));
+                        r.wide_through = need;
                     }
                     launch_step<T, true>(st, a, w1, s1, t);
                     ++r.launches;
@@ -2251,9 +2271,9 @@ template <class T> int route_end_t(trmc_plan *pl)
     s.ms_wide = 0.0;
     {
         const size_t timed_n = std::min<size_t>((size_t)r.wide_next, pl->wide_t0.size());
-        for (size_t i = 0; i < timed_n; ++i) {
+        for (size_t i = 0; i < timed_n; ++i) { // (a tile's clock starts where the previous tile's stopped)
             float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, pl->wide_t0[i], pl->wide_t1[i]));
+            HIP_TRY(hipEventElapsedTime(&ms, i == 0 ? pl->wide_t0[0] : pl->wide_t1[i - 1], pl->wide_t1[i]));
             s.ms_wide += ms;
         }
         if (timed_n > 0 && timed_n < (size_t)r.wide_next) s.ms_wide *= (double)r.wide_next / (double)timed_n;
@@ -2920,8 +2940,6 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_emit) (void)hipEventDestroy(pl->ev_emit);
     if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
     if (pl->wstream) (void)hipStreamDestroy(pl->wstream);
-    for (auto &e : pl->wide_ev)
-        if (e) (void)hipEventDestroy(e);
     for (auto *v : {&pl->wide_t0, &pl->wide_t1})
         for (auto &e : *v)
             if (e) (void)hipEventDestroy(e);
@@ -3558,7 +3576,17 @@ int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_hos
     if (hyd_host && (rowset < 0 || rowset >= (int32_t)pl->rowsets.size())) return fail(TRMC_EINVAL, "unknown row set");
     if (int rc = use_device(pl)) return rc;
     if (!pl->cstream) {
-        HIP_TRY(hipStreamCreateWithFlags(&pl->cstream, hipStreamNonBlocking));
+        // LOW priority: with one hardware queue per priority (GPU_MAX_HW_QUEUES=1) a copy on a stream of ordinary
+        // priority shares the queue of the tile stream, and the barrier packet that orders the copy holds the window's tile
+        // launches back for as long as the copy runs (CONUS: 50 MB, 0.9 ms of an 18 ms window).  The low-priority queue only
+        // carries the result transposes.
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        const char *pr = std::getenv("TRMC_COPY_PRIO"); // "normal": A/B
+        if (pr && pr[0] == 'n')
+            HIP_TRY(hipStreamCreateWithFlags(&pl->cstream, hipStreamNonBlocking));
+        else
+            HIP_TRY(hipStreamCreateWithPriority(&pl->cstream, hipStreamNonBlocking, prio_lo));
         HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_ready, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_done, hipEventDisableTiming));
     }

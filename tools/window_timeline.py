@@ -47,3 +47,6 @@ if "k_mc_tile" in by and "k_mc_step" in by:
         print(f"    tail launch {j:3d}: start {k[j][0] / 1e6:7.3f} dur {(k[j][1] - k[j][0]) / 1e3:7.1f} us")
     for j in (0, len(tiles) // 2, len(tiles) - 1):
         print(f"    wide tile  {j:3d}: start {tiles[j][0] / 1e6:7.3f} dur {(tiles[j][1] - tiles[j][0]) / 1e3:7.1f} us")
+    gaps = [max(0, tiles[i + 1][0] - tiles[i][1]) / 1e3 for i in range(len(tiles) - 1)]
+    print("    gap behind each wide tile, us: " + " ".join(f"{g:.0f}" for g in gaps))
+    print("    duration of each wide tile, us: " + " ".join(f"{(b - a) / 1e3:.0f}" for a, b, _, _ in tiles))
