@@ -35,6 +35,9 @@
 // m.fast_ok(h, h_in, h_over) -> ok; m.div2(a1, a2, b, ok, q1, q2): qi = ai / b; m.div1(a, b, ok) = a / b: the
 // divisions of the hydraulic point, for which a policy may use a cheaper exact sequence when `ok` (its own test of
 // the operand ranges) holds.
+// m.k_of(dx, ck) = dx / ck and m.max_num(a, b) = max(a, b) for the Muskingum K of an in-bank point, where the policy's
+// fast_ok has shown the celerity positive, normal and within 2**95 of dx (DevMathF: a division without scaling or fix-up,
+// one v_max); m.sqrt_r(x, ok): sqrt(x), with `ok` for an x the policy knows to be an ordinary number.
 // M::kInbank: whether the policy wants the in-bank body of the hydraulic point at all (hydraulics_inbank: fewer instructions,
 // more code and registers -- the level kernels take it, the dataflow kernels, whose pace is one wavefront's latency, do not).
 // m.all(pred): true when `pred` holds for every row that is evaluated together with this one (a wavefront's active
@@ -54,7 +57,11 @@ namespace trmc {
 
 template <class T> MC_HD T mc_max(T a, T b) { return a > b ? a : b; }
 template <class T> MC_HD T mc_min(T a, T b) { return a < b ? a : b; }
-template <class T> MC_HD T mc_abs(T a) { return a < T(0) ? -a : a; }
+// |a|.  Every magnitude of the step is only ever COMPARED (the absolute error against the depth floor, the lateral loss
+// against the routed sum), so the sign of a zero and of a NaN cannot show: the sign bit is cleared, which costs nothing
+// on the device (an operand modifier) where the select `a < 0 ? -a : a` was a compare and a move.
+MC_HD float mc_abs(float a) { return __builtin_fabsf(a); }
+MC_HD double mc_abs(double a) { return __builtin_fabs(a); }
 
 // Channel parameters of one segment, as the reference names them.
 template <class T> struct ChannelParams {
@@ -234,11 +241,11 @@ MC_HD HydraulicPoint<T> hydraulics_inbank(T h, const ChannelParams<T> &p, const 
     m.div2(area, wp * p.n, wp, true, R, n_comp);
     const typename M::Log lr = m.log_of_r(R, true);
     const T r23 = m.pow_l_r(lr, R, c23, true);
-    hp.ck = mc_max(T(0), c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, R, c53, true) * m.div1(c.two_sq, twl, true))));
-    {
-        const T kq = mc_max(p.dt, m.divx(p.dx, hp.ck));
-        hp.km = (hp.ck > T(0)) ? kq : p.dt;
-    }
+    // The celerity of an in-bank point under fast_ok is POSITIVE and an ordinary number (the proof is at DevMathF::fast_ok:
+    // the bracket is r23 (5/3 - 2/3 [A 2 sq / (WP twl)]) with the square bracket below one), so max(0, .) returns it, the
+    // guard `ck > 0` of K holds, and K = max(dt, dx / ck) is one division of ordinary numbers and one maximum.
+    hp.ck = c.s0_n * (c53 * r23 - (c23 * m.pow_l_r(lr, R, c53, true) * m.div1(c.two_sq, twl, true)));
+    hp.km = m.max_num(p.dt, m.k_of(p.dx, hp.ck));
     hp.denom = T(2) * twl * p.s0 * hp.ck * p.dx;
     hp.has_wp = true;
     hp.over = false;
@@ -472,7 +479,8 @@ MC_HD T step_velocity(const ChannelParams<T> &p, const ChannelConst<T> &c, T h, 
     const T a = (twl - p.bw) / T(2);
     // (numerator in [2**-44, 2**52], denominator in [2**-14, 2**36]: see fast_ok; one uniform branch, two straight-line bodies)
     if (m.all(m.fast_ok(h, h, T(0)))) {
-        const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), true);
+        // (a = z h up to rounding: a*a + h*h lies in [2**-60, 2**63], an ordinary number)
+        const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt_r(a * a + h * h, true), true);
         return c.inv_n * m.pow_l_r(m.log_of_r(R, true), R, T(2) / T(3), true) * c.sqrt_s0;
     }
     const T R = m.div1(h * (p.bw + twl) / T(2), p.bw + T(2) * m.sqrt(a * a + h * h), false);

@@ -133,7 +133,7 @@ struct DevMathF {
     // bit-identical by construction.  Anything else takes the plain divisions.
     // The divisions of the hydraulic point (hydraulics_at: radius and composite n by the wetted perimeter, the top-width
     // term of the celerity, the reciprocal of the composite n) under the same argument.  `sane` is established once per
-    // plan on the host (params_sane: bw, n, cs, twcc, ncc in [2**-14, 2**17], cs, twcc and ncc possibly 0); with the in-bank and
+    // plan on the host (params_sane: bw, n, cs, twcc, ncc in [2**-14, 2**17], cs, twcc and ncc possibly 0; dt, dx, s0 as at k_of); with the in-bank and
     // over-bank depths in [2**-30, 2**17] the operands are: perimeter W = wp + wpc in [2**-14, 2**36]; area sum in
     // [2**-44, 2**51]; wp*n + wpc*ncc in [2**-28, 2**54]; the composite n in [2**-64, 2**18]; bw + 2hz in
     // [2**-14, 2**36] under 2*sqrt(1 + z*z) in [2, 2**19] -- all normal, no pair more than 2**80 apart, every quotient
@@ -145,7 +145,35 @@ struct DevMathF {
     // A/WP <= h (1 + h z / bw) <= 2**17 (1 + 2**17 2**14 2**14) < 2**63; over bank, twcc h / (twcc + 2 h) lies between
     // min(h, twcc) / 3 and h.  With one rounding of the quotient: 2**-64 < R < 2**63, a positive normal float whose
     // logarithm times 5/3 stays within +-107 -- inside the +-126 where glibc's powf takes its ordinary path.
+    // The Muskingum K of an IN-BANK point (hydraulics_inbank: h <= bankfull depth, so area sum = A, perimeter = WP).
+    // `sane` also bounds s0 in [2**-30, 2**10], dx in [2**-10, 2**19] and dt in [2**-20, 2**40] (params_sane).  The
+    // celerity is ck = (sqrt(s0)/n) (5/3 r23 - 2/3 r53 q), r23 = R**(2/3), r53 = R**(5/3), q = 2 sq / twl.  In exact
+    // arithmetic r53 q = r23 [A 2 sq / (WP twl)] and the bracket is the product of (bw + h z) / (bw + 2 h z) in [1/2, 1)
+    // and 2 h sq / (bw + 2 h sq) in (0, 1): below one.  Each of the dozen roundings on the way (A, WP, twl, the two
+    // quotients, the powers -- glibc's powf is within one unit in the last place --, the products) moves a term by at
+    // most 2**-23 of itself, so the computed bracket is at least r23 (5/3 (1 - 2**-21) - 2/3 (1 + 2**-20)) > 0.99 r23 and at
+    // most 5/3 r23 (1 + 2**-21): with r23 in [2**-43, 2**42] and sqrt(s0)/n in [2**-32, 2**19] the celerity is a positive
+    // normal number in [2**-76, 2**62].  Hence max(0, ck) = ck, the guard `ck > 0` holds, and dx / ck divides a number of
+    // exponent <= 18 by one of exponent >= -76: exponents less than 96 apart, numerator above 2**-103, quotient in
+    // [2**-72, 2**95] -- none of the cases in which v_div_scale / v_div_fmas / v_div_fixup act (see div4), so the
+    // division IS the refinement below; max(dt, K) with both operands ordinary numbers is v_max.
     bool sane;
+    __device__ __forceinline__ float k_of(float dx, float ck) const { return quot(dx, ck, refined_rcp(ck)); }
+    __device__ __forceinline__ float max_num(float a, float b) const { return __builtin_fmaxf(a, b); }
+    // sqrt(x), correctly rounded.  hipcc expands sqrtf into: scale x by 2**32 if x < 2**-96, v_sqrt_f32 (one unit in the
+    // last place), the two neighbours s-, s+ of that result with the residuals x - s- s and x - s+ s (one fma each) choosing
+    // among the three, unscale, and pass zeros / infinities / NaNs through.  For an ordinary x >= 2**-96 the scaling and
+    // the pass-through are the identity; what is left is issued here -- the same instructions, eight fewer.
+    __device__ __forceinline__ float sqrt_r(float x, bool ok) const
+    {
+        if (!ok) return ::sqrtf(x);
+        const float s = __builtin_amdgcn_sqrtf(x);
+        const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+        const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+        float r = (r_dn <= 0.0f) ? s_dn : s;
+        r = (r_up > 0.0f) ? s_up : r;
+        return r;
+    }
     __device__ __forceinline__ bool fast_ok(float h, float h_in, float h_over) const
     {
 #if TRMC_EXPERIMENT_DIV != 1
@@ -260,6 +288,10 @@ struct DevMathD {
     }
     __device__ __forceinline__ double div1(double a, double b, bool) const { return a / b; }
     __device__ __forceinline__ double divx(double a, double b) const { return a / b; }
+    // (only the in-bank body uses these, which this policy never takes: kInbank = false)
+    __device__ __forceinline__ double k_of(double dx, double ck) const { return dx / ck; }
+    __device__ __forceinline__ double max_num(double a, double b) const { return a > b ? a : b; }
+    __device__ __forceinline__ double sqrt_r(double x, bool) const { return ::sqrt(x); }
     __device__ __forceinline__ void div4(double n1, double n2, double n3, double n4, double d, double &q1, double &q2,
                                          double &q3, double &q4) const
     {
@@ -1900,13 +1932,17 @@ template <class T> int upload_params(trmc_plan *pl, const float *params)
     // a benign channel for the padding lanes (never routed, never read back)
     bool sane = true;
     auto in_range = [](float v) { return v >= 0x1p-14f && v <= 0x1p17f; };
+    auto within = [](float v, float lo, float hi) { return v >= lo && v <= hi; };
     for (int64_t p = 0; p < n; ++p) {
         const float *src = params + (size_t)pl->topo.row_of_pos[p] * TRMC_NPARAM;
         for (int c = 0; c < TRMC_NPARAM; ++c) host[(size_t)c * np + p] = (T)src[c];
         const float cs = src[TRMC_P_CS];
         // (the operands of those divisions are made of bw, the side slope, n, ncc, twcc and the depth only)
         sane = sane && in_range(src[TRMC_P_BW]) && in_range(src[TRMC_P_N]) && (cs == 0.0f || in_range(cs))
-               && (src[TRMC_P_TWCC] == 0.0f || in_range(src[TRMC_P_TWCC])) && (src[TRMC_P_NCC] == 0.0f || in_range(src[TRMC_P_NCC]));
+               && (src[TRMC_P_TWCC] == 0.0f || in_range(src[TRMC_P_TWCC])) && (src[TRMC_P_NCC] == 0.0f || in_range(src[TRMC_P_NCC]))
+               // (... and the Muskingum K of an in-bank point of dt, dx, s0 too: DevMathF::k_of)
+               && within(src[TRMC_P_DT], 0x1p-20f, 0x1p40f) && within(src[TRMC_P_DX], 0x1p-10f, 0x1p19f)
+               && within(src[TRMC_P_S0], 0x1p-30f, 0x1p10f);
     }
     pl->params_sane = sane && sizeof(T) == 4;
     if (int rc = pl->params.ensure(all_cols * sizeof(T))) return rc;
@@ -2102,7 +2138,10 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         // -- and K = 12: 17.5 ms; eight levels 16.9; six 16.6; five 16.5 with K = 12 and 16.25 with K = 16; four 16.6; three 16.9;
         // K = 24: 17.0.  Fewer wide levels shorten the ramps of the level skew and give the tail launches more rows to fill the
         // device with after the last tile; the threshold that picks five levels there is 30 % of the rows the device holds at
-        // five wavefronts per SIMD.)
+        // five wavefronts per SIMD.  Spans of unequal length -- short ones at the window's start and end, so that the tail
+        // starts 2 ms earlier and ends closer behind the last tile -- were built and measured: 16.6-17.0 ms against 16.5-16.7,
+        // no gain: the tail falls behind in mid-window whenever it starts; nor does holding the tiles at four or four and a half
+        // wavefronts per SIMD so that a tail wavefront always finds a slot, 16.7 / 17.05 ms.)
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
         const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 384L * ncu), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
