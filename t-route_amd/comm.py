@@ -166,17 +166,63 @@ def default_key():
     return f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
 
 
+_PROBE = """
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from troute_amd import comm as X
+c = X.Comm({rank}, {world}, {device}, backend="rccl", key={key!r})
+send = X.DeviceBuffer.from_array({device}, np.full(256, {rank}, np.uint8))
+recv = X.DeviceBuffer({device}, 256 * {world})
+st = X.stream_create({device})
+c.all_gather(send.ptr, recv.ptr, 256, st)
+got = recv.download(({world}, 256), np.uint8, st)
+assert (got == np.arange({world}, dtype=np.uint8)[:, None]).all()
+c.barrier()
+c.close()
+"""
+
+
+def probe_rccl(rank, world, device, key, timeout=None):
+    """Can the ranks of this launch start RCCL and move a block through it?  Tried in a CHILD process per rank (the children
+    form the same collective), under a time-out: a communicator that cannot start on this node (no peer access, a
+    device shared by two ranks, a driver without the IPC mode RCCL needs) fails or hangs THERE, not in the job."""
+    import subprocess
+    import sys
+    if timeout is None:
+        timeout = float(os.environ.get("TRMC_COMM_PROBE_TIMEOUT_S", "90"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _PROBE.format(root=root, rank=int(rank), world=int(world), device=int(device), key=str(key))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+        return r.returncode == 0
+    except subprocess.TimeoutExpired:
+        return False
+
+
 class Comm:
-    """One rank's handle.  backend: "rccl" | "shm" | "auto" (RCCL when every rank of the node has its own device)."""
+    """One rank's handle.  backend: "rccl" | "shm" | "auto" | "probe".
+    "auto": RCCL when every rank of the node has a device of its own AND a probe of it succeeds on every rank (probe_rccl;
+    the verdicts are agreed over a shared-memory control communicator), else the shared-memory transport.  "probe": the
+    same without counting devices (what the tests use to walk the fall-back on a one-GPU box)."""
 
     def __init__(self, rank, world, device, backend="auto", key=None, shm_bytes=0):
         self.rank, self.world, self.device = int(rank), int(world), int(device)
         key = key or default_key()
         lib = _lib.lib()
         ndev = _lib.device_count()
-        auto = backend == "auto"
+        auto = backend in ("auto", "probe")
         if auto:
-            backend = "rccl" if (ndev >= world and world > 1) else "shm"
+            want = world > 1 and self.device >= 0 and (backend == "probe" or ndev >= world)
+            backend = "shm"
+            if want and os.environ.get("TRMC_COMM_PROBE", "1") != "0":
+                ctl = Comm(rank, world, -1, backend="shm", key=f"{key}_ctl", shm_bytes=1 << 16)
+                ok = probe_rccl(rank, world, self.device, f"{key}_probe")
+                agreed = bool(ctl.all_gather_host(np.array([1 if ok else 0], np.int32)).all())
+                ctl.close()
+                backend = "rccl" if agreed else "shm"
+            elif want:
+                backend = "rccl"
         h = C.c_void_p(0)
         if backend == "rccl":
             def make_id():

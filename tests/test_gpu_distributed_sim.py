@@ -82,3 +82,33 @@ def _two_ranks(short, nchunks, retune):
     for rows, hyd, _, _ in results:
         assert np.array_equal(rows, rows1)
         assert np.array_equal(hyd.view(np.uint32), hyd1.view(np.uint32))
+
+
+def _probe_worker(rank, world, key, tmp):
+    import numpy as np
+    from troute_amd import comm as X
+    c = X.Comm(rank, world, device=0, backend="probe", key=key)
+    send = X.DeviceBuffer.from_array(0, np.full(64, rank + 1, np.uint8))
+    recv = X.DeviceBuffer(0, 64 * world)
+    st = X.stream_create(0)
+    c.all_gather(send.ptr, recv.ptr, 64, st)
+    got = recv.download((world, 64), np.uint8, st)
+    assert (got == (np.arange(world, dtype=np.uint8) + 1)[:, None]).all()
+    c.barrier()
+    open(os.path.join(tmp, f"backend_{rank}"), "w").write(c.backend)
+    c.close()
+
+
+def test_communicator_probes_rccl_and_falls_back_when_it_cannot_start(tmp_path):
+    """backend="probe" (what "auto" does when every rank has a device): RCCL is tried in a child process per rank under a
+    time-out, the verdicts are agreed, and the job's communicator is RCCL only if it started everywhere.  Two ranks that
+    SHARE device 0 -- RCCL refuses that -- must agree on the shared-memory transport and still gather correctly."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    key = f"p{os.getpid()}"
+    ps = [ctx.Process(target=_probe_worker, args=(r, 2, key, str(tmp_path))) for r in range(2)]
+    [p.start() for p in ps]
+    [p.join(300) for p in ps]
+    assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    backends = [open(tmp_path / f"backend_{r}").read() for r in range(2)]
+    assert backends[0] == backends[1] and backends[0] in ("shm", "rccl"), backends
