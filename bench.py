@@ -506,6 +506,21 @@ def main():
         router.close()
         router = make_router(hint, True, qlat_s, q0)
         spin_up(router, True)
+        # Multi-GPU: the pace of a rank depends on what it carries (a trunk owner's drain weighs more the fewer sub-basins
+        # it has beside it), so the partition is fed back once more -- the paces of the ranks on the HINTED plan, measured
+        # on the day-N window the spin-up has just routed -- unless the ranks already finish within 4 % of each other.
+        feedback = []
+        for _ in range(int(os.environ.get("TRMC_BENCH_REBALANCE", "2")) if comm is not None else 0):
+            cost_mine = float(hint[np.concatenate([router.rows0, router.rows1])].astype(np.float64).sum())
+            lt = comm.all_gather_host(np.array([cost_mine, router.last_stats["phase0"]["ms_main"]], dtype=np.float64))
+            feedback.append([round(float(x), 3) for x in lt[:, 1]])
+            if lt[:, 1].max() <= 1.04 * lt[:, 1].mean():
+                break
+            tuned["speed"], tuned["part"] = sharding.rank_speeds(lt[:, 0], lt[:, 1]), router.part
+            router.close()
+            router = make_router(hint, True, qlat_s, q0)
+            spin_up(router, True)
+        tuned["feedback_ms"] = feedback
         router.upload(a.nsteps, qlat_b, None)
         t_tune += time.perf_counter() - t0
 
@@ -690,6 +705,7 @@ def main():
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
                 "transport": None if comm is None else comm.backend,
                 "rank_pace_on_tuning_day": None if tuned["speed"] is None else [round(float(x), 3) for x in tuned["speed"]],
+                "rank_ms_before_each_rebalance": tuned.get("feedback_ms"),
                 "engine": engine,
                 "generate_s": round(t_gen, 2), "plan_s": round(t_plan, 2),
                 "plan_order": "rows grouped by their secant-iteration cost over day N (untimed tuning window); timed on day N+1"

@@ -48,8 +48,8 @@ def draw(rng, nseg, regime):
         bw = logu(lo * 1.01, hi * 0.2, nseg)
         n = logu(lo * 1.01, 0.5, nseg)
         cs = logu(lo * 1.01, hi * 0.99, nseg)
-        s0 = logu(1e-7, 1.0, nseg)
-        dx = logu(1.0, 1e6, nseg)
+        s0 = logu(2.0 ** -30 * 1.01, 2.0 ** 10 * 0.99, nseg)    # (the whole range the fast Muskingum K admits: DevMathF::k_of)
+        dx = logu(2.0 ** -10 * 1.01, 2.0 ** 19 * 0.99, nseg)
         depth = logu(1e-12, 1e4, nseg)
     elif regime == "straddle":
         bw = logu(lo * 0.25, hi * 4.0, nseg)

@@ -26,8 +26,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ranks", type=str, default=None, help="comma list (default: all)")
     ap.add_argument("--retune", action="store_true", help="rebuild every router with the cost hint of a tuning window")
-    ap.add_argument("--rebalance", action="store_true", help="time all ranks, repartition by their measured pace "
-                    "(sharding.partition rank_speed, what bench.py does after its tuning window), time them again")
+    ap.add_argument("--rebalance", type=int, nargs="?", const=1, default=0, help="time all ranks, repartition by their "
+                    "measured pace (sharding.partition rank_speed, what bench.py does after its tuning window), time them "
+                    "again; N: that many feedback steps (bench.py takes up to two more on the hinted plan)")
     a = ap.parse_args()
     from troute_amd import comm as X
     from troute_amd import sharding, synthetic
@@ -71,14 +72,14 @@ def main():
 
     passes = [part]          # (the partition the cut-edge hydrographs above belong to keeps its cut rows: same trunks)
     times_of = {}
-    for ipass in range(2 if a.rebalance else 1):
-      if ipass == 1:
+    for ipass in range(1 + a.rebalance):
+      if ipass >= 1:
         cost = hint.astype(np.float64) if hint is not None else np.ones(nseg)
-        own = passes[0]["owner"][passes[0]["piece"]]
+        own = part["owner"][part["piece"]]
         loads = np.bincount(own, weights=cost, minlength=a.world)
         speed = sharding.rank_speeds(loads, [times_of[k] for k in range(a.world)])
         print("measured pace of the ranks:", np.round(speed, 3))
-        part = sharding.partition(to, a.world, row_cost=hint, rank_speed=speed, previous=passes[0])
+        part = sharding.partition(to, a.world, row_cost=hint, rank_speed=speed, previous=part)
       worst = 0.0
       for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
           r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
