@@ -2141,7 +2141,11 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         // five wavefronts per SIMD.  Spans of unequal length -- short ones at the window's start and end, so that the tail
         // starts 2 ms earlier and ends closer behind the last tile -- were built and measured: 16.6-17.0 ms against 16.5-16.7,
         // no gain: the tail falls behind in mid-window whenever it starts; nor does holding the tiles at four or four and a half
-        // wavefronts per SIMD so that a tail wavefront always finds a slot, 16.7 / 17.05 ms.)
+        // wavefronts per SIMD so that a tail wavefront always finds a slot, 16.7 / 17.05 ms.  Every wide level on a stream of
+        // its own, one launch per (level, span), up to five in flight on eight hardware queues: the wide rows are done at
+        // 12.0 ms instead of 14.6, but the tail's launches then take 60 us instead of 48 and end at 18.2-19.9 ms, and the host
+        // needs some 50 us for every launch that waits for another stream's event.  The first two upstream flows of a
+        // tile's step loaded a step ahead: 16.8-16.9 ms.  All removed again.)
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
         const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 384L * ncu), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
