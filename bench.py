@@ -753,7 +753,8 @@ def pmc_counters(pattern, launches_per_window, args):
     if exe is None:
         return {}
     vals, out = {}, {}
-    passes = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"))
+    passes = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_CYCLES"))
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             for i, counters in enumerate(passes):
@@ -812,6 +813,12 @@ def pmc_counters(pattern, launches_per_window, args):
             "instructions_per_launch": insts, "wavefronts_per_launch": waves,
             "cycles_per_instruction": 4.0 * active / insts,
             "busy_frac": (4.0 * active / n_simd) / (vals["SQ_BUSY_CYCLES"] / n_se),
+            # SQ_BUSY_CYCLES under-counts the cycles of a launch by about a tenth on this part (the device runs this load at
+            # 2.27 GHz by rocm-smi, SQ_BUSY_CYCLES / duration says 2.0): the same ratio over SQ_CYCLES is the honest one
+            "busy_frac_of_all_cycles": (4.0 * active / n_simd) / (vals["SQ_CYCLES"] / max(vals.get("SQ_CYCLES#inst", 32.0), 1.0)),
+            "clock_ghz_sq_cycles": vals["SQ_CYCLES"] / max(vals.get("SQ_CYCLES#inst", 32.0), 1.0) / (vals["avg_us_2"] * 1e3),
+            "mean_resident_wavefronts_per_simd": 4.0 * vals["SQ_WAVE_CYCLES"] / n_simd
+                                                 / (vals["SQ_CYCLES"] / max(vals.get("SQ_CYCLES#inst", 32.0), 1.0)),
             "launch_us_under_counters": vals["avg_us_2"],
             "how": "SQ_INSTS_VALU / SQ_WAVES / steps per launch; 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU; (4 x SQ_ACTIVE_INST_VALU / "
                    f"{n_simd} SIMDs) / (SQ_BUSY_CYCLES / {int(n_se)} instances); last window's launches of {pattern}",
