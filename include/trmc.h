@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 9
+#define TRMC_ABI_VERSION 10
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -365,6 +365,19 @@ int trmc_route(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_sho
  * as reach.pyx:55 passes it.
  */
 int trmc_segments(int device, int precision, int64_t n, const void *in, void *out);
+
+/*
+ * Self-check, on the device, of the short exact forms the fp32 step takes under its range proofs (csrc/trmc.hip,
+ * DevMathF: sqrt_r, k_of / quot, max_num) against the plain correctly rounded operations they stand for:
+ *   what = 0   sqrt(x) for EVERY float x in [2**-60, 2**63], the range of the velocity's radicand under fast_ok
+ *              (n and seed are ignored)
+ *   what = 1   a / b and max(c, a / b) for n pseudo-random triples drawn from `seed`: a in [2**-10, 2**19] (dx), b in
+ *              [2**-76, 2**62] (the celerity of an in-bank point), c in [2**-20, 2**40] (dt) -- significands uniform
+ *              over all 2**23, exponents uniform over the ranges, both ends included
+ * checked_out receives the number of values / triples compared, mismatches_out how many results differ in any bit
+ * (0 is the claim).  No routing state is touched.
+ */
+int trmc_selfcheck_fast_arith(int device, int what, int64_t n, uint64_t seed, int64_t *checked_out, int64_t *mismatches_out);
 
 /*
  * ---- communicator: the ranks of a multi-GPU job on one node (one process, or thread, per rank) ------------------

@@ -2756,6 +2756,51 @@ template <class T> int segments_t(int64_t n, const void *in, void *out)
     return rc;
 }
 
+// trmc_selfcheck_fast_arith: the short forms of DevMathF against the operations they stand for (see trmc.h)
+__global__ void __launch_bounds__(kBlock)
+k_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatches)
+{
+    DevMathF m{nullptr, false};
+    unsigned long long bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t b = (uint64_t)lo_bits + (uint64_t)blockIdx.x * kBlock + threadIdx.x; b <= hi_bits; b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        bad += __float_as_uint(m.sqrt_r(x, true)) != __float_as_uint(::sqrtf(x));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+__device__ __forceinline__ uint64_t selfcheck_mix(uint64_t z) // splitmix64
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+// a float with a uniform significand and an exponent uniform over [e_lo, e_hi] (2**e_hi itself included as the top value)
+__device__ __forceinline__ float selfcheck_draw(uint64_t r, int e_lo, int e_hi)
+{
+    const uint32_t span = (uint32_t)(e_hi - e_lo);
+    const uint32_t e = (uint32_t)((r >> 32) % (span + 1));
+    const uint32_t frac = e == span ? 0u : (uint32_t)r & 0x7fffffu;
+    return __uint_as_float(((uint32_t)(e_lo + (int)e + 127) << 23) | frac);
+}
+__global__ void __launch_bounds__(kBlock)
+k_selfcheck_div(int64_t n, uint64_t seed, unsigned long long *mismatches)
+{
+    DevMathF m{nullptr, false};
+    unsigned long long bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t r0 = selfcheck_mix(seed + 3 * (uint64_t)i), r1 = selfcheck_mix(seed + 3 * (uint64_t)i + 1),
+                       r2 = selfcheck_mix(seed + 3 * (uint64_t)i + 2);
+        const float a = selfcheck_draw(r0, -10, 19), b = selfcheck_draw(r1, -76, 62), c = selfcheck_draw(r2, -20, 40);
+        const float q_fast = m.k_of(a, b), q = a / b;
+        const float k_fast = m.max_num(c, q_fast), k = c > q ? c : q;
+        bad += (__float_as_uint(q_fast) != __float_as_uint(q)) || (__float_as_uint(k_fast) != __float_as_uint(k));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 int check_device(int device)
 {
     int count = 0;
@@ -3738,6 +3783,38 @@ int trmc_segments(int device, int precision, int64_t n, const void *in, void *ou
     if (int rc = check_device(device)) return rc;
     HIP_TRY(hipSetDevice(device));
     return precision == 32 ? segments_t<float>(n, in, out) : segments_t<double>(n, in, out);
+}
+
+int trmc_selfcheck_fast_arith(int device, int what, int64_t n, uint64_t seed, int64_t *checked_out, int64_t *mismatches_out)
+{
+    if (!checked_out || !mismatches_out) return fail(TRMC_EINVAL, "checked_out/mismatches_out is NULL");
+    if (what != 0 && what != 1) return fail(TRMC_EINVAL, "what must be 0 (square root) or 1 (division, maximum)");
+    if (what == 1 && n < 0) return fail(TRMC_EINVAL, "n < 0");
+    if (int rc = check_device(device)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf cnt;
+    if (int rc = cnt.ensure(sizeof(unsigned long long))) return rc;
+    hipError_t e = hipMemset(cnt.p, 0, sizeof(unsigned long long));
+    int64_t checked = 0;
+    if (e == hipSuccess) {
+        if (what == 0) {
+            const uint32_t lo = (uint32_t)(127 - 60) << 23, hi = (uint32_t)(127 + 63) << 23; // 2**-60 .. 2**63 inclusive
+            checked = (int64_t)hi - (int64_t)lo + 1;
+            hipLaunchKernelGGL(k_selfcheck_sqrt, dim3(8192), dim3(kBlock), 0, 0, lo, hi, (unsigned long long *)cnt.p);
+        } else {
+            checked = n;
+            if (n > 0) hipLaunchKernelGGL(k_selfcheck_div, dim3(8192), dim3(kBlock), 0, 0, n, seed, (unsigned long long *)cnt.p);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, cnt.p, sizeof bad, hipMemcpyDeviceToHost);
+    cnt.release();
+    if (e != hipSuccess) return fail(TRMC_EHIP, std::string("trmc_selfcheck_fast_arith: ") + hipGetErrorString(e));
+    *checked_out = checked;
+    *mismatches_out = (int64_t)bad;
+    return 0;
 }
 
 } // extern "C"

@@ -648,3 +648,20 @@ def test_resident_warm_start_between_windows(lc):
             b2 = plan.route(144, 12, short, lc.qlat[:, 12:24], state)   # host round trip
         assert_bit_identical(a2, b2, "resident vs re-uploaded warm start")
         assert_bit_identical(np.concatenate([a1, a2], 1), whole, f"two windows vs one (short={short})")
+
+
+def test_short_exact_forms_equal_the_operations_they_stand_for():
+    """The fp32 step takes short forms of sqrt, division and max where its range proofs hold (csrc/trmc.hip, DevMathF:
+    sqrt_r -- v_sqrt_f32 and its two residual corrections without the scaling and the special-value pass-through;
+    k_of -- the refinement of a reciprocal without v_div_scale / v_div_fmas / v_div_fixup; max_num -- v_max).  On the
+    device itself: sqrt over EVERY float of the admitted range [2**-60, 2**63] and 2**32 pseudo-random (dx, celerity, dt)
+    triples over the whole admitted exponent ranges, ends included, must not differ from sqrtf, `/` and the select in one
+    bit."""
+    import ctypes as C
+    lib = _lib.lib()
+    checked, bad = C.c_int64(0), C.c_int64(-1)
+    _lib.check(lib.trmc_selfcheck_fast_arith(0, 0, 0, 0, C.byref(checked), C.byref(bad)))
+    assert checked.value == (123 << 23) + 1 and bad.value == 0, (checked.value, bad.value)
+    for seed in (1, 0x9e3779b97f4a7c15):
+        _lib.check(lib.trmc_selfcheck_fast_arith(0, 1, 1 << 32, seed, C.byref(checked), C.byref(bad)))
+        assert checked.value == 1 << 32 and bad.value == 0, (seed, checked.value, bad.value)
