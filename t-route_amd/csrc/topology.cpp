@@ -12,7 +12,7 @@ namespace trmc {
 
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows,
-                   bool cost_tiers)
+                   bool cost_tiers, int32_t boundary_floor)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -78,8 +78,13 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             continue;
         }
         ++nrouted;
+        int32_t lvl0 = 0;
+        if (boundary_floor > 0 && block_rows == 0)
+            for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k)
+                if (is_b(up_idx[k])) lvl0 = boundary_floor;
+        if (lvl0 > 0) t.level_of_row[r] = lvl0; // (a floor under whatever its routed upstream rows will say)
         if (indeg[r] == 0) {
-            t.level_of_row[r] = 0;
+            t.level_of_row[r] = lvl0;
             queue.push_back((int32_t)r);
         }
     }

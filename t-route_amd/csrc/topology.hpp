@@ -59,8 +59,13 @@ struct Topology {
 // counts is that a block's rows are close in the network, not close in cost (k_mc_flow).  Reference analogue of the order: dfs_decomposition's
 // "every reach's upstream reaches precede it" (nhd_network.py:503-557); of the blocks: build_subnetworks
 // (nhd_network.py:691-771), here a few hundred rows instead of 10 000 and pipelined in time instead of by order.
+// boundary_floor (level order only): a routed row with a boundary row among its upstream rows gets at least this level.
+// Boundary rows constrain nothing, so the rows they feed would otherwise be headwaters of the level order -- level 0, among
+// the widest levels, the ones the level engine routes several timesteps per launch ahead of the window's progress
+// (k_mc_tile); rows whose inflow arrives chunk by chunk during the window (the trunk of a cut basin, distributed.py) must
+// stay out of those.  Levels between may be empty; results do not depend on it.
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr,
-                   int32_t block_rows = 0, bool cost_tiers = true);
+                   int32_t block_rows = 0, bool cost_tiers = true, int32_t boundary_floor = 0);
 
 } // namespace trmc

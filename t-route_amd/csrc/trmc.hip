@@ -576,6 +576,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 // of every step (what downstream rows and the gathers read) and the depth row of a tile's last step (where the row's next
 // tile, or the final state, picks it up) are written.
 constexpr int kTileStage = 8;
+constexpr int32_t kWideMaxLevels = 16; // at most this many leading levels are routed by k_mc_tile (TRMC_WIDE_LEVELS is capped by it)
 #ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow.  Measured on the CONUS day by
 // padding the blocks' LDS (TRMC_TILE_LDS_PAD) and by this cap: 1 wavefront per SIMD 36.7 ms, 2: 23.9, 3: 20.7, 3.5: 19.5,
 // 4: 18.45, 5 (95 registers, 4 spilled): 17.9, 6 (80 registers, 27 spilled): 19.4 -- the curve of a kernel that hides its
@@ -1876,6 +1877,7 @@ struct trmc_plan {
     bool params_sane = false;            // see DevMathF::fast_ok
     int32_t cost_nsteps = -1;            // nsteps of the window it_sum was collected over
     int32_t maxlag = 0;                  // trmc_plan_set_lag: rows routed `maxlag` launches behind the others
+    int64_t wide_safe_pos = -1;          // first plan position that is lagged or fed by a boundary row (-1: not looked for yet)
     std::vector<int32_t> lag_of_row;
     DevBuf gage_of_pos, da_mode, da_a, da_w, da_nudge; // nudging tables of the staged window
     DevBuf res_of_pos, res_par, res_inflow;             // level-pool reservoirs of the plan
@@ -2129,7 +2131,19 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     // (wide rows run ahead of the window's progress) and no lagged rows (the multi-GPU trunk has its own skew).
     // TRMC_WIDE_MIN_ROWS (rows a level must have, default 384 per compute unit; 0 switches the path off), TRMC_WIDE_LEVELS (at
     // most, default 16) and TRMC_WIDE_K (steps per launch, default 16) are measurement / test knobs.
-    if (short_ts && pl->maxlag == 0 && r.boundary_through == nsteps && pl->nrouted > 0) {
+    // Rows with a lag (the trunk of a cut basin riding in its owner's launches) and rows fed by boundary rows whose values
+    // arrive chunk by chunk stay in the TAIL: the leading levels are only routed ahead if none of them is among their rows
+    // (plans built for assume_short_ts keep such rows below level kWideMaxLevels: topology.hpp, boundary_floor).
+    if (pl->wide_safe_pos < 0) { // first plan position that is lagged or reads a boundary row (host arrays; once per plan / lag)
+        int64_t first = pl->nseg;
+        for (int64_t p = tp.nboundary; p < pl->nseg && first == pl->nseg; ++p) {
+            bool unsafe = pl->maxlag > 0 && !pl->lag_of_row.empty() && pl->lag_of_row[(size_t)tp.row_of_pos[p]] != 0;
+            for (int32_t k = tp.up_ptr[p]; !unsafe && k < tp.up_ptr[p + 1]; ++k) unsafe = tp.up_idx[k] < tp.nboundary;
+            if (unsafe) first = p;
+        }
+        pl->wide_safe_pos = first;
+    }
+    if (short_ts && pl->nrouted > 0) {
         auto env_int = [](const char *name, long dflt) {
             const char *e = std::getenv(name);
             return e && *e ? std::atol(e) : dflt;
@@ -2150,8 +2164,11 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
         const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 384L * ncu), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
         int32_t W = 0;
+        const bool all_in_place = pl->maxlag == 0 && r.boundary_through == nsteps; // (then every level may run ahead)
         if (min_rows > 0)
-            while (W < tp.nlevels && W < max_levels && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows) ++W;
+            while (W < tp.nlevels && W < std::min<long>(max_levels, kWideMaxLevels) && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows
+                   && (all_in_place || (int64_t)tp.lvl_ptr[W + 1] <= pl->wide_safe_pos))
+                ++W;
         if (W > 0) {
             r.wide = W;
             r.wide_k = (int32_t)std::max(1L, std::min((long)nsteps, env_int("TRMC_WIDE_K", std::max(1, std::min(16, nsteps / 8)))));
@@ -2227,11 +2244,15 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                 r.wide_next = ntile;
                 r.wide_through = -1; // (from here on: the last tile the tail has been told to wait for)
             }
+            // (with lagged rows -- always in the tail, route_begin_t -- launch t routes the tail's other rows at step t and the
+            // lagged ones at step t - maxlag, and the window ends at launch nsteps + maxlag: k_mc_step's LAG form)
+            const int32_t lagmax = pl->maxlag;
             for (int32_t t = t0 + 1; t <= t_end; ++t) {
                 if (tail) {
                     // the last wide level has completed step t - 1 after tile ceil((t - 1) / K) + W - 2 ... and, with it,
                     // through step ceil((t - 1) / K) K: the tail waits once per K steps
-                    const int32_t need = t == 1 ? -1 : (t - 2) / K + W - 1; // tile index; none for the first step (state only)
+                    const int32_t tn = std::min(t, nsteps);
+                    const int32_t need = tn == 1 ? -1 : (tn - 2) / K + W - 1; // tile index; none for the first step (state only)
                     if (need > r.wide_through) {
                         HIP_TRY(hipStreamWaitEvent(st, pl->wide_t1[(size_t)std::min(need, ntile - 1)], 0));
                         r.wide_through = need;
@@ -2239,11 +2260,21 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     launch_step<T, true>(st, a, w1, s1, t);
                     ++r.launches;
                 }
-                if (t % kTile == 0 && t < nsteps)
-                    if (int rc = emit_tiles_through<T>(pl, t)) return rc;
+                const int32_t t_all = t - lagmax; // every row has reached step t_all
+                if (t_all > 0 && t_all % kTile == 0 && t_all < nsteps)
+                    if (int rc = emit_tiles_through<T>(pl, t_all)) return rc;
             }
-            HIP_TRY(hipEventRecord(pl->ev_tail, ws));
-            HIP_TRY(hipStreamWaitEvent(st, pl->ev_tail, 0));
+            // what the caller queues next on the plan's stream (a gather of cut-edge flows through t_end, the next window) must
+            // see every WIDE row at t_end too: the tile that completes the last wide level through that step -- not every
+            // tile queued, they are all queued up front and a chunk's hand-off must not wait for the window's last tile
+            {
+                const int32_t te = std::min(t_end, nsteps);
+                const int32_t need_end = te <= 0 ? -1 : std::min((te - 1) / K + W - 1, ntile - 1);
+                if (need_end >= 0 && need_end > r.wide_through) {
+                    HIP_TRY(hipStreamWaitEvent(st, pl->wide_t1[(size_t)need_end], 0));
+                    r.wide_through = need_end;
+                }
+            }
         } else if (r.short_ts) {
             const int32_t s0 = tp.lvl_ptr[0], s1 = tp.lvl_ptr[L];
             const int32_t lagmax = pl->maxlag;
@@ -2930,7 +2961,10 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
     }
     const bool tiers = (flags & TRMC_PLAN_SHORT_TS) != 0;
     std::string err;
-    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0, tiers);
+    // (plans meant for assume_short_ts on the level engine: rows fed by boundary rows stay below the levels that may be routed
+    // several timesteps per launch -- topology.hpp, boundary_floor; TRMC_WIDE_LEVELS never asks for more than kWideMaxLevels)
+    const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0, tiers,
+                                         (tiers && !pl->flow) ? kWideMaxLevels : 0);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
@@ -3441,6 +3475,7 @@ int trmc_plan_set_lag(trmc_plan *pl, const int32_t *lag_of_row)
     if (!pl->rowsets.empty()) return fail(TRMC_ESTATE, "set the lag before registering row sets");
     pl->maxlag = 0;
     pl->lag_of_row.clear();
+    pl->wide_safe_pos = -1;
     if (!lag_of_row) return 0;
     int32_t mx = 0;
     for (int64_t r = 0; r < pl->nseg; ++r) {

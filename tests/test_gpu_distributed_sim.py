@@ -32,11 +32,24 @@ def test_two_ranks_with_chunk_overlap_on_two_streams(monkeypatch):
     _two_ranks(True, None, True)
 
 
-def _two_ranks(short, nchunks, retune):
+@pytest.mark.parametrize("nchunks,retune,wide_k", [(None, False, 4), (6, False, 8), (3, True, 4), (1, False, 4)])
+def test_two_ranks_on_the_level_engine_with_wide_tiles_beside_a_lagged_trunk(monkeypatch, nchunks, retune, wide_k):
+    """The trunk's owner on the level engine: its lagged rows (and the rows the cut-edge boundary rows feed) stay in the
+    tail, so the leading levels of its merged plan are still routed several timesteps per launch ahead of the window
+    (k_mc_tile) while the trunk rides `lag` launches behind in the tail's LAG form -- the same bits as one rank, whatever
+    the chunking of the hand-off."""
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
+    monkeypatch.setenv("TRMC_WIDE_K", str(wide_k))
+    used = _two_ranks(True, nchunks, retune, engine="levels", nsteps=36)
+    assert any(w > 0 for w in used), used        # at least one rank (the trunk's owner among them) took the wide path
+
+
+def _two_ranks(short, nchunks, retune, engine=None, nsteps=24):
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
     q0 = np.zeros((nseg, 3), np.float32)
-    nsteps, qts = 24, 12
+    qts = 12
+    kw = {} if engine is None else {"engine": engine, "assume_short_ts": short}
 
     single = ShardedRouter(net["to"], net["params"])
     single.upload(nsteps, net["qlat"], q0)
@@ -52,7 +65,7 @@ def _two_ranks(short, nchunks, retune):
     def run(rank):
         try:
             comm = Comm(rank, world, device=0, backend="shm", key=key)
-            r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0)
+            r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0, **kw)
             r.enable_device_exchange(comm)
             r.upload(nsteps, net["qlat"], q0)
             r.upload_trunk()
@@ -62,13 +75,14 @@ def _two_ranks(short, nchunks, retune):
                 hint = comm.all_reduce_max_host(r.iteration_hint())   # every rank measured its own rows
                 assert hint.max() > 0
                 r.close()
-                r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0, cost_hint=hint)
+                r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0, cost_hint=hint, **kw)
                 r.enable_device_exchange(comm)
                 r.upload(nsteps, net["qlat"], q0)
                 r.upload_trunk()
             for _ in range(2):                          # twice: the staged buffers must be reusable
                 rows, hyd = r.route_on_device(qts, short, nchunks)
-            results[rank] = (rows, hyd.numpy(), r.cut_rows.shape[0], r.plan1 is not None)
+            results[rank] = (rows, hyd.numpy(), r.cut_rows.shape[0], r.plan1 is not None,
+                             (r.plan1 is not None, r.last_stats["phase0"].get("wide_levels", 0)))
             r.close()
             comm.close()
         except Exception as e:                          # pragma: no cover
@@ -79,9 +93,11 @@ def _two_ranks(short, nchunks, retune):
     [t.join() for t in ts]
     assert not errors, errors
     assert results[0][2] > 0 and (results[0][3] or results[1][3])
-    for rows, hyd, _, _ in results:
+    for rows, hyd, _, _, _ in results:
         assert np.array_equal(rows, rows1)
         assert np.array_equal(hyd.view(np.uint32), hyd1.view(np.uint32))
+    owners = [res[4][1] for res in results if res[4][0]]
+    return owners if owners else [res[4][1] for res in results]
 
 
 def _probe_worker(rank, world, key, tmp):
