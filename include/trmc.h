@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 10
+#define TRMC_ABI_VERSION 11
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -101,9 +101,14 @@ int trmc_device_count(int *count);
  *             (mc_reach.pyx:499-502: upstream_connections[reach[0]] for the
  *             head of a reach, the previous segment inside a reach)
  *   params    [nseg][TRMC_NPARAM] float (always float: compute.py:549)
- *   boundary  [nseg] or NULL; non-zero marks a row that is not routed but
+ *   boundary  [nseg] or NULL; 1 marks a row that is not routed but
  *             carries a prescribed hydrograph (the reference's
- *             upstream_results rows, mc_reach.pyx:451-469)
+ *             upstream_results rows, mc_reach.pyx:451-469); 2 marks a
+ *             ROUTED row that a short-timestep plan of the level engine
+ *             keeps out of its leading levels -- the ones routed several
+ *             timesteps per launch ahead of the window -- like the rows
+ *             boundary rows feed (rows that will carry a lag,
+ *             trmc_plan_set_lag); results do not depend on it
  *   precision 32 or 64
  *   device    HIP device ordinal
  */
@@ -424,6 +429,11 @@ int trmc_dev_download_async(int device, void *dst_host, const void *src_dev, int
 int trmc_dev_gather_rows(int device, const void *src_dev, const int64_t *index_dev, int64_t nrows, int64_t row_bytes,
                          void *dst_dev, void *stream);
 int trmc_stream_create(int device, void **stream_out);
+/* ... with a priority: -1 low, 0 ordinary, +1 high (clamped to what the device offers).  A plan's own streams are: step
+ * launches high, wide tiles ordinary, result transpose and result copies low; with one hardware queue per priority
+ * (GPU_MAX_HW_QUEUES=1, which troute_amd sets) a caller's stream shares the queue of the plan stream of its priority, and
+ * work in it that waits for an event holds back what was queued behind it in that queue. */
+int trmc_stream_create_prio(int device, int priority, void **stream_out);
 int trmc_stream_destroy(int device, void *stream);
 int trmc_stream_synchronize(int device, void *stream);
 int trmc_device_synchronize(int device);

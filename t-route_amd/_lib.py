@@ -99,6 +99,7 @@ SIGNATURES = {
     "trmc_dev_download_async": (_int, [_int, _vp, _vp, _i64, _vp]),
     "trmc_dev_gather_rows": (_int, [_int, _vp, _vp, _i64, _i64, _vp, _vp]),
     "trmc_stream_create": (_int, [_int, _P(_vp)]),
+    "trmc_stream_create_prio": (_int, [_int, _int, _P(_vp)]),
     "trmc_stream_destroy": (_int, [_int, _vp]),
     "trmc_stream_synchronize": (_int, [_int, _vp]),
     "trmc_device_synchronize": (_int, [_int]),

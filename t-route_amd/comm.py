@@ -80,9 +80,13 @@ class DeviceArray:
         return out
 
 
-def stream_create(device):
+def stream_create(device, priority=None):
+    """priority: None (ordinary, the runtime's default), -1 low, 0 ordinary, +1 high"""
     s = C.c_void_p(0)
-    _check(_lib.lib().trmc_stream_create(int(device), C.byref(s)))
+    if priority is None:
+        _check(_lib.lib().trmc_stream_create(int(device), C.byref(s)))
+    else:
+        _check(_lib.lib().trmc_stream_create_prio(int(device), int(priority), C.byref(s)))
     return s.value or 0
 
 

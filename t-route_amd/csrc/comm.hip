@@ -458,6 +458,19 @@ int trmc_stream_create(int device, void **stream_out)
     return 0;
 }
 
+int trmc_stream_create_prio(int device, int priority, void **stream_out)
+{
+    if (!stream_out) return fail_with(TRMC_EINVAL, "stream_out is NULL");
+    *stream_out = nullptr;
+    COMM_HIP_TRY(hipSetDevice(device));
+    int lo = 0, hi = 0; // (numerically: lo is the LEAST urgent, hi the most)
+    COMM_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t s = nullptr;
+    COMM_HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority < 0 ? lo : priority > 0 ? hi : (lo + hi) / 2));
+    *stream_out = (void *)s;
+    return 0;
+}
+
 int trmc_stream_destroy(int device, void *stream)
 {
     if (!stream) return 0;

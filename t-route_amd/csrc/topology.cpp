@@ -38,9 +38,15 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             return -1;
         }
 
+    for (int64_t r = 0; boundary && r < nseg; ++r)
+        if (boundary[r] > 2) {
+            err = "boundary[" + std::to_string(r) + "] must be 0 (routed), 1 (boundary row) or 2 (routed, kept below the leading levels)";
+            return -1;
+        }
     t = Topology();
     t.nseg = nseg;
-    auto is_b = [&](int64_t r) { return boundary && boundary[r] != 0; };
+    auto is_b = [&](int64_t r) { return boundary && boundary[r] == 1; };
+    auto is_late = [&](int64_t r) { return boundary && boundary[r] == 2; }; // a routed row that stays below the leading levels
 
     // downstream CSR over routed rows (edges u -> r for routed r)
     std::vector<int32_t> down_ptr(nseg + 1, 0), indeg(nseg, 0);
@@ -79,9 +85,11 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
         }
         ++nrouted;
         int32_t lvl0 = 0;
-        if (boundary_floor > 0 && block_rows == 0)
+        if (boundary_floor > 0 && block_rows == 0) {
+            if (is_late(r)) lvl0 = boundary_floor;
             for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k)
                 if (is_b(up_idx[k])) lvl0 = boundary_floor;
+        }
         if (lvl0 > 0) t.level_of_row[r] = lvl0; // (a floor under whatever its routed upstream rows will say)
         if (indeg[r] == 0) {
             t.level_of_row[r] = lvl0;

@@ -59,7 +59,9 @@ struct Topology {
 // counts is that a block's rows are close in the network, not close in cost (k_mc_flow).  Reference analogue of the order: dfs_decomposition's
 // "every reach's upstream reaches precede it" (nhd_network.py:503-557); of the blocks: build_subnetworks
 // (nhd_network.py:691-771), here a few hundred rows instead of 10 000 and pipelined in time instead of by order.
-// boundary_floor (level order only): a routed row with a boundary row among its upstream rows gets at least this level.
+// boundary[r]: 0 = routed, 1 = boundary row (prescribed hydrograph), 2 = routed but "late": see boundary_floor.
+// boundary_floor (level order only): a routed row with a boundary row among its upstream rows, or marked late, gets at
+// least this level.
 // Boundary rows constrain nothing, so the rows they feed would otherwise be headwaters of the level order -- level 0, among
 // the widest levels, the ones the level engine routes several timesteps per launch ahead of the window's progress
 // (k_mc_tile); rows whose inflow arrives chunk by chunk during the window (the trunk of a cut basin, distributed.py) must

@@ -2952,7 +2952,7 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
                 engine = std::strcmp(e, "levels") == 0 ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
             else {
                 int64_t nb = 0;
-                for (int64_t r = 0; boundary && r < nseg; ++r) nb += boundary[r] != 0;
+                for (int64_t r = 0; boundary && r < nseg; ++r) nb += boundary[r] == 1;
                 engine = ((flags & TRMC_PLAN_SHORT_TS) && nseg - nb >= 1000000) ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
             }
         }

@@ -213,7 +213,15 @@ class ShardedRouter:
         order = np.argsort(rows, kind="stable")
         self._out_rows = rows[order]
         self._d_out_index = X.DeviceBuffer.from_array(self._dev, slot[order].astype(np.int64))
-        self._sc = X.stream_create(self._dev)          # exchange stream: the collectives are ordered on it
+        # exchange stream: the collectives are ordered on it.  With one hardware queue per stream priority (set at import) it
+        # shares a queue with the plan stream of its priority, in order of submission: on the LEVEL engine the ordinary queue
+        # holds the wide tiles, all queued at the window's first call -- a chunk's exchange queued behind them ran after the
+        # last tile and held the trunk's owner back until then (N = 2: its tail started at 5.7 ms of 12.2) -- so there the
+        # exchange goes to the low-priority queue, beside the result transpose; the dataflow engine has nothing in the ordinary
+        # queue and keeps it there.
+        levels = getattr(self.plan0, "engine", "levels") == "levels"
+        prio = _os.environ.get("TRMC_EXCHANGE_PRIORITY")
+        self._sc = X.stream_create(self._dev, int(prio) if prio not in (None, "") else (-1 if levels else None))
         self._events = []
 
     def _event(self):
@@ -285,7 +293,9 @@ class ShardedRouter:
             up_ptr = np.concatenate([lp0, lp0[-1] + lp1[1:]])
             up_idx = np.concatenate([li0, li1 + n0])
             rows = np.concatenate([self.rows0, self.rows1])
-            boundary = np.concatenate([np.zeros(n0, np.uint8), self.boundary1.astype(np.uint8)])
+            # (1 = boundary copy of a cut row; 2 = trunk row: routed, lagged, kept out of the leading levels of a level-engine
+            # plan so that those can still run ahead of the window -- trmc.h, trmc_plan_create)
+            boundary = np.concatenate([np.zeros(n0, np.uint8), np.where(self.boundary1, 1, 2).astype(np.uint8)])
             lagv = np.concatenate([np.zeros(n0, np.int32), np.where(self.boundary1, 0, lag).astype(np.int32)])
             self._rowsM = rows
             self.planM = mk["factory"](up_ptr, up_idx, mk["params"][rows], boundary, mk["precision"], mk["device"], rows=rows,

@@ -78,7 +78,7 @@ class RoutingPlan:
         self.nseg = nseg
         self.precision = precision
         self.dtype = _lib.np_dtype(precision)
-        self.nboundary = 0 if b is None else int(np.count_nonzero(b))
+        self.nboundary = 0 if b is None else int(np.count_nonzero(b == 1))   # (2 = a routed row kept out of the leading levels)
         hint = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
         if hint is not None and hint.shape != (nseg,):
             raise ValueError("cost_hint shape mismatch")

@@ -13,7 +13,7 @@ class OraclePlan:
         self.up_idx = np.asarray(up_idx, np.int64)
         self.params = np.asarray(params, np.float32)
         self.nseg = self.params.shape[0]
-        self.boundary = np.zeros(self.nseg, bool) if boundary is None else np.asarray(boundary, bool)
+        self.boundary = np.zeros(self.nseg, bool) if boundary is None else (np.asarray(boundary).astype(np.uint8) == 1)   # (2: routed, see trmc.h)
         self.level, _, self.nlevels = topology_levels(self.up_ptr, self.up_idx, self.boundary.astype(np.uint8))
         self.dtype = np.float32
 

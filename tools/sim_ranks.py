@@ -158,7 +158,7 @@ def main():
           h = hyd.numpy()
           sel = np.searchsorted(rows, mine)
           ok = np.array_equal(h[sel].view(np.uint32), ref_hyd[np.searchsorted(ref_rows, mine)].view(np.uint32))
-          print(f"rank {rank} ({r.plan0.engine}): {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
+          print(f"rank {rank} ({r.plan0.engine}, {st['phase0'].get('wide_levels', 0)} wide levels): {t * 1e3:7.2f} ms  phase0 {r.rows0.size} rows main {st['phase0']['ms_main']:.2f} ms"
                 + (f"  trunk {r.rows1.size} rows" + (f" main {st['phase1']['ms_main']:.2f} ms" if "phase1" in st else " (skewed)") if r.plan1 is not None else "")
                 + f"  outlets bit-identical: {ok}")
           if acc:
