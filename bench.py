@@ -811,6 +811,8 @@ def pmc_counters(pattern, launches_per_window, args):
         out["valu"] = {
             "instructions_per_wave_step": insts / waves / steps_per_launch,
             "instructions_per_launch": insts, "wavefronts_per_launch": waves,
+            # (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU: NOT an issue cost -- the counter equals the instruction count for a
+            # kernel of nothing but v_fma_f32, which issues every 2.9 cycles; per-class issue costs: tools/valu_rates.hip)
             "cycles_per_instruction": 4.0 * active / insts,
             "busy_frac": (4.0 * active / n_simd) / (vals["SQ_BUSY_CYCLES"] / n_se),
             # SQ_BUSY_CYCLES under-counts the cycles of a launch by about a tenth on this part (the device runs this load at
