@@ -378,7 +378,9 @@ int trmc_segments(int device, int precision, int64_t n, const void *in, void *ou
  *              (n and seed are ignored)
  *   what = 1   a / b and max(c, a / b) for n pseudo-random triples drawn from `seed`: a in [2**-10, 2**19] (dx), b in
  *              [2**-76, 2**62] (the celerity of an in-bank point), c in [2**-20, 2**40] (dt) -- significands uniform
- *              over all 2**23, exponents uniform over the ranges, both ends included
+ *              over all 2**23, exponents uniform over the ranges, both ends included; one triple in eight has a divisor
+ *              whose significand is all ones, all ones but the last bit, zero or one (the hard cases of division by a
+ *              refined reciprocal)
  * checked_out receives the number of values / triples compared, mismatches_out how many results differ in any bit
  * (0 is the claim).  No routing state is touched.
  */

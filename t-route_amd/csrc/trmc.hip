@@ -2824,7 +2824,15 @@ k_selfcheck_div(int64_t n, uint64_t seed, unsigned long long *mismatches)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint64_t r0 = selfcheck_mix(seed + 3 * (uint64_t)i), r1 = selfcheck_mix(seed + 3 * (uint64_t)i + 1),
                        r2 = selfcheck_mix(seed + 3 * (uint64_t)i + 2);
-        const float a = selfcheck_draw(r0, -10, 19), b = selfcheck_draw(r1, -76, 62), c = selfcheck_draw(r2, -20, 40);
+        float a = selfcheck_draw(r0, -10, 19), b = selfcheck_draw(r1, -76, 62);
+        const float c = selfcheck_draw(r2, -20, 40);
+        // one draw in eight: a divisor (and in half of those a dividend too) with a significand of all ones, all ones but the
+        // last bit, or all zeros -- the hard cases of reciprocal-based division
+        if (((r2 >> 40) & 7u) == 0u) {
+            const uint32_t pick = (uint32_t)(r2 >> 43) & 3u, frac = pick == 0 ? 0x7fffffu : pick == 1 ? 0x7ffffeu : pick == 2 ? 0u : 1u;
+            b = __uint_as_float((__float_as_uint(b) & 0xff800000u) | frac);
+            if ((r2 >> 45) & 1u) a = __uint_as_float((__float_as_uint(a) & 0xff800000u) | (0x7fffffu - frac));
+        }
         const float q_fast = m.k_of(a, b), q = a / b;
         const float k_fast = m.max_num(c, q_fast), k = c > q ? c : q;
         bad += (__float_as_uint(q_fast) != __float_as_uint(q)) || (__float_as_uint(k_fast) != __float_as_uint(k));
