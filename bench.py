@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--no-retune", action="store_true",
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
+    ap.add_argument("--no-two-members", action="store_true", help="skip the two-ensemble-members leg (a second plan of the network)")
     ap.add_argument("--no-parity-sample", action="store_true", help="skip the post-timing oracle check of sampled networks")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic / roofline.valu = null)")
     ap.add_argument("--headline-only", action="store_true", help="stop after the headline's timed windows (what the counter passes run)")
@@ -543,6 +544,16 @@ def main():
             comm.close()
         return
     resident = timed(router, True, max(1, min(a.steps, 3)), 1)
+    two = None
+    if not use_dist and not a.no_two_members:
+        try:
+            two = two_members(router, lambda: make_router(hint, True, qlat_s, q0), spin_up, qlat_b, a, rate_of=segsteps_job)
+        except Exception as e:
+            two = {"error": repr(e)}
+        if os.environ.get("TRMC_BENCH_STOP_AFTER_TWO"):     # (a kernel trace of that leg: tools/trace_two.sh)
+            print(json.dumps(two), file=sys.stderr)
+            router.close()
+            raise SystemExit(0)
     parity = None
     if rank == 0 and not a.no_parity_sample and a.precision == 32:
         try:      # what the timed plan holds after the last timed window, against the oracle (checker use, outside the clock)
@@ -560,7 +571,7 @@ def main():
         allr = comm.all_gather_host(np.array([head["ms_main"], float(seg0)], dtype=np.float64))
         per_rank = [{"rank": i, "ms_main": float(t[0]), "segment_steps": int(t[1])} for i, t in enumerate(allr)]
 
-    extra = {"value_resident": {"value": rate(resident), "unit": "segment-timesteps/s",
+    extra = {"two_members": two, "value_resident": {"value": rate(resident), "unit": "segment-timesteps/s",
                                 "ms_per_step": resident["el"] / resident["steps"] * 1e3, "ms_main": resident["ms_main"],
                                 "what": "the same windows with every result left in HBM (no copy to the host in the clock)"},
              "copied_per_step": f"outlet hydrographs [{len(net['net_sizes'])} x {a.nsteps}] + final state [{nseg} x 3] into page-locked "
@@ -726,6 +737,72 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
+
+
+def two_members(router_a, make_b, spin_up, qlat, a, rate_of):
+    """Two ensemble members of the same network on ONE device, taking turns window by window: member B's window is queued
+    while member A's is still running (trmc_route_begin / _advance / _end: the asynchronous form of a window), so B's wide
+    tiles start behind A's tiles -- while A's tail, which ends a window alone on a half-idle device, is still running -- and
+    B's tail follows A's.  Two independent routing runs (the NWM's ensemble configurations are that), NOT a faster single
+    sequence of days: a window of one member still needs the state its previous window left.  Reports the aggregate rate
+    with every result left in HBM, to set beside `value_resident`."""
+    import time as _t
+    from troute_amd import comm as X
+    os.environ["TRMC_SETUP_ASIDE"] = "1"
+    try:
+        rb = make_b()
+        spin_up(rb, True)
+        rb.upload(a.nsteps, qlat, None)
+        pa, pb = router_a.plan0, rb.plan0
+
+        def queue(p):
+            p.route_begin(a.nsteps, a.qts, True)
+            p.route_advance(a.nsteps)
+        for p in (pa, pb):                      # one window each, alone (the tile stream exists from here on)
+            queue(p)
+            p.route_end()
+        queue(pa)
+        queue(pb)
+        pa.route_end()
+        pb.route_end()
+        X.device_synchronize(0)
+        n = max(2, min(a.steps, 4))
+        t0 = _t.perf_counter()
+        log = []
+
+        def mark(what):
+            log.append((what, round((_t.perf_counter() - t0) * 1e3, 2)))
+        queue(pa)
+        mark("A queued")
+        ms_a, ms_b = [], []
+        for _ in range(n):
+            queue(pb)
+            mark("B queued")
+            ms_a.append(pa.route_end()["ms_main"])
+            mark("A ended")
+            queue(pa)
+            mark("A queued")
+            ms_b.append(pb.route_end()["ms_main"])
+            mark("B ended")
+        ms_a.append(pa.route_end()["ms_main"])
+        mark("A ended")
+        if os.environ.get("TRMC_BENCH_DEBUG"):
+            print("[two_members] host timeline ms:", log, file=sys.stderr)
+        X.device_synchronize(0)
+        el = _t.perf_counter() - t0
+        windows = 2 * n + 1
+        same = np.array_equal(pa.gather_flow_rows(router_a.my_out0_local).view(np.uint32),
+                              pb.gather_flow_rows(rb.my_out0_local).view(np.uint32))
+        rb.close()
+        per = el / windows * 1e3
+        return {"value": rate_of * windows / el, "unit": "segment-timesteps/s (both members together)", "windows": windows,
+                "ms_per_window": per,
+                "roofline_frac": rate_of * ALG_BYTES_PER_SEGSTEP / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "members_identical": bool(same),
+                "what": "two independent members of the same network take turns on the device, a window of one queued while "
+                        "the other's is running; results left in HBM; wall clock over all windows"}
+    finally:
+        os.environ.pop("TRMC_SETUP_ASIDE", None)
 
 
 def pmc_counters(pattern, launches_per_window, args):

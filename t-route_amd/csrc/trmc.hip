@@ -1848,6 +1848,7 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     // wide levels routed K steps per launch with a skew of K steps per level (k_mc_tile); 0 = every level one step per launch
     int32_t wide = 0, wide_k = 0, wide_next = 0, wide_through = 0; // levels; K; tiles queued; last tile the tail waits for
     bool tail_active = false;     // the tail launches of this window go to the tail stream
+    bool end_queued = false;      // route_end_queue has run for this window
 };
 
 struct trmc_plan {
@@ -2101,6 +2102,16 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     }
 
     HIP_TRY(hipEventRecord(pl->ev[0], st));
+    // TRMC_SETUP_ASIDE=1: the window's set-up (forcing transpose, initial state, boundary rows) goes to the TILE stream
+    // instead of the plan's own.  For one plan it is all the same; for two plans that take turns on a device (two ensemble
+    // members, bench.py's `two_members`) it is what lets the tiles of one member's next window start behind the other
+    // member's tiles while that member's tail is still running: with one hardware queue per stream priority the two plans'
+    // high-priority streams share a queue, in order of submission, and a set-up queued there would sit behind the other
+    // member's 288 tail launches -- and the tiles behind the set-up.
+    const char *aside_env = std::getenv("TRMC_SETUP_ASIDE");
+    const bool setup_aside = aside_env && aside_env[0] == '1' && short_ts && pl->wstream != nullptr;
+    hipStream_t const plan_st = st;
+    if (setup_aside) st = pl->wstream;
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st)); // no history at the start of a window
     if (pl->collect_cost) HIP_TRY(hipMemsetAsync(pl->it_sum.p, 0, (size_t)np * sizeof(uint16_t), st));
     // every element the result reads is written below: time row 0 by k_init_state, rows 1..nsteps
@@ -2126,6 +2137,10 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         r.boundary_through = nsteps;
     }
     HIP_TRY(hipEventRecord(pl->ev[1], st));
+    if (setup_aside) {
+        st = plan_st;
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev[1], 0)); // the plan's stream continues behind the set-up
+    }
     // Short-timestep windows of a wide network: the leading levels that can fill the device by themselves are routed K
     // steps per launch (k_mc_tile), the rest one step per launch behind them.  Needs every boundary hydrograph up front
     // (wide rows run ahead of the window's progress) and no lagged rows (the multi-GPU trunk has its own skew).
@@ -2202,6 +2217,22 @@ static unsigned tile_lds_pad()
     }();
     return pad;
 }
+// what ends a window on the device -- the rest of the result transpose and the events the clock reads -- queued (once)
+template <class T> int route_end_queue(trmc_plan *pl)
+{
+    RouteRun &r = pl->run;
+    if (r.end_queued) return 0;
+    hipStream_t st = pl->stream;
+    HIP_TRY(hipEventRecord(pl->ev[2], st));
+    if (int rc = emit_tiles_through<T>(pl, r.nsteps)) return rc; // whatever is left (at least the last tile)
+    HIP_TRY(hipEventRecord(pl->ev_emit, pl->stream2));
+    HIP_TRY(hipStreamWaitEvent(st, pl->ev_emit, 0));
+    HIP_TRY(hipEventRecord(pl->ev[3], st));
+    HIP_TRY(hipGetLastError());
+    r.end_queued = true;
+    return 0;
+}
+
 template <class T> int route_advance_t(trmc_plan *pl, int t_end)
 {
     const trmc::Topology &tp = pl->topo;
@@ -2304,6 +2335,14 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     }
     HIP_TRY(hipGetLastError());
     r.t_done = t_end;
+    // TRMC_SETUP_ASIDE (two plans taking turns on a device, route_begin_t): the window's end is queued with its last launch,
+    // so that what ANOTHER plan queues next in the shared hardware queues comes after it -- trmc_route_end then waits for this
+    // plan's window only, not for the other plan's as well
+    if (t_end >= r.nsteps + pl->maxlag) {
+        const char *aside_env = std::getenv("TRMC_SETUP_ASIDE");
+        if (aside_env && aside_env[0] == '1')
+            if (int rc = route_end_queue<T>(pl)) return rc;
+    }
     return 0;
 }
 
@@ -2313,12 +2352,7 @@ template <class T> int route_end_t(trmc_plan *pl)
     RouteRun &r = pl->run;
     hipStream_t st = pl->stream;
     const int32_t nsteps = r.nsteps;
-    HIP_TRY(hipEventRecord(pl->ev[2], st));
-    if (int rc = emit_tiles_through<T>(pl, nsteps)) return rc; // whatever is left (at least the last tile)
-    HIP_TRY(hipEventRecord(pl->ev_emit, pl->stream2));
-    HIP_TRY(hipStreamWaitEvent(st, pl->ev_emit, 0));
-    HIP_TRY(hipEventRecord(pl->ev[3], st));
-    HIP_TRY(hipGetLastError());
+    if (int rc = route_end_queue<T>(pl)) return rc;
     HIP_TRY(hipStreamSynchronize(st));
 
     float ms01 = 0, ms12 = 0, ms23 = 0;

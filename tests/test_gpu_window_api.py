@@ -265,3 +265,43 @@ def test_rccl_communicator_single_rank_and_device_plumbing():
     X.stream_destroy(0, st)
     X.stream_destroy(0, st2)
     c.close()
+
+
+def test_two_plans_taking_turns_on_the_device_give_each_its_own_window(monkeypatch):
+    """TRMC_SETUP_ASIDE=1 (bench.py's two_members): a window's set-up goes to the tile stream and its end is queued with its
+    last launch, so that two plans of the level engine can take turns on one device -- one's window queued while the other's
+    is running, in the shared hardware queues -- without one waiting for the other's tail.  Each plan must come out with
+    exactly what it routes alone, whatever the interleaving."""
+    monkeypatch.setenv("TRMC_SETUP_ASIDE", "1")
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
+    monkeypatch.setenv("TRMC_WIDE_K", "8")
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(seed=5, nseg=6000)
+    rng = np.random.default_rng(9)
+    qlat_b = rng.uniform(0, 0.7, qlat.shape).astype(np.float32)        # the other member's forcing
+    nsteps, qts = 48, 12
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels") as ref:
+        want_a = ref.route(nsteps, qts, True, qlat, q0)
+        want_b = ref.route(nsteps, qts, True, qlat_b, q0)
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels") as a, \
+            RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels") as b:
+        a.upload_forcing(nsteps, qlat, q0)
+        b.upload_forcing(nsteps, qlat_b, q0)
+
+        def queue(pl):
+            pl.route_begin(nsteps, qts, True)
+            pl.route_advance(nsteps)
+        for pl in (a, b):                       # a first window each: the tile stream exists from the second on
+            queue(pl)
+            assert pl.route_end()["wide_levels"] > 0
+        queue(a)
+        for _ in range(3):
+            queue(b)
+            a.route_end()
+            got_a = a.download_fvd()
+            queue(a)
+            b.route_end()
+            got_b = b.download_fvd()
+            assert np.array_equal(got_a.view(np.uint32), want_a.view(np.uint32))
+            assert np.array_equal(got_b.view(np.uint32), want_b.view(np.uint32))
+        a.route_end()
+        assert np.array_equal(a.download_fvd().view(np.uint32), want_a.view(np.uint32))
