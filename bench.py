@@ -793,14 +793,67 @@ def two_members(router_a, make_b, spin_up, qlat, a, rate_of):
         windows = 2 * n + 1
         same = np.array_equal(pa.gather_flow_rows(router_a.my_out0_local).view(np.uint32),
                               pb.gather_flow_rows(rb.my_out0_local).view(np.uint32))
-        rb.close()
         per = el / windows * 1e3
-        return {"value": rate_of * windows / el, "unit": "segment-timesteps/s (both members together)", "windows": windows,
-                "ms_per_window": per,
-                "roofline_frac": rate_of * ALG_BYTES_PER_SEGSTEP / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "members_identical": bool(same),
-                "what": "two independent members of the same network take turns on the device, a window of one queued while "
-                        "the other's is running; results left in HBM; wall clock over all windows"}
+        out = {"value": rate_of * windows / el, "unit": "segment-timesteps/s (both members together)", "windows": windows,
+               "ms_per_window": per,
+               "roofline_frac": rate_of * ALG_BYTES_PER_SEGSTEP / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "members_identical": bool(same),
+               "what": "two independent members of the same network take turns on the device, a window of one queued while "
+                       "the other's is running; results left in HBM; wall clock over all windows"}
+        # ---- ONE sequence of days on the two plans (trmc_plan_chain_from): window w + 1 starts from the state window w
+        # leaves, handed over on the device in two parts, and is queued while window w is still running.  The days repeat
+        # the timed day's forcing; the state evolves.  Checked against the same days routed one after the other on ONE plan.
+        s0 = pa.download_final_state()
+        m = 2 * n + 1
+        plans = [pa, pb]
+        for p in plans:
+            p.upload_forcing(a.nsteps, qlat, s0)
+        queue(pa)
+        pb.chain_from(pa)
+        queue(pb)
+        pa.route_end()
+        pb.route_end()                                   # (warm: two chained windows, untimed)
+        for p in plans:
+            p.upload_forcing(a.nsteps, qlat, s0)
+        X.device_synchronize(0)
+        t0 = _t.perf_counter()
+        queue(pa)
+        ms_chain, ms_ref = [], []
+        for w in range(1, m):
+            cur, prev = plans[w % 2], plans[(w - 1) % 2]
+            cur.chain_from(prev)
+            queue(cur)
+            ms_chain.append(round(prev.route_end()["ms_main"], 2))
+        last = plans[(m - 1) % 2]
+        ms_chain.append(round(last.route_end()["ms_main"], 2))
+        X.device_synchronize(0)
+        el2 = _t.perf_counter() - t0
+        got_state = last.download_final_state()
+        got_hyd = last.gather_flow_rows(router_a.my_out0_local)
+        # the reference: the same m days on plan A alone, each continuing from the one before
+        pa.upload_forcing(a.nsteps, qlat, s0)
+        t1 = _t.perf_counter()
+        for w in range(m):
+            ms_ref.append(round(pa.route_device(a.nsteps, a.qts, True)["ms_main"], 2))
+            if w < m - 1:
+                pa.upload_forcing(a.nsteps, qlat, None)
+        X.device_synchronize(0)
+        el_ref = _t.perf_counter() - t1
+        ok = (np.array_equal(pa.download_final_state().view(np.uint32), got_state.view(np.uint32))
+              and np.array_equal(pa.gather_flow_rows(router_a.my_out0_local).view(np.uint32), got_hyd.view(np.uint32)))
+        per2 = el2 / m * 1e3
+        out["sequence_on_two_plans"] = {
+            "value": rate_of * m / el2, "unit": "segment-timesteps/s", "windows": m, "ms_per_window": per2,
+            "roofline_frac": rate_of * ALG_BYTES_PER_SEGSTEP / (per2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ms_per_window_on_one_plan": el_ref / m * 1e3,
+            "identical_to_the_sequence_on_one_plan": bool(ok),
+            "ms_main_of_each_window": ms_chain, "ms_main_of_each_window_on_one_plan": ms_ref,
+            "what": "ONE sequence of days (the timed day's forcing repeated, the state carried from day to day) on two plans "
+                    "taking turns: a day starts from the state the day before leaves, handed over on the device, and is queued "
+                    "while that day is still running; results left in HBM; the one-plan figure includes re-staging the "
+                    "forcing every day"}
+        rb.close()
+        return out
     finally:
         os.environ.pop("TRMC_SETUP_ASIDE", None)
 

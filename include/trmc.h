@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 11
+#define TRMC_ABI_VERSION 12
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -370,6 +370,17 @@ int trmc_route(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_sho
  * as reach.pyx:55 passes it.
  */
 int trmc_segments(int device, int precision, int64_t n, const void *in, void *out);
+
+/*
+ * Windows of ONE sequence on TWO plans of the same network (same inputs, same cost hint: the same order), taking turns:
+ * the receiving plan's next window starts from the state the source plan's window leaves, handed over on the device --
+ * the rows of the source's leading ("wide") levels behind its last tile, on the receiver's tile stream, the others behind
+ * its tail, on the receiver's own stream -- so that the receiver's tiles can run while the source's tail is still
+ * finishing its window (with TRMC_SETUP_ASIDE=1).  The source's window must have been queued to its
+ * end (trmc_route_advance to nsteps); the receiver must have its forcing staged; the next trmc_route_begin of the receiver
+ * takes the handed-over state instead of the one staged with its forcing.  Level engine only.
+ */
+int trmc_plan_chain_from(trmc_plan *receiver, trmc_plan *source);
 
 /*
  * Self-check, on the device, of the short exact forms the fp32 step takes under its range proofs (csrc/trmc.hip,

@@ -1879,6 +1879,9 @@ struct trmc_plan {
     int32_t cost_nsteps = -1;            // nsteps of the window it_sum was collected over
     int32_t maxlag = 0;                  // trmc_plan_set_lag: rows routed `maxlag` launches behind the others
     int64_t wide_safe_pos = -1;          // first plan position that is lagged or fed by a boundary row (-1: not looked for yet)
+    // trmc_plan_chain_from: the next window's initial state has been set on the device from another plan's window
+    bool chain_staged = false;
+    hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}; // source's tiles / tail done; this plan's two copies done
     std::vector<int32_t> lag_of_row;
     DevBuf gage_of_pos, da_mode, da_a, da_w, da_nudge; // nudging tables of the staged window
     DevBuf res_of_pos, res_par, res_inflow;             // level-pool reservoirs of the plan
@@ -2121,9 +2124,11 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         if (!pl->qlat_direct)
             hipLaunchKernelGGL((k_prep_qlat<T>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
                                (const T *)pl->in_qlat.p, row_of_pos, (T *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);
-        hipLaunchKernelGGL((k_init_state<T>), dim3(blocks_for(n)), dim3(kBlock), 0, st, (const T *)pl->in_q0.p,
-                           row_of_pos, a.q_tm, a.v_tm, a.d_tm, n);
+        if (!pl->chain_staged) // (else: time row 0 was set on the device by trmc_plan_chain_from)
+            hipLaunchKernelGGL((k_init_state<T>), dim3(blocks_for(n)), dim3(kBlock), 0, st, (const T *)pl->in_q0.p,
+                               row_of_pos, a.q_tm, a.v_tm, a.d_tm, n);
     }
+    pl->chain_staged = false;
     RouteRun &r = pl->run;
     r = RouteRun{};
     r.active = true;
@@ -2821,6 +2826,58 @@ template <class T> int segments_t(int64_t n, const void *in, void *out)
     return rc;
 }
 
+// trmc_plan_chain_from: time row `src_row` of one plan's planes -> time row 0 of another's, positions [lo, hi) (same order)
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_chain_state(const T *__restrict__ sq, const T *__restrict__ sv, const T *__restrict__ sd, T *__restrict__ dq,
+              T *__restrict__ dv, T *__restrict__ dd, int32_t lo, int32_t hi)
+{
+    const int32_t p = lo + (int32_t)blockIdx.x * kBlock + (int32_t)threadIdx.x;
+    if (p >= hi) return;
+    dq[p] = sq[p];
+    dv[p] = sv[p];
+    dd[p] = sd[p];
+}
+template <class T> int chain_from_t(trmc_plan *dst, trmc_plan *src, int nsteps_dst)
+{
+    const trmc::Topology &tp = src->topo;
+    const int64_t np = src->nseg_pad;
+    const int32_t ns = src->run.nsteps;
+    const size_t plane_s = (size_t)(ns + 1) * np, plane_d = (size_t)(nsteps_dst + 1) * np;
+    if (int rc = dst->tm.ensure(3 * plane_d * sizeof(T))) return rc;
+    const T *sq = (const T *)src->tm.p + (size_t)ns * np, *sv = sq + plane_s, *sd = sv + plane_s;
+    T *dq = (T *)dst->tm.p, *dv = dq + plane_d, *dd = dv + plane_d;
+    for (int i = 0; i < 4; ++i)
+        if (!dst->ev_chain[i]) HIP_TRY(hipEventCreateWithFlags(&dst->ev_chain[i], hipEventDisableTiming));
+    if (!dst->wstream) {
+        HIP_TRY(hipStreamCreateWithFlags(&dst->wstream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&dst->ev_tail, hipEventDisableTiming));
+    }
+    // the rows of the source's wide levels are final when its last tile is (they never wrote a velocity row: the velocity
+    // of the initial state is not an input of the step); the other rows when its tail is
+    const int32_t W = src->run.short_ts ? src->run.wide : 0;
+    const int32_t b0 = 0, w1 = tp.lvl_ptr[W], s1 = (int32_t)src->nseg; // (boundary rows, if any, go with the tail's part)
+    const int32_t w0 = W > 0 ? tp.lvl_ptr[0] : w1;
+    if (W > 0 && src->wstream) {
+        HIP_TRY(hipEventRecord(dst->ev_chain[0], src->wstream));
+        HIP_TRY(hipStreamWaitEvent(dst->wstream, dst->ev_chain[0], 0));
+        hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(w1 - w0)), dim3(kBlock), 0, dst->wstream, sq, sq, sd, dq, dv, dd, w0, w1);
+        HIP_TRY(hipEventRecord(dst->ev_chain[2], dst->wstream));
+        HIP_TRY(hipStreamWaitEvent(src->wstream, dst->ev_chain[2], 0)); // the source's next window does not overwrite what is being read
+        HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_chain[2], 0));
+    }
+    HIP_TRY(hipEventRecord(dst->ev_chain[1], src->stream));
+    HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_chain[1], 0));
+    if (w0 > b0) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(w0 - b0)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, b0, w0);
+    if (s1 > w1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(s1 - w1)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, w1, s1);
+    HIP_TRY(hipEventRecord(dst->ev_chain[3], dst->stream));
+    HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_chain[3], 0));
+    if (src->wstream) HIP_TRY(hipStreamWaitEvent(src->wstream, dst->ev_chain[3], 0));
+    HIP_TRY(hipGetLastError());
+    dst->chain_staged = true;
+    return 0;
+}
+
 // trmc_selfcheck_fast_arith: the short forms of DevMathF against the operations they stand for (see trmc.h)
 __global__ void __launch_bounds__(kBlock)
 k_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatches)
@@ -3103,6 +3160,8 @@ void trmc_plan_destroy(trmc_plan *pl)
         if (e) (void)hipEventDestroy(e);
     if (pl->ev_emit) (void)hipEventDestroy(pl->ev_emit);
     if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
+    for (hipEvent_t e : pl->ev_chain)
+        if (e) (void)hipEventDestroy(e);
     if (pl->wstream) (void)hipStreamDestroy(pl->wstream);
     for (auto *v : {&pl->wide_t0, &pl->wide_t1})
         for (auto &e : *v)
@@ -3860,6 +3919,23 @@ int trmc_segments(int device, int precision, int64_t n, const void *in, void *ou
     if (int rc = check_device(device)) return rc;
     HIP_TRY(hipSetDevice(device));
     return precision == 32 ? segments_t<float>(n, in, out) : segments_t<double>(n, in, out);
+}
+
+int trmc_plan_chain_from(trmc_plan *dst, trmc_plan *src)
+{
+    if (!dst || !src || dst == src) return fail(TRMC_EINVAL, "two different plans are needed");
+    if (dst->flow || src->flow) return fail(TRMC_EINVAL, "plans of the level engine only");
+    if (dst->run.active) return fail(TRMC_ESTATE, "a routing window of the receiving plan is in progress");
+    if (dst->staged_nsteps < 1) return fail(TRMC_ESTATE, "the receiving plan has no forcing staged (trmc_upload_forcing)");
+    if (src->run.nsteps < 1 || (!src->run.active && src->routed_nsteps < 0))
+        return fail(TRMC_ESTATE, "the source plan has routed nothing");
+    if (src->run.active && src->run.t_done < src->run.nsteps + (src->run.short_ts ? src->maxlag : 0))
+        return fail(TRMC_ESTATE, "the source plan's window has not been queued to its end (trmc_route_advance)");
+    if (dst->nseg != src->nseg || dst->precision != src->precision || dst->device != src->device
+        || dst->topo.row_of_pos != src->topo.row_of_pos)
+        return fail(TRMC_EINVAL, "the two plans must hold the same network in the same order (same inputs, same cost hint)");
+    if (int rc = use_device(dst)) return rc;
+    return dst->precision == 32 ? chain_from_t<float>(dst, src, dst->staged_nsteps) : chain_from_t<double>(dst, src, dst->staged_nsteps);
 }
 
 int trmc_selfcheck_fast_arith(int device, int what, int64_t n, uint64_t seed, int64_t *checked_out, int64_t *mismatches_out)

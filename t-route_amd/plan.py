@@ -229,6 +229,11 @@ class RoutingPlan:
         return self.stats()
 
     # -- the same window in parts (asynchronous; see include/trmc.h) ------------------------------
+    def chain_from(self, source):
+        """This plan's NEXT window starts from the state `source`'s window (queued to its end) leaves, handed over on the
+        device in two parts so that this plan's wide levels can start before the source's tail has finished (trmc.h)."""
+        _lib.check(_lib.lib().trmc_plan_chain_from(self._h, source._h))
+
     def route_begin(self, nsteps, qts_subdivisions, assume_short_ts):
         _lib.check(_lib.lib().trmc_route_begin(self._h, nsteps, qts_subdivisions, int(bool(assume_short_ts))))
         self._nsteps = nsteps

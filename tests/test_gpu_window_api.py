@@ -305,3 +305,44 @@ def test_two_plans_taking_turns_on_the_device_give_each_its_own_window(monkeypat
             assert np.array_equal(got_b.view(np.uint32), want_b.view(np.uint32))
         a.route_end()
         assert np.array_equal(a.download_fvd().view(np.uint32), want_a.view(np.uint32))
+
+
+def test_a_sequence_of_windows_on_two_plans_taking_turns_equals_the_sequence_on_one(monkeypatch):
+    """trmc_plan_chain_from: consecutive windows of ONE sequence alternate between two plans of the same network, each
+    starting from the state the other's window leaves -- handed over on the device, the wide levels' rows behind the other
+    plan's last tile, the rest behind its tail -- while the other plan's window may still be running.  The same bits as the
+    sequence routed window after window on one plan (trmc_upload_forcing with q0 = NULL)."""
+    monkeypatch.setenv("TRMC_SETUP_ASIDE", "1")
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
+    monkeypatch.setenv("TRMC_WIDE_K", "8")
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(seed=7, nseg=6000)
+    nsteps, qts, nwin = 48, 12, 6
+    want = []
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels") as ref:
+        ref.upload_forcing(nsteps, qlat, q0)
+        for w in range(nwin):
+            ref.route_device(nsteps, qts, True)
+            want.append(ref.download_fvd().copy())
+            ref.upload_forcing(nsteps, qlat, None)          # the next window continues from this one's final state
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels") as a, \
+            RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels") as b:
+        a.upload_forcing(nsteps, qlat, q0)
+        b.upload_forcing(nsteps, qlat, q0)                  # (its initial state is replaced by the hand-over)
+
+        def queue(pl):
+            pl.route_begin(nsteps, qts, True)
+            pl.route_advance(nsteps)
+        plans = [a, b]
+        queue(a)                                            # window 0 on a
+        for w in range(1, nwin):
+            cur, prev = plans[w % 2], plans[(w - 1) % 2]
+            cur.chain_from(prev)                            # window w starts where window w - 1 ends ...
+            queue(cur)                                      # ... and is queued while that one may still be running
+            prev.route_end()
+            got = prev.download_fvd()
+            assert np.array_equal(got.view(np.uint32), want[w - 1].view(np.uint32)), w - 1
+        last = plans[(nwin - 1) % 2]
+        last.route_end()
+        assert np.array_equal(last.download_fvd().view(np.uint32), want[nwin - 1].view(np.uint32))
+        with pytest.raises(ValueError, match="two different plans"):
+            a.chain_from(a)
