@@ -544,8 +544,15 @@ def main():
             comm.close()
         return
     resident = timed(router, True, max(1, min(a.steps, 3)), 1)
+    parity = None
+    if rank == 0 and not a.no_parity_sample and a.precision == 32:
+        try:      # what the timed plan holds after the last timed window, against the oracle (checker use, outside the clock)
+            parity = parity_sample(net, router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
+                                   outlets=(router._out_rows, hyd) if use_dist else None)
+        except Exception as e:
+            parity = {"error": repr(e)}
     two = None
-    if not use_dist and not a.no_two_members:
+    if not use_dist and not a.no_two_members:   # (after the parity sample: this leg routes other days on the timed plan)
         try:
             two = two_members(router, lambda: make_router(hint, True, qlat_s, q0), spin_up, qlat_b, a, rate_of=segsteps_job)
         except Exception as e:
@@ -554,13 +561,6 @@ def main():
             print(json.dumps(two), file=sys.stderr)
             router.close()
             raise SystemExit(0)
-    parity = None
-    if rank == 0 and not a.no_parity_sample and a.precision == 32:
-        try:      # what the timed plan holds after the last timed window, against the oracle (checker use, outside the clock)
-            parity = parity_sample(net, router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
-                                   outlets=(router._out_rows, hyd) if use_dist else None)
-        except Exception as e:
-            parity = {"error": repr(e)}
     value = rate(head)
     info = router.plan0.info()
     stats = head["stats"]
