@@ -169,34 +169,63 @@ _PINNED_CAP = int(os.environ.get("TRMC_PINNED_POOL_MB", "24576")) << 20   # free
 _pinned_free = {}         # nbytes -> [addresses]; guarded by _pinned_lock
 _pinned_order = []        # sizes in the order they were last given back (oldest first): what goes when the pool is full
 import threading as _threading
-_pinned_lock = _threading.Lock()
+import contextlib as _contextlib
+# The pool is entered from weakref finalizers too, and a finalizer can run on ANY allocation -- including one made while
+# this very thread is inside the pool code (a garbage-collection pass triggered by `setdefault(nbytes, [])`, say).  So the
+# lock is re-entrant, and a release that arrives while its thread is already inside the pool is only noted
+# (`_pinned_pending`, list.append is atomic) and carried out by the frame that holds the lock, before it leaves.
+_pinned_lock = _threading.RLock()
+_pinned_pending = []
+_pinned_inside = _threading.local()
+
+
+def _pool_put(address, nbytes, drop):
+    """(lock held) give one buffer back: into the pool, or onto `drop` (to be freed outside the lock)"""
+    pool = _pinned_free.setdefault(nbytes, [])
+    if len(pool) < (_PINNED_KEEP if nbytes <= (4 << 30) else 1):     # (one spare only of the multi-gigabyte buffers)
+        pool.append(address)
+        if nbytes in _pinned_order:
+            _pinned_order.remove(nbytes)
+        _pinned_order.append(nbytes)
+    else:
+        drop.append(address)
+    # a process that routes windows of many sizes must not keep page-locked memory of every one of them: beyond
+    # the cap the sizes given back longest ago are released first
+    total = sum(k * len(v) for k, v in _pinned_free.items())
+    while total > _PINNED_CAP and _pinned_order:
+        k = _pinned_order[0]
+        if _pinned_free.get(k):
+            drop.append(_pinned_free[k].pop())
+            total -= k
+        if not _pinned_free.get(k):
+            _pinned_order.pop(0)
+
+
+@_contextlib.contextmanager
+def _pool():
+    """the pool's critical section; releases noted meanwhile by finalizers of this thread are carried out before it ends"""
+    drop = []
+    _pinned_inside.depth = getattr(_pinned_inside, "depth", 0) + 1
+    try:
+        with _pinned_lock:
+            yield drop
+            while _pinned_pending:
+                a, n = _pinned_pending.pop()
+                _pool_put(a, n, drop)
+    finally:
+        _pinned_inside.depth -= 1
+    if _LIB is not None:
+        for a in drop:
+            _LIB.trmc_host_free(C.c_void_p(a))
 
 
 def _pinned_release(address, nbytes):
     try:
-        drop = []
-        with _pinned_lock:
-            pool = _pinned_free.setdefault(nbytes, [])
-            if len(pool) < (_PINNED_KEEP if nbytes <= (4 << 30) else 1):     # (one spare only of the multi-gigabyte buffers)
-                pool.append(address)
-                if nbytes in _pinned_order:
-                    _pinned_order.remove(nbytes)
-                _pinned_order.append(nbytes)
-            else:
-                drop.append(address)
-            # a process that routes windows of many sizes must not keep page-locked memory of every one of them: beyond
-            # the cap the sizes given back longest ago are released first
-            total = sum(k * len(v) for k, v in _pinned_free.items())
-            while total > _PINNED_CAP and _pinned_order:
-                k = _pinned_order[0]
-                if _pinned_free.get(k):
-                    drop.append(_pinned_free[k].pop())
-                    total -= k
-                if not _pinned_free.get(k):
-                    _pinned_order.pop(0)
-        if _LIB is not None:
-            for a in drop:
-                _LIB.trmc_host_free(C.c_void_p(a))
+        if getattr(_pinned_inside, "depth", 0) > 0:      # a finalizer run by a collection inside the pool code of this thread
+            _pinned_pending.append((address, nbytes))
+            return
+        with _pool() as drop:
+            _pool_put(address, nbytes, drop)
     except Exception:        # interpreter shutdown
         pass
 
@@ -209,7 +238,7 @@ def result_empty(shape, dtype, always_pinned=False):
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if nbytes == 0 or ((nbytes < _PINNED_MIN and not always_pinned) or os.environ.get("TRMC_PINNED_RESULTS", "1") == "0"):
         return np.empty(shape, dtype=dtype)
-    with _pinned_lock:
+    with _pool():
         pool = _pinned_free.get(nbytes)
         address = pool.pop() if pool else None
     if address is None:
@@ -224,7 +253,7 @@ def result_empty(shape, dtype, always_pinned=False):
 
 def pinned_pool_clear():
     """Free the page-locked buffers that are not in use."""
-    with _pinned_lock:
+    with _pool():
         addrs = [a for pool in _pinned_free.values() for a in pool]
         _pinned_free.clear()
         del _pinned_order[:]
@@ -232,7 +261,34 @@ def pinned_pool_clear():
         lib().trmc_host_free(C.c_void_p(a))
 
 
+_hip_started = False     # a call that initialises the HIP runtime has been made through this module
+
+
+def single_hw_queue_per_priority(who):
+    """GPU_MAX_HW_QUEUES=1 for the HIP runtime of this process, unless the caller has set the variable: the multi-GPU path
+    (troute_amd.distributed, troute_amd.comm) wants one hardware queue per stream priority.  The
+    runtime reads the variable when it initialises, so this is done when a communicator or a sharded router is BUILT --
+    not as a side effect of importing a module -- and if the runtime is already up by then the setting cannot take effect
+    any more: said aloud instead of silently changing (or silently not changing) what other HIP users of the process get."""
+    if os.environ.get("GPU_MAX_HW_QUEUES"):
+        return
+    if _hip_started:
+        import warnings
+        warnings.warn(f"{who}: the HIP runtime of this process was initialised before GPU_MAX_HW_QUEUES could be set to 1; "
+                      "export GPU_MAX_HW_QUEUES=1 before the first HIP call for the stream-to-queue mapping the multi-GPU "
+                      "path is tuned for (results are unaffected)", RuntimeWarning, stacklevel=3)
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = "1"
+
+
+def mark_hip_started():
+    """called by whoever is about to make a call that initialises the HIP runtime"""
+    global _hip_started
+    _hip_started = True
+
+
 def device_count():
+    mark_hip_started()
     n = C.c_int(0)
     rc = lib().trmc_device_count(C.byref(n))
     return n.value if rc == 0 else 0

@@ -29,6 +29,7 @@ class DeviceBuffer:
 
     def __init__(self, device, nbytes):
         self.device, self.nbytes = int(device), int(nbytes)
+        _lib.mark_hip_started()
         p = C.c_void_p(0)
         _check(_lib.lib().trmc_dev_alloc(self.device, self.nbytes, C.byref(p)))
         self.ptr = p.value or 0
@@ -137,28 +138,19 @@ def _rendezvous_dir():
     return os.environ.get("TRMC_COMM_DIR", "/tmp")
 
 
-def exchange_id(rank, key, make_id, timeout=120.0):
-    """Rank 0 makes the communicator id and leaves it in a file named after `key`; the others read it.  One node, so a
-    directory every rank sees (TRMC_COMM_DIR, default /tmp) is all the rendezvous needs."""
-    path = os.path.join(_rendezvous_dir(), f"trmc_comm_{key}.id")
-    if rank == 0:
-        blob = make_id()
-        tmp = path + f".{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(blob)
-        os.replace(tmp, path)
-        return blob
-    t0 = time.time()
-    while True:
-        try:
-            blob = open(path, "rb").read()
-            if len(blob) == ID_BYTES:
-                return blob
-        except OSError:
-            pass
-        if time.time() - t0 > timeout:
-            raise RuntimeError(f"communicator rendezvous: {path} did not appear within {timeout:.0f} s")
-        time.sleep(0.01)
+def exchange_id(rank, world, key, make_id):
+    """Rank 0 makes the communicator id; the others receive it -- over a small shared-memory communicator of this launch
+    (`trmc_comm_init_shm`: rank 0 creates the segment exclusively and every other rank only proceeds once the live rank 0 of
+    THIS launch has answered its token), not through a file under the key: a file left by an earlier job with the same key
+    is indistinguishable from a fresh one, and a stale id makes ncclCommInitRank hang."""
+    if world == 1:
+        return make_id()
+    ctl = Comm(rank, world, -1, backend="shm", key=f"{key}_id", shm_bytes=1 << 16)
+    try:
+        mine = np.frombuffer(make_id() if rank == 0 else bytes(ID_BYTES), dtype=np.uint8)
+        return bytes(ctl.all_gather_host(mine)[0])
+    finally:
+        ctl.close()
 
 
 def default_key():
@@ -167,7 +159,10 @@ def default_key():
     k = os.environ.get("TRMC_COMM_KEY")
     if k:
         return k
-    return f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    # (torchrun restarts the ranks of a failed launch under the same parent and port: its run id and restart count tell the
+    # launches apart; a key that does repeat is still safe -- a segment is only ever used by the launch that created it)
+    return (f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', '')}"
+            f"_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
 
 
 _PROBE = """
@@ -212,6 +207,7 @@ class Comm:
 
     def __init__(self, rank, world, device, backend="auto", key=None, shm_bytes=0):
         self.rank, self.world, self.device = int(rank), int(world), int(device)
+        _lib.single_hw_queue_per_priority("troute_amd.comm.Comm")        # (before the runtime is first touched, if it can be)
         key = key or default_key()
         lib = _lib.lib()
         ndev = _lib.device_count()
@@ -234,7 +230,7 @@ class Comm:
                 _check(lib.trmc_comm_unique_id(buf))
                 return bytes(buf)
             try:
-                blob = exchange_id(self.rank, key, make_id)
+                blob = exchange_id(self.rank, self.world, key, make_id)
                 _check(lib.trmc_comm_init(self.rank, self.world, blob, self.device, C.byref(h)))
             except Exception:
                 # RCCL missing or unable to start on this node: with "auto" every rank falls back to the shared-memory

@@ -31,7 +31,25 @@
 #include <new>
 #include <string>
 
-#include <rccl/rccl.h> // types and prototypes only: the library itself is dlopen'ed
+// RCCL: types and prototypes only -- the library itself is dlopen'ed, and a host without its headers still builds the
+// single-GPU library: the handful of declarations the transport needs are then restated here (rccl.h, NCCL's public API)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,
+                           hipStream_t stream);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include "../../include/trmc.h"
 #include "internal.hpp"
@@ -92,13 +110,27 @@ int rccl_fail(const char *what, ncclResult_t rc)
 }
 
 // ---- the shared-memory transport -----------------------------------------------------------------------------------
+// A segment is only ever used by the launch that CREATED it: rank 0 removes whatever an earlier job left under the name
+// (a crashed or killed job leaves its segment behind, with `attached` >= world and barrier counters mid-count -- trusting
+// those let ranks skip the attach wait and barriers release early: silently wrong data) and creates the name exclusively;
+// every other rank proves to itself that the segment it has mapped has a LIVE rank 0 of this launch behind it -- it
+// writes a fresh random token into its `hello` slot and proceeds only once rank 0 has echoed that token into its `ack`
+// slot -- and while it waits it keeps checking that the name still leads to the inode it mapped (if rank 0 has replaced
+// the segment since, it starts over on the new one).  A dead segment never answers.
+constexpr int kShmMaxWorld = 128;
+constexpr uint32_t kShmMagic = 0x74726d63u; // "trmc"
 struct ShmHeader {
     std::atomic<uint32_t> arrived;    // ranks inside the current barrier
     std::atomic<uint32_t> generation; // barriers completed
-    std::atomic<uint32_t> attached;   // ranks that have mapped the segment
+    std::atomic<uint32_t> attached;   // ranks that have completed the handshake and not yet left
     uint32_t world;
+    std::atomic<uint32_t> magic;      // set by rank 0 when the header is ready
+    uint32_t pad_[3];
+    std::atomic<uint64_t> hello[kShmMaxWorld]; // rank r's token of this launch
+    std::atomic<uint64_t> ack[kShmMaxWorld];   // rank 0's echo of it
 };
 constexpr size_t kShmHeader = 4096;
+static_assert(sizeof(ShmHeader) <= kShmHeader, "the header must fit its page");
 
 } // namespace
 
@@ -248,22 +280,99 @@ int trmc_comm_init_shm(int rank, int world, const char *name, int device, int64_
         delete c;
         return fail_with(TRMC_EHIP, msg);
     };
-    c->fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (c->fd < 0) return bail(std::string("shm_open(") + name + "): " + std::strerror(errno));
-    if (ftruncate(c->fd, (off_t)c->bytes) != 0) return bail(std::string("ftruncate: ") + std::strerror(errno));
-    void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
-    if (p == MAP_FAILED) return bail(std::string("mmap: ") + std::strerror(errno));
-    c->base = (uint8_t *)p;
-    ShmHeader *h = header(c);
-    h->world = (uint32_t)world; // (every rank writes the same value; a fresh segment is zero-filled)
-    h->attached.fetch_add(1, std::memory_order_acq_rel);
-    // everybody attached before anybody uses the barrier counters
+    if (world > kShmMaxWorld) return bail("the shared-memory transport serves at most " + std::to_string(kShmMaxWorld) + " ranks");
     const auto t0 = std::chrono::steady_clock::now();
-    while (h->attached.load(std::memory_order_acquire) < (uint32_t)world) {
-        sched_yield();
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s)
-            return bail("communicator: not every rank attached to " + c->shm_name + " within the time-out");
+    auto timed_out = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s; };
+    auto unmap = [&] {
+        if (c->base) munmap(c->base, c->bytes);
+        c->base = nullptr;
+        if (c->fd >= 0) close(c->fd);
+        c->fd = -1;
+    };
+    if (rank == 0) {
+        // whatever is there under this name belongs to an earlier launch: remove it, then create the name exclusively
+        for (int attempt = 0; c->fd < 0; ++attempt) {
+            (void)shm_unlink(name);
+            c->fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (c->fd < 0 && (errno != EEXIST || attempt >= 8)) return bail(std::string("shm_open(") + name + "): " + std::strerror(errno));
+        }
+        if (ftruncate(c->fd, (off_t)c->bytes) != 0) {
+            (void)shm_unlink(name);
+            return bail(std::string("ftruncate: ") + std::strerror(errno));
+        }
+        void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
+        if (p == MAP_FAILED) {
+            (void)shm_unlink(name);
+            return bail(std::string("mmap: ") + std::strerror(errno));
+        }
+        c->base = (uint8_t *)p;
+        ShmHeader *h = header(c); // (a fresh segment is zero-filled: counters, tokens and echoes all start at 0)
+        h->world = (uint32_t)world;
+        h->magic.store(kShmMagic, std::memory_order_release);
+        // answer every rank's token until all of them have been answered
+        for (;;) {
+            int answered = 1;
+            for (int r = 1; r < world; ++r) {
+                const uint64_t t = h->hello[r].load(std::memory_order_acquire);
+                if (t != 0 && h->ack[r].load(std::memory_order_relaxed) != t) h->ack[r].store(t, std::memory_order_release);
+                answered += t != 0;
+            }
+            if (answered == world) break;
+            sched_yield();
+            if (timed_out()) {
+                (void)shm_unlink(name);
+                return bail("communicator: not every rank attached to " + c->shm_name + " within the time-out");
+            }
+        }
+    } else {
+        uint64_t token = 0;
+        {
+            FILE *f = std::fopen("/dev/urandom", "rb");
+            if (f) {
+                if (std::fread(&token, sizeof token, 1, f) != 1) token = 0;
+                std::fclose(f);
+            }
+            if (token == 0)
+                token = ((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)c;
+            token |= 1; // never 0
+        }
+        for (bool done = false; !done;) {
+            unmap();
+            if (timed_out()) return bail("communicator: " + c->shm_name + " did not appear (or its rank 0 never answered) within the time-out");
+            c->fd = shm_open(name, O_RDWR, 0600);
+            struct stat st_fd;
+            if (c->fd < 0 || fstat(c->fd, &st_fd) != 0 || (size_t)st_fd.st_size < c->bytes) { // not there yet, or not sized yet
+                sched_yield();
+                continue;
+            }
+            void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
+            if (p == MAP_FAILED) return bail(std::string("mmap: ") + std::strerror(errno));
+            c->base = (uint8_t *)p;
+            ShmHeader *h = header(c);
+            bool said_hello = false;
+            uint32_t spins = 0;
+            for (;;) {
+                if (!said_hello && h->magic.load(std::memory_order_acquire) == kShmMagic && h->world == (uint32_t)world) {
+                    h->hello[rank].store(token, std::memory_order_release);
+                    said_hello = true;
+                }
+                if (said_hello && h->ack[rank].load(std::memory_order_acquire) == token) {
+                    done = true;
+                    break;
+                }
+                sched_yield();
+                if ((++spins & 255u) == 0) {
+                    // does the name still lead to the segment that is mapped here?  (rank 0 of THIS launch replaces a stale one)
+                    const int fd2 = shm_open(name, O_RDWR, 0600);
+                    struct stat st2;
+                    const bool same = fd2 >= 0 && fstat(fd2, &st2) == 0 && st2.st_ino == st_fd.st_ino && st2.st_dev == st_fd.st_dev;
+                    if (fd2 >= 0) close(fd2);
+                    if (!same || timed_out()) break; // start over on whatever the name leads to now (or give up above)
+                }
+            }
+        }
     }
+    header(c)->attached.fetch_add(1, std::memory_order_acq_rel);
     *out = c;
     return 0;
 }

@@ -1921,6 +1921,10 @@ struct trmc_plan {
     hipStream_t cstream = nullptr;       // copy stream: D2H of window k runs beside the kernels of window k + 1
     hipEvent_t ev_fetch_ready = nullptr, ev_fetch_done = nullptr;
     bool fetch_pending = false;
+    // "the last gather queued on the plan's stream after a window has read the planes" -- what a set-up queued on ANOTHER stream
+    // (TRMC_SETUP_ASIDE) waits for before it lets a new window's tiles overwrite them
+    hipEvent_t ev_gather = nullptr;
+    bool gather_pending = false;
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
     std::vector<int32_t> rowset_lag;
@@ -1973,6 +1977,16 @@ int upload_i32(DevBuf &b, const std::vector<int32_t> &v, size_t min_elems)
 int use_device(const trmc_plan *pl)
 {
     HIP_TRY(hipSetDevice(pl->device));
+    return 0;
+}
+
+// a kernel that reads the result planes of the last window has just been queued on the plan's stream (outside a window)
+int note_gather(trmc_plan *pl)
+{
+    if (pl->run.active) return 0;
+    if (!pl->ev_gather) HIP_TRY(hipEventCreateWithFlags(&pl->ev_gather, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(pl->ev_gather, pl->stream));
+    pl->gather_pending = true;
     return 0;
 }
 
@@ -2114,7 +2128,15 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     const char *aside_env = std::getenv("TRMC_SETUP_ASIDE");
     const bool setup_aside = aside_env && aside_env[0] == '1' && short_ts && pl->wstream != nullptr;
     hipStream_t const plan_st = st;
-    if (setup_aside) st = pl->wstream;
+    if (setup_aside) {
+        st = pl->wstream;
+        // the gathers queued on the plan's own stream since the last window (trmc_fetch_begin, trmc_gather_flow_rows, the
+        // final state) read planes this window's tiles overwrite: the set-up goes behind the last of them (an event
+        // recorded when that gather was queued -- not ev[0] above, which sits behind whatever another plan has put into
+        // the shared high-priority queue since)
+        if (pl->gather_pending) HIP_TRY(hipStreamWaitEvent(st, pl->ev_gather, 0));
+    }
+    pl->gather_pending = false;
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st)); // no history at the start of a window
     if (pl->collect_cost) HIP_TRY(hipMemsetAsync(pl->it_sum.p, 0, (size_t)np * sizeof(uint16_t), st));
     // every element the result reads is written below: time row 0 by k_init_state, rows 1..nsteps
@@ -2865,6 +2887,9 @@ template <class T> int chain_from_t(trmc_plan *dst, trmc_plan *src, int nsteps_d
         HIP_TRY(hipEventRecord(dst->ev_chain[2], dst->wstream));
         HIP_TRY(hipStreamWaitEvent(src->wstream, dst->ev_chain[2], 0)); // the source's next window does not overwrite what is being read
         HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_chain[2], 0));
+        // ... and the receiver's own stream does not read time row 0 of the wide rows before this copy has written it: its
+        // tail's first launch (step 1) takes no tile wait and reads q_tm[0] of its upstream wide rows
+        HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_chain[2], 0));
     }
     HIP_TRY(hipEventRecord(dst->ev_chain[1], src->stream));
     HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_chain[1], 0));
@@ -3150,6 +3175,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->cstream) (void)hipStreamDestroy(pl->cstream);
     if (pl->ev_fetch_ready) (void)hipEventDestroy(pl->ev_fetch_ready);
     if (pl->ev_fetch_done) (void)hipEventDestroy(pl->ev_fetch_done);
+    if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
@@ -3216,7 +3242,7 @@ static int final_state_into(trmc_plan *pl, void *dst)
                            (double *)dst, n, pl->nseg_pad, T_, 1, T_);
     }
     HIP_TRY(hipGetLastError());
-    return 0;
+    return note_gather(pl);
 }
 
 // initial state (or warm start), boundary hydrographs, and the bookkeeping common to every forcing upload
@@ -3656,7 +3682,7 @@ int trmc_gather_flow_range(trmc_plan *pl, int32_t rowset, int t_begin, int t_end
         hipLaunchKernelGGL((k_gather_range<double>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const double *)pl->tm.p,
                            (const int32_t *)pl->rowsets[rowset].p, (double *)dst_dev, nrows, pl->nseg_pad, t_begin, t_end, dst_stride, 1);
     HIP_TRY(hipGetLastError());
-    return 0;
+    return gst == pl->stream ? note_gather(pl) : 0;
 }
 
 int trmc_set_boundary_flow_range(trmc_plan *pl, int t_begin, int t_end, const void *q_dev, int64_t src_stride,
@@ -3826,6 +3852,7 @@ int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_hos
             hipLaunchKernelGGL((k_gather_rows<double>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream, (const double *)pl->tm.p,
                                (const int32_t *)pl->rowsets[rowset].p, (double *)pl->fetch_hyd.p, nrows, pl->nseg_pad, T_, 1);
         HIP_TRY(hipGetLastError());
+        if (int rc = note_gather(pl)) return rc;
     }
     if (qb) {
         if (int rc = pl->fetch_q0.ensure(qb)) return rc;

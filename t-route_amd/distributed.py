@@ -15,18 +15,6 @@ gather logic is exercised with world_size 2 on gloo without a GPU.
 """
 import os as _os
 
-# Before any HIP runtime is loaded by this process: ONE hardware queue per stream priority.  A plan's compute stream
-# (high priority), its transpose stream (low) and the exchange stream (ordinary: the communicator's, RCCL's) then sit on three
-# hardware queues whatever else the process has created.  With more queues per priority the runtime spreads streams over
-# them in creation order, and for some assignments a stream waiting on events of the plan's stream puts that stream's
-# launches in a slow mode -- 67 us instead of 25 us per step launch of a 600 k-row rank, for the whole window.  Which
-# assignments depends on the number of streams created before: round 1 saw it with 3 and 4 queues and never with 2; with
-# one more stream per plan (round 2) it is 2 queues that trigger it (N = 2 and N = 4 owners of the trunk: 21 ms instead
-# of 12.4 / 8.2 ms) and 3 and 4 that do not.  One queue per priority has no assignment to get wrong.
-# The variable is read when the runtime initialises, so it is set at import -- a caller that has already initialised HIP
-# should export it itself.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
-
 import numpy as np
 
 from . import sharding
@@ -47,6 +35,12 @@ def restrict_csr(up_ptr, up_idx, rows, g2l):
     return lp, li
 
 
+class _EngineOf:
+    """stands in for a plan that does not exist yet where only its engine is asked for"""
+    def __init__(self, engine):
+        self.engine = engine
+
+
 class ShardedRouter:
     def __init__(self, to, params, rank=0, world=1, device=0, plan_factory=None, precision=32,
                  partition=None, cost_hint=None, assume_short_ts=None, engine="auto"):
@@ -56,6 +50,11 @@ class ShardedRouter:
         timestep mode the router will be used with, if known; "auto" | "levels" | "flow")."""
         if plan_factory is None:
             from .plan import RoutingPlan  # the HIP engine; no fallback
+            from . import _lib
+            # one hardware queue per stream priority for this process's HIP runtime, if it is not up yet (why: DESIGN.md
+            # section 7b; _lib.single_hw_queue_per_priority).  Done here, when a router is built -- importing this module
+            # changes nothing for other HIP users of the process.
+            _lib.single_hw_queue_per_priority("troute_amd.distributed.ShardedRouter")
 
             def plan_factory(lp, li, par, boundary, prec, dev, short=None, **kw):
                 # short: the merged plan of the short-timestep device path is built for that mode whatever the caller said
@@ -311,6 +310,20 @@ class ShardedRouter:
         self._planM_upload = self._upload_gen
         return self.planM
 
+    def _merged_engine(self):
+        """The engine trmc_plan_create_ex's TRMC_ENGINE_AUTO gives the merged short-timestep plan (rows0 + trunk), without
+        building it: the rule of csrc/trmc.hip (fp64 -> levels; TRMC_ENGINE overrides; fp32 meant for assume_short_ts with a
+        million routed rows or more -> levels; else dataflow)."""
+        if self.plan1 is None:
+            return getattr(self.plan0, "engine", "levels")
+        if self._mk["precision"] != 32:
+            return "levels"
+        env = _os.environ.get("TRMC_ENGINE")
+        if env in ("levels", "flow"):
+            return env
+        routed = int(self.rows0.shape[0]) + int((~np.asarray(self.boundary1, dtype=bool)).sum())
+        return "levels" if routed >= 1_000_000 else "flow"
+
     def _default_chunks(self, plan):
         """time chunks of the hand-off pipeline: a launch per chunk.  The level engine launches per timestep anyway and
         wants the trunk's skew (two chunks) short; the dataflow engine runs a chunk as one persistent launch and wants
@@ -330,9 +343,14 @@ class ShardedRouter:
         X, dev, comm, e = self._X, self._dev, self._comm, self._esz
         nsteps = self.nsteps
         if nchunks is None:
-            # (the merged plan has the same engine as plan0 would be given for the same rows plus the trunk: ask plan0 first,
-            # re-derive below once the merged plan exists)
-            nchunks = self._default_chunks(self.planM if self.planM is not None else self.plan0)
+            # Decided ONCE per router, from the engine the MERGED plan runs on -- not from plan0's on the first window and the
+            # merged plan's afterwards: the two can differ (plan0 under a million rows: dataflow; rows0 + trunk at or above
+            # it: levels), the chunk count would change between the first and the second window, with it the trunk's lag,
+            # and a merged plan rebuilt for the new lag has no resident state to continue from.
+            if getattr(self, "_nchunks_default", None) is None:
+                self._nchunks_default = self._default_chunks(self.planM if self.planM is not None
+                                                             else _EngineOf(self._merged_engine()))
+            nchunks = self._nchunks_default
         K = max(1, -(-nsteps // max(1, int(nchunks))))
         C = -(-nsteps // K)
         lag = 2 * K if self.plan1 is not None else 0

@@ -86,6 +86,7 @@ class RoutingPlan:
         flags = {"auto": _lib.ENGINE_AUTO, "levels": _lib.ENGINE_LEVELS, "flow": _lib.ENGINE_FLOW}[engine]
         if assume_short_ts is not None:
             flags |= _lib.PLAN_SHORT_TS if assume_short_ts else _lib.PLAN_FULL_TS
+        _lib.mark_hip_started()
         _lib.check(_lib.lib().trmc_plan_create_ex(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
                                                   _lib.ptr(b), _lib.ptr(hint), precision, device, flags, C.byref(h)))
         self._h = h

@@ -179,6 +179,58 @@ def test_communicator_chunks_blocks_larger_than_its_segment():
         assert np.array_equal(got[r][0], data[0]) and np.array_equal(got[r][1], data[1])
 
 
+def test_a_segment_left_by_a_dead_job_is_never_used():
+    """A crashed or killed job leaves its shared-memory segment behind: `attached` >= world, barrier counters mid-count.  A
+    new launch under the SAME key must not trust it: rank 0 removes and re-creates the name exclusively, the other ranks
+    only proceed on a segment whose live rank 0 has answered their token -- also when they come first and find the dead
+    one.  Same for the RCCL id, which now travels over such a communicator instead of a file."""
+    import mmap
+    import threading
+    import time
+    from troute_amd import comm as X
+    from troute_amd.comm import Comm
+    key = f"stale{os.getpid()}"
+    path = f"/dev/shm/trmc_{key}"
+    world = 2
+
+    def plant_dead_segment():
+        with open(path, "wb") as f:                                   # header page + data area of a dead two-rank job
+            hdr = np.zeros(1024, np.uint32)
+            hdr[0], hdr[1], hdr[2], hdr[3] = 1, 7, 2, world           # arrived = 1 (mid-barrier), generation, attached = world
+            hdr[4] = 0x74726d63                                       # even its magic is intact
+            f.write(hdr.tobytes() + bytes(64 * 1024))
+    for late_rank0 in (False, True):
+        plant_dead_segment()
+        got, errs = [None] * world, []
+
+        def run(r):
+            try:
+                if (r == 0) == late_rank0:
+                    time.sleep(0.5)                                   # the other rank meets the dead segment first
+                c = Comm(r, world, device=-1, backend="shm", key=key, shm_bytes=64 * 1024)
+                for it in range(20):                                  # barriers inside: counters must start from zero
+                    got[r] = c.all_gather_host(np.full(1000, 10 * it + r, np.int32))
+                    assert (got[r][0] == 10 * it).all() and (got[r][1] == 10 * it + 1).all()
+                c.close()
+            except Exception as e:      # pragma: no cover
+                errs.append(e)
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join(60) for t in ts]
+        assert not errs, errs
+        assert not os.path.exists(path)                               # the last rank out removed the name
+    # the id of an RCCL communicator reaches the other ranks over the same kind of channel, never through a stale file
+    ids = [None] * world
+    blob = bytes(range(128))
+
+    def run_id(r):
+        ids[r] = X.exchange_id(r, world, key, lambda: blob)
+    ts = [threading.Thread(target=run_id, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert ids == [blob, blob]
+
+
 def test_partition_by_measured_cost_balances_cost_not_rows():
     """sharding.partition(row_cost=...): pieces are packed by the cost their rows were measured to need."""
     from troute_amd import sharding, synthetic
@@ -205,18 +257,31 @@ def test_partition_by_measured_cost_balances_cost_not_rows():
             assert (lc[np.setdiff1d(np.arange(nparts), free)] <= lc[free].max()).all()
 
 
-def test_import_pins_one_hardware_queue_per_stream_priority():
-    """troute_amd.distributed sets GPU_MAX_HW_QUEUES before any HIP runtime loads (with several queues per
-    priority some stream-to-queue assignments put a plan's launches in a slow mode); a caller's own setting wins."""
+def test_one_hardware_queue_per_stream_priority_is_set_at_construction_not_at_import():
+    """GPU_MAX_HW_QUEUES=1 (with several queues per priority some stream-to-queue assignments put a plan's
+    launches in a slow mode) is set when a communicator or a sharded router is BUILT and the HIP runtime is not up yet --
+    importing troute_amd.distributed has no side effect on other HIP users of the process; a caller's own setting wins; and
+    when the runtime has already been initialised the library says so instead of changing the variable to no effect."""
     import subprocess
     import sys
-    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import troute_amd.distributed; print(os.environ['GPU_MAX_HW_QUEUES'])"
-    env = dict(os.environ, PYTHONPATH=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "t-route_amd", ".."))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert out.returncode == 0 and out.stdout.strip() == "1", out.stderr
-    code2 = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '4'; import troute_amd.distributed; print(os.environ['GPU_MAX_HW_QUEUES'])"
-    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert out.returncode == 0 and out.stdout.strip() == "4", out.stderr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+
+    def run(code):
+        out = subprocess.run([sys.executable, "-W", "always", "-c", code], capture_output=True, text=True, env=env, cwd=root)
+        assert out.returncode == 0, out.stderr
+        return out.stdout.strip(), out.stderr
+    pre = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import troute_amd.distributed, troute_amd.comm; from troute_amd import _lib; "
+    assert run(pre + "print(os.environ.get('GPU_MAX_HW_QUEUES'))")[0] == "None"                       # import alone: nothing
+    assert run(pre + "_lib.single_hw_queue_per_priority('t'); print(os.environ['GPU_MAX_HW_QUEUES'])")[0] == "1"
+    out, err = run(pre + "_lib.mark_hip_started(); _lib.single_hw_queue_per_priority('t'); print(os.environ.get('GPU_MAX_HW_QUEUES'))")
+    assert out == "None" and "RuntimeWarning" in err and "GPU_MAX_HW_QUEUES" in err
+    assert run("import os; os.environ['GPU_MAX_HW_QUEUES'] = '4'; from troute_amd import _lib; _lib.single_hw_queue_per_priority('t'); "
+               "print(os.environ['GPU_MAX_HW_QUEUES'])")[0] == "4"
+    # the constructors call it: a router built on the CPU stand-in (plan_factory given) leaves the variable alone, the
+    # product path (no factory: the HIP plan) sets it before the first plan is made
+    src = open(os.path.join(root, "t-route_amd", "distributed.py")).read() + open(os.path.join(root, "t-route_amd", "comm.py")).read()
+    assert src.count("single_hw_queue_per_priority(") == 2 and "environ.setdefault(\"GPU_MAX_HW_QUEUES\"" not in src
 
 
 @pytest.mark.parametrize("seed,nseg,nnet,nparts", [(5, 60000, 300, 4), (23, 90000, 120, 8), (7, 40000, 500, 2)])

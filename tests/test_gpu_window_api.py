@@ -307,12 +307,17 @@ def test_two_plans_taking_turns_on_the_device_give_each_its_own_window(monkeypat
         assert np.array_equal(a.download_fvd().view(np.uint32), want_a.view(np.uint32))
 
 
-def test_a_sequence_of_windows_on_two_plans_taking_turns_equals_the_sequence_on_one(monkeypatch):
+@pytest.mark.parametrize("aside", ["1", None])
+def test_a_sequence_of_windows_on_two_plans_taking_turns_equals_the_sequence_on_one(monkeypatch, aside):
     """trmc_plan_chain_from: consecutive windows of ONE sequence alternate between two plans of the same network, each
     starting from the state the other's window leaves -- handed over on the device, the wide levels' rows behind the other
     plan's last tile, the rest behind its tail -- while the other plan's window may still be running.  The same bits as the
-    sequence routed window after window on one plan (trmc_upload_forcing with q0 = NULL)."""
-    monkeypatch.setenv("TRMC_SETUP_ASIDE", "1")
+    sequence routed window after window on one plan (trmc_upload_forcing with q0 = NULL).  The API does not require
+    TRMC_SETUP_ASIDE: without it the receiver's set-up and tail run on its own stream, which must wait for BOTH copies."""
+    if aside:
+        monkeypatch.setenv("TRMC_SETUP_ASIDE", aside)
+    else:
+        monkeypatch.delenv("TRMC_SETUP_ASIDE", raising=False)
     monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
     monkeypatch.setenv("TRMC_WIDE_K", "8")
     to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(seed=7, nseg=6000)
