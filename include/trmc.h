@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 12
+#define TRMC_ABI_VERSION 13
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -370,6 +370,19 @@ int trmc_route(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_sho
  * as reach.pyx:55 passes it.
  */
 int trmc_segments(int device, int precision, int64_t n, const void *in, void *out);
+
+/*
+ * [R3] with its own signature: the reference's bind(c) entry point of one segment-step,
+ * c_muskingcungenwm (src/kernel/muskingum/pyMCsingleSegStime_NoLoop.f90:8-21; C header
+ * src/troute-routing/troute/routing/fast_reach/pyMCsingleSegStime_NoLoop.h:1-21; Cython declaration
+ * fast_reach/fortran_wrappers.pxd:19-40; call site reach.pyx:37-94).  21 float pointers: dt qup quc qdp ql dx bw tw twcc
+ * n ncc cs s0 velp depthp in, qdc velc depthc ck cn X out; no return value.  One step on the device per call (device
+ * TRMC_DEVICE, default 0) -- the binding a maintainer swaps in for the Fortran symbol; batches go through trmc_segments.
+ * It cannot signal either: on failure the six outputs are NaN and trmc_last_error() holds the reason.
+ */
+void trmc_muskingcungenwm(float *dt, float *qup, float *quc, float *qdp, float *ql, float *dx, float *bw, float *tw,
+                          float *twcc, float *n, float *ncc, float *cs, float *s0, float *velp, float *depthp,
+                          float *qdc, float *velc, float *depthc, float *ck, float *cn, float *X);
 
 /*
  * Windows of ONE sequence on TWO plans of the same network (same inputs, same cost hint: the same order), taking turns:

@@ -3948,6 +3948,34 @@ int trmc_segments(int device, int precision, int64_t n, const void *in, void *ou
     return precision == 32 ? segments_t<float>(n, in, out) : segments_t<double>(n, in, out);
 }
 
+// The reference's own C binding of one segment-step -- c_muskingcungenwm, src/kernel/muskingum/pyMCsingleSegStime_NoLoop.f90:8-21
+// (header src/troute-routing/troute/routing/fast_reach/pyMCsingleSegStime_NoLoop.h:1-21, declared to Cython at
+// fast_reach/fortran_wrappers.pxd:19-40): 21 float pointers, 15 in, 6 out, no return value.  One step on the device per call
+// (trmc_segments with n = 1): the drop-in for reach.pyx:37-94's call site, not a fast path -- the fast paths are the batch
+// form and the plans.  Like the Fortran it cannot signal: on failure the six outputs are NaN and trmc_last_error() says why.
+// qdc is taken as 0 on entry (reach.pyx:55 passes 0; f90:74 reads it).  Device: TRMC_DEVICE (default 0).
+void trmc_muskingcungenwm(float *dt, float *qup, float *quc, float *qdp, float *ql, float *dx, float *bw, float *tw,
+                          float *twcc, float *n, float *ncc, float *cs, float *s0, float *velp, float *depthp, float *qdc,
+                          float *velc, float *depthc, float *ck, float *cn, float *X)
+{
+    float *outs[6] = {qdc, velc, depthc, ck, cn, X};
+    const float *ins[15] = {dt, qup, quc, qdp, ql, dx, bw, tw, twcc, n, ncc, cs, s0, velp, depthp};
+    bool ok = true;
+    for (const float *p : ins) ok = ok && p != nullptr;
+    for (float *p : outs) ok = ok && p != nullptr;
+    float in[15], out[6];
+    int rc = TRMC_EINVAL;
+    if (ok) {
+        for (int i = 0; i < 15; ++i) in[i] = *ins[i];
+        const char *d = std::getenv("TRMC_DEVICE");
+        rc = trmc_segments(d ? std::atoi(d) : 0, 32, 1, in, out);
+    } else {
+        (void)fail(TRMC_EINVAL, "trmc_muskingcungenwm: an argument is NULL");
+    }
+    for (int i = 0; i < 6; ++i)
+        if (outs[i]) *outs[i] = rc == 0 ? out[i] : std::nanf("");
+}
+
 int trmc_plan_chain_from(trmc_plan *dst, trmc_plan *src)
 {
     if (!dst || !src || dst == src) return fail(TRMC_EINVAL, "two different plans are needed");

@@ -68,6 +68,30 @@ def test_segment_step_fp64_bit_identical_to_reference_fortran():
     assert_bit_identical(got, kv["ref_qj0_f64"], "fp64 kernel vectors vs reference Fortran (-fdefault-real-8)")
 
 
+def test_reference_signature_entry_point():
+    """trmc_muskingcungenwm: the reference's own C binding of one segment-step (c_muskingcungenwm,
+    pyMCsingleSegStime_NoLoop.f90:8-21 / .h:1-21 -- 21 float pointers, no return value), one step per call.  The first
+    200 golden vectors of the reference Fortran plus its low-flow KAT, all six outputs, bit for bit; a NULL argument gives
+    NaNs and a message, like a routine that cannot signal."""
+    import ctypes as C
+    from troute_amd import _lib
+    lib = _lib.lib()
+    kv = H.load_kernel_vectors()
+    x = kv["inputs_f64"].astype(np.float32)[:200]
+    want = kv["ref_qj0_f32"][:200]
+    got = np.zeros((x.shape[0], 6), np.float32)
+    for i, row in enumerate(x):
+        a = [C.c_float(float(v)) for v in row] + [C.c_float(123.0) for _ in range(6)]   # (outputs start as garbage)
+        lib.trmc_muskingcungenwm(*[C.byref(v) for v in a])
+        got[i] = [v.value for v in a[15:]]
+    assert_bit_identical(got, want, "trmc_muskingcungenwm vs reference Fortran")
+    a = [C.c_float(1.0) for _ in range(21)]
+    ptrs = [C.byref(v) for v in a]
+    ptrs[3] = None
+    lib.trmc_muskingcungenwm(*ptrs)
+    assert all(np.isnan(v.value) for v in a[15:]) and b"NULL" in lib.trmc_last_error()
+
+
 def test_compute_reach_kernel_dict_entry():
     """The reference's dict-returning test entry (reach.pyx:66-103) on its low-flow KAT."""
     r = compute_reach_kernel(60.0, 0.04598825, 0.04598825, 0.21487340, 40.0, 1800.0, 112.0, 448.0,
