@@ -76,7 +76,8 @@ def parse():
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
     ap.add_argument("--no-two-members", action="store_true", help="skip the two-ensemble-members leg (a second plan of the network)")
-    ap.add_argument("--no-parity-sample", action="store_true", help="skip the post-timing oracle check of sampled networks")
+    ap.add_argument("--no-parity-full", "--no-parity-sample", dest="no_parity_full", action="store_true",
+                    help="skip the post-timing check of every segment against the reference on the CPU")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic / roofline.valu = null)")
     ap.add_argument("--headline-only", action="store_true", help="stop after the headline's timed windows (what the counter passes run)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -147,7 +148,8 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
         "cpu_quota": None if quota is None else round(float(quota), 2),
         "kind": kind,
         "per_thread": done / dt / max(nthreads, 1),
-        "sample": f"all {nseg} segments x the first {ns} of {nsteps} timesteps ({done} segment-timesteps), {dt:.1f} s wall; "
+        "sample": f"all {nseg} segments x the first {ns} of {nsteps} timesteps ({done} segment-timesteps; the as-shipped "
+                  f"reference kernel, a bounded sample: {ns} steps, not the whole window), {dt:.1f} s wall; "
                   f"reference decomposition by-subnetwork-jit: {int(job_ptr.shape[0] - 1)} sub-networks of <= 10000 segments in "
                   f"{int(order_ptr.shape[0] - 1)} orders ({', '.join(str(int(j)) for j in jobs)} jobs), OpenMP dynamic, "
                   f"C loop around the reference Fortran kernel; decomposition prepared in {t_prep:.1f} s outside the clock",
@@ -156,61 +158,50 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     }
 
 
-def parity_sample(net, router, days, q0, nsteps, qts, n_networks=50, seed=20250930, outlets=None):
-    """Checker, run AFTER the timed region: ~50 whole independent networks of the workload (10-3 000 segments each) are
-    routed alone by the oracle (oracle/, the CPU restatement pinned to the reference Fortran) through the same sequence
-    of windows the router has been through -- `days`: the forcing of day N-1 (cold start from q0), day N, day N+1 -- and
-    compared bit for bit with what the timed plan holds for them after the LAST timed window: the hydrograph of every
-    sampled row and the final state.  Independent networks do not interact, so the sub-collection's result inside the
-    2.7 M-row run must equal its result alone.  outlets = (rows, hydrographs): the multi-GPU job's product, the gathered
-    outlet hydrographs of EVERY network -- then those of the sampled networks are what is compared."""
+def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0):
+    """Checker, run AFTER the timed region: EVERY segment of the workload -- the dominant basin included -- is routed on the
+    CPU by the reference Fortran kernel (canonical Qj_0; oracle/_ref built from the reference's sources, else the pinned
+    restatement) through the same sequence of windows the router has been through -- `days`: the forcing of day N-1 (cold
+    start from q0), day N, day N+1 -- over the reference's own decomposition into ordered sub-networks
+    (oracle.reference_windows), and compared bit for bit with what the timed plan holds after the LAST timed window: the
+    flow of every row at every step, the velocity and depth series of every row (exact position-weighted checksums of the
+    bit patterns), the final state of every row, the outlet hydrographs the timed windows copied to the host.
+    outlets = (rows, hydrographs): the multi-GPU job's product, the gathered outlet hydrographs of EVERY network -- then
+    those are what is compared (the ranks hold the rest)."""
     from oracle import oracle as O
-    from troute_amd import sharding
-    from troute_amd.distributed import restrict_csr
-    from troute_amd.plan import topology_levels
-    from troute_amd.synthetic import upstream_csr
     to, params = net["to"], net["params"]
     nseg = to.shape[0]
-    rng = np.random.default_rng(seed)
-    outlet = sharding.outlet_of(to)
-    _, lab = np.unique(outlet, return_inverse=True)
-    sizes = np.bincount(lab)
-    cand = np.flatnonzero((sizes >= 10) & (sizes <= 3000))
-    pick = rng.choice(cand, min(n_networks, cand.size), replace=False)
-    rows = np.flatnonzero(np.isin(lab, pick))
     t0 = time.perf_counter()
-    if outlets is None:
-        hyd = router.plan0.gather_flow_rows(rows)           # (world == 1: the plan's rows are the network's rows)
-        final = router.plan0.download_final_state()[rows]
-    up_ptr, up_idx = upstream_csr(to)
-    g2l = np.full(nseg, -1, np.int64)
-    g2l[rows] = np.arange(rows.size)
-    lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)
-    lvl, _, _ = topology_levels(lp, li)
-    state = np.ascontiguousarray(q0[rows])
-    want = None
-    for ql in days:
-        want = O.network_by_segment(nsteps, qts, lp, li, lvl, params[rows], state, np.ascontiguousarray(ql[rows]), True, det=True)
-        state = np.ascontiguousarray(want[:, -1, :][:, [0, 0, 2]])
+    ref = O.reference_windows(to, params, days, q0, nsteps, qts, True, nthreads=threads)
     u32 = lambda x: np.ascontiguousarray(x).view(np.uint32)   # noqa: E731
-    if outlets is not None:
-        o_rows, o_hyd = outlets
-        mine = np.flatnonzero(to[rows] < 0)                   # the sampled networks' outlets, as local rows
-        at = np.searchsorted(o_rows, rows[mine])
-        assert np.array_equal(o_rows[at], rows[mine])
-        same_h = bool(np.array_equal(u32(o_hyd[at]), u32(want[mine, 1:, 0])))
-        return {"networks": int(pick.size), "segments": int(rows.size), "windows": len(days), "timesteps": int(nsteps),
-                "bit_identical": same_h, "compared": "outlet hydrographs of the sampled networks out of the job's all-gathered block",
-                "differing_values": int((u32(o_hyd[at]) != u32(want[mine, 1:, 0])).sum()),
-                "checker": "oracle/ (C restatement pinned to the reference Fortran), det_pow instantiation",
-                "seconds": round(time.perf_counter() - t0, 1)}
-    same_h = bool(np.array_equal(u32(hyd), u32(want[:, 1:, 0])))
-    same_s = bool(np.array_equal(u32(final), u32(state)))
-    return {"networks": int(pick.size), "segments": int(rows.size), "windows": len(days), "timesteps": int(nsteps),
-            "bit_identical": same_h and same_s, "hydrographs_identical": same_h, "final_state_identical": same_s,
-            "differing_values": int((u32(hyd) != u32(want[:, 1:, 0])).sum() + (u32(final) != u32(state)).sum()),
-            "checker": "oracle/ (C restatement pinned to the reference Fortran), det_pow instantiation",
-            "seconds": round(time.perf_counter() - t0, 1)}
+    base = {"segments": int(nseg), "networks": int((to < 0).sum()), "windows": len(days), "timesteps": int(nsteps),
+            "checker": ("reference Fortran kernel (oracle/_ref/libmc_ref_qj0_f32.so, canonical Qj_0), " if ref["kind"] == "reference"
+                        else "oracle/ C restatement (pinned to the reference Fortran), ")
+                       + "C + OpenMP over the reference's by-subnetwork-jit decomposition, every segment, all windows",
+            "checker_seconds": round(ref["seconds"], 1)}
+    o_rows, o_hyd = outlets
+    want_o = ref["q"][o_rows, 1:]
+    same_o = bool(np.array_equal(u32(o_hyd), u32(want_o)))
+    if router is None:
+        base.update({"bit_identical": same_o, "compared": "the all-gathered outlet hydrographs of every network",
+                     "differing_values": int((u32(o_hyd) != u32(want_o)).sum()), "seconds": round(time.perf_counter() - t0, 1)})
+        return base
+    fvd = router.plan0.download_fvd().reshape(nseg, nsteps, 3)
+    final = router.plan0.download_final_state()
+    diff_q = 0
+    for lo in range(0, nseg, 200000):
+        diff_q += int((u32(fvd[lo:lo + 200000, :, 0]) != u32(ref["q"][lo:lo + 200000, 1:])).sum())
+    diff_v = int((O.series_checksum(fvd[:, :, 1]) != ref["chk_v"]).sum())
+    diff_d = int((O.series_checksum(fvd[:, :, 2]) != ref["chk_d"]).sum())
+    diff_s = int((u32(final) != u32(ref["state"])).sum())
+    base.update({"bit_identical": diff_q == 0 and diff_v == 0 and diff_d == 0 and diff_s == 0 and same_o,
+                 "flows_identical": diff_q == 0, "velocity_series_identical": diff_v == 0, "depth_series_identical": diff_d == 0,
+                 "final_state_identical": diff_s == 0, "outlet_hydrographs_identical": same_o,
+                 "differing_values": diff_q + diff_s, "rows_with_differing_velocity_or_depth": diff_v + diff_d,
+                 "compared": "flow of every row at every step; velocity and depth series of every row (exact checksums); final "
+                             "state of every row; the outlet hydrographs of the last timed window",
+                 "seconds": round(time.perf_counter() - t0, 1)})
+    return base
 
 
 def _diffusive_inputs(gold, nsteps):
@@ -545,10 +536,10 @@ def main():
         return
     resident = timed(router, True, max(1, min(a.steps, 3)), 1)
     parity = None
-    if rank == 0 and not a.no_parity_sample and a.precision == 32:
-        try:      # what the timed plan holds after the last timed window, against the oracle (checker use, outside the clock)
-            parity = parity_sample(net, router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
-                                   outlets=(router._out_rows, hyd) if use_dist else None)
+    if rank == 0 and not a.no_parity_full and a.precision == 32:
+        try:      # what the timed plan holds after the last timed window, against the reference (checker use, outside the clock)
+            parity = parity_full(net, None if use_dist else router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
+                                 outlets=(router._out_rows if use_dist else router.my_out0_global, hyd), threads=a.cpu_threads)
         except Exception as e:
             parity = {"error": repr(e)}
     two = None
@@ -724,7 +715,7 @@ def main():
             },
             "roofline": roof,
             "cpu_baseline": cpu,
-            "parity_sample": parity,
+            "parity_full": parity,
             "untuned": untuned,
             "full_ts": full,
             "per_rank": per_rank,
@@ -891,7 +882,7 @@ def pmc_counters(pattern, launches_per_window, args):
                 d = os.path.join(td, f"p{i}")
                 cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "c", "--", sys.executable,
                        os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--headline-only", "--no-cpu-baseline",
-                       "--no-full-ts", "--no-diffusive", "--no-parity-mode", "--no-traffic", "--no-parity-sample",
+                       "--no-full-ts", "--no-diffusive", "--no-parity-mode", "--no-traffic", "--no-parity-full",
                        "--nsteps", str(args.nsteps), "--qts", str(args.qts), "--precision", str(args.precision)]
                 if args.nseg:
                     cmd += ["--nseg", str(args.nseg)]

@@ -31,7 +31,13 @@ typedef void (*kernel_fn)(const float *dt, const float *qup, const float *quc, c
  *     q[job_ptr[j] * (nsteps + 1) + t * m + (k - job_ptr[j])],  m = rows of the job
  * so that a timestep of a job reads one contiguous run and writes the next -- the reference hands every job its own
  * sliced copies of the tables too (compute.py:741-760).  job_of_row[k] names the job of row k (for upstream rows that
- * belong to a job of an earlier order: the hand-over of flowveldepth_interorder, compute.py:882-897). */
+ * belong to a job of an earlier order: the hand-over of flowveldepth_interorder, compute.py:882-897).
+ *
+ * chk_v / chk_d (each [nseg] or NULL): position-weighted checksums of the velocity and depth series of every row,
+ *     chk[row] += (double)(bit pattern of the value at step t) * t,   t = 1..nsteps
+ * -- integers below 2**32 * 2**9 * 2**9, exact in a double whatever the order of the additions -- so that a checker can
+ * compare EVERY (v, d) of a full-size run without holding two more [nseg][nsteps] arrays (tests/test_gpu_parity.py,
+ * bench.py parity_full form the same sums from the device's result). */
 long cpu_baseline_route(kernel_fn kernel, int nsteps, int qts, int short_ts, long norders,
                         const long *order_ptr, /* [norders + 1] jobs of every order, deepest order first          */
                         const long *job_ptr,   /* [njobs + 1] rows of every job                                    */
@@ -39,7 +45,8 @@ long cpu_baseline_route(kernel_fn kernel, int nsteps, int qts, int short_ts, lon
                         const long *up_ptr, const long *up_idx, /* upstream rows of every row, summation order     */
                         const float *params,   /* [nseg][9] dt dx bw tw twcc n ncc cs s0                           */
                         const float *qlat, long nq, float *q, float *d, int nthreads,
-                        double *order_seconds /* [norders] wall time of every order, or NULL */)
+                        double *order_seconds /* [norders] wall time of every order, or NULL */,
+                        double *chk_v, double *chk_d)
 {
     long done = 0;
     const long stride = (long)nsteps + 1;
@@ -76,6 +83,13 @@ long cpu_baseline_route(kernel_fn kernel, int nsteps, int qts, int short_ts, lon
                            &p[5], &p[6], &p[7], &p[8], &velp, &depthp, &qdc, &velc, &depthc, &ck, &cn, &X);
                     q_curr[s - r0] = qdc;
                     d[s] = depthc;
+                    if (chk_v) {
+                        union { float f; unsigned u; } bv, bd;
+                        bv.f = velc;
+                        bd.f = depthc;
+                        chk_v[s] += (double)bv.u * (double)t;
+                        chk_d[s] += (double)bd.u * (double)t;
+                    }
                 }
             }
             done += m * (long)nsteps;

@@ -361,10 +361,12 @@ _CPU = None
 
 
 def cpu_baseline_route(nsteps, qts, short_ts, order_ptr, job_ptr, rows, up_ptr, up_idx, params, qlat, q0,
-                       ref_name=None, nthreads=0):
+                       ref_name=None, nthreads=0, checksums=False):
     """One routing window over ordered sub-networks in C + OpenMP (oracle/cpu_baseline.c); the kernel is the reference
     Fortran symbol of oracle/_ref/<ref_name>, or the oracle's restatement when ref_name is None.
-    Returns (flows [nseg, nsteps+1], depths [nseg], segment-timesteps routed, threads)."""
+    Returns (flows [nseg, nsteps+1], depths [nseg], segment-timesteps routed, threads); with checksums=True the
+    position-weighted checksums of every row's velocity and depth series (cpu_baseline.c; `series_checksum` forms the
+    same sums from a [row][t] array) are left in cpu_baseline_route.chk_v / .chk_d [nseg]."""
     global _CPU
     if _CPU is None:
         _CPU = C.CDLL(os.path.join(_HERE, "libcpu_baseline.so"))
@@ -399,13 +401,16 @@ def cpu_baseline_route(nsteps, qts, short_ts, order_ptr, job_ptr, rows, up_ptr, 
     import time as _time
     order_s = np.zeros(order_ptr.shape[0] - 1, dtype=np.float64)
     q += 0                                              # every page touched before the clock starts
+    chk_v = np.zeros(n if checksums else 1, dtype=np.float64)
+    chk_d = np.zeros(n if checksums else 1, dtype=np.float64)
     t_c = _time.perf_counter()
     done = _CPU.cpu_baseline_route(kern, C.c_int(nsteps), C.c_int(qts), C.c_int(int(bool(short_ts))),
                                    C.c_long(order_ptr.shape[0] - 1), _ptr(order_ptr, C.c_long), _ptr(job_ptr, C.c_long),
                                    _ptr(job_of_row, C.c_long), _ptr(up_ptr, C.c_long), _ptr(up_idx, C.c_long),
                                    _ptr(params, C.c_float), _ptr(qlat, C.c_float), C.c_long(qlat.shape[1]),
                                    _ptr(q, C.c_float), _ptr(d, C.c_float), C.c_int(int(nthreads)),
-                                   _ptr(order_s, C.c_double))
+                                   _ptr(order_s, C.c_double), _ptr(chk_v, C.c_double) if checksums else None,
+                                   _ptr(chk_d, C.c_double) if checksums else None)
     cpu_baseline_route.order_seconds = order_s.tolist()
     cpu_baseline_route.last_seconds = _time.perf_counter() - t_c    # the C call alone
     q_j, d_j = q, d                                                  # back to [row][t], the caller's row order
@@ -415,4 +420,51 @@ def cpu_baseline_route(nsteps, qts, short_ts, order_ptr, job_ptr, rows, up_ptr, 
         q[caller_rows, t] = q_j[slot0 + t * step]
     d = np.empty_like(d_j)
     d[caller_rows] = d_j
+    cpu_baseline_route.chk_v = cpu_baseline_route.chk_d = None
+    if checksums:
+        cpu_baseline_route.chk_v = np.empty(n, np.float64)
+        cpu_baseline_route.chk_d = np.empty(n, np.float64)
+        cpu_baseline_route.chk_v[caller_rows] = chk_v
+        cpu_baseline_route.chk_d[caller_rows] = chk_d
     return q, d, int(done), int(nthreads) if nthreads else int(_CPU.cpu_baseline_max_threads())
+
+
+def series_checksum(x, chunk=100000):
+    """Position-weighted checksum of every row of a float32 [row][t] array: sum over t = 1..T of (bit pattern as an
+    integer) * t, exact in float64 (cpu_baseline.c forms the same sum while it routes).  `x` may be a strided view."""
+    n, T = x.shape
+    w = np.arange(1, T + 1, dtype=np.float64)
+    out = np.empty(n, dtype=np.float64)
+    for lo in range(0, n, chunk):
+        b = np.ascontiguousarray(x[lo:lo + chunk]).view(np.uint32).astype(np.float64)
+        out[lo:lo + chunk] = b @ w
+    return out
+
+
+def reference_windows(to, params, days, q0, nsteps, qts, short_ts=True, nthreads=0, deterministic=True):
+    """EVERY row of a network through consecutive routing windows on the CPU (checker for full-size runs): the
+    reference Fortran kernel with the canonical `Qj_0 = 0` (oracle/_ref/libmc_ref_qj0_f32.so, built from the reference's
+    own sources) when it is there -- else the oracle's restatement, which is pinned to it bit for bit
+    (tests/test_oracle_pinning.py) -- driven by oracle/cpu_baseline.c over the reference's own decomposition into ordered
+    sub-networks (compute.py:553-1209), window after window with the reference's warm start between them
+    (q0 <- (q_T, q_T, depth_T), AbstractNetwork.py:177-191; loop semantics mc_reach.pyx:492-505,:719-750).
+    days: forcing arrays [nseg][nq].  Returns a dict for the LAST window: q [nseg][nsteps+1] (column 0 = initial flow),
+    d_final [nseg], chk_v / chk_d (series_checksum of the velocity / depth series), state [nseg][3] = the next window's
+    q0, kind ("reference" | "port"), seconds."""
+    import time as _time
+    from troute_amd.synthetic import upstream_csr
+    ref_name = "libmc_ref_qj0_f32.so" if (deterministic and have_ref("libmc_ref_qj0_f32.so")) else None
+    t0 = _time.perf_counter()
+    order_ptr, job_ptr, rows = ordered_subnetworks(to, 10000)
+    up_ptr, up_idx = upstream_csr(to)
+    state = np.ascontiguousarray(q0, dtype=np.float32)
+    q = d = None
+    for i, ql in enumerate(days):
+        last = i == len(days) - 1
+        q, d, _, _ = cpu_baseline_route(nsteps, qts, short_ts, order_ptr, job_ptr, rows, up_ptr, up_idx, params, ql, state,
+                                        ref_name=ref_name, nthreads=nthreads, checksums=last)
+        state = np.ascontiguousarray(np.stack([q[:, -1], q[:, -1], d], axis=1))
+        if not last:
+            del q
+    return {"q": q, "d_final": d, "chk_v": cpu_baseline_route.chk_v, "chk_d": cpu_baseline_route.chk_d, "state": state,
+            "kind": "reference" if ref_name else "port", "seconds": _time.perf_counter() - t0}

@@ -14,6 +14,8 @@ Stated tolerances
   full-ts from a cold start is chaotic in the reference itself (test_oracle_pinning.py), which is
   why bit-exactness -- not a tolerance -- is the parity statement.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -507,6 +509,92 @@ def test_conus_bench_sequence_day_n_plus_1_bit_identical_to_oracle(conus):
     assert_bit_identical(hyd, want[:, 1:, 0], "day N+1 hydrographs on the tuned plan")
     assert_bit_identical(final[rows], state, "day N+1 final state on the tuned plan")
     assert (hyd > 0).mean() > 0.5
+
+
+def test_conus_every_segment_bit_identical_to_reference(conus):
+    """EVERY one of the 2 729 077 segments of the timed configuration -- the dominant 1.35 M-segment basin, the only owner
+    of the deep levels the tail kernel routes, included -- against the reference Fortran at full size: the three bench
+    days (N-1 cold, N, N+1 warm; bench.py's sequence on the plan tuned on day N) routed on the CPU by the reference
+    kernel with the canonical Qj_0 (oracle/_ref/libmc_ref_qj0_f32.so built from the reference's sources; the pinned
+    restatement where that build is absent) over the reference's own decomposition into ordered sub-networks
+    (oracle.reference_windows; loop semantics mc_reach.pyx:492-505,:719-750, warm start AbstractNetwork.py:177-191).
+    Compared bit for bit on day N+1: the flow of every row at every one of the 288 steps, the velocity and depth series
+    of every row (exact position-weighted checksums of their bit patterns), the final state of every row -- and the
+    14 713 outlet hydrographs the two-rank device-exchange job gathers for the same three days."""
+    import threading
+    from troute_amd import synthetic
+    from troute_amd.comm import Comm
+    from troute_amd.distributed import ShardedRouter
+    net, up_ptr, up_idx = conus
+    to, params = net["to"], net["params"]
+    nseg = to.shape[0]
+    nsteps, qts = 288, 12
+    qlat_s = net["qlat"]
+    qlat_a = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 1, previous=qlat_s)
+    qlat_b = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2, previous=qlat_a)
+    q0 = np.zeros((nseg, 3), np.float32)
+
+    ref = O.reference_windows(to, params, (qlat_s, qlat_a, qlat_b), q0, nsteps, qts, True)
+    assert ref["q"].shape == (nseg, nsteps + 1)
+
+    r = ShardedRouter(to, params, assume_short_ts=True)
+    assert r.plan0.engine == "levels"
+    r.upload(nsteps, qlat_s, q0)
+    r.route_resident(qts, True)                      # day N-1, cold
+    r.upload(nsteps, qlat_a, None)                   # day N, warm, cost collection on
+    r.collect_cost(True)
+    r.route_resident(qts, True)
+    hint = r.iteration_hint()
+    r.close()
+    r = ShardedRouter(to, params, cost_hint=hint, assume_short_ts=True)
+    r.upload(nsteps, qlat_s, q0)
+    r.route_resident(qts, True)
+    r.upload(nsteps, qlat_a, None)
+    r.route_resident(qts, True)
+    r.upload(nsteps, qlat_b, None)                   # day N+1: the timed window
+    for _ in range(2):
+        r.route_resident(qts, True)
+    assert r.last_stats["phase0"]["segment_steps"] == nseg * nsteps
+    fvd = r.plan0.download_fvd().reshape(nseg, nsteps, 3)
+    final = r.plan0.download_final_state()
+    r.close()
+    for lo in range(0, nseg, 200000):                # (in slices: the comparison's temporaries stay small)
+        assert_bit_identical(np.ascontiguousarray(fvd[lo:lo + 200000, :, 0]), ref["q"][lo:lo + 200000, 1:],
+                             f"flow of every row, rows {lo}..")
+    assert np.array_equal(O.series_checksum(fvd[:, :, 1]), ref["chk_v"]), "velocity series of some row differs"
+    assert np.array_equal(O.series_checksum(fvd[:, :, 2]), ref["chk_d"]), "depth series of some row differs"
+    assert_bit_identical(final, ref["state"], "final state of every row")
+    del fvd
+
+    # the two-rank job (two threads, one device, shared-memory transport): its product is the all-gathered outlet block
+    world, key = 2, f"full{os.getpid()}"
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            comm = Comm(rank, world, device=0, backend="shm", key=key)
+            rr = ShardedRouter(to, params, rank=rank, world=world, device=0, assume_short_ts=True, cost_hint=hint)
+            rr.enable_device_exchange(comm)
+            rr.upload(nsteps, qlat_s, q0)
+            rr.upload_trunk()
+            rr.route_on_device(qts, True, None)
+            rr.upload(nsteps, qlat_a, None)
+            rr.route_on_device(qts, True, None)
+            rr.upload(nsteps, qlat_b, None)
+            rows, hyd = rr.route_on_device(qts, True, None)
+            results[rank] = (rows, hyd.numpy())
+            rr.close()
+            comm.close()
+        except Exception as e:                          # pragma: no cover
+            errors.append(e)
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    outlets = np.flatnonzero(to < 0)
+    for rows, hyd in results:
+        assert np.array_equal(np.sort(rows), outlets)
+        assert_bit_identical(hyd, ref["q"][rows, 1:], "outlet hydrographs gathered by the two-rank job")
 
 
 def test_conus_row_relabelling_invariance(conus):
