@@ -80,7 +80,8 @@ typedef struct trmc_stats {
      * launch by k_mc_tile (0: every level one step per launch) */
     int32_t wide_levels, wide_k;
     int32_t wide_launches;   /* launches of k_mc_tile (part of main_launches)  */
-    int32_t reserved_;
+    int32_t window_kernel;   /* 1: the window went out as ONE persistent launch (k_mc_window: the leading wide_levels levels wide_k
+                              * timesteps per work item, the deeper levels one timestep per item, no transposing pass) */
     int64_t wide_segment_steps; /* segment-steps routed by those launches     */
     double ms_wide;          /* summed duration of those launches (they run beside the tail's, so this is not a share of ms_main) */
 } trmc_stats;

@@ -24,7 +24,7 @@ class Stats(C.Structure):
         ("nseg", C.c_int64), ("nseg_routed", C.c_int64), ("nlevels", C.c_int32), ("nsteps", C.c_int32),
         ("assume_short_ts", C.c_int32), ("main_launches", C.c_int32), ("segment_steps", C.c_int64),
         ("ms_prep", C.c_double), ("ms_main", C.c_double), ("ms_emit", C.c_double), ("ms_total", C.c_double),
-        ("wide_levels", C.c_int32), ("wide_k", C.c_int32), ("wide_launches", C.c_int32), ("reserved_", C.c_int32),
+        ("wide_levels", C.c_int32), ("wide_k", C.c_int32), ("wide_launches", C.c_int32), ("window_kernel", C.c_int32),
         ("wide_segment_steps", C.c_int64), ("ms_wide", C.c_double),
     ]
 

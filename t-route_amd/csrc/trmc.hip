@@ -729,6 +729,527 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535, (int)it_sum[su] + it_acc);
 }
 
+// ---------------------------------------------------------------- the window kernel (fp32, assume_short_ts)
+// ONE persistent launch routes a whole short-timestep window: no kernel boundary per tile, none per timestep, no transposing
+// pass.  The launches it replaces (k_mc_tile x 22, k_mc_step x 288, k_emit x 9 on three streams for a CONUS day) lose a drain
+// at the end of every tile, a boundary and a ramp at every step of the tail, and end a window with the tail alone on a
+// half-idle device.
+//
+// Work items, one WAVEFRONT each (a workgroup is one wavefront: nothing in an item needs a barrier):
+//   * wide item (k, d): the 64 plan positions w0 + 64 k .. of the leading W levels through K timesteps -- a lane of level l
+//     routes the steps (tau K, tau K + K], tau = d - l, of its row: the level skew of k_mc_tile, d its launch index ("sub-
+//     diagonal").  Same body as k_mc_tile: the row's thirteen parameter / constant columns in registers for K steps,
+//     results staged in LDS and written as 96-byte runs of out[row][step][q,v,d];
+//   * tail item (i, t): the 64 positions w1 + 64 i .. of the deeper levels through ONE timestep t -- what k_mc_step does
+//     for them, with (q, v, d) written straight into `out` (12 bytes per row and step; neighbouring steps of a row meet
+//     in the L2 / Infinity Cache): the time-major planes keep the flow and the depth only.
+// With assume_short_ts a row at step t reads flows of step t - 1 (mc_reach.pyx:504-505, :135-136), hence:
+//   * item (k, d) needs item k itself and the items holding its rows' upstream rows to have completed sub-diagonal d - 1
+//     (an upstream row lies at least one level lower, so after d - 1 it is at least K steps ahead): every wide item keeps
+//     ONE progress word prog[k] = sub-diagonals completed (single writer), and a consumer's lanes look at the words of the
+//     items that hold their upstream rows;
+//   * the tail's step t ("phase") needs every tail row at t - 1 -- a count of completed items per phase -- and the wide rows
+//     at t - 1: prog >= (t - 2) / K + W for the items holding its lanes' wide upstream rows.
+// Scheduling: a worker (wavefront) loops: if the tail's next phase is open it claims a tail item, else a wide item in
+// sub-diagonal order; claims are atomic counters sharded by XCD (one word saturates near 88 claims per microsecond; 5 120
+// workers finishing items of 10-50 us need several hundred) with stealing from the other shards.  A wide item is claimed
+// only when every item of the sub-diagonal before is claimed, a tail item only when its phase's predecessor is complete
+// and every wide item it may wait for is claimed: whatever a claimed item waits for is running or done, by induction over
+// the claim order -- no deadlock whatever the dispatch order or the residency of the workers (MI355X_MICROARCH.md:
+// nothing may be assumed about either).  Every wait is bounded by a watchdog that abandons the window (TRMC_EHIP).
+// Visibility between workgroups inside a launch (per-XCD L2s are not coherent, a CU's L1 is never refreshed): everything a
+// later item reads -- q_tm, d_tm, the progress words, the counters -- is stored write-through and loaded past the L1
+// (relaxed agent-scope atomics: global_store / global_load ... sc1), a writer drains its stores (s_waitcnt vmcnt(0)) before
+// it signals; the MI355X guide's recipe R1 with the payload itself stored sc1.  `out`, the iteration bytes and the
+// reservoir / nudging series are only read after the launch.
+constexpr int kWinStage = 8;          // timesteps of (q, v, d) a lane stages in LDS before it writes a run of `out`
+constexpr int kWinShards = 8;         // claim counters per item group: one per XCD
+constexpr int32_t kWinMaxLevels = 64; // at most this many leading levels are routed as wide items
+struct WinArgs {
+    int32_t w0, w1, s1;       // wide positions [w0, w1), tail positions [w1, s1)
+    int32_t K, kshift, W;     // timesteps per wide item (a power of two, 1 << kshift); wide levels
+    int32_t ndiag;            // sub-diagonals: ceil(nsteps / K) + W - 1
+    int32_t nwide, ntail;     // wave-items
+    const int32_t *diag_first, *diag_count; // [ndiag] the wide items active in a sub-diagonal: [first, first + count)
+    const int32_t *col_of_step; // [nsteps + 1] lateral-inflow column (t - 1) / qts of step t
+    int32_t *prog;            // [nwide]
+    int32_t *tile_claim;      // [ndiag][kWinShards]
+    int32_t *tail_claim;      // [nsteps + 1][kWinShards]
+    int32_t *tail_done;       // [nsteps + 1][kWinShards] completed items of a phase, by the shard of the item
+    int32_t *tail_shards;     // [nsteps + 1] complete shards of a phase
+    int32_t *ctl;             // [0] tail phases complete  [1] sub-diagonals wholly claimed  [2] abort  [3] tail phases wholly claimed
+                              // [4..6] what the watchdog's victim was waiting for  [8..15] tallies of a TRMC_WIN_DEBUG build
+    uint64_t watchdog_ticks;  // wall_clock64 ticks (100 MHz) any single wait may last
+};
+struct WindowArgs {
+    StepArgs<float> a;        // (first member: cold_args reads the kernel-argument segment from offset 0)
+    WinArgs w;
+};
+using WinCold = ColdArgs<WindowArgs>;
+
+__device__ __forceinline__ int32_t win_ld(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void win_st(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float win_ldf(const float *base, uint32_t byte_off)
+{
+    return __hip_atomic_load(&at(base, byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void win_stf(float *base, uint32_t byte_off, float v)
+{
+    __hip_atomic_store(&at(base, byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Claim counters and completion counters sit on cache lines of their own (kWinPad words apart): device-scope atomics on
+// one line are served one after the other (a word saturates near 88 per microsecond), and eight shard counters in one
+// 32-byte group were ONE such line -- with every worker that found a phase exhausted probing all eight, a phase of 4 400
+// items cost 40 000 atomics on it: half a millisecond per timestep, the first build of this kernel ran 147 ms a window.
+constexpr int kWinPad = 32;
+// one item of a shard's counter: its index, or -1 when the shard has none left.  One lane looks first (a load does not
+// queue behind the line's atomics the way another atomic does) and only then takes a ticket; the result is uniform.
+__device__ __forceinline__ int32_t win_claim(int32_t *p, const int32_t len)
+{
+    int32_t r = -1;
+    if (threadIdx.x == 0 && win_ld(p) < len) {
+        r = atomicAdd(p, 1);
+        if (r >= len) r = -1;
+    }
+    return __builtin_amdgcn_readfirstlane(r);
+}
+// the four control words every worker reads before it claims anything, as ONE 16-byte load past the L1: [0] tail phases
+// complete, [1] sub-diagonals wholly claimed, [2] abort, [3] tail phases whose items are all claimed
+typedef int32_t win_int4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ win_int4 win_ld_ctl(const int32_t *ctl)
+{
+    win_int4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ctl) : "memory");
+    return v;
+}
+// a wait has lasted too long (or somebody else gave up): the window is abandoned
+__device__ __forceinline__ bool win_watchdog(uint32_t &polls, uint64_t &t_start, WinCold c, int32_t what, int32_t x, int32_t y)
+{
+    if ((++polls & 255u) != 0u) return false;
+    int32_t *const ctl = c->w.ctl;
+    if (t_start == 0) {
+        t_start = wall_clock64();
+        return win_ld(ctl + 2) != 0;
+    }
+    if (wall_clock64() - t_start > c->w.watchdog_ticks || win_ld(ctl + 2) != 0) {
+        if (threadIdx.x == 0 && atomicCAS(ctl + 2, 0, 1) == 0) {
+            ctl[4] = what;
+            ctl[5] = x;
+            ctl[6] = y;
+        }
+        return true;
+    }
+    return false;
+}
+
+// Everything an item needs of the kernel's arguments is read from the kernel-argument segment when the item STARTS, through
+// a pointer the compiler cannot see through (a fresh one per item): scalar loads from the constant cache, a few hundred
+// cycles once per item -- instead of forty pointers held in scalar registers across the scheduler loop, which spilled
+// (135 scalar and 39 vector registers in the first build of this kernel).
+__device__ __forceinline__ WinCold win_args_now(WinCold c)
+{
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
+// the row's channel parameters and constants (plain loads: nothing writes them during a launch)
+__device__ __forceinline__ void win_load_channel(WinCold c, uint32_t ob, trmc::ChannelParams<float> &p, trmc::ChannelConst<float> &k)
+{
+    const float *const dt_col = c->a.dt_col;
+    p.dt = dt_col ? at(dt_col, ob) : c->a.dt;
+    asm volatile("" : "+v"(ob));
+    p.dx = at(c->a.dx, ob);
+    p.bw = at(c->a.bw, ob);
+    p.twcc = at(c->a.twcc, ob);
+    p.n = at(c->a.n, ob);
+    p.ncc = at(c->a.ncc, ob);
+    p.s0 = at(c->a.s0, ob);
+    p.tw = p.cs = 0.0f;
+    k.z = at(c->a.z, ob);
+    k.bfd = at(c->a.bfd, ob);
+    k.sqrt_s0 = at(c->a.sqrt_s0, ob);
+    k.sq1pz2 = at(c->a.sq1pz2, ob);
+    k.s0_n = at(c->a.s0_n, ob);
+    k.s0_ncc = at(c->a.s0_ncc, ob);
+    k.inv_n = at(c->a.inv_n, ob);
+    trmc::derive_const(k, p);
+}
+
+// junction sum of the flows of step t - 1 (`q_up` = that time row) in the reference's order (mc_reach.pyx:499-502); see
+// k_mc_step for the table of the first two upstream positions
+__device__ __forceinline__ float win_upstream_sum(WinCold c, const float *q_up, const int2 u, const uint32_t su)
+{
+    float qup = 0.0f;
+    if (u.x >= 0) qup += win_ldf(q_up, (uint32_t)u.x * 4u);
+    if (u.y >= 0) {
+        qup += win_ldf(q_up, (uint32_t)(u.y & 0x3fffffff) * 4u);
+        if (u.y & 0x40000000) {
+            const int32_t *const up_ptr = c->a.up_ptr, *const up_idx = c->a.up_idx;
+            const int32_t k1 = up_ptr[su + 1];
+            for (int32_t k = up_ptr[su] + 2; k < k1; ++k) qup += win_ldf(q_up, (uint32_t)up_idx[k] * 4u);
+        }
+    }
+    return qup;
+}
+
+// one timestep of one row: reservoir rows, the segment step, nudging (see k_mc_step); returns the iterations spent
+__device__ __forceinline__ int32_t win_step(WinCold c, DevMathF &m, const trmc::ChannelParams<float> &p, const trmc::ChannelConst<float> &k,
+                                            const int32_t ri, const int32_t gi, const int32_t t, const float qup, const float ql,
+                                            const float q_prev, const float d_prev, float &q_new, float &v_new, float &d_new)
+{
+    int32_t iters = 0;
+    if (ri >= 0) { // level-pool reservoir row
+        const float *rp = c->a.res_par + (size_t)ri * 9;
+        const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
+        float H = d_prev;
+        q_new = trmc::levelpool_step<float, DevMathF>(qup, 0.0f, c->a.res_dt, H, lp, m);
+        v_new = 0.0f;
+        d_new = H;
+        c->a.res_inflow[(size_t)ri * (size_t)c->a.nsteps + (size_t)(t - 1)] = qup;
+    } else {
+        trmc::Inflow<float> f;
+        f.qup = qup;
+        f.quc = qup;
+        f.qdp = q_prev;
+        f.ql = ql;
+        const trmc::StepResult<float> r = trmc::mc_segment_step<float, DevMathF>(p, k, f, d_prev, m);
+        q_new = r.qdc;
+        v_new = r.velc;
+        d_new = r.depthc;
+        iters = r.iters;
+        if (gi >= 0) { // streamflow nudging
+            const size_t e = (size_t)gi * (size_t)c->a.nsteps + (size_t)(t - 1);
+            const float *const da_a = c->a.da_a;
+            const uint8_t mode = c->a.da_mode[e];
+            float nudge = 0.0f;
+            if (mode == 1) {
+                nudge = da_a[e] - q_new;
+                q_new = da_a[e];
+            } else if (mode == 2) {
+                nudge = (da_a[e] - q_new) * c->a.da_w[e];
+                q_new = q_new + nudge;
+            }
+            c->a.da_nudge[e] = nudge;
+        }
+    }
+    return iters;
+}
+
+// have the wide items that hold this lane's upstream rows completed `need` sub-diagonals?  (rows below w0 are boundary
+// rows, rows from w1 on tail rows: neither has a progress word)
+__device__ __forceinline__ bool win_upstream_ready(WinCold c, const int2 u, const int32_t s, const int32_t need)
+{
+    const int32_t w0 = c->w.w0, w1 = c->w.w1;
+    const int32_t *const prog = c->w.prog;
+    bool ok = true;
+    if (u.x >= w0 && u.x < w1) ok = ok && win_ld(prog + ((u.x - w0) >> 6)) >= need;
+    if (u.y >= 0) {
+        const int32_t uy = u.y & 0x3fffffff;
+        if (uy >= w0 && uy < w1) ok = ok && win_ld(prog + ((uy - w0) >> 6)) >= need;
+        if (u.y & 0x40000000) {
+            const int32_t *const up_ptr = c->a.up_ptr, *const up_idx = c->a.up_idx;
+            const int32_t k1 = up_ptr[s + 1];
+            for (int32_t k = up_ptr[s] + 2; k < k1; ++k) {
+                const int32_t uk = up_idx[k];
+                if (uk >= w0 && uk < w1) ok = ok && win_ld(prog + ((uk - w0) >> 6)) >= need;
+            }
+        }
+    }
+    return ok;
+}
+
+// A wide item: 64 positions of the leading levels, K timesteps each (a lane of level l: the steps (tau K, tau K + K],
+// tau = d - l).  k_mc_tile's body with the state exchanged through write-through stores and L1-bypassing loads.
+// Returns false when the window has been abandoned.
+__device__ __forceinline__ bool win_item_wide(WinCold cold, DevMathF &m, float *s_out, const int32_t item, const int32_t d)
+{
+    const WinCold c = win_args_now(cold);
+    const int32_t lane = (int32_t)threadIdx.x;
+    const int32_t nsteps = c->a.nsteps, K = c->w.K, kshift = c->w.kshift;
+    const int32_t ntau = (nsteps + K - 1) >> kshift;
+    const int32_t s = c->w.w0 + item * 64 + lane;
+    const bool valid = s < c->w.w1;
+    const int32_t sv = valid ? s : c->w.w0; // (a position that exists, for the lanes beyond the last wide row)
+    const uint32_t su = (uint32_t)sv;
+    const int32_t tau = valid ? d - c->a.level[su] : -1;
+    const bool active = valid && tau >= 0 && tau < ntau;
+    const int2 u = c->a.up2[su];
+    {   // itself and the items holding its rows' upstream rows through sub-diagonal d - 1
+        uint32_t polls = 0;
+        uint64_t t0 = 0;
+        const int32_t *const mine = c->w.prog + item;
+        while (!__all(win_ld(mine) >= d && (!active || win_upstream_ready(c, u, sv, d)))) {
+            __builtin_amdgcn_s_sleep(8);
+            if (win_watchdog(polls, t0, cold, 2, item, d)) return false;
+        }
+    }
+    if (active) {
+        const uint32_t ob = su * 4u;
+        const size_t np = (size_t)c->a.nseg_pad;
+        const int32_t t_lo = (tau << kshift) + 1, t_hi = min((tau << kshift) + K, nsteps);
+        trmc::ChannelParams<float> p;
+        trmc::ChannelConst<float> k;
+        win_load_channel(c, ob, p, k);
+        const int32_t ri = c->a.res_of_pos ? c->a.res_of_pos[su] : -1;
+        const int32_t gi = c->a.gage_of_pos ? c->a.gage_of_pos[su] : -1;
+        float *q_up = c->a.q_tm + (size_t)(t_lo - 1) * np; // the time row of the step before (per lane: the level skew)
+        float q_prev = win_ldf(q_up, ob);
+        float d_prev = win_ldf(c->a.d_tm + (size_t)(t_lo - 1) * np, ob);
+        float *const out_row = c->a.out + (size_t)c->a.row_of_pos[su] * (size_t)nsteps * 3;
+        const bool out_vec = c->a.out_vec;
+        const int32_t qts = c->a.qts;
+        int32_t ql_col = (t_lo - 1) / qts, ql_left = qts - (t_lo - 1) % qts;
+        float ql = at(c->a.qlat_tm + (size_t)ql_col * np, ob);
+        m.coef_ok = coef_guard(p.dt, ql);
+        int32_t it_last = 0, staged = 0;
+        for (int32_t t = t_lo; t <= t_hi; ++t, q_up += np) {
+            if (ql_left == 0) {
+                ++ql_col;
+                ql = at(c->a.qlat_tm + (size_t)ql_col * np, ob);
+                m.coef_ok = coef_guard(p.dt, ql);
+                ql_left = c->a.qts;
+            }
+            --ql_left;
+            const float qup = win_upstream_sum(c, q_up, u, su);
+            float q_new, v_new, d_new;
+            it_last = win_step(c, m, p, k, ri, gi, t, qup, ql, q_prev, d_prev, q_new, v_new, d_new);
+            uint32_t obv = ob;
+            asm volatile("" : "+v"(obv));
+            win_stf(q_up + np, obv, q_new);
+            if (t == t_hi) win_stf(c->a.d_tm + (size_t)t * np, obv, d_new);
+            q_prev = q_new;
+            d_prev = d_new;
+            {   // stage (q, v, d) of step t; a run ends when kWinStage steps are staged and at the item's last step
+                float *so = s_out + (size_t)(staged * 3) * 64 + lane;
+                so[0] = q_new;
+                so[64] = v_new;
+                so[2 * 64] = d_new;
+                ++staged;
+                if (staged == kWinStage || t == t_hi) {
+                    float *dst = out_row + (size_t)(t - staged) * 3;
+                    const float *si = s_out + lane;
+                    if (out_vec && (staged & 3) == 0 && ((t - staged) & 3) == 0) { // (3 * staged / 4 aligned pieces of 16 bytes)
+                        for (int j = 0; j < 3 * staged / 4; ++j) {
+                            float4 v;
+                            v.x = si[(4 * j + 0) * 64];
+                            v.y = si[(4 * j + 1) * 64];
+                            v.z = si[(4 * j + 2) * 64];
+                            v.w = si[(4 * j + 3) * 64];
+                            reinterpret_cast<float4 *>(dst)[j] = v;
+                        }
+                    } else {
+                        for (int32_t e = 0; e < 3 * staged; ++e) dst[e] = si[e * 64];
+                    }
+                    staged = 0;
+                }
+            }
+        }
+        if (t_hi == nsteps) c->a.it_prev[su] = (uint8_t)min(it_last, 255);
+    }
+    // has every row of the item reached the window's end?  (then nobody must ever wait for it again)
+    const bool finished = __all(!valid || (tau >= 0 && ((tau + 1) << kshift) >= nsteps)) != 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of the item has left before its progress is published
+    if (lane == 0) win_st(c->w.prog + item, finished ? 0x7fffffff : d + 1);
+    return true;
+}
+
+// A tail item: 64 positions of the deeper levels through the ONE timestep `ph` (k_mc_step's work for them), (q, v, d)
+// straight into out[row][ph - 1][.].  Returns false when the window has been abandoned.
+__device__ __forceinline__ bool win_item_tail(WinCold cold, DevMathF &m, const int32_t item, const int32_t ph, const int32_t need)
+{
+    const WinCold c = win_args_now(cold);
+    const int32_t lane = (int32_t)threadIdx.x;
+    const int32_t s = c->w.w1 + item * 64 + lane;
+    const bool valid = s < c->w.s1;
+    const uint32_t su = (uint32_t)(valid ? s : c->w.w1);
+    const int2 u = c->a.up2[su];
+    if (need > 0) { // the wide rows above this item's rows at step ph - 1
+        uint32_t polls = 0;
+        uint64_t t0 = 0;
+        while (!__all(!valid || win_upstream_ready(c, u, (int32_t)su, need))) {
+            __builtin_amdgcn_s_sleep(8);
+            if (win_watchdog(polls, t0, cold, 1, item, ph)) return false;
+        }
+    }
+    if (valid) {
+        const uint32_t ob = su * 4u;
+        const size_t np = (size_t)c->a.nseg_pad;
+        const int32_t nsteps = c->a.nsteps;
+        trmc::ChannelParams<float> p;
+        trmc::ChannelConst<float> k;
+        win_load_channel(c, ob, p, k);
+        const int32_t ri = c->a.res_of_pos ? c->a.res_of_pos[su] : -1;
+        const int32_t gi = c->a.gage_of_pos ? c->a.gage_of_pos[su] : -1;
+        const float *const q_up = c->a.q_tm + (size_t)(ph - 1) * np; // (uniform: every lane is at step ph)
+        const float q_prev = win_ldf(q_up, ob);
+        const float d_prev = win_ldf(c->a.d_tm + (size_t)(ph - 1) * np, ob);
+        const float ql = at(c->a.qlat_tm + (size_t)c->w.col_of_step[ph] * np, ob);
+        m.coef_ok = coef_guard(p.dt, ql);
+        const float qup = win_upstream_sum(c, q_up, u, su);
+        float q_new, v_new, d_new;
+        const int32_t iters = win_step(c, m, p, k, ri, gi, ph, qup, ql, q_prev, d_prev, q_new, v_new, d_new);
+        uint32_t obv = ob;
+        asm volatile("" : "+v"(obv));
+        win_stf(c->a.q_tm + (size_t)ph * np, obv, q_new);
+        win_stf(c->a.d_tm + (size_t)ph * np, obv, d_new);
+        float *o = c->a.out + ((size_t)c->a.row_of_pos[su] * (size_t)nsteps + (size_t)(ph - 1)) * 3;
+        o[0] = q_new;
+        o[1] = v_new;
+        o[2] = d_new;
+        if (ph == nsteps) c->a.it_prev[su] = (uint8_t)min(iters, 255);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of the item has left before it is counted
+    if (lane == 0) {
+        const int32_t ntail = c->w.ntail;
+        const int32_t x = item & (kWinShards - 1);
+        const int32_t len = (ntail - x + kWinShards - 1) / kWinShards;
+        if (atomicAdd(c->w.tail_done + (size_t)(ph * kWinShards + x) * kWinPad, 1) + 1 == len) {
+            const int32_t nshards = ntail < kWinShards ? ntail : kWinShards;
+            if (atomicAdd(c->w.tail_shards + ph, 1) + 1 == nshards) win_st(c->w.ctl + 0, ph);
+        }
+    }
+    return true;
+}
+
+#ifndef TRMC_WIN_WAVES
+#define TRMC_WIN_WAVES 5
+#endif
+__global__ void __launch_bounds__(64, TRMC_WIN_WAVES)
+k_mc_window(const WindowArgs wa)
+{
+    const WinCold cold = cold_args<WindowArgs>();
+    __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
+    __shared__ float s_out[3 * kWinStage * 64]; // [step slot * 3 + c][lane]
+    DevMathF m{stage_pow_tables(s_tab), false};
+    m.sane = wa.a.sane;
+
+    const int32_t lane = (int32_t)threadIdx.x;
+    const int32_t xcd = (int32_t)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u); // HW_REG_XCC_ID
+    int32_t d_cur = 0, ph_skip = 0, tail_exh_ph = 0;
+    uint32_t tile_exh = 0, tail_exh = 0; // shards of the current sub-diagonal / phase this worker has found empty
+    uint32_t idle_polls = 0;
+    uint64_t idle_start = 0;
+#ifdef TRMC_WIN_DEBUG // developer build: what the workers did, summed into ctl[8..15] (read by trmc_route_end into stderr)
+    uint32_t dbg_wide = 0, dbg_tail = 0, dbg_idle = 0, dbg_exh = 0;
+    uint64_t dbg_t0 = wall_clock64(), dbg_t_wide = 0, dbg_t_tail = 0;
+#endif
+    for (;;) {
+        const WinCold c = win_args_now(cold);
+        const win_int4 ctl = win_ld_ctl(c->w.ctl);
+        const int32_t tail_through = __builtin_amdgcn_readfirstlane(ctl.x), d_claimed = __builtin_amdgcn_readfirstlane(ctl.y);
+        if (__builtin_amdgcn_readfirstlane(ctl.z) != 0) break;
+        const int32_t tail_claimed = __builtin_amdgcn_readfirstlane(ctl.w);
+        const int32_t nsteps = c->a.nsteps, ndiag = c->w.ndiag, ntail = c->w.ntail;
+        bool did = false;
+        // ---- the tail's next phase, if it is open: every tail row at ph - 1, and every wide item its rows may wait for not
+        // merely claimed but a whole sub-diagonal of claims old (so that the item's wait for them is, in practice, never one)
+        const int32_t ph = tail_through + 1;
+        if (ntail > 0 && ph <= nsteps && ph > tail_claimed && ph != ph_skip) {
+            const int32_t need = ph >= 2 ? ((ph - 2) >> c->w.kshift) + c->w.W : 0; // sub-diagonals the wide items must have completed
+            if (d_claimed >= min(need + (need > 0 ? 1 : 0), ndiag)) {
+                if (tail_exh_ph != ph) {
+                    tail_exh_ph = ph;
+                    tail_exh = 0;
+                }
+                int32_t item = -1;
+                for (int32_t j = 0; j < kWinShards && item < 0; ++j) {
+                    const int32_t x = (xcd + j) & (kWinShards - 1);
+                    const int32_t len = (ntail - x + kWinShards - 1) / kWinShards; // items x, x + 8, ...
+                    if (len <= 0 || (tail_exh & (1u << x))) continue;
+                    const int32_t got = win_claim(c->w.tail_claim + (size_t)(ph * kWinShards + x) * kWinPad, len);
+                    if (got >= 0)
+                        item = x + kWinShards * got;
+                    else
+                        tail_exh |= 1u << x;
+                }
+                if (item >= 0) {
+                    __builtin_amdgcn_s_setprio(3); // the phases are the window's dependent chain
+#ifdef TRMC_WIN_DEBUG
+                    const uint64_t t_in = wall_clock64();
+#endif
+                    const bool alive = win_item_tail(cold, m, item, ph, need);
+                    __builtin_amdgcn_s_setprio(0);
+                    if (!alive) break;
+#ifdef TRMC_WIN_DEBUG
+                    dbg_t_tail += wall_clock64() - t_in;
+                    ++dbg_tail;
+#endif
+                    did = true;
+                } else {
+                    ph_skip = ph; // every item of the phase is taken; its last ones are still running: tell the others
+                    if (lane == 0) atomicMax(c->w.ctl + 3, ph);
+#ifdef TRMC_WIN_DEBUG
+                    ++dbg_exh;
+#endif
+                }
+            }
+        }
+        // ---- else a wide item, in sub-diagonal order
+        if (!did && d_cur < ndiag) {
+            if (d_claimed > d_cur) {
+                d_cur = d_claimed;
+                tile_exh = 0;
+            }
+            if (d_cur < ndiag) {
+                const int32_t first = c->w.diag_first[d_cur], count = c->w.diag_count[d_cur];
+                int32_t item = -1;
+                for (int32_t j = 0; j < kWinShards && item < 0; ++j) {
+                    const int32_t x = (xcd + j) & (kWinShards - 1);
+                    const int32_t base = first + ((x - first) & (kWinShards - 1)); // first item of the range that is = x mod 8
+                    const int32_t len = base < first + count ? (first + count - base + kWinShards - 1) / kWinShards : 0;
+                    if (len <= 0 || (tile_exh & (1u << x))) continue;
+                    const int32_t got = win_claim(c->w.tile_claim + (size_t)(d_cur * kWinShards + x) * kWinPad, len);
+                    if (got >= 0)
+                        item = base + kWinShards * got;
+                    else
+                        tile_exh |= 1u << x;
+                }
+                if (item < 0) { // every item of this sub-diagonal is claimed: the next one opens
+                    if (lane == 0) atomicMax(c->w.ctl + 1, d_cur + 1);
+                    ++d_cur;
+                    tile_exh = 0;
+                } else {
+#ifdef TRMC_WIN_DEBUG
+                    const uint64_t t_in = wall_clock64();
+#endif
+                    if (!win_item_wide(cold, m, s_out, item, d_cur)) break;
+#ifdef TRMC_WIN_DEBUG
+                    dbg_t_wide += wall_clock64() - t_in;
+                    ++dbg_wide;
+#endif
+                }
+                did = true;
+            }
+        }
+        if (did) {
+            idle_polls = 0;
+            idle_start = 0;
+            continue;
+        }
+        // ---- nothing to claim: the window is over, or the tail's last items are still running (sleep long: every poll of
+        // the control words is a request to ONE cache line)
+        if (d_cur >= ndiag && (ntail == 0 || tail_through >= nsteps)) break;
+        __builtin_amdgcn_s_sleep(127);
+#ifdef TRMC_WIN_DEBUG
+        ++dbg_idle;
+#endif
+        if (win_watchdog(idle_polls, idle_start, cold, 3, ph, d_cur)) break;
+    }
+#ifdef TRMC_WIN_DEBUG
+    if (lane == 0) {
+        int32_t *const ctl = cold->w.ctl;
+        atomicAdd(ctl + 8, (int32_t)dbg_wide);
+        atomicAdd(ctl + 9, (int32_t)dbg_tail);
+        atomicAdd(ctl + 10, (int32_t)(dbg_idle >> 4));
+        atomicAdd(ctl + 11, (int32_t)dbg_exh);
+        atomicAdd(ctl + 12, (int32_t)(dbg_t_wide / 100)); // microseconds inside wide items, all workers
+        atomicAdd(ctl + 13, (int32_t)(dbg_t_tail / 100));
+        atomicAdd(ctl + 14, (int32_t)((wall_clock64() - dbg_t0) / 100)); // microseconds alive, all workers
+        atomicAdd(ctl + 15, 1);                                          // workers that ran
+    }
+#endif
+}
+
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
 // written as six more SoA columns behind the nine parameter columns (same device arithmetic the
 // step kernel would otherwise repeat every timestep: 4 divisions and 2 square roots per segment-step)
@@ -1849,6 +2370,9 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     int32_t wide = 0, wide_k = 0, wide_next = 0, wide_through = 0; // levels; K; tiles queued; last tile the tail waits for
     bool tail_active = false;     // the tail launches of this window go to the tail stream
     bool end_queued = false;      // route_end_queue has run for this window
+    // the whole window as ONE persistent launch (k_mc_window): chosen by route_begin_t, launched by the advance that covers it
+    bool win = false, win_ran = false;
+    int32_t win_W = 0, win_K = 0;
 };
 
 struct trmc_plan {
@@ -1925,6 +2449,10 @@ struct trmc_plan {
     // (TRMC_SETUP_ASIDE) waits for before it lets a new window's tiles overwrite them
     hipEvent_t ev_gather = nullptr;
     bool gather_pending = false;
+    // window kernel (k_mc_window): its schedule tables (per W, K, nsteps) and its counters
+    DevBuf win_tab, win_ctr;
+    int32_t win_key[4] = {-1, -1, -1, -1};
+    int32_t win_ndiag = 0, win_nwide = 0, win_ntail = 0, win_workers = 0;
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
     std::vector<int32_t> rowset_lag;
@@ -2071,6 +2599,7 @@ template <class T> int emit_tiles_through(trmc_plan *pl, int32_t t_complete) // 
     const int32_t ntiles = (nsteps + kTile - 1) / kTile;
     const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
     const T *q_tm = (const T *)pl->tm.p;
+    if (r.win_ran) r.tiles_done = ntiles; // (the window kernel wrote every row's result in the caller's layout itself)
     while (r.tiles_done < ntiles && ((r.tiles_done + 1) * kTile <= t_complete || t_complete >= nsteps)) {
         // (with wide tiles: the tail, on the plan's stream, trails them -- its progress is everybody's; without a tail the
         // tile stream's is)
@@ -2185,7 +2714,39 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         }
         pl->wide_safe_pos = first;
     }
-    if (short_ts && pl->nrouted > 0) {
+    // Short-timestep fp32 windows whose leading levels are wide enough go out as ONE persistent launch (k_mc_window, see
+    // there): needs every boundary hydrograph up front and no lagged rows, like the wide tiles below, and no cost collection
+    // (the 16-bit per-row sums are read-modify-written by successive items of a row on different compute units).
+    // TRMC_WINDOW=0 switches it off; TRMC_WIN_MIN_ROWS (rows a level must have to be routed K steps per item; default 64 per
+    // compute unit), TRMC_WIN_LEVELS (at most; default 24) and TRMC_WIN_K (steps per item, a power of two; default 8) are
+    // measurement / test knobs.
+    if (short_ts && pl->nrouted > 0 && sizeof(T) == 4 && !pl->collect_cost) {
+        auto env_int = [](const char *name, long dflt) {
+            const char *e = std::getenv(name);
+            return e && *e ? std::atol(e) : dflt;
+        };
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+        // OFF by default: measured on the CONUS day (MI355X) the persistent launch takes 50-60 ms against
+        // 16.5 ms for the launches it would replace -- every hand-off inside a launch is a write-through store and an
+        // L1-bypassing load, an item pays half a dozen dependent round trips to memory, and a phase of the tail only gets
+        // workers at the rate wide items finish.  Kept as a correct, tested alternative (TRMC_WINDOW=1) and as the record of
+        // what the kernel boundaries buy.
+        const long on = env_int("TRMC_WINDOW", 0), min_rows = env_int("TRMC_WIN_MIN_ROWS", 64L * ncu);
+        const long max_levels = std::min<long>(env_int("TRMC_WIN_LEVELS", 24), kWinMaxLevels);
+        long K = std::max(1L, std::min((long)nsteps, env_int("TRMC_WIN_K", 8)));
+        while (K & (K - 1)) K &= K - 1; // the power of two at or below
+        const bool all_in_place = pl->maxlag == 0 && r.boundary_through == nsteps;
+        int32_t W = 0;
+        if (on && min_rows > 0 && all_in_place)
+            while (W < tp.nlevels && W < max_levels && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows) ++W;
+        if (W > 0 && (uint64_t)pl->nseg * (uint64_t)nsteps * 3ull < (1ull << 62)) {
+            r.win = true;
+            r.win_W = W;
+            r.win_K = (int32_t)K;
+        }
+    }
+    if (short_ts && pl->nrouted > 0 && !r.win) {
         auto env_int = [](const char *name, long dflt) {
             const char *e = std::getenv(name);
             return e && *e ? std::atol(e) : dflt;
@@ -2260,6 +2821,98 @@ template <class T> int route_end_queue(trmc_plan *pl)
     return 0;
 }
 
+// the whole window as one persistent launch (k_mc_window): schedule tables (built once per W, K, nsteps), counters, launch
+int window_launch(trmc_plan *pl, const StepArgs<float> &a)
+{
+    const trmc::Topology &tp = pl->topo;
+    RouteRun &r = pl->run;
+    const int32_t nsteps = r.nsteps, W = r.win_W, K = r.win_K, L = tp.nlevels;
+    const int32_t w0 = tp.lvl_ptr[0], w1 = tp.lvl_ptr[W], s1 = tp.lvl_ptr[L];
+    const int32_t nwide = (w1 - w0 + 63) / 64, ntail = (s1 - w1 + 63) / 64;
+    const int32_t ntau = (nsteps + K - 1) / K, ndiag = ntau + W - 1;
+    hipStream_t st = pl->stream;
+    if (pl->win_key[0] != W || pl->win_key[1] != K || pl->win_key[2] != nsteps || pl->win_key[3] != r.qts) {
+        // levels grow along the plan order: an item's rows span the levels [lo, hi] of its first and last position; it is
+        // active in the sub-diagonals lo .. hi + ntau - 1
+        // tab: diag_first[ndiag] | diag_count[ndiag] | initial prog[nwide] | col_of_step[nsteps + 1]
+        std::vector<int32_t> tab((size_t)2 * ndiag + nwide + nsteps + 1, 0), lo((size_t)nwide), hi((size_t)nwide);
+        for (int32_t t = 1; t <= nsteps; ++t) tab[(size_t)2 * ndiag + nwide + t] = (t - 1) / r.qts;
+        for (int32_t k = 0; k < nwide; ++k) {
+            const int32_t p0 = w0 + 64 * k, p1 = std::min(w1, p0 + 64) - 1;
+            lo[(size_t)k] = tp.level_of_row[(size_t)tp.row_of_pos[(size_t)p0]];
+            hi[(size_t)k] = tp.level_of_row[(size_t)tp.row_of_pos[(size_t)p1]];
+            tab[(size_t)2 * ndiag + k] = lo[(size_t)k]; // prog starts at the first sub-diagonal the item is active in
+        }
+        int32_t first = 0, last = -1;
+        for (int32_t d = 0; d < ndiag; ++d) {
+            while (first < nwide && hi[(size_t)first] + ntau - 1 < d) ++first;
+            while (last + 1 < nwide && lo[(size_t)(last + 1)] <= d) ++last;
+            tab[(size_t)d] = first;
+            tab[(size_t)ndiag + d] = std::max(0, last - first + 1);
+        }
+        if (int rc = upload_i32(pl->win_tab, tab, 1)) return rc;
+        pl->win_key[0] = W;
+        pl->win_key[1] = K;
+        pl->win_key[2] = nsteps;
+        pl->win_key[3] = r.qts;
+        pl->win_ndiag = ndiag;
+        pl->win_nwide = nwide;
+        pl->win_ntail = ntail;
+    }
+    {
+        int nb = 0, ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+        // Workers: as many single-wavefront workgroups as the registers let a compute unit hold (the occupancy query: 20 at
+        // five wavefronts per SIMD).  Nothing depends on how many of them are resident -- claims only ever wait for claimed
+        // items -- so a grid above the true residency would be harmless (the surplus starts when the first workers leave,
+        // finds nothing and leaves too) and one below it only idles slots.
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mc_window, 64, 0) != hipSuccess) nb = -1;
+#ifdef TRMC_WIN_DEBUG
+        std::fprintf(stderr, "[window debug] occupancy query: %d blocks of 64 threads per compute unit\n", nb);
+#endif
+        if (nb < 1) nb = 4 * TRMC_WIN_WAVES;
+        if (const char *e = std::getenv("TRMC_WIN_WORKERS_PER_CU")) nb = std::max(1, std::atoi(e));
+        pl->win_workers = nb * ncu;
+    }
+    // counters: ctl[32] | tail_shards[nsteps + 1] | tile_claim[ndiag][8][pad] | tail_claim[nsteps + 1][8][pad] | tail_done[nsteps + 1][8][pad] | prog[nwide]
+    const size_t n_ctl = 32, n_sh = (size_t)nsteps + 1, n_tc = (size_t)ndiag * kWinShards * kWinPad,
+                 n_tl = ((size_t)nsteps + 1) * kWinShards * kWinPad;
+    const size_t words = n_ctl + n_sh + n_tc + 2 * n_tl + (size_t)nwide;
+    if (int rc = pl->win_ctr.ensure(words * sizeof(int32_t))) return rc;
+    int32_t *base = (int32_t *)pl->win_ctr.p;
+    HIP_TRY(hipMemsetAsync(base, 0, (words - (size_t)nwide) * sizeof(int32_t), st));
+    const int32_t *tab = (const int32_t *)pl->win_tab.p;
+    HIP_TRY(hipMemcpyAsync(base + (words - (size_t)nwide), tab + 2 * (size_t)ndiag, (size_t)nwide * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    WindowArgs wa;
+    wa.a = a;
+    wa.a.out_vec = nsteps % 4 == 0;
+    wa.w.w0 = w0;
+    wa.w.w1 = w1;
+    wa.w.s1 = s1;
+    wa.w.K = K;
+    wa.w.kshift = 0;
+    while ((1 << wa.w.kshift) < K) ++wa.w.kshift;
+    wa.w.W = W;
+    wa.w.ndiag = ndiag;
+    wa.w.nwide = nwide;
+    wa.w.ntail = ntail;
+    wa.w.diag_first = tab;
+    wa.w.diag_count = tab + ndiag;
+    wa.w.col_of_step = tab + 2 * (size_t)ndiag + nwide;
+    wa.w.ctl = base;
+    wa.w.tail_shards = base + n_ctl;
+    wa.w.tile_claim = wa.w.tail_shards + n_sh;
+    wa.w.tail_claim = wa.w.tile_claim + n_tc;
+    wa.w.tail_done = wa.w.tail_claim + n_tl;
+    wa.w.prog = wa.w.tail_done + n_tl;
+    wa.w.watchdog_ticks = pl->watchdog_ticks;
+    hipLaunchKernelGGL(k_mc_window, dim3((unsigned)pl->win_workers), dim3(64), 0, st, wa);
+    HIP_TRY(hipGetLastError());
+    r.win_ran = true;
+    r.launches = 1;
+    return 0;
+}
+
 template <class T> int route_advance_t(trmc_plan *pl, int t_end)
 {
     const trmc::Topology &tp = pl->topo;
@@ -2268,6 +2921,16 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     const int32_t nsteps = r.nsteps, t0 = r.t_done;
     StepArgs<T> a = step_args<T>(pl, nsteps, r.qts);
     hipStream_t st = pl->stream;
+    if (r.win) {
+        if constexpr (sizeof(T) == 4) {
+            if (pl->nrouted > 0 && t0 == 0 && t_end == nsteps) {
+                if (int rc = window_launch(pl, a)) return rc;
+                r.t_done = t_end;
+                return 0;
+            }
+        }
+        r.win = false; // (the window arrives in parts: one step per launch, below)
+    }
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
         if (r.short_ts && r.wide > 0) {
@@ -2381,6 +3044,23 @@ template <class T> int route_end_t(trmc_plan *pl)
     const int32_t nsteps = r.nsteps;
     if (int rc = route_end_queue<T>(pl)) return rc;
     HIP_TRY(hipStreamSynchronize(st));
+    if (r.win_ran) {
+        int32_t ctl[16] = {0};
+        HIP_TRY(hipMemcpy(ctl, pl->win_ctr.p, sizeof ctl, hipMemcpyDeviceToHost));
+#ifdef TRMC_WIN_DEBUG
+        std::fprintf(stderr, "[window debug] workers launched %d ran %d | wide items %d (%.1f us each) tail items %d (%.1f us each) | alive %.1f us per worker, "
+                             "idle polls/16 %d, phases found exhausted %d\n", pl->win_workers, ctl[15], ctl[8], ctl[8] ? (double)ctl[12] / ctl[8] : 0.0, ctl[9],
+                     ctl[9] ? (double)ctl[13] / ctl[9] : 0.0, ctl[15] ? (double)ctl[14] / ctl[15] : 0.0, ctl[10], ctl[11]);
+#endif
+        if (ctl[2] != 0) {
+            r.active = false;
+            static const char *what[] = {"?", "a tail item for the wide rows above it", "a wide item for the sub-diagonal before it", "an idle worker for the window's end"};
+            return fail(TRMC_EHIP, std::string("window kernel: ") + what[ctl[4] >= 0 && ctl[4] <= 3 ? ctl[4] : 0]
+                                       + " waited longer than the watchdog allows (item " + std::to_string(ctl[5]) + ", phase / sub-diagonal "
+                                       + std::to_string(ctl[6]) + "; tail phases complete " + std::to_string(ctl[0]) + ", sub-diagonals claimed "
+                                       + std::to_string(ctl[1]) + "); window abandoned");
+        }
+    }
 
     float ms01 = 0, ms12 = 0, ms23 = 0;
     HIP_TRY(hipEventElapsedTime(&ms01, pl->ev[0], pl->ev[1]));
@@ -2398,11 +3078,12 @@ template <class T> int route_end_t(trmc_plan *pl)
     s.ms_main = ms12;
     s.ms_emit = ms23;
     s.ms_total = (double)ms01 + ms12 + ms23;
-    s.wide_levels = r.wide;
-    s.wide_k = r.wide_k;
+    s.wide_levels = r.win_ran ? r.win_W : r.wide;
+    s.wide_k = r.win_ran ? r.win_K : r.wide_k;
     s.wide_launches = r.wide_next;
-    s.reserved_ = 0;
-    s.wide_segment_steps = r.wide > 0 ? (int64_t)(tp.lvl_ptr[r.wide] - tp.lvl_ptr[0]) * nsteps : 0;
+    s.window_kernel = r.win_ran ? 1 : 0;
+    s.wide_segment_steps = r.win_ran ? (int64_t)(tp.lvl_ptr[r.win_W] - tp.lvl_ptr[0]) * nsteps
+                                     : (r.wide > 0 ? (int64_t)(tp.lvl_ptr[r.wide] - tp.lvl_ptr[0]) * nsteps : 0);
     s.ms_wide = 0.0;
     {
         const size_t timed_n = std::min<size_t>((size_t)r.wide_next, pl->wide_t0.size());
@@ -3178,7 +3859,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->win_tab, &pl->win_ctr})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);

@@ -139,17 +139,21 @@ def test_lowercolorado_return_tuple_shape(lc):
     assert r[6].shape == (lc.nseg, lc.nts) and len(r[7]) == 3 and r[8].shape == (0, lc.nts + 1) and len(r[9]) == 4
 
 
-@pytest.mark.parametrize("engine", ["flow", "levels", "levels-wide"])
+@pytest.mark.parametrize("engine", ["flow", "levels", "levels-wide", "levels-window"])
 @pytest.mark.parametrize("short", [True, False])
 def test_lowercolorado_fp32_bit_identical_to_reference_golden(lc, short, engine, monkeypatch):
     """Golden = reference Fortran kernel symbol driven through the restated loop (make_fixtures.py):
     12 time slices x every segment and 100 probe segments x every step, both timestep modes, on BOTH engines
     (the dataflow engine k_mc_flow and the level engine k_mc_step), the level engine also with its wide levels several
-    steps per launch (k_mc_tile)."""
+    steps per launch (k_mc_tile) and with the whole window as one persistent launch (k_mc_window; short-timestep mode)."""
     monkeypatch.setenv("TRMC_ENGINE", engine.split("-")[0])
+    monkeypatch.setenv("TRMC_WINDOW", "1" if engine.endswith("-window") else "0")
     if engine.endswith("-wide"):
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
         monkeypatch.setenv("TRMC_WIDE_K", "5")
+    if engine.endswith("-window"):
+        monkeypatch.setenv("TRMC_WIN_MIN_ROWS", "32")
+        monkeypatch.setenv("TRMC_WIN_K", "4")
     _, fvd = route_lc(lc, short)
     g = lc.golden()
     tag = "shortts" if short else "fullts"
@@ -254,16 +258,23 @@ def run_both(ups, params, qlat, q0, nsteps, qts, short):
 # TRMC_ENGINE: the dataflow engine (k_mc_flow*), the level engine one step per launch (k_mc_step), and the level engine
 # with its wide levels routed several steps per launch under a level skew (k_mc_tile; at its default thresholds only
 # networks of CONUS width take that path -- here every level of 32 rows or more does, five steps per launch)
-ENGINES = ["flow", "levels", "levels-wide"]
+ENGINES = ["flow", "levels", "levels-wide", "levels-window"]
 
 
 def set_engine(monkeypatch, engine):
+    """levels: one launch per timestep (k_mc_step); levels-wide: the leading levels several steps per launch beside it
+    (k_mc_tile); levels-window: the whole short-timestep window as ONE persistent launch (k_mc_window; other windows as
+    `levels`) -- every level of at least 32 rows as wide items here, so that small networks exercise both item kinds."""
     monkeypatch.setenv("TRMC_ENGINE", engine.split("-")[0])
+    monkeypatch.setenv("TRMC_WINDOW", "1" if engine.endswith("-window") else "0")
     if engine.endswith("-wide"):
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
         monkeypatch.setenv("TRMC_WIDE_K", "8")        # (a multiple of 4: the 16-byte result stores where nsteps allows them)
     else:
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
+    if engine.endswith("-window"):
+        monkeypatch.setenv("TRMC_WIN_MIN_ROWS", "32")
+        monkeypatch.setenv("TRMC_WIN_K", "8")
 
 
 @pytest.mark.parametrize("engine", ENGINES)
@@ -420,8 +431,8 @@ def conus_sample_rows(to, rng, n_mid=80, n_small=200, lo=50, hi=20000):
 
 
 @pytest.mark.parametrize("short,plan_mode,engine", [(True, None, "flow"), (False, None, "flow"), (True, True, "levels"),
-                                                    (False, False, "flow")])
-def test_conus_full_size_samples_bit_identical_to_oracle(conus, short, plan_mode, engine):
+                                                    (True, True, "levels-window"), (False, False, "flow")])
+def test_conus_full_size_samples_bit_identical_to_oracle(conus, short, plan_mode, engine, monkeypatch):
     """Size-independent property at full size: independent networks do not interact, so any
     sub-collection of them routed ALONE by the oracle must equal -- bit for bit -- what the GPU
     produced for them inside the 2.7 M-segment run (outlet and interior hydrographs, final state).
@@ -435,13 +446,18 @@ def test_conus_full_size_samples_bit_identical_to_oracle(conus, short, plan_mode
     q0 = np.zeros((nseg, 3), np.float32)
     rows = conus_sample_rows(to, np.random.default_rng(77))
     assert 10000 < rows.size < 400000
+    # "levels": the default of a short-timestep plan at this size (k_mc_tile + k_mc_step + k_emit); "levels-window": the
+    # same plan with the whole window as one persistent launch (k_mc_window, opt-in)
+    monkeypatch.setenv("TRMC_WINDOW", "1" if engine == "levels-window" else "0")
     with RoutingPlan(up_ptr, up_idx, net["params"], assume_short_ts=plan_mode) as plan:
-        assert plan.engine == engine
+        assert plan.engine == engine.split("-")[0]
         plan.upload_forcing(nsteps, net["qlat"], q0)
         st = plan.route_device(nsteps, qts, short)
         hyd = plan.gather_flow_rows(rows)
         final = plan.download_final_state()
     assert st["segment_steps"] == nseg * nsteps
+    if engine.startswith("levels"):
+        assert st["window_kernel"] == (1 if engine == "levels-window" else 0) and st["wide_levels"] > 0
     g2l = np.full(nseg, -1, np.int64)
     g2l[rows] = np.arange(rows.size)
     lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)

@@ -51,6 +51,54 @@ def test_window_in_parts_equals_one_call(short):
         buf.free()
 
 
+@pytest.mark.parametrize("nseg,nsteps,qts,K,min_rows,max_levels", [
+    (6000, 48, 12, 8, 32, 24), (6000, 50, 7, 4, 32, 24), (6000, 37, 5, 16, 32, 3), (6000, 9, 4, 2, 16, 64),
+    (6000, 24, 24, 1, 32, 2), (900, 33, 12, 8, 8, 24), (20000, 64, 16, 32, 64, 1), (150, 16, 4, 4, 1, 24)])
+def test_the_window_as_one_persistent_launch_equals_the_launches_it_replaces(monkeypatch, nseg, nsteps, qts, K, min_rows, max_levels):
+    """k_mc_window: a short-timestep fp32 window of the level engine as ONE persistent launch -- the leading levels K
+    timesteps per work item under the level skew, the deeper levels one timestep per item in phases, claims through sharded
+    counters, state exchanged through write-through stores -- against the per-step launches of the same plan (which the
+    other tests pin to the oracle and the reference goldens): window lengths that are no multiple of K, forcing columns
+    that change inside an item, K from 1 to 32, one to every level as wide items (no tail at all in the last case), a
+    window in parts (which falls back to the launches), several windows on one plan, a warm start from the resident state."""
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(seed=nseg + K, nseg=nseg)
+    qlat = np.ascontiguousarray(np.tile(qlat, (1, (nsteps + qts - 1) // qts // qlat.shape[1] + 1)))
+    monkeypatch.setenv("TRMC_ENGINE", "levels")
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
+    monkeypatch.setenv("TRMC_WINDOW", "0")
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as ref:
+        want = ref.route(nsteps, qts, True, qlat, q0)
+        assert ref.stats()["window_kernel"] == 0
+        ref.upload_forcing(nsteps, qlat, None)
+        ref.route_device(nsteps, qts, True)
+        want2, state2 = ref.download_fvd(), ref.download_final_state()
+    monkeypatch.setenv("TRMC_WINDOW", "1")
+    monkeypatch.setenv("TRMC_WIN_MIN_ROWS", str(min_rows))
+    monkeypatch.setenv("TRMC_WIN_LEVELS", str(max_levels))
+    monkeypatch.setenv("TRMC_WIN_K", str(K))
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as plan:
+        for _ in range(2):                                      # (twice: the counters are re-initialised per window)
+            got = plan.route(nsteps, qts, True, qlat, q0)
+            st = plan.stats()
+            assert st["window_kernel"] == 1 and st["wide_k"] == K and 1 <= st["wide_levels"] <= max_levels and st["main_launches"] == 1
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        iters = plan.download_iterations()
+        plan.upload_forcing(nsteps, qlat, None)                 # the next window from the resident state
+        plan.route_device(nsteps, qts, True)
+        assert np.array_equal(plan.download_fvd().view(np.uint32), want2.view(np.uint32))
+        assert np.array_equal(plan.download_final_state().view(np.uint32), state2.view(np.uint32))
+        plan.upload_forcing(nsteps, qlat, q0)                   # a window that arrives in parts: one step per launch
+        plan.route_begin(nsteps, qts, True)
+        plan.route_advance(nsteps // 2)
+        plan.route_advance(nsteps)
+        assert plan.route_end()["window_kernel"] == 0
+        assert np.array_equal(plan.download_fvd().view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(plan.download_iterations(), iters)
+        plan.collect_cost(True)                                 # cost collection: the launches as well
+        assert np.array_equal(plan.route(nsteps, qts, True, qlat, q0).view(np.uint32), want.view(np.uint32))
+        assert plan.stats()["window_kernel"] == 0
+
+
 def test_call_order_errors():
     to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=200)
     with RoutingPlan(up_ptr, up_idx, p) as plan:

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../t-route_amd/csrc"
 sfx=$1; shift
-F="-O3 -std=c++17 -fPIC -ffp-contract=off"
+F="-O3 -std=c++17 -fPIC -ffp-contract=off $TRMC_VARIANT_DEFS"
 T=$(mktemp -d)
 ml=""; for o in "$@"; do ml="$ml -mllvm $o"; done
 # (the device-only output is already the offload bundle the host compilation embeds)
@@ -14,6 +14,7 @@ ml=""; for o in "$@"; do ml="$ml -mllvm $o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $F --offload-host-only -Xclang -fcuda-include-gpubinary -Xclang $T/trmc.hipfb -c trmc.hip -o $T/trmc.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $F -c diffusive.hip -o $T/diffusive.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $F -c topology.cpp -o $T/topology.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libtrmc$sfx.so $T/trmc.o $T/diffusive.o $T/topology.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $F -c comm.hip -o $T/comm.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libtrmc$sfx.so $T/trmc.o $T/diffusive.o $T/comm.o $T/topology.o -ldl -lrt
 rm -rf $T
 ls -la ../libtrmc$sfx.so
