@@ -61,7 +61,7 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nseg", type=int, default=None, help="override network size (default CONUS)")
     ap.add_argument("--nnet", type=int, default=None)
@@ -80,6 +80,9 @@ def parse():
                     help="skip the post-timing check of every segment against the reference on the CPU")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic / roofline.valu = null)")
     ap.add_argument("--headline-only", action="store_true", help="stop after the headline's timed windows (what the counter passes run)")
+    ap.add_argument("--persistence", type=float, default=None,
+                    help="share of the rows that keep their forcing magnitude from day to day in the timed sequence "
+                         "(default: synthetic.forcing's 0.8; 0 = every day an independent draw)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: one per CPU the cgroup grants, at most the physical cores)")
     return ap.parse_args()
@@ -158,7 +161,7 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     }
 
 
-def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0):
+def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0, plan=None, final_fetched=None):
     """Checker, run AFTER the timed region: EVERY segment of the workload -- the dominant basin included -- is routed on the
     CPU by the reference Fortran kernel (canonical Qj_0; oracle/_ref built from the reference's sources, else the pinned
     restatement) through the same sequence of windows the router has been through -- `days`: the forcing of day N-1 (cold
@@ -186,8 +189,11 @@ def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0):
         base.update({"bit_identical": same_o, "compared": "the all-gathered outlet hydrographs of every network",
                      "differing_values": int((u32(o_hyd) != u32(want_o)).sum()), "seconds": round(time.perf_counter() - t0, 1)})
         return base
-    fvd = router.plan0.download_fvd().reshape(nseg, nsteps, 3)
-    final = router.plan0.download_final_state()
+    plan = plan if plan is not None else router.plan0          # (the plan that routed the last window)
+    fvd = plan.download_fvd().reshape(nseg, nsteps, 3)
+    final = plan.download_final_state()
+    if final_fetched is not None and not np.array_equal(u32(final_fetched), u32(final)):
+        return dict(base, bit_identical=False, error="the asynchronously fetched final state differs from the plan's")
     diff_q = 0
     for lo in range(0, nseg, 200000):
         diff_q += int((u32(fvd[lo:lo + 200000, :, 0]) != u32(ref["q"][lo:lo + 200000, 1:])).sum())
@@ -486,6 +492,7 @@ def main():
         tuned["speed"], tuned["part"] = sharding.rank_speeds(lt[:, 0], lt[:, 1]), router.part
     router.collect_cost(False)
     t_tune = time.perf_counter() - t0
+    state_n = None if use_dist else router.plan0.download_final_state()   # the state after day N (where the timed sequence starts)
     router.upload(a.nsteps, qlat_b, None)              # day N+1, warm
     unt = timed(router, True, usteps, 1)
     untuned = {"value": rate(unt), "unit": "segment-timesteps/s", "ms_per_step": unt["el"] / usteps * 1e3,
@@ -513,12 +520,46 @@ def main():
             router = make_router(hint, True, qlat_s, q0)
             spin_up(router, True)
         tuned["feedback_ms"] = feedback
+        if not use_dist:
+            state_n = router.plan0.download_final_state()
         router.upload(a.nsteps, qlat_b, None)
         t_tune += time.perf_counter() - t0
 
     # ---- 3. the headline: day N+1 on the plan tuned on day N; every window's outlet hydrographs and final state arrive on
     # the host inside the clock (SURVEY 8d's throughput mode), copied beside the next window ---------------------------
-    head = timed(router, True, a.steps, a.warmup, d2h="state")
+    seq = None
+    if use_dist:
+        head = timed(router, True, a.steps, a.warmup, d2h="state")
+    else:
+        # One GPU: the pass that is timed is a SEQUENCE of consecutive days with distinct forcing (sequence_of_days): day N+1,
+        # N+2, ... -- a ring of `ndays` distinct days in page-locked host memory, each derived from the one before like days
+        # N-1 -> N -> N+1 were (synthetic.forcing) -- on the tuned plan and its clone.
+        from troute_amd import _lib as _tl
+        ndays = max(2, min(int(os.environ.get("TRMC_BENCH_DAYS", "10")), a.steps + a.warmup))
+        t0 = time.perf_counter()
+        ring, prev_day = [], qlat_a
+        for i in range(ndays):
+            day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day,
+                                    persistence=a.persistence)
+            pinned = _tl.result_empty(day.shape, np.float32, always_pinned=True)
+            pinned[...] = day
+            ring.append(pinned)
+            prev_day = day
+        assert np.array_equal(ring[0], qlat_b) or a.persistence is not None
+        t_days = time.perf_counter() - t0
+        plan_b = router.plan0.clone()
+        outlets_rs = [router.plan0.rowset(router.my_out0_local), plan_b.rowset(router.my_out0_local)]
+        os.environ["TRMC_SETUP_ASIDE"] = "1"
+        try:
+            # (untimed: the clone's window buffers -- 19 GB of planes and result -- and both plans' copy streams and page-locked
+            # result rings are made at their first use)
+            sequence_of_days(router.plan0, plan_b, ring[:2], state_n, outlets_rs, a, 2, 0)
+            seq = sequence_of_days(router.plan0, plan_b, ring, state_n, outlets_rs, a, a.steps, a.warmup)
+        finally:
+            os.environ.pop("TRMC_SETUP_ASIDE", None)
+        head = {"el": seq["el"], "ms_main": float(np.mean(seq["ms_main"])), "ms_total": float(np.mean(seq["ms_main"])),
+                "launches": router.plan0.stats()["main_launches"], "stats": {"phase0": seq["last_plan"].stats()},
+                "hyd": seq["hyd"], "steps": a.steps}
     hyd = head["hyd"]
     if hyd is None:                                 # (a rank other than 0 of a multi-GPU job does not fetch the outlet block)
         hyd = np.zeros((0, a.nsteps), np.float32)
@@ -534,14 +575,32 @@ def main():
         if comm is not None:
             comm.close()
         return
-    resident = timed(router, True, max(1, min(a.steps, 3)), 1)
     parity = None
     if rank == 0 and not a.no_parity_full and a.precision == 32:
-        try:      # what the timed plan holds after the last timed window, against the reference (checker use, outside the clock)
-            parity = parity_full(net, None if use_dist else router, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
-                                 outlets=(router._out_rows if use_dist else router.my_out0_global, hyd), threads=a.cpu_threads)
+        try:      # against the reference on the CPU (checker use, outside the clock)
+            if use_dist:   # the job's product: the all-gathered outlet block of the last timed window
+                parity = parity_full(net, None, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
+                                     outlets=(router._out_rows, hyd), threads=a.cpu_threads)
+            else:
+                # the timed pipeline once more, untimed, over the first two days of the ring (days N+1 and N+2 from the state
+                # after day N: plan and clone, staged forcing, state handed over on the device, asynchronous fetch), and the
+                # reference on the CPU through ALL the days from the cold start: N-1, N, N+1, N+2
+                os.environ["TRMC_SETUP_ASIDE"] = "1"
+                try:
+                    chk = sequence_of_days(router.plan0, plan_b, ring[:2], state_n, outlets_rs, a, 2, 0)
+                finally:
+                    os.environ.pop("TRMC_SETUP_ASIDE", None)
+                parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
+                                     outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
+                                     final_fetched=chk["final"])
+                parity["pipeline"] = ("the timed pass's pipeline (plan + clone, forcing staged from page-locked memory, state handed "
+                                      "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
         except Exception as e:
             parity = {"error": repr(e)}
+    if not use_dist:
+        plan_b.close()
+        router.upload(a.nsteps, qlat_b, state_n)     # (the legs below route day N+1 again and again on the one plan)
+    resident = timed(router, True, max(1, min(a.steps, 3)), 1)
     two = None
     if not use_dist and not a.no_two_members:   # (after the parity sample: this leg routes other days on the timed plan)
         try:
@@ -728,6 +787,77 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
+
+
+def sequence_of_days(plan_a, plan_b, days, state0, outlets_rs, a, steps, warmup):
+    """The headline's pass: ONE sequence of consecutive routing windows ("days") with DISTINCT forcing on one network, what
+    an operational cycle does -- every day's forcing arrives from host memory inside the clock, the state is handed from day
+    to day in HBM, and every day's products (outlet hydrographs + final state, SURVEY 8d's throughput mode) reach page-locked
+    host arrays inside the clock.  The days take turns on a plan and its clone (trmc_plan_clone: ONE copy of the topology
+    and parameter columns in HBM, two sets of window buffers): while day w is routed, day w + 1's forcing travels to the idle
+    set on its copy stream (trmc_stage_forcing, from page-locked memory -- where a caller would have read the forcing file
+    to), its state is handed over on the device (trmc_plan_chain_from) and its window is queued, so that its leading levels
+    start while day w's narrow levels are finishing; day w - 1's products are copied to the host beside.
+    `days`: a ring of distinct page-locked forcing arrays, used in turn (the state evolves on: no two windows are the same
+    work).  Times EXACTLY `steps` windows after `warmup` untimed ones; returns wall seconds, per-window device times, the
+    last day's products, and how many days were routed before (for the checker)."""
+    import time as _t
+    from troute_amd import comm as X
+    plans = [plan_a, plan_b]
+    nsteps, qts = a.nsteps, a.qts
+    nd = len(days)
+
+    def queue(p):
+        p.route_begin(nsteps, qts, True)
+        p.route_advance(nsteps)
+    total = warmup + steps
+    plan_a.upload_forcing(nsteps, days[0], state0)          # the first day of the sequence the ordinary way (synchronous)
+    if total > 1:
+        plan_b.stage_forcing(nsteps, days[1 % nd])
+    ms_main, got = [], None
+    dbg = [] if os.environ.get("TRMC_BENCH_DEBUG") else None
+    tz = _t.perf_counter()
+
+    def mark(what):
+        if dbg is not None:
+            dbg.append(f"{what}@{(_t.perf_counter() - tz) * 1e3:.2f}")
+    t0 = _t.perf_counter() if warmup == 0 else None          # (no warm-up day: the clock starts with day 0's window)
+    # Everything a day needs is queued in one go, in the order the hardware queues should see it: the window; BEHIND its
+    # last launch the gathers of its products and their copy to the host; behind its set-up the forcing of this plan's
+    # NEXT day (two days ahead: the staging area is only read by a window's set-up).
+    nofetch = bool(os.environ.get("TRMC_BENCH_NO_FETCH"))    # (experiment: what does the copy of the products cost?)
+    queue(plan_a)
+    if not nofetch:
+        plan_a.fetch_begin(outlets_rs[0], True)
+    if total > 2:
+        plan_a.stage_forcing(nsteps, days[2 % nd])
+    for w in range(1, total + 1):
+        cur, prev = plans[w % 2], plans[(w - 1) % 2]
+        if w < total:
+            mark(f"[day{w}")
+            cur.chain_from(prev)                             # day w starts where day w - 1 ends: handed over in HBM
+            mark("chained")
+            queue(cur)
+            mark("window")
+            if not nofetch:
+                cur.fetch_begin(outlets_rs[w % 2], True)
+            mark("fetchq")
+            if w + 2 < total:
+                cur.stage_forcing(nsteps, days[(w + 2) % nd])
+            mark(f"queued{w}]")
+        st = prev.route_end()                                # day w - 1 is through
+        mark(f"ended{w - 1}({st['ms_main']:.1f})")
+        if w - 1 >= warmup:
+            ms_main.append(st["ms_main"])
+        got = prev.fetch_wait() if not nofetch else (np.zeros((1, 1), np.float32), None)   # ... and its products are on the host
+        mark(f"fetched{w - 1}")
+        if w == warmup and warmup > 0:                       # the clock starts when the last warm-up day is through
+            t0 = _t.perf_counter()
+    X.device_synchronize(0)
+    el = _t.perf_counter() - t0
+    if dbg is not None:
+        print("[sequence] host timeline ms: " + " ".join(dbg), file=sys.stderr)
+    return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total, "last_plan": plans[(total - 1) % 2]}
 
 
 def two_members(router_a, make_b, spin_up, qlat, a, rate_of):

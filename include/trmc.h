@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 13
+#define TRMC_ABI_VERSION 14
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -395,6 +395,29 @@ void trmc_muskingcungenwm(float *dt, float *qup, float *quc, float *qdp, float *
  * takes the handed-over state instead of the one staged with its forcing.  Level engine only.
  */
 int trmc_plan_chain_from(trmc_plan *receiver, trmc_plan *source);
+
+/*
+ * A second set of WINDOW buffers on the static data of `plan`: the clone shares the original's topology, parameter and
+ * constant columns in HBM (no second copy of them, no second flattening) and owns its own forcing, state planes, result
+ * and streams -- so that consecutive windows of one sequence can take turns on the two (trmc_plan_chain_from), the next
+ * day's forcing travelling to the idle one (trmc_stage_forcing) and its leading levels starting while the current day's
+ * narrow levels finish.  Reservoir / nudging tables are per clone (set them on each).  Destroy order is free: the shared
+ * memory goes with the last user.
+ */
+int trmc_plan_clone(trmc_plan *plan, trmc_plan **out);
+
+/*
+ * Stage the NEXT window's forcing without waiting for anything: qlat [nseg][nq] (row order, the plan's precision; page-
+ * locked host memory -- trmc_host_alloc -- for the copy to run asynchronously) is copied on the plan's copy stream, beside
+ * whatever the device is routing; the next trmc_route_begin orders its set-up behind the copy.  The initial state is what
+ * trmc_plan_chain_from hands over, else the state the plan's last window left (q0 = NULL of trmc_upload_forcing).  The
+ * caller's counterpart in the reference: qlat_values arrives with every compute_network_structured call
+ * (mc_reach.pyx:173,:723), the state through AbstractNetwork.new_q0 (AbstractNetwork.py:177-191).  Plans without
+ * boundary rows.  The plan is idle (its last window ended), or routing a window that has been queued to its end -- the
+ * staging area is only read by a window's set-up, so the copy goes behind that; a state must then come from
+ * trmc_plan_chain_from.
+ */
+int trmc_stage_forcing(trmc_plan *plan, int nsteps, const void *qlat, int64_t nq);
 
 /*
  * Self-check, on the device, of the short exact forms the fp32 step takes under its range proofs (csrc/trmc.hip,

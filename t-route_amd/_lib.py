@@ -83,6 +83,8 @@ SIGNATURES = {
     "trmc_segments": (_int, [_int, _int, _i64, _vp, _vp]),
     "trmc_muskingcungenwm": (None, [_P(C.c_float)] * 21),
     "trmc_plan_chain_from": (_int, [_vp, _vp]),
+    "trmc_plan_clone": (_int, [_vp, _P(_vp)]),
+    "trmc_stage_forcing": (_int, [_vp, _int, _vp, _i64]),
     "trmc_selfcheck_fast_arith": (_int, [_int, _int, _i64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     # communicator + device plumbing of the multi-GPU path (csrc/comm.hip)
     "trmc_comm_unique_id": (_int, [_vp]),

@@ -2330,9 +2330,18 @@ k_flow_boundary(const float *__restrict__ src, unsigned long long *gran, float *
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool borrowed = false; // the memory belongs to another plan (trmc_plan_clone): never freed, never regrown here
+    void borrow(const DevBuf &o)
+    {
+        release();
+        p = o.p;
+        bytes = o.bytes;
+        borrowed = true;
+    }
     int ensure(size_t need, bool zero_new = false)
     {
         if (need <= bytes) return 0;
+        if (borrowed) return fail(TRMC_ESTATE, "a buffer shared with the plan this one was cloned from would have to grow");
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -2351,9 +2360,10 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        borrowed = false;
     }
 };
 
@@ -2406,6 +2416,9 @@ struct trmc_plan {
     // trmc_plan_chain_from: the next window's initial state has been set on the device from another plan's window
     bool chain_staged = false;
     hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}; // source's tiles / tail done; this plan's two copies done
+    // as the SOURCE of a hand-over: "the receiver has read my planes" (its two copies), waited for at my next trmc_route_begin
+    hipEvent_t ev_released[2] = {nullptr, nullptr};
+    bool released_pending[2] = {false, false};
     std::vector<int32_t> lag_of_row;
     DevBuf gage_of_pos, da_mode, da_a, da_w, da_nudge; // nudging tables of the staged window
     DevBuf res_of_pos, res_par, res_inflow;             // level-pool reservoirs of the plan
@@ -2449,6 +2462,14 @@ struct trmc_plan {
     // (TRMC_SETUP_ASIDE) waits for before it lets a new window's tiles overwrite them
     hipEvent_t ev_gather = nullptr;
     bool gather_pending = false;
+    // trmc_plan_clone: a second set of WINDOW buffers on the static data (topology, parameters) of `parent`
+    trmc_plan *parent = nullptr;
+    int32_t clones = 0;                  // live clones of this plan
+    bool zombie = false;                 // destroyed while clones were alive: freed with the last of them
+    // trmc_stage_forcing: the next window's forcing is on its way to in_qlat on the copy stream
+    hipEvent_t ev_forcing = nullptr;
+    bool forcing_pending = false;
+    bool state_missing = false;          // ... and there is no initial state yet: trmc_plan_chain_from must supply it
     // window kernel (k_mc_window): its schedule tables (per W, K, nsteps) and its counters
     DevBuf win_tab, win_ctr;
     int32_t win_key[4] = {-1, -1, -1, -1};
@@ -2509,9 +2530,9 @@ int use_device(const trmc_plan *pl)
 }
 
 // a kernel that reads the result planes of the last window has just been queued on the plan's stream (outside a window)
-int note_gather(trmc_plan *pl)
+int note_gather(trmc_plan *pl, bool also_in_window = false)
 {
-    if (pl->run.active) return 0;
+    if (pl->run.active && !also_in_window) return 0;
     if (!pl->ev_gather) HIP_TRY(hipEventCreateWithFlags(&pl->ev_gather, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(pl->ev_gather, pl->stream));
     pl->gather_pending = true;
@@ -2647,6 +2668,12 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         pl->tile_ev.push_back(e);
     }
 
+    for (int i = 0; i < 2; ++i) // a receiver of this plan's last window (trmc_plan_chain_from) has read what this window overwrites
+        if (pl->released_pending[i]) {
+            HIP_TRY(hipStreamWaitEvent(st, pl->ev_released[i], 0));
+            if (pl->wstream) HIP_TRY(hipStreamWaitEvent(pl->wstream, pl->ev_released[i], 0));
+            pl->released_pending[i] = false;
+        }
     HIP_TRY(hipEventRecord(pl->ev[0], st));
     // TRMC_SETUP_ASIDE=1: the window's set-up (forcing transpose, initial state, boundary rows) goes to the TILE stream
     // instead of the plan's own.  For one plan it is all the same; for two plans that take turns on a device (two ensemble
@@ -2666,6 +2693,10 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         if (pl->gather_pending) HIP_TRY(hipStreamWaitEvent(st, pl->ev_gather, 0));
     }
     pl->gather_pending = false;
+    if (pl->forcing_pending) { // (trmc_stage_forcing: the copy into in_qlat runs on the copy stream)
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_forcing, 0));
+        pl->forcing_pending = false;
+    }
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st)); // no history at the start of a window
     if (pl->collect_cost) HIP_TRY(hipMemsetAsync(pl->it_sum.p, 0, (size_t)np * sizeof(uint16_t), st));
     // every element the result reads is written below: time row 0 by k_init_state, rows 1..nsteps
@@ -3289,6 +3320,10 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     pl->tag_span = nsteps + 1;
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
     HIP_TRY(hipEventRecord(pl->ev[0], st));
+    if (pl->forcing_pending) { // (trmc_stage_forcing: the copy into in_qlat runs on the copy stream)
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_forcing, 0));
+        pl->forcing_pending = false;
+    }
     HIP_TRY(hipMemsetAsync(pl->it_prev.p, 0, (size_t)np, st));
     HIP_TRY(hipMemsetAsync(pl->ticket.p, 0, 16 * sizeof(int32_t), st));
     pl->flow_next = pl->flow_last = 0;
@@ -3566,8 +3601,16 @@ template <class T> int chain_from_t(trmc_plan *dst, trmc_plan *src, int nsteps_d
         HIP_TRY(hipStreamWaitEvent(dst->wstream, dst->ev_chain[0], 0));
         hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(w1 - w0)), dim3(kBlock), 0, dst->wstream, sq, sq, sd, dq, dv, dd, w0, w1);
         HIP_TRY(hipEventRecord(dst->ev_chain[2], dst->wstream));
-        HIP_TRY(hipStreamWaitEvent(src->wstream, dst->ev_chain[2], 0)); // the source's next window does not overwrite what is being read
-        HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_chain[2], 0));
+        // The source's NEXT window must not overwrite what is being read here.  Not as waits queued on the source's streams
+        // now: with one hardware queue per stream priority the two plans' tile streams share an in-order queue, and a wait
+        // placed there at this point -- behind the source's tiles, ahead of everything this plan is about to queue -- holds
+        // THIS plan's set-up and tiles back until the event fires: the second one below only does when the source's tail
+        // has ended, so the receiver's leading levels started after the source's whole window instead of behind its last
+        // tile (the timeline of bench.py's sequence showed exactly that).  The source takes the events (its own objects)
+        // and waits for them at its next trmc_route_begin -- a window later, when they have long fired.
+        if (!src->ev_released[0]) HIP_TRY(hipEventCreateWithFlags(&src->ev_released[0], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(src->ev_released[0], dst->wstream));
+        src->released_pending[0] = true;
         // ... and the receiver's own stream does not read time row 0 of the wide rows before this copy has written it: its
         // tail's first launch (step 1) takes no tile wait and reads q_tm[0] of its upstream wide rows
         HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_chain[2], 0));
@@ -3577,8 +3620,9 @@ template <class T> int chain_from_t(trmc_plan *dst, trmc_plan *src, int nsteps_d
     if (w0 > b0) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(w0 - b0)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, b0, w0);
     if (s1 > w1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(s1 - w1)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, w1, s1);
     HIP_TRY(hipEventRecord(dst->ev_chain[3], dst->stream));
-    HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_chain[3], 0));
-    if (src->wstream) HIP_TRY(hipStreamWaitEvent(src->wstream, dst->ev_chain[3], 0));
+    if (!src->ev_released[1]) HIP_TRY(hipEventCreateWithFlags(&src->ev_released[1], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(src->ev_released[1], dst->stream));
+    src->released_pending[1] = true;
     HIP_TRY(hipGetLastError());
     dst->chain_staged = true;
     return 0;
@@ -3849,7 +3893,13 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
 void trmc_plan_destroy(trmc_plan *pl)
 {
     if (!pl) return;
+    if (pl->clones > 0) { // its clones still use its static buffers: the memory goes with the last of them
+        pl->zombie = true;
+        return;
+    }
+    trmc_plan *const parent = pl->parent;
     (void)hipSetDevice(pl->device);
+    if (pl->ev_forcing) (void)hipEventDestroy(pl->ev_forcing);
     for (DevBuf &b : pl->rowsets) b.release();
     pl->fetch_hyd.release();
     pl->fetch_q0.release();
@@ -3869,6 +3919,8 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
     for (hipEvent_t e : pl->ev_chain)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pl->ev_released)
+        if (e) (void)hipEventDestroy(e);
     if (pl->wstream) (void)hipStreamDestroy(pl->wstream);
     for (auto *v : {&pl->wide_t0, &pl->wide_t1})
         for (auto &e : *v)
@@ -3880,6 +3932,126 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_ctl) (void)hipEventDestroy(pl->ev_ctl);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
     delete pl;
+    if (parent && --parent->clones == 0 && parent->zombie) {
+        parent->zombie = false;
+        trmc_plan_destroy(parent);
+    }
+}
+
+static int final_state_into(trmc_plan *pl, void *dst, int32_t nsteps_of_window = -1);
+static int ensure_copy_stream(trmc_plan *pl);
+
+int trmc_plan_clone(trmc_plan *src, trmc_plan **out)
+{
+    if (!out) return fail(TRMC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!src) return fail(TRMC_EINVAL, "plan is NULL");
+    if (src->parent) src = src->parent; // (a clone of a clone shares the same original)
+    if (src->zombie) return fail(TRMC_ESTATE, "the plan has been destroyed");
+    if (int rc = use_device(src)) return rc;
+    trmc_plan *pl = new (std::nothrow) trmc_plan();
+    if (!pl) return fail(TRMC_ENOMEM, "out of host memory");
+    pl->device = src->device;
+    pl->precision = src->precision;
+    pl->esz = src->esz;
+    pl->topo = src->topo;
+    pl->nseg = src->nseg;
+    pl->nseg_pad = src->nseg_pad;
+    pl->nrouted = src->nrouted;
+    pl->dt_uniform = src->dt_uniform;
+    pl->dt = src->dt;
+    pl->hinted = src->hinted;
+    pl->params_sane = src->params_sane;
+    pl->flow = src->flow;
+    pl->watchdog_ticks = src->watchdog_ticks;
+    pl->ncuq = src->ncuq;
+    pl->parent = src;
+    ++src->clones;
+    auto bail = [&](int rc) {
+        trmc_plan_destroy(pl);
+        return rc;
+    };
+    {
+        hipError_t e = hipSuccess;
+        int prio_lo = 0, prio_hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&pl->stream, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&pl->stream2, hipStreamNonBlocking, prio_lo);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_emit, hipEventDisableTiming);
+        if (e == hipSuccess && pl->flow) {
+            e = hipStreamCreateWithPriority(&pl->fstream, hipStreamNonBlocking, prio_hi);
+            for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&pl->ev_chunk[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_ctl, hipEventDisableTiming);
+        }
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
+        if (e != hipSuccess) return bail(fail(TRMC_EHIP, std::string("stream/event setup: ") + hipGetErrorString(e)));
+    }
+    // static data: the original's buffers (plan order, parameters and constants, the dataflow engine's placement tables)
+    pl->params.borrow(src->params);
+    pl->up_ptr.borrow(src->up_ptr);
+    pl->up_idx.borrow(src->up_idx);
+    pl->up2.borrow(src->up2);
+    pl->level.borrow(src->level);
+    pl->row_of_pos.borrow(src->row_of_pos);
+    pl->pos_of_row.borrow(src->pos_of_row);
+    pl->rank.borrow(src->rank);
+    pl->prio.borrow(src->prio);
+    pl->cuq_ptr.borrow(src->cuq_ptr);
+    pl->cuq_blk.borrow(src->cuq_blk);
+    pl->cu_index.borrow(src->cu_index);
+    pl->cuq_perm.borrow(src->cuq_perm);
+    if (int rc = pl->it_prev.ensure((size_t)pl->nseg_pad)) return bail(rc);
+    if (pl->ncuq > 0)
+        if (int rc = pl->cuq_head.ensure((size_t)pl->ncuq * 2 * sizeof(int32_t))) return bail(rc);
+    *out = pl;
+    return 0;
+}
+
+// The next window's forcing on its way to the device WHILE another plan's window (or this plan's copy of results) runs:
+// the host-to-device copy is queued on the plan's copy stream and nothing is waited for; the next trmc_route_begin orders
+// the window's set-up behind it.  The initial state is not touched: it is what trmc_plan_chain_from hands over, or (q0 =
+// NULL semantics of trmc_upload_forcing) the state this plan's last window left.
+int trmc_stage_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    // Also WHILE the plan routes a window that has been queued to its end: the staging area is only read by the window's
+    // set-up (the transposing pass at its start), so the next window's forcing may land in it behind that -- a sequence that
+    // alternates between a plan and its clone stages a day's forcing two days ahead, right after it has queued the plan's
+    // current day, and the copy is through long before the plan's next set-up asks for it.  (Then there is no state of
+    // "the plan's last window" yet: trmc_plan_chain_from must supply one.)
+    const bool busy = pl->run.active;
+    if (busy && pl->run.t_done < pl->run.nsteps + (pl->run.short_ts ? pl->maxlag : 0))
+        return fail(TRMC_ESTATE, "the window in progress has not been queued to its end (trmc_route_advance)");
+    if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
+    if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
+    if (pl->nseg > 0 && !qlat) return fail(TRMC_EINVAL, "qlat is NULL");
+    if (pl->topo.nboundary > 0) return fail(TRMC_EINVAL, "a plan with boundary rows stages its forcing with trmc_upload_forcing");
+    if (int rc = use_device(pl)) return rc;
+    if (int rc = ensure_copy_stream(pl)) return rc;
+    const size_t bytes = (size_t)pl->nseg * nq * pl->esz;
+    if (busy && bytes > pl->in_qlat.bytes)
+        return fail(TRMC_ESTATE, "the staging area would have to grow while the window in progress may still read it");
+    if (int rc = pl->in_qlat.ensure(bytes)) return rc;
+    // the initial state unless trmc_plan_chain_from replaces it: what this plan's last window left (gathered now, on the
+    // plan's stream, before anything overwrites the planes); a plan that has routed nothing must be chained to
+    if (int rc = pl->in_q0.ensure((size_t)pl->nseg * 3 * pl->esz)) return rc;
+    pl->state_missing = busy || pl->routed_nsteps < 0;
+    if (pl->nseg > 0 && !pl->state_missing)
+        if (int rc = final_state_into(pl, pl->in_q0.p)) return rc;
+    // (behind the set-up of the window in progress, which reads the staging area; the plan's last fetch may still be running
+    // on the same copy stream: in order behind it)
+    if (busy) HIP_TRY(hipStreamWaitEvent(pl->cstream, pl->ev[1], 0));
+    if (pl->nseg > 0) HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, bytes, hipMemcpyHostToDevice, pl->cstream));
+    HIP_TRY(hipEventRecord(pl->ev_forcing, pl->cstream));
+    pl->forcing_pending = true;
+    pl->qlat_direct = false;
+    pl->nq = nq;
+    pl->have_boundary = true;
+    pl->ngage = 0; // nudging tables belong to one window (the launches of a window in progress carry their own copy of the pointers)
+    pl->nraw = 0;
+    pl->staged_nsteps = nsteps;
+    if (!busy) pl->routed_nsteps = -1; // (a window in progress sets it when it ends)
+    return 0;
 }
 
 int trmc_plan_info(const trmc_plan *pl, int64_t *nseg, int64_t *nseg_routed, int32_t *nlevels, int32_t *precision,
@@ -3905,9 +4077,9 @@ int trmc_plan_levels(const trmc_plan *pl, int32_t *level_of_row, int64_t *plan_p
 }
 
 // (q_T, q_T, depth_T) of the last routed window, row order, into device memory `dst` [nseg][3]; queued on the plan stream
-static int final_state_into(trmc_plan *pl, void *dst)
+static int final_state_into(trmc_plan *pl, void *dst, int32_t nsteps_of_window)
 {
-    const int32_t n = (int32_t)pl->nseg, T_ = pl->routed_nsteps;
+    const int32_t n = (int32_t)pl->nseg, T_ = nsteps_of_window >= 0 ? nsteps_of_window : pl->routed_nsteps;
     const size_t plane = (size_t)(T_ + 1) * pl->nseg_pad;
     const int32_t *rop = (const int32_t *)pl->row_of_pos.p;
     if (pl->flow) {
@@ -3923,7 +4095,7 @@ static int final_state_into(trmc_plan *pl, void *dst)
                            (double *)dst, n, pl->nseg_pad, T_, 1, T_);
     }
     HIP_TRY(hipGetLastError());
-    return note_gather(pl);
+    return note_gather(pl, nsteps_of_window >= 0);
 }
 
 // initial state (or warm start), boundary hydrographs, and the bookkeeping common to every forcing upload
@@ -3950,6 +4122,8 @@ static int stage_state(trmc_plan *pl, int nsteps, int64_t nq, const void *q0, co
     pl->nraw = 0;
     pl->staged_nsteps = nsteps;
     pl->routed_nsteps = -1;
+    pl->state_missing = false;
+    pl->forcing_pending = false;
     return 0;
 }
 
@@ -4185,6 +4359,8 @@ static int route_check(trmc_plan *pl, int nsteps, int qts_subdivisions, bool bou
     if (!pl->have_boundary && !boundary_later)
         return fail(TRMC_ESTATE, "plan has boundary rows but no boundary hydrographs were supplied");
     if (pl->ngage > 0 && pl->da_nsteps != nsteps) return fail(TRMC_EINVAL, "nudging tables were set for a different nsteps");
+    if (pl->state_missing && !pl->chain_staged)
+        return fail(TRMC_ESTATE, "the forcing was staged on a plan that has routed nothing: trmc_plan_chain_from must hand it a state");
     // the reference's precondition, mc_reach.pyx:246-247
     if ((int64_t)(nsteps - 1) / qts_subdivisions >= pl->nq)
         return fail(TRMC_EINVAL, "Number of columns (timesteps) in Qlat is incorrect: need "
@@ -4499,29 +4675,66 @@ int trmc_download_final_state(trmc_plan *pl, void *q0_out)
     return 0;
 }
 
+} // extern "C"
+namespace {
+// device memory -> page-locked host memory (through the device's mapping of it), 16 bytes per lane; and the odd bytes at the end
+__global__ void __launch_bounds__(kBlock) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+__global__ void k_copy1(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int32_t n)
+{
+    if ((int32_t)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+} // namespace
+extern "C" {
+
+// the plan's copy stream (results to the host beside the next window; the next window's forcing to the device beside this one)
+static int ensure_copy_stream(trmc_plan *pl)
+{
+    if (pl->cstream) return 0;
+    // LOW priority: with one hardware queue per priority (GPU_MAX_HW_QUEUES=1) a copy on a stream of ordinary
+    // priority shares the queue of the tile stream, and the barrier packet that orders the copy holds the window's tile
+    // launches back for as long as the copy runs (CONUS: 50 MB, 0.9 ms of an 18 ms window).  The low-priority queue only
+    // carries the result transposes.
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    const char *pr = std::getenv("TRMC_COPY_PRIO"); // "normal": A/B
+    if (pr && pr[0] == 'n')
+        HIP_TRY(hipStreamCreateWithFlags(&pl->cstream, hipStreamNonBlocking));
+    else
+        HIP_TRY(hipStreamCreateWithPriority(&pl->cstream, hipStreamNonBlocking, prio_lo));
+    HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&pl->ev_forcing, hipEventDisableTiming));
+    return 0;
+}
+
 int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_host)
 {
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
-    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    // After a window (trmc_route_end), or -- level engine -- WITH a window that has been queued to its end: the gathers then go
+    // right behind the window's last launch on the plan's stream.  That is where a sequence alternating between two plans
+    // wants them: queued after the window has been waited for, they would sit in the shared high-priority hardware queue
+    // behind the OTHER plan's 288 tail launches, run a whole window late, and this plan's next window -- which overwrites
+    // the planes they read -- could not start before (the timeline of bench.py's sequence showed exactly that).
+    const bool in_window = pl->run.active;
+    if (in_window) {
+        if (pl->flow) return fail(TRMC_ESTATE, "a fetch queued with the window needs the level engine");
+        if (pl->run.t_done < pl->run.nsteps + (pl->run.short_ts ? pl->maxlag : 0))
+            return fail(TRMC_ESTATE, "the window in progress has not been queued to its end (trmc_route_advance)");
+    } else if (pl->routed_nsteps < 0) {
+        return fail(TRMC_ESTATE, "nothing routed yet");
+    }
     if (pl->fetch_pending) return fail(TRMC_ESTATE, "a fetch is in flight (trmc_fetch_wait it first)");
     if (hyd_host && (rowset < 0 || rowset >= (int32_t)pl->rowsets.size())) return fail(TRMC_EINVAL, "unknown row set");
     if (int rc = use_device(pl)) return rc;
-    if (!pl->cstream) {
-        // LOW priority: with one hardware queue per priority (GPU_MAX_HW_QUEUES=1) a copy on a stream of ordinary
-        // priority shares the queue of the tile stream, and the barrier packet that orders the copy holds the window's tile
-        // launches back for as long as the copy runs (CONUS: 50 MB, 0.9 ms of an 18 ms window).  The low-priority queue only
-        // carries the result transposes.
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        const char *pr = std::getenv("TRMC_COPY_PRIO"); // "normal": A/B
-        if (pr && pr[0] == 'n')
-            HIP_TRY(hipStreamCreateWithFlags(&pl->cstream, hipStreamNonBlocking));
-        else
-            HIP_TRY(hipStreamCreateWithPriority(&pl->cstream, hipStreamNonBlocking, prio_lo));
-        HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_ready, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_done, hipEventDisableTiming));
+    if (int rc = ensure_copy_stream(pl)) return rc;
+    if (in_window) { // (the window's own end -- transposing launches, the clock's events -- first)
+        if (int rc = pl->precision == 32 ? route_end_queue<float>(pl) : route_end_queue<double>(pl)) return rc;
     }
-    const int32_t T_ = pl->routed_nsteps;
+    const int32_t T_ = in_window ? pl->run.nsteps : pl->routed_nsteps;
     const int64_t nrows = hyd_host ? pl->rowset_n[rowset] : 0;
     const size_t hb = (size_t)nrows * T_ * pl->esz, qb = q0_host ? (size_t)pl->nseg * 3 * pl->esz : 0;
     if (hb) {
@@ -4533,16 +4746,51 @@ int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_hos
             hipLaunchKernelGGL((k_gather_rows<double>), dim3(blocks_for(nrows * T_)), dim3(kBlock), 0, pl->stream, (const double *)pl->tm.p,
                                (const int32_t *)pl->rowsets[rowset].p, (double *)pl->fetch_hyd.p, nrows, pl->nseg_pad, T_, 1);
         HIP_TRY(hipGetLastError());
-        if (int rc = note_gather(pl)) return rc;
+        if (int rc = note_gather(pl, in_window)) return rc;
     }
     if (qb) {
         if (int rc = pl->fetch_q0.ensure(qb)) return rc;
-        if (int rc = final_state_into(pl, pl->fetch_q0.p)) return rc;
+        if (int rc = final_state_into(pl, pl->fetch_q0.p, in_window ? T_ : -1)) return rc;
     }
     HIP_TRY(hipEventRecord(pl->ev_fetch_ready, pl->stream));
     HIP_TRY(hipStreamWaitEvent(pl->cstream, pl->ev_fetch_ready, 0));
-    if (hb) HIP_TRY(hipMemcpyAsync(hyd_host, pl->fetch_hyd.p, hb, hipMemcpyDeviceToHost, pl->cstream));
-    if (qb) HIP_TRY(hipMemcpyAsync(q0_host, pl->fetch_q0.p, qb, hipMemcpyDeviceToHost, pl->cstream));
+    // Queued WITH the window the copies have a dependence that is still pending, and hipMemcpyAsync device-to-host then keeps
+    // the calling thread until it is resolved (measured: trmc_fetch_begin returns when the window ends).  TRMC_FETCH_KERNEL=1
+    // copies with a kernel instead, which writes the page-locked host arrays through the device's mapping of them and never
+    // waits on the host -- measured on the CONUS sequence of bench.py it is no gain: a day's narrow levels can only start
+    // when the day before has ended, so a window queued earlier does not finish earlier (16.7 ms per day with the copy
+    // engine, 17.1 with the kernel, whose wavefronts hold slots while their stores cross the host link).
+    const bool by_kernel = in_window && std::getenv("TRMC_FETCH_KERNEL") != nullptr;
+    auto to_host = [&](void *dst_host, const void *src_dev, size_t bytes) -> int {
+        if (!by_kernel) {
+            HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, pl->cstream));
+            return 0;
+        }
+        void *dst_dev = nullptr;
+        if (hipHostGetDevicePointer(&dst_dev, dst_host, 0) != hipSuccess || !dst_dev) {
+            (void)hipGetLastError(); // (not page-locked memory of this runtime: the copy engine, and the wait that comes with it)
+            HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, pl->cstream));
+            return 0;
+        }
+        // (few workgroups: the copy goes at the pace of the host link whatever their number, and a wavefront that waits for its
+        // stores to cross that link holds a slot the window's kernels want -- TRMC_FETCH_BLOCKS, default 16, is a measurement knob)
+        static const long max_blocks = [] {
+            const char *e = std::getenv("TRMC_FETCH_BLOCKS");
+            return e ? std::max(1L, std::atol(e)) : 16L;
+        }();
+        const size_t n16 = bytes / 16;
+        if (n16) hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((size_t)max_blocks, (n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, pl->cstream,
+                                    (const uint4 *)src_dev, (uint4 *)dst_dev, (int64_t)n16);
+        if (bytes % 16)
+            hipLaunchKernelGGL(k_copy1, dim3(1), dim3(16), 0, pl->cstream, (const uint8_t *)src_dev + n16 * 16, (uint8_t *)dst_dev + n16 * 16,
+                               (int32_t)(bytes % 16));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if (hb)
+        if (int rc = to_host(hyd_host, pl->fetch_hyd.p, hb)) return rc;
+    if (qb)
+        if (int rc = to_host(q0_host, pl->fetch_q0.p, qb)) return rc;
     HIP_TRY(hipEventRecord(pl->ev_fetch_done, pl->cstream));
     pl->fetch_pending = true;
     return 0;

@@ -230,6 +230,30 @@ class RoutingPlan:
         return self.stats()
 
     # -- the same window in parts (asynchronous; see include/trmc.h) ------------------------------
+    def clone(self):
+        """A second set of window buffers on this plan's static data (trmc_plan_clone): same topology, parameters and
+        order in HBM, its own forcing / state / result / streams -- for a sequence of windows that takes turns on the two
+        (``chain_from``, ``stage_forcing``)."""
+        other = object.__new__(RoutingPlan)
+        for k in ("nseg", "precision", "dtype", "nboundary", "engine", "maxlag"):
+            setattr(other, k, getattr(self, k))
+        h = C.c_void_p(0)
+        other._h = C.c_void_p(0)
+        _lib.check(_lib.lib().trmc_plan_clone(self._h, C.byref(h)))
+        other._h = h
+        other._nsteps = None
+        return other
+
+    def stage_forcing(self, nsteps, qlat):
+        """The next window's forcing on its way to the device without waiting for anything (trmc_stage_forcing): `qlat`
+        [nseg, nq] should live in page-locked memory (``_lib.result_empty(..., always_pinned=True)``) for the copy to run
+        beside the window another plan is routing.  The array must stay alive and unchanged until that window has begun."""
+        if qlat.dtype != self.dtype or not qlat.flags.c_contiguous or qlat.ndim != 2 or qlat.shape[0] != self.nseg:
+            raise ValueError(f"qlat must be a C-contiguous {np.dtype(self.dtype).name} array of shape ({self.nseg}, nq)")
+        self._staged_qlat = qlat                      # (kept alive while the copy may be in flight)
+        _lib.check(_lib.lib().trmc_stage_forcing(self._h, int(nsteps), _lib.ptr(qlat), qlat.shape[1]))
+        self._nsteps = nsteps
+
     def chain_from(self, source):
         """This plan's NEXT window starts from the state `source`'s window (queued to its end) leaves, handed over on the
         device in two parts so that this plan's wide levels can start before the source's tail has finished (trmc.h)."""

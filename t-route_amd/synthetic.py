@@ -179,7 +179,7 @@ def generate(nseg=CONUS_NSEG, nnet=CONUS_NNET, seed=DEFAULT_SEED, nq=25, cache_d
     return out
 
 
-def forcing(nseg, nq=25, seed=DEFAULT_SEED + 1, previous=None, sigma=0.06, redraw=0.001):
+def forcing(nseg, nq=25, seed=DEFAULT_SEED + 1, previous=None, sigma=0.06, redraw=0.001, persistence=None):
     """Another day of lateral inflow with the statistics of ``generate``'s (11 % zeros, else lognormal with
     median 2.3e-4 m3/s, sigma 2.3, clipped at 1, times a smooth diurnal factor 1 +- 0.2) under its own seed -- the
     window a plan is TIMED on after it was tuned on another one.
@@ -189,7 +189,11 @@ def forcing(nseg, nq=25, seed=DEFAULT_SEED + 1, previous=None, sigma=0.06, redra
     baseflow, whose spatial pattern persists from day to day.  The defaults are what the reference's own forcing files
     show one day apart (test/LowerColorado_TX/channel_forcing, 2021-08-23 13:00-16:00 against 2021-08-24 13:00-16:00,
     qBucket + qSfcLatRunoff of the 11 248 segments): standard deviation of the log ratio 0.056, rank correlation 0.9998,
-    0.05 % of the rows switch between zero and non-zero inflow."""
+    0.05 % of the rows switch between zero and non-zero inflow.
+    persistence (optional, 0..1): the share of rows that keep their magnitude, i.e. redraw = 1 - persistence -- how much a
+    result depends on the day-to-day persistence is measured by varying it (bench.py --persistence)."""
+    if persistence is not None:
+        redraw = 1.0 - float(persistence)
     rng = np.random.default_rng(seed)
     fresh = np.minimum(rng.lognormal(np.log(2.3e-4), 2.3, nseg), 1.0) * (rng.random(nseg) > 0.11)
     if previous is None:

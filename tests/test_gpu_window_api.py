@@ -399,3 +399,99 @@ def test_a_sequence_of_windows_on_two_plans_taking_turns_equals_the_sequence_on_
         assert np.array_equal(last.download_fvd().view(np.uint32), want[nwin - 1].view(np.uint32))
         with pytest.raises(ValueError, match="two different plans"):
             a.chain_from(a)
+
+
+@pytest.mark.parametrize("engine,ahead", [("levels", False), ("levels", True), ("flow", False)])
+def test_a_sequence_of_distinct_days_on_a_plan_and_its_clone_with_staged_forcing(monkeypatch, engine, ahead):
+    """The sequence bench.py times: consecutive windows with DIFFERENT forcing take turns on a plan and its clone
+    (trmc_plan_clone: the original's topology and parameter columns in HBM, its own window buffers), every day's forcing
+    staged from page-locked host memory on the copy stream without a wait (trmc_stage_forcing), the state handed on in HBM
+    (trmc_plan_chain_from), outlet hydrographs and final state fetched asynchronously -- against the same days routed one
+    after the other on one plan with synchronous uploads (warm start q0 = None: AbstractNetwork.py:177-191)."""
+    monkeypatch.setenv("TRMC_SETUP_ASIDE", "1")
+    monkeypatch.setenv("TRMC_ENGINE", engine)
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
+    monkeypatch.setenv("TRMC_WIDE_K", "8")
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(seed=11, nseg=6000)
+    nsteps, qts, ndays = 48, 12, 7
+    rng = np.random.default_rng(3)
+    days = []
+    for _ in range(ndays):                                   # page-locked, distinct
+        d = _lib.result_empty(qlat.shape, np.float32, always_pinned=True)
+        d[...] = rng.uniform(0, 0.6, qlat.shape).astype(np.float32)
+        days.append(d)
+    outlets = np.flatnonzero(to < 0)
+    want_h, want_s = [], []
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as ref:
+        for w in range(ndays):
+            ref.upload_forcing(nsteps, days[w], q0 if w == 0 else None)
+            ref.route_device(nsteps, qts, True)
+            want_h.append(ref.gather_flow_rows(outlets))
+            want_s.append(ref.download_final_state())
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as a:
+        b = a.clone()
+        if engine == "flow":
+            with pytest.raises(ValueError, match="level engine"):
+                b.chain_from(a)
+            b.close()
+            return
+        plans = [a, b]
+        rs = [pl.rowset(outlets) for pl in plans]
+        a.upload_forcing(nsteps, days[0], q0)               # day 0 the ordinary way: the sequence needs a first state
+        a.route_begin(nsteps, qts, True)
+        with pytest.raises(RuntimeError, match="queued to its end"):
+            a.stage_forcing(nsteps, days[2])                # (a window in progress must be queued to its end first)
+        a.route_advance(nsteps)
+        if ahead:                                           # ahead: a day's forcing is staged TWO days before, on the plan
+            b.stage_forcing(nsteps, days[1])                # that will route it, behind the set-up of the day it is routing
+            a.fetch_begin(rs[0], True)
+            a.stage_forcing(nsteps, days[2])
+        got = []
+        keep = lambda hs: (hs[0].copy(), hs[1].copy())      # noqa: E731  (the arrays belong to a ring of three sets per plan)
+        for w in range(1, ndays):
+            cur, prev = plans[w % 2], plans[(w - 1) % 2]
+            if not ahead:
+                cur.stage_forcing(nsteps, days[w])          # (no wait: beside the window `prev` is routing)
+            cur.chain_from(prev)
+            cur.route_begin(nsteps, qts, True)
+            cur.route_advance(nsteps)
+            if ahead:                                       # ... and the day's fetch is queued WITH its window: the gathers
+                cur.fetch_begin(rs[w % 2], True)            # right behind its last launch, not behind the other plan's tail
+                if w + 2 < ndays:
+                    cur.stage_forcing(nsteps, days[w + 2])
+            prev.route_end()
+            if ahead:
+                got.append(keep(prev.fetch_wait()))
+            else:
+                if w >= 2:
+                    got.append(keep(plans[w % 2].fetch_wait()))  # (the fetch of day w - 2 ran on this plan's copy stream)
+                prev.fetch_begin(rs[(w - 1) % 2], True)
+        last = plans[(ndays - 1) % 2]
+        last.route_end()
+        if ahead:
+            got.append(keep(last.fetch_wait()))
+        else:
+            got.append(keep(plans[(ndays - 2) % 2].fetch_wait()))
+            last.fetch_begin(rs[(ndays - 1) % 2], True)
+            got.append(keep(last.fetch_wait()))
+        assert len(got) == ndays
+        for w, (h, st) in enumerate(got):
+            assert np.array_equal(h.view(np.uint32), want_h[w].view(np.uint32)), w
+            assert np.array_equal(st.view(np.uint32), want_s[w].view(np.uint32)), w
+        # a staged forcing without a hand-over continues from the plan's own last window
+        last.stage_forcing(nsteps, days[0])
+        last.route_device(nsteps, qts, True)
+        with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as ref:
+            ref.upload_forcing(nsteps, days[0], want_s[-1])
+            ref.route_device(nsteps, qts, True)
+            assert np.array_equal(last.download_final_state().view(np.uint32), ref.download_final_state().view(np.uint32))
+        # ... and a plan that has routed nothing must be chained to
+        c = a.clone()
+        c.stage_forcing(nsteps, days[1])
+        with pytest.raises(RuntimeError, match="routed nothing"):
+            c.route_begin(nsteps, qts, True)
+        c.close()
+        a.close()                                            # (the original first: the shared memory goes with the last user)
+        b.stage_forcing(nsteps, days[2])
+        b.route_device(nsteps, qts, True)
+        b.close()
