@@ -12,7 +12,7 @@ namespace trmc {
 
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows,
-                   bool cost_tiers, int32_t boundary_floor)
+                   bool cost_tiers, int32_t boundary_floor, int64_t wide_min_rows, int32_t wide_max_levels)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -400,6 +400,22 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                 t.row_of_pos[p0 + i] = rows[idx[i]];
                 t.pos_of_row[rows[idx[i]]] = p0 + i;
             }
+        }
+    }
+
+    // the rows below the leading wide levels: by descending cost across levels (topology.hpp, wide_min_rows)
+    if (cost_hint && wide_min_rows > 0 && wide_max_levels > 0) {
+        int32_t W = 0;
+        while (W < t.nlevels && W < wide_max_levels && (int64_t)(t.lvl_ptr[W + 1] - t.lvl_ptr[W]) >= wide_min_rows) ++W;
+        if (W > 0 && W < t.nlevels) {
+            const int32_t p0 = t.lvl_ptr[W], p1 = t.lvl_ptr[t.nlevels];
+            std::vector<int32_t> rows(t.row_of_pos.begin() + p0, t.row_of_pos.begin() + p1);
+            std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return cost_hint[a] > cost_hint[b]; });
+            for (int32_t i = 0; i < p1 - p0; ++i) {
+                t.row_of_pos[p0 + i] = rows[i];
+                t.pos_of_row[rows[i]] = p0 + i;
+            }
+            t.tail_from_level = W;
         }
     }
 

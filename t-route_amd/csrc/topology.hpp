@@ -28,6 +28,9 @@ struct Topology {
     std::vector<int32_t> row_of_pos;     // [nseg] plan position -> row
     std::vector<int32_t> lvl_ptr;        // [nlevels+1] plan-position offsets of the routed levels
                                          // (positions [0, lvl_ptr[0]) hold the boundary rows)
+    int32_t tail_from_level = 0;         // > 0: only the levels below it are contiguous slices; the rows of the deeper levels
+                                         // -- positions [lvl_ptr[tail_from_level], lvl_ptr[nlevels]) -- are ordered by cost
+                                         // across levels (build_topology, wide_min_rows): a short-timestep plan only
     std::vector<int32_t> up_ptr;         // [nseg+1] CSR over plan positions
     std::vector<int32_t> up_idx;         // upstream plan positions, reference summation order
     std::vector<int32_t> boundary_rows;  // ascending rows flagged as boundary
@@ -66,8 +69,16 @@ struct Topology {
 // the widest levels, the ones the level engine routes several timesteps per launch ahead of the window's progress
 // (k_mc_tile); rows whose inflow arrives chunk by chunk during the window (the trunk of a cut basin, distributed.py) must
 // stay out of those.  Levels between may be empty; results do not depend on it.
+// wide_min_rows > 0 (level order, with a cost hint): the plan is only ever routed with assume_short_ts, where a row at step t
+// reads flows of step t - 1 -- so the rows BELOW the leading wide levels (at most wide_max_levels levels of at least
+// wide_min_rows rows: the ones the level engine routes several timesteps per launch) need not be grouped by level at all:
+// one launch per timestep covers all of them whatever their order.  They are ordered by descending cost ACROSS levels
+// (then by level, then as inside a level): a wavefront holds rows of one cost class also where the levels are a hundred
+// rows wide and the per-level order mixed three classes in one wavefront (917 instructions per wavefront-step there
+// against 788 in the wider levels).  Topology::tail_from_level says where that part begins.
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr,
-                   int32_t block_rows = 0, bool cost_tiers = true, int32_t boundary_floor = 0);
+                   int32_t block_rows = 0, bool cost_tiers = true, int32_t boundary_floor = 0, int64_t wide_min_rows = 0,
+                   int32_t wide_max_levels = 0);
 
 } // namespace trmc

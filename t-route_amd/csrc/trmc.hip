@@ -2769,8 +2769,9 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         while (K & (K - 1)) K &= K - 1; // the power of two at or below
         const bool all_in_place = pl->maxlag == 0 && r.boundary_through == nsteps;
         int32_t W = 0;
+        const int32_t level_cap = tp.tail_from_level > 0 ? tp.tail_from_level : tp.nlevels;
         if (on && min_rows > 0 && all_in_place)
-            while (W < tp.nlevels && W < max_levels && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows) ++W;
+            while (W < level_cap && W < max_levels && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows) ++W;
         if (W > 0 && (uint64_t)pl->nseg * (uint64_t)nsteps * 3ull < (1ull << 62)) {
             r.win = true;
             r.win_W = W;
@@ -2799,8 +2800,9 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 384L * ncu), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
         int32_t W = 0;
         const bool all_in_place = pl->maxlag == 0 && r.boundary_through == nsteps; // (then every level may run ahead)
+        const int32_t level_cap = tp.tail_from_level > 0 ? tp.tail_from_level : tp.nlevels; // (deeper rows are not in level slices)
         if (min_rows > 0)
-            while (W < tp.nlevels && W < std::min<long>(max_levels, kWideMaxLevels) && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows
+            while (W < level_cap && W < std::min<long>(max_levels, kWideMaxLevels) && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows
                    && (all_in_place || (int64_t)tp.lvl_ptr[W + 1] <= pl->wide_safe_pos))
                 ++W;
         if (W > 0) {
@@ -3812,8 +3814,23 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
     std::string err;
     // (plans meant for assume_short_ts on the level engine: rows fed by boundary rows stay below the levels that may be routed
     // several timesteps per launch -- topology.hpp, boundary_floor; TRMC_WIDE_LEVELS never asks for more than kWideMaxLevels)
+    // ... and (a hinted short-timestep plan of the level engine) the rows below the levels that can be routed several timesteps
+    // per launch are ordered by cost across levels: the same rule picks those levels here as in route_begin_t, which never
+    // takes more of them than the plan was ordered for.  TRMC_TAIL_SORT=0 keeps the per-level order (A/B).
+    int64_t wide_min_rows = 0;
+    int32_t wide_max_levels = 0;
+    if (tiers && !pl->flow && cost_hint) {
+        const char *off = std::getenv("TRMC_TAIL_SORT");
+        int ncu = 256;
+        if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        const char *e1 = std::getenv("TRMC_WIDE_MIN_ROWS"), *e2 = std::getenv("TRMC_WIDE_LEVELS");
+        if (!(off && off[0] == '0')) {
+            wide_min_rows = e1 && *e1 ? std::atol(e1) : 384L * ncu;
+            wide_max_levels = (int32_t)std::min<long>(e2 && *e2 ? std::atol(e2) : 16, kWideMaxLevels);
+        }
+    }
     const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0, tiers,
-                                         (tiers && !pl->flow) ? kWideMaxLevels : 0);
+                                         (tiers && !pl->flow) ? kWideMaxLevels : 0, wide_min_rows, wide_max_levels);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
@@ -4370,6 +4387,9 @@ static int route_check(trmc_plan *pl, int nsteps, int qts_subdivisions, bool bou
 
 static int lag_check(trmc_plan *pl, int assume_short_ts)
 {
+    if (pl->topo.tail_from_level > 0 && !assume_short_ts)
+        return fail(TRMC_EINVAL, "this plan was created for assume_short_ts (TRMC_PLAN_SHORT_TS with a cost hint: its deeper rows are "
+                                 "ordered by cost, not by level); create a plan for the general mode");
     if (pl->maxlag > 0 && !assume_short_ts)
         return fail(TRMC_EINVAL, "a plan with lagged rows (trmc_plan_set_lag) routes with assume_short_ts only");
     return 0;
