@@ -569,7 +569,7 @@ def main():
             json_out.write(json.dumps({"metric": "segment-timesteps/sec, CONUS NHD 2.7M-seg MC", "value": rate(head),
                                        "unit": "segment-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                                        "ms_per_step": head["el"] / a.steps * 1e3, "ms_main": head["ms_main"],
-                                       "headline_only": True}) + "\n")
+                                       "headline_only": True, "day_ms": None if seq is None else seq["day_ms"]}) + "\n")
             json_out.flush()
         router.close()
         if comm is not None:
@@ -814,7 +814,7 @@ def sequence_of_days(plan_a, plan_b, days, state0, outlets_rs, a, steps, warmup)
     plan_a.upload_forcing(nsteps, days[0], state0)          # the first day of the sequence the ordinary way (synchronous)
     if total > 1:
         plan_b.stage_forcing(nsteps, days[1 % nd])
-    ms_main, got = [], None
+    ms_main, got, ends = [], None, []
     dbg = [] if os.environ.get("TRMC_BENCH_DEBUG") else None
     tz = _t.perf_counter()
 
@@ -846,6 +846,7 @@ def sequence_of_days(plan_a, plan_b, days, state0, outlets_rs, a, steps, warmup)
                 cur.stage_forcing(nsteps, days[(w + 2) % nd])
             mark(f"queued{w}]")
         st = prev.route_end()                                # day w - 1 is through
+        ends.append(_t.perf_counter())
         mark(f"ended{w - 1}({st['ms_main']:.1f})")
         if w - 1 >= warmup:
             ms_main.append(st["ms_main"])
@@ -857,7 +858,9 @@ def sequence_of_days(plan_a, plan_b, days, state0, outlets_rs, a, steps, warmup)
     el = _t.perf_counter() - t0
     if dbg is not None:
         print("[sequence] host timeline ms: " + " ".join(dbg), file=sys.stderr)
-    return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total, "last_plan": plans[(total - 1) % 2]}
+    day_ms = [round((b - a_) * 1e3, 2) for a_, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
+    return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total, "last_plan": plans[(total - 1) % 2],
+            "day_ms": day_ms}
 
 
 def two_members(router_a, make_b, spin_up, qlat, a, rate_of):

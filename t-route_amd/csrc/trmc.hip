@@ -381,6 +381,11 @@ template <class T> struct StepArgs {
     T *out;
     const int32_t *row_of_pos;
     bool out_vec; // the runs it writes are 16-byte aligned (float, nsteps % 4 == 0, K % 4 == 0)
+    // k_mc_tile: which row a thread takes (nullptr: its own position).  A permutation of the positions inside groups of
+    // kPermGroup, rebuilt before every tile from the cost class every row showed at the end of the tile before (k_tile_perm):
+    // wavefronts hold rows of one class whatever the forcing does and however old the plan's cost hint is.
+    const int32_t *tile_perm;
+    uint8_t *cls_last; // cost class of every row at the last step it was routed in a tile: min(iterations, 3) + 4 if over bank
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -594,8 +599,9 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     M m{stage_pow_tables(s_tab), false};
     m.sane = a.sane;
 
-    const int32_t s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
-    if (s >= s_end) return;
+    const int32_t s_mine = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
+    if (s_mine >= s_end) return;
+    const int32_t s = a.tile_perm ? a.tile_perm[s_mine] : s_mine;
     const int32_t behind = tile - a.level[s];
     if (behind < 0) return;
     const int32_t t_lo = behind * K + 1, t_hi = min(behind * K + K, a.nsteps);
@@ -636,6 +642,7 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     m.coef_ok = coef_guard(p.dt, ql); // (depends on the forcing column only: formed when that changes, not every step)
     const bool count_cost = a.it_sum != nullptr;
     int32_t it_acc = 0, it_last = 0, staged = 0;
+    bool over_last = false;
     // flows of the step before (complete: earlier launches); advanced a row per step -- t differs from lane to lane (the
     // level skew), and (size_t)t * np in vector registers is a 64-bit multiplication per step
     T *q_up = a.q_tm + (size_t)(t_lo - 1) * np;
@@ -679,6 +686,7 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             v_new = r.velc;
             d_new = r.depthc;
             it_last = r.iters;
+            over_last = r.over;
             if (count_cost) it_acc += min(r.iters, 3) + (r.over ? 4 : 0);
             if (gi >= 0) { // streamflow nudging (see k_mc_step)
                 const size_t e = (size_t)gi * (size_t)cold->nsteps + (size_t)(t - 1);
@@ -726,7 +734,51 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         }
     }
     if (t_hi == cold->nsteps) cold->it_prev[su] = (uint8_t)min(it_last, 255);
+    if (uint8_t *const cls = cold->cls_last) cls[su] = (uint8_t)(min(it_last, 3) + (over_last ? 4 : 0));
     if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535, (int)it_sum[su] + it_acc);
+}
+
+// Which row every thread of the next k_mc_tile launch takes: inside each group of kPermGroup consecutive positions the rows
+// are dealt out by DESCENDING cost class (the class each showed at the end of the tile before: a row repeats its secant
+// iteration count from step to step 99.3 % of the time), so a wavefront holds rows of one class -- on the device, tile by
+// tile, from what the rows just did.  The plan's cost hint does the same once, on the host, from an earlier window
+// (topology.hpp), and is worth nothing when the forcing changes: with half of the rows' inflow drawn anew from day to day
+// the tuned plan ran the CONUS day in 20.6 ms, the untuned one in 20.2, against 16.4 on the day it was tuned for.
+// A group is a workgroup here; order inside a class is whatever the atomics give (results do not depend on it).
+// MEASURED (CONUS sequence of bench.py, ms per day; TRMC_TILE_PERM=<group>) and therefore OFF by default: on the plan
+// built from the topology alone 20.2 without, 20.7 / 21.7 / 22.4 with groups of 256 / 512 / 1024; on the tuned plan with
+// half of the rows' inflow redrawn every day 20.6 without, 20.9 with groups of 256; on the tuned plan and its own kind of
+// days 16.0-16.7 either way.  Dealing rows out by class takes a wavefront's 64 rows from 8-27 cache lines of every column
+// instead of 2, and what the uniform wavefronts save in instructions the scattered flow stores and parameter loads cost
+// again: the remedy for a stale hint stays a new hint (a plan rebuilt from trmc_download_cost, 1.6 s on the host).
+constexpr int kPermGroupMax = 1024;
+__global__ void __launch_bounds__(kBlock)
+k_tile_perm(const uint8_t *__restrict__ cls, int32_t *__restrict__ perm, const int32_t s_begin, const int32_t s_end, const int32_t group)
+{   // group: positions per group, a multiple of kBlock up to kPermGroupMax
+    __shared__ int32_t count[8], base[8];
+    const int32_t g0 = s_begin + (int32_t)blockIdx.x * group;
+    if (threadIdx.x < 8) count[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int kPer = kPermGroupMax / kBlock;
+    int32_t key[kPer], rank[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int32_t p = g0 + j * kBlock + (int32_t)threadIdx.x;
+        key[j] = (j * kBlock < group && p < s_end) ? 7 - min((int32_t)cls[p], 7) : -1; // bucket 0 = the costliest class
+        rank[j] = key[j] >= 0 ? atomicAdd(&count[key[j]], 1) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t acc = 0;
+        for (int b = 0; b < 8; ++b) {
+            base[b] = acc;
+            acc += count[b];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (key[j] >= 0) perm[g0 + base[key[j]] + rank[j]] = g0 + j * kBlock + (int32_t)threadIdx.x;
 }
 
 // ---------------------------------------------------------------- the window kernel (fp32, assume_short_ts)
@@ -2471,6 +2523,7 @@ struct trmc_plan {
     bool forcing_pending = false;
     bool state_missing = false;          // ... and there is no initial state yet: trmc_plan_chain_from must supply it
     // window kernel (k_mc_window): its schedule tables (per W, K, nsteps) and its counters
+    DevBuf tile_perm, cls_last;          // k_tile_perm: the row every thread of the next wide tile takes; the classes it is made from
     DevBuf win_tab, win_ctr;
     int32_t win_key[4] = {-1, -1, -1, -1};
     int32_t win_ndiag = 0, win_nwide = 0, win_ntail = 0, win_workers = 0;
@@ -2588,6 +2641,8 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.out = (T *)pl->out.p;
     a.row_of_pos = (const int32_t *)pl->row_of_pos.p;
     a.out_vec = sizeof(T) == 4 && nsteps % 4 == 0 && pl->run.wide_k % 4 == 0;
+    a.tile_perm = nullptr; // (route_advance_t switches the permutation on for its wide tiles)
+    a.cls_last = nullptr;
     return a;
 }
 
@@ -2989,9 +3044,26 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             // ended; the first has a start event of its own) and it is what the tail waits for.
             if (r.wide_next == 0) {
                 const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
+                // TRMC_TILE_PERM=<group>: rows dealt to the threads of every tile by the cost class they showed in the tile before,
+                // inside groups of <group> positions (k_tile_perm).  Off by default -- see the measurements there.
+                const char *perm_env = std::getenv("TRMC_TILE_PERM");
+                const int32_t perm_group = perm_env ? std::min(kPermGroupMax, std::max(0, std::atoi(perm_env)) / kBlock * kBlock) : 0;
+                const bool use_perm = perm_group > 0;
+                StepArgs<T> at = a;
+                if (use_perm) {
+                    const bool fresh = pl->cls_last.bytes < (size_t)pl->nseg_pad;
+                    if (int rc = pl->cls_last.ensure((size_t)pl->nseg_pad)) return rc;
+                    if (int rc = pl->tile_perm.ensure((size_t)pl->nseg_pad * sizeof(int32_t))) return rc;
+                    if (fresh) HIP_TRY(hipMemsetAsync(pl->cls_last.p, 0, (size_t)pl->nseg_pad, ws)); // (no history yet: one class)
+                    at.tile_perm = (const int32_t *)pl->tile_perm.p;
+                    at.cls_last = (uint8_t *)pl->cls_last.p;
+                }
                 HIP_TRY(hipEventRecord(pl->wide_t0[0], ws));
                 for (int32_t j = 0; j < ntile; ++j) {
-                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, tile_lds_pad(), ws, a, w0, w1, j, K);
+                    if (use_perm)
+                        hipLaunchKernelGGL(k_tile_perm, dim3((unsigned)((w1 - w0 + perm_group - 1) / perm_group)), dim3(kBlock), 0, ws,
+                                           (const uint8_t *)pl->cls_last.p, (int32_t *)pl->tile_perm.p, w0, w1, perm_group);
+                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, tile_lds_pad(), ws, at, w0, w1, j, K);
                     HIP_TRY(hipEventRecord(pl->wide_t1[(size_t)j], ws));
                     ++r.launches;
                 }
@@ -3926,7 +3998,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->win_tab, &pl->win_ctr})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->win_tab, &pl->win_ctr, &pl->tile_perm, &pl->cls_last})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);
