@@ -11,14 +11,18 @@ of the control flow, not a measurement).
 
 One "step" = one pass of the hot path over one batch of synthetic input: routing the
 whole seeded synthetic CONUS network (2 729 077 segments, 14 713 independent networks,
-troute_amd/synthetic.py) for one forcing window of 288 x 300 s timesteps with the
+troute_amd/synthetic.py) for one forcing window ("day") of 288 x 300 s timesteps with the
 reference's configured assume_short_ts=True (test/LowerColorado_TX/test_AnA.yaml:32),
-fp32 (the reference's arithmetic type), warm start from the state the day before leaves in HBM -- forcing and topology
-already resident in HBM when the timed region starts, results (incl. the gathered outlet hydrographs) left in HBM in the reference's
-[segment][timestep][q,v,d] layout.
+fp32 (the reference's arithmetic type).
 
-Three consecutive days: day N-1 spins the network up from a cold start, the plan is tuned on day N (untimed) and TIMED on
-day N+1 -- the next day's forcing of the same basin, started from the state day N leaves in HBM.
+What is timed (one GPU): a SEQUENCE of consecutive days with DISTINCT forcing -- day N-1 spins the network up from a cold
+start, the plan is tuned on day N (both untimed), the clock covers days N+1, N+2, ... (a ring of up to ten distinct days,
+each derived from the one before like the reference's own forcing files one day apart).  Inside the clock, per day: the
+forcing travels from page-locked host memory to the device (trmc_stage_forcing, on the copy stream, two days ahead), the
+state is handed from day to day in HBM (trmc_plan_chain_from, between a plan and its clone: one copy of the topology and
+parameter columns, two sets of window buffers), the window is routed, and its products -- outlet hydrographs and final
+state, SURVEY 8d's throughput mode -- are copied to page-locked host arrays.  Topology and parameters are resident.
+(N > 1: the ranks time day N+1 routed `steps` times from the state day N leaves, as in earlier rounds.)
 
 Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   roofline          dominant kernel against the 8 TB/s HBM roofline, timed with HIP events on the plan's own stream
@@ -26,8 +30,11 @@ Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   cpu_baseline      the reference Fortran kernel (oracle/_ref, amdflang -O2) over every segment, decomposed like the
                     reference's by-subnetwork-jit method, C + OpenMP, bounded sample of the timesteps
   untuned           the plan built from the topology alone, day N, cold start
-  value             INCLUDES the copy of what a throughput-mode caller consumes -- outlet hydrographs + final state -- to the
-                    host, made on a copy stream beside the next window;  value_resident: everything left in HBM
+  value             the sequence above: INCLUDES every day's forcing host-to-device and the copy of what a throughput-mode caller
+                    consumes -- outlet hydrographs + final state -- to the host;  value_resident: day N+1 routed
+                    again and again on the one plan, forcing resident, everything left in HBM (earlier rounds' protocol)
+  forcing_persistence   the same pipeline with days whose rows keep their magnitude with probability 0.5 / 0.0
+  parity_full       EVERY segment against the reference Fortran on the CPU (the pipeline re-run over days N+1, N+2)
   parity_mode       the whole flowveldepth array copied to the host inside the timed region
   tuned_window_warm / cold_start / independent_forcing_cold   the tuned plan on the very window it was tuned on, on a
                     cold start, on an unrelated day
@@ -83,6 +90,7 @@ def parse():
     ap.add_argument("--persistence", type=float, default=None,
                     help="share of the rows that keep their forcing magnitude from day to day in the timed sequence "
                          "(default: synthetic.forcing's 0.8; 0 = every day an independent draw)")
+    ap.add_argument("--no-persistence-sweep", action="store_true", help="skip the legs with less persistent forcing")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: one per CPU the cgroup grants, at most the physical cores)")
     return ap.parse_args()
@@ -527,7 +535,7 @@ def main():
 
     # ---- 3. the headline: day N+1 on the plan tuned on day N; every window's outlet hydrographs and final state arrive on
     # the host inside the clock (SURVEY 8d's throughput mode), copied beside the next window ---------------------------
-    seq = None
+    seq, persist = None, None
     if use_dist:
         head = timed(router, True, a.steps, a.warmup, d2h="state")
     else:
@@ -535,7 +543,7 @@ def main():
         # N+2, ... -- a ring of `ndays` distinct days in page-locked host memory, each derived from the one before like days
         # N-1 -> N -> N+1 were (synthetic.forcing) -- on the tuned plan and its clone.
         from troute_amd import _lib as _tl
-        ndays = max(2, min(int(os.environ.get("TRMC_BENCH_DAYS", "10")), a.steps + a.warmup))
+        ndays = max(2 if a.headline_only else 4, min(int(os.environ.get("TRMC_BENCH_DAYS", "10")), a.steps + a.warmup))
         t0 = time.perf_counter()
         ring, prev_day = [], qlat_a
         for i in range(ndays):
@@ -557,9 +565,39 @@ def main():
             seq = sequence_of_days(router.plan0, plan_b, ring, state_n, outlets_rs, a, a.steps, a.warmup)
         finally:
             os.environ.pop("TRMC_SETUP_ASIDE", None)
-        head = {"el": seq["el"], "ms_main": float(np.mean(seq["ms_main"])), "ms_total": float(np.mean(seq["ms_main"])),
+        # (ms_main of the sequence: the WALL time per day, every kernel, copy and hand-over of the pipeline in it -- the events
+        # around a single window also span what the neighbouring day's kernels take of the device while they overlap it)
+        head = {"el": seq["el"], "ms_main": seq["el"] / a.steps * 1e3, "ms_total": seq["el"] / a.steps * 1e3,
+                "ms_window_events": float(np.mean(seq["ms_main"])),
                 "launches": router.plan0.stats()["main_launches"], "stats": {"phase0": seq["last_plan"].stats()},
                 "hyd": seq["hyd"], "steps": a.steps}
+        # how much of this rests on the day-to-day persistence of the forcing: the same pipeline with half, and with none, of
+        # the rows keeping their magnitude from one day to the next (the plan stays the one tuned on day N)
+        persist = None
+        if not a.headline_only and not a.no_persistence_sweep:
+            persist = {}
+            for pv in (0.5, 0.0):
+                r2, prev_day = [], qlat_a
+                for i in range(4):
+                    day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 40 + i, previous=prev_day, persistence=pv)
+                    r2.append(ring[i])                # (the page-locked arrays of the headline's ring are reused)
+                    ring[i][...] = day
+                    prev_day = day
+                os.environ["TRMC_SETUP_ASIDE"] = "1"
+                try:
+                    s2 = sequence_of_days(router.plan0, plan_b, r2, state_n, outlets_rs, a, 4, 1)
+                finally:
+                    os.environ.pop("TRMC_SETUP_ASIDE", None)
+                persist[str(pv)] = {"ms_per_day": s2["el"] / 4 * 1e3,
+                                    "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / (s2["el"] / 4) / 1e9 / HBM_PEAK_GBS}
+            persist["what"] = ("the timed pipeline on the same tuned plan with days whose rows keep their forcing magnitude with "
+                               "probability 0.5 / 0.0 from one day to the next (the headline's days: synthetic.forcing's default, "
+                               "0.999 -- what the reference's own forcing files show one day apart)")
+            prev_day = qlat_a                          # the ring back to the headline's days (the parity pass below uses them)
+            for i in range(min(4, ndays)):
+                day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day, persistence=a.persistence)
+                ring[i][...] = day
+                prev_day = day
     hyd = head["hyd"]
     if hyd is None:                                 # (a rank other than 0 of a multi-GPU job does not fetch the outlet block)
         hyd = np.zeros((0, a.nsteps), np.float32)
@@ -775,6 +813,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity_full": parity,
+            "forcing_persistence": persist,
             "untuned": untuned,
             "full_ts": full,
             "per_rank": per_rank,
@@ -826,36 +865,58 @@ def sequence_of_days(plan_a, plan_b, days, state0, outlets_rs, a, steps, warmup)
     # last launch the gathers of its products and their copy to the host; behind its set-up the forcing of this plan's
     # NEXT day (two days ahead: the staging area is only read by a window's set-up).
     nofetch = bool(os.environ.get("TRMC_BENCH_NO_FETCH"))    # (experiment: what does the copy of the products cost?)
+    # The call that queues a window's copies to the host returns when the window has ended (hipMemcpyAsync device-to-host
+    # behind a pending dependence keeps its caller, csrc/trmc.hip trmc_fetch_begin).  TRMC_BENCH_FETCH_THREAD=1 makes it from
+    # a helper thread, so that the main thread queues the next day while this one runs -- measured: 16.2 ms per day either
+    # way (a day's narrow levels can only start when the day before has ended; queueing earlier does not end it earlier).
+    import concurrent.futures
+    aux = concurrent.futures.ThreadPoolExecutor(1) if os.environ.get("TRMC_BENCH_FETCH_THREAD", "0") == "1" else None
+    pending = [None, None]
+
+    def after_window(i, w):
+        """behind day w's window on plan i: its products to the host, then the forcing of the plan's next day (w + 2)"""
+        if not nofetch:
+            plans[i].fetch_begin(outlets_rs[i], True)
+        if w + 2 < total:
+            plans[i].stage_forcing(nsteps, days[(w + 2) % nd])
+
+    def settle(i):
+        if pending[i] is not None:
+            pending[i].result()
+            pending[i] = None
     queue(plan_a)
-    if not nofetch:
-        plan_a.fetch_begin(outlets_rs[0], True)
-    if total > 2:
-        plan_a.stage_forcing(nsteps, days[2 % nd])
+    if aux is not None:
+        pending[0] = aux.submit(after_window, 0, 0)
+    else:
+        after_window(0, 0)
     for w in range(1, total + 1):
         cur, prev = plans[w % 2], plans[(w - 1) % 2]
         if w < total:
             mark(f"[day{w}")
+            settle(w % 2)                                    # (this plan's last fetch and staging calls have returned)
             cur.chain_from(prev)                             # day w starts where day w - 1 ends: handed over in HBM
             mark("chained")
             queue(cur)
             mark("window")
-            if not nofetch:
-                cur.fetch_begin(outlets_rs[w % 2], True)
-            mark("fetchq")
-            if w + 2 < total:
-                cur.stage_forcing(nsteps, days[(w + 2) % nd])
+            if aux is not None:
+                pending[w % 2] = aux.submit(after_window, w % 2, w)
+            else:
+                after_window(w % 2, w)
             mark(f"queued{w}]")
         st = prev.route_end()                                # day w - 1 is through
         ends.append(_t.perf_counter())
         mark(f"ended{w - 1}({st['ms_main']:.1f})")
         if w - 1 >= warmup:
             ms_main.append(st["ms_main"])
+        settle((w - 1) % 2)
         got = prev.fetch_wait() if not nofetch else (np.zeros((1, 1), np.float32), None)   # ... and its products are on the host
         mark(f"fetched{w - 1}")
         if w == warmup and warmup > 0:                       # the clock starts when the last warm-up day is through
             t0 = _t.perf_counter()
     X.device_synchronize(0)
     el = _t.perf_counter() - t0
+    if aux is not None:
+        aux.shutdown()
     if dbg is not None:
         print("[sequence] host timeline ms: " + " ".join(dbg), file=sys.stderr)
     day_ms = [round((b - a_) * 1e3, 2) for a_, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
