@@ -1048,8 +1048,11 @@ def pmc_counters(pattern, launches_per_window, args):
     only, as MI355X_MICROARCH.md prescribes: FETCH_SIZE; WRITE_SIZE; the SQ instruction / cycle counters) over a child run of
     this script that stops after one headline window (--headline-only), read per dispatch for the LAST window's launches of
     the kernel -- the timed configuration, not an average over tuning and warm-up windows.
-      traffic  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half of the streamed
-               reads; units of KB)
+      traffic  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (units of KB; gfx950: FETCH_SIZE counts half of
+               the streamed reads).  Both factors are CALIBRATED for this path's access patterns on this part
+               (tools/traffic_calib.hip / .sh, profiles/r04_traffic_calibration.json: kernels that move a known 2 GiB --
+               4-byte-per-lane unit-stride reads 2 048 bytes per FETCH_SIZE unit, the same as the guide's 16-byte pattern;
+               4-byte-per-lane stores 1 024 bytes per WRITE_SIZE unit; the 96-byte runs of out[row][step][q,v,d] 966)
       valu     instructions_per_wave_step (SQ_INSTS_VALU / SQ_WAVES / timesteps a launch routes), cycles_per_instruction
                (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU: the counter is in quad-cycles), busy_frac (VALU-active cycles per
                SIMD over the busy cycles of a shader engine: 4 x SQ_ACTIVE_INST_VALU / nSIMD  /  SQ_BUSY_CYCLES / nSE)
@@ -1100,11 +1103,11 @@ def pmc_counters(pattern, launches_per_window, args):
                     vals[name] = total / len(last)                    # per launch, summed over the hardware instances
                     vals[name + "#inst"] = ninst / len(last)          # hardware instances that report the counter
                 vals["avg_us_" + str(i)] = sum(x[2] for x in last) / len(last) / 1e3
-                # ... and every kernel of the last window (it starts with its k_init_state launch), summed
+                # ... and every kernel of the last window, summed
                 alld = con.execute(
                     "select d.event_id, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
                     "on d.kernel_id = s.id order by d.start").fetchall()
-                first = max(j for j, x in enumerate(alld) if "k_init_state" in x[1])
+                first = max(j for j, x in enumerate(alld) if "k_prep_qlat" in x[1])   # (a window starts with its forcing transpose)
                 wev = [x[0] for x in alld[first:]]
                 for lo in range(0, len(wev), 500):
                     part = wev[lo:lo + 500]

@@ -19,7 +19,8 @@ for path in [p for p in sys.argv[1:] if p != "--json"]:
     con = sqlite3.connect(path)
     rows = con.execute("select d.id, d.event_id, s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d join "
                        "rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
-    starts = [i for i, r in enumerate(rows) if "k_init_state" in r[2] or "k_flow_init" in r[2]]
+    # a window starts with its forcing transpose (windows of a sequence handed on in HBM have no k_init_state)
+    starts = [i for i, r in enumerate(rows) if "k_prep_qlat" in r[2]] or [i for i, r in enumerate(rows) if "k_init_state" in r[2] or "k_flow_init" in r[2]]
     win = rows[starts[-1]:] if starts else rows
     pm = {}
     for ev, name, val, n in con.execute("select e.event_id, p.name, sum(e.value), count(*) from rocpd_pmc_event e join rocpd_info_pmc p "

@@ -9,8 +9,8 @@ export TMPDIR=/tmp
 tag=${1:-r}
 out=gpurun_out/$tag
 mkdir -p "$out"
-lean="--headline-only --no-traffic --no-parity-sample"
-timeout 900 rocprofv3 --kernel-trace -d "$out/trace" -o trace -- python bench.py --steps 3 --warmup 1 $lean > "$out/trace.log" 2>&1
+lean="--headline-only --no-traffic --no-parity-full"
+timeout 900 rocprofv3 --kernel-trace -d "$out/trace" -o trace -- python bench.py --steps 4 --warmup 1 $lean > "$out/trace.log" 2>&1
 sets=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES")
 i=0
 for c in "${sets[@]}"; do

@@ -19,11 +19,27 @@ def short(n):
 
 
 rows = [(short(n), s, e, q, st) for n, s, e, q, st in rows]
-starts = [i for i, r in enumerate(rows) if r[0] == "k_init_state"]
+# a window starts with its forcing transpose (the windows of a sequence handed on in HBM have no k_init_state); in such a
+# sequence the next-to-last window is the one shown, between its transpose and the last window's
+starts = [i for i, r in enumerate(rows) if r[0] == "k_prep_qlat"] or [i for i, r in enumerate(rows) if r[0] == "k_init_state"]
 if not starts:
     sys.exit("no window found")
 i0 = starts[-1]
 win = rows[i0:]
+if len(starts) >= 2 and not any(r[0] == "k_init_state" for r in win):
+    # The last window of a pipelined sequence (two plans taking turns) is followed by nothing: the one before it shows the
+    # steady state.  Its launches are those on ITS plan's streams from its transpose on: the tile stream of the tiles that
+    # follow the transpose, the stream of the last tail / transposing launch before the next window's transpose (the other
+    # plan's trailing launches come first in that interval).
+    i0, i1 = starts[-2], starts[-1]
+    inter = rows[i0:i1]
+    mine = set()
+    for kind in ("k_mc_tile", "k_mc_step", "k_emit", "k_prep_qlat"):
+        on = [r[4] for r in inter if r[0] == kind]
+        if on:
+            mine.add((kind, on[-1]))
+    win = [r for r in rows[i0:] if (r[0], r[4]) in mine]
+    print("(pipelined sequence: the next-to-last window, by its plan's streams)")
 t0 = win[0][1]
 print(f"last window: {len(win)} dispatches, span {(max(r[2] for r in win) - t0) / 1e6:.3f} ms")
 by = {}
