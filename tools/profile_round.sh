@@ -20,8 +20,8 @@ done
 tdb=$(find "$out/trace" -name '*.db' | head -1)
 sum=gpurun_out/${tag}_rocprofv3_summary.txt
 {
-  echo "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --headline-only   (every kernel of the process: the untuned plan's"
-  echo "# windows, the tuning window, the spin-up of the tuned plan, then warm-up + 3 timed windows of the headline)"
+  echo "# rocprofv3 --kernel-trace -- python bench.py --steps 4 --warmup 1 --headline-only   (every kernel of the process: the untuned plan's"
+  echo "# windows, the tuning window, the spin-up of the tuned plan, then the timed sequence of days on the plan and its clone)"
   python tools/rocpd_summary.py "$tdb" | cut -c1-170
   echo
   echo "# the last window of that trace (a timed headline window)"
