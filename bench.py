@@ -227,7 +227,7 @@ def _diffusive_inputs(gold, nsteps):
     return ins
 
 
-def _diffusive_call(gold, nsteps, path, sym):
+def _diffusive_call(gold, nsteps, path, sym, prepare_only=False):
     """c_diffnw's argument list on a host library (the reference build or the host restatement): (seconds, outputs)."""
     import ctypes as C
     from troute_amd.routing.fast_reach import diffusive as D
@@ -249,8 +249,11 @@ def _diffusive_call(gold, nsteps, path, sym):
     shape = (nsteps + 1, int(ins["mxncomp_g"]), int(ins["nrch_g"]))
     outs = [np.zeros(shape, dtype=np.float64, order="F") for _ in range(3)]
     args += [o.ctypes.data_as(C.c_void_p) for o in outs]
+    fn = getattr(lib, sym)
+    if prepare_only:                      # (the arguments marshalled, the call left to the caller: a pool of threads times many)
+        return lambda: fn(*args), (keep, outs)
     t0 = time.perf_counter()
-    getattr(lib, sym)(*args)
+    fn(*args)
     return time.perf_counter() - t0, [np.ascontiguousarray(o) for o in outs]
 
 
@@ -282,6 +285,25 @@ def diffusive_leg(nsteps=12):
     if os.path.exists(host):
         out["host_restatement_s"], h = _diffusive_call(gold, nsteps, host, "dw_oracle_diffnw")
         out["gpu_bit_identical_to_host_restatement"] = bool(all(np.array_equal(np.asarray(g), np.asarray(w)) for g, w in zip(got, h)))
+        # What the device is FOR in this solver is many tailwater domains at once (one compute unit each); a single domain is
+        # a chain of dependent fp64 steps that one CPU core walks faster.  So the batch is priced against the same 64 domains
+        # on the host's granted cores: the host restatement (the faster of the two CPU forms) from a pool of threads, one
+        # domain per call (ctypes releases the interpreter lock for the duration of a call).
+        try:
+            import concurrent.futures
+            quota = cpu_quota()
+            cores = max(1, min(os.cpu_count() or 1, int(quota + 0.5) if quota else (os.cpu_count() or 1)))
+            calls = [_diffusive_call(gold, nsteps, host, "dw_oracle_diffnw", prepare_only=True) for _ in range(nb)]
+            with concurrent.futures.ThreadPoolExecutor(cores) as ex:
+                t0 = time.perf_counter()
+                list(ex.map(lambda c: c[0](), calls))
+                cpu_batch = time.perf_counter() - t0
+            out["batch"].update({"host_restatement_s": cpu_batch, "host_cores": cores,
+                                 "gpu_over_host": cpu_batch / out["batch"]["gpu_s"],
+                                 "what": f"{nb} tailwater domains in one launch on the device against the same {nb} domains, one call each, on "
+                                         f"{cores} host threads (the host restatement of the same solver)"})
+        except Exception as e:
+            out["batch"]["host_error"] = repr(e)
     ref = os.path.join(ROOT, "oracle", "_ref", "libdiff_ref.so")
     if os.path.exists(ref):
         # in a child process: the Fortran runtime prints its progress to stdout and flushes it at exit
