@@ -385,7 +385,8 @@ template <class T> struct StepArgs {
     // kPermGroup, rebuilt before every tile from the cost class every row showed at the end of the tile before (k_tile_perm):
     // wavefronts hold rows of one class whatever the forcing does and however old the plan's cost hint is.
     const int32_t *tile_perm;
-    uint8_t *cls_last; // cost class of every row at the last step it was routed in a tile: min(iterations, 3) + 4 if over bank
+    uint8_t *cls_last;
+    bool tail_direct; // k_mc_step<SHORT>: (q, v, d) of the step straight into out[row][step - 1][.] (no velocity plane, no k_emit for them) // cost class of every row at the last step it was routed in a tile: min(iterations, 3) + 4 if over bank
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -514,6 +515,12 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 a.q_tm[row_c + s] = outflow;
                 a.v_tm[row_c + s] = T(0);
                 a.d_tm[row_c + s] = H;
+                if (SHORT && a.tail_direct) {
+                    T *o = a.out + ((size_t)a.row_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1)) * 3;
+                    o[0] = outflow;
+                    o[1] = T(0);
+                    o[2] = H;
+                }
                 a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
                 if (t == a.nsteps) a.it_prev[s] = 0;
                 return;
@@ -550,8 +557,15 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         }
         asm volatile("" : "+v"(ob));
         at(a.q_tm + row_c, ob) = q_new;
-        at(a.v_tm + row_c, ob) = r.velc;
         at(a.d_tm + row_c, ob) = r.depthc;
+        if (SHORT && a.tail_direct) { // 12 bytes per row and step; the neighbouring steps of a row meet in the L2 / Infinity Cache
+            T *o = a.out + ((size_t)a.row_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1)) * 3;
+            o[0] = q_new;
+            o[1] = r.velc;
+            o[2] = r.depthc;
+        } else {
+            at(a.v_tm + row_c, ob) = r.velc;
+        }
         // (only trmc_download_iterations reads it, after the window: one byte-masked store per row and step would be
         // 3 % of the launch)
         if (t == a.nsteps) a.it_prev[su] = (uint8_t)min(r.iters, 255);
@@ -2433,6 +2447,7 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     bool tail_active = false;     // the tail launches of this window go to the tail stream
     bool end_queued = false;      // route_end_queue has run for this window
     // the whole window as ONE persistent launch (k_mc_window): chosen by route_begin_t, launched by the advance that covers it
+    bool tail_direct = false;     // the tail's launches write their rows' results into the caller's layout themselves (no k_emit)
     bool win = false, win_ran = false;
     int32_t win_W = 0, win_K = 0;
 };
@@ -2643,6 +2658,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.out_vec = sizeof(T) == 4 && nsteps % 4 == 0 && pl->run.wide_k % 4 == 0;
     a.tile_perm = nullptr; // (route_advance_t switches the permutation on for its wide tiles)
     a.cls_last = nullptr;
+    a.tail_direct = false;
     return a;
 }
 
@@ -2675,7 +2691,7 @@ template <class T> int emit_tiles_through(trmc_plan *pl, int32_t t_complete) // 
     const int32_t ntiles = (nsteps + kTile - 1) / kTile;
     const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
     const T *q_tm = (const T *)pl->tm.p;
-    if (r.win_ran) r.tiles_done = ntiles; // (the window kernel wrote every row's result in the caller's layout itself)
+    if (r.win_ran || r.tail_direct) r.tiles_done = ntiles; // (every row's result has been written in the caller's layout already)
     while (r.tiles_done < ntiles && ((r.tiles_done + 1) * kTile <= t_complete || t_complete >= nsteps)) {
         // (with wide tiles: the tail, on the plan's stream, trails them -- its progress is everybody's; without a tail the
         // tile stream's is)
@@ -3036,6 +3052,15 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             const bool tail = s1 > w1;
             hipStream_t ws = pl->wstream;
             r.tail_active = tail;
+            // TRMC_TAIL_DIRECT=1 (measurement knob): the tail's step launches write (q, v, d) straight into out[row][step][.]
+            // -- 12 bytes per row and step -- instead of a velocity plane and the transposing pass behind them.  Measured on
+            // the CONUS sequence: 18.1-18.2 ms per day against 16.2-16.3 with the pass: 764 k twelve-byte fragments per step
+            // at a 3 456-byte stride cost more than the 5 GB the transposing pass moves; off.
+            if (t0 == 0) {
+                const char *td = std::getenv("TRMC_TAIL_DIRECT");
+                r.tail_direct = td && td[0] == '1' && tp.nboundary == 0 && pl->maxlag == 0;
+            }
+            a.tail_direct = r.tail_direct;
             // Every tile of the window is queued at once, at the window's first call: the wide path needs all boundary
             // hydrographs up front (route_begin_t), so a tile depends on nothing but the tile before it.  (Queued one by one
             // as the tail came to need them, the last tiles of a window were late -- the host runs only a little ahead of the
