@@ -294,7 +294,13 @@ def diffusive_leg(nsteps=12):
             quota = cpu_quota()
             cores = max(1, min(os.cpu_count() or 1, int(quota + 0.5) if quota else (os.cpu_count() or 1)))
             calls = [_diffusive_call(gold, nsteps, host, "dw_oracle_diffnw", prepare_only=True) for _ in range(nb)]
-            with concurrent.futures.ThreadPoolExecutor(cores) as ex:
+            def unbind():   # (OMP_PROC_BIND has pinned this process's initial thread to one core: the pool's threads inherit that)
+                try:
+                    os.sched_setaffinity(0, range(os.cpu_count() or 1))
+                except Exception:
+                    pass
+            with concurrent.futures.ThreadPoolExecutor(cores, initializer=unbind) as ex:
+                list(ex.map(lambda c: None, range(cores)))      # (threads started before the clock)
                 t0 = time.perf_counter()
                 list(ex.map(lambda c: c[0](), calls))
                 cpu_batch = time.perf_counter() - t0
