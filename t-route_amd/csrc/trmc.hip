@@ -4136,6 +4136,9 @@ int trmc_stage_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq)
     const bool busy = pl->run.active;
     if (busy && pl->run.t_done < pl->run.nsteps + (pl->run.short_ts ? pl->maxlag : 0))
         return fail(TRMC_ESTATE, "the window in progress has not been queued to its end (trmc_route_advance)");
+    if (busy && (pl->ngage > 0 || pl->nres > 0))
+        return fail(TRMC_ESTATE, "a window with nudging tables or reservoirs is in progress: its series are read after trmc_route_end; "
+                                 "stage the next forcing then");
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
     if (pl->nseg > 0 && !qlat) return fail(TRMC_EINVAL, "qlat is NULL");
