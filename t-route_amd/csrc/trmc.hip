@@ -759,7 +759,8 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 // (topology.hpp), and is worth nothing when the forcing changes: with half of the rows' inflow drawn anew from day to day
 // the tuned plan ran the CONUS day in 20.6 ms, the untuned one in 20.2, against 16.4 on the day it was tuned for.
 // A group is a workgroup here; order inside a class is whatever the atomics give (results do not depend on it).
-// MEASURED (CONUS sequence of bench.py, ms per day; TRMC_TILE_PERM=<group>) and therefore OFF by default: on the plan
+// MEASURED (CONUS sequence of bench.py, ms per day; TRMC_TILE_PERM=<group>, 0 = off): ON with groups of 256 for plans built
+// with a cost hint (16.0-16.1 against 16.3-16.4, three runs each), OFF for plans without one: on the plan
 // built from the topology alone 20.2 without, 20.7 / 21.7 / 22.4 with groups of 256 / 512 / 1024; on the tuned plan with
 // half of the rows' inflow redrawn every day 20.6 without, 20.9 with groups of 256; on the tuned plan and its own kind of
 // days 16.0-16.7 either way.  Dealing rows out by class takes a wavefront's 64 rows from 8-27 cache lines of every column
@@ -3070,9 +3071,13 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             if (r.wide_next == 0) {
                 const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
                 // TRMC_TILE_PERM=<group>: rows dealt to the threads of every tile by the cost class they showed in the tile before,
-                // inside groups of <group> positions (k_tile_perm).  Off by default -- see the measurements there.
+                // inside groups of <group> positions (k_tile_perm; 0 = off) -- see the measurements there.
                 const char *perm_env = std::getenv("TRMC_TILE_PERM");
-                const int32_t perm_group = perm_env ? std::min(kPermGroupMax, std::max(0, std::atoi(perm_env)) / kBlock * kBlock) : 0;
+                // (default: groups of 256 on a plan built with a cost hint -- there the re-dealing repairs what is left of mixed
+                // wavefronts at the class boundaries and where rows have drifted since the hint was taken: 16.0-16.1 against
+                // 16.3-16.4 ms per day, three runs each -- and off on a plan without one, where it costs more than it saves)
+                const int32_t perm_group = perm_env ? std::min(kPermGroupMax, std::max(0, std::atoi(perm_env)) / kBlock * kBlock)
+                                                    : (pl->hinted ? 256 : 0);
                 const bool use_perm = perm_group > 0;
                 StepArgs<T> at = a;
                 if (use_perm) {

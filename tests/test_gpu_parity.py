@@ -270,6 +270,7 @@ def set_engine(monkeypatch, engine):
     if engine.endswith("-wide"):
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
         monkeypatch.setenv("TRMC_WIDE_K", "8")        # (a multiple of 4: the 16-byte result stores where nsteps allows them)
+        monkeypatch.setenv("TRMC_TILE_PERM", "512")   # (rows re-dealt to a tile's threads by class, also on plans without a hint)
     else:
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
     if engine.endswith("-window"):
