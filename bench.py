@@ -827,7 +827,10 @@ def main():
                 "workload": "synthetic CONUS NHDPlus-shaped network, MC-only, 24 h @ 300 s dt (configs[2])",
                 "segments": int(nseg), "networks": int(len(net["net_sizes"])), "timesteps": a.nsteps,
                 "qts_subdivisions": a.qts, "assume_short_ts": True,
-                "timed_window": "day N+1 of three consecutive days of the same basin (N-1 spin-up from cold, N tuning, N+1 timed), warm start from the state day N leaves in HBM",
+                "timed_window": ("a sequence of consecutive days with distinct forcing after day N-1 (spin-up from cold) and day N (tuning): forcing "
+                                 "host-to-device, state handed on in HBM, outlet hydrographs + final state to the host, all inside the clock, "
+                                 "on a plan and its clone") if seq is not None else
+                                "day N+1 of three consecutive days of the same basin (N-1 spin-up from cold, N tuning, N+1 timed), warm start from the state day N leaves in HBM",
                 "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
                 "transport": None if comm is None else comm.backend,
@@ -835,6 +838,7 @@ def main():
                 "rank_ms_before_each_rebalance": tuned.get("feedback_ms"),
                 "engine": engine,
                 "generate_s": round(t_gen, 2), "plan_s": round(t_plan, 2),
+                "days_in_the_ring": None if seq is None else ndays, "days_made_s": None if seq is None else round(t_days, 2),
                 "plan_order": "rows grouped by their secant-iteration cost over day N (untimed tuning window); timed on day N+1"
                 if not a.no_retune else "topological only", "tune_s": round(t_tune, 2),
             },
