@@ -113,6 +113,19 @@ def cpu_quota():
         return None
 
 
+def usable_threads():
+    """One thread per CPU the cgroup grants, never more than the physical cores.  Given to the checker legs EXPLICITLY:
+    torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks, and an OpenMP checker left to that default takes sixteen
+    times as long on rank 0 while the other ranks wait for it."""
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        physical = os.cpu_count() or 1
+    quota = cpu_quota()
+    return physical if quota is None else max(1, min(physical, int(quota + 0.5)))
+
+
 def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     """The reference's CPU path on this host's cores, over EVERY segment of the workload.
 
@@ -183,7 +196,7 @@ def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0, pla
     to, params = net["to"], net["params"]
     nseg = to.shape[0]
     t0 = time.perf_counter()
-    ref = O.reference_windows(to, params, days, q0, nsteps, qts, True, nthreads=threads)
+    ref = O.reference_windows(to, params, days, q0, nsteps, qts, True, nthreads=threads or usable_threads())
     u32 = lambda x: np.ascontiguousarray(x).view(np.uint32)   # noqa: E731
     base = {"segments": int(nseg), "networks": int((to < 0).sum()), "windows": len(days), "timesteps": int(nsteps),
             "checker": ("reference Fortran kernel (oracle/_ref/libmc_ref_qj0_f32.so, canonical Qj_0), " if ref["kind"] == "reference"
@@ -642,25 +655,24 @@ def main():
             comm.close()
         return
     parity = None
-    if rank == 0 and not a.no_parity_full and a.precision == 32:
+    # (a multi-rank job: the checker runs on rank 0 alone and takes a minute or two -- AFTER the last leg the ranks take
+    # together, below; the other ranks would give up at a barrier in the meantime)
+    dist_outlets = (np.array(router._out_rows, copy=True), hyd) if use_dist and rank == 0 else None
+    if rank == 0 and not a.no_parity_full and a.precision == 32 and not use_dist:
         try:      # against the reference on the CPU (checker use, outside the clock)
-            if use_dist:   # the job's product: the all-gathered outlet block of the last timed window
-                parity = parity_full(net, None, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts,
-                                     outlets=(router._out_rows, hyd), threads=a.cpu_threads)
-            else:
-                # the timed pipeline once more, untimed, over the first two days of the ring (days N+1 and N+2 from the state
-                # after day N: plan and clone, staged forcing, state handed over on the device, asynchronous fetch), and the
-                # reference on the CPU through ALL the days from the cold start: N-1, N, N+1, N+2
-                os.environ["TRMC_SETUP_ASIDE"] = "1"
-                try:
-                    chk = sequence_of_days(router.plan0, plan_b, ring[:2], state_n, outlets_rs, a, 2, 0)
-                finally:
-                    os.environ.pop("TRMC_SETUP_ASIDE", None)
-                parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
-                                     outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
-                                     final_fetched=chk["final"])
-                parity["pipeline"] = ("the timed pass's pipeline (plan + clone, forcing staged from page-locked memory, state handed "
-                                      "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
+            # the timed pipeline once more, untimed, over the first two days of the ring (days N+1 and N+2 from the state
+            # after day N: plan and clone, staged forcing, state handed over on the device, asynchronous fetch), and the
+            # reference on the CPU through ALL the days from the cold start: N-1, N, N+1, N+2
+            os.environ["TRMC_SETUP_ASIDE"] = "1"
+            try:
+                chk = sequence_of_days(router.plan0, plan_b, ring[:2], state_n, outlets_rs, a, 2, 0)
+            finally:
+                os.environ.pop("TRMC_SETUP_ASIDE", None)
+            parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
+                                 outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
+                                 final_fetched=chk["final"])
+            parity["pipeline"] = ("the timed pass's pipeline (plan + clone, forcing staged from page-locked memory, state handed "
+                                  "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
         except Exception as e:
             parity = {"error": repr(e)}
     if not use_dist:
@@ -734,6 +746,19 @@ def main():
                 "launches": f["launches"], "ms_main": f["ms_main"], "roofline_frac": frac(f),
                 "engine": getattr(rf.plan0, "engine", "levels"), "window": "day N+1 forcing, cold start"}
         rf.close()
+
+    transport = None
+    if comm is not None:      # the last thing the ranks do together: what follows is rank 0's alone (checker, counter passes)
+        transport = comm.backend
+        comm.barrier()
+        comm.close()
+        comm = None
+    if dist_outlets is not None and not a.no_parity_full and a.precision == 32:
+        try:      # the job's product -- the all-gathered outlet block of the last timed window -- against the reference on the CPU
+            parity = parity_full(net, None, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts, outlets=dist_outlets,
+                                 threads=a.cpu_threads)
+        except Exception as e:
+            parity = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -833,7 +858,7 @@ def main():
                                 "day N+1 of three consecutive days of the same basin (N-1 spin-up from cold, N tuning, N+1 timed), warm start from the state day N leaves in HBM",
                 "segment_levels": int(info["nlevels"]), "reach_depth": int(net["reach_depth"]),
                 "sharding": "independent networks + dominant basin cut at tributary mouths" if world > 1 else "none",
-                "transport": None if comm is None else comm.backend,
+                "transport": transport,
                 "rank_pace_on_tuning_day": None if tuned["speed"] is None else [round(float(x), 3) for x in tuned["speed"]],
                 "rank_ms_before_each_rebalance": tuned.get("feedback_ms"),
                 "engine": engine,
@@ -855,9 +880,6 @@ def main():
         line.update(extra)
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
-    if comm is not None:
-        comm.barrier()
-        comm.close()
 
 
 def sequence_of_days(plan_a, plan_b, days, state0, outlets_rs, a, steps, warmup):
