@@ -105,14 +105,36 @@ def main():
         for short in (True, False):
             want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params, q0, qlat, short, det=True)[:, 1:, :]
             fin = np.isfinite(want).all(axis=(1, 2))
-            for engine in ("levels", "flow"):
-                with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=short, engine=engine) as plan:
-                    got = plan.route(nsteps, qts, short, qlat, q0)
-                    it = plan.download_iterations()
-                # the same window on the plan ordered by the measured cost of every row
-                with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=short, engine=engine,
-                                 cost_hint=np.minimum(it, 3)) as plan:
-                    got2 = plan.route(nsteps, qts, short, qlat, q0)
+            # (label, engine, settings for the run): the level engine's one-step launches, the dataflow engine, and -- short
+            # timesteps only -- the wide levels K steps per launch (k_mc_tile; on the cost-ordered plan with the rows below
+            # them sorted by cost across levels and k_tile_perm dealing rows to threads by class) and the window as one
+            # persistent launch (k_mc_window), both with thresholds small enough for these networks to take them
+            variants = [("levels", "levels", {"TRMC_WIDE_MIN_ROWS": "0"}), ("flow", "flow", {})]
+            if short:
+                variants.append(("levels-wide", "levels", {"TRMC_WIDE_MIN_ROWS": "32", "TRMC_WIDE_K": str(int(rng.choice([3, 4, 8, 16]))),
+                                                           "TRMC_WIDE_LEVELS": str(int(rng.choice([2, 5, 16]))),
+                                                           "TRMC_TILE_PERM": str(int(rng.choice([0, 256, 512, 1024])))}))
+                variants.append(("levels-window", "levels", {"TRMC_WINDOW": "1", "TRMC_WIN_MIN_ROWS": "32",
+                                                             "TRMC_WIN_K": str(int(rng.choice([2, 4, 8]))),
+                                                             "TRMC_WIN_LEVELS": str(int(rng.choice([3, 8, 24])))}))
+            for label, engine, env in variants:
+                saved = {k: os.environ.get(k) for k in env}
+                os.environ.update(env)
+                try:
+                    with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=short, engine=engine) as plan:
+                        got = plan.route(nsteps, qts, short, qlat, q0)
+                        it = plan.download_iterations()
+                    # the same window on the plan ordered by the measured cost of every row
+                    with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=short, engine=engine,
+                                     cost_hint=np.minimum(it, 3)) as plan:
+                        got2 = plan.route(nsteps, qts, short, qlat, q0)
+                finally:
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+                engine = label
                 ok = np.array_equal(bits(got[fin]), bits(want[fin])) and \
                     np.array_equal(np.isfinite(got).all(axis=(1, 2)), fin) and \
                     np.array_equal(bits(got2[fin]), bits(want[fin]))
@@ -126,8 +148,8 @@ def main():
         print(f"seed {seed:4d} {regime:10s} nseg {nseg:6d} steps {nsteps:2d} qts {qts} finite {fin.mean():.4f} "
               f"differing runs so far {bad_rounds}", flush=True)
         seed += 1
-    print(f"fuzz_parity: {rounds} rounds, {total} finite segment-steps compared (2 engines x 2 modes x plain and "
-          f"cost-ordered plan), {bad_rounds} differing runs")
+    print(f"fuzz_parity: {rounds} rounds, {total} finite segment-steps compared (one-step launches, dataflow engine, wide tiles and the "
+          f"window kernel x both modes where they apply x plain and cost-ordered plan), {bad_rounds} differing runs")
     sys.exit(1 if bad_rounds else 0)
 
 
