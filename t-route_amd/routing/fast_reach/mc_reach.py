@@ -36,13 +36,64 @@ def binary_find(arr, els):
     return idx_c.tolist()
 
 
+class RetunePolicy:
+    """When the row order of a tuned plan is worth taking again.
+
+    The order groups rows by the secant-iteration cost they showed in ONE window; it serves for as long as the rows keep
+    their classes -- day after day of an ordinary sequence -- and is worth nothing once half of them have changed (then a
+    window costs what it costs on the untuned plan, a quarter more).  The cache therefore watches the
+    device time of every window on the tuned plan: ``patience`` consecutive windows slower than ``slow_ratio`` x the fastest
+    one seen on this order ask for a re-tune -- the next window collects costs again, the call after it rebuilds the plan
+    from them (1.6 s on the host for CONUS).  A re-tune that does not bring the time back (a forcing whose classes do not
+    persist from window to window cannot be tuned for) makes the new, slower time the yardstick, so the next request needs
+    another ``slow_ratio`` on top of it, and doubles the number of windows to sit out before one may be made at all.
+    Pure bookkeeping: results never depend on the order.  ``TRMC_RETUNE=0`` switches it off."""
+
+    def __init__(self, slow_ratio=1.12, patience=2, first_hold=8, max_hold=1024, min_gap_ms=0.5):
+        self.slow_ratio, self.patience, self.first_hold, self.max_hold = slow_ratio, patience, first_hold, max_hold
+        self.min_gap_ms = min_gap_ms  # ... and slower by at least this much (the windows of a small network are all launch latency)
+        self.best = None          # fastest window on the current order, ms
+        self.slow = 0             # consecutive slow windows
+        self.hold = 0             # windows to sit out before the next request
+        self.next_hold = first_hold
+        self.before = None        # the window time that made the last request
+        self.retunes = 0
+
+    def window(self, ms):
+        """``ms``: device time of the window just routed on the tuned order.  True: collect costs in the next window."""
+        if not (ms > 0):
+            return False
+        if self.best is None or ms < self.best:
+            self.best = ms
+        if self.hold > 0:
+            self.hold -= 1
+            self.slow = 0
+            return False
+        self.slow = self.slow + 1 if ms > self.slow_ratio * self.best and ms - self.best >= self.min_gap_ms else 0
+        if self.slow < self.patience:
+            return False
+        self.slow, self.before = 0, ms
+        return True
+
+    def rebuilt(self, ms):
+        """``ms``: the first window on the order a re-tune produced."""
+        self.retunes += 1
+        if self.before is not None and ms > 0.95 * self.before:    # it did not help
+            self.hold, self.next_hold = self.next_hold, min(2 * self.next_hold, self.max_hold)
+        else:
+            self.next_hold = self.first_hold
+        self.best, self.before = (ms if ms > 0 else None), None
+
+
 class _PlanCache:
     """Plans of the networks this process has routed, by content (``nwm_route`` calls the kernel callable once per loop
     with the same network: topology, order and device copies of the parameters are built once instead of per call).
     The first window of a short-timestep fp32 network is routed on a plan built from the topology alone while its
-    secant-iteration costs are collected; the second call rebuilds the plan ONCE with those costs as the row-order hint
-    (results do not depend on the order), and later calls reuse it.  ``TRMC_PLAN_CACHE=<n>`` sets the number of plans
-    kept (default 2; 0: a fresh plan per call, as the reference's callable is stateless)."""
+    secant-iteration costs are collected; the second call rebuilds the plan with those costs as the row-order hint
+    (results do not depend on the order), and later calls reuse it -- until its windows have become slower than they were
+    (RetunePolicy: the forcing has moved on), when costs are collected and the plan is rebuilt again.
+    ``TRMC_PLAN_CACHE=<n>`` sets the number of plans kept (default 2; 0: a fresh plan per call, as the reference's callable
+    is stateless)."""
 
     def __init__(self):
         import collections
@@ -90,15 +141,16 @@ class _PlanCache:
                 key = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine)
                 e = self._d.pop(key, None)
                 tune = short_ts and precision == 32
+                retune = tune and os.environ.get("TRMC_RETUNE", "1") != "0"
                 if e is None:
-                    e = {"plan": build(), "stage": 0 if tune else 2}
+                    e = {"plan": build(), "stage": 0 if tune else 2, "policy": RetunePolicy() if retune else None, "fresh": 0}
                     if tune:
                         e["plan"].collect_cost(True)
-                elif e["stage"] == 1:                          # costs of the first window -> the tuned plan, once
+                elif e["stage"] == 1:                          # costs of the window before -> the tuned plan
                     cost, n = e["plan"].download_cost()
                     hint = np.minimum((cost.astype(np.int64) * 16 + n - 1) // max(n, 1), 255).astype(np.uint8)
                     e["plan"].close()
-                    e = {"plan": build(hint), "stage": 2}
+                    e = {"plan": build(hint), "stage": 2, "policy": e.get("policy"), "fresh": e.get("fresh", 0)}
                 ok = False
                 try:
                     yield e["plan"]
@@ -107,6 +159,19 @@ class _PlanCache:
                     if ok:
                         if e["stage"] == 0:
                             e["stage"] = 1
+                        elif e["stage"] == 2 and e.get("policy") is not None:
+                            try:
+                                ms = float(e["plan"].stats()["ms_main"])
+                            except Exception:
+                                ms = 0.0
+                            pol = e["policy"]
+                            if e.get("fresh"):                 # a re-tuned order is judged by its SECOND window (the first
+                                e["fresh"] -= 1                # of a new plan also pays for its buffers' first use)
+                                if e["fresh"] == 0:
+                                    pol.rebuilt(ms)
+                            elif pol.window(ms):               # slower than this order used to be: take the costs again
+                                e["plan"].collect_cost(True)
+                                e["stage"], e["fresh"] = 0, 2
                         self._d[key] = e
                         while len(self._d) > keep:
                             self._d.popitem(last=False)[1]["plan"].close()

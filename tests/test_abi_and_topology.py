@@ -287,3 +287,28 @@ def test_block_order_groups_rows_by_cost_tier_and_keeps_chains_together():
     blocks_cheap_only = np.setdiff1d(np.unique(pos[hint == 16] // B), blocks_costly)
     assert blocks_cheap_only.max() < blocks_costly.min()                # cheap blocks first
     assert blocks_costly.size <= -(-int((hint == 48).sum() + 1) // B) + 1
+
+
+def test_retune_policy_asks_for_new_costs_when_windows_slow_down_and_backs_off_when_that_does_not_help():
+    """The drop-in's plan cache re-tunes the row order when the windows on the tuned plan have become slower than they
+    were (mc_reach.RetunePolicy): two consecutive windows 12 % and half a millisecond above the fastest; a re-tune that does
+    not bring the time back makes the slower time the yardstick and doubles the number of windows to sit out."""
+    from troute_amd.routing.fast_reach.mc_reach import RetunePolicy
+    p = RetunePolicy()
+    assert [p.window(ms) for ms in (16.0, 16.2, 15.9, 16.4)] == [False] * 4 and p.best == 15.9
+    assert [p.window(ms) for ms in (19.0, 16.0, 19.0)] == [False] * 3             # (not consecutive)
+    assert p.window(19.5) is True                                                  # the second in a row: the forcing has moved on
+    p.rebuilt(16.1)                                                                # the new order serves: no sitting out
+    assert p.hold == 0 and p.best == 16.1 and p.retunes == 1
+    assert [p.window(ms) for ms in (16.1, 20.3, 20.4)] == [False, False, True]
+    p.rebuilt(20.2)                                                                # it did not help: classes that do not persist
+    assert p.hold == 8 and p.next_hold == 16 and p.best == 20.2
+    assert [p.window(30.0) for _ in range(8)] == [False] * 8 and p.hold == 0       # sat out, however slow
+    assert [p.window(ms) for ms in (20.3, 20.1, 22.0, 22.1)] == [False] * 4        # 12 % over the NEW yardstick is 22.5
+    assert [p.window(ms) for ms in (23.0, 23.0)] == [False, True]
+    p.rebuilt(22.9)
+    assert p.hold == 16 and p.next_hold == 32
+    # the windows of a small network are launch latency: half a millisecond of noise is no reason
+    q = RetunePolicy()
+    assert [q.window(ms) for ms in (0.50, 0.70, 0.72, 0.75)] == [False] * 4
+    assert [q.window(ms) for ms in (0.0, -1.0, float("nan"))] == [False] * 3       # no timing: no verdict

@@ -213,5 +213,25 @@ def test_kernel_callable_reuses_and_tunes_its_plan_without_changing_results(monk
         assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), k
         stages.append([e["stage"] for e in M._PLANS._d.values()])
     assert stages == [[1], [2], [2], [2], [2]]
+    # ... and when the windows on the tuned plan have become slower than they were (RetunePolicy; here: told so), the next
+    # window collects costs again and the call after it routes on a plan rebuilt from them -- the same bits throughout
+    verdicts = iter([False, True, False])
+    monkeypatch.setattr(M.RetunePolicy, "window", lambda self, ms: next(verdicts))
+    stages, plans = [], []
+    for k in (2, 0, 1, 2, 0, 1):                               # tuned; tuned, asked; collecting; rebuilt; tuned; tuned
+        got = call(*windows[k])[1]
+        assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), k
+        (e,) = M._PLANS._d.values()
+        stages.append(e["stage"])
+        plans.append(id(e["plan"]))
+    assert stages == [2, 0, 1, 2, 2, 2]
+    assert plans[0] == plans[1] == plans[2] and plans[3] != plans[2] and plans[3] == plans[4] == plans[5]
+    assert e["policy"].retunes == 1 and e["fresh"] == 0        # (judged by the second window on the new order)
+    monkeypatch.setenv("TRMC_RETUNE", "0")                     # switched off: a plan is tuned once and kept
+    M._PLANS.clear()
+    for k in (0, 1, 2):
+        call(*windows[k])
+    (e,) = M._PLANS._d.values()
+    assert e["stage"] == 2 and e["policy"] is None
     M._PLANS.clear()
     assert not M._PLANS._d
