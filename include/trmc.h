@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 14
+#define TRMC_ABI_VERSION 15
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -166,6 +166,17 @@ int trmc_topology_levels_hinted(int64_t nseg, const int64_t *up_ptr, const int64
 int trmc_topology_blocks(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                          const uint8_t *boundary, const uint8_t *cost_hint, int cost_tiers,
                          int64_t *plan_pos_of_row, int32_t *rank_of_row, int32_t *block_rows, int32_t *nblocks);
+
+/* Host-only: the block order of a plan built for the GENERAL mode (TRMC_PLAN_FULL_TS on the dataflow engine) -- the plain
+ * post-order (no cost tiers), except that a basin whose longest path has at least stem_min_rows rows (the library's
+ * default: 1 024, TRMC_STEM_MIN_ROWS) is laid out as [its side tributaries, those joining at the TOP of that path first]
+ * [the path, top to bottom], the path's run of positions beginning and ending on a block boundary (the gap filled with
+ * whole small networks).  early_blocks[min(*nearly, early_cap)]: the blocks that hold such paths, ascending -- the general
+ * mode's kernel starts them first, so that the dependent chain of mc_reach.pyx:499-505 (a row needs its upstream rows at the
+ * SAME timestep) runs down behind the sweep over its basin instead of after it.  Outputs may be NULL. */
+int trmc_topology_blocks_general(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
+                                 int32_t stem_min_rows, int64_t *plan_pos_of_row, int32_t *rank_of_row, int32_t *block_rows,
+                                 int32_t *nblocks, int32_t *early_blocks, int32_t early_cap, int32_t *nearly);
 
 /* Facts about the flattened topology (host side, no device work). */
 int trmc_plan_info(const trmc_plan *plan, int64_t *nseg, int64_t *nseg_routed,

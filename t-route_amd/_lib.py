@@ -47,6 +47,7 @@ SIGNATURES = {
     "trmc_topology_levels": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
     "trmc_topology_levels_hinted": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
     "trmc_topology_blocks": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _P(_i32), _P(_i32)]),
+    "trmc_topology_blocks_general": (_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _P(_i32), _P(_i32), _vp, _i32, _P(_i32)]),
     "trmc_plan_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i32), _P(_i32), _P(_i32)]),
     "trmc_plan_levels": (_int, [_vp, _vp, _vp]),
     "trmc_upload_forcing": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),

@@ -12,7 +12,7 @@ namespace trmc {
 
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows,
-                   bool cost_tiers, int32_t boundary_floor, int64_t wide_min_rows, int32_t wide_max_levels)
+                   bool cost_tiers, int32_t boundary_floor, int64_t wide_min_rows, int32_t wide_max_levels, int32_t stem_min_rows)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -145,14 +145,26 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
         std::stable_sort(outlets.begin(), outlets.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
         std::vector<int32_t> post; // routed rows, every row after all rows draining into it
         post.reserve(nrouted);
+        std::vector<std::pair<int64_t, int64_t>> stem_runs; // [first, last) indices into `post` of the long main stems
         {
             std::vector<uint8_t> seen(nseg, 0);
             std::vector<int32_t> kids;               // scratch: routed upstream rows of the row being expanded
             std::vector<std::pair<int32_t, int32_t>> stack; // (row, state): state 0 = expand, 1 = emit
-            for (const int32_t o : outlets) {
-                if (seen[o]) continue;
-                seen[o] = 1;
-                stack.emplace_back(o, 0);
+            // the routed upstream rows of r not visited yet, by descending size (marks them visited)
+            auto kids_of = [&](int32_t r) {
+                kids.clear();
+                for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) {
+                    const int32_t u = (int32_t)up_idx[k];
+                    if (!is_b(u) && !seen[u]) {
+                        seen[u] = 1;
+                        kids.push_back(u);
+                    }
+                }
+                std::stable_sort(kids.begin(), kids.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
+            };
+            // post-order of the sub-tree of `root` (marked visited by the caller)
+            auto walk = [&](int32_t root) {
+                stack.emplace_back(root, 0);
                 while (!stack.empty()) {
                     auto [r, st] = stack.back();
                     stack.pop_back();
@@ -161,19 +173,75 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                         continue;
                     }
                     stack.emplace_back(r, 1);
-                    kids.clear();
-                    for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) {
-                        const int32_t u = (int32_t)up_idx[k];
-                        if (!is_b(u) && !seen[u]) {
-                            seen[u] = 1;
-                            kids.push_back(u);
-                        }
-                    }
                     // visited in ascending size (the largest tributary last, right before its junction): pushed in
                     // descending order of visit
-                    std::stable_sort(kids.begin(), kids.end(), [&](int32_t a, int32_t b) { return drain[a] > drain[b]; });
+                    kids_of(r);
                     for (const int32_t u : kids) stack.emplace_back(u, 0);
                 }
+            };
+            std::vector<int32_t> stem, side;
+            std::vector<int64_t> side_ptr;
+            // A stem's run of positions begins and ends on a block boundary: the rows of a block advance together (a
+            // wavefront waits when one of its lanes does), so a stem row must not share its block with rows whose inflows
+            // are routed much later -- the end of the last side tributary in front of it, the start of the next basin behind
+            // it.  The gap is filled with whole small networks from the end of the list (they need nobody and are through
+            // at once).
+            size_t small_end = outlets.size();
+            auto pad_to_block = [&]() {
+                int64_t pad = (block_rows - (int64_t)post.size() % block_rows) % block_rows;
+                size_t j = small_end;
+                for (int tries = 0; pad > 0 && j > 0 && tries < 65536; ++tries) {
+                    const int32_t o2 = outlets[--j];
+                    if (seen[o2]) {
+                        if (j + 1 == small_end) small_end = j;
+                        continue;
+                    }
+                    if (drain[o2] > pad) continue;
+                    seen[o2] = 1;
+                    const size_t before = post.size(); // (drain is an upper bound of what the walk emits: boundary rows, bifurcations)
+                    walk(o2);
+                    pad -= (int64_t)(post.size() - before);
+                    if (j + 1 == small_end) small_end = j;
+                }
+            };
+            for (const int32_t o : outlets) {
+                if (seen[o]) continue;
+                seen[o] = 1;
+                if (stem_min_rows > 0 && !cost_tiers && t.level_of_row[o] + 1 >= stem_min_rows) {
+                    // the stem: the LONGEST path into the outlet (always into the tributary of the highest level; the larger
+                    // one among equals) -- the chain the window's last step has to come down -- and, per stem row, its
+                    // other tributaries in the plain walk's order of visit (ascending size)
+                    stem.clear();
+                    side.clear();
+                    side_ptr.assign(1, 0);
+                    for (int32_t v = o;;) {
+                        stem.push_back(v);
+                        kids_of(v);
+                        size_t up = 0;
+                        for (size_t i = 1; i < kids.size(); ++i)
+                            if (t.level_of_row[kids[i]] > t.level_of_row[kids[up]]) up = i;
+                        for (size_t i = kids.size(); i-- > 0;)
+                            if (i != up) side.push_back(kids[i]);
+                        side_ptr.push_back((int64_t)side.size());
+                        if (kids.empty()) break;
+                        v = kids[up];
+                    }
+                    if ((int64_t)stem.size() >= stem_min_rows) {
+                        for (size_t i = stem.size(); i-- > 0;) // from the top of the stem down
+                            for (int64_t k = side_ptr[i]; k < side_ptr[i + 1]; ++k) walk(side[(size_t)k]);
+                        pad_to_block();
+                        stem_runs.emplace_back((int64_t)post.size(), (int64_t)(post.size() + stem.size()));
+                        for (size_t i = stem.size(); i-- > 0;) post.push_back(stem[i]);
+                        pad_to_block();
+                        continue;
+                    } else { // a short stem (levels lifted by a floor, not by rows): side tributaries from the bottom up
+                        for (size_t i = 0; i < stem.size(); ++i)
+                            for (int64_t k = side_ptr[i]; k < side_ptr[i + 1]; ++k) walk(side[(size_t)k]);
+                    }
+                    for (size_t i = stem.size(); i-- > 0;) post.push_back(stem[i]);
+                    continue;
+                }
+                walk(o);
             }
         }
         if ((int64_t)post.size() != nrouted) { // cannot happen in a DAG
@@ -215,6 +283,16 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             t.row_of_pos[b] = t.boundary_rows[b];
         }
         t.nblocks = (int32_t)((nrouted + block_rows - 1) / block_rows);
+        // the blocks of the long stems, largest basin first, at most kEarlyBlocksMax of them in all: they hold their slots
+        // from the first moment of a launch, and what they wait for needs slots too
+        constexpr size_t kEarlyBlocksMax = 64;
+        t.early_blocks.clear();
+        for (const auto &run : stem_runs) {
+            const int64_t b0 = run.first / block_rows, b1 = (run.second - 1) / block_rows;
+            if (t.early_blocks.size() + (size_t)(b1 - b0 + 1) > kEarlyBlocksMax) break;
+            for (int64_t b = b0; b <= b1; ++b)
+                if (t.early_blocks.empty() || t.early_blocks.back() < (int32_t)b) t.early_blocks.push_back((int32_t)b);
+        }
         t.rank_of_pos.assign(nseg, 0);
         std::vector<int32_t> idx;
         std::vector<int64_t> key;
@@ -226,6 +304,9 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             for (int32_t i = 0; i < m; ++i) {
                 const int32_t r = post[i0 + i];
                 idx[i] = i;
+                // (by size, not by the dependency depth inside the block -- lanes dealt out shallow rows first, so that a
+                // wavefront's ranks span a quarter of the block's, were measured for the general mode: 36.4 ms against 31.3;
+                // by size the rows of a chain sit in neighbouring lanes of ONE wavefront and hand over without a wait)
                 key[i] = cost_hint ? (int64_t)cost_hint[r] : drain[r];
             }
             std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t c) { return key[a] > key[c]; });

@@ -42,6 +42,8 @@ struct Topology {
     std::vector<uint8_t> cost_of_wave;   // [ceil(routed / 64)] the costliest row's hint (or drainage class) of every wavefront of the block order
     std::vector<uint8_t> prio_of_wave;   // [ceil(routed / 64)] issue priority 0..3 of every wavefront of the block order: by the
                                          // costliest row it holds (cost hint, else drainage size); costlier = higher
+    std::vector<int32_t> early_blocks;   // block order with stem_min_rows > 0: the blocks that hold the long main stems, ascending
+                                         // (the general mode starts them FIRST, see build_topology)
 };
 
 // Returns 0 on success; -1 bad argument, -2 cycle.  `err` receives a message.
@@ -76,9 +78,19 @@ struct Topology {
 // (then by level, then as inside a level): a wavefront holds rows of one cost class also where the levels are a hundred
 // rows wide and the per-level order mixed three classes in one wavefront (917 instructions per wavefront-step there
 // against 788 in the wider levels).  Topology::tail_from_level says where that part begins.
+// stem_min_rows > 0 (block order without cost tiers: plans built for the GENERAL mode, where a row needs its upstream rows
+// at the SAME step and a chain of n rows cannot finish a window before n + nsteps dependent steps have run one after the
+// other): a basin whose STEM -- the longest path into its outlet: from the outlet upstream, always into the tributary of
+// the highest level -- has at least that many rows is laid out as  [side tributaries, the one joining at the TOP of the stem first] [the stem, top to
+// bottom]  instead of the plain post-order (which comes to: side tributaries from the BOTTOM up, then the stem).  With the
+// plain order the stem's first row waits for the tributary that is routed last; with this one every stem row's side
+// tributary is routed before those of the rows below it, so a stem that STARTS with the window advances behind the sweep
+// over its basin instead of after it.  Topology::early_blocks lists the blocks that hold such stems; k_mc_flow<false> hands
+// them out first (they wait for their inflows in place; every other block still only needs blocks that were started before
+// it or are among those few).
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr,
                    int32_t block_rows = 0, bool cost_tiers = true, int32_t boundary_floor = 0, int64_t wide_min_rows = 0,
-                   int32_t wide_max_levels = 0);
+                   int32_t wide_max_levels = 0, int32_t stem_min_rows = 0);
 
 } // namespace trmc

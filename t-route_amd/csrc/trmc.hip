@@ -1662,6 +1662,8 @@ struct FlowArgs {
     int32_t ncuq;
     unsigned long long *dbg;       // nullptr, or [nblocks][2]: wall clock at the start and the end of every block (TRMC_FLOW_DEBUG)
     int32_t nblocks_dbg;
+    const int32_t *ticket_map;     // general mode: ticket -> block, the blocks of the long main stems first (topology.hpp,
+                                   // stem_min_rows); nullptr = block tickets in order
 };
 
 using FlowCold = ColdArgs<FlowArgs>;
@@ -1799,7 +1801,13 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
     __shared__ float s_out[3 * kFlowStage * kFlowBlock];             // [step slot * 3 + c][thread]
     __shared__ unsigned long long s_ring[kFlowRing * kFlowBlock];    // [step % kFlowRing][thread] granules
     __shared__ int32_t s_blk;
-    if (threadIdx.x == 0) s_blk = atomicAdd(a.ticket, 1);
+    if (threadIdx.x == 0) {
+        // General mode on a plan laid out for it: the first tickets go to the blocks of the long main stems.  They wait for
+        // their inflows in place -- a stem then advances behind the sweep over its basin instead of after it -- and every
+        // other block still only needs blocks that took their tickets before it or are among those few, all resident.
+        const int32_t tk = atomicAdd(a.ticket, 1);
+        s_blk = (!SHORT && cold->ticket_map) ? cold->ticket_map[tk] : tk;
+    }
 #pragma unroll
     for (int j = 0; j < kFlowRing; ++j) s_ring[j * kFlowBlock + threadIdx.x] = 0ull; // tag 0: older than any live tag
     M m{stage_pow_tables(s_tab), false}; // (its barrier also publishes s_blk and the cleared ring)
@@ -2515,6 +2523,7 @@ struct trmc_plan {
     hipEvent_t ev_ctl = nullptr;         // ordering of the two compute streams against each other
     int flow_next = 0;                   // which of the two the next trmc_route_advance uses (only toggles in overlap mode)
     int flow_last = 0;                   // ... and which one the last launch went to
+    DevBuf ticket_map;                   // [nblocks] ticket -> block of a general-mode plan with long main stems (topo.early_blocks)
     DevBuf d_state, ticket, rank, dbg;   // depth column; {block ticket, abort flag}; level rank of a position inside its block
     DevBuf cuq_ptr, cuq_blk, cuq_head, cu_index, cuq_perm; // blocks dealt to compute units by cost (flow_place_blocks); heads: one set per compute stream
     int32_t ncuq = 0;                    // number of queues (= compute units found), 0 = block tickets
@@ -3353,6 +3362,7 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     // short-timestep mode: the skew of trmc_plan_set_lag; general mode: the level rank inside the block
     a.lag = short_ts ? (pl->maxlag > 0 ? (const int32_t *)pl->lag.p : nullptr)
                      : (pl->topo.maxrank > 0 ? (const int32_t *)pl->rank.p : nullptr);
+    a.ticket_map = short_ts ? nullptr : (const int32_t *)pl->ticket_map.p;
     a.qlat_tm = (const float *)pl->qlat_tm.p;
     a.gran = (unsigned long long *)pl->tm.p;
     a.d_state = (float *)pl->d_state.p;
@@ -3856,6 +3866,26 @@ int trmc_topology_blocks(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
     return 0;
 }
 
+int trmc_topology_blocks_general(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
+                                 int32_t stem_min_rows, int64_t *plan_pos_of_row, int32_t *rank_of_row, int32_t *block_rows,
+                                 int32_t *nblocks, int32_t *early_blocks, int32_t early_cap, int32_t *nearly)
+{
+    trmc::Topology t;
+    std::string err;
+    const int rc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, t, err, nullptr, kFlowBlock, false, 0, 0, 0,
+                                        std::max<int32_t>(0, stem_min_rows));
+    if (rc) return fail(rc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
+    for (int64_t r = 0; r < nseg; ++r) {
+        if (plan_pos_of_row) plan_pos_of_row[r] = t.pos_of_row[r];
+        if (rank_of_row) rank_of_row[r] = t.rank_of_pos[t.pos_of_row[r]];
+    }
+    if (block_rows) *block_rows = t.block_rows;
+    if (nblocks) *nblocks = t.nblocks;
+    if (nearly) *nearly = (int32_t)t.early_blocks.size();
+    for (int32_t i = 0; early_blocks && i < early_cap && i < (int32_t)t.early_blocks.size(); ++i) early_blocks[i] = t.early_blocks[(size_t)i];
+    return 0;
+}
+
 int trmc_plan_create(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
                      const uint8_t *boundary, int precision, int device, trmc_plan **out)
 {
@@ -3931,8 +3961,16 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
             wide_max_levels = (int32_t)std::min<long>(e2 && *e2 ? std::atol(e2) : 16, kWideMaxLevels);
         }
     }
+    // (a dataflow plan built for the general mode: basins with a main stem of at least TRMC_STEM_MIN_ROWS rows -- default
+    // 1 024, 0 = off -- are laid out stem-last with the side tributaries from the top of the stem down, and their stems'
+    // blocks take the first tickets: topology.hpp, stem_min_rows)
+    int32_t stem_min_rows = 0;
+    if (pl->flow && (flags & TRMC_PLAN_FULL_TS)) {
+        const char *e = std::getenv("TRMC_STEM_MIN_ROWS");
+        stem_min_rows = (int32_t)std::max(0L, e && *e ? std::atol(e) : 1024L);
+    }
     const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0, tiers,
-                                         (tiers && !pl->flow) ? kWideMaxLevels : 0, wide_min_rows, wide_max_levels);
+                                         (tiers && !pl->flow) ? kWideMaxLevels : 0, wide_min_rows, wide_max_levels, stem_min_rows);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
@@ -4001,6 +4039,19 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
             && hipMemcpy(pl->prio.p, pl->topo.prio_of_wave.data(), pl->topo.prio_of_wave.size(), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(TRMC_EHIP, "uploading the wavefront priorities failed"));
         if ((rc = flow_place_blocks(pl))) return bail(rc);
+        if (!pl->topo.early_blocks.empty()) { // ticket -> block: the stems' blocks, then everybody else in order
+            const int32_t nb = pl->topo.nblocks;
+            std::vector<int32_t> map;
+            map.reserve((size_t)nb);
+            std::vector<uint8_t> early((size_t)nb, 0);
+            for (const int32_t b : pl->topo.early_blocks) {
+                early[(size_t)b] = 1;
+                map.push_back(b);
+            }
+            for (int32_t b = 0; b < nb; ++b)
+                if (!early[(size_t)b]) map.push_back(b);
+            if ((rc = upload_i32(pl->ticket_map, map, 1))) return bail(rc);
+        }
     }
     if ((rc = upload_i32(pl->row_of_pos, pl->topo.row_of_pos, 1))) return bail(rc);
     if ((rc = upload_i32(pl->pos_of_row, pl->topo.pos_of_row, 1))) return bail(rc);
@@ -4026,7 +4077,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_fetch_ready) (void)hipEventDestroy(pl->ev_fetch_ready);
     if (pl->ev_fetch_done) (void)hipEventDestroy(pl->ev_fetch_done);
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->win_tab, &pl->win_ctr, &pl->tile_perm, &pl->cls_last})
         b->release();
@@ -4115,6 +4166,7 @@ int trmc_plan_clone(trmc_plan *src, trmc_plan **out)
     pl->pos_of_row.borrow(src->pos_of_row);
     pl->rank.borrow(src->rank);
     pl->prio.borrow(src->prio);
+    pl->ticket_map.borrow(src->ticket_map);
     pl->cuq_ptr.borrow(src->cuq_ptr);
     pl->cuq_blk.borrow(src->cuq_blk);
     pl->cu_index.borrow(src->cu_index);

@@ -52,6 +52,23 @@ def topology_blocks(up_ptr, up_idx, boundary=None, cost_hint=None, cost_tiers=Tr
     return pos, rank, br.value, nb.value
 
 
+def topology_blocks_general(up_ptr, up_idx, boundary=None, stem_min_rows=1024):
+    """Host-only block order of a dataflow plan built for the general mode (no GPU): long stems last in their basin, their
+    side tributaries from the top down.  Returns (plan_pos_of_row, rank_of_row, block_rows, nblocks, early_blocks)."""
+    up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
+    up_idx = np.ascontiguousarray(up_idx, dtype=np.int64)
+    nseg = up_ptr.shape[0] - 1
+    b = None if boundary is None else np.ascontiguousarray(boundary, dtype=np.uint8)
+    pos = np.empty(nseg, dtype=np.int64)
+    rank = np.empty(nseg, dtype=np.int32)
+    early = np.empty(256, dtype=np.int32)
+    br, nb, ne = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.lib().trmc_topology_blocks_general(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(b), int(stem_min_rows),
+                                                       _lib.ptr(pos), _lib.ptr(rank), C.byref(br), C.byref(nb),
+                                                       _lib.ptr(early), early.shape[0], C.byref(ne)))
+    return pos, rank, br.value, nb.value, early[:min(ne.value, early.shape[0])].copy()
+
+
 class RoutingPlan:
     def __init__(self, up_ptr, up_idx, params, boundary=None, precision=32, device=0, cost_hint=None,
                  assume_short_ts=None, engine="auto"):

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in trmc.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with trmc.h"
-    assert lib.trmc_abi_version() == 14
+    assert lib.trmc_abi_version() == 15
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "trdw.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(trdw_[a-z0-9_]+)\s*\(", hdr))
     for name in declared:
@@ -312,3 +312,109 @@ def test_retune_policy_asks_for_new_costs_when_windows_slow_down_and_backs_off_w
     q = RetunePolicy()
     assert [q.window(ms) for ms in (0.50, 0.70, 0.72, 0.75)] == [False] * 4
     assert [q.window(ms) for ms in (0.0, -1.0, float("nan"))] == [False] * 3       # no timing: no verdict
+
+
+def _check_general_order(up_ptr, up_idx, boundary, stem_min_rows):
+    """validity of the general-mode block order (every upstream row in the row's block or an earlier one, ranks growing
+    along the edges inside a block); returns (pos, rank, B, nb, early)"""
+    from troute_amd.plan import topology_blocks_general
+    n = len(up_ptr) - 1
+    pos, rank, B, nb, early = topology_blocks_general(up_ptr, up_idx, boundary, stem_min_rows)
+    assert sorted(pos) == list(range(n))
+    nbound = 0 if boundary is None else int(np.count_nonzero(boundary))
+    assert nb == -(-(n - nbound) // B)
+    blk = (pos - nbound) // B
+    for r in range(n):
+        if boundary is not None and boundary[r]:
+            continue
+        for u in up_idx[up_ptr[r]:up_ptr[r + 1]]:
+            if boundary is not None and boundary[u]:
+                continue
+            assert blk[u] <= blk[r], "a row needs a LATER block"
+            if blk[u] == blk[r]:
+                assert rank[u] < rank[r]
+    return pos, rank, B, nb, early
+
+
+def test_general_mode_block_order_puts_long_stems_last_with_their_tributaries_from_the_top_down():
+    """A plan built for the general mode (a row needs its upstream rows at the SAME step, mc_reach.pyx:499-505) lays a basin
+    with a long stem out as [side tributaries, the top of the stem's first][the stem], the stem's run aligned to blocks,
+    and names the stem's blocks for an early start -- still a valid dataflow order."""
+    rng = np.random.default_rng(8)
+    L = 700                                                            # the stem: rows 0 (top) .. L - 1 (outlet)
+    ups = [[] if i == 0 else [i - 1] for i in range(L)]
+    side_of = {}                                                       # stem row -> rows of its side tributaries
+    for i in range(1, L):
+        if rng.random() < 0.4:                                         # a side tributary: a small random tree
+            m = int(rng.integers(1, 30))
+            base = len(ups)
+            for j in range(m):
+                ups.append([])
+                if j:
+                    ups[base + int(rng.integers(0, j))].append(base + j)   # base is the root (feeds the stem row)
+            ups[i].append(base)
+            side_of[i] = list(range(base, base + m))
+    long_side = len(ups)                                               # one side tributary LONGER than the rest of the stem
+    for j in range(120):                                               # above it is not: the stem stays the longest path
+        ups.append([] if j == 0 else [len(ups) - 1])
+    ups[400].append(len(ups) - 1)
+    side_of.setdefault(400, []).extend(range(long_side, long_side + 120))
+    n_basin = len(ups)
+    for _ in range(300):                                               # small networks of one to three rows (the padding)
+        k = int(rng.integers(1, 4))
+        base = len(ups)
+        for j in range(k):
+            ups.append([] if j == 0 else [base + j - 1])
+    n = len(ups)
+    perm = rng.permutation(n)                                          # rows in random order
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    ups_p = [[] for _ in range(n)]
+    for r in range(n):
+        ups_p[inv[r]] = [int(inv[u]) for u in ups[r]]
+    up_ptr, up_idx = csr_from_lists(ups_p)
+    pos, rank, B, nb, early = _check_general_order(up_ptr, up_idx, None, 512)
+    from troute_amd.plan import topology_levels
+    lvl, _, _ = topology_levels(up_ptr, up_idx)
+    outlet = int(inv[L - 1])
+    drain = np.ones(n, np.int64)
+    for r in np.argsort(lvl, kind="stable"):                           # upstream rows before the rows they feed
+        drain[r] += drain[up_idx[up_ptr[r]:up_ptr[r + 1]]].sum()
+    stem = [outlet]                                                    # the longest path into the outlet (no ties on it here)
+    while True:
+        us = up_idx[up_ptr[stem[-1]]:up_ptr[stem[-1] + 1]]
+        if us.size == 0:
+            break
+        # (the highest level; among equals the one that drains most rows; among those the first listed)
+        stem.append(int(max(us, key=lambda u: (lvl[u], drain[u], -list(us).index(u)))))
+    stem = np.asarray(stem[::-1])                                      # top to bottom
+    assert stem.size == lvl[outlet] + 1 and stem.size >= 512
+    stem_pos = pos[stem]
+    lo, hi = stem_pos.min(), stem_pos.max()
+    assert hi - lo + 1 == stem.size                                    # one run of positions ...
+    assert np.array_equal(stem_pos // B, (lo + np.arange(stem.size)) // B)     # ... block by block from the top down
+    assert lo % B == 0                                                 # begins on a block boundary ...
+    others_in_last_block = [r for r in range(n) if hi < pos[r] < -(-(hi + 1) // B) * B]
+    assert all(perm[r] >= n_basin for r in others_in_last_block)       # ... and shares its last block with small networks only
+    assert np.array_equal(early, np.arange(lo // B, hi // B + 1))
+    on_stem = np.zeros(n, bool)
+    on_stem[stem] = True
+    last = -1                                                          # side tributaries: the top of the stem's first
+    for v in stem:
+        sub, todo = [], [int(u) for u in up_idx[up_ptr[v]:up_ptr[v + 1]] if not on_stem[u]]
+        while todo:
+            r = todo.pop()
+            sub.append(r)
+            todo.extend(int(u) for u in up_idx[up_ptr[r]:up_ptr[r + 1]])
+        if sub:                                                        # (inside a block the rows are dealt out by size)
+            p = pos[np.asarray(sub)]
+            assert p.min() // B >= last and p.max() < lo
+            last = p.max() // B
+    # a stem shorter than asked for: the plain post-order, nothing started early; and the order is valid with boundary rows
+    pos0, _, _, _, early0 = _check_general_order(up_ptr, up_idx, None, 4096)
+    from troute_amd.plan import topology_blocks
+    assert early0.size == 0 and np.array_equal(pos0, topology_blocks(up_ptr, up_idx, None, None, False)[0])
+    boundary = np.zeros(n, np.uint8)
+    boundary[inv[np.asarray(side_of[400][:1])]] = 1                    # the head of the long side tributary is prescribed
+    _check_general_order(up_ptr, up_idx, boundary, 512)
+    _check_general_order(up_ptr, up_idx, None, 0)

@@ -351,6 +351,55 @@ def test_deep_chain_and_wide_junction():
         assert_bit_identical(got, want, "wide junction")
 
 
+@pytest.mark.parametrize("stem_min", [None, "64"])
+def test_general_mode_on_a_basin_with_a_long_stem_starts_the_stem_first_and_keeps_the_bits(monkeypatch, stem_min):
+    """A dataflow plan built for the general mode lays a basin with a long stem out stem-last, side tributaries from the top
+    of the stem down, and starts the stem's blocks first (topology.hpp, stem_min_rows; k_mc_flow<false>'s ticket map) --
+    the same bits as the oracle, window after window; also with small stems (several basins started early) and a
+    short-timestep window on the same plan."""
+    from troute_amd.plan import topology_blocks_general
+    set_engine(monkeypatch, "flow")
+    if stem_min:
+        monkeypatch.setenv("TRMC_STEM_MIN_ROWS", stem_min)
+    rng = np.random.default_rng(21)
+    ups = [[] if i == 0 else [i - 1] for i in range(1300)]             # a stem of 1 300 rows ...
+    for i in range(1, 1300):
+        if rng.random() < 0.5:                                         # ... with side tributaries: small random trees
+            base, m = len(ups), int(rng.integers(1, 40))
+            for j in range(m):
+                ups.append([])
+                if j:
+                    ups[base + int(rng.integers(0, j))].append(base + j)
+            ups[i].append(base)
+    for _ in range(40):                                                # other basins: chains of 1 to 200 rows
+        base, m = len(ups), int(rng.integers(1, 200))
+        for j in range(m):
+            ups.append([] if j == 0 else [base + j - 1])
+    n = len(ups)
+    perm = rng.permutation(n)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    ups_p = [[] for _ in range(n)]
+    for r in range(n):
+        ups_p[inv[r]] = [int(inv[u]) for u in ups[r]]
+    up_ptr, up_idx = csr_from_lists(ups_p)
+    early = topology_blocks_general(up_ptr, up_idx, None, int(stem_min or 1024))[4]
+    assert early.size >= (6 if stem_min is None else 7)               # the long stem's blocks (and, with 64, other basins')
+    lvl, _, _ = topology_levels(up_ptr, up_idx)
+    params, qlat, q0 = synth_inputs(rng, n, 3)
+    nsteps, qts = 30, 12
+    with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=False, engine="flow") as plan:
+        assert plan.engine == "flow"
+        got = plan.route(nsteps, qts, False, qlat, q0)
+        again = plan.route(nsteps, qts, False, qlat, q0)
+        short = plan.route(nsteps, qts, True, qlat, q0)
+    want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params, q0, qlat, False, det=True)[:, 1:, :]
+    assert_bit_identical(got, want, "long stem, general mode")
+    assert_bit_identical(again, want, "long stem, general mode, second window")
+    want = O.network_by_segment(nsteps, qts, up_ptr, up_idx, lvl, params, q0, qlat, True, det=True)[:, 1:, :]
+    assert_bit_identical(short, want, "long stem, a short-timestep window on the plan laid out for the general mode")
+
+
 def test_non_uniform_dt_column():
     rng = np.random.default_rng(11)
     nseg = 500
