@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""The general mode (assume_short_ts=False) on the bench network, dataflow engine, with the plain block order
+(TRMC_STEM_MIN_ROWS=0) and with long stems laid out last and started first (the default, csrc/topology.hpp stem_min_rows):
+device time of the second window, and the two results compared bit for bit -- the final state of every row, the flow series
+of 30 000 random rows, every outlet hydrograph.  (Developer tool, GPU box; the arithmetic itself is pinned to the oracle by
+the tests.)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
