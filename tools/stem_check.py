@@ -18,7 +18,8 @@ rng = np.random.default_rng(1)
 rows = np.sort(rng.choice(nseg, 30000, replace=False))
 outlets = np.flatnonzero(to < 0)
 res = {}
-for stem in ("0", "1024"):
+variants = sys.argv[1:] or ["1024"]                                 # python tools/stem_check.py [stem_min_rows ...]
+for stem in ["0"] + variants:
     os.environ["TRMC_STEM_MIN_ROWS"] = stem
     with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=False, engine="flow") as plan:
         plan.upload_forcing(288, qlat, q0)
@@ -28,7 +29,9 @@ for stem in ("0", "1024"):
             ms = plan.stats()["ms_main"]
         res[stem] = (plan.download_final_state(), plan.gather_flow_rows(rows), plan.gather_flow_rows(outlets), ms)
         print("stem", stem, "ms_main", ms, flush=True)
-a, b = res["0"], res["1024"]
-for k, name in enumerate(("final state of every row", "flow series of 30 000 rows", "outlet hydrographs")):
-    same = np.array_equal(np.ascontiguousarray(a[k]).view(np.uint32), np.ascontiguousarray(b[k]).view(np.uint32))
-    print(name, "identical" if same else "DIFFERENT")
+a = res["0"]
+for stem in variants:
+    b = res[stem]
+    for k, name in enumerate(("final state of every row", "flow series of 30 000 rows", "outlet hydrographs")):
+        same = np.array_equal(np.ascontiguousarray(a[k]).view(np.uint32), np.ascontiguousarray(b[k]).view(np.uint32))
+        print(f"stems of at least {stem} rows: {name}", "identical" if same else "DIFFERENT")
