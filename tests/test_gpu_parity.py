@@ -663,6 +663,35 @@ def test_conus_every_segment_bit_identical_to_reference(conus):
         assert_bit_identical(hyd, ref["q"][rows, 1:], "outlet hydrographs gathered by the two-rank job")
 
 
+def test_conus_general_mode_every_segment_bit_identical_to_reference(conus):
+    """The GENERAL mode (assume_short_ts=False, the reference's configuration default, compute_parameters.py:47) at full
+    size: every one of the 2 729 077 segments through a 288-step day from the cold start on the dataflow engine -- on the
+    plan built for that mode, i.e. with the dominant basin's 2 700-row stem laid out last, its side tributaries from the top
+    down, and its blocks started first (topology.hpp, stem_min_rows) -- against the reference Fortran on the CPU over the
+    reference's ordered sub-networks (loop semantics without the short-timestep assumption: mc_reach.pyx:499-505): the flow
+    of every row at every step, the velocity and depth series (exact checksums), the final state."""
+    from troute_amd.plan import topology_blocks_general
+    net, up_ptr, up_idx = conus
+    to, params, qlat = net["to"], net["params"], net["qlat"]
+    nseg = to.shape[0]
+    nsteps, qts = 288, 12
+    q0 = np.zeros((nseg, 3), np.float32)
+    assert topology_blocks_general(up_ptr, up_idx, None, 1024)[4].size >= 8      # the long stems' blocks, started first
+    ref = O.reference_windows(to, params, (qlat,), q0, nsteps, qts, False)
+    with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=False) as plan:
+        assert plan.engine == "flow"
+        plan.upload_forcing(nsteps, qlat, q0)
+        plan.route_device(nsteps, qts, False)
+        fvd = plan.download_fvd().reshape(nseg, nsteps, 3)
+        final = plan.download_final_state()
+    for lo in range(0, nseg, 200000):
+        assert_bit_identical(np.ascontiguousarray(fvd[lo:lo + 200000, :, 0]), ref["q"][lo:lo + 200000, 1:],
+                             f"general mode: flow of every row, rows {lo}..")
+    assert np.array_equal(O.series_checksum(fvd[:, :, 1]), ref["chk_v"]), "general mode: velocity series of some row differs"
+    assert np.array_equal(O.series_checksum(fvd[:, :, 2]), ref["chk_d"]), "general mode: depth series of some row differs"
+    assert_bit_identical(final, ref["state"], "general mode: final state of every row")
+
+
 def test_conus_row_relabelling_invariance(conus):
     """Permuting the caller's row labels must permute the result and change nothing else (bitwise):
     exercises the level flattening, the gather maps and the result transpose at full width."""
