@@ -289,11 +289,13 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
 
     def empty(df):
         return df is None or getattr(df, "empty", True)
+    # the gage table goes to the marshalling when the key is present, whatever its value (compute.py:1798-1803); the solver
+    # -- the reference's Fortran and this one -- copies the arrays fp_da_map makes of it and computes nothing from them
+    # (diffusive.f90:1282-1303, :1316-1319: the nudging branch is commented out)
     if da_parameter_dict and "diffusive_streamflow_nudging" in da_parameter_dict and not empty(usgs_df):
-        # the reference forwards usgs_df to the solver in this case (compute.py:1799-1803); nudging inside the
-        # diffusive solver is not covered here, and dropping it silently would change results
-        raise NotImplementedError("diffusive_streamflow_nudging: data assimilation inside the diffusive solver is "
-                                  "not covered by the device solver")
+        diffusive_usgs_df = usgs_df
+    else:
+        diffusive_usgs_df = pd.DataFrame()
     tws = list(diffusive_network_data)
     inputs = []
     for tw in tws:
@@ -322,7 +324,7 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
         inputs.append(diff_utils.diffusive_input_data_v02(
             tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
             dn["param_df"], dq, q0, junction_inflows, qts_subdivisions, t0, nts, dt, waterbodies_df, topo,
-            pd.DataFrame(), rdomain, rreaches, coastal, pd.DataFrame()))
+            diffusive_usgs_df, rdomain, rreaches, coastal, pd.DataFrame()))
     outs = diffusive.compute_diffusive_batch(inputs, device=device)
     e = np.asarray([])
     results_diffusive = []

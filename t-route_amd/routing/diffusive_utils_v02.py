@@ -23,7 +23,9 @@ Refactored hydrofabric (``refactored_diffusive_domain`` / ``refactored_reaches``
 cannot run; here the solver's crosswalk arguments (``rdx_ar_g``, ``crosswalk_g``, ``z_thalweg_g``: what ``trdw_diffnw``
 maps results back to the original links with, diffusive.f90:849-920) are taken from the domain dictionary when the caller
 supplies them under those names, and without them the call fails with a message that says so.
-Not covered (NotImplementedError): gage data for diffusive nudging (the branch is switched off inside the reference solver).
+Gage data for diffusive nudging (``usgs_df``): marshalled by ``fp_da_map`` exactly as the reference does (:512-574) and
+handed to the solver, which -- like the reference's Fortran, whose use of ``usgs_da`` is commented out
+(diffusive.f90:1282-1303, :1316-1319) -- copies the arrays and computes nothing from them.
 """
 import math
 from functools import partial
@@ -162,6 +164,32 @@ def fp_coastal_boundary_input_map(tw, coastal_boundary_depth_df, nrch_g, t0, t0_
     return dt_db_g, 1, nts_db_g, df.loc[tw].values.astype(float)
 
 
+def fp_da_map(mx_jorder, ordered_reaches, usgs_df, nrch_g, t0, nsteps, dt_da_g, t0_g, tfin_g):
+    """Gage observations for the solver (:512-574) -> (number of DA times, ``usgs_da_g[time, reach]``, 1-based index of
+    every reach that holds a gage segment, 0 elsewhere).  A reach takes the series of the LAST of its nodes found in the
+    table; missing stamps and NaN become -4444."""
+    import pandas as pd
+    nts_da_g = int((tfin_g - t0_g) * 3600.0 / dt_da_g) + 1
+    usgs_da_g = -4444.0 * np.ones((nts_da_g, nrch_g))
+    usgs_da_reach_g = np.zeros(nrch_g, dtype="i4")
+    if usgs_df is None or usgs_df.empty:
+        return nts_da_g, usgs_da_g, usgs_da_reach_g
+    step = pd.Timedelta(minutes=dt_da_g / 60.0)
+    stamps = pd.date_range(t0, t0 + step * nsteps, freq=step)
+    table = usgs_df.reindex(columns=stamps).fillna(-4444.0)
+    where = {seg: k for k, seg in enumerate(table.index.values)}
+    values = table.values
+    frj = -1
+    for x in range(mx_jorder, -1, -1):
+        for _, reach in ordered_reaches[x]:
+            frj += 1
+            hits = [where[s] for s in reach["segments_list"] if s in where]
+            if hits:
+                usgs_da_g[:, frj] = values[hits[-1], :nts_da_g]
+                usgs_da_reach_g[frj] = frj + 1
+    return nts_da_g, usgs_da_g, usgs_da_reach_g
+
+
 def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_list, trib_seg_list, diffusive_parameters,
                              param_df, qlat, initial_conditions, junction_inflows, qts_subdivisions, t0, nsteps, dt,
                              waterbodies_df, topobathy_bytw, usgs_df, refactored_diffusive_domain, refactored_reaches,
@@ -178,8 +206,6 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
                 "branch reads unassigned names (diffusive_utils_v02.py:1033-1038, :1115-1142); supply 'rdx_ar_g', 'crosswalk_g' "
                 "and 'z_thalweg_g' in refactored_diffusive_domain (the solver maps results back with them, trdw_diffnw cwnrow_g > 0)")
         crosswalk = {k: np.asarray(refactored_diffusive_domain[k], dtype=np.float64) for k in need}
-    if not empty(usgs_df):
-        raise NotImplementedError("gage data for diffusive nudging: the branch is disabled in the reference solver itself")
 
     # ---- time and numerical parameters (:700-745)
     dt_ql_g, saveinterval, tfin_g = 3600.0, dt, (dt * nsteps) / 60 / 60
@@ -244,7 +270,7 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
     para_ar_g[10] = dsbd_option
     x_bathy_g, z_bathy_g, mann_bathy_g, size_bathy_g, mxnbathy_g = fp_naturalxsec_map(
         ordered, mainstem_seg_list, topobathy_bytw, param_df, mx_jorder, mxncomp_g, nrch_g, dbfksegID)
-    nts_da_g = int(tfin_g * 3600.0 / dt) + 1                        # fp_da_map, empty table (:537-539)
+    nts_da_g, usgs_da_g, usgs_da_reach_g = fp_da_map(mx_jorder, ordered, usgs_df, nrch_g, t0, nsteps, dt, 0.0, tfin_g)  # :1022-1031
     ins = {
         "timestep_ar_g": timestep_ar_g, "nts_ql_g": nts_ql_g, "nts_ub_g": nts_ub_g, "nts_db_g": nts_db_g,
         "nts_qtrib_g": nts_qtrib_g, "ntss_ev_g": int(tfin_g * 3600.0 / dt) + 1, "nts_da_g": nts_da_g,
@@ -254,7 +280,7 @@ def diffusive_input_data_v02(tw, connections, rconn, reach_list, mainstem_seg_li
         "ubcd_g": np.zeros((nts_ub_g, nrch_g)), "dbcd_g": dbcd_g, "qtrib_g": qtrib_g, "paradim": 11,
         "para_ar_g": para_ar_g, "mxnbathy_g": mxnbathy_g, "x_bathy_g": x_bathy_g, "z_bathy_g": z_bathy_g,
         "mann_bathy_g": mann_bathy_g, "size_bathy_g": size_bathy_g, "iniq": iniq, "pynw": pynw, "ordered_reaches": ordered,
-        "usgs_da_g": -4444.0 * np.ones((nts_da_g, nrch_g)), "usgs_da_reach_g": np.zeros(nrch_g, dtype="i4"),
+        "usgs_da_g": usgs_da_g, "usgs_da_reach_g": usgs_da_reach_g,
         "rdx_ar_g": np.array([]).reshape(0, 0), "cwnrow_g": 0, "cwncol_g": 0, "crosswalk_g": np.array([]).reshape(0, 0),
         "z_thalweg_g": np.array([]).reshape(0, 0),
     }

@@ -11,6 +11,11 @@ Outputs come from the reference Fortran built from its own sources (oracle/_ref/
 
 Writes tests/golden/diffusive_lowercolorado.npz (every input array of the c_diffnw call + q/elv/depth outputs)
 and tests/golden/diffusive_small.npz (hand-made small mainstems, same call).
+
+--da: only tests/golden/diffusive_da.npz -- the same domain with a gage table handed to the reference's marshalling
+(``usgs_df`` as nwm_route passes it on, nwm_routing/__main__.py:1292-1311 -> compute.py:1798-1803 -> fp_da_map :512-574):
+the table, the three DA arguments the reference made of it, and the reference Fortran's outputs WITH those arguments,
+which the script asserts are the bits of its outputs WITHOUT them (diffusive.f90:1282-1303: the branch is commented out).
 """
 import ctypes as C
 import importlib.util
@@ -120,7 +125,18 @@ def synthetic_coastal_depths(tw, t0, hours):
     return df
 
 
-def lowercolorado(nn, du, nsteps, natural=False, coastal=False):
+def synthetic_gage_table(mainstem, trib, t0, nsteps, dt):
+    """Observations "interpolated at dt" as nwm_route holds them: rows = gaged segments (two in one mainstem reach, one
+    tributary, one id outside the domain), columns = stamps; a NaN record, and the last stamps missing altogether."""
+    cols = pd.date_range(t0, periods=nsteps - 4, freq=pd.Timedelta(seconds=dt))
+    ids = [mainstem[1], mainstem[2], mainstem[len(mainstem) // 2], trib[0], 999999999]
+    k = np.arange(len(cols))
+    vals = np.stack([3.0 + i + np.sin(k / (5.0 + i)) for i in range(len(ids))]).astype(np.float32)
+    vals[1, 3] = np.nan
+    return pd.DataFrame(vals, index=ids, columns=cols)
+
+
+def lowercolorado(nn, du, nsteps, natural=False, coastal=False, gages=False):
     lc = H.LowerColorado()
     d = f"{REF}/test/LowerColorado_TX"
     dom = yaml.safe_load(open(f"{d}/domain/coastal_domain_subset.yaml"))
@@ -151,9 +167,12 @@ def lowercolorado(nn, du, nsteps, natural=False, coastal=False):
     t0 = pd.Timestamp("2021-08-23 13:00")
     topo = synthetic_topobathy(mainstem, param_df) if natural else pd.DataFrame()
     coast = synthetic_coastal_depths(tw, t0, max(2, int(np.ceil(nsteps * lc.dt / 3600.0)) + 1)) if coastal else pd.DataFrame()
+    usgs = synthetic_gage_table(mainstem, trib, t0, nsteps, lc.dt) if gages else pd.DataFrame()
     ins = du.diffusive_input_data_v02(
         tw, connections, rconn, reaches, mainstem, trib, None, param_df, qlat_df, q0, junction_inflows, lc.qts,
-        t0, nsteps, lc.dt, pd.DataFrame(), topo, pd.DataFrame(), None, None, coast, pd.DataFrame())
+        t0, nsteps, lc.dt, pd.DataFrame(), topo, usgs, None, None, coast, pd.DataFrame())
+    if gages:
+        ins["_usgs_df"] = usgs
     extra = {"mainstem": np.array(mainstem), "trib": np.array(trib), "tw": np.array(tw),
              "alt": param_df_alt(alt, lc), "junction_inflows": junction_inflows.values}
     if natural:
@@ -301,6 +320,25 @@ if __name__ == "__main__":
         sys.exit(0)
     nn = import_ref_nhd_network()
     du = import_ref_diffusive_utils(nn)
+    if "--da" in sys.argv:              # only the gage-table fixture (the others are unchanged)
+        ins, segs = lowercolorado(nn, du, nsteps=36, gages=True)
+        usgs = ins.pop("_usgs_df")
+        plain, _ = lowercolorado(nn, du, nsteps=36)
+        assert (ins["usgs_da_reach_g"] != 0).sum() >= 2 and (ins["usgs_da_g"] > 0).any() and not plain["usgs_da_reach_g"].any()
+        for k in ARG_ORDER:
+            if k not in ("usgs_da_g", "usgs_da_reach_g"):
+                assert np.array_equal(np.asarray(ins[k]), np.asarray(plain[k])), k
+        outs, outs_plain = call_reference(ins), call_reference(plain)
+        for a, b in zip(outs, outs_plain):
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64))     # the solver computes nothing from the gage arrays
+        z = {"in_nts_da_g": np.array(int(ins["nts_da_g"])), "in_usgs_da_g": np.asarray(ins["usgs_da_g"], np.float64),
+             "in_usgs_da_reach_g": np.asarray(ins["usgs_da_reach_g"], np.int32), "usgs_index": usgs.index.values,
+             "usgs_values": usgs.values, "usgs_times": np.array([str(c) for c in usgs.columns]),
+             "out_q": outs[0], "out_elv": outs[1], "out_depth": outs[2], "junction_inflows": segs["junction_inflows"]}
+        np.savez_compressed(os.path.join(HERE, "diffusive_da.npz"), **z)
+        print("gage table", usgs.shape, "reaches with a gage", np.flatnonzero(ins["usgs_da_reach_g"]) + 1, "nts_da", ins["nts_da_g"],
+              "size", os.path.getsize(os.path.join(HERE, "diffusive_da.npz")))
+        sys.exit(0)
     small = {}
     for name, d in small_cases():
         outs = call_reference(d)

@@ -193,6 +193,53 @@ def test_input_marshalling_equals_reference_dictionary():
     assert ins2["rdx_ar_g"].shape == (4, 2) and np.array_equal(ins2["z_ar_g"], ins["z_ar_g"])
 
 
+def gage_table_case():
+    """The LowerColorado domain with the gage table of tests/golden/diffusive_da.npz handed to THIS package's marshalling."""
+    import pandas as pd
+    from troute_amd.routing import diffusive_utils_v02 as DU
+    z, lc, tw, dn, qlat_df, q0 = lowercolorado_diffusive_network()
+    g = np.load(os.path.join(H.GOLDEN, "diffusive_da.npz"))
+    usgs_df = pd.DataFrame(g["usgs_values"], index=g["usgs_index"], columns=pd.to_datetime(g["usgs_times"]))
+    nsteps = int(g["in_nts_da_g"]) - 1
+    junction_inflows = pd.DataFrame(g["junction_inflows"], index=dn["tributary_segments"])
+    ins = DU.diffusive_input_data_v02(
+        tw, dn["connections"], dn["rconn"], dn["reaches"], dn["mainstem_segs"], dn["tributary_segments"], None,
+        dn["param_df"], qlat_df, q0, junction_inflows, lc.qts, pd.Timestamp("2021-08-23 13:00"), nsteps, lc.dt,
+        pd.DataFrame(), pd.DataFrame(), usgs_df, None, None, pd.DataFrame(), pd.DataFrame())
+    return ins, g, usgs_df
+
+
+def test_gage_table_is_marshalled_like_the_reference_and_changes_nothing_in_the_solver():
+    """``usgs_df`` reaches the marshalling whenever the DA dictionary has the key (compute.py:1798-1803; the reference's
+    dictionary ALWAYS has it, DataAssimilation.py:86): fp_da_map's three arguments equal the reference's (a reach with two
+    gaged nodes, a NaN record, stamps missing at the window's end, an id outside the domain), and the solver -- the
+    reference Fortran in the fixture, the host restatement here -- gives the bits it gives without them
+    (diffusive.f90:1282-1303: the branch is commented out)."""
+    ins, g, usgs_df = gage_table_case()
+    assert int(ins["nts_da_g"]) == int(g["in_nts_da_g"])
+    assert ins["usgs_da_g"].dtype == np.float64 and same_bits(ins["usgs_da_g"], g["in_usgs_da_g"])
+    assert np.array_equal(ins["usgs_da_reach_g"], g["in_usgs_da_reach_g"]) and ins["usgs_da_reach_g"].dtype == np.int32
+    assert (ins["usgs_da_reach_g"] != 0).sum() >= 2 and (ins["usgs_da_g"] == -4444.0).any() and (ins["usgs_da_g"] > 0).any()
+    rc, got = call_c(host_oracle(), "dw_oracle_diffnw", ins)
+    assert rc == 0
+    for gg, name in zip(got, ("out_q", "out_elv", "out_depth")):
+        assert same_bits(gg, g[name]), name
+    plain = dict(ins)
+    plain["usgs_da_g"] = np.full_like(ins["usgs_da_g"], -4444.0)
+    plain["usgs_da_reach_g"] = np.zeros_like(ins["usgs_da_reach_g"])
+    rc, got0 = call_c(host_oracle(), "dw_oracle_diffnw", plain)
+    assert rc == 0 and all(same_bits(a, b) for a, b in zip(got, got0))
+
+
+@pytest.mark.gpu
+def test_gpu_with_gage_table_equals_reference_fortran_bitwise():
+    from troute_amd.routing.fast_reach import diffusive as D
+    ins, g, _ = gage_table_case()
+    got = D.compute_diffusive(ins)
+    for gg, name in zip(got, ("out_q", "out_elv", "out_depth")):
+        assert same_bits(gg, g[name]), name
+
+
 def natural_and_coastal_tables(z):
     import pandas as pd
     topo = pd.DataFrame({"xid_d": z["topo_xid_d"], "z": z["topo_z"], "n": z["topo_n"]},

@@ -97,6 +97,7 @@ def test_gpu_shipped_configuration_nudging_reservoirs_and_diffusive_together(sho
     import test_diffusive as TD
     from troute_amd.routing import compute as RC
     from troute_amd.routing.fast_reach import diffusive as DIFF
+    from troute_amd.routing import diffusive_utils_v02 as DU
     nts = 48 if short else 24
     c = shipped_case(nts)
     lc, ids, is_lake, lakes = c["lc"], c["ids"], c["is_lake"], c["lakes"]
@@ -145,8 +146,13 @@ def test_gpu_shipped_configuration_nudging_reservoirs_and_diffusive_together(sho
     full_ql = pd.DataFrame(lc.qlat * 40.0, index=lc.ids)
     dsteps = 12
     short_results = [(r[0], r[1][:, :3 * dsteps]) + tuple(r[2:])]
-    got = RC.compute_diffusive_routing(short_results, {tw: dn}, 1, t0, lc.dt, dsteps, full_q0, full_ql, lc.qts, e, e, {}, e,
-                                       e, None, None, e, e)
+    # what nwm_route passes on (nwm_routing/__main__.py:1292-1311): the gage table interpolated at dt (stamps as columns), the
+    # last-observation table, and the DA dictionary -- which ALWAYS carries the diffusive key (DataAssimilation.py:86,93)
+    usgs_ts = usgs_df.copy()
+    usgs_ts.columns = pd.date_range(t0, periods=usgs_df.shape[1], freq=pd.Timedelta(seconds=lc.dt))
+    da_dict = {"da_decay_coefficient": 120.0, "diffusive_streamflow_nudging": False}
+    got = RC.compute_diffusive_routing(short_results, {tw: dn}, 1, t0, lc.dt, dsteps, full_q0, full_ql, lc.qts, usgs_ts,
+                                       lastobs_df, da_dict, e, e, None, None, e, e)
     host = TD.host_oracle()
 
     def host_batch(inputs, device=0):
@@ -158,8 +164,20 @@ def test_gpu_shipped_configuration_nudging_reservoirs_and_diffusive_together(sho
         return outs
     monkeypatch.setattr(DIFF, "compute_diffusive_batch", host_batch)
     oracle_results = [(ids.astype(np.intp), np.ascontiguousarray(want[:, 1:dsteps + 1, :]).reshape(len(ids), -1))]
-    ref = RC.compute_diffusive_routing(oracle_results, {tw: dn}, 1, t0, lc.dt, dsteps, full_q0, full_ql, lc.qts, e, e, {}, e,
-                                       e, None, None, e, e)
+    ref = RC.compute_diffusive_routing(oracle_results, {tw: dn}, 1, t0, lc.dt, dsteps, full_q0, full_ql, lc.qts, usgs_ts,
+                                       lastobs_df, da_dict, e, e, None, None, e, e)
+    seen = {}
+    real_marshal = DU.diffusive_input_data_v02
+
+    def spy(*a, **k):
+        seen["ins"] = real_marshal(*a, **k)
+        return seen["ins"]
+    monkeypatch.setattr(DU, "diffusive_input_data_v02", spy)
+    RC.compute_diffusive_routing(oracle_results, {tw: dn}, 1, t0, lc.dt, dsteps, full_q0, full_ql, lc.qts, usgs_ts,
+                                 lastobs_df, da_dict, e, e, None, None, e, e)
+    in_domain = set(dn["mainstem_segs"]) | set(dn["tributary_segments"])
+    if any(g in in_domain for g in c["gage_ids"]):       # gages inside the diffusive domain reach the solver's arguments
+        assert seen["ins"]["usgs_da_reach_g"].any()
     assert len(got) == len(ref) == 1
     assert np.array_equal(got[0][0], ref[0][0]) and got[0][1].shape == ref[0][1].shape
     assert np.array_equal(got[0][1].view(np.uint64) if got[0][1].dtype == np.float64 else got[0][1].view(np.uint32),
