@@ -22,7 +22,9 @@ forcing travels from page-locked host memory to the device (trmc_stage_forcing, 
 state is handed from day to day in HBM (trmc_plan_chain_from, between a plan and its clone: one copy of the topology and
 parameter columns, two sets of window buffers), the window is routed, and its products -- outlet hydrographs and final
 state, SURVEY 8d's throughput mode -- are copied to page-locked host arrays.  Topology and parameters are resident.
-(N > 1: the ranks time day N+1 routed `steps` times from the state day N leaves, as in earlier rounds.)
+The pipeline is the package's (troute_amd.sequence.DaySequence), and N > 1 is timed by the SAME protocol: every rank
+stages its rows of each day's forcing from page-locked memory, carries its state on in HBM, exchanges the cut-edge
+hydrographs chunk by chunk and fetches its final state (rank 0: the gathered outlet block too) beside the next day.
 
 Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   roofline          dominant kernel against the 8 TB/s HBM roofline, timed with HIP events on the plan's own stream
@@ -33,6 +35,8 @@ Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   value             the sequence above: INCLUDES every day's forcing host-to-device and the copy of what a throughput-mode caller
                     consumes -- outlet hydrographs + final state -- to the host;  value_resident: day N+1 routed
                     again and again on the one plan, forcing resident, everything left in HBM (earlier rounds' protocol)
+  value_tolerance   the same sequence on a plan created with TRMC_ARITH_TOLERANCE (hardware log2 / exp2 / reciprocal: NOT
+                    bit-comparable; its stated tolerance is tested in tests/test_gpu_tolerance.py) -- beside the headline, never it
   forcing_persistence   the same pipeline with days whose rows keep their magnitude with probability 0.5 / 0.0
   parity_full       EVERY segment against the reference Fortran on the CPU (the pipeline re-run over days N+1, N+2)
   parity_mode       the whole flowveldepth array copied to the host inside the timed region
@@ -82,7 +86,7 @@ def parse():
     ap.add_argument("--no-retune", action="store_true",
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
-    ap.add_argument("--no-two-members", action="store_true", help="skip the two-ensemble-members leg (a second plan of the network)")
+    ap.add_argument("--no-tolerance", action="store_true", help="skip the TRMC_ARITH_TOLERANCE leg (a second router of the network)")
     ap.add_argument("--no-parity-full", "--no-parity-sample", dest="no_parity_full", action="store_true",
                     help="skip the post-timing check of every segment against the reference on the CPU")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run counter passes (roofline.traffic / roofline.valu = null)")
@@ -431,13 +435,13 @@ def main():
 
     tuned = {"speed": None, "part": None}
 
-    def make_router(hint, short_ts, qlat, state):
+    def make_router(hint, short_ts, qlat, state, options=None):
         # with a hint (the measured cost of every row on the tuning day) the partition is packed by cost as well, and by the
         # pace every rank was MEASURED to keep on that day (what a trunk does to its owner is in there; sharding.partition)
         part = (sharding.partition(to, world, row_cost=hint, rank_speed=tuned["speed"], previous=tuned["part"])
                 if (hint is not None and world > 1) else None)
         r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint,
-                          assume_short_ts=short_ts, partition=part)
+                          assume_short_ts=short_ts, partition=part, options=options)
         r.upload(a.nsteps, qlat, state)
         if use_dist:
             r.enable_device_exchange(comm)
@@ -576,36 +580,34 @@ def main():
 
     # ---- 3. the headline: day N+1 on the plan tuned on day N; every window's outlet hydrographs and final state arrive on
     # the host inside the clock (SURVEY 8d's throughput mode), copied beside the next window ---------------------------
-    seq, persist = None, None
+    # One protocol for every N (troute_amd.sequence.DaySequence): a SEQUENCE of consecutive days with distinct forcing -- day
+    # N+1, N+2, ... -- a ring of `ndays` distinct days in page-locked host memory, each derived from the one before like days
+    # N-1 -> N -> N+1 were (synthetic.forcing).  One GPU: on the tuned plan and its clone; a rank of a multi-GPU job: on its
+    # merged plan, its rows of every day staged from page-locked memory, the state carried on in HBM.
+    from troute_amd.sequence import DaySequence, pinned_like
+    ndays = max(2 if a.headline_only else 4, min(int(os.environ.get("TRMC_BENCH_DAYS", "10")), a.steps + a.warmup))
+    t0 = time.perf_counter()
+    ring, prev_day = [], qlat_a
+    for i in range(ndays):
+        day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day, persistence=a.persistence)
+        ring.append(pinned_like(day) if not use_dist else day)
+        prev_day = day
+    assert np.array_equal(ring[0], qlat_b) or a.persistence is not None
+    t_days = time.perf_counter() - t0
+    persist = None
+    dayseq = DaySequence(router, a.nsteps, a.qts, nchunks=a.chunks)
     if use_dist:
-        head = timed(router, True, a.steps, a.warmup, d2h="state")
+        # the state after day N, this rank's rows, so that the check below can replay the first days of the timed sequence
+        state_n = router._state_plans[0].download_final_state()
+        local_ring = dayseq.prepare_days(ring)          # (this rank's rows of every day, page-locked: outside the clock)
+        seq = dayseq.run(local_ring, state_n, a.steps, a.warmup, prepared=True)
+        head = {"el": seq["el"], "ms_main": float(np.mean(seq["ms_main"])), "ms_total": seq["el"] / a.steps * 1e3,
+                "launches": router.last_stats["phase0"]["main_launches"], "stats": router.last_stats, "hyd": seq["hyd"], "steps": a.steps}
     else:
-        # One GPU: the pass that is timed is a SEQUENCE of consecutive days with distinct forcing (sequence_of_days): day N+1,
-        # N+2, ... -- a ring of `ndays` distinct days in page-locked host memory, each derived from the one before like days
-        # N-1 -> N -> N+1 were (synthetic.forcing) -- on the tuned plan and its clone.
-        from troute_amd import _lib as _tl
-        ndays = max(2 if a.headline_only else 4, min(int(os.environ.get("TRMC_BENCH_DAYS", "10")), a.steps + a.warmup))
-        t0 = time.perf_counter()
-        ring, prev_day = [], qlat_a
-        for i in range(ndays):
-            day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day,
-                                    persistence=a.persistence)
-            pinned = _tl.result_empty(day.shape, np.float32, always_pinned=True)
-            pinned[...] = day
-            ring.append(pinned)
-            prev_day = day
-        assert np.array_equal(ring[0], qlat_b) or a.persistence is not None
-        t_days = time.perf_counter() - t0
-        plan_b = router.plan0.clone()
-        outlets_rs = [router.plan0.rowset(router.my_out0_local), plan_b.rowset(router.my_out0_local)]
-        os.environ["TRMC_SETUP_ASIDE"] = "1"
-        try:
-            # (untimed: the clone's window buffers -- 19 GB of planes and result -- and both plans' copy streams and page-locked
-            # result rings are made at their first use)
-            sequence_of_days(router.plan0, plan_b, ring[:2], state_n, outlets_rs, a, 2, 0)
-            seq = sequence_of_days(router.plan0, plan_b, ring, state_n, outlets_rs, a, a.steps, a.warmup)
-        finally:
-            os.environ.pop("TRMC_SETUP_ASIDE", None)
+        # (untimed: the clone's window buffers -- 19 GB of planes and result -- and both plans' copy streams and page-locked
+        # result rings are made at their first use)
+        dayseq.run(ring[:2], state_n, 2, 0)
+        seq = dayseq.run(ring, state_n, a.steps, a.warmup)
         # (ms_main of the sequence: the WALL time per day, every kernel, copy and hand-over of the pipeline in it -- the events
         # around a single window also span what the neighbouring day's kernels take of the device while they overlap it)
         head = {"el": seq["el"], "ms_main": seq["el"] / a.steps * 1e3, "ms_total": seq["el"] / a.steps * 1e3,
@@ -614,7 +616,6 @@ def main():
                 "hyd": seq["hyd"], "steps": a.steps}
         # how much of this rests on the day-to-day persistence of the forcing: the same pipeline with half, and with none, of
         # the rows keeping their magnitude from one day to the next (the plan stays the one tuned on day N)
-        persist = None
         if not a.headline_only and not a.no_persistence_sweep:
             persist = {}
             for pv in (0.5, 0.0):
@@ -624,11 +625,7 @@ def main():
                     r2.append(ring[i])                # (the page-locked arrays of the headline's ring are reused)
                     ring[i][...] = day
                     prev_day = day
-                os.environ["TRMC_SETUP_ASIDE"] = "1"
-                try:
-                    s2 = sequence_of_days(router.plan0, plan_b, r2, state_n, outlets_rs, a, 4, 1)
-                finally:
-                    os.environ.pop("TRMC_SETUP_ASIDE", None)
+                s2 = dayseq.run(r2, state_n, 4, 1)
                 persist[str(pv)] = {"ms_per_day": s2["el"] / 4 * 1e3,
                                     "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / (s2["el"] / 4) / 1e9 / HBM_PEAK_GBS}
             persist["what"] = ("the timed pipeline on the same tuned plan with days whose rows keep their forcing magnitude with "
@@ -648,8 +645,9 @@ def main():
             json_out.write(json.dumps({"metric": "segment-timesteps/sec, CONUS NHD 2.7M-seg MC", "value": rate(head),
                                        "unit": "segment-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                                        "ms_per_step": head["el"] / a.steps * 1e3, "ms_main": head["ms_main"],
-                                       "headline_only": True, "day_ms": None if seq is None else seq["day_ms"]}) + "\n")
+                                       "headline_only": True, "day_ms": seq["day_ms"]}) + "\n")
             json_out.flush()
+        dayseq.close()
         router.close()
         if comm is not None:
             comm.close()
@@ -657,17 +655,19 @@ def main():
     parity = None
     # (a multi-rank job: the checker runs on rank 0 alone and takes a minute or two -- AFTER the last leg the ranks take
     # together, below; the other ranks would give up at a barrier in the meantime)
-    dist_outlets = (np.array(router._out_rows, copy=True), hyd) if use_dist and rank == 0 else None
+    dist_outlets = None
+    if use_dist and not a.no_parity_full and a.precision == 32:
+        # the first two days of the timed sequence once more, untimed, from the state after day N: the all-gathered outlet block
+        # of day N+2 is what rank 0 hands to the checker (AFTER the last leg the ranks take together)
+        chk = dayseq.run(local_ring[:2], state_n, 2, 0, prepared=True)
+        if rank == 0:
+            dist_outlets = (np.array(router._out_rows, copy=True), np.array(chk["hyd"], copy=True))
     if rank == 0 and not a.no_parity_full and a.precision == 32 and not use_dist:
         try:      # against the reference on the CPU (checker use, outside the clock)
             # the timed pipeline once more, untimed, over the first two days of the ring (days N+1 and N+2 from the state
             # after day N: plan and clone, staged forcing, state handed over on the device, asynchronous fetch), and the
             # reference on the CPU through ALL the days from the cold start: N-1, N, N+1, N+2
-            os.environ["TRMC_SETUP_ASIDE"] = "1"
-            try:
-                chk = sequence_of_days(router.plan0, plan_b, ring[:2], state_n, outlets_rs, a, 2, 0)
-            finally:
-                os.environ.pop("TRMC_SETUP_ASIDE", None)
+            chk = dayseq.run(ring[:2], state_n, 2, 0)
             parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
                                  outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
                                  final_fetched=chk["final"])
@@ -675,20 +675,28 @@ def main():
                                   "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
         except Exception as e:
             parity = {"error": repr(e)}
-    if not use_dist:
-        plan_b.close()
-        router.upload(a.nsteps, qlat_b, state_n)     # (the legs below route day N+1 again and again on the one plan)
-    resident = timed(router, True, max(1, min(a.steps, 3)), 1)
-    two = None
-    if not use_dist and not a.no_two_members:   # (after the parity sample: this leg routes other days on the timed plan)
+    dayseq.close()
+    # ---- the same sequence in TOLERANCE arithmetic (trmc_plan_options.arithmetic; never the headline) -----------------------
+    tolerance = None
+    if not use_dist and not a.no_tolerance and a.precision == 32:
         try:
-            two = two_members(router, lambda: make_router(hint, True, qlat_s, q0), spin_up, qlat_b, a, rate_of=segsteps_job)
+            rt = make_router(hint, True, qlat_a, state_n, options={"arithmetic": "tolerance"})
+            with DaySequence(rt, a.nsteps, a.qts) as ts:
+                ts.run(ring[:2], state_n, 2, 0)
+                tsteps = max(2, min(a.steps, 6))
+                s3 = ts.run(ring, state_n, tsteps, 1)
+            per = s3["el"] / tsteps
+            tolerance = {"value": nseg * a.nsteps / per, "unit": "segment-timesteps/s", "ms_per_step": per * 1e3, "steps": tsteps,
+                         "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / per / 1e9 / HBM_PEAK_GBS,
+                         "outlet_hydrographs_rel_max_vs_exact": None,
+                         "what": "the headline's pipeline and days on a plan created with TRMC_ARITH_TOLERANCE (hardware log2 / exp2 power, "
+                                 "reciprocal-multiply division): not bit-comparable; stated tolerance and its test: include/trmc.h, "
+                                 "tests/test_gpu_tolerance.py, profiles/r05_tolerance_report.json"}
+            rt.close()
         except Exception as e:
-            two = {"error": repr(e)}
-        if os.environ.get("TRMC_BENCH_STOP_AFTER_TWO"):     # (a kernel trace of that leg: tools/trace_two.sh)
-            print(json.dumps(two), file=sys.stderr)
-            router.close()
-            raise SystemExit(0)
+            tolerance = {"error": repr(e)}
+    router.upload(a.nsteps, qlat_b, None if use_dist else state_n)   # (the legs below route day N+1 again and again on the one plan)
+    resident = timed(router, True, max(1, min(a.steps, 3)), 1)
     value = rate(head)
     info = router.plan0.info()
     stats = head["stats"]
@@ -699,7 +707,7 @@ def main():
         allr = comm.all_gather_host(np.array([head["ms_main"], float(seg0)], dtype=np.float64))
         per_rank = [{"rank": i, "ms_main": float(t[0]), "segment_steps": int(t[1])} for i, t in enumerate(allr)]
 
-    extra = {"two_members": two, "value_resident": {"value": rate(resident), "unit": "segment-timesteps/s",
+    extra = {"value_tolerance": tolerance, "value_resident": {"value": rate(resident), "unit": "segment-timesteps/s",
                                 "ms_per_step": resident["el"] / resident["steps"] * 1e3, "ms_main": resident["ms_main"],
                                 "what": "the same windows with every result left in HBM (no copy to the host in the clock)"},
              "copied_per_step": f"outlet hydrographs [{len(net['net_sizes'])} x {a.nsteps}] + final state [{nseg} x 3] into page-locked "
@@ -880,221 +888,6 @@ def main():
         line.update(extra)
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
-
-
-def sequence_of_days(plan_a, plan_b, days, state0, outlets_rs, a, steps, warmup):
-    """The headline's pass: ONE sequence of consecutive routing windows ("days") with DISTINCT forcing on one network, what
-    an operational cycle does -- every day's forcing arrives from host memory inside the clock, the state is handed from day
-    to day in HBM, and every day's products (outlet hydrographs + final state, SURVEY 8d's throughput mode) reach page-locked
-    host arrays inside the clock.  The days take turns on a plan and its clone (trmc_plan_clone: ONE copy of the topology
-    and parameter columns in HBM, two sets of window buffers): while day w is routed, day w + 1's forcing travels to the idle
-    set on its copy stream (trmc_stage_forcing, from page-locked memory -- where a caller would have read the forcing file
-    to), its state is handed over on the device (trmc_plan_chain_from) and its window is queued, so that its leading levels
-    start while day w's narrow levels are finishing; day w - 1's products are copied to the host beside.
-    `days`: a ring of distinct page-locked forcing arrays, used in turn (the state evolves on: no two windows are the same
-    work).  Times EXACTLY `steps` windows after `warmup` untimed ones; returns wall seconds, per-window device times, the
-    last day's products, and how many days were routed before (for the checker)."""
-    import time as _t
-    from troute_amd import comm as X
-    plans = [plan_a, plan_b]
-    nsteps, qts = a.nsteps, a.qts
-    nd = len(days)
-
-    def queue(p):
-        p.route_begin(nsteps, qts, True)
-        p.route_advance(nsteps)
-    total = warmup + steps
-    plan_a.upload_forcing(nsteps, days[0], state0)          # the first day of the sequence the ordinary way (synchronous)
-    if total > 1:
-        plan_b.stage_forcing(nsteps, days[1 % nd])
-    ms_main, got, ends = [], None, []
-    dbg = [] if os.environ.get("TRMC_BENCH_DEBUG") else None
-    tz = _t.perf_counter()
-
-    def mark(what):
-        if dbg is not None:
-            dbg.append(f"{what}@{(_t.perf_counter() - tz) * 1e3:.2f}")
-    t0 = _t.perf_counter() if warmup == 0 else None          # (no warm-up day: the clock starts with day 0's window)
-    # Everything a day needs is queued in one go, in the order the hardware queues should see it: the window; BEHIND its
-    # last launch the gathers of its products and their copy to the host; behind its set-up the forcing of this plan's
-    # NEXT day (two days ahead: the staging area is only read by a window's set-up).
-    nofetch = bool(os.environ.get("TRMC_BENCH_NO_FETCH"))    # (experiment: what does the copy of the products cost?)
-    # The call that queues a window's copies to the host returns when the window has ended (hipMemcpyAsync device-to-host
-    # behind a pending dependence keeps its caller, csrc/trmc.hip trmc_fetch_begin).  TRMC_BENCH_FETCH_THREAD=1 makes it from
-    # a helper thread, so that the main thread queues the next day while this one runs -- measured: 16.2 ms per day either
-    # way (a day's narrow levels can only start when the day before has ended; queueing earlier does not end it earlier).
-    import concurrent.futures
-    aux = concurrent.futures.ThreadPoolExecutor(1) if os.environ.get("TRMC_BENCH_FETCH_THREAD", "0") == "1" else None
-    pending = [None, None]
-
-    def after_window(i, w):
-        """behind day w's window on plan i: its products to the host, then the forcing of the plan's next day (w + 2)"""
-        if not nofetch:
-            plans[i].fetch_begin(outlets_rs[i], True)
-        if w + 2 < total:
-            plans[i].stage_forcing(nsteps, days[(w + 2) % nd])
-
-    def settle(i):
-        if pending[i] is not None:
-            pending[i].result()
-            pending[i] = None
-    queue(plan_a)
-    if aux is not None:
-        pending[0] = aux.submit(after_window, 0, 0)
-    else:
-        after_window(0, 0)
-    for w in range(1, total + 1):
-        cur, prev = plans[w % 2], plans[(w - 1) % 2]
-        if w < total:
-            mark(f"[day{w}")
-            settle(w % 2)                                    # (this plan's last fetch and staging calls have returned)
-            cur.chain_from(prev)                             # day w starts where day w - 1 ends: handed over in HBM
-            mark("chained")
-            queue(cur)
-            mark("window")
-            if aux is not None:
-                pending[w % 2] = aux.submit(after_window, w % 2, w)
-            else:
-                after_window(w % 2, w)
-            mark(f"queued{w}]")
-        st = prev.route_end()                                # day w - 1 is through
-        ends.append(_t.perf_counter())
-        mark(f"ended{w - 1}({st['ms_main']:.1f})")
-        if w - 1 >= warmup:
-            ms_main.append(st["ms_main"])
-        settle((w - 1) % 2)
-        got = prev.fetch_wait() if not nofetch else (np.zeros((1, 1), np.float32), None)   # ... and its products are on the host
-        mark(f"fetched{w - 1}")
-        if w == warmup and warmup > 0:                       # the clock starts when the last warm-up day is through
-            t0 = _t.perf_counter()
-    X.device_synchronize(0)
-    el = _t.perf_counter() - t0
-    if aux is not None:
-        aux.shutdown()
-    if dbg is not None:
-        print("[sequence] host timeline ms: " + " ".join(dbg), file=sys.stderr)
-    day_ms = [round((b - a_) * 1e3, 2) for a_, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
-    return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total, "last_plan": plans[(total - 1) % 2],
-            "day_ms": day_ms}
-
-
-def two_members(router_a, make_b, spin_up, qlat, a, rate_of):
-    """Two ensemble members of the same network on ONE device, taking turns window by window: member B's window is queued
-    while member A's is still running (trmc_route_begin / _advance / _end: the asynchronous form of a window), so B's wide
-    tiles start behind A's tiles -- while A's tail, which ends a window alone on a half-idle device, is still running -- and
-    B's tail follows A's.  Two independent routing runs (the NWM's ensemble configurations are that), NOT a faster single
-    sequence of days: a window of one member still needs the state its previous window left.  Reports the aggregate rate
-    with every result left in HBM, to set beside `value_resident`."""
-    import time as _t
-    from troute_amd import comm as X
-    os.environ["TRMC_SETUP_ASIDE"] = "1"
-    try:
-        rb = make_b()
-        spin_up(rb, True)
-        rb.upload(a.nsteps, qlat, None)
-        pa, pb = router_a.plan0, rb.plan0
-
-        def queue(p):
-            p.route_begin(a.nsteps, a.qts, True)
-            p.route_advance(a.nsteps)
-        for p in (pa, pb):                      # one window each, alone (the tile stream exists from here on)
-            queue(p)
-            p.route_end()
-        queue(pa)
-        queue(pb)
-        pa.route_end()
-        pb.route_end()
-        X.device_synchronize(0)
-        n = max(2, min(a.steps, 4))
-        t0 = _t.perf_counter()
-        log = []
-
-        def mark(what):
-            log.append((what, round((_t.perf_counter() - t0) * 1e3, 2)))
-        queue(pa)
-        mark("A queued")
-        ms_a, ms_b = [], []
-        for _ in range(n):
-            queue(pb)
-            mark("B queued")
-            ms_a.append(pa.route_end()["ms_main"])
-            mark("A ended")
-            queue(pa)
-            mark("A queued")
-            ms_b.append(pb.route_end()["ms_main"])
-            mark("B ended")
-        ms_a.append(pa.route_end()["ms_main"])
-        mark("A ended")
-        if os.environ.get("TRMC_BENCH_DEBUG"):
-            print("[two_members] host timeline ms:", log, file=sys.stderr)
-        X.device_synchronize(0)
-        el = _t.perf_counter() - t0
-        windows = 2 * n + 1
-        same = np.array_equal(pa.gather_flow_rows(router_a.my_out0_local).view(np.uint32),
-                              pb.gather_flow_rows(rb.my_out0_local).view(np.uint32))
-        per = el / windows * 1e3
-        out = {"value": rate_of * windows / el, "unit": "segment-timesteps/s (both members together)", "windows": windows,
-               "ms_per_window": per,
-               "roofline_frac": rate_of * ALG_BYTES_PER_SEGSTEP / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
-               "members_identical": bool(same),
-               "what": "two independent members of the same network take turns on the device, a window of one queued while "
-                       "the other's is running; results left in HBM; wall clock over all windows"}
-        # ---- ONE sequence of days on the two plans (trmc_plan_chain_from): window w + 1 starts from the state window w
-        # leaves, handed over on the device in two parts, and is queued while window w is still running.  The days repeat
-        # the timed day's forcing; the state evolves.  Checked against the same days routed one after the other on ONE plan.
-        s0 = pa.download_final_state()
-        m = 2 * n + 1
-        plans = [pa, pb]
-        for p in plans:
-            p.upload_forcing(a.nsteps, qlat, s0)
-        queue(pa)
-        pb.chain_from(pa)
-        queue(pb)
-        pa.route_end()
-        pb.route_end()                                   # (warm: two chained windows, untimed)
-        for p in plans:
-            p.upload_forcing(a.nsteps, qlat, s0)
-        X.device_synchronize(0)
-        t0 = _t.perf_counter()
-        queue(pa)
-        ms_chain, ms_ref = [], []
-        for w in range(1, m):
-            cur, prev = plans[w % 2], plans[(w - 1) % 2]
-            cur.chain_from(prev)
-            queue(cur)
-            ms_chain.append(round(prev.route_end()["ms_main"], 2))
-        last = plans[(m - 1) % 2]
-        ms_chain.append(round(last.route_end()["ms_main"], 2))
-        X.device_synchronize(0)
-        el2 = _t.perf_counter() - t0
-        got_state = last.download_final_state()
-        got_hyd = last.gather_flow_rows(router_a.my_out0_local)
-        # the reference: the same m days on plan A alone, each continuing from the one before
-        pa.upload_forcing(a.nsteps, qlat, s0)
-        t1 = _t.perf_counter()
-        for w in range(m):
-            ms_ref.append(round(pa.route_device(a.nsteps, a.qts, True)["ms_main"], 2))
-            if w < m - 1:
-                pa.upload_forcing(a.nsteps, qlat, None)
-        X.device_synchronize(0)
-        el_ref = _t.perf_counter() - t1
-        ok = (np.array_equal(pa.download_final_state().view(np.uint32), got_state.view(np.uint32))
-              and np.array_equal(pa.gather_flow_rows(router_a.my_out0_local).view(np.uint32), got_hyd.view(np.uint32)))
-        per2 = el2 / m * 1e3
-        out["sequence_on_two_plans"] = {
-            "value": rate_of * m / el2, "unit": "segment-timesteps/s", "windows": m, "ms_per_window": per2,
-            "roofline_frac": rate_of * ALG_BYTES_PER_SEGSTEP / (per2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "ms_per_window_on_one_plan": el_ref / m * 1e3,
-            "identical_to_the_sequence_on_one_plan": bool(ok),
-            "ms_main_of_each_window": ms_chain, "ms_main_of_each_window_on_one_plan": ms_ref,
-            "what": "ONE sequence of days (the timed day's forcing repeated, the state carried from day to day) on two plans "
-                    "taking turns: a day starts from the state the day before leaves, handed over on the device, and is queued "
-                    "while that day is still running; results left in HBM; the one-plan figure includes re-staging the "
-                    "forcing every day"}
-        rb.close()
-        return out
-    finally:
-        os.environ.pop("TRMC_SETUP_ASIDE", None)
 
 
 def pmc_counters(pattern, launches_per_window, args):

@@ -37,13 +37,14 @@
 #ifndef TRMC_H
 #define TRMC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 15
+#define TRMC_ABI_VERSION 16
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -80,10 +81,12 @@ typedef struct trmc_stats {
      * launch by k_mc_tile (0: every level one step per launch) */
     int32_t wide_levels, wide_k;
     int32_t wide_launches;   /* launches of k_mc_tile (part of main_launches)  */
-    int32_t window_kernel;   /* 1: the window went out as ONE persistent launch (k_mc_window: the leading wide_levels levels wide_k
-                              * timesteps per work item, the deeper levels one timestep per item, no transposing pass) */
-    int64_t wide_segment_steps; /* segment-steps routed by those launches     */
-    double ms_wide;          /* summed duration of those launches (they run beside the tail's, so this is not a share of ms_main) */
+    int32_t mid_levels;      /* ... and the `mid_levels` levels right below them `mid_k` steps per launch (second tier; 0: none) */
+    int64_t wide_segment_steps; /* segment-steps routed by the launches of both tiers */
+    double ms_wide;          /* summed duration of the first tier's launches (they run beside the tail's, so this is not a share of ms_main) */
+    int32_t mid_k, mid_launches;
+    int32_t arithmetic;      /* TRMC_ARITH_EXACT / TRMC_ARITH_TOLERANCE of the plan */
+    int32_t reserved0;
 } trmc_stats;
 
 const char *trmc_last_error(void);
@@ -135,12 +138,65 @@ int trmc_plan_create_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *
  *           knows it (compute_nhd_routing_v02 does).  A plan routes correctly in either mode whatever it was built for;
  *           the flag chooses the row order that is fast for that mode (block order with cost tiers for the first, plain
  *           sub-tree blocks for the second and when unknown).
- * The environment variable TRMC_ENGINE=levels|flow overrides TRMC_ENGINE_AUTO (A/B measurements). */
+ * (troute_amd.plan maps the environment variable TRMC_ENGINE=levels|flow onto the engine flag of an "auto" plan: A/B runs.) */
 enum { TRMC_ENGINE_AUTO = 0, TRMC_ENGINE_LEVELS = 1, TRMC_ENGINE_FLOW = 2, TRMC_ENGINE_MASK = 3,
        TRMC_PLAN_SHORT_TS = 4, TRMC_PLAN_FULL_TS = 8 };
 int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                         const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
                         int precision, int device, int flags, trmc_plan **out);
+/* The same with OPTIONS (ABI 16): everything that used to be an environment variable read inside the library is a
+ * field here, read ONCE when the plan is created (a clone inherits them).  A NULL pointer or a zero-filled struct means
+ * the defaults; struct_size = sizeof(trmc_plan_options) lets the struct grow.  The library itself reads no environment
+ * variable that decides how a plan routes (the Python host layer maps its documented TRMC_* test / measurement variables
+ * onto this struct, troute_amd/plan.py).
+ *   arithmetic     TRMC_ARITH_EXACT (0): every segment-step bit-identical to the reference Fortran (fp32: glibc's powf
+ *                  restated, IEEE division and square root; fp64: glibc's pow restated).
+ *                  TRMC_ARITH_TOLERANCE (1), precision 32 only: hardware log2 / exp2 power, reciprocal-multiply division,
+ *                  hardware square root -- each within one unit in the last place, NOT bit-comparable.  Stated tolerance
+ *                  against the reference (tests/test_gpu_tolerance.py): one segment-step rtol 2e-6 (+ 1e-9
+ *                  absolute) on q, velocity and depth wherever the secant iteration takes the same number of iterations; a
+ *                  routed day: 99.9 % of all (row, step) flows within rtol 1e-4 + atol 1e-6 m3/s, every flow within the
+ *                  1 % the iteration's own exit test allows a depth to move (MCsingleSegStime_f2py_NOLOOP.f90:83).
+ *   wide_min_rows  rows a leading level must have to be routed wide_k steps per launch (k_mc_tile); 0 = default (384 per
+ *                  compute unit), < 0 = never.  wide_levels: at most so many (0 = default 16).  wide_k: 0 = default 16.
+ *   mid_min_rows   the same for the SECOND tier: the levels right below the wide ones, mid_k steps per launch under their
+ *                  own skew; 0 = default, < 0 = never.  mid_levels (0 = default), mid_k (0 = default).
+ *   tile_perm_group  rows re-dealt to the threads of a wide tile by the cost class they showed in the tile before, inside
+ *                  groups of so many positions (a multiple of 256 up to 1024); 0 = default (256 on a plan created with a
+ *                  cost hint, off otherwise), < 0 = off.
+ *   tail_sort      < 0: keep the per-level order below the tiled levels of a hinted short-timestep plan (default: by cost).
+ *   stem_min_rows  general-mode dataflow plans: basins whose longest path has at least so many rows are laid out stem-last
+ *                  (0 = default 1 024, < 0 = off).
+ *   sequence_mode  != 0: the plan is one of several that take turns on the device (trmc_plan_clone, trmc_plan_chain_from):
+ *                  a window's set-up is queued on the tile stream and its end with its last launch, so that another plan's
+ *                  launches in the shared hardware queues do not hold it back.  Also trmc_plan_set_sequence_mode.
+ *   flow_watchdog_ms  how long a poll of the dataflow engine may wait before the window is abandoned (0 = default 30 000).
+ *   flow_overlap   != 0: consecutive time chunks of a dataflow window alternate between two compute streams.
+ *   flow_lean      0 = automatic, > 0 always, < 0 never: the lean form of the dataflow kernel. */
+enum { TRMC_ARITH_EXACT = 0, TRMC_ARITH_TOLERANCE = 1 };
+typedef struct trmc_plan_options {
+    int32_t struct_size;
+    int32_t arithmetic;
+    int64_t wide_min_rows;
+    int32_t wide_levels, wide_k;
+    int64_t mid_min_rows;
+    int32_t mid_levels, mid_k;
+    int32_t tile_perm_group;
+    int32_t tail_sort;
+    int32_t stem_min_rows;
+    int32_t sequence_mode;
+    int32_t flow_watchdog_ms;
+    int32_t flow_overlap;
+    int32_t flow_lean;
+    int32_t reserved[9];
+} trmc_plan_options;
+int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
+                         const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
+                         int precision, int device, int flags, const trmc_plan_options *options, trmc_plan **out);
+/* Switch the sequence mode of a plan (see trmc_plan_options) between windows. */
+int trmc_plan_set_sequence_mode(trmc_plan *plan, int on);
+/* 1 if the plan computes in TRMC_ARITH_TOLERANCE, else 0. */
+int trmc_plan_arithmetic(const trmc_plan *plan, int32_t *arithmetic);
 /* 1 if the plan runs on the dataflow engine, 0 on the level engine. */
 int trmc_plan_engine(const trmc_plan *plan, int32_t *is_flow);
 void trmc_plan_destroy(trmc_plan *plan);
@@ -382,6 +438,9 @@ int trmc_route(trmc_plan *plan, int nsteps, int qts_subdivisions, int assume_sho
  * as reach.pyx:55 passes it.
  */
 int trmc_segments(int device, int precision, int64_t n, const void *in, void *out);
+/* The same in a chosen arithmetic (TRMC_ARITH_EXACT / TRMC_ARITH_TOLERANCE, see trmc_plan_options), and -- iters_out [n]
+ * or NULL -- the secant iterations every step took (f90:83-134, all retries together; 0 where nothing was routed). */
+int trmc_segments_ex(int device, int precision, int arithmetic, int64_t n, const void *in, void *out, int32_t *iters_out);
 
 /*
  * [R3] with its own signature: the reference's bind(c) entry point of one segment-step,
@@ -401,7 +460,7 @@ void trmc_muskingcungenwm(float *dt, float *qup, float *quc, float *qdp, float *
  * the receiving plan's next window starts from the state the source plan's window leaves, handed over on the device --
  * the rows of the source's leading ("wide") levels behind its last tile, on the receiver's tile stream, the others behind
  * its tail, on the receiver's own stream -- so that the receiver's tiles can run while the source's tail is still
- * finishing its window (with TRMC_SETUP_ASIDE=1).  The source's window must have been queued to its
+ * finishing its window (both plans in sequence mode: trmc_plan_options.sequence_mode).  The source's window must have been queued to its
  * end (trmc_route_advance to nsteps); the receiver must have its forcing staged; the next trmc_route_begin of the receiver
  * takes the handed-over state instead of the one staged with its forcing.  Level engine only.
  */
@@ -423,8 +482,9 @@ int trmc_plan_clone(trmc_plan *plan, trmc_plan **out);
  * whatever the device is routing; the next trmc_route_begin orders its set-up behind the copy.  The initial state is what
  * trmc_plan_chain_from hands over, else the state the plan's last window left (q0 = NULL of trmc_upload_forcing).  The
  * caller's counterpart in the reference: qlat_values arrives with every compute_network_structured call
- * (mc_reach.pyx:173,:723), the state through AbstractNetwork.new_q0 (AbstractNetwork.py:177-191).  Plans without
- * boundary rows.  The plan is idle (its last window ended), or routing a window that has been queued to its end -- the
+ * (mc_reach.pyx:173,:723), the state through AbstractNetwork.new_q0 (AbstractNetwork.py:177-191).  A plan with
+ * boundary rows gets their hydrographs of the staged window afterwards (trmc_set_boundary_flow_device before the
+ * window begins, or trmc_set_boundary_flow_range while it runs).  The plan is idle (its last window ended), or routing a window that has been queued to its end -- the
  * staging area is only read by a window's set-up, so the copy goes behind that; a state must then come from
  * trmc_plan_chain_from.
  */

@@ -24,12 +24,66 @@ class Stats(C.Structure):
         ("nseg", C.c_int64), ("nseg_routed", C.c_int64), ("nlevels", C.c_int32), ("nsteps", C.c_int32),
         ("assume_short_ts", C.c_int32), ("main_launches", C.c_int32), ("segment_steps", C.c_int64),
         ("ms_prep", C.c_double), ("ms_main", C.c_double), ("ms_emit", C.c_double), ("ms_total", C.c_double),
-        ("wide_levels", C.c_int32), ("wide_k", C.c_int32), ("wide_launches", C.c_int32), ("window_kernel", C.c_int32),
-        ("wide_segment_steps", C.c_int64), ("ms_wide", C.c_double),
+        ("wide_levels", C.c_int32), ("wide_k", C.c_int32), ("wide_launches", C.c_int32), ("mid_levels", C.c_int32),
+        ("wide_segment_steps", C.c_int64), ("ms_wide", C.c_double), ("mid_k", C.c_int32), ("mid_launches", C.c_int32),
+        ("arithmetic", C.c_int32), ("reserved0", C.c_int32),
     ]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PlanOptions(C.Structure):
+    """trmc_plan_options (include/trmc.h): a zero-filled struct means the defaults"""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("arithmetic", C.c_int32), ("wide_min_rows", C.c_int64), ("wide_levels", C.c_int32),
+        ("wide_k", C.c_int32), ("mid_min_rows", C.c_int64), ("mid_levels", C.c_int32), ("mid_k", C.c_int32),
+        ("tile_perm_group", C.c_int32), ("tail_sort", C.c_int32), ("stem_min_rows", C.c_int32), ("sequence_mode", C.c_int32),
+        ("flow_watchdog_ms", C.c_int32), ("flow_overlap", C.c_int32), ("flow_lean", C.c_int32), ("reserved", C.c_int32 * 9),
+    ]
+
+
+ARITH_EXACT, ARITH_TOLERANCE = 0, 1
+# Environment variables the HOST layer maps onto trmc_plan_options when a plan is created (tests and A/B measurements; the
+# library itself reads none of them).  name -> (field, how): "off0" = the variable's 0 means "off" (the field's < 0), any
+# other number is the value; "int" = the number as it is; "flag" = 1 when the variable is "1".
+OPTION_ENV = {
+    "TRMC_WIDE_MIN_ROWS": ("wide_min_rows", "off0"), "TRMC_WIDE_LEVELS": ("wide_levels", "int"), "TRMC_WIDE_K": ("wide_k", "int"),
+    "TRMC_MID_MIN_ROWS": ("mid_min_rows", "off0"), "TRMC_MID_LEVELS": ("mid_levels", "int"), "TRMC_MID_K": ("mid_k", "int"),
+    "TRMC_TILE_PERM": ("tile_perm_group", "off0"), "TRMC_TAIL_SORT": ("tail_sort", "off0"),
+    "TRMC_STEM_MIN_ROWS": ("stem_min_rows", "off0"), "TRMC_SETUP_ASIDE": ("sequence_mode", "flag"),
+    "TRMC_FLOW_WATCHDOG_MS": ("flow_watchdog_ms", "int"), "TRMC_FLOW_OVERLAP": ("flow_overlap", "flag"),
+    "TRMC_FLOW_LEAN": ("flow_lean", "lean"),
+}
+
+
+def plan_options(options=None):
+    """A PlanOptions from the environment (OPTION_ENV, TRMC_ARITHMETIC=exact|tolerance) overridden by `options` (a dict of
+    field names; ``arithmetic`` may be "exact" / "tolerance")."""
+    o = PlanOptions()
+    o.struct_size = C.sizeof(PlanOptions)
+    for name, (field, how) in OPTION_ENV.items():
+        v = os.environ.get(name)
+        if v is None or v == "":
+            continue
+        n = int(v)
+        if how == "off0":
+            n = -1 if n == 0 else n
+        elif how == "flag":
+            n = 1 if n == 1 else 0
+        elif how == "lean":
+            n = 1 if n == 1 else -1
+        setattr(o, field, n)
+    a = os.environ.get("TRMC_ARITHMETIC")
+    if a:
+        o.arithmetic = {"exact": ARITH_EXACT, "tolerance": ARITH_TOLERANCE}[a]
+    for k, v in (options or {}).items():
+        if k == "arithmetic" and isinstance(v, str):
+            v = {"exact": ARITH_EXACT, "tolerance": ARITH_TOLERANCE}[v]
+        if not hasattr(o, k) or k in ("struct_size", "reserved"):
+            raise ValueError(f"unknown plan option {k!r}")
+        setattr(o, k, int(v))
+    return o
 
 
 _vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
@@ -42,6 +96,9 @@ SIGNATURES = {
     "trmc_plan_create": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _int, _P(_vp)]),
     "trmc_plan_create_hinted": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _P(_vp)]),
     "trmc_plan_create_ex": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _P(_vp)]),
+    "trmc_plan_create_opt": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _P(PlanOptions), _P(_vp)]),
+    "trmc_plan_set_sequence_mode": (_int, [_vp, _int]),
+    "trmc_plan_arithmetic": (_int, [_vp, _P(_i32)]),
     "trmc_plan_engine": (_int, [_vp, _P(_i32)]),
     "trmc_plan_destroy": (None, [_vp]),
     "trmc_topology_levels": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
@@ -82,6 +139,7 @@ SIGNATURES = {
     "trmc_get_stats": (_int, [_vp, _P(Stats)]),
     "trmc_route": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "trmc_segments": (_int, [_int, _int, _i64, _vp, _vp]),
+    "trmc_segments_ex": (_int, [_int, _int, _int, _i64, _vp, _vp, _vp]),
     "trmc_muskingcungenwm": (None, [_P(C.c_float)] * 21),
     "trmc_plan_chain_from": (_int, [_vp, _vp]),
     "trmc_plan_clone": (_int, [_vp, _P(_vp)]),

@@ -12,7 +12,8 @@ namespace trmc {
 
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows,
-                   bool cost_tiers, int32_t boundary_floor, int64_t wide_min_rows, int32_t wide_max_levels, int32_t stem_min_rows)
+                   bool cost_tiers, int32_t boundary_floor, int64_t wide_min_rows, int32_t wide_max_levels, int32_t stem_min_rows,
+                   int64_t mid_min_rows, int32_t mid_max_levels)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -488,6 +489,8 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
     if (cost_hint && wide_min_rows > 0 && wide_max_levels > 0) {
         int32_t W = 0;
         while (W < t.nlevels && W < wide_max_levels && (int64_t)(t.lvl_ptr[W + 1] - t.lvl_ptr[W]) >= wide_min_rows) ++W;
+        if (W > 0 && mid_min_rows > 0) // the second tier (topology.hpp): level slices as well
+            for (int32_t m = 0; W < t.nlevels && m < mid_max_levels && (int64_t)(t.lvl_ptr[W + 1] - t.lvl_ptr[W]) >= mid_min_rows; ++m) ++W;
         if (W > 0 && W < t.nlevels) {
             const int32_t p0 = t.lvl_ptr[W], p1 = t.lvl_ptr[t.nlevels];
             std::vector<int32_t> rows(t.row_of_pos.begin() + p0, t.row_of_pos.begin() + p1);

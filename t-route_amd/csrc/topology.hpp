@@ -78,6 +78,9 @@ struct Topology {
 // (then by level, then as inside a level): a wavefront holds rows of one cost class also where the levels are a hundred
 // rows wide and the per-level order mixed three classes in one wavefront (917 instructions per wavefront-step there
 // against 788 in the wider levels).  Topology::tail_from_level says where that part begins.
+// mid_min_rows / mid_max_levels: the level engine's SECOND tier -- up to mid_max_levels further levels of at least mid_min_rows
+// rows right below the wide ones, routed a few timesteps per launch under a skew of their own -- stays in level slices too;
+// the cost order begins below it.
 // stem_min_rows > 0 (block order without cost tiers: plans built for the GENERAL mode, where a row needs its upstream rows
 // at the SAME step and a chain of n rows cannot finish a window before n + nsteps dependent steps have run one after the
 // other): a basin whose STEM -- the longest path into its outlet: from the outlet upstream, always into the tributary of
@@ -91,6 +94,6 @@ struct Topology {
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr,
                    int32_t block_rows = 0, bool cost_tiers = true, int32_t boundary_floor = 0, int64_t wide_min_rows = 0,
-                   int32_t wide_max_levels = 0, int32_t stem_min_rows = 0);
+                   int32_t wide_max_levels = 0, int32_t stem_min_rows = 0, int64_t mid_min_rows = 0, int32_t mid_max_levels = 0);
 
 } // namespace trmc

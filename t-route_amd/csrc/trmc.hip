@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/trmc.h"
@@ -264,6 +265,57 @@ struct DevMathF {
 struct DevMathFlow : DevMathF {
     static constexpr bool kInbank = TRMC_FLOW_INBANK != 0;
 };
+// fp32, TOLERANCE arithmetic (a plan created with trmc_plan_options.arithmetic = TRMC_ARITH_TOLERANCE): the power as
+// exp2(y * log2(x)) on the hardware's v_log_f32 / v_exp_f32, every division as a * v_rcp_f32(b), the square root as
+// v_sqrt_f32 -- each within one unit in the last place of its exact result, the power within |y log2 x| 2**-23 (some 1e-6 for
+// a hydraulic radius between a millimetre and a hundred metres).  NOT bit-comparable with the reference: its results are
+// stated and tested against a tolerance (include/trmc.h, tests/test_gpu_tolerance.py), and the 1 % exit of the secant
+// iteration (MCsingleSegStime_f2py_NOLOOP.f90:83) turns a last-place difference into a different iteration count now and
+// then.  The special values the step relies on keep their meaning: log2(0) = -inf and exp2(-inf) = 0 (a dry point's
+// power is 0), a quotient by zero is inf or NaN and is discarded by the selects that guard it (mc_segment.hpp).
+struct DevMathTol {
+    const uint64_t *tab; // unused (no tables)
+    bool sane;
+    bool coef_ok;        // unused
+    using Log = float;
+    __device__ __forceinline__ Log log_of(float x) const { return __builtin_amdgcn_logf(x); }
+    __device__ __forceinline__ float pow_l(Log l, float, float y) const { return __builtin_amdgcn_exp2f(y * l); }
+    __device__ __forceinline__ float pow(float x, float y) const { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+    __device__ __forceinline__ Log log_of_r(float x, bool) const { return __builtin_amdgcn_logf(x); }
+    __device__ __forceinline__ float pow_l_r(Log l, float, float y, bool) const { return __builtin_amdgcn_exp2f(y * l); }
+    __device__ __forceinline__ float sqrt(float x) const { return __builtin_amdgcn_sqrtf(x); }
+    __device__ __forceinline__ float sqrt_r(float x, bool) const { return __builtin_amdgcn_sqrtf(x); }
+    __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
+    static constexpr bool kInbank = true;
+    // (the ranges under which the in-bank body of the hydraulic point stands for the general one are DevMathF's: its argument
+    // leaves a margin of 1 % on the sign of the celerity, far more than these operations give away)
+    __device__ __forceinline__ bool fast_ok(float h, float h_in, float h_over) const
+    {
+        return sane && h_in >= 0x1p-30f && h <= 0x1p17f && (h_over == 0.0f || h_over >= 0x1p-30f);
+    }
+    __device__ __forceinline__ float k_of(float dx, float ck) const { return dx * __builtin_amdgcn_rcpf(ck); }
+    __device__ __forceinline__ float max_num(float a, float b) const { return __builtin_fmaxf(a, b); }
+    __device__ __forceinline__ void div2(float a1, float a2, float b, bool, float &q1, float &q2) const
+    {
+        const float y = __builtin_amdgcn_rcpf(b);
+        q1 = a1 * y;
+        q2 = a2 * y;
+    }
+    __device__ __forceinline__ float div1(float a, float b, bool) const { return a * __builtin_amdgcn_rcpf(b); }
+    __device__ __forceinline__ float divx(float a, float b) const { return a * __builtin_amdgcn_rcpf(b); }
+    __device__ __forceinline__ void div4(float n1, float n2, float n3, float n4, float d, float &q1, float &q2, float &q3,
+                                         float &q4) const
+    {
+        const float y = __builtin_amdgcn_rcpf(d);
+        q1 = n1 * y;
+        q2 = n2 * y;
+        q3 = n3 * y;
+        q4 = n4 * y;
+    }
+};
+struct DevMathTolFlow : DevMathTol {
+    static constexpr bool kInbank = TRMC_FLOW_INBANK != 0;
+};
 // fp64: the bit-reproducible double power of det_pow64.h (glibc 2.35 pow restated, the one the reference links when it
 // is built with -fdefault-real-8: oracle/_ref/libmc_ref_qj0_f64.so), so that the fp64 path -- BASELINE configs[1] -- is
 // bit-comparable with the reference too, not merely close; / and sqrt are the correctly rounded forms.
@@ -315,9 +367,11 @@ __device__ __forceinline__ bool coef_guard(float dt, float ql)
     return (dt >= 0x1p-20f) && (dt <= 0x1p40f) && ((__float_as_uint(n4) == 0u) || (an4 >= 0x1p-60f && an4 <= 0x1p60f));
 }
 __device__ __forceinline__ bool coef_guard(double, double) { return false; }
-template <class T> struct DevMath;
-template <> struct DevMath<float> { using type = DevMathF; };
-template <> struct DevMath<double> { using type = DevMathD; };
+// TOL: the plan's arithmetic is TRMC_ARITH_TOLERANCE (fp32 plans only)
+template <class T, bool TOL = false> struct DevMath;
+template <> struct DevMath<float, false> { using type = DevMathF; };
+template <> struct DevMath<float, true> { using type = DevMathTol; };
+template <> struct DevMath<double, false> { using type = DevMathD; };
 
 constexpr int kBlock = 256;
 
@@ -385,8 +439,7 @@ template <class T> struct StepArgs {
     // kPermGroup, rebuilt before every tile from the cost class every row showed at the end of the tile before (k_tile_perm):
     // wavefronts hold rows of one class whatever the forcing does and however old the plan's cost hint is.
     const int32_t *tile_perm;
-    uint8_t *cls_last;
-    bool tail_direct; // k_mc_step<SHORT>: (q, v, d) of the step straight into out[row][step - 1][.] (no velocity plane, no k_emit for them) // cost class of every row at the last step it was routed in a tile: min(iterations, 3) + 4 if over bank
+    uint8_t *cls_last; // cost class of every row at the last step it was routed in a tile: min(iterations, 3) + 4 if over bank
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -416,12 +469,12 @@ constexpr int kStepBlock = TRMC_STEP_BLOCK;
 #else
 #define TRMC_STEP_ATTR
 #endif
-template <class T, bool SHORT, bool LAG = false>
+template <class T, bool SHORT, bool LAG = false, bool TOL = false>
 __global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES) TRMC_STEP_ATTR
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag, const int32_t ql_col)
 {   // ql_col: the lateral-inflow column (diag - 1) / qts of a launch whose rows are all at step diag (SHORT, no lag) -- formed
     // by the host: an integer division by a run-time divisor is some 35 instructions per thread
-    using M = typename DevMath<T>::type;
+    using M = typename DevMath<T, TOL>::type;
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     // Issue priority over whatever else is resident: beside the wide tiles (k_mc_tile) these launches are the narrow tail of
     // the level order -- 288 launches that wait for each other, the critical path of the window -- and a wavefront of theirs
@@ -515,12 +568,6 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 a.q_tm[row_c + s] = outflow;
                 a.v_tm[row_c + s] = T(0);
                 a.d_tm[row_c + s] = H;
-                if (SHORT && a.tail_direct) {
-                    T *o = a.out + ((size_t)a.row_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1)) * 3;
-                    o[0] = outflow;
-                    o[1] = T(0);
-                    o[2] = H;
-                }
                 a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
                 if (t == a.nsteps) a.it_prev[s] = 0;
                 return;
@@ -558,14 +605,7 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         asm volatile("" : "+v"(ob));
         at(a.q_tm + row_c, ob) = q_new;
         at(a.d_tm + row_c, ob) = r.depthc;
-        if (SHORT && a.tail_direct) { // 12 bytes per row and step; the neighbouring steps of a row meet in the L2 / Infinity Cache
-            T *o = a.out + ((size_t)a.row_of_pos[su] * (size_t)a.nsteps + (size_t)(t - 1)) * 3;
-            o[0] = q_new;
-            o[1] = r.velc;
-            o[2] = r.depthc;
-        } else {
-            at(a.v_tm + row_c, ob) = r.velc;
-        }
+        at(a.v_tm + row_c, ob) = r.velc;
         // (only trmc_download_iterations reads it, after the window: one byte-masked store per row and step would be
         // 3 % of the launch)
         if (t == a.nsteps) a.it_prev[su] = (uint8_t)min(r.iters, 255);
@@ -595,18 +635,20 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 // of every step (what downstream rows and the gathers read) and the depth row of a tile's last step (where the row's next
 // tile, or the final state, picks it up) are written.
 constexpr int kTileStage = 8;
-constexpr int32_t kWideMaxLevels = 16; // at most this many leading levels are routed by k_mc_tile (TRMC_WIDE_LEVELS is capped by it)
+constexpr int32_t kWideMaxLevels = 16; // at most this many leading levels are routed by k_mc_tile's first tier (wide_levels is capped by it)
+constexpr int32_t kMidMaxLevels = 32;  // ... and at most this many more by its second tier (mid_levels)
+constexpr int64_t kMidDefaultRowsPerCu = 0; // default threshold of the second tier in rows per compute unit; 0 = off unless asked for
 #ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow.  Measured on the CONUS day by
 // padding the blocks' LDS (TRMC_TILE_LDS_PAD) and by this cap: 1 wavefront per SIMD 36.7 ms, 2: 23.9, 3: 20.7, 3.5: 19.5,
 // 4: 18.45, 5 (95 registers, 4 spilled): 17.9, 6 (80 registers, 27 spilled): 19.4 -- the curve of a kernel that hides its
 // latencies with other wavefronts and is close to its issue limit at four
 #define TRMC_TILE_WAVES 5
 #endif
-template <class T>
+template <class T, bool TOL = false>
 __global__ void __launch_bounds__(kStepBlock, sizeof(T) == 4 ? TRMC_TILE_WAVES : 1)
 k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t tile, const int32_t K)
 {
-    using M = typename DevMath<T>::type;
+    using M = typename DevMath<T, TOL>::type;
     const ColdArgs<StepArgs<T>> cold = cold_args<StepArgs<T>>(); // (see cold_args: what the loop rarely needs is not kept in registers)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ T s_out[3 * kTileStage * kStepBlock]; // [step slot * 3 + c][thread]
@@ -794,527 +836,6 @@ k_tile_perm(const uint8_t *__restrict__ cls, int32_t *__restrict__ perm, const i
 #pragma unroll
     for (int j = 0; j < kPer; ++j)
         if (key[j] >= 0) perm[g0 + base[key[j]] + rank[j]] = g0 + j * kBlock + (int32_t)threadIdx.x;
-}
-
-// ---------------------------------------------------------------- the window kernel (fp32, assume_short_ts)
-// ONE persistent launch routes a whole short-timestep window: no kernel boundary per tile, none per timestep, no transposing
-// pass.  The launches it replaces (k_mc_tile x 22, k_mc_step x 288, k_emit x 9 on three streams for a CONUS day) lose a drain
-// at the end of every tile, a boundary and a ramp at every step of the tail, and end a window with the tail alone on a
-// half-idle device.
-//
-// Work items, one WAVEFRONT each (a workgroup is one wavefront: nothing in an item needs a barrier):
-//   * wide item (k, d): the 64 plan positions w0 + 64 k .. of the leading W levels through K timesteps -- a lane of level l
-//     routes the steps (tau K, tau K + K], tau = d - l, of its row: the level skew of k_mc_tile, d its launch index ("sub-
-//     diagonal").  Same body as k_mc_tile: the row's thirteen parameter / constant columns in registers for K steps,
-//     results staged in LDS and written as 96-byte runs of out[row][step][q,v,d];
-//   * tail item (i, t): the 64 positions w1 + 64 i .. of the deeper levels through ONE timestep t -- what k_mc_step does
-//     for them, with (q, v, d) written straight into `out` (12 bytes per row and step; neighbouring steps of a row meet
-//     in the L2 / Infinity Cache): the time-major planes keep the flow and the depth only.
-// With assume_short_ts a row at step t reads flows of step t - 1 (mc_reach.pyx:504-505, :135-136), hence:
-//   * item (k, d) needs item k itself and the items holding its rows' upstream rows to have completed sub-diagonal d - 1
-//     (an upstream row lies at least one level lower, so after d - 1 it is at least K steps ahead): every wide item keeps
-//     ONE progress word prog[k] = sub-diagonals completed (single writer), and a consumer's lanes look at the words of the
-//     items that hold their upstream rows;
-//   * the tail's step t ("phase") needs every tail row at t - 1 -- a count of completed items per phase -- and the wide rows
-//     at t - 1: prog >= (t - 2) / K + W for the items holding its lanes' wide upstream rows.
-// Scheduling: a worker (wavefront) loops: if the tail's next phase is open it claims a tail item, else a wide item in
-// sub-diagonal order; claims are atomic counters sharded by XCD (one word saturates near 88 claims per microsecond; 5 120
-// workers finishing items of 10-50 us need several hundred) with stealing from the other shards.  A wide item is claimed
-// only when every item of the sub-diagonal before is claimed, a tail item only when its phase's predecessor is complete
-// and every wide item it may wait for is claimed: whatever a claimed item waits for is running or done, by induction over
-// the claim order -- no deadlock whatever the dispatch order or the residency of the workers (MI355X_MICROARCH.md:
-// nothing may be assumed about either).  Every wait is bounded by a watchdog that abandons the window (TRMC_EHIP).
-// Visibility between workgroups inside a launch (per-XCD L2s are not coherent, a CU's L1 is never refreshed): everything a
-// later item reads -- q_tm, d_tm, the progress words, the counters -- is stored write-through and loaded past the L1
-// (relaxed agent-scope atomics: global_store / global_load ... sc1), a writer drains its stores (s_waitcnt vmcnt(0)) before
-// it signals; the MI355X guide's recipe R1 with the payload itself stored sc1.  `out`, the iteration bytes and the
-// reservoir / nudging series are only read after the launch.
-constexpr int kWinStage = 8;          // timesteps of (q, v, d) a lane stages in LDS before it writes a run of `out`
-constexpr int kWinShards = 8;         // claim counters per item group: one per XCD
-constexpr int32_t kWinMaxLevels = 64; // at most this many leading levels are routed as wide items
-struct WinArgs {
-    int32_t w0, w1, s1;       // wide positions [w0, w1), tail positions [w1, s1)
-    int32_t K, kshift, W;     // timesteps per wide item (a power of two, 1 << kshift); wide levels
-    int32_t ndiag;            // sub-diagonals: ceil(nsteps / K) + W - 1
-    int32_t nwide, ntail;     // wave-items
-    const int32_t *diag_first, *diag_count; // [ndiag] the wide items active in a sub-diagonal: [first, first + count)
-    const int32_t *col_of_step; // [nsteps + 1] lateral-inflow column (t - 1) / qts of step t
-    int32_t *prog;            // [nwide]
-    int32_t *tile_claim;      // [ndiag][kWinShards]
-    int32_t *tail_claim;      // [nsteps + 1][kWinShards]
-    int32_t *tail_done;       // [nsteps + 1][kWinShards] completed items of a phase, by the shard of the item
-    int32_t *tail_shards;     // [nsteps + 1] complete shards of a phase
-    int32_t *ctl;             // [0] tail phases complete  [1] sub-diagonals wholly claimed  [2] abort  [3] tail phases wholly claimed
-                              // [4..6] what the watchdog's victim was waiting for  [8..15] tallies of a TRMC_WIN_DEBUG build
-    uint64_t watchdog_ticks;  // wall_clock64 ticks (100 MHz) any single wait may last
-};
-struct WindowArgs {
-    StepArgs<float> a;        // (first member: cold_args reads the kernel-argument segment from offset 0)
-    WinArgs w;
-};
-using WinCold = ColdArgs<WindowArgs>;
-
-__device__ __forceinline__ int32_t win_ld(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void win_st(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float win_ldf(const float *base, uint32_t byte_off)
-{
-    return __hip_atomic_load(&at(base, byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void win_stf(float *base, uint32_t byte_off, float v)
-{
-    __hip_atomic_store(&at(base, byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Claim counters and completion counters sit on cache lines of their own (kWinPad words apart): device-scope atomics on
-// one line are served one after the other (a word saturates near 88 per microsecond), and eight shard counters in one
-// 32-byte group were ONE such line -- with every worker that found a phase exhausted probing all eight, a phase of 4 400
-// items cost 40 000 atomics on it: half a millisecond per timestep, the first build of this kernel ran 147 ms a window.
-constexpr int kWinPad = 32;
-// one item of a shard's counter: its index, or -1 when the shard has none left.  One lane looks first (a load does not
-// queue behind the line's atomics the way another atomic does) and only then takes a ticket; the result is uniform.
-__device__ __forceinline__ int32_t win_claim(int32_t *p, const int32_t len)
-{
-    int32_t r = -1;
-    if (threadIdx.x == 0 && win_ld(p) < len) {
-        r = atomicAdd(p, 1);
-        if (r >= len) r = -1;
-    }
-    return __builtin_amdgcn_readfirstlane(r);
-}
-// the four control words every worker reads before it claims anything, as ONE 16-byte load past the L1: [0] tail phases
-// complete, [1] sub-diagonals wholly claimed, [2] abort, [3] tail phases whose items are all claimed
-typedef int32_t win_int4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ win_int4 win_ld_ctl(const int32_t *ctl)
-{
-    win_int4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ctl) : "memory");
-    return v;
-}
-// a wait has lasted too long (or somebody else gave up): the window is abandoned
-__device__ __forceinline__ bool win_watchdog(uint32_t &polls, uint64_t &t_start, WinCold c, int32_t what, int32_t x, int32_t y)
-{
-    if ((++polls & 255u) != 0u) return false;
-    int32_t *const ctl = c->w.ctl;
-    if (t_start == 0) {
-        t_start = wall_clock64();
-        return win_ld(ctl + 2) != 0;
-    }
-    if (wall_clock64() - t_start > c->w.watchdog_ticks || win_ld(ctl + 2) != 0) {
-        if (threadIdx.x == 0 && atomicCAS(ctl + 2, 0, 1) == 0) {
-            ctl[4] = what;
-            ctl[5] = x;
-            ctl[6] = y;
-        }
-        return true;
-    }
-    return false;
-}
-
-// Everything an item needs of the kernel's arguments is read from the kernel-argument segment when the item STARTS, through
-// a pointer the compiler cannot see through (a fresh one per item): scalar loads from the constant cache, a few hundred
-// cycles once per item -- instead of forty pointers held in scalar registers across the scheduler loop, which spilled
-// (135 scalar and 39 vector registers in the first build of this kernel).
-__device__ __forceinline__ WinCold win_args_now(WinCold c)
-{
-    asm volatile("" : "+s"(c));
-    return c;
-}
-
-// the row's channel parameters and constants (plain loads: nothing writes them during a launch)
-__device__ __forceinline__ void win_load_channel(WinCold c, uint32_t ob, trmc::ChannelParams<float> &p, trmc::ChannelConst<float> &k)
-{
-    const float *const dt_col = c->a.dt_col;
-    p.dt = dt_col ? at(dt_col, ob) : c->a.dt;
-    asm volatile("" : "+v"(ob));
-    p.dx = at(c->a.dx, ob);
-    p.bw = at(c->a.bw, ob);
-    p.twcc = at(c->a.twcc, ob);
-    p.n = at(c->a.n, ob);
-    p.ncc = at(c->a.ncc, ob);
-    p.s0 = at(c->a.s0, ob);
-    p.tw = p.cs = 0.0f;
-    k.z = at(c->a.z, ob);
-    k.bfd = at(c->a.bfd, ob);
-    k.sqrt_s0 = at(c->a.sqrt_s0, ob);
-    k.sq1pz2 = at(c->a.sq1pz2, ob);
-    k.s0_n = at(c->a.s0_n, ob);
-    k.s0_ncc = at(c->a.s0_ncc, ob);
-    k.inv_n = at(c->a.inv_n, ob);
-    trmc::derive_const(k, p);
-}
-
-// junction sum of the flows of step t - 1 (`q_up` = that time row) in the reference's order (mc_reach.pyx:499-502); see
-// k_mc_step for the table of the first two upstream positions
-__device__ __forceinline__ float win_upstream_sum(WinCold c, const float *q_up, const int2 u, const uint32_t su)
-{
-    float qup = 0.0f;
-    if (u.x >= 0) qup += win_ldf(q_up, (uint32_t)u.x * 4u);
-    if (u.y >= 0) {
-        qup += win_ldf(q_up, (uint32_t)(u.y & 0x3fffffff) * 4u);
-        if (u.y & 0x40000000) {
-            const int32_t *const up_ptr = c->a.up_ptr, *const up_idx = c->a.up_idx;
-            const int32_t k1 = up_ptr[su + 1];
-            for (int32_t k = up_ptr[su] + 2; k < k1; ++k) qup += win_ldf(q_up, (uint32_t)up_idx[k] * 4u);
-        }
-    }
-    return qup;
-}
-
-// one timestep of one row: reservoir rows, the segment step, nudging (see k_mc_step); returns the iterations spent
-__device__ __forceinline__ int32_t win_step(WinCold c, DevMathF &m, const trmc::ChannelParams<float> &p, const trmc::ChannelConst<float> &k,
-                                            const int32_t ri, const int32_t gi, const int32_t t, const float qup, const float ql,
-                                            const float q_prev, const float d_prev, float &q_new, float &v_new, float &d_new)
-{
-    int32_t iters = 0;
-    if (ri >= 0) { // level-pool reservoir row
-        const float *rp = c->a.res_par + (size_t)ri * 9;
-        const trmc::LevelPoolParams<float> lp{rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], rp[8]};
-        float H = d_prev;
-        q_new = trmc::levelpool_step<float, DevMathF>(qup, 0.0f, c->a.res_dt, H, lp, m);
-        v_new = 0.0f;
-        d_new = H;
-        c->a.res_inflow[(size_t)ri * (size_t)c->a.nsteps + (size_t)(t - 1)] = qup;
-    } else {
-        trmc::Inflow<float> f;
-        f.qup = qup;
-        f.quc = qup;
-        f.qdp = q_prev;
-        f.ql = ql;
-        const trmc::StepResult<float> r = trmc::mc_segment_step<float, DevMathF>(p, k, f, d_prev, m);
-        q_new = r.qdc;
-        v_new = r.velc;
-        d_new = r.depthc;
-        iters = r.iters;
-        if (gi >= 0) { // streamflow nudging
-            const size_t e = (size_t)gi * (size_t)c->a.nsteps + (size_t)(t - 1);
-            const float *const da_a = c->a.da_a;
-            const uint8_t mode = c->a.da_mode[e];
-            float nudge = 0.0f;
-            if (mode == 1) {
-                nudge = da_a[e] - q_new;
-                q_new = da_a[e];
-            } else if (mode == 2) {
-                nudge = (da_a[e] - q_new) * c->a.da_w[e];
-                q_new = q_new + nudge;
-            }
-            c->a.da_nudge[e] = nudge;
-        }
-    }
-    return iters;
-}
-
-// have the wide items that hold this lane's upstream rows completed `need` sub-diagonals?  (rows below w0 are boundary
-// rows, rows from w1 on tail rows: neither has a progress word)
-__device__ __forceinline__ bool win_upstream_ready(WinCold c, const int2 u, const int32_t s, const int32_t need)
-{
-    const int32_t w0 = c->w.w0, w1 = c->w.w1;
-    const int32_t *const prog = c->w.prog;
-    bool ok = true;
-    if (u.x >= w0 && u.x < w1) ok = ok && win_ld(prog + ((u.x - w0) >> 6)) >= need;
-    if (u.y >= 0) {
-        const int32_t uy = u.y & 0x3fffffff;
-        if (uy >= w0 && uy < w1) ok = ok && win_ld(prog + ((uy - w0) >> 6)) >= need;
-        if (u.y & 0x40000000) {
-            const int32_t *const up_ptr = c->a.up_ptr, *const up_idx = c->a.up_idx;
-            const int32_t k1 = up_ptr[s + 1];
-            for (int32_t k = up_ptr[s] + 2; k < k1; ++k) {
-                const int32_t uk = up_idx[k];
-                if (uk >= w0 && uk < w1) ok = ok && win_ld(prog + ((uk - w0) >> 6)) >= need;
-            }
-        }
-    }
-    return ok;
-}
-
-// A wide item: 64 positions of the leading levels, K timesteps each (a lane of level l: the steps (tau K, tau K + K],
-// tau = d - l).  k_mc_tile's body with the state exchanged through write-through stores and L1-bypassing loads.
-// Returns false when the window has been abandoned.
-__device__ __forceinline__ bool win_item_wide(WinCold cold, DevMathF &m, float *s_out, const int32_t item, const int32_t d)
-{
-    const WinCold c = win_args_now(cold);
-    const int32_t lane = (int32_t)threadIdx.x;
-    const int32_t nsteps = c->a.nsteps, K = c->w.K, kshift = c->w.kshift;
-    const int32_t ntau = (nsteps + K - 1) >> kshift;
-    const int32_t s = c->w.w0 + item * 64 + lane;
-    const bool valid = s < c->w.w1;
-    const int32_t sv = valid ? s : c->w.w0; // (a position that exists, for the lanes beyond the last wide row)
-    const uint32_t su = (uint32_t)sv;
-    const int32_t tau = valid ? d - c->a.level[su] : -1;
-    const bool active = valid && tau >= 0 && tau < ntau;
-    const int2 u = c->a.up2[su];
-    {   // itself and the items holding its rows' upstream rows through sub-diagonal d - 1
-        uint32_t polls = 0;
-        uint64_t t0 = 0;
-        const int32_t *const mine = c->w.prog + item;
-        while (!__all(win_ld(mine) >= d && (!active || win_upstream_ready(c, u, sv, d)))) {
-            __builtin_amdgcn_s_sleep(8);
-            if (win_watchdog(polls, t0, cold, 2, item, d)) return false;
-        }
-    }
-    if (active) {
-        const uint32_t ob = su * 4u;
-        const size_t np = (size_t)c->a.nseg_pad;
-        const int32_t t_lo = (tau << kshift) + 1, t_hi = min((tau << kshift) + K, nsteps);
-        trmc::ChannelParams<float> p;
-        trmc::ChannelConst<float> k;
-        win_load_channel(c, ob, p, k);
-        const int32_t ri = c->a.res_of_pos ? c->a.res_of_pos[su] : -1;
-        const int32_t gi = c->a.gage_of_pos ? c->a.gage_of_pos[su] : -1;
-        float *q_up = c->a.q_tm + (size_t)(t_lo - 1) * np; // the time row of the step before (per lane: the level skew)
-        float q_prev = win_ldf(q_up, ob);
-        float d_prev = win_ldf(c->a.d_tm + (size_t)(t_lo - 1) * np, ob);
-        float *const out_row = c->a.out + (size_t)c->a.row_of_pos[su] * (size_t)nsteps * 3;
-        const bool out_vec = c->a.out_vec;
-        const int32_t qts = c->a.qts;
-        int32_t ql_col = (t_lo - 1) / qts, ql_left = qts - (t_lo - 1) % qts;
-        float ql = at(c->a.qlat_tm + (size_t)ql_col * np, ob);
-        m.coef_ok = coef_guard(p.dt, ql);
-        int32_t it_last = 0, staged = 0;
-        for (int32_t t = t_lo; t <= t_hi; ++t, q_up += np) {
-            if (ql_left == 0) {
-                ++ql_col;
-                ql = at(c->a.qlat_tm + (size_t)ql_col * np, ob);
-                m.coef_ok = coef_guard(p.dt, ql);
-                ql_left = c->a.qts;
-            }
-            --ql_left;
-            const float qup = win_upstream_sum(c, q_up, u, su);
-            float q_new, v_new, d_new;
-            it_last = win_step(c, m, p, k, ri, gi, t, qup, ql, q_prev, d_prev, q_new, v_new, d_new);
-            uint32_t obv = ob;
-            asm volatile("" : "+v"(obv));
-            win_stf(q_up + np, obv, q_new);
-            if (t == t_hi) win_stf(c->a.d_tm + (size_t)t * np, obv, d_new);
-            q_prev = q_new;
-            d_prev = d_new;
-            {   // stage (q, v, d) of step t; a run ends when kWinStage steps are staged and at the item's last step
-                float *so = s_out + (size_t)(staged * 3) * 64 + lane;
-                so[0] = q_new;
-                so[64] = v_new;
-                so[2 * 64] = d_new;
-                ++staged;
-                if (staged == kWinStage || t == t_hi) {
-                    float *dst = out_row + (size_t)(t - staged) * 3;
-                    const float *si = s_out + lane;
-                    if (out_vec && (staged & 3) == 0 && ((t - staged) & 3) == 0) { // (3 * staged / 4 aligned pieces of 16 bytes)
-                        for (int j = 0; j < 3 * staged / 4; ++j) {
-                            float4 v;
-                            v.x = si[(4 * j + 0) * 64];
-                            v.y = si[(4 * j + 1) * 64];
-                            v.z = si[(4 * j + 2) * 64];
-                            v.w = si[(4 * j + 3) * 64];
-                            reinterpret_cast<float4 *>(dst)[j] = v;
-                        }
-                    } else {
-                        for (int32_t e = 0; e < 3 * staged; ++e) dst[e] = si[e * 64];
-                    }
-                    staged = 0;
-                }
-            }
-        }
-        if (t_hi == nsteps) c->a.it_prev[su] = (uint8_t)min(it_last, 255);
-    }
-    // has every row of the item reached the window's end?  (then nobody must ever wait for it again)
-    const bool finished = __all(!valid || (tau >= 0 && ((tau + 1) << kshift) >= nsteps)) != 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of the item has left before its progress is published
-    if (lane == 0) win_st(c->w.prog + item, finished ? 0x7fffffff : d + 1);
-    return true;
-}
-
-// A tail item: 64 positions of the deeper levels through the ONE timestep `ph` (k_mc_step's work for them), (q, v, d)
-// straight into out[row][ph - 1][.].  Returns false when the window has been abandoned.
-__device__ __forceinline__ bool win_item_tail(WinCold cold, DevMathF &m, const int32_t item, const int32_t ph, const int32_t need)
-{
-    const WinCold c = win_args_now(cold);
-    const int32_t lane = (int32_t)threadIdx.x;
-    const int32_t s = c->w.w1 + item * 64 + lane;
-    const bool valid = s < c->w.s1;
-    const uint32_t su = (uint32_t)(valid ? s : c->w.w1);
-    const int2 u = c->a.up2[su];
-    if (need > 0) { // the wide rows above this item's rows at step ph - 1
-        uint32_t polls = 0;
-        uint64_t t0 = 0;
-        while (!__all(!valid || win_upstream_ready(c, u, (int32_t)su, need))) {
-            __builtin_amdgcn_s_sleep(8);
-            if (win_watchdog(polls, t0, cold, 1, item, ph)) return false;
-        }
-    }
-    if (valid) {
-        const uint32_t ob = su * 4u;
-        const size_t np = (size_t)c->a.nseg_pad;
-        const int32_t nsteps = c->a.nsteps;
-        trmc::ChannelParams<float> p;
-        trmc::ChannelConst<float> k;
-        win_load_channel(c, ob, p, k);
-        const int32_t ri = c->a.res_of_pos ? c->a.res_of_pos[su] : -1;
-        const int32_t gi = c->a.gage_of_pos ? c->a.gage_of_pos[su] : -1;
-        const float *const q_up = c->a.q_tm + (size_t)(ph - 1) * np; // (uniform: every lane is at step ph)
-        const float q_prev = win_ldf(q_up, ob);
-        const float d_prev = win_ldf(c->a.d_tm + (size_t)(ph - 1) * np, ob);
-        const float ql = at(c->a.qlat_tm + (size_t)c->w.col_of_step[ph] * np, ob);
-        m.coef_ok = coef_guard(p.dt, ql);
-        const float qup = win_upstream_sum(c, q_up, u, su);
-        float q_new, v_new, d_new;
-        const int32_t iters = win_step(c, m, p, k, ri, gi, ph, qup, ql, q_prev, d_prev, q_new, v_new, d_new);
-        uint32_t obv = ob;
-        asm volatile("" : "+v"(obv));
-        win_stf(c->a.q_tm + (size_t)ph * np, obv, q_new);
-        win_stf(c->a.d_tm + (size_t)ph * np, obv, d_new);
-        float *o = c->a.out + ((size_t)c->a.row_of_pos[su] * (size_t)nsteps + (size_t)(ph - 1)) * 3;
-        o[0] = q_new;
-        o[1] = v_new;
-        o[2] = d_new;
-        if (ph == nsteps) c->a.it_prev[su] = (uint8_t)min(iters, 255);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of the item has left before it is counted
-    if (lane == 0) {
-        const int32_t ntail = c->w.ntail;
-        const int32_t x = item & (kWinShards - 1);
-        const int32_t len = (ntail - x + kWinShards - 1) / kWinShards;
-        if (atomicAdd(c->w.tail_done + (size_t)(ph * kWinShards + x) * kWinPad, 1) + 1 == len) {
-            const int32_t nshards = ntail < kWinShards ? ntail : kWinShards;
-            if (atomicAdd(c->w.tail_shards + ph, 1) + 1 == nshards) win_st(c->w.ctl + 0, ph);
-        }
-    }
-    return true;
-}
-
-#ifndef TRMC_WIN_WAVES
-#define TRMC_WIN_WAVES 5
-#endif
-__global__ void __launch_bounds__(64, TRMC_WIN_WAVES)
-k_mc_window(const WindowArgs wa)
-{
-    const WinCold cold = cold_args<WindowArgs>();
-    __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
-    __shared__ float s_out[3 * kWinStage * 64]; // [step slot * 3 + c][lane]
-    DevMathF m{stage_pow_tables(s_tab), false};
-    m.sane = wa.a.sane;
-
-    const int32_t lane = (int32_t)threadIdx.x;
-    const int32_t xcd = (int32_t)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u); // HW_REG_XCC_ID
-    int32_t d_cur = 0, ph_skip = 0, tail_exh_ph = 0;
-    uint32_t tile_exh = 0, tail_exh = 0; // shards of the current sub-diagonal / phase this worker has found empty
-    uint32_t idle_polls = 0;
-    uint64_t idle_start = 0;
-#ifdef TRMC_WIN_DEBUG // developer build: what the workers did, summed into ctl[8..15] (read by trmc_route_end into stderr)
-    uint32_t dbg_wide = 0, dbg_tail = 0, dbg_idle = 0, dbg_exh = 0;
-    uint64_t dbg_t0 = wall_clock64(), dbg_t_wide = 0, dbg_t_tail = 0;
-#endif
-    for (;;) {
-        const WinCold c = win_args_now(cold);
-        const win_int4 ctl = win_ld_ctl(c->w.ctl);
-        const int32_t tail_through = __builtin_amdgcn_readfirstlane(ctl.x), d_claimed = __builtin_amdgcn_readfirstlane(ctl.y);
-        if (__builtin_amdgcn_readfirstlane(ctl.z) != 0) break;
-        const int32_t tail_claimed = __builtin_amdgcn_readfirstlane(ctl.w);
-        const int32_t nsteps = c->a.nsteps, ndiag = c->w.ndiag, ntail = c->w.ntail;
-        bool did = false;
-        // ---- the tail's next phase, if it is open: every tail row at ph - 1, and every wide item its rows may wait for not
-        // merely claimed but a whole sub-diagonal of claims old (so that the item's wait for them is, in practice, never one)
-        const int32_t ph = tail_through + 1;
-        if (ntail > 0 && ph <= nsteps && ph > tail_claimed && ph != ph_skip) {
-            const int32_t need = ph >= 2 ? ((ph - 2) >> c->w.kshift) + c->w.W : 0; // sub-diagonals the wide items must have completed
-            if (d_claimed >= min(need + (need > 0 ? 1 : 0), ndiag)) {
-                if (tail_exh_ph != ph) {
-                    tail_exh_ph = ph;
-                    tail_exh = 0;
-                }
-                int32_t item = -1;
-                for (int32_t j = 0; j < kWinShards && item < 0; ++j) {
-                    const int32_t x = (xcd + j) & (kWinShards - 1);
-                    const int32_t len = (ntail - x + kWinShards - 1) / kWinShards; // items x, x + 8, ...
-                    if (len <= 0 || (tail_exh & (1u << x))) continue;
-                    const int32_t got = win_claim(c->w.tail_claim + (size_t)(ph * kWinShards + x) * kWinPad, len);
-                    if (got >= 0)
-                        item = x + kWinShards * got;
-                    else
-                        tail_exh |= 1u << x;
-                }
-                if (item >= 0) {
-                    __builtin_amdgcn_s_setprio(3); // the phases are the window's dependent chain
-#ifdef TRMC_WIN_DEBUG
-                    const uint64_t t_in = wall_clock64();
-#endif
-                    const bool alive = win_item_tail(cold, m, item, ph, need);
-                    __builtin_amdgcn_s_setprio(0);
-                    if (!alive) break;
-#ifdef TRMC_WIN_DEBUG
-                    dbg_t_tail += wall_clock64() - t_in;
-                    ++dbg_tail;
-#endif
-                    did = true;
-                } else {
-                    ph_skip = ph; // every item of the phase is taken; its last ones are still running: tell the others
-                    if (lane == 0) atomicMax(c->w.ctl + 3, ph);
-#ifdef TRMC_WIN_DEBUG
-                    ++dbg_exh;
-#endif
-                }
-            }
-        }
-        // ---- else a wide item, in sub-diagonal order
-        if (!did && d_cur < ndiag) {
-            if (d_claimed > d_cur) {
-                d_cur = d_claimed;
-                tile_exh = 0;
-            }
-            if (d_cur < ndiag) {
-                const int32_t first = c->w.diag_first[d_cur], count = c->w.diag_count[d_cur];
-                int32_t item = -1;
-                for (int32_t j = 0; j < kWinShards && item < 0; ++j) {
-                    const int32_t x = (xcd + j) & (kWinShards - 1);
-                    const int32_t base = first + ((x - first) & (kWinShards - 1)); // first item of the range that is = x mod 8
-                    const int32_t len = base < first + count ? (first + count - base + kWinShards - 1) / kWinShards : 0;
-                    if (len <= 0 || (tile_exh & (1u << x))) continue;
-                    const int32_t got = win_claim(c->w.tile_claim + (size_t)(d_cur * kWinShards + x) * kWinPad, len);
-                    if (got >= 0)
-                        item = base + kWinShards * got;
-                    else
-                        tile_exh |= 1u << x;
-                }
-                if (item < 0) { // every item of this sub-diagonal is claimed: the next one opens
-                    if (lane == 0) atomicMax(c->w.ctl + 1, d_cur + 1);
-                    ++d_cur;
-                    tile_exh = 0;
-                } else {
-#ifdef TRMC_WIN_DEBUG
-                    const uint64_t t_in = wall_clock64();
-#endif
-                    if (!win_item_wide(cold, m, s_out, item, d_cur)) break;
-#ifdef TRMC_WIN_DEBUG
-                    dbg_t_wide += wall_clock64() - t_in;
-                    ++dbg_wide;
-#endif
-                }
-                did = true;
-            }
-        }
-        if (did) {
-            idle_polls = 0;
-            idle_start = 0;
-            continue;
-        }
-        // ---- nothing to claim: the window is over, or the tail's last items are still running (sleep long: every poll of
-        // the control words is a request to ONE cache line)
-        if (d_cur >= ndiag && (ntail == 0 || tail_through >= nsteps)) break;
-        __builtin_amdgcn_s_sleep(127);
-#ifdef TRMC_WIN_DEBUG
-        ++dbg_idle;
-#endif
-        if (win_watchdog(idle_polls, idle_start, cold, 3, ph, d_cur)) break;
-    }
-#ifdef TRMC_WIN_DEBUG
-    if (lane == 0) {
-        int32_t *const ctl = cold->w.ctl;
-        atomicAdd(ctl + 8, (int32_t)dbg_wide);
-        atomicAdd(ctl + 9, (int32_t)dbg_tail);
-        atomicAdd(ctl + 10, (int32_t)(dbg_idle >> 4));
-        atomicAdd(ctl + 11, (int32_t)dbg_exh);
-        atomicAdd(ctl + 12, (int32_t)(dbg_t_wide / 100)); // microseconds inside wide items, all workers
-        atomicAdd(ctl + 13, (int32_t)(dbg_t_tail / 100));
-        atomicAdd(ctl + 14, (int32_t)((wall_clock64() - dbg_t0) / 100)); // microseconds alive, all workers
-        atomicAdd(ctl + 15, 1);                                          // workers that ran
-    }
-#endif
 }
 
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
@@ -1564,13 +1085,15 @@ k_fill_boundary_range(const T *__restrict__ q, T *q_tm, T *v_tm, T *d_tm, int32_
 }
 
 // independent single-segment steps: in[n][15] -> out[n][6] (with courant), cf. reach.pyx:66-103
-template <class T>
+template <class T, bool TOL = false>
 __global__ void __launch_bounds__(kBlock)
-k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
+k_segments(const T *__restrict__ in, T *__restrict__ out, int32_t *__restrict__ iters_out, int64_t n)
 {
-    using M = typename DevMath<T>::type;
+    using M = typename DevMath<T, TOL>::type;
+    using MX = typename DevMath<T, false>::type; // (the segment-invariant constants are exact in either arithmetic, as in a plan: k_make_const)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     M m{stage_pow_tables(s_tab), false};
+    const MX mx{s_tab, false};
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const T *x = in + i * 15;
@@ -1581,12 +1104,13 @@ k_segments(const T *__restrict__ in, T *__restrict__ out, int64_t n)
     p.cs = x[11]; p.s0 = x[12];
     const T depthp = x[14];
     m.coef_ok = coef_guard(p.dt, f.ql);
-    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, f, depthp, m);
+    const trmc::ChannelConst<T> c = trmc::make_const<T, MX>(p, mx);
+    const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, c, f, depthp, m);
     T ck, cn;
-    const trmc::ChannelConst<T> c = trmc::make_const<T, M>(p, m);
     trmc::courant_at<T, M>(r.h, p, c, ck, cn, m);
     T *o = out + i * 6;
     o[0] = r.qdc; o[1] = r.velc; o[2] = r.depthc; o[3] = ck; o[4] = cn; o[5] = r.X;
+    if (iters_out) iters_out[i] = r.iters;
 }
 
 // ---------------------------------------------------------------- dataflow engine (fp32)
@@ -1791,11 +1315,11 @@ __device__ __forceinline__ float flow_edge_get(FlowEdge &e, const unsigned long 
 #else
 #define TRMC_FLOW_ATTR
 #endif
-template <bool SHORT>
+template <bool SHORT, bool TOL = false>
 __global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES) TRMC_FLOW_ATTR
 k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the launches / steps (t0, t1] of the window
 {
-    using M = DevMathFlow;
+    using M = std::conditional_t<TOL, DevMathTolFlow, DevMathFlow>;
     const FlowCold cold = cold_args<FlowArgs>(); // (see cold_args: what the loop rarely needs is not kept in registers)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ float s_out[3 * kFlowStage * kFlowBlock];             // [step slot * 3 + c][thread]
@@ -2127,11 +1651,11 @@ __device__ __forceinline__ int32_t lean_pick_block(const FlowArgs &a)
     return -1; // (cannot happen: as many workgroups as blocks)
 }
 
-template <bool LAG>
+template <bool LAG, bool TOL = false>
 __global__ void __launch_bounds__(kFlowBlock, TRMC_LEAN_WAVES)
 k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
 {
-    using M = DevMathFlow;
+    using M = std::conditional_t<TOL, DevMathTolFlow, DevMathFlow>;
     const FlowCold cold = cold_args<FlowArgs>(); // (see cold_args: what the loop rarely needs is not kept in registers)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
     __shared__ float s_par[kLeanCols * kFlowBlock];                 // [column][thread]
@@ -2453,12 +1977,11 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     int32_t tiles_done = 0, launches = 0;
     // wide levels routed K steps per launch with a skew of K steps per level (k_mc_tile); 0 = every level one step per launch
     int32_t wide = 0, wide_k = 0, wide_next = 0, wide_through = 0; // levels; K; tiles queued; last tile the tail waits for
+    // second tier: the `mid` levels right below the wide ones, mid_k steps per launch under their own skew (k_mc_tile again),
+    // queued on the plan's stream between the tail's launches
+    int32_t mid = 0, mid_k = 0, mid_next = 0;
     bool tail_active = false;     // the tail launches of this window go to the tail stream
     bool end_queued = false;      // route_end_queue has run for this window
-    // the whole window as ONE persistent launch (k_mc_window): chosen by route_begin_t, launched by the advance that covers it
-    bool tail_direct = false;     // the tail's launches write their rows' results into the caller's layout themselves (no k_emit)
-    bool win = false, win_ran = false;
-    int32_t win_W = 0, win_K = 0;
 };
 
 struct trmc_plan {
@@ -2528,6 +2051,18 @@ struct trmc_plan {
     DevBuf cuq_ptr, cuq_blk, cuq_head, cu_index, cuq_perm; // blocks dealt to compute units by cost (flow_place_blocks); heads: one set per compute stream
     int32_t ncuq = 0;                    // number of queues (= compute units found), 0 = block tickets
     uint64_t watchdog_ticks = 3000000000ull; // 30 s of wall_clock64 (100 MHz): long enough for a device that is shared or profiled (TRMC_FLOW_WATCHDOG_MS)
+    // trmc_plan_options, resolved at creation (a clone copies them)
+    struct Opt {
+        bool tol = false;                    // TRMC_ARITH_TOLERANCE
+        int64_t wide_min_rows = 0;           // <= 0: no wide tier
+        int32_t wide_levels = 16, wide_k = 16;
+        int64_t mid_min_rows = 0;            // <= 0: no second tier
+        int32_t mid_levels = 12, mid_k = 4;
+        int32_t tile_perm_group = -1;        // -1: by the hint (256 / off); 0: off; else the group
+        bool sequence = false;
+        bool flow_overlap = false;
+        int32_t flow_lean = 0;
+    } opt;
     trmc_stats stats{};
     RouteRun run;
     // asynchronous fetch of what a throughput-mode caller consumes (trmc_fetch_begin / trmc_fetch_wait)
@@ -2547,11 +2082,10 @@ struct trmc_plan {
     hipEvent_t ev_forcing = nullptr;
     bool forcing_pending = false;
     bool state_missing = false;          // ... and there is no initial state yet: trmc_plan_chain_from must supply it
-    // window kernel (k_mc_window): its schedule tables (per W, K, nsteps) and its counters
+    bool q0_staged = false;              // in_q0 holds the initial state of the window that is staged (an upload's q0, or the last
+                                         // window's final state gathered by an upload with q0 = NULL / trmc_stage_forcing): valid
+                                         // until a window consumes it, whatever routed_nsteps says in the meantime
     DevBuf tile_perm, cls_last;          // k_tile_perm: the row every thread of the next wide tile takes; the classes it is made from
-    DevBuf win_tab, win_ctr;
-    int32_t win_key[4] = {-1, -1, -1, -1};
-    int32_t win_ndiag = 0, win_nwide = 0, win_ntail = 0, win_workers = 0;
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
     std::vector<int32_t> rowset_lag;
@@ -2668,21 +2202,42 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.out_vec = sizeof(T) == 4 && nsteps % 4 == 0 && pl->run.wide_k % 4 == 0;
     a.tile_perm = nullptr; // (route_advance_t switches the permutation on for its wide tiles)
     a.cls_last = nullptr;
-    a.tail_direct = false;
     return a;
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-template <class T, bool SHORT>
-inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d)
+template <class T, bool SHORT, bool TOL>
+inline void launch_step_m(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d)
 {
     const int64_t n = (int64_t)s1 - s0;
     const dim3 grid((unsigned)((n + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
     if (SHORT && a.lag)
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, SHORT>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, SHORT, TOL>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
     else
-        hipLaunchKernelGGL((k_mc_step<T, SHORT, false>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
+        hipLaunchKernelGGL((k_mc_step<T, SHORT, false, TOL>), grid, block, 0, st, a, s0, s1, d, (d - 1) / a.qts);
+}
+// (tol: the plan's arithmetic is TRMC_ARITH_TOLERANCE -- precision-32 plans only, trmc_plan_create_opt sees to that)
+template <class T, bool SHORT>
+inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d, bool tol)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (tol) return launch_step_m<T, SHORT, true>(st, a, s0, s1, d);
+    }
+    launch_step_m<T, SHORT, false>(st, a, s0, s1, d);
+}
+// one launch of k_mc_tile: positions [p0, p1), `tile` = launch index + the first level of the tier, K steps
+template <class T>
+inline void launch_tile(hipStream_t st, const StepArgs<T> &a, int32_t p0, int32_t p1, int32_t tile, int32_t K, bool tol)
+{
+    const dim3 grid((unsigned)((p1 - p0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
+    if constexpr (sizeof(T) == 4) {
+        if (tol) {
+            hipLaunchKernelGGL((k_mc_tile<T, true>), grid, block, 0, st, a, p0, p1, tile, K);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_mc_tile<T, false>), grid, block, 0, st, a, p0, p1, tile, K);
 }
 
 // A routing window runs in three parts so that a caller can interleave other device work (the multi-GPU
@@ -2701,14 +2256,13 @@ template <class T> int emit_tiles_through(trmc_plan *pl, int32_t t_complete) // 
     const int32_t ntiles = (nsteps + kTile - 1) / kTile;
     const size_t plane = (size_t)(nsteps + 1) * pl->nseg_pad;
     const T *q_tm = (const T *)pl->tm.p;
-    if (r.win_ran || r.tail_direct) r.tiles_done = ntiles; // (every row's result has been written in the caller's layout already)
     while (r.tiles_done < ntiles && ((r.tiles_done + 1) * kTile <= t_complete || t_complete >= nsteps)) {
         // (with wide tiles: the tail, on the plan's stream, trails them -- its progress is everybody's; without a tail the
         // tile stream's is)
         HIP_TRY(hipEventRecord(pl->tile_ev[r.tiles_done], (r.wide > 0 && !r.tail_active) ? pl->wstream : pl->stream));
         HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->tile_ev[r.tiles_done], 0));
         // (rows of the wide levels wrote their results themselves, k_mc_tile: their positions are left out)
-        const int32_t skip_lo = r.wide > 0 ? pl->topo.lvl_ptr[0] : 0, skip_hi = r.wide > 0 ? pl->topo.lvl_ptr[r.wide] : 0;
+        const int32_t skip_lo = r.wide > 0 ? pl->topo.lvl_ptr[0] : 0, skip_hi = r.wide > 0 ? pl->topo.lvl_ptr[r.wide + r.mid] : 0;
         const int32_t shift_from = (skip_lo + 63) / 64 * 64, shift = std::max(0, (skip_hi - shift_from) / 64 * 64);
         const int32_t n_emit = n - shift;
         if (n_emit > 0) {
@@ -2756,14 +2310,13 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
             pl->released_pending[i] = false;
         }
     HIP_TRY(hipEventRecord(pl->ev[0], st));
-    // TRMC_SETUP_ASIDE=1: the window's set-up (forcing transpose, initial state, boundary rows) goes to the TILE stream
-    // instead of the plan's own.  For one plan it is all the same; for two plans that take turns on a device (two ensemble
+    // Sequence mode (trmc_plan_options.sequence_mode): the window's set-up (forcing transpose, initial state, boundary rows)
+    // goes to the TILE stream instead of the plan's own.  For one plan it is all the same; for two plans that take turns on a device (two ensemble
     // members, bench.py's `two_members`) it is what lets the tiles of one member's next window start behind the other
     // member's tiles while that member's tail is still running: with one hardware queue per stream priority the two plans'
     // high-priority streams share a queue, in order of submission, and a set-up queued there would sit behind the other
     // member's 288 tail launches -- and the tiles behind the set-up.
-    const char *aside_env = std::getenv("TRMC_SETUP_ASIDE");
-    const bool setup_aside = aside_env && aside_env[0] == '1' && short_ts && pl->wstream != nullptr;
+    const bool setup_aside = pl->opt.sequence && short_ts && pl->wstream != nullptr;
     hipStream_t const plan_st = st;
     if (setup_aside) {
         st = pl->wstream;
@@ -2792,6 +2345,7 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
                                row_of_pos, a.q_tm, a.v_tm, a.d_tm, n);
     }
     pl->chain_staged = false;
+    pl->q0_staged = false; // (consumed: the next staging gathers this window's final state)
     RouteRun &r = pl->run;
     r = RouteRun{};
     r.active = true;
@@ -2826,69 +2380,29 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         }
         pl->wide_safe_pos = first;
     }
-    // Short-timestep fp32 windows whose leading levels are wide enough go out as ONE persistent launch (k_mc_window, see
-    // there): needs every boundary hydrograph up front and no lagged rows, like the wide tiles below, and no cost collection
-    // (the 16-bit per-row sums are read-modify-written by successive items of a row on different compute units).
-    // TRMC_WINDOW=0 switches it off; TRMC_WIN_MIN_ROWS (rows a level must have to be routed K steps per item; default 64 per
-    // compute unit), TRMC_WIN_LEVELS (at most; default 24) and TRMC_WIN_K (steps per item, a power of two; default 8) are
-    // measurement / test knobs.
-    if (short_ts && pl->nrouted > 0 && sizeof(T) == 4 && !pl->collect_cost) {
-        auto env_int = [](const char *name, long dflt) {
-            const char *e = std::getenv(name);
-            return e && *e ? std::atol(e) : dflt;
-        };
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
-        // OFF by default: measured on the CONUS day (MI355X) the persistent launch takes 50-60 ms against
-        // 16.5 ms for the launches it would replace -- every hand-off inside a launch is a write-through store and an
-        // L1-bypassing load, an item pays half a dozen dependent round trips to memory, and a phase of the tail only gets
-        // workers at the rate wide items finish.  Kept as a correct, tested alternative (TRMC_WINDOW=1) and as the record of
-        // what the kernel boundaries buy.
-        const long on = env_int("TRMC_WINDOW", 0), min_rows = env_int("TRMC_WIN_MIN_ROWS", 64L * ncu);
-        const long max_levels = std::min<long>(env_int("TRMC_WIN_LEVELS", 24), kWinMaxLevels);
-        long K = std::max(1L, std::min((long)nsteps, env_int("TRMC_WIN_K", 8)));
-        while (K & (K - 1)) K &= K - 1; // the power of two at or below
-        const bool all_in_place = pl->maxlag == 0 && r.boundary_through == nsteps;
-        int32_t W = 0;
-        const int32_t level_cap = tp.tail_from_level > 0 ? tp.tail_from_level : tp.nlevels;
-        if (on && min_rows > 0 && all_in_place)
-            while (W < level_cap && W < max_levels && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows) ++W;
-        if (W > 0 && (uint64_t)pl->nseg * (uint64_t)nsteps * 3ull < (1ull << 62)) {
-            r.win = true;
-            r.win_W = W;
-            r.win_K = (int32_t)K;
-        }
-    }
-    if (short_ts && pl->nrouted > 0 && !r.win) {
-        auto env_int = [](const char *name, long dflt) {
-            const char *e = std::getenv(name);
-            return e && *e ? std::atol(e) : dflt;
-        };
+    if (short_ts && pl->nrouted > 0) {
         // (measured on the CONUS day, MI355X, with every tile queued up front: levels of at least 32 768 rows -- eleven of them
         // -- and K = 12: 17.5 ms; eight levels 16.9; six 16.6; five 16.5 with K = 12 and 16.25 with K = 16; four 16.6; three 16.9;
         // K = 24: 17.0.  Fewer wide levels shorten the ramps of the level skew and give the tail launches more rows to fill the
         // device with after the last tile; the threshold that picks five levels there is 30 % of the rows the device holds at
-        // five wavefronts per SIMD.  Spans of unequal length -- short ones at the window's start and end, so that the tail
-        // starts 2 ms earlier and ends closer behind the last tile -- were built and measured: 16.6-17.0 ms against 16.5-16.7,
-        // no gain: the tail falls behind in mid-window whenever it starts; nor does holding the tiles at four or four and a half
-        // wavefronts per SIMD so that a tail wavefront always finds a slot, 16.7 / 17.05 ms.  Every wide level on a stream of
-        // its own, one launch per (level, span), up to five in flight on eight hardware queues: the wide rows are done at
-        // 12.0 ms instead of 14.6, but the tail's launches then take 60 us instead of 48 and end at 18.2-19.9 ms, and the host
-        // needs some 50 us for every launch that waits for another stream's event.  The first two upstream flows of a
-        // tile's step loaded a step ahead: 16.8-16.9 ms.  All removed again.)
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
-        const long min_rows = env_int("TRMC_WIDE_MIN_ROWS", 384L * ncu), max_levels = env_int("TRMC_WIDE_LEVELS", 16);
-        int32_t W = 0;
+        // five wavefronts per SIMD.  DESIGN.md lists what else was tried on this schedule.)
+        const int64_t min_rows = pl->opt.wide_min_rows;
+        int32_t W = 0, M = 0;
         const bool all_in_place = pl->maxlag == 0 && r.boundary_through == nsteps; // (then every level may run ahead)
         const int32_t level_cap = tp.tail_from_level > 0 ? tp.tail_from_level : tp.nlevels; // (deeper rows are not in level slices)
+        auto level_ok = [&](int32_t l, int64_t need) {
+            return l < level_cap && tp.lvl_ptr[l + 1] - tp.lvl_ptr[l] >= need && (all_in_place || (int64_t)tp.lvl_ptr[l + 1] <= pl->wide_safe_pos);
+        };
         if (min_rows > 0)
-            while (W < level_cap && W < std::min<long>(max_levels, kWideMaxLevels) && tp.lvl_ptr[W + 1] - tp.lvl_ptr[W] >= min_rows
-                   && (all_in_place || (int64_t)tp.lvl_ptr[W + 1] <= pl->wide_safe_pos))
-                ++W;
+            while (W < std::min<int32_t>(pl->opt.wide_levels, kWideMaxLevels) && level_ok(W, min_rows)) ++W;
+        // the second tier: the levels right below, fewer steps per launch (a skew of mid_k steps per level instead of wide_k)
+        if (W > 0 && pl->opt.mid_min_rows > 0)
+            while (M < pl->opt.mid_levels && level_ok(W + M, pl->opt.mid_min_rows)) ++M;
         if (W > 0) {
             r.wide = W;
-            r.wide_k = (int32_t)std::max(1L, std::min((long)nsteps, env_int("TRMC_WIDE_K", std::max(1, std::min(16, nsteps / 8)))));
+            r.wide_k = std::max(1, std::min(nsteps, pl->opt.wide_k > 0 ? pl->opt.wide_k : std::max(1, std::min(16, nsteps / 8))));
+            r.mid = M;
+            r.mid_k = M > 0 ? std::max(1, std::min(r.wide_k, pl->opt.mid_k)) : 0;
             if (!pl->wstream) {
                 // ordinary priority: between the tail's step launches (high) and the result transpose (low); one hardware queue each
                 HIP_TRY(hipStreamCreateWithFlags(&pl->wstream, hipStreamNonBlocking));
@@ -2910,15 +2424,6 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     return 0;
 }
 
-// occupancy experiment (TRMC_TILE_LDS_PAD = bytes of dynamic LDS per block that nobody uses: fewer blocks fit a compute unit)
-static unsigned tile_lds_pad()
-{
-    static const unsigned pad = [] {
-        const char *e = std::getenv("TRMC_TILE_LDS_PAD");
-        return e ? (unsigned)std::atoi(e) : 0u;
-    }();
-    return pad;
-}
 // what ends a window on the device -- the rest of the result transpose and the events the clock reads -- queued (once)
 template <class T> int route_end_queue(trmc_plan *pl)
 {
@@ -2935,98 +2440,6 @@ template <class T> int route_end_queue(trmc_plan *pl)
     return 0;
 }
 
-// the whole window as one persistent launch (k_mc_window): schedule tables (built once per W, K, nsteps), counters, launch
-int window_launch(trmc_plan *pl, const StepArgs<float> &a)
-{
-    const trmc::Topology &tp = pl->topo;
-    RouteRun &r = pl->run;
-    const int32_t nsteps = r.nsteps, W = r.win_W, K = r.win_K, L = tp.nlevels;
-    const int32_t w0 = tp.lvl_ptr[0], w1 = tp.lvl_ptr[W], s1 = tp.lvl_ptr[L];
-    const int32_t nwide = (w1 - w0 + 63) / 64, ntail = (s1 - w1 + 63) / 64;
-    const int32_t ntau = (nsteps + K - 1) / K, ndiag = ntau + W - 1;
-    hipStream_t st = pl->stream;
-    if (pl->win_key[0] != W || pl->win_key[1] != K || pl->win_key[2] != nsteps || pl->win_key[3] != r.qts) {
-        // levels grow along the plan order: an item's rows span the levels [lo, hi] of its first and last position; it is
-        // active in the sub-diagonals lo .. hi + ntau - 1
-        // tab: diag_first[ndiag] | diag_count[ndiag] | initial prog[nwide] | col_of_step[nsteps + 1]
-        std::vector<int32_t> tab((size_t)2 * ndiag + nwide + nsteps + 1, 0), lo((size_t)nwide), hi((size_t)nwide);
-        for (int32_t t = 1; t <= nsteps; ++t) tab[(size_t)2 * ndiag + nwide + t] = (t - 1) / r.qts;
-        for (int32_t k = 0; k < nwide; ++k) {
-            const int32_t p0 = w0 + 64 * k, p1 = std::min(w1, p0 + 64) - 1;
-            lo[(size_t)k] = tp.level_of_row[(size_t)tp.row_of_pos[(size_t)p0]];
-            hi[(size_t)k] = tp.level_of_row[(size_t)tp.row_of_pos[(size_t)p1]];
-            tab[(size_t)2 * ndiag + k] = lo[(size_t)k]; // prog starts at the first sub-diagonal the item is active in
-        }
-        int32_t first = 0, last = -1;
-        for (int32_t d = 0; d < ndiag; ++d) {
-            while (first < nwide && hi[(size_t)first] + ntau - 1 < d) ++first;
-            while (last + 1 < nwide && lo[(size_t)(last + 1)] <= d) ++last;
-            tab[(size_t)d] = first;
-            tab[(size_t)ndiag + d] = std::max(0, last - first + 1);
-        }
-        if (int rc = upload_i32(pl->win_tab, tab, 1)) return rc;
-        pl->win_key[0] = W;
-        pl->win_key[1] = K;
-        pl->win_key[2] = nsteps;
-        pl->win_key[3] = r.qts;
-        pl->win_ndiag = ndiag;
-        pl->win_nwide = nwide;
-        pl->win_ntail = ntail;
-    }
-    {
-        int nb = 0, ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
-        // Workers: as many single-wavefront workgroups as the registers let a compute unit hold (the occupancy query: 20 at
-        // five wavefronts per SIMD).  Nothing depends on how many of them are resident -- claims only ever wait for claimed
-        // items -- so a grid above the true residency would be harmless (the surplus starts when the first workers leave,
-        // finds nothing and leaves too) and one below it only idles slots.
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mc_window, 64, 0) != hipSuccess) nb = -1;
-#ifdef TRMC_WIN_DEBUG
-        std::fprintf(stderr, "[window debug] occupancy query: %d blocks of 64 threads per compute unit\n", nb);
-#endif
-        if (nb < 1) nb = 4 * TRMC_WIN_WAVES;
-        if (const char *e = std::getenv("TRMC_WIN_WORKERS_PER_CU")) nb = std::max(1, std::atoi(e));
-        pl->win_workers = nb * ncu;
-    }
-    // counters: ctl[32] | tail_shards[nsteps + 1] | tile_claim[ndiag][8][pad] | tail_claim[nsteps + 1][8][pad] | tail_done[nsteps + 1][8][pad] | prog[nwide]
-    const size_t n_ctl = 32, n_sh = (size_t)nsteps + 1, n_tc = (size_t)ndiag * kWinShards * kWinPad,
-                 n_tl = ((size_t)nsteps + 1) * kWinShards * kWinPad;
-    const size_t words = n_ctl + n_sh + n_tc + 2 * n_tl + (size_t)nwide;
-    if (int rc = pl->win_ctr.ensure(words * sizeof(int32_t))) return rc;
-    int32_t *base = (int32_t *)pl->win_ctr.p;
-    HIP_TRY(hipMemsetAsync(base, 0, (words - (size_t)nwide) * sizeof(int32_t), st));
-    const int32_t *tab = (const int32_t *)pl->win_tab.p;
-    HIP_TRY(hipMemcpyAsync(base + (words - (size_t)nwide), tab + 2 * (size_t)ndiag, (size_t)nwide * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    WindowArgs wa;
-    wa.a = a;
-    wa.a.out_vec = nsteps % 4 == 0;
-    wa.w.w0 = w0;
-    wa.w.w1 = w1;
-    wa.w.s1 = s1;
-    wa.w.K = K;
-    wa.w.kshift = 0;
-    while ((1 << wa.w.kshift) < K) ++wa.w.kshift;
-    wa.w.W = W;
-    wa.w.ndiag = ndiag;
-    wa.w.nwide = nwide;
-    wa.w.ntail = ntail;
-    wa.w.diag_first = tab;
-    wa.w.diag_count = tab + ndiag;
-    wa.w.col_of_step = tab + 2 * (size_t)ndiag + nwide;
-    wa.w.ctl = base;
-    wa.w.tail_shards = base + n_ctl;
-    wa.w.tile_claim = wa.w.tail_shards + n_sh;
-    wa.w.tail_claim = wa.w.tile_claim + n_tc;
-    wa.w.tail_done = wa.w.tail_claim + n_tl;
-    wa.w.prog = wa.w.tail_done + n_tl;
-    wa.w.watchdog_ticks = pl->watchdog_ticks;
-    hipLaunchKernelGGL(k_mc_window, dim3((unsigned)pl->win_workers), dim3(64), 0, st, wa);
-    HIP_TRY(hipGetLastError());
-    r.win_ran = true;
-    r.launches = 1;
-    return 0;
-}
-
 template <class T> int route_advance_t(trmc_plan *pl, int t_end)
 {
     const trmc::Topology &tp = pl->topo;
@@ -3035,16 +2448,6 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     const int32_t nsteps = r.nsteps, t0 = r.t_done;
     StepArgs<T> a = step_args<T>(pl, nsteps, r.qts);
     hipStream_t st = pl->stream;
-    if (r.win) {
-        if constexpr (sizeof(T) == 4) {
-            if (pl->nrouted > 0 && t0 == 0 && t_end == nsteps) {
-                if (int rc = window_launch(pl, a)) return rc;
-                r.t_done = t_end;
-                return 0;
-            }
-        }
-        r.win = false; // (the window arrives in parts: one step per launch, below)
-    }
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
         if (r.short_ts && r.wide > 0) {
@@ -3056,21 +2459,14 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             // 2.4 ms past the last tile.  A tile is queued when the tail needs it; at the end of the call the plan's stream
             // waits for the tiles queued so far, so whatever the caller queues next (a gather, the next window) sees every
             // row at t_end.
-            const int32_t K = r.wide_k, W = r.wide;
-            const int32_t w0 = tp.lvl_ptr[0], w1 = tp.lvl_ptr[W], s1 = tp.lvl_ptr[L];
+            const int32_t K = r.wide_k, W = r.wide, M = r.mid, K2 = r.mid_k;
+            const int32_t w0 = tp.lvl_ptr[0], w1 = tp.lvl_ptr[W], m1 = tp.lvl_ptr[W + M], s1 = tp.lvl_ptr[L];
             const int32_t ntile = (nsteps + K - 1) / K + W - 1;
-            const bool tail = s1 > w1;
+            const int32_t nmid = M > 0 ? (nsteps + K2 - 1) / K2 + M - 1 : 0;
+            const bool tail = s1 > m1;
+            const bool tol = pl->opt.tol;
             hipStream_t ws = pl->wstream;
-            r.tail_active = tail;
-            // TRMC_TAIL_DIRECT=1 (measurement knob): the tail's step launches write (q, v, d) straight into out[row][step][.]
-            // -- 12 bytes per row and step -- instead of a velocity plane and the transposing pass behind them.  Measured on
-            // the CONUS sequence: 18.1-18.2 ms per day against 16.2-16.3 with the pass: 764 k twelve-byte fragments per step
-            // at a 3 456-byte stride cost more than the 5 GB the transposing pass moves; off.
-            if (t0 == 0) {
-                const char *td = std::getenv("TRMC_TAIL_DIRECT");
-                r.tail_direct = td && td[0] == '1' && tp.nboundary == 0 && pl->maxlag == 0;
-            }
-            a.tail_direct = r.tail_direct;
+            r.tail_active = tail || M > 0;
             // Every tile of the window is queued at once, at the window's first call: the wide path needs all boundary
             // hydrographs up front (route_begin_t), so a tile depends on nothing but the tile before it.  (Queued one by one
             // as the tail came to need them, the last tiles of a window were late -- the host runs only a little ahead of the
@@ -3078,15 +2474,13 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             // 1.2 ms for them.)  One event per tile: it ends the tile for the clock (a tile starts where the one before it
             // ended; the first has a start event of its own) and it is what the tail waits for.
             if (r.wide_next == 0) {
-                const dim3 grid((unsigned)((w1 - w0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
-                // TRMC_TILE_PERM=<group>: rows dealt to the threads of every tile by the cost class they showed in the tile before,
-                // inside groups of <group> positions (k_tile_perm; 0 = off) -- see the measurements there.
-                const char *perm_env = std::getenv("TRMC_TILE_PERM");
-                // (default: groups of 256 on a plan built with a cost hint -- there the re-dealing repairs what is left of mixed
-                // wavefronts at the class boundaries and where rows have drifted since the hint was taken: 16.0-16.1 against
-                // 16.3-16.4 ms per day, three runs each -- and off on a plan without one, where it costs more than it saves)
-                const int32_t perm_group = perm_env ? std::min(kPermGroupMax, std::max(0, std::atoi(perm_env)) / kBlock * kBlock)
-                                                    : (pl->hinted ? 256 : 0);
+                // rows dealt to the threads of every tile by the cost class they showed in the tile before, inside groups of
+                // `perm_group` positions (k_tile_perm, see the measurements there).  Default: groups of 256 on a plan built
+                // with a cost hint -- there the re-dealing repairs what is left of mixed wavefronts at the class boundaries and
+                // where rows have drifted since the hint was taken: 16.0-16.1 against 16.3-16.4 ms per day, three runs each --
+                // and off on a plan without one, where it costs more than it saves
+                const int32_t perm_group = pl->opt.tile_perm_group >= 0 ? std::min(kPermGroupMax, pl->opt.tile_perm_group) / kBlock * kBlock
+                                                                        : (pl->hinted ? 256 : 0);
                 const bool use_perm = perm_group > 0;
                 StepArgs<T> at = a;
                 if (use_perm) {
@@ -3102,27 +2496,53 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     if (use_perm)
                         hipLaunchKernelGGL(k_tile_perm, dim3((unsigned)((w1 - w0 + perm_group - 1) / perm_group)), dim3(kBlock), 0, ws,
                                            (const uint8_t *)pl->cls_last.p, (int32_t *)pl->tile_perm.p, w0, w1, perm_group);
-                    hipLaunchKernelGGL((k_mc_tile<T>), grid, block, tile_lds_pad(), ws, at, w0, w1, j, K);
+                    launch_tile<T>(ws, at, w0, w1, j, K, tol);
                     HIP_TRY(hipEventRecord(pl->wide_t1[(size_t)j], ws));
                     ++r.launches;
                 }
                 r.wide_next = ntile;
                 r.wide_through = -1; // (from here on: the last tile the tail has been told to wait for)
             }
+            auto wait_tile = [&](int32_t need) -> int { // the plan's stream behind wide tile `need` (once per tile)
+                if (need > r.wide_through) {
+                    HIP_TRY(hipStreamWaitEvent(st, pl->wide_t1[(size_t)std::min(need, ntile - 1)], 0));
+                    r.wide_through = need;
+                }
+                return 0;
+            };
+            // The SECOND tier (levels W .. W + M - 1, K2 steps per launch, level l trailing level l - 1 by K2 steps): the same
+            // kernel on the plan's own stream, in order with the tail's launches.  Launch j2 routes level W + m through the
+            // steps ((j2 - m) K2, (j2 - m + 1) K2]; its rows read the wide rows (any level below W) one step behind, so it goes
+            // behind the tile that completes the LAST wide level through step (j2 + 1) K2 - 1; level W + m has completed
+            // step s after launch m + ceil(s / K2) - 1.
+            StepArgs<T> am = a;
+            am.out_vec = a.out_vec && K2 % 4 == 0 && sizeof(T) == 4 && nsteps % 4 == 0;
+            auto mid_through = [&](int32_t j2_last) -> int { // queue the second tier's launches up to index j2_last
+                for (; r.mid_next <= std::min(j2_last, nmid - 1); ++r.mid_next) {
+                    const int32_t j2 = r.mid_next;
+                    const int32_t s_need = std::min((j2 + 1) * K2, nsteps) - 1; // the wide rows' step the launch reads up to
+                    if (s_need >= 1)
+                        if (int rc = wait_tile((s_need - 1) / K + W - 1)) return rc;
+                    launch_tile<T>(st, am, w1, m1, j2 + W, K2, tol);
+                    ++r.launches;
+                }
+                return 0;
+            };
             // (with lagged rows -- always in the tail, route_begin_t -- launch t routes the tail's other rows at step t and the
             // lagged ones at step t - maxlag, and the window ends at launch nsteps + maxlag: k_mc_step's LAG form)
             const int32_t lagmax = pl->maxlag;
             for (int32_t t = t0 + 1; t <= t_end; ++t) {
+                const int32_t tn = std::min(t, nsteps);
+                // the tail's step t reads the rows above it at step t - 1: the last level of the second tier is there after
+                // launch M - 2 + ceil((t - 1) / K2) ...
+                if (M > 0 && tn >= 2)
+                    if (int rc = mid_through(M - 2 + (tn - 1 + K2 - 1) / K2)) return rc;
                 if (tail) {
-                    // the last wide level has completed step t - 1 after tile ceil((t - 1) / K) + W - 2 ... and, with it,
-                    // through step ceil((t - 1) / K) K: the tail waits once per K steps
-                    const int32_t tn = std::min(t, nsteps);
-                    const int32_t need = tn == 1 ? -1 : (tn - 2) / K + W - 1; // tile index; none for the first step (state only)
-                    if (need > r.wide_through) {
-                        HIP_TRY(hipStreamWaitEvent(st, pl->wide_t1[(size_t)std::min(need, ntile - 1)], 0));
-                        r.wide_through = need;
-                    }
-                    launch_step<T, true>(st, a, w1, s1, t);
+                    // ... and the last wide level after tile ceil((t - 1) / K) + W - 2 (and, with it, through step
+                    // ceil((t - 1) / K) K: the tail waits once per K steps)
+                    if (tn >= 2)
+                        if (int rc = wait_tile((tn - 2) / K + W - 1)) return rc;
+                    launch_step<T, true>(st, a, m1, s1, t, tol);
                     ++r.launches;
                 }
                 const int32_t t_all = t - lagmax; // every row has reached step t_all
@@ -3131,20 +2551,21 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             }
             // what the caller queues next on the plan's stream (a gather of cut-edge flows through t_end, the next window) must
             // see every WIDE row at t_end too: the tile that completes the last wide level through that step -- not every
-            // tile queued, they are all queued up front and a chunk's hand-off must not wait for the window's last tile
+            // tile queued, they are all queued up front and a chunk's hand-off must not wait for the window's last tile --
+            // and every row of the second tier: its launches through the one that completes its last level
             {
                 const int32_t te = std::min(t_end, nsteps);
+                if (M > 0 && te >= 1)
+                    if (int rc = mid_through(M - 2 + (te + K2 - 1) / K2)) return rc;
                 const int32_t need_end = te <= 0 ? -1 : std::min((te - 1) / K + W - 1, ntile - 1);
-                if (need_end >= 0 && need_end > r.wide_through) {
-                    HIP_TRY(hipStreamWaitEvent(st, pl->wide_t1[(size_t)need_end], 0));
-                    r.wide_through = need_end;
-                }
+                if (need_end >= 0)
+                    if (int rc = wait_tile(need_end)) return rc;
             }
         } else if (r.short_ts) {
             const int32_t s0 = tp.lvl_ptr[0], s1 = tp.lvl_ptr[L];
             const int32_t lagmax = pl->maxlag;
             for (int32_t t = t0 + 1; t <= t_end; ++t) { // launch t: rows at step t, lagged rows at step t - lagmax
-                launch_step<T, true>(st, a, s0, s1, t);
+                launch_step<T, true>(st, a, s0, s1, t, pl->opt.tol);
                 ++r.launches;
                 const int32_t t_all = t - lagmax; // every row has reached step t_all
                 if (t_all > 0 && t_all % kTile == 0 && t_all < nsteps)
@@ -3158,7 +2579,7 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                 const int32_t hi = d - 1 < L - 1 ? d - 1 : L - 1;
                 const int32_t s0 = tp.lvl_ptr[lo], s1 = tp.lvl_ptr[hi + 1];
                 if (s1 > s0) {
-                    launch_step<T, false>(st, a, s0, s1, t0 + d);
+                    launch_step<T, false>(st, a, s0, s1, t0 + d, pl->opt.tol);
                     ++r.launches;
                 }
                 const int32_t t_all = t0 + d - (L - 1); // every level has reached step t_all
@@ -3169,14 +2590,11 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     }
     HIP_TRY(hipGetLastError());
     r.t_done = t_end;
-    // TRMC_SETUP_ASIDE (two plans taking turns on a device, route_begin_t): the window's end is queued with its last launch,
+    // Sequence mode (several plans taking turns on a device, route_begin_t): the window's end is queued with its last launch,
     // so that what ANOTHER plan queues next in the shared hardware queues comes after it -- trmc_route_end then waits for this
     // plan's window only, not for the other plan's as well
-    if (t_end >= r.nsteps + pl->maxlag) {
-        const char *aside_env = std::getenv("TRMC_SETUP_ASIDE");
-        if (aside_env && aside_env[0] == '1')
-            if (int rc = route_end_queue<T>(pl)) return rc;
-    }
+    if (t_end >= r.nsteps + pl->maxlag && pl->opt.sequence)
+        if (int rc = route_end_queue<T>(pl)) return rc;
     return 0;
 }
 
@@ -3188,24 +2606,6 @@ template <class T> int route_end_t(trmc_plan *pl)
     const int32_t nsteps = r.nsteps;
     if (int rc = route_end_queue<T>(pl)) return rc;
     HIP_TRY(hipStreamSynchronize(st));
-    if (r.win_ran) {
-        int32_t ctl[16] = {0};
-        HIP_TRY(hipMemcpy(ctl, pl->win_ctr.p, sizeof ctl, hipMemcpyDeviceToHost));
-#ifdef TRMC_WIN_DEBUG
-        std::fprintf(stderr, "[window debug] workers launched %d ran %d | wide items %d (%.1f us each) tail items %d (%.1f us each) | alive %.1f us per worker, "
-                             "idle polls/16 %d, phases found exhausted %d\n", pl->win_workers, ctl[15], ctl[8], ctl[8] ? (double)ctl[12] / ctl[8] : 0.0, ctl[9],
-                     ctl[9] ? (double)ctl[13] / ctl[9] : 0.0, ctl[15] ? (double)ctl[14] / ctl[15] : 0.0, ctl[10], ctl[11]);
-#endif
-        if (ctl[2] != 0) {
-            r.active = false;
-            static const char *what[] = {"?", "a tail item for the wide rows above it", "a wide item for the sub-diagonal before it", "an idle worker for the window's end"};
-            return fail(TRMC_EHIP, std::string("window kernel: ") + what[ctl[4] >= 0 && ctl[4] <= 3 ? ctl[4] : 0]
-                                       + " waited longer than the watchdog allows (item " + std::to_string(ctl[5]) + ", phase / sub-diagonal "
-                                       + std::to_string(ctl[6]) + "; tail phases complete " + std::to_string(ctl[0]) + ", sub-diagonals claimed "
-                                       + std::to_string(ctl[1]) + "); window abandoned");
-        }
-    }
-
     float ms01 = 0, ms12 = 0, ms23 = 0;
     HIP_TRY(hipEventElapsedTime(&ms01, pl->ev[0], pl->ev[1]));
     HIP_TRY(hipEventElapsedTime(&ms12, pl->ev[1], pl->ev[2]));
@@ -3222,12 +2622,14 @@ template <class T> int route_end_t(trmc_plan *pl)
     s.ms_main = ms12;
     s.ms_emit = ms23;
     s.ms_total = (double)ms01 + ms12 + ms23;
-    s.wide_levels = r.win_ran ? r.win_W : r.wide;
-    s.wide_k = r.win_ran ? r.win_K : r.wide_k;
+    s.wide_levels = r.wide;
+    s.wide_k = r.wide_k;
     s.wide_launches = r.wide_next;
-    s.window_kernel = r.win_ran ? 1 : 0;
-    s.wide_segment_steps = r.win_ran ? (int64_t)(tp.lvl_ptr[r.win_W] - tp.lvl_ptr[0]) * nsteps
-                                     : (r.wide > 0 ? (int64_t)(tp.lvl_ptr[r.wide] - tp.lvl_ptr[0]) * nsteps : 0);
+    s.mid_levels = r.mid;
+    s.mid_k = r.mid_k;
+    s.mid_launches = r.mid_next;
+    s.arithmetic = pl->opt.tol ? TRMC_ARITH_TOLERANCE : TRMC_ARITH_EXACT;
+    s.wide_segment_steps = r.wide > 0 ? (int64_t)(tp.lvl_ptr[r.wide + r.mid] - tp.lvl_ptr[0]) * nsteps : 0;
     s.ms_wide = 0.0;
     {
         const size_t timed_n = std::min<size_t>((size_t)r.wide_next, pl->wide_t0.size());
@@ -3434,6 +2836,7 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     pl->tag_span = nsteps + 1;
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
     HIP_TRY(hipEventRecord(pl->ev[0], st));
+    pl->q0_staged = false; // (consumed by this window)
     if (pl->forcing_pending) { // (trmc_stage_forcing: the copy into in_qlat runs on the copy stream)
         HIP_TRY(hipStreamWaitEvent(st, pl->ev_forcing, 0));
         pl->forcing_pending = false;
@@ -3480,11 +2883,11 @@ static bool flow_lean(const trmc_plan *pl, int nsteps)
 {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
-    const char *force = std::getenv("TRMC_FLOW_LEAN"); // "0" / "1": A/B measurements
+    const int32_t force = pl->opt.flow_lean; // (trmc_plan_options.flow_lean: > 0 always, < 0 never -- A/B measurements)
     return (uint64_t)pl->nseg * (uint64_t)nsteps * 3ull < (1ull << 32)
-           && (force ? force[0] == '1' : pl->topo.nblocks <= TRMC_LEAN_WAVES * (256 / kFlowBlock) * ncu);
+           && (force ? force > 0 : pl->topo.nblocks <= TRMC_LEAN_WAVES * (256 / kFlowBlock) * ncu);
 }
-// Optional (TRMC_FLOW_OVERLAP=1; off by default): consecutive launches of a short-timestep window on the lean kernel
+// Optional (trmc_plan_options.flow_overlap; off by default): consecutive launches of a short-timestep window on the lean kernel
 // alternate between two compute streams.  Rows hand their state from launch to launch through granules (flow plane,
 // d_gran), so launch c+1 needs no kernel boundary behind launch c -- its cheap blocks take the slots launch c's cheap blocks
 // have left while c's costly blocks are still finishing.  Safe because every block of a launch is resident (flow_lean):
@@ -3493,8 +2896,7 @@ static bool flow_lean(const trmc_plan *pl, int nsteps)
 // GPU_MAX_HW_QUEUES=1, which troute_amd.distributed sets -- hence opt-in.
 static bool flow_overlap(const trmc_plan *pl)
 {
-    const char *on = std::getenv("TRMC_FLOW_OVERLAP");
-    return on && on[0] == '1' && pl->run.short_ts && flow_lean(pl, pl->run.nsteps);
+    return pl->opt.flow_overlap && pl->run.short_ts && flow_lean(pl, pl->run.nsteps);
 }
 static hipStream_t flow_stream(const trmc_plan *pl, int which) { return which ? pl->fstream : pl->stream; }
 
@@ -3519,7 +2921,16 @@ int flow_route_advance(trmc_plan *pl, int t_end)
             HIP_TRY(hipMemsetAsync(a.cuq_head, 0, (size_t)pl->ncuq * sizeof(int32_t), st));
         }
         const dim3 grid((unsigned)pl->topo.nblocks), block(kFlowBlock);
-        if (lean && a.lag)
+        if (pl->opt.tol) {
+            if (lean && a.lag)
+                hipLaunchKernelGGL((k_mc_flow_lean<true, true>), grid, block, 0, st, a, r.t_done, t_end);
+            else if (lean)
+                hipLaunchKernelGGL((k_mc_flow_lean<false, true>), grid, block, 0, st, a, r.t_done, t_end);
+            else if (r.short_ts)
+                hipLaunchKernelGGL((k_mc_flow<true, true>), grid, block, 0, st, a, r.t_done, t_end);
+            else
+                hipLaunchKernelGGL((k_mc_flow<false, true>), grid, block, 0, st, a, r.t_done, t_end);
+        } else if (lean && a.lag)
             hipLaunchKernelGGL((k_mc_flow_lean<true>), grid, block, 0, st, a, r.t_done, t_end);
         else if (lean)
             hipLaunchKernelGGL((k_mc_flow_lean<false>), grid, block, 0, st, a, r.t_done, t_end);
@@ -3658,23 +3069,36 @@ int flow_route_end(trmc_plan *pl)
     return 0;
 }
 
-template <class T> int segments_t(int64_t n, const void *in, void *out)
+template <class T> int segments_t(int64_t n, const void *in, void *out, bool tol, int32_t *iters_out)
 {
-    DevBuf din, dout;
+    DevBuf din, dout, dit;
     int rc = din.ensure((size_t)n * 15 * sizeof(T));
     if (!rc) rc = dout.ensure((size_t)n * 6 * sizeof(T));
+    if (!rc && iters_out) rc = dit.ensure((size_t)n * sizeof(int32_t));
     if (!rc) {
         hipError_t e = hipMemcpy(din.p, in, (size_t)n * 15 * sizeof(T), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((k_segments<T>), dim3(blocks_for(n)), dim3(kBlock), 0, 0, (const T *)din.p, (T *)dout.p, n);
+            bool launched = false;
+            if constexpr (sizeof(T) == 4) {
+                if (tol) {
+                    hipLaunchKernelGGL((k_segments<T, true>), dim3(blocks_for(n)), dim3(kBlock), 0, 0, (const T *)din.p, (T *)dout.p,
+                                       (int32_t *)dit.p, n);
+                    launched = true;
+                }
+            }
+            if (!launched)
+                hipLaunchKernelGGL((k_segments<T, false>), dim3(blocks_for(n)), dim3(kBlock), 0, 0, (const T *)din.p, (T *)dout.p,
+                                   (int32_t *)dit.p, n);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)n * 6 * sizeof(T), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && iters_out) e = hipMemcpy(iters_out, dit.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(TRMC_EHIP, std::string("trmc_segments: ") + hipGetErrorString(e));
     }
     din.release();
     dout.release();
+    dit.release();
     return rc;
 }
 
@@ -3707,9 +3131,10 @@ template <class T> int chain_from_t(trmc_plan *dst, trmc_plan *src, int nsteps_d
     }
     // the rows of the source's wide levels are final when its last tile is (they never wrote a velocity row: the velocity
     // of the initial state is not an input of the step); the other rows when its tail is
-    const int32_t W = src->run.short_ts ? src->run.wide : 0;
+    const int32_t W = src->run.short_ts ? src->run.wide : 0, M = W > 0 ? src->run.mid : 0;
     const int32_t b0 = 0, w1 = tp.lvl_ptr[W], s1 = (int32_t)src->nseg; // (boundary rows, if any, go with the tail's part)
     const int32_t w0 = W > 0 ? tp.lvl_ptr[0] : w1;
+    const int32_t m1 = tp.lvl_ptr[W + M]; // (the second tier's rows, [w1, m1): routed on the source's own stream, no velocity row either)
     if (W > 0 && src->wstream) {
         HIP_TRY(hipEventRecord(dst->ev_chain[0], src->wstream));
         HIP_TRY(hipStreamWaitEvent(dst->wstream, dst->ev_chain[0], 0));
@@ -3732,7 +3157,8 @@ template <class T> int chain_from_t(trmc_plan *dst, trmc_plan *src, int nsteps_d
     HIP_TRY(hipEventRecord(dst->ev_chain[1], src->stream));
     HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_chain[1], 0));
     if (w0 > b0) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(w0 - b0)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, b0, w0);
-    if (s1 > w1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(s1 - w1)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, w1, s1);
+    if (m1 > w1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(m1 - w1)), dim3(kBlock), 0, dst->stream, sq, sq, sd, dq, dv, dd, w1, m1);
+    if (s1 > m1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(s1 - m1)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, m1, s1);
     HIP_TRY(hipEventRecord(dst->ev_chain[3], dst->stream));
     if (!src->ev_released[1]) HIP_TRY(hipEventCreateWithFlags(&src->ev_released[1], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(src->ev_released[1], dst->stream));
@@ -3905,11 +3331,43 @@ int trmc_plan_engine(const trmc_plan *pl, int32_t *is_flow)
     return 0;
 }
 
+int trmc_plan_set_sequence_mode(trmc_plan *pl, int on)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
+    pl->opt.sequence = on != 0;
+    return 0;
+}
+
+int trmc_plan_arithmetic(const trmc_plan *pl, int32_t *arithmetic)
+{
+    if (!pl || !arithmetic) return fail(TRMC_EINVAL, "plan/arithmetic is NULL");
+    *arithmetic = pl->opt.tol ? TRMC_ARITH_TOLERANCE : TRMC_ARITH_EXACT;
+    return 0;
+}
+
 int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
                         const uint8_t *boundary, const uint8_t *cost_hint, int precision, int device, int flags,
                         trmc_plan **out)
 {
+    return trmc_plan_create_opt(nseg, up_ptr, up_idx, params, boundary, cost_hint, precision, device, flags, nullptr, out);
+}
+
+int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const float *params,
+                         const uint8_t *boundary, const uint8_t *cost_hint, int precision, int device, int flags,
+                         const trmc_plan_options *options, trmc_plan **out)
+{
     if (!out) return fail(TRMC_EINVAL, "out is NULL");
+    trmc_plan_options o{};
+    if (options) {
+        if (options->struct_size < 8 || options->struct_size > (int32_t)sizeof(trmc_plan_options))
+            return fail(TRMC_EINVAL, "trmc_plan_options.struct_size is not the size of a trmc_plan_options this library knows");
+        std::memcpy(&o, options, (size_t)options->struct_size);
+    }
+    if (o.arithmetic != TRMC_ARITH_EXACT && o.arithmetic != TRMC_ARITH_TOLERANCE) return fail(TRMC_EINVAL, "bad trmc_plan_options.arithmetic");
+    if (o.arithmetic == TRMC_ARITH_TOLERANCE && precision != 32)
+        return fail(TRMC_EINVAL, "TRMC_ARITH_TOLERANCE is an arithmetic of precision-32 plans");
+    if (o.tile_perm_group > 0 && o.tile_perm_group % kBlock != 0) return fail(TRMC_EINVAL, "tile_perm_group must be a multiple of 256");
     *out = nullptr;
     if (precision != 32 && precision != 64) return fail(TRMC_EINVAL, "precision must be 32 or 64");
     if (nseg > 0 && !params) return fail(TRMC_EINVAL, "params is NULL");
@@ -3922,55 +3380,57 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
 
     trmc_plan *pl = new (std::nothrow) trmc_plan();
     if (!pl) return fail(TRMC_ENOMEM, "out of host memory");
-    {
-        const char *e = std::getenv("TRMC_ENGINE");
-        if (e && std::strcmp(e, "levels") != 0 && std::strcmp(e, "flow") != 0) {
-            delete pl;
-            return fail(TRMC_EINVAL, "TRMC_ENGINE must be 'flow' or 'levels'");
+    if (engine == TRMC_ENGINE_AUTO) {
+        if (precision != 32)
+            engine = TRMC_ENGINE_LEVELS;
+        else {
+            int64_t nb = 0;
+            for (int64_t r = 0; boundary && r < nseg; ++r) nb += boundary[r] == 1;
+            engine = ((flags & TRMC_PLAN_SHORT_TS) && nseg - nb >= 1000000) ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
         }
-        if (engine == TRMC_ENGINE_AUTO) {
-            if (precision != 32)
-                engine = TRMC_ENGINE_LEVELS;
-            else if (e)
-                engine = std::strcmp(e, "levels") == 0 ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
-            else {
-                int64_t nb = 0;
-                for (int64_t r = 0; boundary && r < nseg; ++r) nb += boundary[r] == 1;
-                engine = ((flags & TRMC_PLAN_SHORT_TS) && nseg - nb >= 1000000) ? TRMC_ENGINE_LEVELS : TRMC_ENGINE_FLOW;
-            }
-        }
-        pl->flow = engine == TRMC_ENGINE_FLOW;
-        if (const char *w = std::getenv("TRMC_FLOW_WATCHDOG_MS")) pl->watchdog_ticks = (uint64_t)std::max(1L, std::atol(w)) * 100000ull;
+    }
+    pl->flow = engine == TRMC_ENGINE_FLOW;
+    pl->watchdog_ticks = (uint64_t)(o.flow_watchdog_ms > 0 ? o.flow_watchdog_ms : 30000) * 100000ull;
+    {   // the options, resolved once (see trmc.h)
+        int ncu = 256;
+        if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        trmc_plan::Opt &po = pl->opt;
+        po.tol = o.arithmetic == TRMC_ARITH_TOLERANCE;
+        po.wide_min_rows = o.wide_min_rows < 0 ? 0 : (o.wide_min_rows > 0 ? o.wide_min_rows : 384L * ncu);
+        po.wide_levels = (int32_t)std::min<long>(o.wide_levels > 0 ? o.wide_levels : 16, kWideMaxLevels);
+        po.wide_k = o.wide_k > 0 ? o.wide_k : 0; // (0: 16, or an eighth of a short window -- route_begin_t)
+        po.mid_min_rows = o.mid_min_rows < 0 ? 0 : (o.mid_min_rows > 0 ? o.mid_min_rows : kMidDefaultRowsPerCu * (int64_t)ncu);
+        po.mid_levels = (int32_t)std::min<long>(o.mid_levels > 0 ? o.mid_levels : 12, kMidMaxLevels);
+        po.mid_k = o.mid_k > 0 ? o.mid_k : 4;
+        po.tile_perm_group = o.tile_perm_group < 0 ? 0 : (o.tile_perm_group > 0 ? o.tile_perm_group : -1);
+        po.sequence = o.sequence_mode != 0;
+        po.flow_overlap = o.flow_overlap != 0;
+        po.flow_lean = o.flow_lean;
     }
     const bool tiers = (flags & TRMC_PLAN_SHORT_TS) != 0;
     std::string err;
     // (plans meant for assume_short_ts on the level engine: rows fed by boundary rows stay below the levels that may be routed
-    // several timesteps per launch -- topology.hpp, boundary_floor; TRMC_WIDE_LEVELS never asks for more than kWideMaxLevels)
+    // several timesteps per launch -- topology.hpp, boundary_floor; wide_levels never asks for more than kWideMaxLevels, and the
+    // second tier only takes levels none of whose rows reads a boundary row: route_begin_t)
     // ... and (a hinted short-timestep plan of the level engine) the rows below the levels that can be routed several timesteps
     // per launch are ordered by cost across levels: the same rule picks those levels here as in route_begin_t, which never
-    // takes more of them than the plan was ordered for.  TRMC_TAIL_SORT=0 keeps the per-level order (A/B).
-    int64_t wide_min_rows = 0;
-    int32_t wide_max_levels = 0;
-    if (tiers && !pl->flow && cost_hint) {
-        const char *off = std::getenv("TRMC_TAIL_SORT");
-        int ncu = 256;
-        if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-        const char *e1 = std::getenv("TRMC_WIDE_MIN_ROWS"), *e2 = std::getenv("TRMC_WIDE_LEVELS");
-        if (!(off && off[0] == '0')) {
-            wide_min_rows = e1 && *e1 ? std::atol(e1) : 384L * ncu;
-            wide_max_levels = (int32_t)std::min<long>(e2 && *e2 ? std::atol(e2) : 16, kWideMaxLevels);
-        }
+    // takes more of them than the plan was ordered for.  tail_sort < 0 keeps the per-level order (A/B).
+    int64_t wide_min_rows = 0, mid_min_rows = 0;
+    int32_t wide_max_levels = 0, mid_max_levels = 0;
+    if (tiers && !pl->flow && cost_hint && o.tail_sort >= 0) {
+        wide_min_rows = pl->opt.wide_min_rows;
+        wide_max_levels = pl->opt.wide_levels;
+        mid_min_rows = pl->opt.mid_min_rows;
+        mid_max_levels = pl->opt.mid_levels;
     }
-    // (a dataflow plan built for the general mode: basins with a main stem of at least TRMC_STEM_MIN_ROWS rows -- default
-    // 1 024, 0 = off -- are laid out stem-last with the side tributaries from the top of the stem down, and their stems'
-    // blocks take the first tickets: topology.hpp, stem_min_rows)
+    // (a dataflow plan built for the general mode: basins with a main stem of at least stem_min_rows rows -- default 1 024,
+    // < 0 = off -- are laid out stem-last with the side tributaries from the top of the stem down, and their stems' blocks take
+    // the first tickets: topology.hpp, stem_min_rows)
     int32_t stem_min_rows = 0;
-    if (pl->flow && (flags & TRMC_PLAN_FULL_TS)) {
-        const char *e = std::getenv("TRMC_STEM_MIN_ROWS");
-        stem_min_rows = (int32_t)std::max(0L, e && *e ? std::atol(e) : 1024L);
-    }
+    if (pl->flow && (flags & TRMC_PLAN_FULL_TS)) stem_min_rows = o.stem_min_rows < 0 ? 0 : (o.stem_min_rows > 0 ? o.stem_min_rows : 1024);
     const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0, tiers,
-                                         (tiers && !pl->flow) ? kWideMaxLevels : 0, wide_min_rows, wide_max_levels, stem_min_rows);
+                                         (tiers && !pl->flow) ? kWideMaxLevels : 0, wide_min_rows, wide_max_levels, stem_min_rows,
+                                         mid_min_rows, mid_max_levels);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
@@ -4079,7 +3539,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->win_tab, &pl->win_ctr, &pl->tile_perm, &pl->cls_last})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->tile_perm, &pl->cls_last})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);
@@ -4134,6 +3594,7 @@ int trmc_plan_clone(trmc_plan *src, trmc_plan **out)
     pl->params_sane = src->params_sane;
     pl->flow = src->flow;
     pl->watchdog_ticks = src->watchdog_ticks;
+    pl->opt = src->opt;
     pl->ncuq = src->ncuq;
     pl->parent = src;
     ++src->clones;
@@ -4199,7 +3660,6 @@ int trmc_stage_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq)
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
     if (pl->nseg > 0 && !qlat) return fail(TRMC_EINVAL, "qlat is NULL");
-    if (pl->topo.nboundary > 0) return fail(TRMC_EINVAL, "a plan with boundary rows stages its forcing with trmc_upload_forcing");
     if (int rc = use_device(pl)) return rc;
     if (int rc = ensure_copy_stream(pl)) return rc;
     const size_t bytes = (size_t)pl->nseg * nq * pl->esz;
@@ -4209,9 +3669,13 @@ int trmc_stage_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq)
     // the initial state unless trmc_plan_chain_from replaces it: what this plan's last window left (gathered now, on the
     // plan's stream, before anything overwrites the planes); a plan that has routed nothing must be chained to
     if (int rc = pl->in_q0.ensure((size_t)pl->nseg * 3 * pl->esz)) return rc;
-    pl->state_missing = busy || pl->routed_nsteps < 0;
-    if (pl->nseg > 0 && !pl->state_missing)
+    // (a second staging before the window is routed -- a corrected forcing -- finds routed_nsteps < 0 but the state the first
+    // one gathered still in in_q0: q0_staged)
+    pl->state_missing = busy || (pl->routed_nsteps < 0 && !pl->q0_staged);
+    if (pl->nseg > 0 && !pl->state_missing && pl->routed_nsteps >= 0)
         if (int rc = final_state_into(pl, pl->in_q0.p)) return rc;
+    pl->q0_staged = !pl->state_missing;
+    // (a forcing staged earlier and not routed yet is still on its way on the same copy stream: the new copy lands behind it)
     // (behind the set-up of the window in progress, which reads the staging area; the plan's last fetch may still be running
     // on the same copy stream: in order behind it)
     if (busy) HIP_TRY(hipStreamWaitEvent(pl->cstream, pl->ev[1], 0));
@@ -4220,7 +3684,9 @@ int trmc_stage_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq)
     pl->forcing_pending = true;
     pl->qlat_direct = false;
     pl->nq = nq;
-    pl->have_boundary = true;
+    // (a plan with boundary rows: their hydrographs of the staged window arrive in ranges while it runs --
+    // trmc_set_boundary_flow_range, the multi-GPU hand-off -- or with trmc_set_boundary_flow_device before it begins)
+    pl->have_boundary = pl->topo.nboundary == 0;
     pl->ngage = 0; // nudging tables belong to one window (the launches of a window in progress carry their own copy of the pointers)
     pl->nraw = 0;
     pl->staged_nsteps = nsteps;
@@ -4280,9 +3746,9 @@ static int stage_state(trmc_plan *pl, int nsteps, int64_t nq, const void *q0, co
     if (pl->nseg > 0) {
         if (q0) {
             HIP_TRY(hipMemcpyAsync(pl->in_q0.p, q0, (size_t)pl->nseg * 3 * e, hipMemcpyHostToDevice, pl->stream));
-        } else { // warm start in HBM: (q_T, q_T, depth_T) of the previous window, AbstractNetwork.py:182-190
+        } else if (pl->routed_nsteps >= 0) { // warm start in HBM: (q_T, q_T, depth_T) of the previous window, AbstractNetwork.py:182-190
             if (int rc = final_state_into(pl, pl->in_q0.p)) return rc;
-        }
+        } // (else: q0_staged -- the state an earlier staging of this window put into in_q0 stands, upload_check)
     }
     if (pl->topo.nboundary > 0 && boundary_fvd) {
         const size_t b = (size_t)pl->topo.nboundary * nsteps * 3 * e;
@@ -4297,7 +3763,7 @@ static int stage_state(trmc_plan *pl, int nsteps, int64_t nq, const void *q0, co
     pl->staged_nsteps = nsteps;
     pl->routed_nsteps = -1;
     pl->state_missing = false;
-    pl->forcing_pending = false;
+    pl->q0_staged = true;
     return 0;
 }
 
@@ -4307,9 +3773,16 @@ static int upload_check(trmc_plan *pl, int nsteps, int64_t nq, const void *q0)
     if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
-    if (pl->nseg > 0 && !q0 && pl->routed_nsteps < 0)
+    if (pl->nseg > 0 && !q0 && pl->routed_nsteps < 0 && !pl->q0_staged)
         return fail(TRMC_ESTATE, "q0 is NULL (continue from the resident state) but nothing has been routed yet");
-    return use_device(pl);
+    if (int rc = use_device(pl)) return rc;
+    if (pl->forcing_pending) {
+        // a forcing staged with trmc_stage_forcing is (or may still be) on its way into in_qlat on the copy stream: this upload
+        // replaces it, and its own copy must not be overtaken by the older one
+        HIP_TRY(hipEventSynchronize(pl->ev_forcing));
+        pl->forcing_pending = false;
+    }
+    return 0;
 }
 
 int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq, const void *q0,
@@ -5045,13 +4518,22 @@ int trmc_route(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short
 
 int trmc_segments(int device, int precision, int64_t n, const void *in, void *out)
 {
+    return trmc_segments_ex(device, precision, TRMC_ARITH_EXACT, n, in, out, nullptr);
+}
+
+int trmc_segments_ex(int device, int precision, int arithmetic, int64_t n, const void *in, void *out, int32_t *iters_out)
+{
+    if (arithmetic != TRMC_ARITH_EXACT && arithmetic != TRMC_ARITH_TOLERANCE) return fail(TRMC_EINVAL, "bad arithmetic");
+    if (arithmetic == TRMC_ARITH_TOLERANCE && precision != 32)
+        return fail(TRMC_EINVAL, "TRMC_ARITH_TOLERANCE is an arithmetic of precision 32");
     if (precision != 32 && precision != 64) return fail(TRMC_EINVAL, "precision must be 32 or 64");
     if (n < 0) return fail(TRMC_EINVAL, "n < 0");
     if (n == 0) return 0;
     if (!in || !out) return fail(TRMC_EINVAL, "in/out is NULL");
     if (int rc = check_device(device)) return rc;
     HIP_TRY(hipSetDevice(device));
-    return precision == 32 ? segments_t<float>(n, in, out) : segments_t<double>(n, in, out);
+    const bool tol = arithmetic == TRMC_ARITH_TOLERANCE;
+    return precision == 32 ? segments_t<float>(n, in, out, tol, iters_out) : segments_t<double>(n, in, out, false, iters_out);
 }
 
 // The reference's own C binding of one segment-step -- c_muskingcungenwm, src/kernel/muskingum/pyMCsingleSegStime_NoLoop.f90:8-21

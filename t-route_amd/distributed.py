@@ -43,11 +43,12 @@ class _EngineOf:
 
 class ShardedRouter:
     def __init__(self, to, params, rank=0, world=1, device=0, plan_factory=None, precision=32,
-                 partition=None, cost_hint=None, assume_short_ts=None, engine="auto"):
+                 partition=None, cost_hint=None, assume_short_ts=None, engine="auto", options=None):
         """cost_hint: optional uint8 [nseg] (global rows), the ``iteration_hint()`` of a router of the same network
         after a window -- every plan then groups its rows by that cost (RoutingPlan ``cost_hint``; results unchanged,
         the kernels' wavefronts become uniform in cost).  assume_short_ts / engine: passed to every RoutingPlan (the
-        timestep mode the router will be used with, if known; "auto" | "levels" | "flow")."""
+        timestep mode the router will be used with, if known; "auto" | "levels" | "flow"); options: RoutingPlan's (a dict of
+        trmc_plan_options fields, e.g. {"arithmetic": "tolerance"})."""
         if plan_factory is None:
             from .plan import RoutingPlan  # the HIP engine; no fallback
             from . import _lib
@@ -59,7 +60,7 @@ class ShardedRouter:
             def plan_factory(lp, li, par, boundary, prec, dev, short=None, **kw):
                 # short: the merged plan of the short-timestep device path is built for that mode whatever the caller said
                 return RoutingPlan(lp, li, par, boundary, prec, dev,
-                                   assume_short_ts=assume_short_ts if short is None else short, engine=engine, **kw)
+                                   assume_short_ts=assume_short_ts if short is None else short, engine=engine, options=options, **kw)
         from .synthetic import upstream_csr
         self._hint = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
         if self._hint is not None:
@@ -271,16 +272,17 @@ class ShardedRouter:
         return self._route_phased(qts_subdivisions, assume_short_ts, nchunks)
 
     # ---- short-timestep path: one plan, trunk time-skewed -----------------------------------------------
-    def _merged_plan(self, lag):
+    def _merged_plan(self, lag, upload=True):
         """plan0's table followed by the trunk table (trunk rows + boundary copies of the cut rows that feed
-        it); trunk rows carry `lag`.  Built once per lag, forcing staged once per upload()."""
+        it); trunk rows carry `lag`.  Built once per lag, forcing staged once per upload() (upload=False: the caller stages
+        the forcing itself -- a sequence of days, troute_amd.sequence)."""
         if self.plan1 is None:                      # nothing to merge: plan0 itself, forcing staged by upload()
             if not hasattr(self, "_rsM_cut"):
                 self._rsM_cut = self.plan0.rowset(self.my_cut_local)
                 self._rsM_out0 = self.plan0.rowset(self.my_out0_local)
                 self._rsM_out1 = None
             return self.plan0
-        if self.planM is not None and self._planM_lag == lag and self._planM_upload == self._upload_gen:
+        if self.planM is not None and self._planM_lag == lag and (not upload or self._planM_upload == self._upload_gen):
             return self.planM
         mk = self._mk
         n0 = self.rows0.shape[0]
@@ -306,9 +308,51 @@ class ShardedRouter:
             self._rsM_cut = self.planM.rowset(self.my_cut_local)
             self._rsM_out0 = self.planM.rowset(self.my_out0_local)
             self._rsM_out1 = self.planM.rowset(n0 + self.my_out1_local) if self.my_out1_global.size else None
-        self.planM.upload_forcing(self.nsteps, self._qlat[self._rowsM], self._q0_of(self._rowsM), None)
-        self._planM_upload = self._upload_gen
+        if upload:
+            self.planM.upload_forcing(self.nsteps, self._qlat[self._rowsM], self._q0_of(self._rowsM), None)
+            self._planM_upload = self._upload_gen
         return self.planM
+
+    # ---- a sequence of days on this rank (troute_amd.sequence.DaySequence): the forcing staged by the caller, day by day ----
+    def sequence_rows(self):
+        """global rows of the plan a short-timestep window of this rank runs on, in its row order: the sub-basins, then (a
+        trunk owner) the trunk table -- trunk rows and the boundary copies of the cut rows that feed it"""
+        return self.rows0 if self.plan1 is None else np.concatenate([self.rows0, self.rows1])
+
+    def _chunking(self, nchunks):
+        """(steps per chunk, chunks, the trunk's lag) of a short-timestep window: decided ONCE per router (see _route_skewed)"""
+        if nchunks is None:
+            if getattr(self, "_nchunks_default", None) is None:
+                self._nchunks_default = self._default_chunks(self.planM if self.planM is not None
+                                                             else _EngineOf(self._merged_engine()))
+            nchunks = self._nchunks_default
+        K = max(1, -(-self.nsteps // max(1, int(nchunks))))
+        return K, -(-self.nsteps // K), (2 * K if self.plan1 is not None else 0)
+
+    def begin_sequence(self, nsteps, local_qlat, state0, qts_subdivisions, nchunks=None):
+        """Day 0 of a sequence: this rank's rows of the forcing (``sequence_rows()`` order) and the state -- global
+        [nseg, 3], or None to continue from what the rank's last window left in HBM -- staged synchronously."""
+        self.nsteps = nsteps
+        P = self._merged_plan(self._chunking(nchunks)[2], upload=False)
+        rows = self.sequence_rows()
+        if state0 is None:
+            q0 = None
+        elif state0.shape[0] == rows.shape[0] and rows.shape[0] != self.nseg:   # (already this rank's rows, in that order)
+            q0 = np.ascontiguousarray(state0)
+        else:
+            q0 = np.ascontiguousarray(state0[rows])
+        P.upload_forcing(nsteps, local_qlat, q0, None)
+        self._plan0_staged = self.plan1 is None
+
+    def stage_next(self, nsteps, local_qlat):
+        """The NEXT day's forcing of this rank's rows (page-locked memory) on its way to the device beside whatever runs; the
+        day starts from the state the last window leaves (trmc_stage_forcing)."""
+        P = self.planM if self.plan1 is not None else self.plan0
+        P.stage_forcing(nsteps, local_qlat)
+
+    def route_staged(self, qts_subdivisions, nchunks=None):
+        """One short-timestep window on the forcing staged by begin_sequence() / stage_next(): route_on_device()'s body."""
+        return self._route_skewed(qts_subdivisions, nchunks, staged=True)
 
     def _merged_engine(self):
         """The engine trmc_plan_create_ex's TRMC_ENGINE_AUTO gives the merged short-timestep plan (rows0 + trunk), without
@@ -332,7 +376,7 @@ class ShardedRouter:
         engine of the plan that actually runs the window."""
         return 4 if getattr(plan, "engine", "levels") == "flow" else 24
 
-    def _route_skewed(self, qts_subdivisions, nchunks):
+    def _route_skewed(self, qts_subdivisions, nchunks, staged=False):
         """assume_short_ts: a row at step t reads its upstream rows at step t-1 only.  The window is cut into
         chunks of K steps.  After this rank's sub-basins have been queued through chunk c, the chunk's
         cut-edge hydrographs are gathered (plan stream), all-gathered and written into the trunk's boundary
@@ -342,19 +386,12 @@ class ShardedRouter:
         except the 2K that drain it at the end.  The host never waits inside the window."""
         X, dev, comm, e = self._X, self._dev, self._comm, self._esz
         nsteps = self.nsteps
-        if nchunks is None:
-            # Decided ONCE per router, from the engine the MERGED plan runs on -- not from plan0's on the first window and the
-            # merged plan's afterwards: the two can differ (plan0 under a million rows: dataflow; rows0 + trunk at or above
-            # it: levels), the chunk count would change between the first and the second window, with it the trunk's lag,
-            # and a merged plan rebuilt for the new lag has no resident state to continue from.
-            if getattr(self, "_nchunks_default", None) is None:
-                self._nchunks_default = self._default_chunks(self.planM if self.planM is not None
-                                                             else _EngineOf(self._merged_engine()))
-            nchunks = self._nchunks_default
-        K = max(1, -(-nsteps // max(1, int(nchunks))))
-        C = -(-nsteps // K)
-        lag = 2 * K if self.plan1 is not None else 0
-        P = self._merged_plan(lag)
+        # (the default number of chunks is decided ONCE per router, from the engine the MERGED plan runs on -- not from plan0's
+        # on the first window and the merged plan's afterwards: the two can differ (plan0 under a million rows: dataflow;
+        # rows0 + trunk at or above it: levels), the chunk count would change between the first and the second window, with
+        # it the trunk's lag, and a merged plan rebuilt for the new lag has no resident state to continue from)
+        K, C, lag = self._chunking(nchunks)
+        P = self._merged_plan(lag, upload=not staged)
         x = self._window_buffers([min(nsteps, (c + 1) * K) - c * K for c in range(C)], nsteps)
         sc = self._sc
         P.route_begin(nsteps, qts_subdivisions, True)

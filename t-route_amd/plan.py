@@ -6,6 +6,7 @@ MC_Reach objects on every compute_network_structured call,
 mc_reach.pyx:283-378).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -71,8 +72,11 @@ def topology_blocks_general(up_ptr, up_idx, boundary=None, stem_min_rows=1024):
 
 class RoutingPlan:
     def __init__(self, up_ptr, up_idx, params, boundary=None, precision=32, device=0, cost_hint=None,
-                 assume_short_ts=None, engine="auto"):
+                 assume_short_ts=None, engine="auto", options=None):
         """
+        options       : dict of trmc_plan_options fields (include/trmc.h), e.g. {"arithmetic": "tolerance"} or
+                        {"wide_min_rows": 32, "wide_k": 8}; the TRMC_* variables of ``_lib.OPTION_ENV`` (tests, A/B runs)
+                        fill what the dict leaves out.  ``engine="auto"`` also honours TRMC_ENGINE=levels|flow.
         assume_short_ts : the timestep mode the plan will be routed with, if known (None: unknown) -- it routes
                         correctly either way, the value picks the row order that is fast for the mode
         engine        : "auto" | "levels" | "flow"  (include/trmc.h, trmc_plan_create_ex)
@@ -100,13 +104,20 @@ class RoutingPlan:
         if hint is not None and hint.shape != (nseg,):
             raise ValueError("cost_hint shape mismatch")
         h = C.c_void_p(0)
+        if engine == "auto" and precision == 32 and os.environ.get("TRMC_ENGINE"):       # (A/B runs; fp64 plans: level engine)
+            engine = os.environ["TRMC_ENGINE"]
+            if engine not in ("levels", "flow"):
+                raise ValueError("TRMC_ENGINE must be 'flow' or 'levels'")
         flags = {"auto": _lib.ENGINE_AUTO, "levels": _lib.ENGINE_LEVELS, "flow": _lib.ENGINE_FLOW}[engine]
         if assume_short_ts is not None:
             flags |= _lib.PLAN_SHORT_TS if assume_short_ts else _lib.PLAN_FULL_TS
+        opt = _lib.plan_options(options)
         _lib.mark_hip_started()
-        _lib.check(_lib.lib().trmc_plan_create_ex(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
-                                                  _lib.ptr(b), _lib.ptr(hint), precision, device, flags, C.byref(h)))
+        _lib.check(_lib.lib().trmc_plan_create_opt(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(params),
+                                                   _lib.ptr(b), _lib.ptr(hint), precision, device, flags, C.byref(opt),
+                                                   C.byref(h)))
         self._h = h
+        self.arithmetic = "tolerance" if opt.arithmetic == _lib.ARITH_TOLERANCE else "exact"
         f = C.c_int32(0)
         _lib.check(_lib.lib().trmc_plan_engine(self._h, C.byref(f)))
         self.engine = "flow" if f.value else "levels"
@@ -252,7 +263,7 @@ class RoutingPlan:
         order in HBM, its own forcing / state / result / streams -- for a sequence of windows that takes turns on the two
         (``chain_from``, ``stage_forcing``)."""
         other = object.__new__(RoutingPlan)
-        for k in ("nseg", "precision", "dtype", "nboundary", "engine", "maxlag"):
+        for k in ("nseg", "precision", "dtype", "nboundary", "engine", "maxlag", "arithmetic"):
             setattr(other, k, getattr(self, k))
         h = C.c_void_p(0)
         other._h = C.c_void_p(0)
@@ -260,6 +271,11 @@ class RoutingPlan:
         other._h = h
         other._nsteps = None
         return other
+
+    def set_sequence_mode(self, on=True):
+        """The plan is one of several that take turns on the device (``clone``, ``chain_from``): a window's set-up goes to
+        the tile stream and its end is queued with its last launch (include/trmc.h, trmc_plan_options.sequence_mode)."""
+        _lib.check(_lib.lib().trmc_plan_set_sequence_mode(self._h, int(bool(on))))
 
     def stage_forcing(self, nsteps, qlat):
         """The next window's forcing on its way to the device without waiting for anything (trmc_stage_forcing): `qlat`
@@ -402,8 +418,9 @@ class RoutingPlan:
         return self.download_fvd()
 
 
-def segments(inputs, device=0):
-    """Batch of independent single-segment steps on the GPU.  inputs [n,15] -> [n,6]."""
+def segments(inputs, device=0, arithmetic="exact", with_iterations=False):
+    """Batch of independent single-segment steps on the GPU.  inputs [n,15] -> [n,6] (and, with_iterations, the secant
+    iterations of every step, int32 [n]).  arithmetic: "exact" | "tolerance" (include/trmc.h, trmc_plan_options)."""
     inputs = np.ascontiguousarray(inputs)
     if inputs.dtype == np.float32:
         precision = 32
@@ -414,5 +431,8 @@ def segments(inputs, device=0):
     if inputs.ndim != 2 or inputs.shape[1] != 15:
         raise ValueError("inputs must be [n, 15]")
     out = np.empty((inputs.shape[0], 6), dtype=inputs.dtype)
-    _lib.check(_lib.lib().trmc_segments(device, precision, inputs.shape[0], _lib.ptr(inputs), _lib.ptr(out)))
-    return out
+    iters = np.zeros(inputs.shape[0], dtype=np.int32) if with_iterations else None
+    _lib.mark_hip_started()
+    _lib.check(_lib.lib().trmc_segments_ex(device, precision, {"exact": _lib.ARITH_EXACT, "tolerance": _lib.ARITH_TOLERANCE}[arithmetic],
+                                           inputs.shape[0], _lib.ptr(inputs), _lib.ptr(out), _lib.ptr(iters)))
+    return (out, iters) if with_iterations else out

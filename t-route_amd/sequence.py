@@ -1,0 +1,182 @@
+"""A SEQUENCE of routing windows ("days") on one network -- what an operational cycle does with the reference: every call of
+``compute_nhd_routing_v02`` gets that window's ``qlat_values`` (mc_reach.pyx:173,:723) and starts from the state the window
+before left (``AbstractNetwork.new_q0``, AbstractNetwork.py:177-191).  Here the windows follow each other on the device
+without the host in between:
+
+  * every day's forcing travels host -> device on a copy stream while the day before is being routed (page-locked memory,
+    ``trmc_stage_forcing``);
+  * the state is handed from day to day in HBM (``trmc_plan_chain_from`` between a plan and its clone on one GPU; the
+    resident state of the merged plan on a rank of a multi-GPU job);
+  * every day's products -- the outlet hydrographs and the final state, SURVEY 8d's throughput mode -- are copied to
+    page-locked host arrays beside the next day's kernels (``trmc_fetch_begin``) and handed to the caller a day later.
+
+One GPU (``world == 1``): the days take turns on the router's plan and a clone of it (ONE copy of topology and parameter
+columns in HBM, two sets of window buffers), both in sequence mode (trmc_plan_options.sequence_mode), so that day w + 1's
+leading levels run while day w's narrow levels are finishing.  The order in which a day's pieces are queued is what the
+shared hardware queues need ("A sequence of days"): the window; BEHIND its last launch the gathers of its
+products and their copy to the host; behind its set-up the forcing of the plan's NEXT day, two days ahead.
+
+Several ranks (``ShardedRouter`` with a communicator): the same protocol on every rank's merged plan (its sub-basins plus
+the time-skewed trunk it owns): the day's forcing of the rank's rows staged from page-locked memory, the cut-edge
+hydrographs exchanged chunk by chunk (``ShardedRouter.route_on_device``), the outlet block gathered, the rank's final
+state and the block fetched beside the next day.
+
+Reference analogue of the loop: nwm_routing/__main__.py:1112-1226 (``nwm_route`` per run set, ``new_q0`` between them).
+"""
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+def pinned_like(array):
+    """A page-locked copy of a forcing array (what ``stage_forcing`` wants to copy from without a wait)."""
+    out = _lib.result_empty(array.shape, array.dtype, always_pinned=True)
+    out[...] = array
+    return out
+
+
+class DaySequence:
+    """``DaySequence(router, nsteps, qts_subdivisions)`` then ``run(days, state0, steps, warmup)``.
+
+    router : a ``ShardedRouter`` (one rank of a job of any size; ``enable_device_exchange`` done when world > 1)
+    """
+
+    def __init__(self, router, nsteps, qts_subdivisions, assume_short_ts=True, nchunks=None):
+        if not assume_short_ts:
+            raise ValueError("a pipelined sequence of windows needs assume_short_ts (a day's leading levels run ahead of the "
+                             "day before's narrow ones only there); route general-mode windows one by one")
+        self.r = router
+        self.nsteps, self.qts, self.nchunks = int(nsteps), int(qts_subdivisions), nchunks
+        self.world = router.world
+        self._clone = None
+        self._local_days = None
+        if self.world == 1:
+            p = router.plan0
+            if p.engine != "levels":
+                raise ValueError("the one-GPU sequence pipeline runs on the level engine (a plan created for assume_short_ts "
+                                 "with a million rows or more, or engine='levels')")
+            self._clone = p.clone()
+            self.plans = [p, self._clone]
+            for pl in self.plans:
+                pl.set_sequence_mode(True)
+            self._rs = [pl.rowset(router.my_out0_local) for pl in self.plans]
+
+    def close(self):
+        if self._clone is not None:
+            self._clone.close()
+            self._clone = None
+            self.r.plan0.set_sequence_mode(False)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def prepare_days(self, days):
+        """Multi-rank jobs: this rank's rows of every day in page-locked memory (where a caller would have read them from the
+        forcing file to).  One GPU: the arrays as they are (they should be page-locked: ``pinned_like``)."""
+        if self.world == 1:
+            return list(days)
+        rows = self.r.sequence_rows()
+        return [pinned_like(np.ascontiguousarray(d[rows])) for d in days]
+
+    def run(self, days, state0, steps, warmup=0, on_day=None, prepared=False):
+        """Route ``warmup + steps`` consecutive days; day w takes ``days[w % len(days)]`` (global rows; a ring that is used in
+        turn -- the state evolves on, no two windows are the same work) and starts from day w - 1's final state (day 0 from
+        ``state0`` [nseg, 3], or from the router's resident state if None).  The clock covers the ``steps`` days after the
+        warm-up ones, everything a day needs inside it.  ``on_day(w, hydrographs, final_state)`` is called as each day's
+        products arrive on the host (arrays of a ring of three: copy what is kept).
+
+        Returns {"el": wall seconds of the timed days, "ms_main": [per-day device ms], "day_ms": [host-observed periods],
+        "hyd", "final": the last day's products, "days_routed", "last_plan"}."""
+        days = list(days) if prepared else self.prepare_days(days)
+        if self.world == 1:
+            return self._run_one_gpu(days, state0, steps, warmup, on_day)
+        return self._run_rank(days, state0, steps, warmup, on_day)
+
+    # ---- one GPU: a plan and its clone ---------------------------------------------------------------------------------
+    def _run_one_gpu(self, days, state0, steps, warmup, on_day):
+        from . import comm as X
+        plans, rs, nsteps, qts = self.plans, self._rs, self.nsteps, self.qts
+        nd, total = len(days), warmup + steps
+        dev = plans[0].info()["device"]
+
+        def queue(p):
+            p.route_begin(nsteps, qts, True)
+            p.route_advance(nsteps)
+
+        def after_window(i, w):
+            """behind day w's window on plan i: its products to the host, then the forcing of the plan's next day (w + 2)"""
+            plans[i].fetch_begin(rs[i], True)
+            if w + 2 < total:
+                plans[i].stage_forcing(nsteps, days[(w + 2) % nd])
+        plans[0].upload_forcing(nsteps, days[0], state0)        # the first day the ordinary way (synchronous)
+        if total > 1:
+            plans[1].stage_forcing(nsteps, days[1 % nd])
+        ms_main, ends, got = [], [], (None, None)
+        t0 = time.perf_counter() if warmup == 0 else None       # (no warm-up day: the clock starts with day 0's window)
+        queue(plans[0])
+        after_window(0, 0)
+        for w in range(1, total + 1):
+            cur, prev = plans[w % 2], plans[(w - 1) % 2]
+            if w < total:
+                cur.chain_from(prev)                            # day w starts where day w - 1 ends: handed over in HBM
+                queue(cur)
+                after_window(w % 2, w)
+            st = prev.route_end()                               # day w - 1 is through
+            ends.append(time.perf_counter())
+            if w - 1 >= warmup:
+                ms_main.append(st["ms_main"])
+            got = prev.fetch_wait()                             # ... and its products are on the host
+            if on_day is not None:
+                on_day(w - 1, got[0], got[1])
+            if w == warmup and warmup > 0:                      # the clock starts when the last warm-up day is through
+                t0 = time.perf_counter()
+        X.device_synchronize(dev)
+        el = time.perf_counter() - t0
+        day_ms = [round((b - a) * 1e3, 2) for a, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
+        return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total,
+                "last_plan": plans[(total - 1) % 2], "day_ms": day_ms}
+
+    # ---- one rank of a multi-GPU job: the merged plan, day after day ----------------------------------------------------------
+    def _run_rank(self, days, state0, steps, warmup, on_day):
+        r = self.r
+        X, dev, comm = r._X, r._dev, r._comm
+        nsteps, qts = self.nsteps, self.qts
+        nd, total = len(days), warmup + steps
+        r.begin_sequence(nsteps, days[0], state0, qts, self.nchunks)   # day 0's forcing and state, synchronously
+        ms_main, ends, got = [], [], (None, None)
+
+        def sync():
+            X.device_synchronize(dev)
+            comm.barrier()
+        sync()
+        t0 = time.perf_counter() if warmup == 0 else None
+        for w in range(total):
+            rows, hyd = r.route_staged(qts, self.nchunks)          # day w: every hand-off in HBM (route_on_device's body)
+            ends.append(time.perf_counter())
+            if w >= warmup:
+                ms_main.append(r.last_stats["phase0"]["ms_main"])
+            if w >= 1:
+                got = r.fetch_wait()                                # day w - 1's products (copied beside day w)
+                if on_day is not None:
+                    on_day(w - 1, got[0], got[1])
+            r.fetch_begin(hyd, want_hyd=(r.rank == 0))
+            if w + 1 < total:
+                r.stage_next(nsteps, days[(w + 1) % nd])            # day w + 1's forcing on its way; its state: what day w leaves
+            if w + 1 == warmup:                                     # the clock starts when the last warm-up day is through
+                sync()
+                t0 = time.perf_counter()
+        got = r.fetch_wait()
+        if on_day is not None:
+            on_day(total - 1, got[0], got[1])
+        sync()
+        el = time.perf_counter() - t0
+        el = float(comm.all_reduce_max_host(np.array([el], dtype=np.float64))[0])
+        day_ms = [round((b - a) * 1e3, 2) for a, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
+        return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total, "last_plan": r._state_plans[0],
+                "day_ms": day_ms}

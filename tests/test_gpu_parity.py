@@ -139,21 +139,22 @@ def test_lowercolorado_return_tuple_shape(lc):
     assert r[6].shape == (lc.nseg, lc.nts) and len(r[7]) == 3 and r[8].shape == (0, lc.nts + 1) and len(r[9]) == 4
 
 
-@pytest.mark.parametrize("engine", ["flow", "levels", "levels-wide", "levels-window"])
+@pytest.mark.parametrize("engine", ["flow", "levels", "levels-wide", "levels-mid"])
 @pytest.mark.parametrize("short", [True, False])
 def test_lowercolorado_fp32_bit_identical_to_reference_golden(lc, short, engine, monkeypatch):
     """Golden = reference Fortran kernel symbol driven through the restated loop (make_fixtures.py):
     12 time slices x every segment and 100 probe segments x every step, both timestep modes, on BOTH engines
     (the dataflow engine k_mc_flow and the level engine k_mc_step), the level engine also with its wide levels several
-    steps per launch (k_mc_tile) and with the whole window as one persistent launch (k_mc_window; short-timestep mode)."""
+    steps per launch (k_mc_tile), and with a second tier of levels below those (short-timestep mode)."""
     monkeypatch.setenv("TRMC_ENGINE", engine.split("-")[0])
-    monkeypatch.setenv("TRMC_WINDOW", "1" if engine.endswith("-window") else "0")
     if engine.endswith("-wide"):
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
         monkeypatch.setenv("TRMC_WIDE_K", "5")
-    if engine.endswith("-window"):
-        monkeypatch.setenv("TRMC_WIN_MIN_ROWS", "32")
-        monkeypatch.setenv("TRMC_WIN_K", "4")
+    if engine.endswith("-mid"):
+        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
+        monkeypatch.setenv("TRMC_WIDE_K", "8")
+        monkeypatch.setenv("TRMC_MID_MIN_ROWS", "8")
+        monkeypatch.setenv("TRMC_MID_K", "2")
     _, fvd = route_lc(lc, short)
     g = lc.golden()
     tag = "shortts" if short else "fullts"
@@ -258,24 +259,26 @@ def run_both(ups, params, qlat, q0, nsteps, qts, short):
 # TRMC_ENGINE: the dataflow engine (k_mc_flow*), the level engine one step per launch (k_mc_step), and the level engine
 # with its wide levels routed several steps per launch under a level skew (k_mc_tile; at its default thresholds only
 # networks of CONUS width take that path -- here every level of 32 rows or more does, five steps per launch)
-ENGINES = ["flow", "levels", "levels-wide", "levels-window"]
+ENGINES = ["flow", "levels", "levels-wide", "levels-mid"]
 
 
 def set_engine(monkeypatch, engine):
     """levels: one launch per timestep (k_mc_step); levels-wide: the leading levels several steps per launch beside it
-    (k_mc_tile); levels-window: the whole short-timestep window as ONE persistent launch (k_mc_window; other windows as
-    `levels`) -- every level of at least 32 rows as wide items here, so that small networks exercise both item kinds."""
+    (k_mc_tile); levels-mid: two tiers of them -- levels of at least 64 rows eight steps per launch, the levels of at least 8
+    rows right below them four steps per launch under their own skew, the rest one step per launch."""
     monkeypatch.setenv("TRMC_ENGINE", engine.split("-")[0])
-    monkeypatch.setenv("TRMC_WINDOW", "1" if engine.endswith("-window") else "0")
-    if engine.endswith("-wide"):
+    if engine.endswith("-mid"):
+        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
+        monkeypatch.setenv("TRMC_WIDE_K", "8")
+        monkeypatch.setenv("TRMC_MID_MIN_ROWS", "8")
+        monkeypatch.setenv("TRMC_MID_K", "4")
+        monkeypatch.setenv("TRMC_MID_LEVELS", "20")
+    elif engine.endswith("-wide"):
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
         monkeypatch.setenv("TRMC_WIDE_K", "8")        # (a multiple of 4: the 16-byte result stores where nsteps allows them)
         monkeypatch.setenv("TRMC_TILE_PERM", "512")   # (rows re-dealt to a tile's threads by class, also on plans without a hint)
     else:
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
-    if engine.endswith("-window"):
-        monkeypatch.setenv("TRMC_WIN_MIN_ROWS", "32")
-        monkeypatch.setenv("TRMC_WIN_K", "8")
 
 
 @pytest.mark.parametrize("engine", ENGINES)
@@ -481,7 +484,7 @@ def conus_sample_rows(to, rng, n_mid=80, n_small=200, lo=50, hi=20000):
 
 
 @pytest.mark.parametrize("short,plan_mode,engine", [(True, None, "flow"), (False, None, "flow"), (True, True, "levels"),
-                                                    (True, True, "levels-window"), (False, False, "flow")])
+                                                    (True, True, "levels-mid"), (False, False, "flow")])
 def test_conus_full_size_samples_bit_identical_to_oracle(conus, short, plan_mode, engine, monkeypatch):
     """Size-independent property at full size: independent networks do not interact, so any
     sub-collection of them routed ALONE by the oracle must equal -- bit for bit -- what the GPU
@@ -496,9 +499,10 @@ def test_conus_full_size_samples_bit_identical_to_oracle(conus, short, plan_mode
     q0 = np.zeros((nseg, 3), np.float32)
     rows = conus_sample_rows(to, np.random.default_rng(77))
     assert 10000 < rows.size < 400000
-    # "levels": the default of a short-timestep plan at this size (k_mc_tile + k_mc_step + k_emit); "levels-window": the
-    # same plan with the whole window as one persistent launch (k_mc_window, opt-in)
-    monkeypatch.setenv("TRMC_WINDOW", "1" if engine == "levels-window" else "0")
+    # "levels": the default of a short-timestep plan at this size (k_mc_tile + k_mc_step + k_emit); "levels-mid": the
+    # same plan with a second tier of tiles below the wide levels (levels of at least 16 384 rows, four steps per launch)
+    if engine == "levels-mid":
+        monkeypatch.setenv("TRMC_MID_MIN_ROWS", "16384")
     with RoutingPlan(up_ptr, up_idx, net["params"], assume_short_ts=plan_mode) as plan:
         assert plan.engine == engine.split("-")[0]
         plan.upload_forcing(nsteps, net["qlat"], q0)
@@ -507,7 +511,7 @@ def test_conus_full_size_samples_bit_identical_to_oracle(conus, short, plan_mode
         final = plan.download_final_state()
     assert st["segment_steps"] == nseg * nsteps
     if engine.startswith("levels"):
-        assert st["window_kernel"] == (1 if engine == "levels-window" else 0) and st["wide_levels"] > 0
+        assert st["wide_levels"] > 0 and (st["mid_levels"] > 0) == (engine == "levels-mid")
     g2l = np.full(nseg, -1, np.int64)
     g2l[rows] = np.arange(rows.size)
     lp, li = restrict_csr(up_ptr, up_idx, rows, g2l)

@@ -51,52 +51,72 @@ def test_window_in_parts_equals_one_call(short):
         buf.free()
 
 
-@pytest.mark.parametrize("nseg,nsteps,qts,K,min_rows,max_levels", [
-    (6000, 48, 12, 8, 32, 24), (6000, 50, 7, 4, 32, 24), (6000, 37, 5, 16, 32, 3), (6000, 9, 4, 2, 16, 64),
-    (6000, 24, 24, 1, 32, 2), (900, 33, 12, 8, 8, 24), (20000, 64, 16, 32, 64, 1), (150, 16, 4, 4, 1, 24)])
-def test_the_window_as_one_persistent_launch_equals_the_launches_it_replaces(monkeypatch, nseg, nsteps, qts, K, min_rows, max_levels):
-    """k_mc_window: a short-timestep fp32 window of the level engine as ONE persistent launch -- the leading levels K
-    timesteps per work item under the level skew, the deeper levels one timestep per item in phases, claims through sharded
-    counters, state exchanged through write-through stores -- against the per-step launches of the same plan (which the
-    other tests pin to the oracle and the reference goldens): window lengths that are no multiple of K, forcing columns
-    that change inside an item, K from 1 to 32, one to every level as wide items (no tail at all in the last case), a
-    window in parts (which falls back to the launches), several windows on one plan, a warm start from the resident state."""
+@pytest.mark.parametrize("nseg,nsteps,qts,K,K2,wide_rows,mid_rows,mid_levels", [
+    (6000, 48, 12, 8, 4, 64, 8, 12), (6000, 50, 7, 16, 3, 128, 16, 32), (6000, 37, 5, 5, 5, 64, 4, 3), (6000, 9, 4, 2, 1, 32, 8, 32),
+    (900, 33, 12, 8, 2, 16, 2, 12), (20000, 64, 16, 16, 4, 256, 32, 6), (150, 16, 4, 4, 2, 4, 1, 32)])
+def test_two_tiers_of_tiles_equal_the_one_step_launches(nseg, nsteps, qts, K, K2, wide_rows, mid_rows, mid_levels):
+    """The level engine's second tier (trmc_plan_options.mid_*): the levels right below the wide ones routed K2 steps per
+    launch under a skew of their own, on the plan's stream between the tail's launches -- against the one-step launches of the
+    same network (which the other tests pin to the oracle and the reference goldens): window lengths that are no multiple of
+    K or K2, forcing columns that change inside a tile, K2 = 1 .. K, a tail or none, a window in parts, several windows on one
+    plan, a warm start, cost collection, the asynchronous fetch and a state handed to a clone."""
     to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(seed=nseg + K, nseg=nseg)
     qlat = np.ascontiguousarray(np.tile(qlat, (1, (nsteps + qts - 1) // qts // qlat.shape[1] + 1)))
-    monkeypatch.setenv("TRMC_ENGINE", "levels")
-    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
-    monkeypatch.setenv("TRMC_WINDOW", "0")
-    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as ref:
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels", options={"wide_min_rows": -1}) as ref:
         want = ref.route(nsteps, qts, True, qlat, q0)
-        assert ref.stats()["window_kernel"] == 0
+        assert ref.stats()["wide_levels"] == 0
         ref.upload_forcing(nsteps, qlat, None)
         ref.route_device(nsteps, qts, True)
         want2, state2 = ref.download_fvd(), ref.download_final_state()
-    monkeypatch.setenv("TRMC_WINDOW", "1")
-    monkeypatch.setenv("TRMC_WIN_MIN_ROWS", str(min_rows))
-    monkeypatch.setenv("TRMC_WIN_LEVELS", str(max_levels))
-    monkeypatch.setenv("TRMC_WIN_K", str(K))
-    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as plan:
-        for _ in range(2):                                      # (twice: the counters are re-initialised per window)
+    opts = {"wide_min_rows": wide_rows, "wide_k": K, "mid_min_rows": mid_rows, "mid_k": K2, "mid_levels": mid_levels}
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, engine="levels", options=opts) as plan:
+        for _ in range(2):
             got = plan.route(nsteps, qts, True, qlat, q0)
             st = plan.stats()
-            assert st["window_kernel"] == 1 and st["wide_k"] == K and 1 <= st["wide_levels"] <= max_levels and st["main_launches"] == 1
+            assert st["wide_levels"] >= 1 and st["wide_k"] == K and 1 <= st["mid_levels"] <= mid_levels and st["mid_k"] == min(K, K2)
+            assert st["mid_launches"] == -(-nsteps // st["mid_k"]) + st["mid_levels"] - 1
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         iters = plan.download_iterations()
         plan.upload_forcing(nsteps, qlat, None)                 # the next window from the resident state
         plan.route_device(nsteps, qts, True)
         assert np.array_equal(plan.download_fvd().view(np.uint32), want2.view(np.uint32))
         assert np.array_equal(plan.download_final_state().view(np.uint32), state2.view(np.uint32))
-        plan.upload_forcing(nsteps, qlat, q0)                   # a window that arrives in parts: one step per launch
+        plan.upload_forcing(nsteps, qlat, q0)                   # a window that arrives in parts
         plan.route_begin(nsteps, qts, True)
-        plan.route_advance(nsteps // 2)
+        plan.route_advance(nsteps // 3)
+        plan.route_advance(nsteps // 3)                         # (nothing new)
+        plan.route_advance(nsteps - 1)
         plan.route_advance(nsteps)
-        assert plan.route_end()["window_kernel"] == 0
+        plan.route_end()
         assert np.array_equal(plan.download_fvd().view(np.uint32), want.view(np.uint32))
         assert np.array_equal(plan.download_iterations(), iters)
-        plan.collect_cost(True)                                 # cost collection: the launches as well
+        plan.collect_cost(True)
         assert np.array_equal(plan.route(nsteps, qts, True, qlat, q0).view(np.uint32), want.view(np.uint32))
-        assert plan.stats()["window_kernel"] == 0
+        cost, n = plan.download_cost()
+        assert n == nsteps and cost.max() > 0
+        plan.collect_cost(False)
+        # the state handed to a clone on the device, both plans in sequence mode; products fetched with the window
+        clone = plan.clone()
+        for pl in (plan, clone):
+            pl.set_sequence_mode(True)
+        outlets = np.flatnonzero(to < 0)
+        rs = clone.rowset(outlets)
+        pinned = _lib.result_empty(qlat.shape, np.float32, always_pinned=True)
+        pinned[...] = qlat
+        plan.upload_forcing(nsteps, qlat, q0)
+        plan.route_begin(nsteps, qts, True)
+        plan.route_advance(nsteps)
+        clone.stage_forcing(nsteps, pinned)
+        clone.chain_from(plan)
+        clone.route_begin(nsteps, qts, True)
+        clone.route_advance(nsteps)
+        clone.fetch_begin(rs, True)
+        plan.route_end()
+        clone.route_end()
+        hyd, state = clone.fetch_wait()
+        assert np.array_equal(state.view(np.uint32), state2.view(np.uint32))
+        assert np.array_equal(hyd.view(np.uint32), np.ascontiguousarray(want2[outlets, :, 0]).view(np.uint32))
+        clone.close()
 
 
 def test_call_order_errors():
@@ -485,6 +505,25 @@ def test_a_sequence_of_distinct_days_on_a_plan_and_its_clone_with_staged_forcing
             ref.upload_forcing(nsteps, days[0], want_s[-1])
             ref.route_device(nsteps, qts, True)
             assert np.array_equal(last.download_final_state().view(np.uint32), ref.download_final_state().view(np.uint32))
+        # a forcing staged twice before its window (a corrected file), and a synchronous upload that replaces a staged one:
+        # the state gathered by the first staging stands, and the older copy cannot land on top of the newer forcing
+        want_next = ref_state = None
+        with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as ref:
+            ref.upload_forcing(nsteps, days[3], last.download_final_state())
+            ref.route_device(nsteps, qts, True)
+            want_next = ref.download_final_state()
+        last.stage_forcing(nsteps, days[2])                  # the wrong day
+        last.stage_forcing(nsteps, days[3])                  # corrected: routed_nsteps is -1 by now, the state is in in_q0
+        last.route_device(nsteps, qts, True)
+        assert np.array_equal(last.download_final_state().view(np.uint32), want_next.view(np.uint32))
+        with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as ref:
+            ref.upload_forcing(nsteps, days[4], want_next)
+            ref.route_device(nsteps, qts, True)
+            ref_state = ref.download_final_state()
+        last.stage_forcing(nsteps, days[5])                  # the wrong day again, asynchronously ...
+        last.upload_forcing(nsteps, days[4], None)           # ... replaced by a synchronous upload that continues the state
+        last.route_device(nsteps, qts, True)
+        assert np.array_equal(last.download_final_state().view(np.uint32), ref_state.view(np.uint32))
         # ... and a plan that has routed nothing must be chained to
         c = a.clone()
         c.stage_forcing(nsteps, days[1])

@@ -87,19 +87,18 @@ def gaged_lowercolorado(ngage=60, gmax=200, seed=8):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("short,engine", [(True, None), (False, None), (True, "levels"), (True, "levels-wide"), (True, "levels-window")])
+@pytest.mark.parametrize("short,engine", [(True, None), (False, None), (True, "levels"), (True, "levels-wide"), (True, "levels-mid")])
 def test_gpu_nudging_bit_identical_to_oracle(short, engine, monkeypatch):
     """engine: None = the default (dataflow engine at this size); "levels" = k_mc_step; "levels-wide" = the level engine with
-    its wide levels several steps per launch under a level skew (k_mc_tile); "levels-window" = the whole window as one
-    persistent launch (k_mc_window)"""
+    its wide levels several steps per launch under a level skew (k_mc_tile); "levels-mid" = the same with a second tier
+    below the wide levels, fewer steps per launch under its own skew"""
     if engine:
         monkeypatch.setenv("TRMC_ENGINE", "levels")
         monkeypatch.setenv("TRMC_PLAN_CACHE", "0")
-        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32" if engine.endswith("wide") else "0")
+        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0" if engine == "levels" else ("64" if engine.endswith("mid") else "32"))
         monkeypatch.setenv("TRMC_WIDE_K", "7")
-        monkeypatch.setenv("TRMC_WINDOW", "1" if engine.endswith("window") else "0")
-        monkeypatch.setenv("TRMC_WIN_MIN_ROWS", "32")
-        monkeypatch.setenv("TRMC_WIN_K", "4")
+        monkeypatch.setenv("TRMC_MID_MIN_ROWS", "8" if engine.endswith("mid") else "0")
+        monkeypatch.setenv("TRMC_MID_K", "3")
     from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
     lc, reaches, net, gage_ids, upos, upr, upg, usgs, lv0, lt0 = gaged_lowercolorado()
     decay = 120.0

@@ -107,16 +107,17 @@ def main():
             fin = np.isfinite(want).all(axis=(1, 2))
             # (label, engine, settings for the run): the level engine's one-step launches, the dataflow engine, and -- short
             # timesteps only -- the wide levels K steps per launch (k_mc_tile; on the cost-ordered plan with the rows below
-            # them sorted by cost across levels and k_tile_perm dealing rows to threads by class) and the window as one
-            # persistent launch (k_mc_window), both with thresholds small enough for these networks to take them
+            # them sorted by cost across levels and k_tile_perm dealing rows to threads by class) and a
+            # second tier of tiles below them, both with thresholds small enough for these networks to take them
             variants = [("levels", "levels", {"TRMC_WIDE_MIN_ROWS": "0"}), ("flow", "flow", {})]
             if short:
                 variants.append(("levels-wide", "levels", {"TRMC_WIDE_MIN_ROWS": "32", "TRMC_WIDE_K": str(int(rng.choice([3, 4, 8, 16]))),
                                                            "TRMC_WIDE_LEVELS": str(int(rng.choice([2, 5, 16]))),
                                                            "TRMC_TILE_PERM": str(int(rng.choice([0, 256, 512, 1024])))}))
-                variants.append(("levels-window", "levels", {"TRMC_WINDOW": "1", "TRMC_WIN_MIN_ROWS": "32",
-                                                             "TRMC_WIN_K": str(int(rng.choice([2, 4, 8]))),
-                                                             "TRMC_WIN_LEVELS": str(int(rng.choice([3, 8, 24])))}))
+                variants.append(("levels-mid", "levels", {"TRMC_WIDE_MIN_ROWS": "64", "TRMC_WIDE_K": str(int(rng.choice([4, 8, 16]))),
+                                                          "TRMC_MID_MIN_ROWS": str(int(rng.choice([2, 8, 16]))),
+                                                          "TRMC_MID_K": str(int(rng.choice([1, 2, 3, 4]))),
+                                                          "TRMC_MID_LEVELS": str(int(rng.choice([3, 12, 32])))}))
             for label, engine, env in variants:
                 saved = {k: os.environ.get(k) for k in env}
                 os.environ.update(env)
