@@ -40,6 +40,7 @@ Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   forcing_persistence   the same pipeline with days whose rows keep their magnitude with probability 0.5 / 0.0
   parity_full       EVERY segment against the reference Fortran on the CPU (the pipeline re-run over days N+1, N+2)
   parity_mode       the whole flowveldepth array copied to the host inside the timed region
+  hourly_output     every qts-th step of it (what the reference's writers keep), decimated on the device, copied inside the timed region
   tuned_window_warm / cold_start / independent_forcing_cold   the tuned plan on the very window it was tuned on, on a
                     cold start, on an unrelated day
   full_ts           the same workload without the short-timestep assumption (dataflow engine)
@@ -474,6 +475,8 @@ def main():
             rows, hyd = route_once(router, short_ts)
             if d2h == "full":
                 router.plan0.download_fvd()
+            elif d2h == "hourly":
+                router.plan0.download_fvd(a.qts)
             return hyd
 
         def drain():
@@ -726,6 +729,14 @@ def main():
             extra["parity_mode"]["pageable"] = {"value": rate(w), "ms_per_step": w["el"] * 1e3}
             from troute_amd import _lib as _tl
             _tl.pinned_pool_clear()
+            # ... and what the reference's WRITERS consume of it: every qts-th step (hourly output of 5-minute steps,
+            # nwm_routing/output.py:209-216, nhd_io.py:2379-2382), decimated on the device (trmc_download_fvd_strided: what
+            # compute_network_structured(..., output_stride=qts) returns), synchronously inside the timed region
+            w = timed(router, True, 3, 1, d2h="hourly")
+            extra["hourly_output"] = {"value": rate(w), "unit": "segment-timesteps/s", "ms_per_step": w["el"] / 3 * 1e3,
+                                      "copied": f"flowveldepth at every {a.qts}th step [{nseg} x {a.nsteps // a.qts} x 3] "
+                                                f"({nseg * (a.nsteps // a.qts) * 12 / 1e9:.2f} GB), decimated on the device, into a "
+                                                "page-locked array from the library's pool, inside the timed region"}
         # the window the plan was tuned on (day N, warm), a cold start (round 1's configuration), and an unrelated day
         spin_up(router, False)
         router.upload(a.nsteps, qlat_a, None)

@@ -383,6 +383,11 @@ int trmc_plan_set_lag(trmc_plan *plan, const int32_t *lag_of_row);
 /* Full result, row order: fvd_out[nseg][nsteps][3] = (q, vel, depth) per step,
  * i.e. flowveldepth[:, 1:, :] of [R1] (mc_reach.pyx:807-813).  D2H. */
 int trmc_download_fvd(trmc_plan *plan, void *fvd_out);
+/* Every `stride`-th step of it, decimated ON THE DEVICE: fvd_out[nseg][nsteps / stride][3], entry k = step stride (k + 1)
+ * (1-based) -- the steps the reference's writers keep of a window (nwm_routing/output.py:209-216, :232-240: those whose end
+ * falls on a multiple of dt * qts_subdivisions; stride = qts_subdivisions for hourly output of 5-minute steps).  A twelfth
+ * of the bytes crosses the host link: a CONUS day 0.78 GB instead of 9.4.  Bit-identical to slicing the full array. */
+int trmc_download_fvd_strided(trmc_plan *plan, int stride, void *fvd_out);
 /* Page-locked host memory for result arrays: a D2H copy into it runs at the speed of the link instead of through the
  * driver's staging buffers (the 9.4 GB flowveldepth array of a CONUS day: 0.2 s instead of 0.8 s).  The Python host side
  * keeps a small pool of these behind download_fvd(); a C caller may use them for any *_out argument.  Plain memory to the
@@ -471,8 +476,10 @@ int trmc_plan_chain_from(trmc_plan *receiver, trmc_plan *source);
  * constant columns in HBM (no second copy of them, no second flattening) and owns its own forcing, state planes, result
  * and streams -- so that consecutive windows of one sequence can take turns on the two (trmc_plan_chain_from), the next
  * day's forcing travelling to the idle one (trmc_stage_forcing) and its leading levels starting while the current day's
- * narrow levels finish.  Reservoir / nudging tables are per clone (set them on each).  Destroy order is free: the shared
- * memory goes with the last user.
+ * narrow levels finish.  The clone inherits the plan's options (trmc_plan_options) and the lag of its rows
+ * (trmc_plan_set_lag: set it BEFORE cloning); reservoir / nudging tables, row sets and the cost collection are per clone
+ * (set them on each).  Destroy order is free: the shared memory goes with the last user, the window buffers of a destroyed
+ * original at once.
  */
 int trmc_plan_clone(trmc_plan *plan, trmc_plan **out);
 

@@ -249,6 +249,32 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
             err = "internal: depth-first walk missed rows";
             return -2;
         }
+        {   // The block order's one promise: every row comes AFTER all the rows draining into it (a block only ever needs
+            // its own rows and earlier blocks).  The plain post-order keeps it by construction; the stem layout marks stem
+            // rows and side-tributary roots as seen before it emits them, and in a network with bifurcations a side
+            // sub-tree can hold a row whose second upstream row is a stem row or a later side root -- emitted before it.
+            // Checked here on every edge; a network the stem layout cannot order goes back to the plain post-order.
+            std::vector<int32_t> at(nseg, -1);
+            for (size_t i = 0; i < post.size(); ++i) at[post[i]] = (int32_t)i;
+            bool ordered = true;
+            for (size_t i = 0; ordered && i < post.size(); ++i) {
+                const int32_t r = post[i];
+                for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) {
+                    const int64_t u = up_idx[k];
+                    if (!is_b(u) && at[u] > (int32_t)i) {
+                        ordered = false;
+                        break;
+                    }
+                }
+            }
+            if (!ordered) {
+                if (stem_min_rows > 0)
+                    return build_topology(nseg, up_ptr, up_idx, boundary, t, err, cost_hint, block_rows, cost_tiers, boundary_floor,
+                                          wide_min_rows, wide_max_levels, 0, mid_min_rows, mid_max_levels);
+                err = "internal: the block order puts a row ahead of a row that drains into it";
+                return -2;
+            }
+        }
         if (!cost_tiers) cost_hint = nullptr;
         // Cost tiers.  A block runs at the pace of its costliest wavefront, so blocks should hold rows of one cost.  Every
         // row gets a tier -- its hint quantised to at most 8 steps, or without a hint the size class of its drainage --

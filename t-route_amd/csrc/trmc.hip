@@ -1925,6 +1925,25 @@ k_flow_boundary(const float *__restrict__ src, unsigned long long *gran, float *
     o[2] = ncomp > 2 ? v[2] : 0.0f;
 }
 
+// Every `stride`-th step of the result, out[row][t][3] -> dec[row][k][3] with t = stride (k + 1) - 1 (0-based): what the
+// reference's writers consume of a window (nwm_routing/output.py:209-216 and :232-240 keep the steps whose END falls on a
+// multiple of dt * qts_subdivisions).  One thread per (row, kept step): a 12-byte triple read at a stride of 12 * stride
+// bytes, written densely.
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_decimate(const T *__restrict__ out, T *__restrict__ dec, int64_t nseg, int32_t nsteps, int32_t stride, int32_t nkeep)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nseg * nkeep) return;
+    const int64_t row = i / nkeep;
+    const int32_t k = (int32_t)(i - row * nkeep);
+    const T *src = out + ((size_t)row * (size_t)nsteps + (size_t)(stride * (k + 1) - 1)) * 3;
+    T *dst = dec + (size_t)i * 3;
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
+
 // ---------------------------------------------------------------- plan
 struct DevBuf {
     void *p = nullptr;
@@ -3499,6 +3518,16 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
             && hipMemcpy(pl->prio.p, pl->topo.prio_of_wave.data(), pl->topo.prio_of_wave.size(), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(TRMC_EHIP, "uploading the wavefront priorities failed"));
         if ((rc = flow_place_blocks(pl))) return bail(rc);
+        // The stems' blocks take the first tickets and wait IN PLACE for their inflows: nothing deadlocks as long as the device
+        // holds more workgroups of the kernel at once than there are such blocks -- the others then still find slots.  Asked
+        // of the runtime for THIS device (occupancy x compute units; a smaller part, a masked one); a plan whose stems would
+        // take more than half of the slots routes in the plain ticket order instead.
+        if (!pl->topo.early_blocks.empty()) {
+            int per_cu = 0, ncu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mc_flow<false, false>, kFlowBlock, 0) != hipSuccess) per_cu = 0;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+            if ((int64_t)pl->topo.early_blocks.size() * 2 > (int64_t)per_cu * ncu) pl->topo.early_blocks.clear();
+        }
         if (!pl->topo.early_blocks.empty()) { // ticket -> block: the stems' blocks, then everybody else in order
             const int32_t nb = pl->topo.nblocks;
             std::vector<int32_t> map;
@@ -3523,7 +3552,20 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
 void trmc_plan_destroy(trmc_plan *pl)
 {
     if (!pl) return;
-    if (pl->clones > 0) { // its clones still use its static buffers: the memory goes with the last of them
+    if (pl->clones > 0) {
+        // its clones still use its STATIC buffers (topology, parameter columns, placement tables, the lag table): those go with
+        // the last of them.  Everything else -- the window buffers, gigabytes of planes and results -- is freed now (hipFree
+        // waits for the device); the handle is dead for the caller from here on.
+        if (!pl->zombie) {
+            (void)hipSetDevice(pl->device);
+            for (DevBuf &b : pl->rowsets) b.release();
+            pl->rowsets.clear();
+            for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
+                              &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos, &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos,
+                              &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch,
+                              &pl->gathered, &pl->tile_perm, &pl->cls_last})
+                b->release();
+        }
         pl->zombie = true;
         return;
     }
@@ -3632,6 +3674,13 @@ int trmc_plan_clone(trmc_plan *src, trmc_plan **out)
     pl->cuq_blk.borrow(src->cuq_blk);
     pl->cu_index.borrow(src->cu_index);
     pl->cuq_perm.borrow(src->cuq_perm);
+    // the lag of its rows (trmc_plan_set_lag: the trunk of a cut basin riding behind its owner's sub-basins) is part of how
+    // the plan routes: the clone routes the same way (row sets and the cost collection are per plan and start empty)
+    if (src->maxlag > 0) {
+        pl->lag.borrow(src->lag);
+        pl->lag_of_row = src->lag_of_row;
+        pl->maxlag = src->maxlag;
+    }
     if (int rc = pl->it_prev.ensure((size_t)pl->nseg_pad)) return bail(rc);
     if (pl->ncuq > 0)
         if (int rc = pl->cuq_head.ensure((size_t)pl->ncuq * 2 * sizeof(int32_t))) return bail(rc);
@@ -4107,6 +4156,7 @@ int trmc_plan_set_lag(trmc_plan *pl, const int32_t *lag_of_row)
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
     if (!pl->rowsets.empty()) return fail(TRMC_ESTATE, "set the lag before registering row sets");
+    if (pl->clones > 0 || pl->parent) return fail(TRMC_ESTATE, "set the lag before cloning the plan (a clone shares the lag table)");
     pl->maxlag = 0;
     pl->lag_of_row.clear();
     pl->wide_safe_pos = -1;
@@ -4252,6 +4302,32 @@ int trmc_download_fvd(trmc_plan *pl, void *fvd_out)
     if (!fvd_out) return fail(TRMC_EINVAL, "fvd_out is NULL");
     if (int rc = use_device(pl)) return rc;
     HIP_TRY(hipMemcpy(fvd_out, pl->out.p, (size_t)pl->nseg * pl->routed_nsteps * 3 * pl->esz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int trmc_download_fvd_strided(trmc_plan *pl, int stride, void *fvd_out)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->routed_nsteps < 0) return fail(TRMC_ESTATE, "nothing routed yet");
+    if (stride < 1) return fail(TRMC_EINVAL, "stride must be >= 1");
+    if (stride == 1) return trmc_download_fvd(pl, fvd_out);
+    const int32_t nkeep = pl->routed_nsteps / stride;
+    if (pl->nseg == 0 || nkeep == 0) return 0;
+    if (!fvd_out) return fail(TRMC_EINVAL, "fvd_out is NULL");
+    if (int rc = use_device(pl)) return rc;
+    const size_t bytes = (size_t)pl->nseg * nkeep * 3 * pl->esz;
+    if (int rc = pl->gathered.ensure(bytes)) return rc; // (the plan's scratch block for gathers of its result)
+    pl->gathered_bytes = 0;
+    const int64_t work = pl->nseg * (int64_t)nkeep;
+    if (pl->precision == 32)
+        hipLaunchKernelGGL((k_decimate<float>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const float *)pl->out.p,
+                           (float *)pl->gathered.p, pl->nseg, pl->routed_nsteps, stride, nkeep);
+    else
+        hipLaunchKernelGGL((k_decimate<double>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const double *)pl->out.p,
+                           (double *)pl->gathered.p, pl->nseg, pl->routed_nsteps, stride, nkeep);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(fvd_out, pl->gathered.p, bytes, hipMemcpyDeviceToHost, pl->stream));
+    HIP_TRY(hipStreamSynchronize(pl->stream));
     return 0;
 }
 

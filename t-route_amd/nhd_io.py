@@ -9,6 +9,7 @@ Same names and return shapes as the reference's readers/writers in
   get_channel_restart_from_wrf_hydro   :1368-1430 (qu0, qd0, h0) from a HYDRO_RST file
   read_lite_restart / write_lite_restart :1433-1504 pandas pickles of the state frames
   write_flowveldepth_netcdf            :2089-2235 flow / velocity / depth / nudge [feature_id, time]
+  write_flowveldepth                   :2348-2462 the stream-output files of a run from its flowveldepth frame (no mask file)
 
 plus ``chrtout_packed`` -- the raw packed columns and packing facts of a list of CHRTOUT files, which
 ``RoutingPlan.upload_forcing_packed`` hands to the device so that decoding, the join on feature id and
@@ -262,3 +263,61 @@ def write_flowveldepth_netcdf(stream_output_directory, file_name, flow, velocity
         f.set_attr("file_reference_time", t0.strftime("%Y-%m-%d_%H:%M:%S"))
         f.set_attr("code_version", "")
     return path
+
+
+def write_flowveldepth(stream_output_directory, stream_output_mask, flowveldepth, nudge, usgs_positions_id, t0, dt,
+                       stream_output_timediff, stream_output_type, stream_output_internal_frequency=5, cpu_pool=1,
+                       poi_crosswalk=None, nexus_dict=None, *, output_stride=1):
+    """The reference's stream-output writer (nhd_io.py:2348-2462) for a run without a mask file: flow, velocity, depth and
+    nudge at ``stream_output_internal_frequency`` minutes -- the steps ts, 2 ts, ... with ts = frequency // (dt // 60) -- in
+    one file (``stream_output_timediff`` = -1) or one per ``stream_output_timediff`` hours, named
+    ``troute_output_<YYYYmmddHHMM><type>``; every feature is labelled "wb" as the reference does (updated_flowveldepth,
+    :2270-2274).  NetCDF only.
+
+    ``output_stride`` (keyword-only): the frame already holds only every n-th timestep -- what
+    ``compute_nhd_routing_v02(..., output_stride=n)`` returns, decimated on the device -- so the writer takes every
+    (ts // n)-th of ITS columns; n must divide ts.  The files are the same bytes either way."""
+    import datetime
+
+    import pandas as pd
+    if stream_output_mask is not None:
+        raise NotImplementedError("stream-output mask files (HYFeatures nexus / POI selection) are outside the NHD Muskingum-Cunge path")
+    if stream_output_type != ".nc":
+        raise NotImplementedError("stream output as NetCDF only ('.nc')")
+    n = int(output_stride)
+    ts = int(stream_output_internal_frequency // (dt // 60))
+    if n < 1 or ts % n:
+        raise ValueError(f"output_stride {n} must divide the {ts} timesteps between two output times")
+    n_cols = flowveldepth.shape[1] // 3
+    ind = list(range(ts // n - 1, n_cols, ts // n))                  # (:2379-2381 on the decimated frame)
+    timestamps_sec = [(i + 1) * n * dt for i in ind]
+    idx = pd.MultiIndex.from_arrays([np.asarray(flowveldepth.index), ["wb"] * flowveldepth.shape[0]], names=["featureID", "Type"])
+    values = np.asarray(flowveldepth)
+    flow = pd.DataFrame(values[:, 0::3][:, ind], index=idx)
+    velocity = pd.DataFrame(values[:, 1::3][:, ind], index=idx)
+    depth = pd.DataFrame(values[:, 2::3][:, ind], index=idx)
+    nudge = np.asarray(nudge)
+    if nudge.shape[0] and np.all(nudge[:, 0] == 0):                   # (:2388-2391: the column of the initial time)
+        nudge = nudge[:, 1:]
+    full_ind = list(range(ts - 1, n_cols * n, ts))                    # the nudge array always has every timestep
+    gage_rows = {int(g): k for k, g in enumerate(np.asarray(usgs_positions_id).tolist())}
+    nudge_v = np.full((flowveldepth.shape[0], len(ind)), -9999.0, dtype=np.float64)
+    for r, fid in enumerate(np.asarray(flowveldepth.index).tolist()):
+        k = gage_rows.get(int(fid))
+        if k is not None:
+            nudge_v[r] = nudge[k][full_ind]
+    nudge_df = pd.DataFrame(nudge_v, index=idx)
+    written, file_time = [], t0
+    if stream_output_timediff > 0:
+        per_file = stream_output_timediff * 60 // stream_output_internal_frequency
+        num_files = max(1, int(n_cols * n * dt // (stream_output_timediff * 60 * 60)))
+        for k in range(num_files):
+            sl = slice(k * per_file, (k + 1) * per_file)
+            name = "troute_output_" + file_time.strftime("%Y%m%d%H%M") + stream_output_type
+            written.append(write_flowveldepth_netcdf(stream_output_directory, name, flow.iloc[:, sl], velocity.iloc[:, sl],
+                                                     depth.iloc[:, sl], nudge_df.iloc[:, sl], timestamps_sec[sl], t0))
+            file_time = file_time + datetime.timedelta(hours=stream_output_timediff)
+    elif stream_output_timediff == -1:
+        name = "troute_output_" + file_time.strftime("%Y%m%d%H%M") + stream_output_type
+        written.append(write_flowveldepth_netcdf(stream_output_directory, name, flow, velocity, depth, nudge_df, timestamps_sec, t0))
+    return written

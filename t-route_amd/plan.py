@@ -337,9 +337,15 @@ class RoutingPlan:
         _lib.check(_lib.lib().trmc_plan_set_lag(self._h, _lib.ptr(lag)))
         self.maxlag = 0 if lag is None else int(lag.max(initial=0))
 
-    def download_fvd(self):
-        out = _lib.result_empty((self.nseg, self._nsteps, 3), self.dtype)
-        _lib.check(_lib.lib().trmc_download_fvd(self._h, _lib.ptr(out)))
+    def download_fvd(self, stride=1):
+        """fvd [nseg, nsteps // stride, 3]: every `stride`-th step (the steps stride, 2 stride, ... counted from 1), decimated
+        on the device (trmc_download_fvd_strided); stride = 1: the whole result."""
+        stride = int(stride)
+        if stride < 1:
+            raise ValueError("stride must be >= 1")
+        out = _lib.result_empty((self.nseg, self._nsteps // stride, 3), self.dtype)
+        if out.size:
+            _lib.check(_lib.lib().trmc_download_fvd_strided(self._h, stride, _lib.ptr(out)))
         return out
 
     def download_final_state(self):

@@ -122,6 +122,7 @@ def compute_nhd_routing_v02(
     *,
     precision=32,
     device=0,
+    output_stride=None,
 ):
     """Route every independent network of the call for ``nts`` timesteps.
 
@@ -137,6 +138,11 @@ def compute_nhd_routing_v02(
     1589,:1649-1655,:1729-1732): ``{segment id: {"results": flowveldepth row [nts*3]}}`` -- segments routed elsewhere
     whose hydrographs enter this call's networks.  They join the table as rows with a prescribed hydrograph
     (``upstream_results`` of the kernel callable) and are left out of the results, as in the reference.
+
+    ``output_stride`` (keyword-only; None = the reference's result): n > 1 keeps every n-th timestep of ``flowveldepth``
+    only -- the steps n, 2n, ..., which are the ones the reference's writers take when n = ``qts_subdivisions``
+    (nwm_routing/output.py:209-216, :232-240) -- decimated on the device (``compute_network_structured``); with ``nts`` a
+    multiple of n the last step is among them, so ``new_q0`` works on the result as it is.
     """
     if parallel_compute_method not in _PARALLEL_METHODS and parallel_compute_method is not None:
         raise ValueError(f"unknown parallel_compute_method {parallel_compute_method!r}")
@@ -233,7 +239,8 @@ def compute_nhd_routing_v02(
         e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
         e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
         e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
-        upstream_results, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device)
+        upstream_results, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device,
+        output_stride=output_stride)
     ids = r[0].astype("int64")                   # (the rows of upstream_results are masked out, mc_reach.pyx:451,:812)
     nseg = ids.shape[0]
     fvd, upstream = r[1], r[6]

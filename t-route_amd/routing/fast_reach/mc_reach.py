@@ -310,14 +310,23 @@ def compute_network_structured(
     precision=32,
     device=0,
     return_stats=False,
+    output_stride=None,
 ):
     """Route one (sub)network for ``nsteps`` timesteps on the GPU.
 
     Arguments and return value: see the reference docstring,
     mc_reach.pyx:225-240, and SURVEY.md 8(b).  Keyword-only extensions:
     ``precision`` (32 = the reference's arithmetic type, 64 = double),
-    ``device`` (HIP ordinal), ``return_stats`` (append the trmc_stats dict).
+    ``device`` (HIP ordinal), ``return_stats`` (append the trmc_stats dict),
+    ``output_stride`` (None or 1: the reference's result; n > 1: element [1] holds
+    every n-th step only -- ``flowveldepth[:, 3 * (n (k + 1) - 1) : ...]``, the steps
+    the reference's writers keep when n = qts_subdivisions, nwm_routing/output.py:209-216,
+    :232-240 -- decimated on the device, so that a twelfth of the bytes crosses the host
+    link; bit-identical to slicing the full result; the other elements are unchanged).
     """
+    stride = 1 if output_stride is None else int(output_stride)
+    if stride < 1:
+        raise ValueError("output_stride must be a positive number of timesteps")
     data_idx = np.ascontiguousarray(data_idx, dtype=np.int64)
     data_values = np.asarray(data_values)
     qlat_values = np.asarray(qlat_values)
@@ -457,14 +466,14 @@ def compute_network_structured(
             if nudging[5] is not None:
                 plan.set_nudging_successors(nudging[5])
         plan.route_device(nsteps, qts_subdivisions, assume_short_ts)
-        fvd = plan.download_fvd()
+        fvd = plan.download_fvd(stride)
         if nudging is not None:
             nudge[nudging[4], 1:] = plan.download_nudge()
         res_inflow = plan.download_reservoir_inflow() if res_rows else None
         stats = plan.stats()
 
     out_dtype = np.float32 if precision == 32 else np.float64
-    flowveldepth = fvd.reshape(nseg, nsteps * 3).astype(out_dtype, copy=False)
+    flowveldepth = fvd.reshape(nseg, (nsteps // stride) * 3).astype(out_dtype, copy=False)
     if not fill_index_mask.all():          # (no copy of the result when no off-network upstream rows were spliced in)
         flowveldepth = flowveldepth[fill_index_mask]
     upstream = np.zeros((nseg, nsteps), dtype="float32")  # np.empty in the reference (:487), reservoir rows filled (:710)

@@ -134,6 +134,40 @@ def test_write_flowveldepth_netcdf_layout(tmp_path):
         assert f.has_attr("streamflow", "DIMENSION_LIST")
 
 
+def test_write_flowveldepth_from_a_device_decimated_frame_writes_the_same_files(tmp_path):
+    """``write_flowveldepth`` (the reference's stream-output writer, nhd_io.py:2348-2462): hourly files from 5-minute steps,
+    once from the full frame and once from the frame ``compute_nhd_routing_v02(..., output_stride=12)`` returns (every
+    twelfth step, decimated on the device): the same bytes, the reference's step selection (:2379-2382) and file names."""
+    import filecmp
+    rng = np.random.default_rng(0)
+    n, nts, dt, stride = 9, 48, 300, 12
+    full = rng.random((n, nts * 3)).astype(np.float32)
+    ids = np.arange(100, 100 + n)
+    dec = full.reshape(n, nts, 3)[:, stride - 1::stride, :].reshape(n, -1)
+    nudge = np.zeros((3, nts + 1), np.float32)
+    nudge[:, 1:] = rng.random((3, nts))
+    gids = ids[[1, 4, 7]]
+    t0 = datetime.datetime(2021, 8, 23, 13, 0)
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    for timediff, names in ((-1, ["troute_output_202108231300.nc"]),
+                            (2, ["troute_output_202108231300.nc", "troute_output_202108231500.nc"])):
+        fa = nhd_io.write_flowveldepth(a, None, pd.DataFrame(full, index=ids), nudge, gids, t0, dt, timediff, ".nc", 60)
+        fb = nhd_io.write_flowveldepth(b, None, pd.DataFrame(dec, index=ids), nudge, gids, t0, dt, timediff, ".nc", 60,
+                                       output_stride=stride)
+        assert [os.path.basename(x) for x in fa] == names
+        assert all(filecmp.cmp(x, y, shallow=False) for x, y in zip(fa, fb))
+    with h5.File(fa[0]) as f:
+        assert f.shape("flow") == (n, 2) and np.array_equal(f.read("time"), [3600.0, 7200.0])
+        assert np.array_equal(f.read("flow"), full[:, 0::3][:, [11, 23]])
+        assert np.array_equal(f.read("depth"), full[:, 2::3][:, [11, 23]])
+        nd = f.read("nudge")
+        assert np.array_equal(nd[1], nudge[0, 1:][[11, 23]]) and (nd[0] == -9999.0).all()
+    with pytest.raises(ValueError, match="must divide"):
+        nhd_io.write_flowveldepth(b, None, pd.DataFrame(dec, index=ids), nudge, gids, t0, dt, -1, ".nc", 60, output_stride=5)
+
+
 def test_decoding_of_planted_fill_and_out_of_range_cells_against_h5dump(tmp_path):
     """A packed variable written with cells planted at _FillValue, at missing_value, below valid_min and above valid_max:
     h5dump's independent view of the bytes and attributes on disk, decoded by the CF rule the forcing ingest implements

@@ -21,14 +21,14 @@ def frames(ids, params9, q0, qlat):
     return param_df, q0_df, qlat_df
 
 
-def call(conn, param_df, q0_df, qlat_df, nts, qts, short, method="by-network", interorder=None):
+def call(conn, param_df, q0_df, qlat_df, nts, qts, short, method="by-network", interorder=None, **kw):
     ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
     e = pd.DataFrame()
     sub_in = [{}, {}]
     out = compute_nhd_routing_v02(
         conn, rconn, {}, reaches_bytw, "V02-structured", method, 10000, 4, None, 300.0, nts, qts, ind,
         param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, short, False, e, {}, e, False,
-        sub_in, {} if interorder is None else interorder)
+        sub_in, {} if interorder is None else interorder, **kw)
     # what the reference returns (compute.py:1738) and how nwm_route unpacks it (nwm_routing/__main__.py:1256-1257)
     assert isinstance(out, tuple) and len(out) == 2
     subnetwork_list = out[1]
@@ -53,6 +53,31 @@ def test_lowercolorado_through_compute_nhd_routing_v02(short):
     assert np.array_equal(fvd.reshape(lc.nseg, lc.nts, 3).view(np.uint32), want.view(np.uint32))
     nq0 = new_q0(results)
     assert np.array_equal(nq0.values, want[:, -1, :][:, [0, 0, 2]])
+
+
+@pytest.mark.parametrize("short,engine", [(True, "flow"), (True, "levels"), (False, "flow"), (False, "levels")])
+def test_output_stride_is_the_full_result_sliced(short, engine, monkeypatch):
+    """``output_stride`` (keyword-only extension of the drop-in): every n-th timestep, decimated on the device -- what the
+    reference's writers keep of a window (nwm_routing/output.py:209-216, nhd_io.py:2379-2382) -- equals slicing the full
+    ``flowveldepth`` bit for bit, whatever n; the final state (``new_q0``) is the same when n divides nts."""
+    monkeypatch.setenv("TRMC_ENGINE", engine)
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
+    lc = H.LowerColorado()
+    conn = {int(s): ([int(t)] if t != 0 else []) for s, t in zip(lc.ids, lc.to)}
+    param_df, q0_df, qlat_df = frames(lc.ids, lc.params9, lc.q0, lc.qlat)
+    nts = 96
+    full, _, _ = call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short)
+    want = full[0][1].reshape(lc.nseg, nts, 3)
+    for n in (12, 7, 96, 100):
+        got, _, _ = call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short, output_stride=n)
+        fvd = got[0][1]
+        assert fvd.shape == (lc.nseg, (nts // n) * 3) and fvd.dtype == np.float32
+        assert np.array_equal(fvd.reshape(lc.nseg, nts // n, 3).view(np.uint32), want[:, n - 1::n, :].view(np.uint32)), n
+        assert np.array_equal(got[0][0], full[0][0]) and np.array_equal(got[0][8], full[0][8])
+    got, _, _ = call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short, output_stride=12)
+    assert np.array_equal(new_q0(got).values, new_q0(full).values)
+    with pytest.raises(ValueError, match="output_stride"):
+        call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short, output_stride=0)
 
 
 def test_many_networks_one_plan_results_per_tailwater():
