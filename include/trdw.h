@@ -75,6 +75,20 @@ typedef struct trdw_args {
 } trdw_args;
 int trdw_diffnw_batch(int ndomains, const trdw_args *args);
 
+/* How the calls of THIS THREAD solve (the library reads no environment variable; troute_amd maps its TRDW_* test variables
+ * onto this): solver 0 = the parallel time loop (one workgroup per domain: coefficients per node, recurrences per reach, the
+ * depth chain on one wavefront), 1 = the whole loop in one wavefront (the first form, kept as a cross-check: same bits);
+ * chain_global / window_rows: where the depth chain keeps its state (measurement knobs); phase_ticks: per-phase clock ticks
+ * of the first domain printed on stderr (a diagnostic).  NULL or a zero-filled struct = the defaults. */
+typedef struct trdw_options {
+    int32_t struct_size;
+    int32_t solver;
+    int32_t chain_global;
+    int32_t window_rows;
+    int32_t phase_ticks;
+} trdw_options;
+int trdw_configure(const trdw_options *options);
+
 /* Device time of the last trdw_diffnw / trdw_diffnw_batch call of this thread: tables_ms (cross-section tables), solve_ms (time loop). */
 int trdw_last_timing(double *tables_ms, double *solve_ms);
 

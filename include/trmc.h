@@ -153,14 +153,19 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *                  restated, IEEE division and square root; fp64: glibc's pow restated).
  *                  TRMC_ARITH_TOLERANCE (1), precision 32 only: hardware log2 / exp2 power, reciprocal-multiply division,
  *                  hardware square root -- each within one unit in the last place, NOT bit-comparable.  Stated tolerance
- *                  against the reference (tests/test_gpu_tolerance.py): one segment-step rtol 2e-6 (+ 1e-9
- *                  absolute) on q, velocity and depth wherever the secant iteration takes the same number of iterations; a
- *                  routed day: 99.9 % of all (row, step) flows within rtol 1e-4 + atol 1e-6 m3/s, every flow within the
- *                  1 % the iteration's own exit test allows a depth to move (MCsingleSegStime_f2py_NOLOOP.f90:83).
+ *                  against the reference Fortran (tests/test_gpu_tolerance.py asserts it, profiles/r05_tolerance_report.json
+ *                  holds the measured distributions): a routed window with assume_short_ts: >= 99.9 % of all (row, step)
+ *                  flows within rtol 1e-4 + atol 1e-6 m3/s, >= 99.99 % within rtol 3e-2 + atol 1e-4, every one within rtol
+ *                  1e-1 + atol 1e-3; one segment-step on the reference's own kernel-vector population: 99 % of q / velocity /
+ *                  depth within rtol 2e-5, 99.8 % within 1e-3, at most 0.1 % of the steps beyond 3e-2 -- the tail is the secant
+ *                  iteration's 1 % exit test (MCsingleSegStime_f2py_NOLOOP.f90:83) amplifying a last-place difference where it
+ *                  converges slowly, not the arithmetic's.  Without assume_short_ts the reference recurrence amplifies
+ *                  differences from a cold start and no tolerance is claimed.
  *   wide_min_rows  rows a leading level must have to be routed wide_k steps per launch (k_mc_tile); 0 = default (384 per
- *                  compute unit), < 0 = never.  wide_levels: at most so many (0 = default 16).  wide_k: 0 = default 16.
- *   mid_min_rows   the same for the SECOND tier: the levels right below the wide ones, mid_k steps per launch under their
- *                  own skew; 0 = default, < 0 = never.  mid_levels (0 = default), mid_k (0 = default).
+ *                  compute unit; 256 in tolerance arithmetic), < 0 = never.  wide_levels: at most so many (0 = default 16).  wide_k: 0 = default 16.
+ *   mid_min_rows   the same for a SECOND tier: the levels right below the wide ones, mid_k steps per launch under their own
+ *                  skew, queued on the plan's stream between the tail's launches; 0 = default (OFF: measured slower on the
+ *                  CONUS day at every setting tried), < 0 = never.  mid_levels (0 = 12), mid_k (0 = 4).
  *   tile_perm_group  rows re-dealt to the threads of a wide tile by the cost class they showed in the tile before, inside
  *                  groups of so many positions (a multiple of 256 up to 1024); 0 = default (256 on a plan created with a
  *                  cost hint, off otherwise), < 0 = off.
@@ -172,7 +177,9 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *                  launches in the shared hardware queues do not hold it back.  Also trmc_plan_set_sequence_mode.
  *   flow_watchdog_ms  how long a poll of the dataflow engine may wait before the window is abandoned (0 = default 30 000).
  *   flow_overlap   != 0: consecutive time chunks of a dataflow window alternate between two compute streams.
- *   flow_lean      0 = automatic, > 0 always, < 0 never: the lean form of the dataflow kernel. */
+ *   flow_lean      0 = automatic, > 0 always, < 0 never: the lean form of the dataflow kernel.
+ *   flow_debug     != 0: the dataflow engine records when every block ran, and trmc_route_end prints a summary on stderr
+ *                  (one line per block into the file named by TRMC_FLOW_DEBUG_FILE, if set) -- a diagnostic. */
 enum { TRMC_ARITH_EXACT = 0, TRMC_ARITH_TOLERANCE = 1 };
 typedef struct trmc_plan_options {
     int32_t struct_size;
@@ -188,7 +195,8 @@ typedef struct trmc_plan_options {
     int32_t flow_watchdog_ms;
     int32_t flow_overlap;
     int32_t flow_lean;
-    int32_t reserved[9];
+    int32_t flow_debug;
+    int32_t reserved[8];
 } trmc_plan_options;
 int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                          const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
@@ -492,8 +500,9 @@ int trmc_plan_clone(trmc_plan *plan, trmc_plan **out);
  * (mc_reach.pyx:173,:723), the state through AbstractNetwork.new_q0 (AbstractNetwork.py:177-191).  A plan with
  * boundary rows gets their hydrographs of the staged window afterwards (trmc_set_boundary_flow_device before the
  * window begins, or trmc_set_boundary_flow_range while it runs).  The plan is idle (its last window ended), or routing a window that has been queued to its end -- the
- * staging area is only read by a window's set-up, so the copy goes behind that; a state must then come from
- * trmc_plan_chain_from.
+ * staging area is only read by a window's set-up, so the copy goes behind that; the state then comes from
+ * trmc_plan_chain_from, or, if nobody hands one over, from that very window once it has ended (trmc_route_end before the next
+ * trmc_route_begin): one plan routing day after day with every day's forcing on its way a whole window ahead.
  */
 int trmc_stage_forcing(trmc_plan *plan, int nsteps, const void *qlat, int64_t nq);
 

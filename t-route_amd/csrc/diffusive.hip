@@ -25,6 +25,7 @@ namespace {
 thread_local std::string g_dw_err;
 thread_local int g_dw_device = 0;
 thread_local double g_dw_tables_ms = 0.0, g_dw_solve_ms = 0.0;
+thread_local trdw_options g_options = {(int32_t)sizeof(trdw_options), 0, 0, 0, 0};
 
 int dw_fail(int code, const std::string &msg)
 {
@@ -350,7 +351,7 @@ struct ParItem {
     const int32_t *m_of_reach;   // [nrch] reach j (1-based) -> m, -1 for tributaries
     double *scratch;             // [nnodes][12]: forward coefficients, recurrence lines, node contributions
     double *chain_state;         // records and windows of the chain in global memory, for a domain too long for LDS
-    unsigned long long *phase_ticks; // developer aid (TRDW_PHASES=1): [8] wall-clock ticks per phase, [8] window misses
+    unsigned long long *phase_ticks; // developer aid (trdw_options.phase_ticks): [8] wall-clock ticks per phase, [8] window misses
     int nnodes;
 };
 
@@ -977,18 +978,15 @@ int run_batch(const trdw_args *args, int n)
     }
     DW_TRY(hipEventRecord(run.ev[1], st));
     // the parallel time loop when every domain's chain state fits LDS (TRDW_SOLVER=serial: the one-wavefront kernel)
-    const char *solver = std::getenv("TRDW_SOLVER");
-    bool par = !(solver && std::string(solver) == "serial");
+    const trdw_options cfg = g_options; // (trdw_configure; the library reads no environment variable)
+    bool par = cfg.solver != 1;
     int par_rows = 7, nn_max = 0;
     for (int b = 0; b < n; ++b) {
         par_rows = par_rows < run.doms[b].par_rows ? par_rows : run.doms[b].par_rows;
         nn_max = nn_max > run.doms[b].nnodes ? nn_max : run.doms[b].nnodes;
     }
-    if (std::getenv("TRDW_CHAIN_GLOBAL")) par_rows = 0; // developer A/B: chain state in global memory
-    if (const char *e = std::getenv("TRDW_WINDOW_ROWS")) { // developer A/B
-        const int wr = std::atoi(e);
-        if (wr >= 5 && wr <= par_rows) par_rows = wr;
-    }
+    if (cfg.chain_global) par_rows = 0; // developer A/B: chain state in global memory
+    if (cfg.window_rows >= 5 && cfg.window_rows <= par_rows) par_rows = cfg.window_rows; // developer A/B
     if (par) {
         std::vector<ParItem> pitems((size_t)n);
         for (int b = 0; b < n; ++b) {
@@ -1004,7 +1002,7 @@ int run_batch(const trdw_args *args, int n)
             pitems[b].nnodes = dm.nnodes;
             pitems[b].phase_ticks = nullptr;
         }
-        if (std::getenv("TRDW_PHASES")) {
+        if (cfg.phase_ticks) {
             DW_TRY(hipMalloc(&run.d_ticks, 16 * sizeof(unsigned long long)));
             DW_TRY(hipMemsetAsync(run.d_ticks, 0, 16 * sizeof(unsigned long long), st));
             pitems[0].phase_ticks = (unsigned long long *)run.d_ticks;
@@ -1081,6 +1079,24 @@ int trdw_select_device(int device)
         return dw_fail(TRDW_ENODEVICE, "no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= count) return dw_fail(TRDW_EINVAL, "device ordinal out of range");
     g_dw_device = device;
+    return 0;
+}
+
+int trdw_configure(const trdw_options *options)
+{
+    trdw_options o = {(int32_t)sizeof(trdw_options), 0, 0, 0, 0};
+    if (options) {
+        if (options->struct_size < 8 || options->struct_size > (int32_t)sizeof(trdw_options)) {
+            g_dw_err = "trdw_options.struct_size is not the size of a trdw_options this library knows";
+            return TRDW_EINVAL;
+        }
+        std::memcpy(&o, options, (size_t)options->struct_size);
+    }
+    if (o.solver != 0 && o.solver != 1) {
+        g_dw_err = "trdw_options.solver must be 0 (parallel) or 1 (serial)";
+        return TRDW_EINVAL;
+    }
+    g_options = o;
     return 0;
 }
 

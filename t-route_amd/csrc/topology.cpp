@@ -351,18 +351,14 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
         // the higher its priority on the SIMD it shares (s_setprio): the slow ones run at the pace of a wavefront alone,
         // the cheap ones fill the issue slots they leave.
         {
-            int64_t lo = std::numeric_limits<int64_t>::max(), hi = 0;
+            int64_t lo = std::numeric_limits<int64_t>::max();
             auto cost_of = [&](int32_t r) -> int64_t {
                 if (cost_hint) return cost_hint[r];
                 int64_t b = 0;
                 for (int64_t d = drain[r]; d >= 4 && b < 3; d >>= 2) ++b;
                 return b;
             };
-            for (const int32_t r : post) {
-                lo = std::min(lo, cost_of(r));
-                hi = std::max(hi, cost_of(r));
-            }
-            const int64_t span = std::max<int64_t>(1, hi - lo + 1);
+            for (const int32_t r : post) lo = std::min(lo, cost_of(r));
             const int64_t nw = (nrouted + 63) / 64;
             t.prio_of_wave.assign((size_t)nw, 0);
             std::vector<int64_t> wcost((size_t)nw, lo);
@@ -371,21 +367,11 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                     wcost[(size_t)w] = std::max(wcost[(size_t)w], cost_of(t.row_of_pos[p]));
             t.cost_of_wave.resize((size_t)nw);
             for (int64_t w = 0; w < nw; ++w) t.cost_of_wave[(size_t)w] = (uint8_t)std::min<int64_t>(255, wcost[(size_t)w]);
-            const char *pm = std::getenv("TRMC_FLOW_PRIO_MODE"); // developer A/B: "linear", "block"; default by wavefront
-            const std::string mode = pm ? pm : "wave";
-            if (mode == "linear") {
-                for (int64_t w = 0; w < nw; ++w) t.prio_of_wave[(size_t)w] = (uint8_t)std::min<int64_t>(3, (wcost[(size_t)w] - lo) * 4 / span);
-            } else if (nw > 0) {
+            if (nw > 0) {
                 // By rank, not by value: a handful of rows with a hint far above the rest would compress everybody else into
                 // priorities 0 and 1.  Equal costs get equal priorities.  (One priority per block -- its wavefronts exchange
-                // flows every step -- measured worse on the ranks of an 8-way partition: 5.3 ms against 4.65 ms.)
-                const int64_t wpb = std::max<int64_t>(1, block_rows / 64);
-                if (mode != "wave")
-                    for (int64_t w0 = 0; w0 < nw; w0 += wpb) {
-                        int64_t mx = lo;
-                        for (int64_t w = w0; w < std::min(nw, w0 + wpb); ++w) mx = std::max(mx, wcost[(size_t)w]);
-                        for (int64_t w = w0; w < std::min(nw, w0 + wpb); ++w) wcost[(size_t)w] = mx;
-                    }
+                // flows every step -- measured worse on the ranks of an 8-way partition: 5.3 ms against 4.65 ms; priorities
+                // linear in the cost value likewise.)
                 std::vector<int64_t> sorted(wcost);
                 std::sort(sorted.begin(), sorted.end());
                 const int pc[3] = {60, 84, 94};

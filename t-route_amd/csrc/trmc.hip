@@ -2081,6 +2081,7 @@ struct trmc_plan {
         bool sequence = false;
         bool flow_overlap = false;
         int32_t flow_lean = 0;
+        bool flow_debug = false;
     } opt;
     trmc_stats stats{};
     RouteRun run;
@@ -2674,8 +2675,6 @@ template <class T> int route_end_t(trmc_plan *pl)
 int flow_place_blocks(trmc_plan *pl)
 {
     pl->ncuq = 0;
-    const char *off = std::getenv("TRMC_FLOW_PLACE");
-    if (off && off[0] == '0') return 0;
     const int32_t nb = pl->topo.nblocks;
     if (nb <= 0) return 0;
     constexpr int kKeys = 4096;
@@ -2812,9 +2811,9 @@ FlowArgs flow_args(trmc_plan *pl, int nsteps, int qts, bool short_ts)
     a.tag_base = pl->tag_base;
     a.ticket = (int32_t *)pl->ticket.p;
     a.watchdog_ticks = pl->watchdog_ticks;
-    a.dbg = std::getenv("TRMC_FLOW_DEBUG") ? (unsigned long long *)pl->dbg.p : nullptr;
+    a.dbg = pl->opt.flow_debug ? (unsigned long long *)pl->dbg.p : nullptr; // (trmc_plan_options.flow_debug: when did every block run?)
     a.nblocks_dbg = pl->topo.nblocks;
-    a.prio = std::getenv("TRMC_FLOW_NOPRIO") ? nullptr : (const uint8_t *)pl->prio.p;
+    a.prio = (const uint8_t *)pl->prio.p;
     a.cuq_ptr = a.cuq_blk = a.cu_index = nullptr; // (flow_route_advance switches the queues on for lean launches)
     a.cuq_perm = nullptr;
     a.cuq_head = nullptr;
@@ -2832,7 +2831,7 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     if (int rc = pl->d_state.ensure((size_t)np * sizeof(float))) return rc;
     if (int rc = pl->d_gran.ensure((size_t)np * sizeof(unsigned long long), true)) return rc;
     if (int rc = pl->ticket.ensure(16 * sizeof(int32_t))) return rc; // one set of 8 per compute stream
-    if (std::getenv("TRMC_FLOW_DEBUG")) {
+    if (pl->opt.flow_debug) {
         if (int rc = pl->dbg.ensure((size_t)(tp.nblocks + 1) * 6 * sizeof(unsigned long long))) return rc;
         HIP_TRY(hipMemsetAsync(pl->dbg.p, 0, pl->dbg.bytes, st));
     }
@@ -2934,7 +2933,7 @@ int flow_route_advance(trmc_plan *pl, int t_end)
             a.cuq_ptr = (const int32_t *)pl->cuq_ptr.p;
             a.cuq_blk = (const int32_t *)pl->cuq_blk.p;
             a.cu_index = (const int32_t *)pl->cu_index.p;
-            a.cuq_perm = std::getenv("TRMC_FLOW_NOPERM") ? nullptr : (const uint8_t *)pl->cuq_perm.p;
+            a.cuq_perm = (const uint8_t *)pl->cuq_perm.p;
             a.cuq_head = (int32_t *)pl->cuq_head.p + (size_t)pl->ncuq * which;
             a.ncuq = pl->ncuq;
             HIP_TRY(hipMemsetAsync(a.cuq_head, 0, (size_t)pl->ncuq * sizeof(int32_t), st));
@@ -2992,7 +2991,7 @@ int flow_route_end(trmc_plan *pl)
                                + ") at step " + std::to_string(idx / np) + ", tag " + std::to_string((uint32_t)flags[4]) + ", found tag "
                                + std::to_string((uint32_t)flags[5]) + ", window tag base " + std::to_string(pl->tag_base) + "]");
     }
-    if (std::getenv("TRMC_FLOW_DEBUG") && pl->topo.nblocks > 0) { // developer aid: when did every block run?
+    if (pl->opt.flow_debug && pl->topo.nblocks > 0) { // developer aid: when did every block run?
         const int32_t nb = pl->topo.nblocks;
         std::vector<unsigned long long> d((size_t)nb * 2);
         HIP_TRY(hipMemcpy(d.data(), pl->dbg.p, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -3083,6 +3082,10 @@ int flow_route_end(trmc_plan *pl)
     s.ms_main = ms12;
     s.ms_emit = 0.0; // results are written in the caller's layout by the routing kernel itself
     s.ms_total = (double)ms01 + ms12;
+    s.wide_levels = s.wide_k = s.wide_launches = s.mid_levels = s.mid_k = s.mid_launches = 0;
+    s.wide_segment_steps = 0;
+    s.ms_wide = 0.0;
+    s.arithmetic = pl->opt.tol ? TRMC_ARITH_TOLERANCE : TRMC_ARITH_EXACT;
     pl->routed_nsteps = r.nsteps;
     r.active = false;
     return 0;
@@ -3415,7 +3418,11 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
         trmc_plan::Opt &po = pl->opt;
         po.tol = o.arithmetic == TRMC_ARITH_TOLERANCE;
-        po.wide_min_rows = o.wide_min_rows < 0 ? 0 : (o.wide_min_rows > 0 ? o.wide_min_rows : 384L * ncu);
+        // (default threshold of the wide tier: 384 rows per compute unit -- five levels of the CONUS network -- in exact arithmetic,
+        // where the tiles are what the device is busy with and the ramps of the skew cost; 256 -- seven levels -- in tolerance
+        // arithmetic, where a tile's arithmetic is a quarter cheaper and the window waits for the tail's chain of launches:
+        // 12.8 ms per CONUS day against 14.0, measured on the sequence of bench.py; 192: 13.0, 128: 13.4)
+        po.wide_min_rows = o.wide_min_rows < 0 ? 0 : (o.wide_min_rows > 0 ? o.wide_min_rows : (po.tol ? 256L : 384L) * ncu);
         po.wide_levels = (int32_t)std::min<long>(o.wide_levels > 0 ? o.wide_levels : 16, kWideMaxLevels);
         po.wide_k = o.wide_k > 0 ? o.wide_k : 0; // (0: 16, or an eighth of a short window -- route_begin_t)
         po.mid_min_rows = o.mid_min_rows < 0 ? 0 : (o.mid_min_rows > 0 ? o.mid_min_rows : kMidDefaultRowsPerCu * (int64_t)ncu);
@@ -3425,6 +3432,7 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         po.sequence = o.sequence_mode != 0;
         po.flow_overlap = o.flow_overlap != 0;
         po.flow_lean = o.flow_lean;
+        po.flow_debug = o.flow_debug != 0;
     }
     const bool tiers = (flags & TRMC_PLAN_SHORT_TS) != 0;
     std::string err;
@@ -4056,7 +4064,8 @@ static int route_check(trmc_plan *pl, int nsteps, int qts_subdivisions, bool bou
         return fail(TRMC_ESTATE, "plan has boundary rows but no boundary hydrographs were supplied");
     if (pl->ngage > 0 && pl->da_nsteps != nsteps) return fail(TRMC_EINVAL, "nudging tables were set for a different nsteps");
     if (pl->state_missing && !pl->chain_staged)
-        return fail(TRMC_ESTATE, "the forcing was staged on a plan that has routed nothing: trmc_plan_chain_from must hand it a state");
+        return fail(TRMC_ESTATE, "the forcing was staged on a plan that has routed nothing (or whose window has not ended yet): "
+                                 "trmc_plan_chain_from must hand it a state, or trmc_route_end the window first");
     // the reference's precondition, mc_reach.pyx:246-247
     if ((int64_t)(nsteps - 1) / qts_subdivisions >= pl->nq)
         return fail(TRMC_EINVAL, "Number of columns (timesteps) in Qlat is incorrect: need "
@@ -4074,8 +4083,23 @@ static int lag_check(trmc_plan *pl, int assume_short_ts)
     return 0;
 }
 
+// A forcing staged WHILE the plan's own window was in flight (trmc_stage_forcing on a busy plan) had no state to take then; if
+// that window has ended since and nobody has handed a state over (trmc_plan_chain_from), the window continues from it: the
+// gather of (q_T, q_T, depth_T) that an idle staging does at once is done here, at the head of the new window's queue.
+static int settle_deferred_state(trmc_plan *pl)
+{
+    if (!pl || !pl->state_missing || pl->chain_staged || pl->run.active || pl->routed_nsteps < 0) return 0;
+    if (int rc = use_device(pl)) return rc;
+    if (pl->nseg > 0)
+        if (int rc = final_state_into(pl, pl->in_q0.p)) return rc;
+    pl->state_missing = false;
+    pl->q0_staged = true;
+    return 0;
+}
+
 int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts)
 {
+    if (int rc = settle_deferred_state(pl)) return rc;
     if (int rc = route_check(pl, nsteps, qts_subdivisions, false)) return rc;
     if (int rc = lag_check(pl, assume_short_ts)) return rc;
     const bool f = pl->precision == 32;
@@ -4097,6 +4121,7 @@ int trmc_route_device(trmc_plan *pl, int nsteps, int qts_subdivisions, int assum
 
 int trmc_route_begin(trmc_plan *pl, int nsteps, int qts_subdivisions, int assume_short_ts)
 {
+    if (int rc = settle_deferred_state(pl)) return rc;
     if (int rc = route_check(pl, nsteps, qts_subdivisions, true)) return rc;
     if (int rc = lag_check(pl, assume_short_ts)) return rc;
     const int rc = pl->flow ? flow_route_begin(pl, nsteps, qts_subdivisions, assume_short_ts)
@@ -4401,21 +4426,6 @@ int trmc_download_final_state(trmc_plan *pl, void *q0_out)
     return 0;
 }
 
-} // extern "C"
-namespace {
-// device memory -> page-locked host memory (through the device's mapping of it), 16 bytes per lane; and the odd bytes at the end
-__global__ void __launch_bounds__(kBlock) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int64_t n)
-{
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[i];
-}
-__global__ void k_copy1(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int32_t n)
-{
-    if ((int32_t)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
-}
-} // namespace
-extern "C" {
-
 // the plan's copy stream (results to the host beside the next window; the next window's forcing to the device beside this one)
 static int ensure_copy_stream(trmc_plan *pl)
 {
@@ -4426,11 +4436,7 @@ static int ensure_copy_stream(trmc_plan *pl)
     // carries the result transposes.
     int prio_lo = 0, prio_hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    const char *pr = std::getenv("TRMC_COPY_PRIO"); // "normal": A/B
-    if (pr && pr[0] == 'n')
-        HIP_TRY(hipStreamCreateWithFlags(&pl->cstream, hipStreamNonBlocking));
-    else
-        HIP_TRY(hipStreamCreateWithPriority(&pl->cstream, hipStreamNonBlocking, prio_lo));
+    HIP_TRY(hipStreamCreateWithPriority(&pl->cstream, hipStreamNonBlocking, prio_lo));
     HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&pl->ev_forcing, hipEventDisableTiming));
@@ -4480,37 +4486,12 @@ int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_hos
     }
     HIP_TRY(hipEventRecord(pl->ev_fetch_ready, pl->stream));
     HIP_TRY(hipStreamWaitEvent(pl->cstream, pl->ev_fetch_ready, 0));
-    // Queued WITH the window the copies have a dependence that is still pending, and hipMemcpyAsync device-to-host then keeps
-    // the calling thread until it is resolved (measured: trmc_fetch_begin returns when the window ends).  TRMC_FETCH_KERNEL=1
-    // copies with a kernel instead, which writes the page-locked host arrays through the device's mapping of them and never
-    // waits on the host -- measured on the CONUS sequence of bench.py it is no gain: a day's narrow levels can only start
-    // when the day before has ended, so a window queued earlier does not finish earlier (16.7 ms per day with the copy
-    // engine, 17.1 with the kernel, whose wavefronts hold slots while their stores cross the host link).
-    const bool by_kernel = in_window && std::getenv("TRMC_FETCH_KERNEL") != nullptr;
+    // (Queued WITH the window the copies have a dependence that is still pending, and hipMemcpyAsync device-to-host then keeps
+    // the calling thread until it is resolved: trmc_fetch_begin returns when the window ends.  A copy by a kernel that writes
+    // the page-locked arrays through the device's mapping never waits on the host, but was no gain on the CONUS sequence --
+    // 17.1 ms per day against 16.7: a day's narrow levels can only start when the day before has ended -- and is gone.)
     auto to_host = [&](void *dst_host, const void *src_dev, size_t bytes) -> int {
-        if (!by_kernel) {
-            HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, pl->cstream));
-            return 0;
-        }
-        void *dst_dev = nullptr;
-        if (hipHostGetDevicePointer(&dst_dev, dst_host, 0) != hipSuccess || !dst_dev) {
-            (void)hipGetLastError(); // (not page-locked memory of this runtime: the copy engine, and the wait that comes with it)
-            HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, pl->cstream));
-            return 0;
-        }
-        // (few workgroups: the copy goes at the pace of the host link whatever their number, and a wavefront that waits for its
-        // stores to cross that link holds a slot the window's kernels want -- TRMC_FETCH_BLOCKS, default 16, is a measurement knob)
-        static const long max_blocks = [] {
-            const char *e = std::getenv("TRMC_FETCH_BLOCKS");
-            return e ? std::max(1L, std::atol(e)) : 16L;
-        }();
-        const size_t n16 = bytes / 16;
-        if (n16) hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((size_t)max_blocks, (n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, pl->cstream,
-                                    (const uint4 *)src_dev, (uint4 *)dst_dev, (int64_t)n16);
-        if (bytes % 16)
-            hipLaunchKernelGGL(k_copy1, dim3(1), dim3(16), 0, pl->cstream, (const uint8_t *)src_dev + n16 * 16, (uint8_t *)dst_dev + n16 * 16,
-                               (int32_t)(bytes % 16));
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, pl->cstream));
         return 0;
     };
     if (hb)

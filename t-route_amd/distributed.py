@@ -350,9 +350,13 @@ class ShardedRouter:
         P = self.planM if self.plan1 is not None else self.plan0
         P.stage_forcing(nsteps, local_qlat)
 
-    def route_staged(self, qts_subdivisions, nchunks=None):
-        """One short-timestep window on the forcing staged by begin_sequence() / stage_next(): route_on_device()'s body."""
-        return self._route_skewed(qts_subdivisions, nchunks, staged=True)
+    def route_staged(self, qts_subdivisions, nchunks=None, next_qlat=None):
+        """One short-timestep window on the forcing staged by begin_sequence() / stage_next(): route_on_device()'s body.
+        next_qlat: the NEXT day's forcing of this rank's rows (page-locked) -- staged as soon as this window is queued to its
+        end, so that it travels beside the window instead of between two (the next window then continues from this one's
+        final state: trmc_stage_forcing on a busy plan)."""
+        hook = None if next_qlat is None else (lambda: self.stage_next(self.nsteps, next_qlat))
+        return self._route_skewed(qts_subdivisions, nchunks, staged=True, before_end=hook)
 
     def _merged_engine(self):
         """The engine trmc_plan_create_ex's TRMC_ENGINE_AUTO gives the merged short-timestep plan (rows0 + trunk), without
@@ -376,7 +380,7 @@ class ShardedRouter:
         engine of the plan that actually runs the window."""
         return 4 if getattr(plan, "engine", "levels") == "flow" else 24
 
-    def _route_skewed(self, qts_subdivisions, nchunks, staged=False):
+    def _route_skewed(self, qts_subdivisions, nchunks, staged=False, before_end=None):
         """assume_short_ts: a row at step t reads its upstream rows at step t-1 only.  The window is cut into
         chunks of K steps.  After this rank's sub-basins have been queued through chunk c, the chunk's
         cut-edge hydrographs are gathered (plan stream), all-gathered and written into the trunk's boundary
@@ -434,6 +438,8 @@ class ShardedRouter:
         x["flip"] ^= 1
         hyd = x["hyd"][x["flip"]]
         X.gather_rows(dev, recv_o.ptr, self._d_out_index.ptr, self._out_rows.shape[0], nsteps * e, hyd.ptr, sc)
+        if before_end is not None:        # (the window is queued to its end: what the caller wants in flight beside it)
+            before_end()
         self.last_stats = {"phase0": P.route_end()}
         X.stream_synchronize(dev, sc)
         self._state_plans = [P]

@@ -54,9 +54,25 @@ def _raise(lib, rc):
         raise RuntimeError(f"trdw error {rc}: {msg}")
 
 
+class _Options(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("solver", C.c_int32), ("chain_global", C.c_int32), ("window_rows", C.c_int32),
+                ("phase_ticks", C.c_int32)]
+
+
+def _configure(lib):
+    """trdw_configure from the test / measurement variables of the host layer (the library reads no environment):
+    TRDW_SOLVER=serial, TRDW_CHAIN_GLOBAL, TRDW_WINDOW_ROWS=<n>, TRDW_PHASES"""
+    import os
+    o = _Options(C.sizeof(_Options), 1 if os.environ.get("TRDW_SOLVER") == "serial" else 0,
+                 1 if os.environ.get("TRDW_CHAIN_GLOBAL") else 0, int(os.environ.get("TRDW_WINDOW_ROWS") or 0),
+                 1 if os.environ.get("TRDW_PHASES") else 0)
+    _raise(lib, lib.trdw_configure(C.byref(o)))
+
+
 def compute_diffusive(diff_inputs, device=0):
     lib = _lib.lib()
     keep, args, outs = _marshal(diff_inputs)
+    _configure(lib)
     rc = lib.trdw_select_device(int(device))
     if rc == 0:
         rc = lib.trdw_diffnw(*args)
@@ -80,6 +96,7 @@ def compute_diffusive_batch(diff_inputs_list, device=0):
         outs_all.append(outs)
         for k, a in enumerate(args):
             arr[b][k] = a.value if isinstance(a, C.c_void_p) else C.cast(a, C.c_void_p).value
+    _configure(lib)
     rc = lib.trdw_select_device(int(device))
     if rc == 0:
         rc = lib.trdw_diffnw_batch(n, C.cast(arr, C.c_void_p))

@@ -43,13 +43,14 @@ class DaySequence:
     router : a ``ShardedRouter`` (one rank of a job of any size; ``enable_device_exchange`` done when world > 1)
     """
 
-    def __init__(self, router, nsteps, qts_subdivisions, assume_short_ts=True, nchunks=None):
+    def __init__(self, router, nsteps, qts_subdivisions, assume_short_ts=True, nchunks=None, hydrographs_on_every_rank=False):
         if not assume_short_ts:
             raise ValueError("a pipelined sequence of windows needs assume_short_ts (a day's leading levels run ahead of the "
                              "day before's narrow ones only there); route general-mode windows one by one")
         self.r = router
         self.nsteps, self.qts, self.nchunks = int(nsteps), int(qts_subdivisions), nchunks
         self.world = router.world
+        self._hyd_everywhere = bool(hydrographs_on_every_rank)   # (default: the gathered outlet block goes to rank 0's host only)
         self._clone = None
         self._local_days = None
         if self.world == 1:
@@ -157,7 +158,10 @@ class DaySequence:
         sync()
         t0 = time.perf_counter() if warmup == 0 else None
         for w in range(total):
-            rows, hyd = r.route_staged(qts, self.nchunks)          # day w: every hand-off in HBM (route_on_device's body)
+            # day w: every hand-off in HBM (route_on_device's body); day w + 1's forcing is staged as soon as day w is queued
+            # to its end -- it travels beside the window, and day w + 1 continues from the state day w leaves
+            nxt = days[(w + 1) % nd] if w + 1 < total else None
+            rows, hyd = r.route_staged(qts, self.nchunks, next_qlat=nxt)
             ends.append(time.perf_counter())
             if w >= warmup:
                 ms_main.append(r.last_stats["phase0"]["ms_main"])
@@ -165,9 +169,7 @@ class DaySequence:
                 got = r.fetch_wait()                                # day w - 1's products (copied beside day w)
                 if on_day is not None:
                     on_day(w - 1, got[0], got[1])
-            r.fetch_begin(hyd, want_hyd=(r.rank == 0))
-            if w + 1 < total:
-                r.stage_next(nsteps, days[(w + 1) % nd])            # day w + 1's forcing on its way; its state: what day w leaves
+            r.fetch_begin(hyd, want_hyd=(r.rank == 0 or self._hyd_everywhere))
             if w + 1 == warmup:                                     # the clock starts when the last warm-up day is through
                 sync()
                 t0 = time.perf_counter()

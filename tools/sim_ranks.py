@@ -6,6 +6,9 @@ The cut-edge hydrographs a rank would receive from its peers are taken from a co
 time of route_on_device -- the job time of the real N-GPU run is about the maximum (plus RCCL latency).
 
     python tools/sim_ranks.py --world 8 [--chunks 4] [--full-ts]
+    python tools/sim_ranks.py --world 8 --retune --sequence 6     # the per-day PERIOD of every rank under the sequence
+                                                                  # pipeline (troute_amd.sequence.DaySequence): distinct days,
+                                                                  # forcing staged, state carried on in HBM, products fetched
 """
 import argparse
 import os
@@ -26,6 +29,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ranks", type=str, default=None, help="comma list (default: all)")
     ap.add_argument("--retune", action="store_true", help="rebuild every router with the cost hint of a tuning window")
+    ap.add_argument("--sequence", type=int, default=0, help="D > 1: time D consecutive distinct days per rank through "
+                    "troute_amd.sequence.DaySequence (the first is a warm-up) and report the period per day")
     ap.add_argument("--rebalance", type=int, nargs="?", const=1, default=0, help="time all ranks, repartition by their "
                     "measured pace (sharding.partition rank_speed, what bench.py does after its tuning window), time them "
                     "again; N: that many feedback steps (bench.py takes up to two more on the hinted plan)")
@@ -70,6 +75,8 @@ def main():
     single.close()
     print(f"single GPU ({single_engine} engine): {t_single * 1e3:.2f} ms   cut rows {cut_rows.size}")
 
+    if a.sequence > 1:
+        return sequence_mode(a, net, to, params, qlat, q0, part, hint, nsteps, qts, eng, dev, X, synthetic, ShardedRouter, t_single)
     passes = [part]          # (the partition the cut-edge hydrographs above belong to keeps its cut rows: same trunks)
     times_of = {}
     for ipass in range(1 + a.rebalance):
@@ -165,6 +172,106 @@ def main():
               print("   host ms (all reps):", {k: round(v * 1e3, 2) for k, v in acc.items()})
           r.close()
       print(f"max over ranks {worst * 1e3:.2f} ms -> speed-up vs single {t_single / worst:.2f}x at world {a.world}")
+
+
+def sequence_mode(a, net, to, params, qlat, q0, part, hint, nsteps, qts, eng, dev, X, synthetic, ShardedRouter, t_single):
+    """D consecutive distinct days: first on ONE router (the truth: every day's cut-edge and outlet hydrographs, and the
+    single-GPU period under the same pipeline), then every rank of the partition by itself through DaySequence, its peers
+    played back day by day."""
+    from troute_amd.sequence import DaySequence, pinned_like
+    nseg, D = to.shape[0], a.sequence
+    days, prev = [], qlat
+    for i in range(D):
+        prev = synthetic.forcing(nseg, qlat.shape[1], synthetic.DEFAULT_SEED + 1 + i, previous=prev)
+        days.append(prev)
+    cut_rows = part["cut_rows"]
+    single = ShardedRouter(to, params, cost_hint=hint, assume_short_ts=True, engine=eng)
+    cut_q, ref_hyd = [], []
+    state = q0
+    for d in days:                                       # the truth, day by day
+        single.upload(nsteps, d, state)
+        state = None
+        single.route_resident(qts, True)
+        cut_q.append(single.plan0.gather_flow_rows(cut_rows) if cut_rows.size else np.zeros((0, nsteps), np.float32))
+        ref_hyd.append(single.outlet_hydrographs())
+    ref_rows = single.my_out0_global
+    period_single = None
+    if single.plan0.engine == "levels":
+        with DaySequence(single, nsteps, qts) as ds:
+            ring = [pinned_like(d) for d in days]
+            ds.run(ring[:2], q0, 2, 0)
+            out = ds.run(ring, q0, D - 1, 1)
+            period_single = out["el"] / (D - 1)
+    single.close()
+    print(f"single GPU under the sequence pipeline: {period_single * 1e3 if period_single else float('nan'):.2f} ms per day "
+          f"(one window alone: {t_single * 1e3:.2f} ms)")
+    worst = 0.0
+    for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
+        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
+                          assume_short_ts=True, engine=eng)
+
+        class SimComm:
+            """the peers of this rank, played back day by day (see main())"""
+            rank, world, backend = 0, a.world, "sim"
+
+            def __init__(self, router):
+                self.r, self.call, self.blocks, self.per_day = router, 0, None, 1
+
+            def prepare(self, K, C):
+                mc = max(self.r._max_cut, 1)
+                idx = np.zeros(cut_rows.size, dtype=np.int64)
+                for k in range(a.world):
+                    m = self.r.cut_owner == k
+                    idx[m] = np.arange(int(m.sum()))
+                self.blocks = []
+                for dq in cut_q:
+                    peers = np.zeros((a.world, mc, nsteps), np.float32)
+                    if cut_rows.size:
+                        peers[self.r.cut_owner.astype(np.int64), idx] = dq
+                    self.blocks.append([X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, c * K:min(nsteps, (c + 1) * K)]))
+                                        for c in range(C)])
+                self.per_day = (C if self.r._max_cut > 0 else 0) + 1
+
+            def all_gather(self, send_ptr, recv_ptr, nbytes, stream=0):
+                day, c = divmod(self.call, self.per_day)
+                self.call += 1
+                blocks = self.blocks[day % len(self.blocks)]
+                if self.r._max_cut > 0 and c < len(blocks):
+                    X.device_copy(dev, recv_ptr, blocks[c].ptr, blocks[c].nbytes, stream)
+                X.device_copy(dev, recv_ptr + rank * nbytes, send_ptr, nbytes, stream)
+
+            def barrier(self):
+                pass
+
+            def all_reduce_max_host(self, x):
+                return x
+
+        sim = SimComm(r)
+        r.enable_device_exchange(sim, dev)
+        r.nsteps = nsteps
+        ds = DaySequence(r, nsteps, qts, nchunks=a.chunks, hydrographs_on_every_rank=True)
+        K, C, _ = r._chunking(a.chunks)
+        sim.prepare(K, C)
+        local = ds.prepare_days(days)
+        got = {}
+        mine = np.concatenate([r.my_out0_global, r.my_out1_global])
+        best = None
+        for rep in range(max(1, a.reps)):
+            sim.call = 0
+            got.clear()
+            out = ds.run(local, q0, D - 1, 1, prepared=True,
+                         on_day=lambda w, h, s: got.__setitem__(w, None if h is None else np.array(h[np.searchsorted(r._out_rows, mine)], copy=True)))
+            per = out["el"] / (D - 1)
+            best = per if best is None else min(best, per)
+        ok = all(np.array_equal(got[w].view(np.uint32), ref_hyd[w][np.searchsorted(ref_rows, mine)].view(np.uint32)) for w in range(D))
+        worst = max(worst, best)
+        st = r.last_stats["phase0"]
+        print(f"rank {rank} ({r._state_plans[0].engine}, {st.get('wide_levels', 0)} wide levels): period {best * 1e3:7.2f} ms per day  "
+              f"(device window {np.mean(out['ms_main']):.2f} ms)  rows {r.sequence_rows().size}  outlets of every day bit-identical: {ok}")
+        ds.close()
+        r.close()
+    base = period_single if period_single else t_single
+    print(f"slowest rank {worst * 1e3:.2f} ms per day -> speed-up vs single GPU under the same pipeline {base / worst:.2f}x at world {a.world}")
 
 
 if __name__ == "__main__":
