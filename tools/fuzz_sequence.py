@@ -59,7 +59,9 @@ def one_round(rng, nseg_max):
     env = {"TRMC_SETUP_ASIDE": "1", "TRMC_ENGINE": "levels",
            "TRMC_WIDE_MIN_ROWS": str(int(rng.choice([0, 32, 512, 4096]))),
            "TRMC_WIDE_K": str(int(rng.choice([2, 4, 8, 16]))),
-           "TRMC_WIDE_LEVELS": str(int(rng.choice([2, 5, 16])))}
+           "TRMC_WIDE_LEVELS": str(int(rng.choice([2, 5, 16]))),
+           "TRMC_MID_MIN_ROWS": str(int(rng.choice([0, 0, 8, 64]))),      # (a second tier of tiles below the wide levels)
+           "TRMC_MID_K": str(int(rng.choice([1, 2, 4]))), "TRMC_MID_LEVELS": str(int(rng.choice([3, 12, 32])))}
     dawdle = float(rng.choice([0.0, 0.0, 0.002, 0.01]))
     hinted = bool(rng.integers(0, 2))
     saved = {k: os.environ.get(k) for k in env}

@@ -205,71 +205,82 @@ def sequence_mode(a, net, to, params, qlat, q0, part, hint, nsteps, qts, eng, de
     single.close()
     print(f"single GPU under the sequence pipeline: {period_single * 1e3 if period_single else float('nan'):.2f} ms per day "
           f"(one window alone: {t_single * 1e3:.2f} ms)")
-    worst = 0.0
-    for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
-        r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
-                          assume_short_ts=True, engine=eng)
+    from troute_amd import sharding
+    periods = {}
+    for ipass in range(1 + a.rebalance):
+      if ipass >= 1:          # the partition fed back with every rank's measured PERIOD (what bench.py does with its tuning day)
+        cost = hint.astype(np.float64) if hint is not None else np.ones(nseg)
+        own = part["owner"][part["piece"]]
+        loads = np.bincount(own, weights=cost, minlength=a.world)
+        speed = sharding.rank_speeds(loads, [periods[k] for k in range(a.world)])
+        print("measured pace of the ranks:", np.round(speed, 3))
+        part = sharding.partition(to, a.world, row_cost=hint, rank_speed=speed, previous=part)
+      worst = 0.0
+      for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
+          r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint,
+                            assume_short_ts=True, engine=eng)
 
-        class SimComm:
-            """the peers of this rank, played back day by day (see main())"""
-            rank, world, backend = 0, a.world, "sim"
+          class SimComm:
+              """the peers of this rank, played back day by day (see main())"""
+              rank, world, backend = 0, a.world, "sim"
 
-            def __init__(self, router):
-                self.r, self.call, self.blocks, self.per_day = router, 0, None, 1
+              def __init__(self, router):
+                  self.r, self.call, self.blocks, self.per_day = router, 0, None, 1
 
-            def prepare(self, K, C):
-                mc = max(self.r._max_cut, 1)
-                idx = np.zeros(cut_rows.size, dtype=np.int64)
-                for k in range(a.world):
-                    m = self.r.cut_owner == k
-                    idx[m] = np.arange(int(m.sum()))
-                self.blocks = []
-                for dq in cut_q:
-                    peers = np.zeros((a.world, mc, nsteps), np.float32)
-                    if cut_rows.size:
-                        peers[self.r.cut_owner.astype(np.int64), idx] = dq
-                    self.blocks.append([X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, c * K:min(nsteps, (c + 1) * K)]))
-                                        for c in range(C)])
-                self.per_day = (C if self.r._max_cut > 0 else 0) + 1
+              def prepare(self, K, C):
+                  mc = max(self.r._max_cut, 1)
+                  idx = np.zeros(cut_rows.size, dtype=np.int64)
+                  for k in range(a.world):
+                      m = self.r.cut_owner == k
+                      idx[m] = np.arange(int(m.sum()))
+                  self.blocks = []
+                  for dq in cut_q:
+                      peers = np.zeros((a.world, mc, nsteps), np.float32)
+                      if cut_rows.size:
+                          peers[self.r.cut_owner.astype(np.int64), idx] = dq
+                      self.blocks.append([X.DeviceBuffer.from_array(dev, np.ascontiguousarray(peers[:, :, c * K:min(nsteps, (c + 1) * K)]))
+                                          for c in range(C)])
+                  self.per_day = (C if self.r._max_cut > 0 else 0) + 1
 
-            def all_gather(self, send_ptr, recv_ptr, nbytes, stream=0):
-                day, c = divmod(self.call, self.per_day)
-                self.call += 1
-                blocks = self.blocks[day % len(self.blocks)]
-                if self.r._max_cut > 0 and c < len(blocks):
-                    X.device_copy(dev, recv_ptr, blocks[c].ptr, blocks[c].nbytes, stream)
-                X.device_copy(dev, recv_ptr + rank * nbytes, send_ptr, nbytes, stream)
+              def all_gather(self, send_ptr, recv_ptr, nbytes, stream=0):
+                  day, c = divmod(self.call, self.per_day)
+                  self.call += 1
+                  blocks = self.blocks[day % len(self.blocks)]
+                  if self.r._max_cut > 0 and c < len(blocks):
+                      X.device_copy(dev, recv_ptr, blocks[c].ptr, blocks[c].nbytes, stream)
+                  X.device_copy(dev, recv_ptr + rank * nbytes, send_ptr, nbytes, stream)
 
-            def barrier(self):
-                pass
+              def barrier(self):
+                  pass
 
-            def all_reduce_max_host(self, x):
-                return x
+              def all_reduce_max_host(self, x):
+                  return x
 
-        sim = SimComm(r)
-        r.enable_device_exchange(sim, dev)
-        r.nsteps = nsteps
-        ds = DaySequence(r, nsteps, qts, nchunks=a.chunks, hydrographs_on_every_rank=True)
-        K, C, _ = r._chunking(a.chunks)
-        sim.prepare(K, C)
-        local = ds.prepare_days(days)
-        got = {}
-        mine = np.concatenate([r.my_out0_global, r.my_out1_global])
-        best = None
-        for rep in range(max(1, a.reps)):
-            sim.call = 0
-            got.clear()
-            out = ds.run(local, q0, D - 1, 1, prepared=True,
-                         on_day=lambda w, h, s: got.__setitem__(w, None if h is None else np.array(h[np.searchsorted(r._out_rows, mine)], copy=True)))
-            per = out["el"] / (D - 1)
-            best = per if best is None else min(best, per)
-        ok = all(np.array_equal(got[w].view(np.uint32), ref_hyd[w][np.searchsorted(ref_rows, mine)].view(np.uint32)) for w in range(D))
-        worst = max(worst, best)
-        st = r.last_stats["phase0"]
-        print(f"rank {rank} ({r._state_plans[0].engine}, {st.get('wide_levels', 0)} wide levels): period {best * 1e3:7.2f} ms per day  "
-              f"(device window {np.mean(out['ms_main']):.2f} ms)  rows {r.sequence_rows().size}  outlets of every day bit-identical: {ok}")
-        ds.close()
-        r.close()
+          sim = SimComm(r)
+          r.enable_device_exchange(sim, dev)
+          r.nsteps = nsteps
+          ds = DaySequence(r, nsteps, qts, nchunks=a.chunks, hydrographs_on_every_rank=True)
+          K, C, _ = r._chunking(a.chunks)
+          sim.prepare(K, C)
+          local = ds.prepare_days(days)
+          got = {}
+          mine = np.concatenate([r.my_out0_global, r.my_out1_global])
+          best = None
+          for rep in range(max(1, a.reps)):
+              sim.call = 0
+              got.clear()
+              out = ds.run(local, q0, D - 1, 1, prepared=True,
+                           on_day=lambda w, h, s: got.__setitem__(w, None if h is None else np.array(h[np.searchsorted(r._out_rows, mine)], copy=True)))
+              per = out["el"] / (D - 1)
+              best = per if best is None else min(best, per)
+          ok = all(np.array_equal(got[w].view(np.uint32), ref_hyd[w][np.searchsorted(ref_rows, mine)].view(np.uint32)) for w in range(D))
+          worst = max(worst, best)
+          periods[rank] = best
+          st = r.last_stats["phase0"]
+          print(f"rank {rank} ({r._state_plans[0].engine}, {st.get('wide_levels', 0)} wide levels): period {best * 1e3:7.2f} ms per day  "
+                f"(device window {np.mean(out['ms_main']):.2f} ms)  rows {r.sequence_rows().size}  outlets of every day bit-identical: {ok}")
+          ds.close()
+          r.close()
     base = period_single if period_single else t_single
     print(f"slowest rank {worst * 1e3:.2f} ms per day -> speed-up vs single GPU under the same pipeline {base / worst:.2f}x at world {a.world}")
 
