@@ -166,9 +166,9 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *   mid_min_rows   the same for a SECOND tier: the levels right below the wide ones, mid_k steps per launch under their own
  *                  skew, queued on the plan's stream between the tail's launches; 0 = default (OFF: measured slower on the
  *                  CONUS day at every setting tried), < 0 = never.  mid_levels (0 = 12), mid_k (0 = 4).
- *   tile_perm_group  rows re-dealt to the threads of a wide tile by the cost class they showed in the tile before, inside
- *                  groups of so many positions (a multiple of 256 up to 1024); 0 = default (256 on a plan created with a
- *                  cost hint, off otherwise), < 0 = off.
+ *   tile_perm_group  the threads of every block of a wide tile take the block's rows by the cost class the rows showed in the
+ *                  tile before (inside the launch; wavefronts of one class whatever the forcing does): 0 = default (on for a
+ *                  plan created with a cost hint), > 0 = on, < 0 = off.
  *   tail_sort      < 0: keep the per-level order below the tiled levels of a hinted short-timestep plan (default: by cost).
  *   stem_min_rows  general-mode dataflow plans: basins whose longest path has at least so many rows are laid out stem-last
  *                  (0 = default 1 024, < 0 = off).

@@ -435,11 +435,9 @@ template <class T> struct StepArgs {
     T *out;
     const int32_t *row_of_pos;
     bool out_vec; // the runs it writes are 16-byte aligned (float, nsteps % 4 == 0, K % 4 == 0)
-    // k_mc_tile: which row a thread takes (nullptr: its own position).  A permutation of the positions inside groups of
-    // kPermGroup, rebuilt before every tile from the cost class every row showed at the end of the tile before (k_tile_perm):
-    // wavefronts hold rows of one class whatever the forcing does and however old the plan's cost hint is.
-    const int32_t *tile_perm;
-    uint8_t *cls_last; // cost class of every row at the last step it was routed in a tile: min(iterations, 3) + 4 if over bank
+    // k_mc_tile: non-null = the threads of a block take the block's rows by descending cost class (see the kernel's prologue):
+    // the class of every row at the last step it was routed in a tile, min(iterations, 3) + 4 if over bank
+    uint8_t *cls_last;
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -634,8 +632,13 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 // need no transposing pass (k_emit skips them) and no velocity plane at all; of the time-major planes only the flow row
 // of every step (what downstream rows and the gathers read) and the depth row of a tile's last step (where the row's next
 // tile, or the final state, picks it up) are written.
+#ifndef TRMC_TILE_PARTITION_UNHINTED
+#define TRMC_TILE_PARTITION_UNHINTED 0
+#endif
 constexpr int kTileStage = 8;
 constexpr int32_t kWideMaxLevels = 16; // at most this many leading levels are routed by k_mc_tile's first tier (wide_levels is capped by it)
+// in-block partition of a tile's rows by cost class: on for plans built with a cost hint, and (measured) ...
+constexpr bool kTilePartitionDefault(bool hinted) { return hinted || TRMC_TILE_PARTITION_UNHINTED; }
 constexpr int32_t kMidMaxLevels = 32;  // ... and at most this many more by its second tier (mid_levels)
 constexpr int64_t kMidDefaultRowsPerCu = 0; // default threshold of the second tier in rows per compute unit; 0 = off unless asked for
 #ifndef TRMC_TILE_WAVES // wavefronts per SIMD the register allocation of k_mc_tile must allow.  Measured on the CONUS day by
@@ -656,8 +659,35 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     m.sane = a.sane;
 
     const int32_t s_mine = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
-    if (s_mine >= s_end) return;
-    const int32_t s = a.tile_perm ? a.tile_perm[s_mine] : s_mine;
+    int32_t s = s_mine;
+    if (a.cls_last) {
+        // Which row a thread takes: the block's kStepBlock positions dealt out by DESCENDING cost class -- the class every row
+        // showed at the end of the tile before (a row repeats its secant iteration count from step to step 99.3 % of the time)
+        // -- so that a wavefront holds rows of one class whatever the forcing does and however old the plan's cost hint is.
+        // Once per K steps, inside the launch: a count per class in LDS, a prefix over the eight classes, a scatter of lane
+        // numbers.  (Until round 5 a launch of its own between the tiles, k_tile_perm, over groups of 256 positions: 13-25 us
+        // of the tile stream per tile, 0.55 ms of a CONUS day spent between tiles.)  Order inside a class is whatever the
+        // atomics give; results do not depend on which thread routes a row.
+        __shared__ int32_t s_cnt[9], s_base[9];
+        __shared__ int16_t s_lane[kStepBlock];
+        if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const int32_t key = s_mine < s_end ? 7 - min((int32_t)a.cls_last[s_mine], 7) : 8; // bucket 0 = the costliest; 8 = no row
+        const int32_t rank = atomicAdd(&s_cnt[key], 1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t acc = 0;
+            for (int b = 0; b < 9; ++b) {
+                s_base[b] = acc;
+                acc += s_cnt[b];
+            }
+        }
+        __syncthreads();
+        s_lane[s_base[key] + rank] = (int16_t)threadIdx.x;
+        __syncthreads();
+        s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)s_lane[threadIdx.x];
+    }
+    if (s >= s_end) return;
     const int32_t behind = tile - a.level[s];
     if (behind < 0) return;
     const int32_t t_lo = behind * K + 1, t_hi = min(behind * K + K, a.nsteps);
@@ -792,50 +822,6 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     if (t_hi == cold->nsteps) cold->it_prev[su] = (uint8_t)min(it_last, 255);
     if (uint8_t *const cls = cold->cls_last) cls[su] = (uint8_t)(min(it_last, 3) + (over_last ? 4 : 0));
     if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535, (int)it_sum[su] + it_acc);
-}
-
-// Which row every thread of the next k_mc_tile launch takes: inside each group of kPermGroup consecutive positions the rows
-// are dealt out by DESCENDING cost class (the class each showed at the end of the tile before: a row repeats its secant
-// iteration count from step to step 99.3 % of the time), so a wavefront holds rows of one class -- on the device, tile by
-// tile, from what the rows just did.  The plan's cost hint does the same once, on the host, from an earlier window
-// (topology.hpp), and is worth nothing when the forcing changes: with half of the rows' inflow drawn anew from day to day
-// the tuned plan ran the CONUS day in 20.6 ms, the untuned one in 20.2, against 16.4 on the day it was tuned for.
-// A group is a workgroup here; order inside a class is whatever the atomics give (results do not depend on it).
-// MEASURED (CONUS sequence of bench.py, ms per day; TRMC_TILE_PERM=<group>, 0 = off): ON with groups of 256 for plans built
-// with a cost hint (16.0-16.1 against 16.3-16.4, three runs each), OFF for plans without one: on the plan
-// built from the topology alone 20.2 without, 20.7 / 21.7 / 22.4 with groups of 256 / 512 / 1024; on the tuned plan with
-// half of the rows' inflow redrawn every day 20.6 without, 20.9 with groups of 256; on the tuned plan and its own kind of
-// days 16.0-16.7 either way.  Dealing rows out by class takes a wavefront's 64 rows from 8-27 cache lines of every column
-// instead of 2, and what the uniform wavefronts save in instructions the scattered flow stores and parameter loads cost
-// again: the remedy for a stale hint stays a new hint (a plan rebuilt from trmc_download_cost, 1.6 s on the host).
-constexpr int kPermGroupMax = 1024;
-__global__ void __launch_bounds__(kBlock)
-k_tile_perm(const uint8_t *__restrict__ cls, int32_t *__restrict__ perm, const int32_t s_begin, const int32_t s_end, const int32_t group)
-{   // group: positions per group, a multiple of kBlock up to kPermGroupMax
-    __shared__ int32_t count[8], base[8];
-    const int32_t g0 = s_begin + (int32_t)blockIdx.x * group;
-    if (threadIdx.x < 8) count[threadIdx.x] = 0;
-    __syncthreads();
-    constexpr int kPer = kPermGroupMax / kBlock;
-    int32_t key[kPer], rank[kPer];
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int32_t p = g0 + j * kBlock + (int32_t)threadIdx.x;
-        key[j] = (j * kBlock < group && p < s_end) ? 7 - min((int32_t)cls[p], 7) : -1; // bucket 0 = the costliest class
-        rank[j] = key[j] >= 0 ? atomicAdd(&count[key[j]], 1) : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t acc = 0;
-        for (int b = 0; b < 8; ++b) {
-            base[b] = acc;
-            acc += count[b];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kPer; ++j)
-        if (key[j] >= 0) perm[g0 + base[key[j]] + rank[j]] = g0 + j * kBlock + (int32_t)threadIdx.x;
 }
 
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
@@ -2077,7 +2063,7 @@ struct trmc_plan {
         int32_t wide_levels = 16, wide_k = 16;
         int64_t mid_min_rows = 0;            // <= 0: no second tier
         int32_t mid_levels = 12, mid_k = 4;
-        int32_t tile_perm_group = -1;        // -1: by the hint (256 / off); 0: off; else the group
+        int32_t tile_perm_group = -1;        // -1: the default (see route_advance_t); 0: off; 1: on
         bool sequence = false;
         bool flow_overlap = false;
         int32_t flow_lean = 0;
@@ -2105,7 +2091,7 @@ struct trmc_plan {
     bool q0_staged = false;              // in_q0 holds the initial state of the window that is staged (an upload's q0, or the last
                                          // window's final state gathered by an upload with q0 = NULL / trmc_stage_forcing): valid
                                          // until a window consumes it, whatever routed_nsteps says in the meantime
-    DevBuf tile_perm, cls_last;          // k_tile_perm: the row every thread of the next wide tile takes; the classes it is made from
+    DevBuf cls_last;                     // the cost class every wide row showed at the end of its last tile (k_mc_tile's in-block partition)
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
     std::vector<int32_t> rowset_lag;
@@ -2220,8 +2206,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.out = (T *)pl->out.p;
     a.row_of_pos = (const int32_t *)pl->row_of_pos.p;
     a.out_vec = sizeof(T) == 4 && nsteps % 4 == 0 && pl->run.wide_k % 4 == 0;
-    a.tile_perm = nullptr; // (route_advance_t switches the permutation on for its wide tiles)
-    a.cls_last = nullptr;
+    a.cls_last = nullptr; // (route_advance_t switches the in-block partition on for its wide tiles)
     return a;
 }
 
@@ -2494,28 +2479,18 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             // 1.2 ms for them.)  One event per tile: it ends the tile for the clock (a tile starts where the one before it
             // ended; the first has a start event of its own) and it is what the tail waits for.
             if (r.wide_next == 0) {
-                // rows dealt to the threads of every tile by the cost class they showed in the tile before, inside groups of
-                // `perm_group` positions (k_tile_perm, see the measurements there).  Default: groups of 256 on a plan built
-                // with a cost hint -- there the re-dealing repairs what is left of mixed wavefronts at the class boundaries and
-                // where rows have drifted since the hint was taken: 16.0-16.1 against 16.3-16.4 ms per day, three runs each --
-                // and off on a plan without one, where it costs more than it saves
-                const int32_t perm_group = pl->opt.tile_perm_group >= 0 ? std::min(kPermGroupMax, pl->opt.tile_perm_group) / kBlock * kBlock
-                                                                        : (pl->hinted ? 256 : 0);
-                const bool use_perm = perm_group > 0;
+                // rows dealt to the threads of every block of a tile by the cost class they showed in the tile before (k_mc_tile's
+                // prologue; trmc_plan_options.tile_perm_group: < 0 off, > 0 on, 0 the default below).
+                const bool use_perm = pl->opt.tile_perm_group > 0 || (pl->opt.tile_perm_group < 0 && kTilePartitionDefault(pl->hinted));
                 StepArgs<T> at = a;
                 if (use_perm) {
                     const bool fresh = pl->cls_last.bytes < (size_t)pl->nseg_pad;
                     if (int rc = pl->cls_last.ensure((size_t)pl->nseg_pad)) return rc;
-                    if (int rc = pl->tile_perm.ensure((size_t)pl->nseg_pad * sizeof(int32_t))) return rc;
                     if (fresh) HIP_TRY(hipMemsetAsync(pl->cls_last.p, 0, (size_t)pl->nseg_pad, ws)); // (no history yet: one class)
-                    at.tile_perm = (const int32_t *)pl->tile_perm.p;
                     at.cls_last = (uint8_t *)pl->cls_last.p;
                 }
                 HIP_TRY(hipEventRecord(pl->wide_t0[0], ws));
                 for (int32_t j = 0; j < ntile; ++j) {
-                    if (use_perm)
-                        hipLaunchKernelGGL(k_tile_perm, dim3((unsigned)((w1 - w0 + perm_group - 1) / perm_group)), dim3(kBlock), 0, ws,
-                                           (const uint8_t *)pl->cls_last.p, (int32_t *)pl->tile_perm.p, w0, w1, perm_group);
                     launch_tile<T>(ws, at, w0, w1, j, K, tol);
                     HIP_TRY(hipEventRecord(pl->wide_t1[(size_t)j], ws));
                     ++r.launches;
@@ -3389,7 +3364,6 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
     if (o.arithmetic != TRMC_ARITH_EXACT && o.arithmetic != TRMC_ARITH_TOLERANCE) return fail(TRMC_EINVAL, "bad trmc_plan_options.arithmetic");
     if (o.arithmetic == TRMC_ARITH_TOLERANCE && precision != 32)
         return fail(TRMC_EINVAL, "TRMC_ARITH_TOLERANCE is an arithmetic of precision-32 plans");
-    if (o.tile_perm_group > 0 && o.tile_perm_group % kBlock != 0) return fail(TRMC_EINVAL, "tile_perm_group must be a multiple of 256");
     *out = nullptr;
     if (precision != 32 && precision != 64) return fail(TRMC_EINVAL, "precision must be 32 or 64");
     if (nseg > 0 && !params) return fail(TRMC_EINVAL, "params is NULL");
@@ -3428,7 +3402,7 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         po.mid_min_rows = o.mid_min_rows < 0 ? 0 : (o.mid_min_rows > 0 ? o.mid_min_rows : kMidDefaultRowsPerCu * (int64_t)ncu);
         po.mid_levels = (int32_t)std::min<long>(o.mid_levels > 0 ? o.mid_levels : 12, kMidMaxLevels);
         po.mid_k = o.mid_k > 0 ? o.mid_k : 4;
-        po.tile_perm_group = o.tile_perm_group < 0 ? 0 : (o.tile_perm_group > 0 ? o.tile_perm_group : -1);
+        po.tile_perm_group = o.tile_perm_group < 0 ? 0 : (o.tile_perm_group > 0 ? 1 : -1); // off / on / by the plan (default)
         po.sequence = o.sequence_mode != 0;
         po.flow_overlap = o.flow_overlap != 0;
         po.flow_lean = o.flow_lean;
@@ -3571,7 +3545,7 @@ void trmc_plan_destroy(trmc_plan *pl)
             for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
                               &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos, &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos,
                               &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch,
-                              &pl->gathered, &pl->tile_perm, &pl->cls_last})
+                              &pl->gathered, &pl->cls_last})
                 b->release();
         }
         pl->zombie = true;
@@ -3589,7 +3563,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->tile_perm, &pl->cls_last})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);
