@@ -548,7 +548,11 @@ def main():
         tuned["speed"], tuned["part"] = sharding.rank_speeds(lt[:, 0], lt[:, 1]), router.part
     router.collect_cost(False)
     t_tune = time.perf_counter() - t0
-    state_n = None if use_dist else router.plan0.download_final_state()   # the state after day N (where the timed sequence starts)
+    def state_after_day_n(r):
+        """the state after day N, where the timed sequence starts: every row (one GPU), or this rank's rows in the order of its
+        merged plan (DaySequence takes either)"""
+        return r._state_plans[0].download_final_state() if use_dist else r.plan0.download_final_state()
+    state_n = state_after_day_n(router)
     router.upload(a.nsteps, qlat_b, None)              # day N+1, warm
     unt = timed(router, True, usteps, 1)
     untuned = {"value": rate(unt), "unit": "segment-timesteps/s", "ms_per_step": unt["el"] / usteps * 1e3,
@@ -576,8 +580,7 @@ def main():
             router = make_router(hint, True, qlat_s, q0)
             spin_up(router, True)
         tuned["feedback_ms"] = feedback
-        if not use_dist:
-            state_n = router.plan0.download_final_state()
+        state_n = state_after_day_n(router)
         router.upload(a.nsteps, qlat_b, None)
         t_tune += time.perf_counter() - t0
 
@@ -600,8 +603,6 @@ def main():
     persist = None
     dayseq = DaySequence(router, a.nsteps, a.qts, nchunks=a.chunks)
     if use_dist:
-        # the state after day N, this rank's rows, so that the check below can replay the first days of the timed sequence
-        state_n = router._state_plans[0].download_final_state()
         local_ring = dayseq.prepare_days(ring)          # (this rank's rows of every day, page-locked: outside the clock)
         seq = dayseq.run(local_ring, state_n, a.steps, a.warmup, prepared=True)
         head = {"el": seq["el"], "ms_main": float(np.mean(seq["ms_main"])), "ms_total": seq["el"] / a.steps * 1e3,

@@ -184,6 +184,31 @@ SIGNATURES_DW = {
 }
 
 _LIB = None
+# entry points that never touch the HIP runtime (everything else may initialise it: single_hw_queue_per_priority must know)
+_HOST_ONLY = {"trmc_last_error", "trmc_abi_version", "trmc_topology_levels", "trmc_topology_levels_hinted", "trmc_topology_blocks",
+              "trmc_topology_blocks_general", "trmc_get_stats", "trmc_plan_info", "trmc_plan_levels", "trmc_plan_engine",
+              "trmc_plan_arithmetic", "trdw_last_error", "trdw_last_timing", "trdw_configure", "trmc_comm_info"}
+
+
+class _Marking:
+    """The loaded library; any call that may start the HIP runtime of the process is noted (``_hip_started``) before it is
+    made, whoever makes it -- a plan, a page-locked allocation, the single-segment entry point."""
+
+    def __init__(self, cdll):
+        self.__dict__["_cdll"] = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if name in _HOST_ONLY:
+            self.__dict__[name] = fn
+            return fn
+
+        def call(*args, _fn=fn):
+            global _hip_started
+            _hip_started = True
+            return _fn(*args)
+        self.__dict__[name] = call
+        return call
 
 
 def lib():
@@ -202,7 +227,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        _LIB = h
+        _LIB = _Marking(h)
     return _LIB
 
 
@@ -272,15 +297,17 @@ def _pool():
     _pinned_inside.depth = getattr(_pinned_inside, "depth", 0) + 1
     try:
         with _pinned_lock:
-            yield drop
-            while _pinned_pending:
-                a, n = _pinned_pending.pop()
-                _pool_put(a, n, drop)
+            try:
+                yield drop
+            finally:                         # (also when the body raises: what finalizers noted meanwhile is still carried out)
+                while _pinned_pending:
+                    a, n = _pinned_pending.pop()
+                    _pool_put(a, n, drop)
     finally:
         _pinned_inside.depth -= 1
-    if _LIB is not None:
-        for a in drop:
-            _LIB.trmc_host_free(C.c_void_p(a))
+        if _LIB is not None:
+            for a in drop:
+                _LIB.trmc_host_free(C.c_void_p(a))
 
 
 def _pinned_release(address, nbytes):
