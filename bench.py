@@ -406,6 +406,10 @@ def main():
         wd = threading.Timer(limit, give_up)
         wd.daemon = True
         wd.start()
+        # ... and one that stands still says where: every thread's stack on stderr (TRMC_BENCH_STACKS_S, default: never)
+        if os.environ.get("TRMC_BENCH_STACKS_S"):
+            import faulthandler
+            faulthandler.dump_traceback_later(float(os.environ["TRMC_BENCH_STACKS_S"]), repeat=True, file=sys.stderr)
     if use_dist:
         comm = X.Comm(rank, world, device, backend=os.environ.get("TRMC_BENCH_BACKEND", "auto"))
     local_rank = device

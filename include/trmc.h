@@ -161,7 +161,7 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *                  iteration's 1 % exit test (MCsingleSegStime_f2py_NOLOOP.f90:83) amplifying a last-place difference where it
  *                  converges slowly, not the arithmetic's.  Without assume_short_ts the reference recurrence amplifies
  *                  differences from a cold start and no tolerance is claimed.
- *   wide_min_rows  rows a leading level must have to be routed wide_k steps per launch (k_mc_tile); 0 = default (384 per
+ *   wide_min_rows  rows a leading level must have to be routed wide_k steps per launch (k_mc_tile); 0 = default (288 per
  *                  compute unit; 256 in tolerance arithmetic), < 0 = never.  wide_levels: at most so many (0 = default 16).  wide_k: 0 = default 16.
  *   mid_min_rows   the same for a SECOND tier: the levels right below the wide ones, mid_k steps per launch under their own
  *                  skew, queued on the plan's stream between the tail's launches; 0 = default (OFF: measured slower on the

@@ -636,6 +636,10 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
 #define TRMC_TILE_PARTITION_UNHINTED 1
 #endif
 constexpr int kTileStage = 8;
+#ifndef TRMC_TILE_BLOCK // threads per block of k_mc_tile: also the group its in-block partition deals rows in
+#define TRMC_TILE_BLOCK 128
+#endif
+constexpr int kTileBlock = TRMC_TILE_BLOCK;
 constexpr int32_t kWideMaxLevels = 16; // at most this many leading levels are routed by k_mc_tile's first tier (wide_levels is capped by it)
 // in-block partition of a tile's rows by cost class: on.  Measured on the CONUS sequence (ms per day, on / off): plan built from
 // the topology alone 19.3 / 20.4, tuned plan on days whose forcing is drawn anew 19.8 / 20.8, tuned plan on its own kind of days
@@ -650,20 +654,20 @@ constexpr int64_t kMidDefaultRowsPerCu = 0; // default threshold of the second t
 #define TRMC_TILE_WAVES 5
 #endif
 template <class T, bool TOL = false>
-__global__ void __launch_bounds__(kStepBlock, sizeof(T) == 4 ? TRMC_TILE_WAVES : 1)
+__global__ void __launch_bounds__(kTileBlock, sizeof(T) == 4 ? TRMC_TILE_WAVES : 1)
 k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t tile, const int32_t K)
 {
     using M = typename DevMath<T, TOL>::type;
     const ColdArgs<StepArgs<T>> cold = cold_args<StepArgs<T>>(); // (see cold_args: what the loop rarely needs is not kept in registers)
     __shared__ uint64_t s_tab[TRMC_POW_TAB_WORDS];
-    __shared__ T s_out[3 * kTileStage * kStepBlock]; // [step slot * 3 + c][thread]
+    __shared__ T s_out[3 * kTileStage * kTileBlock]; // [step slot * 3 + c][thread]
     M m{stage_pow_tables(s_tab), false};
     m.sane = a.sane;
 
-    const int32_t s_mine = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
+    const int32_t s_mine = s_begin + (int32_t)blockIdx.x * kTileBlock + (int32_t)threadIdx.x;
     int32_t s = s_mine;
     if (a.cls_last) {
-        // Which row a thread takes: the block's kStepBlock positions dealt out by DESCENDING cost class -- the class every row
+        // Which row a thread takes: the block's kTileBlock positions dealt out by DESCENDING cost class -- the class every row
         // showed at the end of the tile before (a row repeats its secant iteration count from step to step 99.3 % of the time)
         // -- so that a wavefront holds rows of one class whatever the forcing does and however old the plan's cost hint is.
         // Once per K steps, inside the launch: a count per class in LDS, a prefix over the eight classes, a scatter of lane
@@ -671,7 +675,7 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // of the tile stream per tile, 0.55 ms of a CONUS day spent between tiles.)  Order inside a class is whatever the
         // atomics give; results do not depend on which thread routes a row.
         __shared__ int32_t s_cnt[9], s_base[9];
-        __shared__ int16_t s_lane[kStepBlock];
+        __shared__ int16_t s_lane[kTileBlock];
         if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
         __syncthreads();
         const int32_t key = s_mine < s_end ? 7 - min((int32_t)a.cls_last[s_mine], 7) : 8; // bucket 0 = the costliest; 8 = no row
@@ -687,7 +691,7 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         __syncthreads();
         s_lane[s_base[key] + rank] = (int16_t)threadIdx.x;
         __syncthreads();
-        s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)s_lane[threadIdx.x];
+        s = s_begin + (int32_t)blockIdx.x * kTileBlock + (int32_t)s_lane[threadIdx.x];
     }
     if (s >= s_end) return;
     const int32_t behind = tile - a.level[s];
@@ -797,10 +801,10 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         q_prev = q_new;
         d_prev = d_new;
         {   // stage (q, v, d) of step t; a run ends when kTileStage steps are staged and at the tile's last step
-            T *so = s_out + (size_t)(staged * 3) * kStepBlock + threadIdx.x;
+            T *so = s_out + (size_t)(staged * 3) * kTileBlock + threadIdx.x;
             so[0] = q_new;
-            so[kStepBlock] = v_new;
-            so[2 * kStepBlock] = d_new;
+            so[kTileBlock] = v_new;
+            so[2 * kTileBlock] = d_new;
             ++staged;
             if (staged == kTileStage || t == t_hi) {
                 T *dst = out_row + (size_t)(t - staged) * 3;
@@ -808,14 +812,14 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 if (a.out_vec && (staged & 3) == 0) { // (float: 3 * staged values = 3 * staged / 4 pieces of 16 bytes)
                     for (int j = 0; j < 3 * staged / 4; ++j) {
                         float4 v;
-                        v.x = (float)si[(4 * j + 0) * kStepBlock];
-                        v.y = (float)si[(4 * j + 1) * kStepBlock];
-                        v.z = (float)si[(4 * j + 2) * kStepBlock];
-                        v.w = (float)si[(4 * j + 3) * kStepBlock];
+                        v.x = (float)si[(4 * j + 0) * kTileBlock];
+                        v.y = (float)si[(4 * j + 1) * kTileBlock];
+                        v.z = (float)si[(4 * j + 2) * kTileBlock];
+                        v.w = (float)si[(4 * j + 3) * kTileBlock];
                         reinterpret_cast<float4 *>(dst)[j] = v;
                     }
                 } else {
-                    for (int32_t e = 0; e < 3 * staged; ++e) dst[e] = si[e * kStepBlock];
+                    for (int32_t e = 0; e < 3 * staged; ++e) dst[e] = si[e * kTileBlock];
                 }
                 staged = 0;
             }
@@ -2237,7 +2241,7 @@ inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_
 template <class T>
 inline void launch_tile(hipStream_t st, const StepArgs<T> &a, int32_t p0, int32_t p1, int32_t tile, int32_t K, bool tol)
 {
-    const dim3 grid((unsigned)((p1 - p0 + kStepBlock - 1) / kStepBlock)), block(kStepBlock);
+    const dim3 grid((unsigned)((p1 - p0 + kTileBlock - 1) / kTileBlock)), block(kTileBlock);
     if constexpr (sizeof(T) == 4) {
         if (tol) {
             hipLaunchKernelGGL((k_mc_tile<T, true>), grid, block, 0, st, a, p0, p1, tile, K);
@@ -3394,11 +3398,14 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
         trmc_plan::Opt &po = pl->opt;
         po.tol = o.arithmetic == TRMC_ARITH_TOLERANCE;
-        // (default threshold of the wide tier: 384 rows per compute unit -- five levels of the CONUS network -- in exact arithmetic,
+        // (default threshold of the wide tier, until round 5: 384 rows per compute unit -- five levels of the CONUS network -- in exact arithmetic,
         // where the tiles are what the device is busy with and the ramps of the skew cost; 256 -- seven levels -- in tolerance
         // arithmetic, where a tile's arithmetic is a quarter cheaper and the window waits for the tail's chain of launches:
         // 12.8 ms per CONUS day against 14.0, measured on the sequence of bench.py; 192: 13.0, 128: 13.4)
-        po.wide_min_rows = o.wide_min_rows < 0 ? 0 : (o.wide_min_rows > 0 ? o.wide_min_rows : (po.tol ? 256L : 384L) * ncu);
+        // Round 5, with the partition of a tile's rows inside the launch (no launch between tiles any more): exact arithmetic
+        // 288 rows per compute unit -- six levels of CONUS -- 16.7 ms per day against 17.2 with five, 16.85 with seven or eight
+        // (three runs each on one box).
+        po.wide_min_rows = o.wide_min_rows < 0 ? 0 : (o.wide_min_rows > 0 ? o.wide_min_rows : (po.tol ? 256L : 288L) * ncu);
         po.wide_levels = (int32_t)std::min<long>(o.wide_levels > 0 ? o.wide_levels : 16, kWideMaxLevels);
         po.wide_k = o.wide_k > 0 ? o.wide_k : 0; // (0: 16, or an eighth of a short window -- route_begin_t)
         po.mid_min_rows = o.mid_min_rows < 0 ? 0 : (o.mid_min_rows > 0 ? o.mid_min_rows : kMidDefaultRowsPerCu * (int64_t)ncu);
