@@ -409,7 +409,8 @@ def main():
         # ... and one that stands still says where: every thread's stack on stderr (TRMC_BENCH_STACKS_S, default: never)
         if os.environ.get("TRMC_BENCH_STACKS_S"):
             import faulthandler
-            faulthandler.dump_traceback_later(float(os.environ["TRMC_BENCH_STACKS_S"]), repeat=True, file=sys.stderr)
+            _stacks = open(os.path.join(os.environ.get("TRMC_BENCH_STACKS_DIR", "/tmp"), f"bench_stacks_rank{rank}.txt"), "w")
+            faulthandler.dump_traceback_later(float(os.environ["TRMC_BENCH_STACKS_S"]), repeat=True, file=_stacks)
     if use_dist:
         comm = X.Comm(rank, world, device, backend=os.environ.get("TRMC_BENCH_BACKEND", "auto"))
     local_rank = device
@@ -779,8 +780,9 @@ def main():
         comm = None
     if dist_outlets is not None and not a.no_parity_full and a.precision == 32:
         try:      # the job's product -- the all-gathered outlet block of the last timed window -- against the reference on the CPU
-            parity = parity_full(net, None, (qlat_s, qlat_a, qlat_b), q0, a.nsteps, a.qts, outlets=dist_outlets,
+            parity = parity_full(net, None, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts, outlets=dist_outlets,
                                  threads=a.cpu_threads)
+            parity["pipeline"] = "the timed pass's pipeline re-run untimed over days N+1, N+2 on every rank; the all-gathered outlet block of day N+2"
         except Exception as e:
             parity = {"error": repr(e)}
 

@@ -76,6 +76,7 @@ class ShardedRouter:
             def plan_factory(lp, li, par, boundary, prec, dev, rows=None, **kw):   # noqa: F811
                 return base_factory(lp, li, par, boundary, prec, dev, **kw)
         self.rank, self.world = rank, world
+        self._engine_arg, self._short_arg = engine, assume_short_ts
         self.nseg = to.shape[0]
         self.dtype = np.float32 if precision == 32 else np.float64
         part = sharding.partition(to, world) if partition is None else partition
@@ -376,9 +377,37 @@ class ShardedRouter:
         """time chunks of the hand-off pipeline: a launch per chunk.  The level engine launches per timestep anyway and
         wants the trunk's skew (two chunks) short; the dataflow engine runs a chunk as one persistent launch and wants
         few of them (349 k-row ranks: 5.7 ms with 24 chunks, 4.5 with 8, 4.3 with 4 of 72 steps -- every launch ends in
-        a drain; with 2 or 3 the trunk's owner, who trails by two chunks, is the slowest rank again).  Decided from the
-        engine of the plan that actually runs the window."""
-        return 4 if getattr(plan, "engine", "levels") == "flow" else 24
+        a drain; with 2 or 3 the trunk's owner, who trails by two chunks, is the slowest rank again).
+        The number of chunks is the number of all-gathers of a window: EVERY rank must arrive at the same one.  It is
+        therefore decided from what every rank knows -- the whole partition, hence the engine every rank's window runs on
+        (the rule of trmc_plan_create_opt applied to each rank's row count) -- not from this rank's own engine: a partition
+        rebalanced by measured pace can leave one rank of two under the million rows at which the engines change, and
+        ranks that disagreed on the count waited for each other for ever (seen once in three bench launches at N = 2)."""
+        engines = set(self._engines_of_all_ranks())
+        if engines == {"flow"}:
+            return 4
+        if engines == {"levels"}:
+            return 24
+        return 8
+
+    def _engines_of_all_ranks(self):
+        """the engine of every rank's short-timestep window (sub-basins + the trunk it owns), from the partition alone"""
+        part = self.part
+        piece, phase, owner = part["piece"], part["phase"], part["owner"]
+        routed = np.bincount(owner[piece], minlength=self.world)          # sub-basin rows and trunk rows of every rank
+        owns_trunk = np.bincount(owner[phase == 1], minlength=self.world) > 0   # (its merged plan is built for assume_short_ts)
+        env = _os.environ.get("TRMC_ENGINE")
+        out = []
+        for r in range(self.world):
+            if self._mk["precision"] != 32:
+                out.append("levels")
+            elif self._engine_arg in ("levels", "flow"):
+                out.append(self._engine_arg)
+            elif env in ("levels", "flow"):
+                out.append(env)
+            else:
+                out.append("levels" if ((self._short_arg or owns_trunk[r]) and int(routed[r]) >= 1_000_000) else "flow")
+        return out
 
     def _route_skewed(self, qts_subdivisions, nchunks, staged=False, before_end=None):
         """assume_short_ts: a row at step t reads its upstream rows at step t-1 only.  The window is cut into

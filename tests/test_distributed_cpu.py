@@ -318,3 +318,36 @@ def test_partition_by_measured_rank_pace(seed, nseg, nnet, nparts):
     assert finish.max() / finish.min() < 1.05, finish
     if fast.size:
         assert (loads2[owners] < loads[owners]).all()                                   # the slow ranks were relieved
+
+
+def test_every_rank_arrives_at_the_same_number_of_chunks(monkeypatch):
+    """The chunks of a window are its all-gathers: every rank must count the same.  The count follows the engines of ALL
+    ranks' windows, derived from the partition every rank holds -- not from a rank's own engine: with a partition that leaves
+    one rank under the row count at which the engines change, ranks that decided for themselves would wait for each other
+    for ever (seen at N = 2 after a rebalancing by measured pace)."""
+    import troute_amd.distributed as D
+    from oracle_plan import OraclePlan
+    from troute_amd.distributed import ShardedRouter
+    net = small_conus()
+    to = net["to"]
+    world = 2
+    part = sharding.partition(to, world, rank_speed=np.array([0.55, 1.45]))      # a lopsided partition
+    sizes = np.bincount(part["owner"][part["piece"]], minlength=world)
+    assert sizes.min() < 0.9 * sizes.max()
+    # the threshold at which trmc_plan_create_opt changes engines, scaled down to this network: between the two ranks' sizes
+    threshold = int((sizes.min() + sizes.max()) // 2)
+    src = D.ShardedRouter._engines_of_all_ranks
+    monkeypatch.setattr(D.ShardedRouter, "_engines_of_all_ranks",
+                        lambda self: ["levels" if n >= threshold else "flow"
+                                      for n in np.bincount(self.part["owner"][self.part["piece"]], minlength=self.world)])
+    counts = []
+    for rank in range(world):
+        r = ShardedRouter(to, net["params"], rank=rank, world=world, plan_factory=OraclePlan, partition=part, assume_short_ts=True)
+        r.nsteps = 288
+        counts.append((r._default_chunks(None), r._chunking(None)))
+    assert counts[0] == counts[1] and counts[0][0] == 8            # mixed engines: one agreed count
+    monkeypatch.setattr(D.ShardedRouter, "_engines_of_all_ranks", src)
+    r = ShardedRouter(to, net["params"], rank=0, world=world, plan_factory=OraclePlan, partition=part, assume_short_ts=True)
+    assert r._engines_of_all_ranks() == ["flow", "flow"] and r._default_chunks(None) == 4   # (both far under a million rows)
+    monkeypatch.setenv("TRMC_ENGINE", "levels")
+    assert r._engines_of_all_ranks() == ["levels", "levels"] and r._default_chunks(None) == 24
