@@ -671,39 +671,6 @@ def main():
         chk = dayseq.run(local_ring[:2], state_n, 2, 0, prepared=True)
         if rank == 0:
             dist_outlets = (np.array(router._out_rows, copy=True), np.array(chk["hyd"], copy=True))
-    if rank == 0 and not a.no_parity_full and a.precision == 32 and not use_dist:
-        try:      # against the reference on the CPU (checker use, outside the clock)
-            # the timed pipeline once more, untimed, over the first two days of the ring (days N+1 and N+2 from the state
-            # after day N: plan and clone, staged forcing, state handed over on the device, asynchronous fetch), and the
-            # reference on the CPU through ALL the days from the cold start: N-1, N, N+1, N+2
-            chk = dayseq.run(ring[:2], state_n, 2, 0)
-            parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
-                                 outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
-                                 final_fetched=chk["final"])
-            parity["pipeline"] = ("the timed pass's pipeline (plan + clone, forcing staged from page-locked memory, state handed "
-                                  "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
-        except Exception as e:
-            parity = {"error": repr(e)}
-    dayseq.close()
-    # ---- the same sequence in TOLERANCE arithmetic (trmc_plan_options.arithmetic; never the headline) -----------------------
-    tolerance = None
-    if not use_dist and not a.no_tolerance and a.precision == 32:
-        try:
-            rt = make_router(hint, True, qlat_a, state_n, options={"arithmetic": "tolerance"})
-            with DaySequence(rt, a.nsteps, a.qts) as ts:
-                ts.run(ring[:2], state_n, 2, 0)
-                tsteps = max(2, min(a.steps, 6))
-                s3 = ts.run(ring, state_n, tsteps, 1)
-            per = s3["el"] / tsteps
-            tolerance = {"value": nseg * a.nsteps / per, "unit": "segment-timesteps/s", "ms_per_step": per * 1e3, "steps": tsteps,
-                         "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / per / 1e9 / HBM_PEAK_GBS,
-                         "outlet_hydrographs_rel_max_vs_exact": None,
-                         "what": "the headline's pipeline and days on a plan created with TRMC_ARITH_TOLERANCE (hardware log2 / exp2 power, "
-                                 "reciprocal-multiply division): not bit-comparable; stated tolerance and its test: include/trmc.h, "
-                                 "tests/test_gpu_tolerance.py, profiles/r05_tolerance_report.json"}
-            rt.close()
-        except Exception as e:
-            tolerance = {"error": repr(e)}
     router.upload(a.nsteps, qlat_b, None if use_dist else state_n)   # (the legs below route day N+1 again and again on the one plan)
     resident = timed(router, True, max(1, min(a.steps, 3)), 1)
     value = rate(head)
@@ -716,7 +683,7 @@ def main():
         allr = comm.all_gather_host(np.array([head["ms_main"], float(seg0)], dtype=np.float64))
         per_rank = [{"rank": i, "ms_main": float(t[0]), "segment_steps": int(t[1])} for i, t in enumerate(allr)]
 
-    extra = {"value_tolerance": tolerance, "value_resident": {"value": rate(resident), "unit": "segment-timesteps/s",
+    extra = {"value_tolerance": None, "value_resident": {"value": rate(resident), "unit": "segment-timesteps/s",
                                 "ms_per_step": resident["el"] / resident["steps"] * 1e3, "ms_main": resident["ms_main"],
                                 "what": "the same windows with every result left in HBM (no copy to the host in the clock)"},
              "copied_per_step": f"outlet hydrographs [{len(net['net_sizes'])} x {a.nsteps}] + final state [{nseg} x 3] into page-locked "
@@ -760,6 +727,42 @@ def main():
                                              "ms_per_step": w["el"] / usteps * 1e3, "ms_main": w["ms_main"],
                                              "roofline_frac": frac(w),
                                              "window": "an independent draw of the forcing (no row keeps its magnitude), cold start"}
+    # ---- the same sequence in TOLERANCE arithmetic (trmc_plan_options.arithmetic; never the headline) -----------------------
+    tolerance = None
+    if not use_dist and not a.no_tolerance and a.precision == 32:
+        try:
+            rt = make_router(hint, True, qlat_a, state_n, options={"arithmetic": "tolerance"})
+            with DaySequence(rt, a.nsteps, a.qts) as ts:
+                ts.run(ring[:2], state_n, 2, 0)
+                tsteps = max(2, min(a.steps, 6))
+                s3 = ts.run(ring, state_n, tsteps, 1)
+            per = s3["el"] / tsteps
+            tolerance = {"value": nseg * a.nsteps / per, "unit": "segment-timesteps/s", "ms_per_step": per * 1e3, "steps": tsteps,
+                         "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / per / 1e9 / HBM_PEAK_GBS,
+                         "outlet_hydrographs_rel_max_vs_exact": None,
+                         "what": "the headline's pipeline and days on a plan created with TRMC_ARITH_TOLERANCE (hardware log2 / exp2 power, "
+                                 "reciprocal-multiply division): not bit-comparable; stated tolerance and its test: include/trmc.h, "
+                                 "tests/test_gpu_tolerance.py, profiles/r05_tolerance_report.json"}
+            rt.close()
+        except Exception as e:
+            tolerance = {"error": repr(e)}
+    extra["value_tolerance"] = tolerance
+    # ---- the checker, LAST of the legs on this router (it runs OpenMP in this process and pins large host arrays: the copy
+    # legs above are timed before it) ------------------------------------------------------------------------------------
+    if rank == 0 and not a.no_parity_full and a.precision == 32 and not use_dist:
+        try:      # against the reference on the CPU (checker use, outside the clock)
+            # the timed pipeline once more, untimed, over the first two days of the ring (days N+1 and N+2 from the state
+            # after day N: plan and clone, staged forcing, state handed over on the device, asynchronous fetch), and the
+            # reference on the CPU through ALL the days from the cold start: N-1, N, N+1, N+2
+            chk = dayseq.run(ring[:2], state_n, 2, 0)
+            parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
+                                 outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
+                                 final_fetched=chk["final"])
+            parity["pipeline"] = ("the timed pass's pipeline (plan + clone, forcing staged from page-locked memory, state handed "
+                                  "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
+        except Exception as e:
+            parity = {"error": repr(e)}
+    dayseq.close()
     router.close()
 
     full = None
