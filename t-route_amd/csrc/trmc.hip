@@ -463,7 +463,6 @@ template <class T> struct StepArgs {
     // k_mc_tile: non-null = the threads of a block take the block's rows by descending cost class (see the kernel's prologue):
     // the class of every row at the last step it was routed in a tile, min(iterations, 3) + 4 if over bank
     uint8_t *cls_last;
-    uint8_t *cls_tail; // k_mc_step<SHORT>: non-null = the same for the narrow tail, once per step (the class of the step before)
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -509,17 +508,10 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     m.sane = a.sane;
 
     {
-        int32_t s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
-        if (SHORT && !LAG) {
-            // the narrow tail of a short-timestep window on a plan whose rows are NOT ordered by cost (no hint, or a hint the
-            // forcing has left behind): the block's rows dealt to its threads by the class each showed on the step before, as
-            // k_mc_tile does once per K steps -- here once per step: some fifty instructions and four barriers against a
-            // wavefront that would otherwise run the iterations of its costliest lane (trmc_plan_options.tail_partition)
-            if (a.cls_tail) {
-                const int32_t key = s < s_end ? 7 - min((int32_t)a.cls_tail[s], 7) : 8;
-                s = s_begin + (int32_t)blockIdx.x * kStepBlock + block_partition_by_class<kStepBlock>(key);
-            }
-        }
+        const int32_t s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
+        // (the block's rows dealt to its threads by the class of the step before, as k_mc_tile does once per K steps, was
+        // built and measured here in round 5 -- some fifty instructions and four barriers per step: untuned plan 19.39 ms per
+        // day against 19.44 without, tuned plan 16.15 against 16.09, tolerance arithmetic 13.5 against 12.4 -- and removed)
         if (s >= s_end) return;
         const int32_t t = SHORT ? (LAG ? diag - a.lag[s] : diag) : diag - a.level[s];
         if (t < 1 || t > a.nsteps) return;
@@ -604,7 +596,6 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                 a.d_tm[row_c + s] = H;
                 a.res_inflow[(size_t)ri * (size_t)a.nsteps + (size_t)(t - 1)] = f.quc;
                 if (t == a.nsteps) a.it_prev[s] = 0;
-                if (SHORT && !LAG && a.cls_tail) a.cls_tail[s] = 0;
                 return;
             }
         }
@@ -644,7 +635,6 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // (only trmc_download_iterations reads it, after the window: one byte-masked store per row and step would be
         // 3 % of the launch)
         if (t == a.nsteps) a.it_prev[su] = (uint8_t)min(r.iters, 255);
-        if (SHORT && !LAG && a.cls_tail) a.cls_tail[su] = (uint8_t)(min(r.iters, 3) + (r.over ? 4 : 0));
         // cost of the step for the plan's cost hint: the iteration class, plus 4 where the compound-channel branch ran
         // (a wavefront pays that branch -- two more divisions, one more power per evaluation -- as soon as one lane takes it)
         if (a.it_sum) a.it_sum[su] = (uint16_t)min(65535, (int)a.it_sum[su] + min(r.iters, 3) + (r.over ? 4 : 0));
@@ -2096,7 +2086,6 @@ struct trmc_plan {
         bool flow_overlap = false;
         int32_t flow_lean = 0;
         bool flow_debug = false;
-        int32_t tail_partition = 0;         // > 0 on, < 0 off, 0: on for a plan without a cost hint
     } opt;
     trmc_stats stats{};
     RouteRun run;
@@ -2121,7 +2110,6 @@ struct trmc_plan {
                                          // window's final state gathered by an upload with q0 = NULL / trmc_stage_forcing): valid
                                          // until a window consumes it, whatever routed_nsteps says in the meantime
     DevBuf cls_last;                     // the cost class every wide row showed at the end of its last tile (k_mc_tile's in-block partition)
-    DevBuf cls_tail;                     // ... and every other row on its last step (k_mc_step's, plans without a cost order)
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
     std::vector<int32_t> rowset_lag;
@@ -2237,7 +2225,6 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.row_of_pos = (const int32_t *)pl->row_of_pos.p;
     a.out_vec = sizeof(T) == 4 && nsteps % 4 == 0 && pl->run.wide_k % 4 == 0;
     a.cls_last = nullptr; // (route_advance_t switches the in-block partition on for its wide tiles)
-    a.cls_tail = nullptr; // (... and, on plans without a cost order, for the tail's launches)
     return a;
 }
 
@@ -2484,14 +2471,6 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     const int32_t nsteps = r.nsteps, t0 = r.t_done;
     StepArgs<T> a = step_args<T>(pl, nsteps, r.qts);
     hipStream_t st = pl->stream;
-    // the one-step launches of a short-timestep window deal their block's rows out by cost class themselves (k_mc_step's
-    // prologue) where the plan's order does not: no cost hint (trmc_plan_options.tail_partition: > 0 always, < 0 never)
-    if (r.short_ts && pl->maxlag == 0 && (pl->opt.tail_partition > 0 || (pl->opt.tail_partition == 0 && !pl->hinted))) {
-        const bool fresh = pl->cls_tail.bytes < (size_t)pl->nseg_pad;
-        if (int rc = pl->cls_tail.ensure((size_t)pl->nseg_pad)) return rc;
-        if (fresh) HIP_TRY(hipMemsetAsync(pl->cls_tail.p, 0, (size_t)pl->nseg_pad, st)); // (no history yet: one class)
-        a.cls_tail = (uint8_t *)pl->cls_tail.p;
-    }
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
         if (r.short_ts && r.wide > 0) {
@@ -3449,7 +3428,6 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         po.flow_overlap = o.flow_overlap != 0;
         po.flow_lean = o.flow_lean;
         po.flow_debug = o.flow_debug != 0;
-        po.tail_partition = o.tail_partition;
     }
     const bool tiers = (flags & TRMC_PLAN_SHORT_TS) != 0;
     std::string err;
@@ -3588,7 +3566,7 @@ void trmc_plan_destroy(trmc_plan *pl)
             for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
                               &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos, &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos,
                               &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch,
-                              &pl->gathered, &pl->cls_last, &pl->cls_tail})
+                              &pl->gathered, &pl->cls_last})
                 b->release();
         }
         pl->zombie = true;
@@ -3606,7 +3584,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last, &pl->cls_tail})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);
