@@ -2335,7 +2335,7 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     HIP_TRY(hipEventRecord(pl->ev[0], st));
     // Sequence mode (trmc_plan_options.sequence_mode): the window's set-up (forcing transpose, initial state, boundary rows)
     // goes to the TILE stream instead of the plan's own.  For one plan it is all the same; for two plans that take turns on a device (two ensemble
-    // members, bench.py's `two_members`) it is what lets the tiles of one member's next window start behind the other
+    // members) it is what lets the tiles of one member's next window start behind the other
     // member's tiles while that member's tail is still running: with one hardware queue per stream priority the two plans'
     // high-priority streams share a queue, in order of submission, and a set-up queued there would sit behind the other
     // member's 288 tail launches -- and the tiles behind the set-up.

@@ -295,17 +295,14 @@ def test_random_forests_bit_identical(nseg, short, engine, monkeypatch):
     assert_bit_identical(got, want, f"forest n={nseg} short={short}")
 
 
-@pytest.mark.parametrize("place", ["tickets", "queues", "queues+simd"])
+@pytest.mark.parametrize("place", ["lean", "staged"])
 def test_flow_engine_block_placement_changes_nothing(place, monkeypatch):
     """Lean launches of the dataflow engine deal their blocks to the compute units by cost (per-unit queues, row groups
-    matched with SIMDs; trmc.hip lean_pick_block / flow_place_blocks).  Block tickets, queues alone and the default give
-    the same bits -- also with far fewer blocks than units (every workgroup but a few takes from a queue not its own) and
-    with a cost hint that makes the queues uneven."""
+    matched with SIMDs; trmc.hip lean_pick_block / flow_place_blocks); the staged form hands its blocks out by ticket
+    (trmc_plan_options.flow_lean < 0).  The same bits either way -- also with far fewer blocks than units (every workgroup
+    but a few takes from a queue not its own) and with a cost hint that makes the queues uneven."""
     set_engine(monkeypatch, "flow")
-    if place == "tickets":
-        monkeypatch.setenv("TRMC_FLOW_PLACE", "0")
-    elif place == "queues":
-        monkeypatch.setenv("TRMC_FLOW_NOPERM", "1")
+    monkeypatch.setenv("TRMC_FLOW_LEAN", "1" if place == "lean" else "0")
     for nseg in (700, 40000):
         rng = np.random.default_rng(77 + nseg)
         to = H.random_network(rng, nseg)

@@ -336,7 +336,7 @@ def test_rccl_communicator_single_rank_and_device_plumbing():
 
 
 def test_two_plans_taking_turns_on_the_device_give_each_its_own_window(monkeypatch):
-    """TRMC_SETUP_ASIDE=1 (bench.py's two_members): a window's set-up goes to the tile stream and its end is queued with its
+    """TRMC_SETUP_ASIDE=1 (sequence mode, trmc_plan_options.sequence_mode): a window's set-up goes to the tile stream and its end is queued with its
     last launch, so that two plans of the level engine can take turns on one device -- one's window queued while the other's
     is running, in the shared hardware queues -- without one waiting for the other's tail.  Each plan must come out with
     exactly what it routes alone, whatever the interleaving."""

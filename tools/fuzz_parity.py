@@ -107,7 +107,7 @@ def main():
             fin = np.isfinite(want).all(axis=(1, 2))
             # (label, engine, settings for the run): the level engine's one-step launches, the dataflow engine, and -- short
             # timesteps only -- the wide levels K steps per launch (k_mc_tile; on the cost-ordered plan with the rows below
-            # them sorted by cost across levels and k_tile_perm dealing rows to threads by class) and a
+            # them sorted by cost across levels and the tile kernel dealing its rows to threads by class) and a
             # second tier of tiles below them, both with thresholds small enough for these networks to take them
             variants = [("levels", "levels", {"TRMC_WIDE_MIN_ROWS": "0"}), ("flow", "flow", {})]
             if short:
