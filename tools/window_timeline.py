@@ -66,3 +66,16 @@ if "k_mc_tile" in by and "k_mc_step" in by:
     gaps = [max(0, tiles[i + 1][0] - tiles[i][1]) / 1e3 for i in range(len(tiles) - 1)]
     print("    gap behind each wide tile, us: " + " ".join(f"{g:.0f}" for g in gaps))
     print("    duration of each wide tile, us: " + " ".join(f"{(b - a) / 1e3:.0f}" for a, b, _, _ in tiles))
+    # the tail's chain: gaps between its consecutive launches (launch latency, or a wait for a tile), and where it stands when
+    # the last tile ends
+    tg = [(k[i + 1][0] - k[i][1]) / 1e3 for i in range(len(k) - 1)]
+    srt = sorted(tg)
+    print(f"    gaps between consecutive tail launches, us: median {srt[len(srt) // 2]:.1f}  p10 {srt[len(srt) // 10]:.1f}  p90 {srt[9 * len(srt) // 10]:.1f}"
+          f"  sum {sum(tg) / 1e3:.3f} ms; the {sum(1 for g in tg if g > 3 * srt[len(srt) // 2])} above three medians sum to "
+          f"{sum(g for g in tg if g > 3 * srt[len(srt) // 2]) / 1e3:.3f} ms")
+    last_tile_end = tiles[-1][1]
+    behind = sum(1 for a, b, _, _ in k if a >= last_tile_end)
+    alone = [(b - a) / 1e3 for a, b, _, _ in k if a >= last_tile_end]
+    ag = [tg[i] for i in range(len(tg)) if k[i][1] >= last_tile_end]
+    print(f"    tail launches that start after the last tile has ended: {behind} (mean {sum(alone) / max(len(alone), 1):.1f} us each, gaps between them "
+          f"mean {sum(ag) / max(len(ag), 1):.1f} us); the tail ends {(k[-1][1] - last_tile_end) / 1e6:.3f} ms after the last tile")
