@@ -40,7 +40,8 @@ Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
   forcing_persistence   the same pipeline with days whose rows keep their magnitude with probability 0.5 / 0.0
   parity_full       EVERY segment against the reference Fortran on the CPU (the pipeline re-run over days N+1, N+2)
   parity_mode       the whole flowveldepth array copied to the host inside the timed region
-  hourly_output     every qts-th step of it (what the reference's writers keep), decimated on the device, copied inside the timed region
+  hourly_output     every qts-th step of it (what the reference's writers keep), decimated on the device, copied inside the timed region;
+                    in_sequence: the same product fetched beside the next day in the pipeline
   tuned_window_warm / cold_start / independent_forcing_cold   the tuned plan on the very window it was tuned on, on a
                     cold start, on an unrelated day
   full_ts           the same workload without the short-timestep assumption (dataflow engine)
@@ -606,7 +607,11 @@ def main():
     assert np.array_equal(ring[0], qlat_b) or a.persistence is not None
     t_days = time.perf_counter() - t0
     persist = None
-    dayseq = DaySequence(router, a.nsteps, a.qts, nchunks=a.chunks)
+    # (diagnosis only, with --headline-only: TRMC_BENCH_OUTPUT_STRIDE=n times / traces the pipeline with the decimated result
+    # among each day's products -- the `hourly_output.in_sequence` leg -- in place of the headline's)
+    ostride = (int(os.environ.get("TRMC_BENCH_OUTPUT_STRIDE", "0")) or None) if a.headline_only else None
+    dayseq = DaySequence(router, a.nsteps, a.qts, nchunks=a.chunks, output_stride=ostride,
+                         timeline=bool(os.environ.get("TRMC_BENCH_DEBUG")))
     if use_dist:
         local_ring = dayseq.prepare_days(ring)          # (this rank's rows of every day, page-locked: outside the clock)
         seq = dayseq.run(local_ring, state_n, a.steps, a.warmup, prepared=True)
@@ -645,6 +650,9 @@ def main():
                 day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day, persistence=a.persistence)
                 ring[i][...] = day
                 prev_day = day
+    if dayseq.timeline:
+        print("[sequence] host timeline (ms, call returned, day): " + " ".join(f"{t}:{k}:{w}" for t, k, w in dayseq.timeline[-60:]),
+              file=sys.stderr)
     hyd = head["hyd"]
     if hyd is None:                                 # (a rank other than 0 of a multi-GPU job does not fetch the outlet block)
         hyd = np.zeros((0, a.nsteps), np.float32)
@@ -654,7 +662,7 @@ def main():
             json_out.write(json.dumps({"metric": "segment-timesteps/sec, CONUS NHD 2.7M-seg MC", "value": rate(head),
                                        "unit": "segment-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                                        "ms_per_step": head["el"] / a.steps * 1e3, "ms_main": head["ms_main"],
-                                       "headline_only": True, "day_ms": seq["day_ms"]}) + "\n")
+                                       "headline_only": True, "output_stride": ostride, "day_ms": seq["day_ms"]}) + "\n")
             json_out.flush()
         dayseq.close()
         router.close()
@@ -710,6 +718,29 @@ def main():
                                       "copied": f"flowveldepth at every {a.qts}th step [{nseg} x {a.nsteps // a.qts} x 3] "
                                                 f"({nseg * (a.nsteps // a.qts) * 12 / 1e9:.2f} GB), decimated on the device, into a "
                                                 "page-locked array from the library's pool, inside the timed region"}
+            # ... and the same product inside the PIPELINE (DaySequence(output_stride=qts): decimated on the copy stream, copied
+            # beside the next day -- trmc_fetch_begin_fvd): the period of a day that also hands every row's hourly (q, v, d) over
+            try:
+                dayseq.output_stride = a.qts
+                dayseq.run(ring[:2], state_n, 2, 0)           # (untimed: the page-locked rings of both plans are made here)
+                hsteps = max(2, min(a.steps, 6))
+                hs = dayseq.run(ring, state_n, hsteps, 1)
+                per = hs["el"] / hsteps
+                rows_o = router.my_out0_global
+                extra["hourly_output"]["in_sequence"] = {
+                    "value": nseg * a.nsteps / per, "ms_per_step": per * 1e3, "steps": hsteps,
+                    "outlet_rows_equal_the_fetched_hydrographs": bool(np.array_equal(
+                        hs["fvd"][rows_o, :, 0].view(np.uint32), hs["hyd"][:, a.qts - 1::a.qts].view(np.uint32))),
+                    "what": "the headline's pipeline with every row's (q, v, d) at every qts-th step among each day's products, "
+                            "decimated on the device and copied beside the next day"}
+                del hs
+            except Exception as e:
+                extra["hourly_output"]["in_sequence"] = {"error": repr(e)}
+            finally:
+                dayseq.output_stride = None
+                for pl_ in dayseq.plans:
+                    pl_._fetch_ring = None
+                _tl.pinned_pool_clear()
         # the window the plan was tuned on (day N, warm), a cold start (round 1's configuration), and an unrelated day
         spin_up(router, False)
         router.upload(a.nsteps, qlat_a, None)

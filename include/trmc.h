@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 16
+#define TRMC_ABI_VERSION 17
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -144,7 +144,7 @@ enum { TRMC_ENGINE_AUTO = 0, TRMC_ENGINE_LEVELS = 1, TRMC_ENGINE_FLOW = 2, TRMC_
 int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                         const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
                         int precision, int device, int flags, trmc_plan **out);
-/* The same with OPTIONS (ABI 16): everything that used to be an environment variable read inside the library is a
+/* The same with OPTIONS (since ABI 16): everything that used to be an environment variable read inside the library is a
  * field here, read ONCE when the plan is created (a clone inherits them).  A NULL pointer or a zero-filled struct means
  * the defaults; struct_size = sizeof(trmc_plan_options) lets the struct grow.  The library itself reads no environment
  * variable that decides how a plan routes (the Python host layer maps its documented TRMC_* test / measurement variables
@@ -432,6 +432,12 @@ int trmc_download_gathered(trmc_plan *plan, void *out);
  * [rows of the set][nsteps] and q0_host [nseg][3] should be page-locked (trmc_host_alloc); either may be NULL.
  * trmc_fetch_wait returns when both arrays are complete; one fetch in flight per plan. */
 int trmc_fetch_begin(trmc_plan *plan, int32_t rowset, void *hyd_host, void *q0_host);
+/* The same, and with it every `stride`-th step of (q, v, d) of EVERY row -- fvd_host [nseg][nsteps / stride][3], page-locked;
+ * the steps stride, 2 stride, ... counted from 1, as trmc_download_fvd_strided -- decimated behind the window's last launch
+ * and copied beside the next window: what the reference's writers take of a window at stream_output_internal_frequency
+ * (nwm_routing/output.py:209-216).  The plan's next window starts its set-up behind the decimation (behind the copy itself
+ * when stride == 1: the whole array then leaves straight from the result buffer).  fvd_host NULL: trmc_fetch_begin. */
+int trmc_fetch_begin_fvd(trmc_plan *plan, int32_t rowset, void *hyd_host, void *q0_host, int stride, void *fvd_host);
 int trmc_fetch_wait(trmc_plan *plan);
 
 int trmc_get_stats(const trmc_plan *plan, trmc_stats *stats);

@@ -2090,8 +2090,11 @@ struct trmc_plan {
     trmc_stats stats{};
     RouteRun run;
     // asynchronous fetch of what a throughput-mode caller consumes (trmc_fetch_begin / trmc_fetch_wait)
-    DevBuf fetch_hyd, fetch_q0;
+    DevBuf fetch_hyd, fetch_q0, fetch_fvd;
+    hipEvent_t ev_dec = nullptr;         // "the copy stream has read `out`" (a fetch of the decimated result): the next window's
+    bool dec_pending = false;            // set-up goes behind it
     hipStream_t cstream = nullptr;       // copy stream: D2H of window k runs beside the kernels of window k + 1
+    hipStream_t hstream = nullptr;       // ... and the one of the other direction: a staged forcing on its way to the device
     hipEvent_t ev_fetch_ready = nullptr, ev_fetch_done = nullptr;
     bool fetch_pending = false;
     // "the last gather queued on the plan's stream after a window has read the planes" -- what a set-up queued on ANOTHER stream
@@ -2350,6 +2353,10 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         if (pl->gather_pending) HIP_TRY(hipStreamWaitEvent(st, pl->ev_gather, 0));
     }
     pl->gather_pending = false;
+    if (pl->dec_pending) { // (trmc_fetch_begin_fvd: the copy stream reads `out`, which this window's kernels overwrite)
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_dec, 0));
+        pl->dec_pending = false;
+    }
     if (pl->forcing_pending) { // (trmc_stage_forcing: the copy into in_qlat runs on the copy stream)
         HIP_TRY(hipStreamWaitEvent(st, pl->ev_forcing, 0));
         pl->forcing_pending = false;
@@ -2848,6 +2855,11 @@ int flow_route_begin(trmc_plan *pl, int nsteps, int qts, int short_ts)
     const int32_t *row_of_pos = (const int32_t *)pl->row_of_pos.p;
     HIP_TRY(hipEventRecord(pl->ev[0], st));
     pl->q0_staged = false; // (consumed by this window)
+    if (pl->dec_pending) { // (trmc_fetch_begin_fvd: the copy stream reads `out`)
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_dec, 0));
+        if (pl->fstream) HIP_TRY(hipStreamWaitEvent(pl->fstream, pl->ev_dec, 0));
+        pl->dec_pending = false;
+    }
     if (pl->forcing_pending) { // (trmc_stage_forcing: the copy into in_qlat runs on the copy stream)
         HIP_TRY(hipStreamWaitEvent(st, pl->ev_forcing, 0));
         pl->forcing_pending = false;
@@ -3563,7 +3575,7 @@ void trmc_plan_destroy(trmc_plan *pl)
             (void)hipSetDevice(pl->device);
             for (DevBuf &b : pl->rowsets) b.release();
             pl->rowsets.clear();
-            for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
+            for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->fetch_fvd, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
                               &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos, &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos,
                               &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch,
                               &pl->gathered, &pl->cls_last})
@@ -3578,7 +3590,10 @@ void trmc_plan_destroy(trmc_plan *pl)
     for (DevBuf &b : pl->rowsets) b.release();
     pl->fetch_hyd.release();
     pl->fetch_q0.release();
+    pl->fetch_fvd.release();
+    if (pl->ev_dec) (void)hipEventDestroy(pl->ev_dec);
     if (pl->cstream) (void)hipStreamDestroy(pl->cstream);
+    if (pl->hstream) (void)hipStreamDestroy(pl->hstream);
     if (pl->ev_fetch_ready) (void)hipEventDestroy(pl->ev_fetch_ready);
     if (pl->ev_fetch_done) (void)hipEventDestroy(pl->ev_fetch_done);
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
@@ -3727,12 +3742,11 @@ int trmc_stage_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq)
     if (pl->nseg > 0 && !pl->state_missing && pl->routed_nsteps >= 0)
         if (int rc = final_state_into(pl, pl->in_q0.p)) return rc;
     pl->q0_staged = !pl->state_missing;
-    // (a forcing staged earlier and not routed yet is still on its way on the same copy stream: the new copy lands behind it)
-    // (behind the set-up of the window in progress, which reads the staging area; the plan's last fetch may still be running
-    // on the same copy stream: in order behind it)
-    if (busy) HIP_TRY(hipStreamWaitEvent(pl->cstream, pl->ev[1], 0));
-    if (pl->nseg > 0) HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, bytes, hipMemcpyHostToDevice, pl->cstream));
-    HIP_TRY(hipEventRecord(pl->ev_forcing, pl->cstream));
+    // (a forcing staged earlier and not routed yet is still on its way on the same stream: the new copy lands behind it)
+    // (behind the set-up of the window in progress, which reads the staging area)
+    if (busy) HIP_TRY(hipStreamWaitEvent(pl->hstream, pl->ev[1], 0));
+    if (pl->nseg > 0) HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, bytes, hipMemcpyHostToDevice, pl->hstream));
+    HIP_TRY(hipEventRecord(pl->ev_forcing, pl->hstream));
     pl->forcing_pending = true;
     pl->qlat_direct = false;
     pl->nq = nq;
@@ -4432,6 +4446,9 @@ static int ensure_copy_stream(trmc_plan *pl)
     int prio_lo = 0, prio_hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIP_TRY(hipStreamCreateWithPriority(&pl->cstream, hipStreamNonBlocking, prio_lo));
+    // (a stream per direction: a day's decimated result on its way out -- 0.8 GB for a CONUS day, most of a window -- does not
+    // hold the next day's forcing back, which the plan's next set-up waits for)
+    HIP_TRY(hipStreamCreateWithPriority(&pl->hstream, hipStreamNonBlocking, prio_lo));
     HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&pl->ev_fetch_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&pl->ev_forcing, hipEventDisableTiming));
@@ -4440,7 +4457,13 @@ static int ensure_copy_stream(trmc_plan *pl)
 
 int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_host)
 {
+    return trmc_fetch_begin_fvd(pl, rowset, hyd_host, q0_host, 0, nullptr);
+}
+
+int trmc_fetch_begin_fvd(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_host, int stride, void *fvd_host)
+{
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (fvd_host && stride < 1) return fail(TRMC_EINVAL, "stride must be >= 1");
     // After a window (trmc_route_end), or -- level engine -- WITH a window that has been queued to its end: the gathers then go
     // right behind the window's last launch on the plan's stream.  That is where a sequence alternating between two plans
     // wants them: queued after the window has been waited for, they would sit in the shared high-priority hardware queue
@@ -4479,6 +4502,28 @@ int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_hos
         if (int rc = pl->fetch_q0.ensure(qb)) return rc;
         if (int rc = final_state_into(pl, pl->fetch_q0.p, in_window ? T_ : -1)) return rc;
     }
+    // Every stride-th step of (q, v, d) of every row: decimated on the plan's stream, which at this point follows everything
+    // that writes `out` (the tiles and the transposes: route_end_queue).  The kernel reads the whole result once (12 bytes of
+    // every 144 at stride 12: every cache line) -- about 2 ms of a CONUS day's period wherever it runs; measured on the sequence
+    // with hourly output (ms per day; 17.3 with neither kernel nor copy): here 19.4; on the transpose stream (low priority) 19.3
+    // with the copy on a stream of its own and 28 with the copy on the copy stream (the in-order hardware queue of that
+    // priority then also holds the next day's transposes and forcing behind the 14-ms copy); without the kernel 17.5.
+    const int32_t nkeep = fvd_host ? T_ / stride : 0;
+    const size_t fb = (size_t)pl->nseg * nkeep * 3 * pl->esz;
+    const void *fvd_src = pl->out.p;
+    if (fb && stride > 1) {
+        if (int rc = pl->fetch_fvd.ensure(fb)) return rc;
+        const int64_t work = pl->nseg * (int64_t)nkeep;
+        if (pl->precision == 32)
+            hipLaunchKernelGGL((k_decimate<float>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const float *)pl->out.p,
+                               (float *)pl->fetch_fvd.p, pl->nseg, T_, stride, nkeep);
+        else
+            hipLaunchKernelGGL((k_decimate<double>), dim3(blocks_for(work)), dim3(kBlock), 0, pl->stream, (const double *)pl->out.p,
+                               (double *)pl->fetch_fvd.p, pl->nseg, T_, stride, nkeep);
+        HIP_TRY(hipGetLastError());
+        if (int rc = note_gather(pl, in_window)) return rc; // (the next window's set-up, wherever it is queued, goes behind it)
+        fvd_src = pl->fetch_fvd.p;
+    }
     HIP_TRY(hipEventRecord(pl->ev_fetch_ready, pl->stream));
     HIP_TRY(hipStreamWaitEvent(pl->cstream, pl->ev_fetch_ready, 0));
     // (Queued WITH the window the copies have a dependence that is still pending, and hipMemcpyAsync device-to-host then keeps
@@ -4493,6 +4538,14 @@ int trmc_fetch_begin(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0_hos
         if (int rc = to_host(hyd_host, pl->fetch_hyd.p, hb)) return rc;
     if (qb)
         if (int rc = to_host(q0_host, pl->fetch_q0.p, qb)) return rc;
+    if (fb) {
+        if (int rc = to_host(fvd_host, fvd_src, fb)) return rc;
+        if (stride == 1) { // (the whole result leaves straight from `out`: the plan's next window starts behind the copy)
+            if (!pl->ev_dec) HIP_TRY(hipEventCreateWithFlags(&pl->ev_dec, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(pl->ev_dec, pl->cstream));
+            pl->dec_pending = true;
+        }
+    }
     HIP_TRY(hipEventRecord(pl->ev_fetch_done, pl->cstream));
     pl->fetch_pending = true;
     return 0;
@@ -4505,6 +4558,7 @@ int trmc_fetch_wait(trmc_plan *pl)
     if (int rc = use_device(pl)) return rc;
     pl->fetch_pending = false;
     HIP_TRY(hipEventSynchronize(pl->ev_fetch_done));
+
     return 0;
 }
 

@@ -608,14 +608,15 @@ class ShardedRouter:
         self._fetching = ("single",)
         return prev
 
-    def fetch_begin(self, hyd_dev, want_hyd=True):
+    def fetch_begin(self, hyd_dev, want_hyd=True, output_stride=None):
         """Multi-rank form, after route_on_device(): this rank's final state (every plan that holds one) and, if wanted,
-        the gathered outlet block start their way to the host."""
+        the gathered outlet block start their way to the host; with output_stride = n also every n-th step of (q, v, d) of
+        this rank's rows (fetch_wait() then returns a third item: one block per plan that holds state)."""
         X = self._X
         if not hasattr(self, "_cs"):
             self._cs = X.stream_create(self._dev)
         for plan in self._state_plans:
-            plan.fetch_begin(None, True)
+            plan.fetch_begin(None, True, output_stride)
         hyd = None
         if want_hyd:                       # (a ring of three page-locked blocks, made once: no allocation in a steady pipeline)
             ring = getattr(self, "_hyd_ring", None)
@@ -625,7 +626,7 @@ class ShardedRouter:
                 self._hyd_ring = ring
             hyd = hyd_dev.download_async(self._cs, out=ring[0][ring[1] % 3])
             ring[1] += 1
-        self._fetching = ("dist", hyd)
+        self._fetching = ("dist", hyd, output_stride is not None)
 
     def fetch_wait(self):
         f, self._fetching = getattr(self, "_fetching", None), None
@@ -633,9 +634,11 @@ class ShardedRouter:
             return None, None
         if f[0] == "single":
             return self.plan0.fetch_wait()
-        states = [plan.fetch_wait()[1] for plan in self._state_plans]
+        got = [plan.fetch_wait() for plan in self._state_plans]
         self._X.stream_synchronize(self._dev, self._cs)
-        return f[1], states
+        if f[2]:
+            return f[1], [g[1] for g in got], [g[2] for g in got]
+        return f[1], [g[1] for g in got]
 
     def route(self, qts_subdivisions, assume_short_ts, all_gather=None):
         """One routing window.  ``all_gather(array) -> list of arrays (one per rank)``.

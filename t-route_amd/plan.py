@@ -383,24 +383,37 @@ class RoutingPlan:
             _lib.check(_lib.lib().trmc_download_gathered(self._h, _lib.ptr(out)))
         return out
 
-    def fetch_begin(self, rowset, want_state=True):
+    def fetch_begin(self, rowset, want_state=True, output_stride=None):
         """Start the asynchronous fetch of a window's products (include/trmc.h trmc_fetch_begin): the hydrographs of a
         registered row set and / or the final state, into page-locked arrays; returns at once.  ``fetch_wait()`` hands the
         arrays over when the copy stream is through -- typically after the NEXT window has been queued.  The arrays come
         from a ring of three sets the plan keeps (all made at the first call: no allocation in a steady pipeline), so what
-        ``fetch_wait()`` returned stays valid until the third fetch_begin() after it."""
+        ``fetch_wait()`` returned stays valid until the third fetch_begin() after it.
+
+        output_stride = n: also every n-th step of (q, v, d) of every row, [nseg, nsteps // n, 3], decimated on the device
+        and copied beside the next window (trmc_fetch_begin_fvd); ``fetch_wait()`` then returns three arrays."""
         nrows = 0 if rowset is None else self._rowset_n[rowset]
-        shape = ((nrows, self._nsteps) if rowset is not None else None, (self.nseg, 3) if want_state else None)
+        stride = None if output_stride is None else int(output_stride)
+        if stride is not None and stride < 1:
+            raise ValueError("output_stride must be >= 1")
+        shape = ((nrows, self._nsteps) if rowset is not None else None, (self.nseg, 3) if want_state else None,
+                 None if stride is None else (self.nseg, self._nsteps // stride, 3))
         ring = getattr(self, "_fetch_ring", None)
         if ring is None or ring["shape"] != shape:
             ring = {"shape": shape, "k": 0,
                     "sets": [tuple(None if sh is None else _lib.result_empty(sh, self.dtype, always_pinned=True) for sh in shape)
                              for _ in range(3)]}
             self._fetch_ring = ring
-        hyd, q0 = ring["sets"][ring["k"] % 3]
+        hyd, q0, fvd = ring["sets"][ring["k"] % 3]
         ring["k"] += 1
-        _lib.check(_lib.lib().trmc_fetch_begin(self._h, -1 if rowset is None else int(rowset), _lib.ptr(hyd), _lib.ptr(q0)))
-        self._fetch = (hyd, q0)
+        rs = -1 if rowset is None else int(rowset)
+        if stride is None:
+            _lib.check(_lib.lib().trmc_fetch_begin(self._h, rs, _lib.ptr(hyd), _lib.ptr(q0)))
+            self._fetch = (hyd, q0)
+        else:
+            _lib.check(_lib.lib().trmc_fetch_begin_fvd(self._h, rs, _lib.ptr(hyd), _lib.ptr(q0), stride,
+                                                       _lib.ptr(fvd) if fvd.size else None))
+            self._fetch = (hyd, q0, fvd)
 
     def fetch_wait(self):
         _lib.check(_lib.lib().trmc_fetch_wait(self._h))

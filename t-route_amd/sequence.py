@@ -41,9 +41,11 @@ class DaySequence:
     """``DaySequence(router, nsteps, qts_subdivisions)`` then ``run(days, state0, steps, warmup)``.
 
     router : a ``ShardedRouter`` (one rank of a job of any size; ``enable_device_exchange`` done when world > 1)
+    output_stride : None, or n -- every n-th step of every row's (q, v, d) with each day's products
     """
 
-    def __init__(self, router, nsteps, qts_subdivisions, assume_short_ts=True, nchunks=None, hydrographs_on_every_rank=False):
+    def __init__(self, router, nsteps, qts_subdivisions, assume_short_ts=True, nchunks=None, hydrographs_on_every_rank=False,
+                 output_stride=None, timeline=False):
         if not assume_short_ts:
             raise ValueError("a pipelined sequence of windows needs assume_short_ts (a day's leading levels run ahead of the "
                              "day before's narrow ones only there); route general-mode windows one by one")
@@ -51,8 +53,13 @@ class DaySequence:
         self.nsteps, self.qts, self.nchunks = int(nsteps), int(qts_subdivisions), nchunks
         self.world = router.world
         self._hyd_everywhere = bool(hydrographs_on_every_rank)   # (default: the gathered outlet block goes to rank 0's host only)
+        # every output_stride-th step of (q, v, d) of every row as a further product of each day -- what the reference's
+        # writers take at stream_output_internal_frequency (nwm_routing/output.py:209-216) -- decimated on the device and
+        # copied beside the next day (trmc_fetch_begin_fvd); on_day then gets a fourth argument
+        self.output_stride = None if output_stride is None else int(output_stride)
         self._clone = None
         self._local_days = None
+        self.timeline = [] if timeline else None            # (diagnosis: host time, in ms, at which each call of a day returned)
         if self.world == 1:
             p = router.plan0
             if p.engine != "levels":
@@ -89,8 +96,10 @@ class DaySequence:
         """Route ``warmup + steps`` consecutive days; day w takes ``days[w % len(days)]`` (global rows; a ring that is used in
         turn -- the state evolves on, no two windows are the same work) and starts from day w - 1's final state (day 0 from
         ``state0`` [nseg, 3], or from the router's resident state if None).  The clock covers the ``steps`` days after the
-        warm-up ones, everything a day needs inside it.  ``on_day(w, hydrographs, final_state)`` is called as each day's
-        products arrive on the host (arrays of a ring of three: copy what is kept).
+        warm-up ones, everything a day needs inside it.  ``on_day(w, hydrographs, final_state)`` -- with ``output_stride``
+        ``on_day(w, hydrographs, final_state, fvd)``, fvd [rows, nsteps // output_stride, 3] (one GPU: all rows in the
+        caller's order; a rank: a list with the block of its ``sequence_rows()``) -- is called as each day's products arrive
+        on the host (arrays of a ring of three: copy what is kept).
 
         Returns {"el": wall seconds of the timed days, "ms_main": [per-day device ms], "day_ms": [host-observed periods],
         "hyd", "final": the last day's products, "days_routed", "last_plan"}."""
@@ -106,19 +115,39 @@ class DaySequence:
         nd, total = len(days), warmup + steps
         dev = plans[0].info()["device"]
 
+        tl, tl0 = self.timeline, time.perf_counter()
+
+        def mark(what, w):
+            if tl is not None:
+                tl.append((round((time.perf_counter() - tl0) * 1e3, 2), what, w))
+
         def queue(p):
             p.route_begin(nsteps, qts, True)
             p.route_advance(nsteps)
 
         def after_window(i, w):
             """behind day w's window on plan i: its products to the host, then the forcing of the plan's next day (w + 2)"""
-            plans[i].fetch_begin(rs[i], True)
+            plans[i].fetch_begin(rs[i], True, self.output_stride)
+            mark("fetch_begin", w)
             if w + 2 < total:
                 plans[i].stage_forcing(nsteps, days[(w + 2) % nd])
+                mark("stage_forcing", w + 2)
         plans[0].upload_forcing(nsteps, days[0], state0)        # the first day the ordinary way (synchronous)
         if total > 1:
             plans[1].stage_forcing(nsteps, days[1 % nd])
-        ms_main, ends, got = [], [], (None, None)
+        ms_main, ends, got = [], [], (None, None, None)
+
+        def deliver(d):
+            nonlocal got
+            got = plans[d % 2].fetch_wait()                     # day d's products are on the host
+            mark("fetch_wait", d)
+            if on_day is not None:
+                on_day(d, *got)
+        # Products are handed over a day after their window -- or TWO days after it when every row's decimated series is
+        # among them: that block (0.8 GB of a CONUS day) takes most of the next window to cross PCIe, and a host that waited
+        # for it before queueing the day after would let the device run out of queued work once a day.  (A plan has one fetch
+        # in flight: day w - 2's is waited for right before day w's begins, on the same plan.)
+        lag = 2 if self.output_stride else 1
         t0 = time.perf_counter() if warmup == 0 else None       # (no warm-up day: the clock starts with day 0's window)
         queue(plans[0])
         after_window(0, 0)
@@ -126,22 +155,29 @@ class DaySequence:
             cur, prev = plans[w % 2], plans[(w - 1) % 2]
             if w < total:
                 cur.chain_from(prev)                            # day w starts where day w - 1 ends: handed over in HBM
+                mark("chained", w)
                 queue(cur)
+                mark("queued", w)
+                if lag == 2 and w >= 2:
+                    deliver(w - 2)
                 after_window(w % 2, w)
             st = prev.route_end()                               # day w - 1 is through
+            mark("route_end", w - 1)
             ends.append(time.perf_counter())
             if w - 1 >= warmup:
                 ms_main.append(st["ms_main"])
-            got = prev.fetch_wait()                             # ... and its products are on the host
-            if on_day is not None:
-                on_day(w - 1, got[0], got[1])
+            if lag == 1:
+                deliver(w - 1)
             if w == warmup and warmup > 0:                      # the clock starts when the last warm-up day is through
                 t0 = time.perf_counter()
+        if lag == 2:
+            for d in range(max(0, total - 2), total):
+                deliver(d)
         X.device_synchronize(dev)
         el = time.perf_counter() - t0
         day_ms = [round((b - a) * 1e3, 2) for a, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
-        return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total,
-                "last_plan": plans[(total - 1) % 2], "day_ms": day_ms}
+        return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "fvd": got[2] if len(got) > 2 else None,
+                "days_routed": total, "last_plan": plans[(total - 1) % 2], "day_ms": day_ms}
 
     # ---- one rank of a multi-GPU job: the merged plan, day after day ----------------------------------------------------------
     def _run_rank(self, days, state0, steps, warmup, on_day):
@@ -168,17 +204,17 @@ class DaySequence:
             if w >= 1:
                 got = r.fetch_wait()                                # day w - 1's products (copied beside day w)
                 if on_day is not None:
-                    on_day(w - 1, got[0], got[1])
-            r.fetch_begin(hyd, want_hyd=(r.rank == 0 or self._hyd_everywhere))
+                    on_day(w - 1, *got)
+            r.fetch_begin(hyd, want_hyd=(r.rank == 0 or self._hyd_everywhere), output_stride=self.output_stride)
             if w + 1 == warmup:                                     # the clock starts when the last warm-up day is through
                 sync()
                 t0 = time.perf_counter()
         got = r.fetch_wait()
         if on_day is not None:
-            on_day(total - 1, got[0], got[1])
+            on_day(total - 1, *got)
         sync()
         el = time.perf_counter() - t0
         el = float(comm.all_reduce_max_host(np.array([el], dtype=np.float64))[0])
         day_ms = [round((b - a) * 1e3, 2) for a, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
-        return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "days_routed": total, "last_plan": r._state_plans[0],
-                "day_ms": day_ms}
+        return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "fvd": got[2] if len(got) > 2 else None,
+                "days_routed": total, "last_plan": r._state_plans[0], "day_ms": day_ms}

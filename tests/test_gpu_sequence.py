@@ -23,18 +23,21 @@ def days_of(net, n, seed=3):
     return [rng.uniform(0, 0.6, net["qlat"].shape).astype(np.float32) for _ in range(n)]
 
 
-def reference_days(net, days, q0, nsteps, qts):
-    """every day on ONE plain router, the state through the host: (outlet rows, [hydrographs per day], [final state per day])"""
+def reference_days(net, days, q0, nsteps, qts, stride=None):
+    """every day on ONE plain router, the state through the host: (outlet rows, [hydrographs per day], [final state per day]
+    [, every stride-th step of every row per day])"""
     r = ShardedRouter(net["to"], net["params"], assume_short_ts=True)
-    hyds, states, state = [], [], q0
+    hyds, states, fvds, state = [], [], [], q0
     for d in days:
         r.upload(nsteps, d, state)
         rows, hyd = r.route(qts, True)
         state = r.plan0.download_final_state()
         hyds.append(hyd)
         states.append(state)
+        if stride:
+            fvds.append(r.plan0.download_fvd()[:, stride - 1::stride].copy())
     r.close()
-    return rows, hyds, states
+    return (rows, hyds, states, fvds) if stride else (rows, hyds, states)
 
 
 @pytest.mark.parametrize("mid", [False, True])
@@ -88,7 +91,8 @@ def test_a_sequence_of_days_on_two_ranks_equals_the_days_routed_one_by_one(monke
     q0 = np.random.default_rng(2).uniform(0, 1, (nseg, 3)).astype(np.float32)
     days = days_of(net, 3, seed=5)
     seq_days = [days[w % 3] for w in range(ndays)]
-    rows1, want_h, want_s = reference_days(net, seq_days, q0, nsteps, qts)
+    stride = 12 if engine == "levels" else None          # (one of the two variants also asks for the decimated result)
+    rows1, want_h, want_s, *want_f = reference_days(net, seq_days, q0, nsteps, qts, stride)
     kw = {} if engine is None else {"engine": engine, "assume_short_ts": True}
     world = 2
     _serial[0] += 1
@@ -101,9 +105,10 @@ def test_a_sequence_of_days_on_two_ranks_equals_the_days_routed_one_by_one(monke
             r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0, **kw)
             r.enable_device_exchange(comm)
             got = {}
-            seq = DaySequence(r, nsteps, qts)
-            out = seq.run(days, q0, ndays - 1, 1, on_day=lambda w, h, s: got.__setitem__(
-                w, (None if h is None else np.array(h, copy=True), [np.array(x, copy=True) for x in s])))
+            seq = DaySequence(r, nsteps, qts, output_stride=stride)
+            out = seq.run(days, q0, ndays - 1, 1, on_day=lambda w, h, s, *f: got.__setitem__(
+                w, (None if h is None else np.array(h, copy=True), [np.array(x, copy=True) for x in s],
+                    [np.array(x, copy=True) for x in f[0]] if f else None)))
             routed = np.ones(r.sequence_rows().shape[0], bool)          # (not the boundary copies of the cut rows: flow only)
             if r.plan1 is not None:
                 routed[r.rows0.shape[0]:] = ~r.boundary1
@@ -132,3 +137,36 @@ def test_a_sequence_of_days_on_two_ranks_equals_the_days_routed_one_by_one(monke
             assert state.shape == (srows.shape[0], 3)
             assert np.array_equal(state[routed][:, [0, 2]].view(np.uint32), want_s[w][srows[routed]][:, [0, 2]].view(np.uint32)), (rank, w)
             assert np.array_equal(state[:, 0].view(np.uint32), want_s[w][srows][:, 0].view(np.uint32)), (rank, w)
+            if stride:
+                fvd = got[w][2][0]
+                assert fvd.shape == (srows.shape[0], nsteps // stride, 3)
+                assert np.array_equal(fvd[routed].view(np.uint32), want_f[0][w][srows[routed]].view(np.uint32)), (rank, w)
+
+
+def test_a_sequence_with_decimated_output_hands_every_day_the_slices_of_its_result(monkeypatch):
+    """DaySequence(output_stride=n): every n-th step of every row's (q, v, d) arrives with each day's products -- copied
+    beside the NEXT day on the plan's clone -- and equals the slices of the day routed by itself."""
+    monkeypatch.setenv("TRMC_ENGINE", "levels")
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
+    monkeypatch.setenv("TRMC_WIDE_K", "8")
+    net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
+    nseg = net["to"].shape[0]
+    nsteps, qts, ndays, stride = 36, 12, 5, 12
+    q0 = np.random.default_rng(1).uniform(0, 1, (nseg, 3)).astype(np.float32)
+    days = days_of(net, 3)
+    r = ShardedRouter(net["to"], net["params"], assume_short_ts=True)
+    want, state = [], q0
+    for w in range(ndays):
+        r.upload(nsteps, days[w % 3], state)
+        r.route(qts, True)
+        want.append(r.plan0.download_fvd()[:, stride - 1::stride].copy())
+        state = r.plan0.download_final_state()
+    got = {}
+    with DaySequence(r, nsteps, qts, output_stride=stride) as seq:
+        out = seq.run([pinned_like(d) for d in days], q0, ndays - 1, 1,
+                      on_day=lambda w, h, s, f: got.__setitem__(w, f.copy()))
+        assert out["fvd"].shape == (nseg, nsteps // stride, 3)
+    assert sorted(got) == list(range(ndays))
+    for w in range(ndays):
+        assert np.array_equal(got[w].view(np.uint32), want[w].view(np.uint32)), w
+    r.close()

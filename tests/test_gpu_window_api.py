@@ -303,6 +303,46 @@ def test_asynchronous_fetch_equals_the_synchronous_downloads():
         plan.fetch_wait()
 
 
+@pytest.mark.parametrize("engine", [None, "levels"])
+def test_asynchronous_fetch_of_the_decimated_result_equals_slicing(monkeypatch, engine):
+    """trmc_fetch_begin_fvd: every n-th step of (q, v, d) of every row joins the products of a window -- decimated on the copy
+    stream, copied beside the next window, which must not overwrite the result before it has been read (the next window's
+    set-up waits for the decimation).  Both engines, strides that do and do not divide the window, stride 1 (the whole array
+    straight from the result buffer), and the plain fetch in between."""
+    if engine == "levels":
+        monkeypatch.setenv("TRMC_ENGINE", "levels")
+        monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
+        monkeypatch.setenv("TRMC_WIDE_K", "8")
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=6000)
+    nsteps, qts = 48, 12
+    rows = np.array([3, 5999, 17], np.int64)
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as plan:
+        rs = plan.rowset(rows)
+        plan.upload_forcing(nsteps, qlat, q0)
+        want = []
+        for k, stride in enumerate([12, 5, 1, None, 12, 100]):
+            plan.route_device(nsteps, qts, True)
+            full = plan.download_fvd()
+            want.append((stride, plan.gather_flow_rows(rows), plan.download_final_state(),
+                         None if stride is None else full[:, stride - 1::stride][:, :nsteps // stride].copy()))
+            prev = plan.fetch_wait()
+            plan.fetch_begin(rs, True, stride)
+            # the next window is queued while the copy is (possibly) still running: other forcing, warm start
+            plan.upload_forcing(nsteps, qlat * np.float32(1.0 + 0.2 * (k + 1)), None)
+            if k > 0:
+                s0, h0, f0, d0 = want[k - 1]
+                assert len(prev) == (2 if s0 is None else 3)
+                assert np.array_equal(prev[0].view(np.uint32), h0.view(np.uint32))
+                assert np.array_equal(prev[1].view(np.uint32), f0.view(np.uint32))
+                if s0 is not None:
+                    assert prev[2].shape == d0.shape and np.array_equal(prev[2].view(np.uint32), d0.view(np.uint32)), s0
+        plan.route_device(nsteps, qts, True)                 # a window AFTER the last fetch was begun, before it is waited for
+        last = plan.fetch_wait()
+        assert last[2].shape == (6000, 0, 3)
+        with pytest.raises(ValueError, match="output_stride"):
+            plan.fetch_begin(rs, True, 0)
+
+
 def test_rccl_communicator_single_rank_and_device_plumbing():
     """The RCCL transport of the package's communicator (librccl.so by dlopen: ncclGetUniqueId / ncclCommInitRank /
     ncclAllGather through include/trmc.h) at world size 1 -- what one GPU can run of it -- plus the device buffers, streams,

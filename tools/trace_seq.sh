@@ -26,7 +26,7 @@ for t in tabs:
             print("copy table", t, cols, e)
         break
 def short(n):
-    for k in ("k_mc_tile", "k_mc_step", "k_emit", "k_prep_qlat", "k_chain_state", "k_gather_rows", "k_final_state", "k_init_state"):
+    for k in ("k_mc_tile", "k_mc_step", "k_emit", "k_prep_qlat", "k_chain_state", "k_gather_rows", "k_final_state", "k_init_state", "k_decimate"):
         if k in n: return k
     return None
 # the last three windows: find the last three k_prep_qlat launches
