@@ -1,7 +1,8 @@
 """Randomised stress of the sequence pipeline (developer tool, GPU box): the order of bench.py's timed pass -- a plan and its
 clone taking turns, every day's forcing staged two days ahead from page-locked memory (trmc_stage_forcing), the state
 handed over on the device (trmc_plan_chain_from), the products fetched asynchronously with the window
-(trmc_fetch_begin / trmc_fetch_wait) -- against the same days routed one after the other on ONE plan with synchronous
+(trmc_fetch_begin / trmc_fetch_wait; in half of the rounds with every n-th step of every row's (q, v, d) among them,
+trmc_fetch_begin_fvd) -- against the same days routed one after the other on ONE plan with synchronous
 uploads, bit for bit: every day's outlet hydrographs and final state.
 
     python tools/fuzz_sequence.py --seconds 300 [--nseg 200000] [--seed 1]
@@ -63,18 +64,22 @@ def one_round(rng, nseg_max):
            "TRMC_MID_MIN_ROWS": str(int(rng.choice([0, 0, 8, 64]))),      # (a second tier of tiles below the wide levels)
            "TRMC_MID_K": str(int(rng.choice([1, 2, 4]))), "TRMC_MID_LEVELS": str(int(rng.choice([3, 12, 32])))}
     dawdle = float(rng.choice([0.0, 0.0, 0.002, 0.01]))
+    # every stride-th step of every row among each day's products (trmc_fetch_begin_fvd), in half of the rounds
+    stride = int(rng.choice([0, 0, 1, 2, 3, qts, 7]))
+    stride = stride if 0 < stride <= nsteps else None
     hinted = bool(rng.integers(0, 2))
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         hint = None
-        want_h, want_s = [], []
+        want_h, want_s, want_f = [], [], []
         with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=True) as ref:
             for w in range(ndays):
                 ref.upload_forcing(nsteps, days[w], q0 if w == 0 else None)
                 ref.route_device(nsteps, qts, True)
                 want_h.append(ref.gather_flow_rows(outlets))
                 want_s.append(ref.download_final_state())
+                want_f.append(None if stride is None else ref.download_fvd()[:, stride - 1::stride][:, :nsteps // stride].copy())
             if hinted:
                 hint = np.minimum(ref.download_iterations(), 3)
         with RoutingPlan(up_ptr, up_idx, params, assume_short_ts=True, cost_hint=hint) as a:
@@ -90,7 +95,7 @@ def one_round(rng, nseg_max):
             a.route_advance(nsteps)
             if ndays > 1:
                 b.stage_forcing(nsteps, days[1])
-            a.fetch_begin(rs[0], True)
+            a.fetch_begin(rs[0], True, stride)
             if ndays > 2:
                 a.stage_forcing(nsteps, days[2])
             got = []
@@ -101,28 +106,29 @@ def one_round(rng, nseg_max):
                 cur.route_begin(nsteps, qts, True)
                 cur.route_advance(nsteps)
                 nap()
-                cur.fetch_begin(rs[w % 2], True)
+                cur.fetch_begin(rs[w % 2], True, stride)
                 if w + 2 < ndays:
                     cur.stage_forcing(nsteps, days[w + 2])
                 nap()
                 prev.route_end()
-                h, st = prev.fetch_wait()
-                got.append((h.copy(), st.copy()))
+                h, st, *f = prev.fetch_wait()
+                got.append((h.copy(), st.copy(), f[0].copy() if f else None))
             last = plans[(ndays - 1) % 2]
             last.route_end()
-            h, st = last.fetch_wait()
-            got.append((h.copy(), st.copy()))
+            h, st, *f = last.fetch_wait()
+            got.append((h.copy(), st.copy(), f[0].copy() if f else None))
             wide = a.stats().get("wide_levels", 0)
             b.close()
-        bad = [w for w, (h, st) in enumerate(got)
-               if not (np.array_equal(bits(h), bits(want_h[w])) and np.array_equal(bits(st), bits(want_s[w])))]
+        bad = [w for w, (h, st, f) in enumerate(got)
+               if not (np.array_equal(bits(h), bits(want_h[w])) and np.array_equal(bits(st), bits(want_s[w]))
+                       and (stride is None or (f.shape == want_f[w].shape and np.array_equal(bits(f), bits(want_f[w])))))]
     finally:
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    return nseg, ndays, nsteps, qts, wide, hinted, dawdle, bad
+    return nseg, ndays, nsteps, qts, wide, hinted, dawdle, stride, bad
 
 
 def main():
@@ -136,13 +142,13 @@ def main():
     seed = a.seed
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
-        nseg, ndays, nsteps, qts, wide, hinted, dawdle, bad = one_round(rng, a.nseg)
+        nseg, ndays, nsteps, qts, wide, hinted, dawdle, stride, bad = one_round(rng, a.nseg)
         rounds += 1
         days_total += ndays
         if bad:
             bad_rounds += 1
         print(f"seed {seed:4d} nseg {nseg:7d} days {ndays} steps {nsteps:3d} qts {qts:2d} wide levels {wide:2d} hinted {int(hinted)} "
-              f"dawdle {dawdle:.3f}  {'DIFFERENT days ' + str(bad) if bad else 'identical'}", flush=True)
+              f"dawdle {dawdle:.3f} stride {stride}  {'DIFFERENT days ' + str(bad) if bad else 'identical'}", flush=True)
         seed += 1
     print(f"fuzz_sequence: {rounds} rounds, {days_total} days, {bad_rounds} rounds with a day that differs")
     sys.exit(1 if bad_rounds else 0)
