@@ -650,6 +650,9 @@ def main():
                 day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day, persistence=a.persistence)
                 ring[i][...] = day
                 prev_day = day
+    if dayseq.timeline and getattr(dayseq, "device_days", None):
+        print("[sequence] device clock, ms (day, tiles begin, tiles end, tail begins, tail ends): "
+              + " ".join(str(d) for d in dayseq.device_days), file=sys.stderr)
     if dayseq.timeline:
         print("[sequence] host timeline (ms, call returned, day): " + " ".join(f"{t}:{k}:{w}" for t, k, w in dayseq.timeline[-60:]),
               file=sys.stderr)

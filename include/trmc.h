@@ -431,6 +431,13 @@ int trmc_download_gathered(trmc_plan *plan, void *out);
  * window k + 1 (the planes the gathers read are only overwritten by kernels queued after them).  hyd_host
  * [rows of the set][nsteps] and q0_host [nseg][3] should be page-locked (trmc_host_alloc); either may be NULL.
  * trmc_fetch_wait returns when both arrays are complete; one fetch in flight per plan. */
+/* Diagnosis: a timeline of consecutive windows without a profiler attached (one that serialises what overlaps).  host_ring
+ * [nwindows][4] uint64 in page-locked memory (trmc_host_alloc), or NULL to switch it off: window k since the call (level
+ * engine, assume_short_ts, leading levels tiled) leaves in row k % nwindows the device's 100 MHz clock when its tiles
+ * begin, when its last tile has ended, when its tail begins (the plan's stream is past the set-up and the hand-over) and
+ * when its last step launch has ended -- four one-thread launches per window.  Clocks of plans on one device compare. */
+int trmc_plan_set_stamps(trmc_plan *plan, void *host_ring, int32_t nwindows);
+
 int trmc_fetch_begin(trmc_plan *plan, int32_t rowset, void *hyd_host, void *q0_host);
 /* The same, and with it every `stride`-th step of (q, v, d) of EVERY row -- fvd_host [nseg][nsteps / stride][3], page-locked;
  * the steps stride, 2 stride, ... counted from 1, as trmc_download_fvd_strided -- decimated behind the window's last launch

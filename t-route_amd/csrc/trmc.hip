@@ -1929,6 +1929,10 @@ k_flow_boundary(const float *__restrict__ src, unsigned long long *gran, float *
     o[2] = ncomp > 2 ? v[2] : 0.0f;
 }
 
+// trmc_plan_set_stamps: the device's constant-rate clock (100 MHz) at four points of a window, written straight into
+// page-locked host memory -- a timeline of consecutive windows of several plans without a profiler attached
+__global__ void k_stamp(unsigned long long *slot) { *slot = wall_clock64(); }
+
 // Every `stride`-th step of the result, out[row][t][3] -> dec[row][k][3] with t = stride (k + 1) - 1 (0-based): what the
 // reference's writers consume of a window (nwm_routing/output.py:209-216 and :232-240 keep the steps whose END falls on a
 // multiple of dt * qts_subdivisions).  One thread per (row, kept step): a 12-byte triple read at a stride of 12 * stride
@@ -2090,6 +2094,9 @@ struct trmc_plan {
     trmc_stats stats{};
     RouteRun run;
     // asynchronous fetch of what a throughput-mode caller consumes (trmc_fetch_begin / trmc_fetch_wait)
+    unsigned long long *stamps = nullptr; // trmc_plan_set_stamps: [nstamp_windows][4] in page-locked host memory (the caller's)
+    int32_t nstamp_windows = 0;
+    int64_t stamp_seq = -1;               // windows begun since the ring was set, minus one
     DevBuf fetch_hyd, fetch_q0, fetch_fvd;
     hipEvent_t ev_dec = nullptr;         // "the copy stream has read `out`" (a fetch of the decimated result): the next window's
     bool dec_pending = false;            // set-up goes behind it
@@ -2176,6 +2183,13 @@ int note_gather(trmc_plan *pl, bool also_in_window = false)
     HIP_TRY(hipEventRecord(pl->ev_gather, pl->stream));
     pl->gather_pending = true;
     return 0;
+}
+
+// diagnosis: slot `which` (0 tiles begin, 1 tiles end, 2 tail begins, 3 window ends) of the current window's stamps
+inline void stamp(trmc_plan *pl, hipStream_t st, int which)
+{
+    if (!pl->stamps || pl->stamp_seq < 0) return;
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, st, pl->stamps + (size_t)(pl->stamp_seq % pl->nstamp_windows) * 4 + which);
 }
 
 template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
@@ -2382,6 +2396,7 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     r.nsteps = nsteps;
     r.qts = qts;
     r.short_ts = short_ts ? 1 : 0;
+    if (pl->stamps) ++pl->stamp_seq;
     r.boundary_through = tp.nboundary > 0 ? 0 : nsteps;
     if (tp.nboundary > 0 && pl->have_boundary) {
         hipLaunchKernelGGL((k_fill_boundary<T>), dim3(blocks_for(tp.nboundary * (int64_t)nsteps)), dim3(kBlock), 0, st,
@@ -2460,6 +2475,7 @@ template <class T> int route_end_queue(trmc_plan *pl)
     RouteRun &r = pl->run;
     if (r.end_queued) return 0;
     hipStream_t st = pl->stream;
+    stamp(pl, st, 3);
     HIP_TRY(hipEventRecord(pl->ev[2], st));
     if (int rc = emit_tiles_through<T>(pl, r.nsteps)) return rc; // whatever is left (at least the last tile)
     HIP_TRY(hipEventRecord(pl->ev_emit, pl->stream2));
@@ -2514,12 +2530,15 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     if (fresh) HIP_TRY(hipMemsetAsync(pl->cls_last.p, 0, (size_t)pl->nseg_pad, ws)); // (no history yet: one class)
                     at.cls_last = (uint8_t *)pl->cls_last.p;
                 }
+                stamp(pl, ws, 0);
                 HIP_TRY(hipEventRecord(pl->wide_t0[0], ws));
                 for (int32_t j = 0; j < ntile; ++j) {
                     launch_tile<T>(ws, at, w0, w1, j, K, tol);
                     HIP_TRY(hipEventRecord(pl->wide_t1[(size_t)j], ws));
                     ++r.launches;
                 }
+                stamp(pl, ws, 1);
+                stamp(pl, st, 2);
                 r.wide_next = ntile;
                 r.wide_through = -1; // (from here on: the last tile the tail has been told to wait for)
             }
@@ -2622,10 +2641,13 @@ template <class T> int route_end_t(trmc_plan *pl)
 {
     const trmc::Topology &tp = pl->topo;
     RouteRun &r = pl->run;
-    hipStream_t st = pl->stream;
     const int32_t nsteps = r.nsteps;
     if (int rc = route_end_queue<T>(pl)) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
+    // (The STREAM, not the event behind the window's last launch: measured on the sequence with the decimated result among
+    // the products -- 22.8 ms per day with the event against 19.5.  Behind a kernel queued after the window the stream's wait
+    // returns when the OTHER plan's next window has ended; the host then queues every day a little late -- a pacing under which
+    // the copies of consecutive days, 14 ms each on one PCIe direction, were observed not to run into each other.)
+    HIP_TRY(hipStreamSynchronize(pl->stream));
     float ms01 = 0, ms12 = 0, ms23 = 0;
     HIP_TRY(hipEventElapsedTime(&ms01, pl->ev[0], pl->ev[1]));
     HIP_TRY(hipEventElapsedTime(&ms12, pl->ev[1], pl->ev[2]));
@@ -3363,6 +3385,17 @@ int trmc_plan_set_sequence_mode(trmc_plan *pl, int on)
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
     pl->opt.sequence = on != 0;
+    return 0;
+}
+
+int trmc_plan_set_stamps(trmc_plan *pl, void *host_ring, int32_t nwindows)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is open");
+    if (host_ring && nwindows < 1) return fail(TRMC_EINVAL, "nwindows must be >= 1");
+    pl->stamps = (unsigned long long *)host_ring;
+    pl->nstamp_windows = host_ring ? nwindows : 0;
+    pl->stamp_seq = -1;
     return 0;
 }
 
@@ -4507,7 +4540,9 @@ int trmc_fetch_begin_fvd(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0
     // every 144 at stride 12: every cache line) -- about 2 ms of a CONUS day's period wherever it runs; measured on the sequence
     // with hourly output (ms per day; 17.3 with neither kernel nor copy): here 19.4; on the transpose stream (low priority) 19.3
     // with the copy on a stream of its own and 28 with the copy on the copy stream (the in-order hardware queue of that
-    // priority then also holds the next day's transposes and forcing behind the 14-ms copy); without the kernel 17.5.
+    // priority then also holds the next day's transposes and forcing behind the 14-ms copy); without the kernel 17.5.  The copy
+    // on a stream of its own with no event behind it (its end polled with hipStreamQuery): days of 24.7 and 15 ms in turn,
+    // 20.7 on average -- the copies of consecutive days overlap on the one PCIe direction.
     const int32_t nkeep = fvd_host ? T_ / stride : 0;
     const size_t fb = (size_t)pl->nseg * nkeep * 3 * pl->esz;
     const void *fvd_src = pl->out.p;

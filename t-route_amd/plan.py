@@ -383,6 +383,20 @@ class RoutingPlan:
             _lib.check(_lib.lib().trmc_download_gathered(self._h, _lib.ptr(out)))
         return out
 
+    def set_stamps(self, nwindows=8):
+        """Diagnosis (trmc_plan_set_stamps): returns a page-locked uint64 array [nwindows, 4] that window k since this call
+        fills (row k % nwindows) with the device clock (100 MHz) at: tiles begin, last tile ended, tail begins, last step
+        launch ended.  nwindows = 0 switches it off."""
+        if not nwindows:
+            _lib.check(_lib.lib().trmc_plan_set_stamps(self._h, None, 0))
+            self._stamps = None
+            return None
+        ring = _lib.result_empty((int(nwindows), 4), np.uint64, always_pinned=True)
+        ring[...] = 0
+        _lib.check(_lib.lib().trmc_plan_set_stamps(self._h, _lib.ptr(ring), int(nwindows)))
+        self._stamps = ring
+        return ring
+
     def fetch_begin(self, rowset, want_state=True, output_stride=None):
         """Start the asynchronous fetch of a window's products (include/trmc.h trmc_fetch_begin): the hydrographs of a
         registered row set and / or the final state, into page-locked arrays; returns at once.  ``fetch_wait()`` hands the

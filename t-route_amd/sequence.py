@@ -116,6 +116,7 @@ class DaySequence:
         dev = plans[0].info()["device"]
 
         tl, tl0 = self.timeline, time.perf_counter()
+        rings = [p.set_stamps(16) for p in plans] if tl is not None else None   # (diagnosis: the device's own clock per window)
 
         def mark(what, w):
             if tl is not None:
@@ -126,12 +127,15 @@ class DaySequence:
             p.route_advance(nsteps)
 
         def after_window(i, w):
-            """behind day w's window on plan i: its products to the host, then the forcing of the plan's next day (w + 2)"""
-            plans[i].fetch_begin(rs[i], True, self.output_stride)
-            mark("fetch_begin", w)
+            """behind day w's set-up on plan i the forcing of the plan's next day (w + 2), behind its last launch its products to
+            the host.  In this order: copies and the events behind them share ONE in-order hardware queue (the low-priority
+            one), and the forcing queued behind a day's products would wait for their copy to end -- with the decimated result
+            among them (14 ms) it then reached the device 5 ms after the day it is for should have begun."""
             if w + 2 < total:
                 plans[i].stage_forcing(nsteps, days[(w + 2) % nd])
                 mark("stage_forcing", w + 2)
+            plans[i].fetch_begin(rs[i], True, self.output_stride)
+            mark("fetch_begin", w)
         plans[0].upload_forcing(nsteps, days[0], state0)        # the first day the ordinary way (synchronous)
         if total > 1:
             plans[1].stage_forcing(nsteps, days[1 % nd])
@@ -176,6 +180,13 @@ class DaySequence:
         X.device_synchronize(dev)
         el = time.perf_counter() - t0
         day_ms = [round((b - a) * 1e3, 2) for a, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
+        if rings is not None:       # the last days on the device's clock (ms from the first of them): tiles begin / end, tail begins / ends
+            first = max(0, total - 8)
+            rows = [rings[d % 2][(d // 2) % 16].astype(np.int64) for d in range(first, total)]
+            base = int(min(r[0] if r[0] else r[2] for r in rows))
+            self.device_days = [(first + i, *[round((int(v) - base) / 1e5, 2) if v else None for v in r]) for i, r in enumerate(rows)]
+            for p in plans:
+                p.set_stamps(0)
         return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "fvd": got[2] if len(got) > 2 else None,
                 "days_routed": total, "last_plan": plans[(total - 1) % 2], "day_ms": day_ms}
 

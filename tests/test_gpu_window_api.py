@@ -343,6 +343,30 @@ def test_asynchronous_fetch_of_the_decimated_result_equals_slicing(monkeypatch, 
             plan.fetch_begin(rs, True, 0)
 
 
+def test_device_clock_stamps_of_consecutive_windows(monkeypatch):
+    """trmc_plan_set_stamps: every window leaves the device clock at four points (tiles begin / end, tail begins / ends) in a
+    page-locked ring -- in order inside a window, and the windows one after the other."""
+    monkeypatch.setenv("TRMC_ENGINE", "levels")
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
+    monkeypatch.setenv("TRMC_WIDE_K", "8")
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=6000)
+    nsteps, qts = 48, 12
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as plan:
+        ring = plan.set_stamps(4)
+        plan.upload_forcing(nsteps, qlat, q0)
+        for _ in range(3):
+            plan.route_device(nsteps, qts, True)
+        assert plan.stats()["wide_levels"] > 0
+        r = ring[:3].astype(np.int64)
+        assert (r > 0).all() and (ring[3] == 0).all()
+        assert (r[:, 0] < r[:, 1]).all() and (r[:, 2] < r[:, 3]).all() and (r[:, 0] <= r[:, 2]).all()
+        assert (r[1:, 0] > r[:-1, 3]).all()                       # (one plan: a window begins after the one before has ended)
+        plan.set_stamps(0)
+        before = ring.copy()
+        plan.route_device(nsteps, qts, True)
+        assert np.array_equal(ring, before)
+
+
 def test_rccl_communicator_single_rank_and_device_plumbing():
     """The RCCL transport of the package's communicator (librccl.so by dlopen: ncclGetUniqueId / ncclCommInitRank /
     ncclAllGather through include/trmc.h) at world size 1 -- what one GPU can run of it -- plus the device buffers, streams,
