@@ -431,6 +431,13 @@ int trmc_download_gathered(trmc_plan *plan, void *out);
  * window k + 1 (the planes the gathers read are only overwritten by kernels queued after them).  hyd_host
  * [rows of the set][nsteps] and q0_host [nseg][3] should be page-locked (trmc_host_alloc); either may be NULL.
  * trmc_fetch_wait returns when both arrays are complete; one fetch in flight per plan. */
+/* Tell a plan which steps a caller will ask for with trmc_fetch_begin_fvd: windows begun afterwards write every stride-th step
+ * of (q, v, d) into a block of their own AS THEY GO -- the rows of the tiled leading levels from the kernel that routes them,
+ * the others gathered from the time-major planes when the block is fetched -- instead of reading the whole result once more
+ * (9.4 GB of a CONUS day) to pick them out.  Results are the same; 0 switches it off.  A fetch with another stride, or of a
+ * window that ran without tiles, decimates the result as before. */
+int trmc_plan_set_output_stride(trmc_plan *plan, int32_t stride);
+
 /* Diagnosis: a timeline of consecutive windows without a profiler attached (one that serialises what overlaps).  host_ring
  * [nwindows][4] uint64 in page-locked memory (trmc_host_alloc), or NULL to switch it off: window k since the call (level
  * engine, assume_short_ts, leading levels tiled) leaves in row k % nwindows the device's 100 MHz clock when its tiles

@@ -136,6 +136,7 @@ SIGNATURES = {
     "trmc_gather_flow_rows": (_int, [_vp, _vp, _i64, _vp, _int]),
     "trmc_download_gathered": (_int, [_vp, _vp]),
     "trmc_plan_set_stamps": (_int, [_vp, _vp, _i32]),
+    "trmc_plan_set_output_stride": (_int, [_vp, _i32]),
     "trmc_fetch_begin": (_int, [_vp, _i32, _vp, _vp]),
     "trmc_fetch_begin_fvd": (_int, [_vp, _i32, _vp, _vp, _int, _vp]),
     "trmc_fetch_wait": (_int, [_vp]),

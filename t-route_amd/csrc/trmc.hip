@@ -463,6 +463,10 @@ template <class T> struct StepArgs {
     // k_mc_tile: non-null = the threads of a block take the block's rows by descending cost class (see the kernel's prologue):
     // the class of every row at the last step it was routed in a tile, min(iterations, 3) + 4 if over bank
     uint8_t *cls_last;
+    // k_mc_tile<.., DEC>: every dec_stride-th step of its rows' (q, v, d) also goes to dec[row][k][3], k = t / dec_stride - 1 <
+    // dec_keep (trmc_plan_set_output_stride: what the reference's writers take of a window, written where it is produced)
+    T *dec;
+    int32_t dec_stride, dec_keep;
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -681,7 +685,7 @@ constexpr int64_t kMidDefaultRowsPerCu = 0; // default threshold of the second t
 // latencies with other wavefronts and is close to its issue limit at four
 #define TRMC_TILE_WAVES 5
 #endif
-template <class T, bool TOL = false>
+template <class T, bool TOL = false, bool DEC = false>
 __global__ void __launch_bounds__(kTileBlock, sizeof(T) == 4 ? TRMC_TILE_WAVES : 1)
 k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t tile, const int32_t K)
 {
@@ -832,6 +836,18 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                     }
                 } else {
                     for (int32_t e = 0; e < 3 * staged; ++e) dst[e] = si[e * kTileBlock];
+                }
+                if constexpr (DEC) {
+                    // the kept steps among the ones just written, (t - staged, t]: the multiples of dec_stride, newest first
+                    const int32_t ds = cold->dec_stride;
+                    for (int32_t k = t / ds; k >= 1 && k * ds > t - staged; --k) {
+                        if (k > cold->dec_keep) continue;
+                        const int32_t slot = k * ds - (t - staged) - 1;
+                        T *dd = cold->dec + ((size_t)cold->row_of_pos[su] * (size_t)cold->dec_keep + (size_t)(k - 1)) * 3;
+                        dd[0] = si[(slot * 3 + 0) * kTileBlock];
+                        dd[1] = si[(slot * 3 + 1) * kTileBlock];
+                        dd[2] = si[(slot * 3 + 2) * kTileBlock];
+                    }
                 }
                 staged = 0;
             }
@@ -1952,6 +1968,24 @@ k_decimate(const T *__restrict__ out, T *__restrict__ dec, int64_t nseg, int32_t
     dst[2] = src[2];
 }
 
+// The rows a window's tiles did NOT decimate as they went (k_mc_tile<.., DEC>): their kept steps from the time-major planes --
+// coalesced by position -- into dec[row][k][3]; positions [skip_lo, skip_hi) are the tiles'.
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_decimate_planes(const T *__restrict__ q_tm, const T *__restrict__ v_tm, const T *__restrict__ d_tm, const int32_t *__restrict__ row_of_pos,
+                  T *__restrict__ dec, int32_t nseg, int64_t nseg_pad, int32_t stride, int32_t nkeep, int32_t skip_lo, int32_t skip_hi)
+{
+    const int32_t p = (int32_t)blockIdx.x * kBlock + (int32_t)threadIdx.x;
+    if (p >= nseg || (p >= skip_lo && p < skip_hi)) return;
+    T *dst = dec + (size_t)row_of_pos[p] * (size_t)nkeep * 3;
+    size_t src = (size_t)stride * (size_t)nseg_pad + (size_t)p;
+    for (int32_t k = 0; k < nkeep; ++k, src += (size_t)stride * (size_t)nseg_pad, dst += 3) {
+        dst[0] = q_tm[src];
+        dst[1] = v_tm[src];
+        dst[2] = d_tm[src];
+    }
+}
+
 // ---------------------------------------------------------------- plan
 struct DevBuf {
     void *p = nullptr;
@@ -2009,6 +2043,8 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     int32_t mid = 0, mid_k = 0, mid_next = 0;
     bool tail_active = false;     // the tail launches of this window go to the tail stream
     bool end_queued = false;      // route_end_queue has run for this window
+    int32_t dec_stride = 0, dec_keep = 0; // the tiles of this window write the kept steps of their rows into the plan's `dec`
+    int32_t dec_lo = 0, dec_hi = 0;       // ... the plan positions [dec_lo, dec_hi) that do
 };
 
 struct trmc_plan {
@@ -2094,6 +2130,11 @@ struct trmc_plan {
     trmc_stats stats{};
     RouteRun run;
     // asynchronous fetch of what a throughput-mode caller consumes (trmc_fetch_begin / trmc_fetch_wait)
+    // trmc_plan_set_output_stride: windows write every out_stride-th step of every row's (q, v, d) into `dec` as they go (the
+    // tiled rows from k_mc_tile; the others are gathered from the time-major planes when the block is fetched)
+    int32_t out_stride = 0;
+    DevBuf dec;
+    int32_t dec_stride_done = 0, dec_keep_done = 0, dec_nsteps_done = 0, dec_lo_done = 0, dec_hi_done = 0; // ... what the last window left there
     unsigned long long *stamps = nullptr; // trmc_plan_set_stamps: [nstamp_windows][4] in page-locked host memory (the caller's)
     int32_t nstamp_windows = 0;
     int64_t stamp_seq = -1;               // windows begun since the ring was set, minus one
@@ -2210,6 +2251,8 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.s0_n = col<T>(pl, TRMC_NPARAM + 4);
     a.s0_ncc = col<T>(pl, TRMC_NPARAM + 5);
     a.inv_n = col<T>(pl, TRMC_NPARAM + 6);
+    a.dec = nullptr; // (set for the tile launches of a window that decimates as it goes: route_advance_t)
+    a.dec_stride = a.dec_keep = 0;
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.up2 = (const int2 *)pl->up2.p;
@@ -2271,13 +2314,16 @@ template <class T>
 inline void launch_tile(hipStream_t st, const StepArgs<T> &a, int32_t p0, int32_t p1, int32_t tile, int32_t K, bool tol)
 {
     const dim3 grid((unsigned)((p1 - p0 + kTileBlock - 1) / kTileBlock)), block(kTileBlock);
+    const bool dec = a.dec != nullptr;
     if constexpr (sizeof(T) == 4) {
         if (tol) {
-            hipLaunchKernelGGL((k_mc_tile<T, true>), grid, block, 0, st, a, p0, p1, tile, K);
+            if (dec) hipLaunchKernelGGL((k_mc_tile<T, true, true>), grid, block, 0, st, a, p0, p1, tile, K);
+            else hipLaunchKernelGGL((k_mc_tile<T, true, false>), grid, block, 0, st, a, p0, p1, tile, K);
             return;
         }
     }
-    hipLaunchKernelGGL((k_mc_tile<T, false>), grid, block, 0, st, a, p0, p1, tile, K);
+    if (dec) hipLaunchKernelGGL((k_mc_tile<T, false, true>), grid, block, 0, st, a, p0, p1, tile, K);
+    else hipLaunchKernelGGL((k_mc_tile<T, false, false>), grid, block, 0, st, a, p0, p1, tile, K);
 }
 
 // A routing window runs in three parts so that a caller can interleave other device work (the multi-GPU
@@ -2524,6 +2570,16 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                 // prologue; trmc_plan_options.tile_perm_group: < 0 off, > 0 on, 0 the default below).
                 const bool use_perm = pl->opt.tile_perm_group > 0 || (pl->opt.tile_perm_group < 0 && kTilePartitionDefault(pl->hinted));
                 StepArgs<T> at = a;
+                if (pl->out_stride > 0 && nsteps / pl->out_stride >= 1) {
+                    r.dec_stride = pl->out_stride;
+                    r.dec_keep = nsteps / pl->out_stride;
+                    if (int rc = pl->dec.ensure((size_t)pl->nseg * r.dec_keep * 3 * sizeof(T))) return rc;
+                    at.dec = (T *)pl->dec.p;
+                    at.dec_stride = r.dec_stride;
+                    at.dec_keep = r.dec_keep;
+                    r.dec_lo = w0;
+                    r.dec_hi = m1;
+                }
                 if (use_perm) {
                     const bool fresh = pl->cls_last.bytes < (size_t)pl->nseg_pad;
                     if (int rc = pl->cls_last.ensure((size_t)pl->nseg_pad)) return rc;
@@ -2556,6 +2612,11 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             // step s after launch m + ceil(s / K2) - 1.
             StepArgs<T> am = a;
             am.out_vec = a.out_vec && K2 % 4 == 0 && sizeof(T) == 4 && nsteps % 4 == 0;
+            if (r.dec_stride > 0) {
+                am.dec = (T *)pl->dec.p;
+                am.dec_stride = r.dec_stride;
+                am.dec_keep = r.dec_keep;
+            }
             auto mid_through = [&](int32_t j2_last) -> int { // queue the second tier's launches up to index j2_last
                 for (; r.mid_next <= std::min(j2_last, nmid - 1); ++r.mid_next) {
                     const int32_t j2 = r.mid_next;
@@ -2644,7 +2705,7 @@ template <class T> int route_end_t(trmc_plan *pl)
     const int32_t nsteps = r.nsteps;
     if (int rc = route_end_queue<T>(pl)) return rc;
     // (The STREAM, not the event behind the window's last launch: measured on the sequence with the decimated result among
-    // the products -- 22.8 ms per day with the event against 19.5.  Behind a kernel queued after the window the stream's wait
+    // the products -- 22.8 ms per day with the event against 19.5; 26.4 against 19.0 once the windows decimate as they go.  Behind a kernel queued after the window the stream's wait
     // returns when the OTHER plan's next window has ended; the host then queues every day a little late -- a pacing under which
     // the copies of consecutive days, 14 ms each on one PCIe direction, were observed not to run into each other.)
     HIP_TRY(hipStreamSynchronize(pl->stream));
@@ -2683,6 +2744,11 @@ template <class T> int route_end_t(trmc_plan *pl)
         if (timed_n > 0 && timed_n < (size_t)r.wide_next) s.ms_wide *= (double)r.wide_next / (double)timed_n;
     }
     pl->routed_nsteps = nsteps;
+    pl->dec_stride_done = r.dec_stride;
+    pl->dec_keep_done = r.dec_keep;
+    pl->dec_nsteps_done = nsteps;
+    pl->dec_lo_done = r.dec_lo;
+    pl->dec_hi_done = r.dec_hi;
     r.active = false;
     return 0;
 }
@@ -3388,6 +3454,15 @@ int trmc_plan_set_sequence_mode(trmc_plan *pl, int on)
     return 0;
 }
 
+int trmc_plan_set_output_stride(trmc_plan *pl, int32_t stride)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is open");
+    if (stride < 0) return fail(TRMC_EINVAL, "stride must be >= 0");
+    pl->out_stride = stride;
+    return 0;
+}
+
 int trmc_plan_set_stamps(trmc_plan *pl, void *host_ring, int32_t nwindows)
 {
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
@@ -3624,6 +3699,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     pl->fetch_hyd.release();
     pl->fetch_q0.release();
     pl->fetch_fvd.release();
+    pl->dec.release();
     if (pl->ev_dec) (void)hipEventDestroy(pl->ev_dec);
     if (pl->cstream) (void)hipStreamDestroy(pl->cstream);
     if (pl->hstream) (void)hipStreamDestroy(pl->hstream);
@@ -4546,7 +4622,29 @@ int trmc_fetch_begin_fvd(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0
     const int32_t nkeep = fvd_host ? T_ / stride : 0;
     const size_t fb = (size_t)pl->nseg * nkeep * 3 * pl->esz;
     const void *fvd_src = pl->out.p;
-    if (fb && stride > 1) {
+    // ... unless the window decimated as it went (trmc_plan_set_output_stride): the tiled rows' kept steps are in `dec` already,
+    // the others are gathered from the time-major planes (coalesced; 0.2 GB of a CONUS day instead of 9.4)
+    const bool have_dec = fb && !pl->flow && pl->dec.p
+                          && (in_window ? pl->run.dec_stride == stride && pl->run.dec_keep == nkeep
+                                        : pl->dec_stride_done == stride && pl->dec_keep_done == nkeep && pl->dec_nsteps_done == T_);
+    bool from_dec = false;
+    if (have_dec) {
+        const int32_t lo = in_window ? pl->run.dec_lo : pl->dec_lo_done, hi = in_window ? pl->run.dec_hi : pl->dec_hi_done;
+        const size_t plane = (size_t)(T_ + 1) * pl->nseg_pad;
+        if (pl->precision == 32) {
+            const float *q = (const float *)pl->tm.p;
+            hipLaunchKernelGGL((k_decimate_planes<float>), dim3(blocks_for(pl->nseg)), dim3(kBlock), 0, pl->stream, q, q + plane, q + 2 * plane,
+                               (const int32_t *)pl->row_of_pos.p, (float *)pl->dec.p, (int32_t)pl->nseg, pl->nseg_pad, stride, nkeep, lo, hi);
+        } else {
+            const double *q = (const double *)pl->tm.p;
+            hipLaunchKernelGGL((k_decimate_planes<double>), dim3(blocks_for(pl->nseg)), dim3(kBlock), 0, pl->stream, q, q + plane, q + 2 * plane,
+                               (const int32_t *)pl->row_of_pos.p, (double *)pl->dec.p, (int32_t)pl->nseg, pl->nseg_pad, stride, nkeep, lo, hi);
+        }
+        HIP_TRY(hipGetLastError());
+        if (int rc = note_gather(pl, in_window)) return rc;
+        fvd_src = pl->dec.p;
+        from_dec = true;
+    } else if (fb && stride > 1) {
         if (int rc = pl->fetch_fvd.ensure(fb)) return rc;
         const int64_t work = pl->nseg * (int64_t)nkeep;
         if (pl->precision == 32)
@@ -4575,7 +4673,7 @@ int trmc_fetch_begin_fvd(trmc_plan *pl, int32_t rowset, void *hyd_host, void *q0
         if (int rc = to_host(q0_host, pl->fetch_q0.p, qb)) return rc;
     if (fb) {
         if (int rc = to_host(fvd_host, fvd_src, fb)) return rc;
-        if (stride == 1) { // (the whole result leaves straight from `out`: the plan's next window starts behind the copy)
+        if (stride == 1 || from_dec) { // (copied from `out` / `dec` themselves: the plan's next window, which writes them, starts behind the copy)
             if (!pl->ev_dec) HIP_TRY(hipEventCreateWithFlags(&pl->ev_dec, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(pl->ev_dec, pl->cstream));
             pl->dec_pending = true;
@@ -4593,7 +4691,6 @@ int trmc_fetch_wait(trmc_plan *pl)
     if (int rc = use_device(pl)) return rc;
     pl->fetch_pending = false;
     HIP_TRY(hipEventSynchronize(pl->ev_fetch_done));
-
     return 0;
 }
 

@@ -383,6 +383,11 @@ class RoutingPlan:
             _lib.check(_lib.lib().trmc_download_gathered(self._h, _lib.ptr(out)))
         return out
 
+    def set_output_stride(self, stride):
+        """Windows begun from now on write every `stride`-th step of (q, v, d) aside as they go (trmc_plan_set_output_stride):
+        what ``fetch_begin(..., output_stride=stride)`` then copies without another pass over the result; 0 / None: off."""
+        _lib.check(_lib.lib().trmc_plan_set_output_stride(self._h, int(stride or 0)))
+
     def set_stamps(self, nwindows=8):
         """Diagnosis (trmc_plan_set_stamps): returns a page-locked uint64 array [nwindows, 4] that window k since this call
         fills (row k % nwindows) with the device clock (100 MHz) at: tiles begin, last tile ended, tail begins, last step

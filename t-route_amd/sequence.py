@@ -69,6 +69,7 @@ class DaySequence:
             self.plans = [p, self._clone]
             for pl in self.plans:
                 pl.set_sequence_mode(True)
+                pl.set_output_stride(self.output_stride)     # (the kept steps written aside as the windows go)
             self._rs = [pl.rowset(router.my_out0_local) for pl in self.plans]
 
     def close(self):
@@ -76,6 +77,7 @@ class DaySequence:
             self._clone.close()
             self._clone = None
             self.r.plan0.set_sequence_mode(False)
+            self.r.plan0.set_output_stride(0)
 
     def __enter__(self):
         return self

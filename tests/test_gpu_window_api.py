@@ -343,6 +343,43 @@ def test_asynchronous_fetch_of_the_decimated_result_equals_slicing(monkeypatch, 
             plan.fetch_begin(rs, True, 0)
 
 
+@pytest.mark.parametrize("mid", [False, True])
+def test_windows_that_decimate_as_they_go_hand_over_the_same_block(monkeypatch, mid):
+    """trmc_plan_set_output_stride: the tiles write the kept steps of their rows aside as they route them, the other rows are
+    gathered from the time-major planes at the fetch -- the block must equal the slices of the full result, for strides that
+    do and do not divide the window or the tiles' K, with a second tier of tiles, after a change of the stride, and for a
+    fetch that asks for another stride than the plan was told (decimated from the result as before)."""
+    monkeypatch.setenv("TRMC_ENGINE", "levels")
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
+    monkeypatch.setenv("TRMC_WIDE_K", "8")
+    monkeypatch.setenv("TRMC_MID_MIN_ROWS", "8" if mid else "0")
+    monkeypatch.setenv("TRMC_MID_K", "2")
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=6000)
+    nsteps, qts = 48, 12
+    rows = np.array([3, 5999, 17], np.int64)
+    with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True) as plan:
+        rs = plan.rowset(rows)
+        plan.upload_forcing(nsteps, qlat, q0)
+        want = []
+        for k, (told, asked) in enumerate([(12, 12), (5, 5), (3, 3), (1, 1), (12, 4), (100, 100), (7, 7), (0, 6)]):
+            plan.set_output_stride(told)
+            plan.route_device(nsteps, qts, True)
+            if k == 0:
+                st = plan.stats()
+                assert st["wide_levels"] > 0 and (st["mid_levels"] > 0) == mid
+            full = plan.download_fvd()
+            want.append(full[:, asked - 1::asked][:, :nsteps // asked].copy())
+            prev = plan.fetch_wait()
+            plan.fetch_begin(rs, True, asked)
+            plan.upload_forcing(nsteps, qlat * np.float32(1.0 + 0.2 * (k + 1)), None)   # (the next window is queued beside the copy)
+            if k > 0:
+                assert prev[2].shape == want[k - 1].shape and np.array_equal(prev[2].view(np.uint32), want[k - 1].view(np.uint32)), k - 1
+        last = plan.fetch_wait()
+        assert np.array_equal(last[2].view(np.uint32), want[-1].view(np.uint32))
+        with pytest.raises(ValueError, match="stride"):
+            plan.set_output_stride(-1)
+
+
 def test_device_clock_stamps_of_consecutive_windows(monkeypatch):
     """trmc_plan_set_stamps: every window leaves the device clock at four points (tiles begin / end, tail begins / ends) in a
     page-locked ring -- in order inside a window, and the windows one after the other."""
