@@ -86,6 +86,11 @@ def one_round(rng, nseg_max):
             b = a.clone()
             plans = [a, b]
             rs = [pl.rowset(outlets) for pl in plans]
+            # ... in two of three of those the windows write the kept steps aside as they go (trmc_plan_set_output_stride),
+            # now and then told another stride than the fetch asks for (the fetch then decimates the result itself)
+            told = {0: 0, 1: stride, 2: stride, 3: (stride or 0) + 1}[int(rng.integers(0, 4))] if stride else 0
+            for pl in plans:
+                pl.set_output_stride(told)
 
             def nap():
                 if dawdle:
