@@ -69,15 +69,27 @@ class DaySequence:
             self.plans = [p, self._clone]
             for pl in self.plans:
                 pl.set_sequence_mode(True)
-                pl.set_output_stride(self.output_stride)     # (the kept steps written aside as the windows go)
+            self.set_output_stride(self.output_stride)
             self._rs = [pl.rowset(router.my_out0_local) for pl in self.plans]
+
+    def set_output_stride(self, stride):
+        """(Between runs.)  None / 0: the days' products are the outlet hydrographs and the final state; n: also every n-th step
+        of every row's (q, v, d) -- the plans are told, so that their windows write the kept steps aside as they go
+        (trmc_plan_set_output_stride)."""
+        stride = int(stride) if stride else None
+        if self.world == 1 and (stride or self.output_stride):
+            for pl in self.plans:
+                pl.set_output_stride(stride or 0)
+        self.output_stride = stride
 
     def close(self):
         if self._clone is not None:
             self._clone.close()
             self._clone = None
             self.r.plan0.set_sequence_mode(False)
-            self.r.plan0.set_output_stride(0)
+            if self.output_stride:
+                self.r.plan0.set_output_stride(0)
+                self.output_stride = None
 
     def __enter__(self):
         return self
