@@ -149,8 +149,8 @@ def main():
         print(f"seed {seed:4d} {regime:10s} nseg {nseg:6d} steps {nsteps:2d} qts {qts} finite {fin.mean():.4f} "
               f"differing runs so far {bad_rounds}", flush=True)
         seed += 1
-    print(f"fuzz_parity: {rounds} rounds, {total} finite segment-steps compared (one-step launches, dataflow engine, wide tiles and the "
-          f"window kernel x both modes where they apply x plain and cost-ordered plan), {bad_rounds} differing runs")
+    print(f"fuzz_parity: {rounds} rounds, {total} finite segment-steps compared (one-step launches, dataflow engine, wide tiles with and "
+          f"without a second tier x both modes where they apply x plain and cost-ordered plan), {bad_rounds} differing runs")
     sys.exit(1 if bad_rounds else 0)
 
 
