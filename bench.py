@@ -564,6 +564,31 @@ def main():
     untuned = {"value": rate(unt), "unit": "segment-timesteps/s", "ms_per_step": unt["el"] / usteps * 1e3,
                "ms_main": unt["ms_main"], "roofline_frac": frac(unt),
                "window": "day N+1, warm start (the headline's window) on the plan built from the topology alone"}
+    # the days of the timed sequence (a ring of distinct days in page-locked memory: see 3.)
+    from troute_amd.sequence import DaySequence, pinned_like
+    ndays = max(2 if a.headline_only else 4, min(int(os.environ.get("TRMC_BENCH_DAYS", "10")), a.steps + a.warmup))
+    t0 = time.perf_counter()
+    ring, prev_day = [], qlat_a
+    for i in range(ndays):
+        day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day, persistence=a.persistence)
+        ring.append(pinned_like(day) if not use_dist else day)
+        prev_day = day
+    assert np.array_equal(ring[0], qlat_b) or a.persistence is not None
+    t_days = time.perf_counter() - t0
+    # ... and the headline's own protocol -- the sequence of days, plan and clone -- on that plan, before it is rebuilt
+    if not use_dist and not a.headline_only and not a.no_retune and a.precision == 32:
+        try:
+            with DaySequence(router, a.nsteps, a.qts) as us:
+                us.run(ring, state_n, max(6, len(ring)), 0)
+                ssteps = max(2, min(a.steps, 6))
+                s1 = us.run(ring, state_n, ssteps, 1)
+            untuned["in_sequence"] = {"ms_per_step": s1["el"] / ssteps * 1e3, "steps": ssteps,
+                                      "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / (s1["el"] / ssteps) / 1e9 / HBM_PEAK_GBS,
+                                      "what": "the headline's pipeline (DaySequence, plan + clone, distinct days) on the plan built from the "
+                                              "topology alone"}
+            router.upload(a.nsteps, qlat_b, state_n)
+        except Exception as e:
+            untuned["in_sequence"] = {"error": repr(e)}
 
     # ---- 2. the plan rebuilt with day N's costs as its hint (same results: tests/test_gpu_parity.py), spun up again ----
     if not a.no_retune:
@@ -596,16 +621,6 @@ def main():
     # N+1, N+2, ... -- a ring of `ndays` distinct days in page-locked host memory, each derived from the one before like days
     # N-1 -> N -> N+1 were (synthetic.forcing).  One GPU: on the tuned plan and its clone; a rank of a multi-GPU job: on its
     # merged plan, its rows of every day staged from page-locked memory, the state carried on in HBM.
-    from troute_amd.sequence import DaySequence, pinned_like
-    ndays = max(2 if a.headline_only else 4, min(int(os.environ.get("TRMC_BENCH_DAYS", "10")), a.steps + a.warmup))
-    t0 = time.perf_counter()
-    ring, prev_day = [], qlat_a
-    for i in range(ndays):
-        day = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2 + i, previous=prev_day, persistence=a.persistence)
-        ring.append(pinned_like(day) if not use_dist else day)
-        prev_day = day
-    assert np.array_equal(ring[0], qlat_b) or a.persistence is not None
-    t_days = time.perf_counter() - t0
     persist = None
     # (diagnosis only, with --headline-only: TRMC_BENCH_OUTPUT_STRIDE=n times / traces the pipeline with the decimated result
     # among each day's products -- the `hourly_output.in_sequence` leg -- in place of the headline's)

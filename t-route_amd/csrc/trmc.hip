@@ -467,6 +467,11 @@ template <class T> struct StepArgs {
     // dec_keep (trmc_plan_set_output_stride: what the reference's writers take of a window, written where it is produced)
     T *dec;
     int32_t dec_stride, dec_keep;
+    // k_mc_tile, hot rows: rows of class >= 3 at the end of a tile are routed by blocks of their own in the next one.  Three
+    // lists of positions [3][hot_cap] and their lengths [3], used in turn: a launch reads `hot_cur`, appends to the next and
+    // clears the length of the one after; bit 7 of cls_last = "this row is in the list the next launch reads".
+    int32_t *hot_list, *hot_cnt;
+    int32_t hot_cap, hot_cur, hot_home; // (hot_home: blocks of the launch that take positions; the ones behind take the list)
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -696,24 +701,48 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     M m{stage_pow_tables(s_tab), false};
     m.sane = a.sane;
 
-    const int32_t s_mine = s_begin + (int32_t)blockIdx.x * kTileBlock + (int32_t)threadIdx.x;
-    int32_t s = s_mine;
-    if (a.cls_last) {
-        // Which row a thread takes: the block's kTileBlock positions dealt out by DESCENDING cost class -- the class every row
-        // showed at the end of the tile before (a row repeats its secant iteration count from step to step 99.3 % of the time)
-        // -- so that a wavefront holds rows of one class whatever the forcing does and however old the plan's cost hint is.
-        // Once per K steps, inside the launch: a count per class in LDS, a prefix over the eight classes, a scatter of lane
-        // numbers.  (Until round 5 a launch of its own between the tiles, k_tile_perm, over groups of 256 positions: 13-25 us
-        // of the tile stream per tile, 0.55 ms of a CONUS day spent between tiles.)  Order inside a class is whatever the
-        // atomics give; results do not depend on which thread routes a row.
-        const int32_t key = s_mine < s_end ? 7 - min((int32_t)a.cls_last[s_mine], 7) : 8; // bucket 0 = the costliest; 8 = no row
-        s = s_begin + (int32_t)blockIdx.x * kTileBlock + block_partition_by_class<kTileBlock>(key);
+    int32_t s;
+    bool from_hot = false;
+    int32_t *const hot_list = a.cls_last ? cold->hot_list : nullptr;
+    if (hot_list && (int32_t)blockIdx.x >= cold->hot_home) {
+        // HOT ROWS.  The blocks behind the ones that take positions take the list the tile before left: the rows that ended it in
+        // class 3 or above -- three or more secant iterations, over bank; 1.5 % of the rows of an unordered CONUS plan, and one of
+        // them in a wavefront makes all 64 lanes wait through its extra iterations (they sat in half of the wavefronts: 903
+        // instructions per wavefront-step against 619 on the cost-ordered plan).  Gathered here they pace each other only.
+        const int32_t cur = cold->hot_cur, cap = cold->hot_cap;
+        const int32_t i = ((int32_t)blockIdx.x - cold->hot_home) * kTileBlock + (int32_t)threadIdx.x;
+        if (i >= min(cold->hot_cnt[cur], cap)) return;
+        s = hot_list[(size_t)cur * (size_t)cap + (size_t)i];
+        from_hot = true;
+        if (s < s_begin || s >= s_end) { // (listed by a window whose tiled levels reached further: back to where it is routed now)
+            cold->cls_last[s] &= 0x7f;
+            return;
+        }
+    } else {
+        const int32_t s_mine = s_begin + (int32_t)blockIdx.x * kTileBlock + (int32_t)threadIdx.x;
+        s = s_mine;
+        if (a.cls_last) {
+            // Which row a thread takes: the block's kTileBlock positions dealt out by DESCENDING cost class -- the class every row
+            // showed at the end of the tile before (a row repeats its secant iteration count from step to step 99.3 % of the time)
+            // -- so that a wavefront holds rows of one class whatever the forcing does and however old the plan's cost hint is.
+            // Once per K steps, inside the launch: a count per class in LDS, a prefix over the eight classes, a scatter of lane
+            // numbers.  (Until round 5 a launch of its own between the tiles, k_tile_perm, over groups of 256 positions: 13-25 us
+            // of the tile stream per tile, 0.55 ms of a CONUS day spent between tiles.)  Order inside a class is whatever the
+            // atomics give; results do not depend on which thread routes a row.  (Bit 7: the row is in the hot list.)
+            if (hot_list && blockIdx.x == 0 && threadIdx.x == 0) cold->hot_cnt[(cold->hot_cur + 2) % 3] = 0; // (the list after next)
+            const int32_t c = s_mine < s_end ? (int32_t)a.cls_last[s_mine] : 0x80;
+            const int32_t key = (c & 0x80) ? 8 : 7 - min(c, 7); // bucket 0 = the costliest; 8 = no row
+            s = s_begin + (int32_t)blockIdx.x * kTileBlock + block_partition_by_class<kTileBlock>(key);
+        }
+        if (s >= s_end) return;
+        if (hot_list && (a.cls_last[s] & 0x80)) return; // (routed by a block of the hot list)
     }
-    if (s >= s_end) return;
     const int32_t behind = tile - a.level[s];
-    if (behind < 0) return;
     const int32_t t_lo = behind * K + 1, t_hi = min(behind * K + K, a.nsteps);
-    if (t_lo > t_hi) return;
+    if (behind < 0 || t_lo > t_hi) {
+        if (from_hot) cold->cls_last[s] &= 0x7f; // (not routed in this launch: back to its block, which does that bookkeeping)
+        return;
+    }
 
     const uint32_t su = (uint32_t)s;
     uint32_t ob = su * (uint32_t)sizeof(T);
@@ -854,7 +883,21 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         }
     }
     if (t_hi == cold->nsteps) cold->it_prev[su] = (uint8_t)min(it_last, 255);
-    if (uint8_t *const cls = cold->cls_last) cls[su] = (uint8_t)(min(it_last, 3) + (over_last ? 4 : 0));
+    if (uint8_t *const cls = cold->cls_last) {
+        uint8_t c = (uint8_t)(min(it_last, 3) + (over_last ? 4 : 0));
+        // (a row that has finished the window starts the next one in its block; and a wavefront that holds sixteen or more of
+        // them -- the first blocks of every level of a cost-ordered plan -- keeps them: they pace each other where they are)
+        const bool hot = hot_list && c >= 3 && t_hi < cold->nsteps;
+        if (hot && (from_hot || __builtin_popcountll(__ballot(hot)) < 16)) {
+            const int32_t nxt = (cold->hot_cur + 1) % 3, cap = cold->hot_cap;
+            const int32_t i = atomicAdd(&cold->hot_cnt[nxt], 1);
+            if (i < cap) {
+                hot_list[(size_t)nxt * (size_t)cap + (size_t)i] = s;
+                c |= 0x80;
+            }
+        }
+        cls[su] = c;
+    }
     if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535, (int)it_sum[su] + it_acc);
 }
 
@@ -2122,6 +2165,7 @@ struct trmc_plan {
         int64_t mid_min_rows = 0;            // <= 0: no second tier
         int32_t mid_levels = 12, mid_k = 4;
         int32_t tile_perm_group = -1;        // -1: the default (see route_advance_t); 0: off; 1: on
+        int32_t hot_rows = -1;               // -1: with the partition; 0: off; 1: on
         bool sequence = false;
         bool flow_overlap = false;
         int32_t flow_lean = 0;
@@ -2160,6 +2204,9 @@ struct trmc_plan {
     bool q0_staged = false;              // in_q0 holds the initial state of the window that is staged (an upload's q0, or the last
                                          // window's final state gathered by an upload with q0 = NULL / trmc_stage_forcing): valid
                                          // until a window consumes it, whatever routed_nsteps says in the meantime
+    DevBuf hot_list, hot_cnt;            // k_mc_tile's hot rows (StepArgs::hot_list): [3][hot_cap] positions, [3] lengths
+    int32_t hot_cap = 0;
+    int64_t tile_seq = 0;                // tile launches of the wide tier so far, all windows: which of the three lists is read
     DevBuf cls_last;                     // the cost class every wide row showed at the end of its last tile (k_mc_tile's in-block partition)
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
@@ -2253,6 +2300,8 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.inv_n = col<T>(pl, TRMC_NPARAM + 6);
     a.dec = nullptr; // (set for the tile launches of a window that decimates as it goes: route_advance_t)
     a.dec_stride = a.dec_keep = 0;
+    a.hot_list = a.hot_cnt = nullptr;
+    a.hot_cap = a.hot_cur = a.hot_home = 0;
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.up2 = (const int2 *)pl->up2.p;
@@ -2313,7 +2362,9 @@ inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_
 template <class T>
 inline void launch_tile(hipStream_t st, const StepArgs<T> &a, int32_t p0, int32_t p1, int32_t tile, int32_t K, bool tol)
 {
-    const dim3 grid((unsigned)((p1 - p0 + kTileBlock - 1) / kTileBlock)), block(kTileBlock);
+    // (with hot rows: a.hot_home blocks take positions, the blocks behind them the list)
+    const unsigned home = (unsigned)((p1 - p0 + kTileBlock - 1) / kTileBlock);
+    const dim3 grid(home + (a.hot_list ? (unsigned)((a.hot_cap + kTileBlock - 1) / kTileBlock) : 0u)), block(kTileBlock);
     const bool dec = a.dec != nullptr;
     if constexpr (sizeof(T) == 4) {
         if (tol) {
@@ -2585,10 +2636,26 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     if (int rc = pl->cls_last.ensure((size_t)pl->nseg_pad)) return rc;
                     if (fresh) HIP_TRY(hipMemsetAsync(pl->cls_last.p, 0, (size_t)pl->nseg_pad, ws)); // (no history yet: one class)
                     at.cls_last = (uint8_t *)pl->cls_last.p;
+                    // hot rows (trmc_plan_options.hot_rows): by default where the plan's own order does not group them already
+                    if (pl->opt.hot_rows > 0 || (pl->opt.hot_rows < 0 && !pl->hinted)) {
+                        const int32_t cap = std::max<int32_t>(kTileBlock, ((w1 - w0) / 32 + kTileBlock - 1) / kTileBlock * kTileBlock);
+                        if (pl->hot_cap != cap || !pl->hot_list.p) { // (a tier of another size: the lists start empty, the marks are cleared)
+                            if (int rc = pl->hot_list.ensure((size_t)3 * cap * sizeof(int32_t))) return rc;
+                            if (int rc = pl->hot_cnt.ensure(3 * sizeof(int32_t))) return rc;
+                            HIP_TRY(hipMemsetAsync(pl->hot_cnt.p, 0, 3 * sizeof(int32_t), ws));
+                            if (!fresh) HIP_TRY(hipMemsetAsync(pl->cls_last.p, 0, (size_t)pl->nseg_pad, ws));
+                            pl->hot_cap = cap;
+                        }
+                        at.hot_list = (int32_t *)pl->hot_list.p;
+                        at.hot_cnt = (int32_t *)pl->hot_cnt.p;
+                        at.hot_cap = cap;
+                        at.hot_home = (w1 - w0 + kTileBlock - 1) / kTileBlock;
+                    }
                 }
                 stamp(pl, ws, 0);
                 HIP_TRY(hipEventRecord(pl->wide_t0[0], ws));
                 for (int32_t j = 0; j < ntile; ++j) {
+                    at.hot_cur = (int32_t)(pl->tile_seq++ % 3);
                     launch_tile<T>(ws, at, w0, w1, j, K, tol);
                     HIP_TRY(hipEventRecord(pl->wide_t1[(size_t)j], ws));
                     ++r.launches;
@@ -3544,6 +3611,7 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         po.mid_levels = (int32_t)std::min<long>(o.mid_levels > 0 ? o.mid_levels : 12, kMidMaxLevels);
         po.mid_k = o.mid_k > 0 ? o.mid_k : 4;
         po.tile_perm_group = o.tile_perm_group < 0 ? 0 : (o.tile_perm_group > 0 ? 1 : -1); // off / on / by the plan (default)
+        po.hot_rows = o.hot_rows < 0 ? 0 : (o.hot_rows > 0 ? 1 : -1);
         po.sequence = o.sequence_mode != 0;
         po.flow_overlap = o.flow_overlap != 0;
         po.flow_lean = o.flow_lean;
@@ -3686,7 +3754,7 @@ void trmc_plan_destroy(trmc_plan *pl)
             for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->fetch_fvd, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
                               &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos, &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos,
                               &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch,
-                              &pl->gathered, &pl->cls_last})
+                              &pl->gathered, &pl->cls_last, &pl->hot_list, &pl->hot_cnt})
                 b->release();
         }
         pl->zombie = true;
@@ -3708,7 +3776,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last, &pl->hot_list, &pl->hot_cnt})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);

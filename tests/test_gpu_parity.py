@@ -273,10 +273,12 @@ def set_engine(monkeypatch, engine):
         monkeypatch.setenv("TRMC_MID_MIN_ROWS", "8")
         monkeypatch.setenv("TRMC_MID_K", "4")
         monkeypatch.setenv("TRMC_MID_LEVELS", "20")
+        monkeypatch.setenv("TRMC_HOT_ROWS", "1")
     elif engine.endswith("-wide"):
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
         monkeypatch.setenv("TRMC_WIDE_K", "8")        # (a multiple of 4: the 16-byte result stores where nsteps allows them)
         monkeypatch.setenv("TRMC_TILE_PERM", "512")   # (rows re-dealt to a tile's threads by class, also on plans without a hint)
+        monkeypatch.setenv("TRMC_HOT_ROWS", "1")      # (rows of three or more iterations in blocks of their own, hinted plans too)
     else:
         monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "0")
 
