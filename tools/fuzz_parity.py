@@ -113,7 +113,8 @@ def main():
             if short:
                 variants.append(("levels-wide", "levels", {"TRMC_WIDE_MIN_ROWS": "32", "TRMC_WIDE_K": str(int(rng.choice([3, 4, 8, 16]))),
                                                            "TRMC_WIDE_LEVELS": str(int(rng.choice([2, 5, 16]))),
-                                                           "TRMC_TILE_PERM": str(int(rng.choice([0, 256, 512, 1024])))}))
+                                                           "TRMC_TILE_PERM": str(int(rng.choice([0, 256, 512, 1024]))),
+                                                           "TRMC_HOT_ROWS": str(int(rng.choice([0, 1, 1])))}))
                 variants.append(("levels-mid", "levels", {"TRMC_WIDE_MIN_ROWS": "64", "TRMC_WIDE_K": str(int(rng.choice([4, 8, 16]))),
                                                           "TRMC_MID_MIN_ROWS": str(int(rng.choice([2, 8, 16]))),
                                                           "TRMC_MID_K": str(int(rng.choice([1, 2, 3, 4]))),

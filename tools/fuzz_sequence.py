@@ -62,7 +62,9 @@ def one_round(rng, nseg_max):
            "TRMC_WIDE_K": str(int(rng.choice([2, 4, 8, 16]))),
            "TRMC_WIDE_LEVELS": str(int(rng.choice([2, 5, 16]))),
            "TRMC_MID_MIN_ROWS": str(int(rng.choice([0, 0, 8, 64]))),      # (a second tier of tiles below the wide levels)
-           "TRMC_MID_K": str(int(rng.choice([1, 2, 4]))), "TRMC_MID_LEVELS": str(int(rng.choice([3, 12, 32])))}
+           "TRMC_MID_K": str(int(rng.choice([1, 2, 4]))), "TRMC_MID_LEVELS": str(int(rng.choice([3, 12, 32]))),
+           # hot rows (the few rows of three or more iterations in blocks of their own): off / on, also on hinted plans
+           "TRMC_HOT_ROWS": str(int(rng.choice([0, 1, 1])))}
     dawdle = float(rng.choice([0.0, 0.0, 0.002, 0.01]))
     # every stride-th step of every row among each day's products (trmc_fetch_begin_fvd), in half of the rounds
     stride = int(rng.choice([0, 0, 1, 2, 3, qts, 7]))
