@@ -436,6 +436,10 @@ int trmc_download_gathered(trmc_plan *plan, void *out);
  * window k + 1 (the planes the gathers read are only overwritten by kernels queued after them).  hyd_host
  * [rows of the set][nsteps] and q0_host [nseg][3] should be page-locked (trmc_host_alloc); either may be NULL.
  * trmc_fetch_wait returns when both arrays are complete; one fetch in flight per plan. */
+/* Diagnosis: how many rows the tiles of this plan have routed from the hot list so far (trmc_plan_options.hot_rows; a running
+ * total over all launches and windows, modulo 2^31; waits for the device). */
+int trmc_plan_hot_rows(trmc_plan *plan, int64_t *rows_out);
+
 /* Tell a plan which steps a caller will ask for with trmc_fetch_begin_fvd: windows begun afterwards write every stride-th step
  * of (q, v, d) into a block of their own AS THEY GO -- the rows of the tiled leading levels from the kernel that routes them,
  * the others gathered from the time-major planes when the block is fetched -- instead of reading the whole result once more

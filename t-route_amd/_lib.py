@@ -138,6 +138,7 @@ SIGNATURES = {
     "trmc_download_gathered": (_int, [_vp, _vp]),
     "trmc_plan_set_stamps": (_int, [_vp, _vp, _i32]),
     "trmc_plan_set_output_stride": (_int, [_vp, _i32]),
+    "trmc_plan_hot_rows": (_int, [_vp, _P(_i64)]),
     "trmc_fetch_begin": (_int, [_vp, _i32, _vp, _vp]),
     "trmc_fetch_begin_fvd": (_int, [_vp, _i32, _vp, _vp, _int, _vp]),
     "trmc_fetch_wait": (_int, [_vp]),

@@ -711,7 +711,9 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // instructions per wavefront-step against 619 on the cost-ordered plan).  Gathered here they pace each other only.
         const int32_t cur = cold->hot_cur, cap = cold->hot_cap;
         const int32_t i = ((int32_t)blockIdx.x - cold->hot_home) * kTileBlock + (int32_t)threadIdx.x;
-        if (i >= min(cold->hot_cnt[cur], cap)) return;
+        const int32_t nlist = min(cold->hot_cnt[cur], cap);
+        if (i >= nlist) return;
+        if (threadIdx.x == 0) atomicAdd(&cold->hot_cnt[3], min(nlist - i, kTileBlock)); // (trmc_plan_hot_rows: a running total)
         s = hot_list[(size_t)cur * (size_t)cap + (size_t)i];
         from_hot = true;
         if (s < s_begin || s >= s_end) { // (listed by a window whose tiled levels reached further: back to where it is routed now)
@@ -2641,8 +2643,9 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                         const int32_t cap = std::max<int32_t>(kTileBlock, ((w1 - w0) / 32 + kTileBlock - 1) / kTileBlock * kTileBlock);
                         if (pl->hot_cap != cap || !pl->hot_list.p) { // (a tier of another size: the lists start empty, the marks are cleared)
                             if (int rc = pl->hot_list.ensure((size_t)3 * cap * sizeof(int32_t))) return rc;
-                            if (int rc = pl->hot_cnt.ensure(3 * sizeof(int32_t))) return rc;
-                            HIP_TRY(hipMemsetAsync(pl->hot_cnt.p, 0, 3 * sizeof(int32_t), ws));
+                            const bool first = !pl->hot_cnt.p;
+                            if (int rc = pl->hot_cnt.ensure(4 * sizeof(int32_t))) return rc;
+                            HIP_TRY(hipMemsetAsync(pl->hot_cnt.p, 0, (first ? 4 : 3) * sizeof(int32_t), ws));
                             if (!fresh) HIP_TRY(hipMemsetAsync(pl->cls_last.p, 0, (size_t)pl->nseg_pad, ws));
                             pl->hot_cap = cap;
                         }
@@ -3518,6 +3521,19 @@ int trmc_plan_set_sequence_mode(trmc_plan *pl, int on)
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
     pl->opt.sequence = on != 0;
+    return 0;
+}
+
+int trmc_plan_hot_rows(trmc_plan *pl, int64_t *rows_out)
+{
+    if (!pl || !rows_out) return fail(TRMC_EINVAL, "plan/rows_out is NULL");
+    *rows_out = 0;
+    if (!pl->hot_cnt.p) return 0;
+    if (int rc = use_device(pl)) return rc;
+    int32_t n = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&n, (const int32_t *)pl->hot_cnt.p + 3, sizeof n, hipMemcpyDeviceToHost));
+    *rows_out = n;
     return 0;
 }
 

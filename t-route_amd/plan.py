@@ -383,6 +383,12 @@ class RoutingPlan:
             _lib.check(_lib.lib().trmc_download_gathered(self._h, _lib.ptr(out)))
         return out
 
+    def hot_rows(self):
+        """Diagnosis (trmc_plan_hot_rows): rows the tiles have routed from the hot list so far, all windows together."""
+        n = C.c_int64(0)
+        _lib.check(_lib.lib().trmc_plan_hot_rows(self._h, C.byref(n)))
+        return n.value
+
     def set_output_stride(self, stride):
         """Windows begun from now on write every `stride`-th step of (q, v, d) aside as they go (trmc_plan_set_output_stride):
         what ``fetch_begin(..., output_stride=stride)`` then copies without another pass over the result; 0 / None: off."""

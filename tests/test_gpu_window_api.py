@@ -380,6 +380,38 @@ def test_windows_that_decimate_as_they_go_hand_over_the_same_block(monkeypatch, 
             plan.set_output_stride(-1)
 
 
+@pytest.mark.parametrize("hinted", [False, True])
+def test_hot_rows_are_routed_by_blocks_of_their_own_and_change_nothing(monkeypatch, hinted):
+    """trmc_plan_options.hot_rows: rows that end a tile in three or more secant iterations (or over bank) are taken out of their
+    blocks for the next tile.  A forcing that floods part of the network makes sure there are some -- more than the list holds
+    (the rest stay where they are) -- over several windows, and the result must be the one without the option, bit for bit."""
+    monkeypatch.setenv("TRMC_ENGINE", "levels")
+    monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
+    monkeypatch.setenv("TRMC_WIDE_K", "4")
+    to, ups, up_ptr, up_idx, p, qlat, q0 = small_forest(nseg=6000)
+    rng = np.random.default_rng(5)
+    qlat = qlat.copy()
+    qlat[rng.uniform(0, 1, qlat.shape[0]) < 0.08] *= np.float32(400.0)          # (over bank, many iterations)
+    nsteps, qts = 48, 12
+    out = {}
+    for hot in (0, 1):
+        monkeypatch.setenv("TRMC_HOT_ROWS", str(hot))
+        hint = (rng.integers(0, 4, to.shape[0]).astype(np.uint8) if hinted else None)
+        with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, cost_hint=hint) as plan:
+            res = []
+            plan.upload_forcing(nsteps, qlat, q0)
+            for k in range(3):
+                plan.route_device(nsteps, qts, True)
+                res.append(plan.download_fvd())
+                plan.upload_forcing(nsteps, qlat * np.float32(1.0 + 0.5 * (k + 1)), None)
+            assert plan.stats()["wide_levels"] > 0
+            n = plan.hot_rows()
+            assert (n > 200) == bool(hot), n
+            out[hot] = res
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_device_clock_stamps_of_consecutive_windows(monkeypatch):
     """trmc_plan_set_stamps: every window leaves the device clock at four points (tiles begin / end, tail begins / ends) in a
     page-locked ring -- in order inside a window, and the windows one after the other."""
