@@ -171,8 +171,8 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *                  plan created with a cost hint), > 0 = on, < 0 = off.
  *   hot_rows       the few rows of a wide tile that showed three or more secant iterations (or went over bank) in the tile before
  *                  are routed by blocks of their own in the next one, so that they do not set the pace of the wavefront they
- *                  would otherwise sit in (1.5 % of the rows of an unordered CONUS plan are in half of its wavefronts):
- *                  0 = default (on when the in-block partition is), > 0 = on, < 0 = off.
+ *                  would otherwise sit in (1.5 % of the rows of an unordered CONUS plan are in half of its wavefronts); those
+ *                  blocks are the first of the launch.  0 = default (on when the in-block partition is), > 0 = on, < 0 = off.
  *   tail_sort      < 0: keep the per-level order below the tiled levels of a hinted short-timestep plan (default: by cost).
  *   stem_min_rows  general-mode dataflow plans: basins whose longest path has at least so many rows are laid out stem-last
  *                  (0 = default 1 024, < 0 = off).

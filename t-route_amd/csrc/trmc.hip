@@ -378,8 +378,8 @@ constexpr int kBlock = 256;
 // The threads of a block take the block's NB positions by DESCENDING cost class (cls: one byte per position; 8 = no row): a count
 // per class in LDS, a prefix over the classes, a scatter of lane numbers.  Returns the lane whose position this thread takes.
 // Every thread of the block must call it (three barriers).  Order inside a class is whatever the atomics give; results do not
-// depend on which thread routes a row.
-template <int NB> __device__ __forceinline__ int32_t block_partition_by_class(int32_t key)
+// depend on which thread routes a row.  `none`: the position this thread takes is one of key 8 (no row there).
+template <int NB> __device__ __forceinline__ int32_t block_partition_by_class(int32_t key, bool &none)
 {
     __shared__ int32_t s_cnt[9], s_base[9];
     __shared__ int16_t s_lane[NB];
@@ -397,6 +397,7 @@ template <int NB> __device__ __forceinline__ int32_t block_partition_by_class(in
     __syncthreads();
     s_lane[s_base[key] + rank] = (int16_t)threadIdx.x;
     __syncthreads();
+    none = (int32_t)threadIdx.x >= s_base[8];
     return (int32_t)s_lane[threadIdx.x];
 }
 
@@ -471,7 +472,7 @@ template <class T> struct StepArgs {
     // lists of positions [3][hot_cap] and their lengths [3], used in turn: a launch reads `hot_cur`, appends to the next and
     // clears the length of the one after; bit 7 of cls_last = "this row is in the list the next launch reads".
     int32_t *hot_list, *hot_cnt;
-    int32_t hot_cap, hot_cur, hot_home; // (hot_home: blocks of the launch that take positions; the ones behind take the list)
+    int32_t hot_cap, hot_cur, hot_home; // (hot_home: the launch's first so many blocks take the list, the ones behind them positions)
 };
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
@@ -704,13 +705,19 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     int32_t s;
     bool from_hot = false;
     int32_t *const hot_list = a.cls_last ? cold->hot_list : nullptr;
-    if (hot_list && (int32_t)blockIdx.x >= cold->hot_home) {
-        // HOT ROWS.  The blocks behind the ones that take positions take the list the tile before left: the rows that ended it in
+    const int32_t hot_blocks = hot_list ? cold->hot_home : 0; // (the launch's FIRST blocks: the costliest rows start first)
+    if ((int32_t)blockIdx.x < hot_blocks) {
+        // HOT ROWS.  The first blocks of the launch take the list the tile before left: the rows that ended it in
         // class 3 or above -- three or more secant iterations, over bank; 1.5 % of the rows of an unordered CONUS plan, and one of
         // them in a wavefront makes all 64 lanes wait through its extra iterations (they sat in half of the wavefronts: 903
         // instructions per wavefront-step against 619 on the cost-ordered plan).  Gathered here they pace each other only.
+        // Bookkeeping: the mark (bit 7 of the row's class byte) is only ever set together with an entry in the list the NEXT
+        // launch reads, and that launch's list thread either routes the row -- and rewrites the byte at its end -- or clears
+        // the mark: no row is left marked without being listed.  A row that a list thread has routed AND found cooled down
+        // before a late block of the same launch looks at its byte is routed a second time by that block: the same steps from
+        // the same inputs (a tile reads nothing it writes), so the same values are stored twice -- work, not a difference.
         const int32_t cur = cold->hot_cur, cap = cold->hot_cap;
-        const int32_t i = ((int32_t)blockIdx.x - cold->hot_home) * kTileBlock + (int32_t)threadIdx.x;
+        const int32_t i = (int32_t)blockIdx.x * kTileBlock + (int32_t)threadIdx.x;
         const int32_t nlist = min(cold->hot_cnt[cur], cap);
         if (i >= nlist) return;
         if (threadIdx.x == 0) atomicAdd(&cold->hot_cnt[3], min(nlist - i, kTileBlock)); // (trmc_plan_hot_rows: a running total)
@@ -721,7 +728,8 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             return;
         }
     } else {
-        const int32_t s_mine = s_begin + (int32_t)blockIdx.x * kTileBlock + (int32_t)threadIdx.x;
+        const int32_t home = (int32_t)blockIdx.x - hot_blocks;
+        const int32_t s_mine = s_begin + home * kTileBlock + (int32_t)threadIdx.x;
         s = s_mine;
         if (a.cls_last) {
             // Which row a thread takes: the block's kTileBlock positions dealt out by DESCENDING cost class -- the class every row
@@ -731,13 +739,14 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             // numbers.  (Until round 5 a launch of its own between the tiles, k_tile_perm, over groups of 256 positions: 13-25 us
             // of the tile stream per tile, 0.55 ms of a CONUS day spent between tiles.)  Order inside a class is whatever the
             // atomics give; results do not depend on which thread routes a row.  (Bit 7: the row is in the hot list.)
-            if (hot_list && blockIdx.x == 0 && threadIdx.x == 0) cold->hot_cnt[(cold->hot_cur + 2) % 3] = 0; // (the list after next)
+            if (hot_list && home == 0 && threadIdx.x == 0) cold->hot_cnt[(cold->hot_cur + 2) % 3] = 0; // (the list after next)
             const int32_t c = s_mine < s_end ? (int32_t)a.cls_last[s_mine] : 0x80;
             const int32_t key = (c & 0x80) ? 8 : 7 - min(c, 7); // bucket 0 = the costliest; 8 = no row
-            s = s_begin + (int32_t)blockIdx.x * kTileBlock + block_partition_by_class<kTileBlock>(key);
+            bool none;
+            s = s_begin + home * kTileBlock + block_partition_by_class<kTileBlock>(key, none);
+            if (none) return; // (behind the tier's last position, or routed by a block of the hot list)
         }
         if (s >= s_end) return;
-        if (hot_list && (a.cls_last[s] & 0x80)) return; // (routed by a block of the hot list)
     }
     const int32_t behind = tile - a.level[s];
     const int32_t t_lo = behind * K + 1, t_hi = min(behind * K + K, a.nsteps);
@@ -2167,7 +2176,7 @@ struct trmc_plan {
         int64_t mid_min_rows = 0;            // <= 0: no second tier
         int32_t mid_levels = 12, mid_k = 4;
         int32_t tile_perm_group = -1;        // -1: the default (see route_advance_t); 0: off; 1: on
-        int32_t hot_rows = -1;               // -1: with the partition; 0: off; 1: on
+        int32_t hot_rows = -1;               // -1 (default) or 1: with the partition; 0: off
         bool sequence = false;
         bool flow_overlap = false;
         int32_t flow_lean = 0;
@@ -2364,9 +2373,9 @@ inline void launch_step(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_
 template <class T>
 inline void launch_tile(hipStream_t st, const StepArgs<T> &a, int32_t p0, int32_t p1, int32_t tile, int32_t K, bool tol)
 {
-    // (with hot rows: a.hot_home blocks take positions, the blocks behind them the list)
+    // (with hot rows: the first a.hot_home blocks take the list, the blocks behind them positions)
     const unsigned home = (unsigned)((p1 - p0 + kTileBlock - 1) / kTileBlock);
-    const dim3 grid(home + (a.hot_list ? (unsigned)((a.hot_cap + kTileBlock - 1) / kTileBlock) : 0u)), block(kTileBlock);
+    const dim3 grid(home + (a.hot_list ? (unsigned)a.hot_home : 0u)), block(kTileBlock);
     const bool dec = a.dec != nullptr;
     if constexpr (sizeof(T) == 4) {
         if (tol) {
@@ -2638,8 +2647,11 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     if (int rc = pl->cls_last.ensure((size_t)pl->nseg_pad)) return rc;
                     if (fresh) HIP_TRY(hipMemsetAsync(pl->cls_last.p, 0, (size_t)pl->nseg_pad, ws)); // (no history yet: one class)
                     at.cls_last = (uint8_t *)pl->cls_last.p;
-                    // hot rows (trmc_plan_options.hot_rows): by default where the plan's own order does not group them already
-                    if (pl->opt.hot_rows > 0 || (pl->opt.hot_rows < 0 && !pl->hinted)) {
+                    // hot rows (trmc_plan_options.hot_rows): with the partition unless switched off.  Measured on the CONUS sequence
+                    // (ms per day, with / without): plan built from the topology alone 17.4 / 19.5; cost-ordered plan on its own
+                    // kind of days 16.22 / 16.34 -- once the list's blocks were made the FIRST of the launch: behind the others
+                    // (the costliest rows of all started last, every launch ended on them) it was 16.7 / 16.2 and 18.3 / 19.4.
+                    if (pl->opt.hot_rows != 0) {
                         const int32_t cap = std::max<int32_t>(kTileBlock, ((w1 - w0) / 32 + kTileBlock - 1) / kTileBlock * kTileBlock);
                         if (pl->hot_cap != cap || !pl->hot_list.p) { // (a tier of another size: the lists start empty, the marks are cleared)
                             if (int rc = pl->hot_list.ensure((size_t)3 * cap * sizeof(int32_t))) return rc;
@@ -2652,7 +2664,7 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                         at.hot_list = (int32_t *)pl->hot_list.p;
                         at.hot_cnt = (int32_t *)pl->hot_cnt.p;
                         at.hot_cap = cap;
-                        at.hot_home = (w1 - w0 + kTileBlock - 1) / kTileBlock;
+                        at.hot_home = (cap + kTileBlock - 1) / kTileBlock;
                     }
                 }
                 stamp(pl, ws, 0);
