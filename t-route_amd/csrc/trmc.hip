@@ -691,6 +691,10 @@ constexpr int64_t kMidDefaultRowsPerCu = 0; // default threshold of the second t
 // latencies with other wavefronts and is close to its issue limit at four
 #define TRMC_TILE_WAVES 5
 #endif
+#ifndef TRMC_HOT_WAVE_MAX // a wavefront with at least so many hot rows keeps them (k_mc_tile's epilogue); measured on the CONUS
+// sequence, ms per day on the cost-ordered / the unordered plan: 6: 16.06 / 17.55, 16: 16.07 / 17.33, 40: 16.06 / 17.36
+#define TRMC_HOT_WAVE_MAX 16
+#endif
 template <class T, bool TOL = false, bool DEC = false>
 __global__ void __launch_bounds__(kTileBlock, sizeof(T) == 4 ? TRMC_TILE_WAVES : 1)
 k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t tile, const int32_t K)
@@ -899,7 +903,7 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // (a row that has finished the window starts the next one in its block; and a wavefront that holds sixteen or more of
         // them -- the first blocks of every level of a cost-ordered plan -- keeps them: they pace each other where they are)
         const bool hot = hot_list && c >= 3 && t_hi < cold->nsteps;
-        if (hot && (from_hot || __builtin_popcountll(__ballot(hot)) < 16)) {
+        if (hot && (from_hot || __builtin_popcountll(__ballot(hot)) < TRMC_HOT_WAVE_MAX)) {
             const int32_t nxt = (cold->hot_cur + 1) % 3, cap = cold->hot_cap;
             const int32_t i = atomicAdd(&cold->hot_cnt[nxt], 1);
             if (i < cap) {
