@@ -521,7 +521,10 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         const int32_t s = s_begin + (int32_t)blockIdx.x * kStepBlock + (int32_t)threadIdx.x;
         // (the block's rows dealt to its threads by the class of the step before, as k_mc_tile does once per K steps, was
         // built and measured here in round 5 -- some fifty instructions and four barriers per step: untuned plan 19.39 ms per
-        // day against 19.44 without, tuned plan 16.15 against 16.09, tolerance arithmetic 13.5 against 12.4 -- and removed)
+        // day against 19.44 without, tuned plan 16.15 against 16.09, tolerance arithmetic 13.5 against 12.4 -- and removed.
+        // So were k_mc_tile's hot rows per STEP -- the rows of three or more iterations in the step before routed by the
+        // launch's first blocks, an atomic append per hot row and launch: cost-ordered plan 16.67 ms per day against 16.2,
+        // unordered 20.1 against 17.3 -- these launches are the window's dependent chain, and what lengthens one lengthens it.)
         if (s >= s_end) return;
         const int32_t t = SHORT ? (LAG ? diag - a.lag[s] : diag) : diag - a.level[s];
         if (t < 1 || t > a.nsteps) return;
