@@ -2156,6 +2156,8 @@ struct trmc_plan {
     size_t gathered_bytes = 0;
     int64_t nq = 0;
     bool qlat_direct = false;   // qlat_tm was filled by trmc_upload_forcing_packed: no transpose at route time
+    DevBuf qlat_alt;            // sequence mode: the STAGED forcing already transposed (trmc_stage_forcing, behind its copy) into
+    bool qlat_alt_ready = false; // the buffer the window in progress does not read; the next window's set-up swaps the two
     bool have_boundary = true;  // boundary hydrographs present for the staged window
     int32_t staged_nsteps = -1; // nsteps the staged forcing was uploaded for
     int32_t routed_nsteps = -1; // nsteps of the last completed route
@@ -2440,6 +2442,9 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     hipStream_t st = pl->stream;
     const size_t plane = (size_t)(nsteps + 1) * np;
     if (int rc = pl->tm.ensure(3 * plane * sizeof(T))) return rc;
+    const bool qlat_early = pl->qlat_alt_ready; // (the staged forcing is in plan order already: the other buffer becomes this window's)
+    if (qlat_early) std::swap(pl->qlat_tm, pl->qlat_alt);
+    pl->qlat_alt_ready = false;
     if (int rc = pl->qlat_tm.ensure((size_t)pl->nq * np * sizeof(T))) return rc;
     if (int rc = pl->out.ensure((size_t)pl->nseg * nsteps * 3 * sizeof(T))) return rc;
     if (pl->nres > 0)
@@ -2496,7 +2501,7 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
     // of routed positions by k_mc_step and of boundary positions by k_fill_boundary (the padding
     // lanes of each row are never read), so the reference's zero fill (mc_reach.pyx:253) is moot
     if (n > 0) {
-        if (!pl->qlat_direct)
+        if (!pl->qlat_direct && !qlat_early)
             hipLaunchKernelGGL((k_prep_qlat<T>), dim3((n + 63) / 64, (unsigned)((pl->nq + 31) / 32)), dim3(kBlock), 0, st,
                                (const T *)pl->in_qlat.p, row_of_pos, (T *)pl->qlat_tm.p, n, np, (int32_t)pl->nq);
         if (!pl->chain_staged) // (else: time row 0 was set on the device by trmc_plan_chain_from)
@@ -3788,7 +3793,7 @@ void trmc_plan_destroy(trmc_plan *pl)
             pl->rowsets.clear();
             for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->fetch_fvd, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
                               &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos, &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos,
-                              &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch,
+                              &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->qlat_alt, &pl->tm, &pl->out, &pl->scratch,
                               &pl->gathered, &pl->cls_last, &pl->hot_list, &pl->hot_cnt})
                 b->release();
         }
@@ -3811,7 +3816,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
     for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
-                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last, &pl->hot_list, &pl->hot_cnt})
+                      &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->qlat_alt, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last, &pl->hot_list, &pl->hot_cnt})
         b->release();
     for (auto &e : pl->ev)
         if (e) (void)hipEventDestroy(e);
@@ -3958,6 +3963,23 @@ int trmc_stage_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq)
     // (behind the set-up of the window in progress, which reads the staging area)
     if (busy) HIP_TRY(hipStreamWaitEvent(pl->hstream, pl->ev[1], 0));
     if (pl->nseg > 0) HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, bytes, hipMemcpyHostToDevice, pl->hstream));
+    // Sequence mode, level engine: the transpose into plan order right behind the copy, into the forcing buffer the window in
+    // progress does not read -- 0.27 ms of a CONUS day that the next window's set-up, which sits in the tile queue between
+    // one day's last tile and the next day's first, no longer has to do
+    pl->qlat_alt_ready = false;
+    if (pl->opt.sequence && !pl->flow && pl->nseg > 0) {
+        if (int rc = pl->qlat_alt.ensure((size_t)nq * pl->nseg_pad * pl->esz)) return rc;
+        const int32_t n = (int32_t)pl->nseg;
+        const dim3 grid((n + 63) / 64, (unsigned)((nq + 31) / 32));
+        if (pl->precision == 32)
+            hipLaunchKernelGGL((k_prep_qlat<float>), grid, dim3(kBlock), 0, pl->hstream, (const float *)pl->in_qlat.p,
+                               (const int32_t *)pl->row_of_pos.p, (float *)pl->qlat_alt.p, n, pl->nseg_pad, (int32_t)nq);
+        else
+            hipLaunchKernelGGL((k_prep_qlat<double>), grid, dim3(kBlock), 0, pl->hstream, (const double *)pl->in_qlat.p,
+                               (const int32_t *)pl->row_of_pos.p, (double *)pl->qlat_alt.p, n, pl->nseg_pad, (int32_t)nq);
+        HIP_TRY(hipGetLastError());
+        pl->qlat_alt_ready = true;
+    }
     HIP_TRY(hipEventRecord(pl->ev_forcing, pl->hstream));
     pl->forcing_pending = true;
     pl->qlat_direct = false;
@@ -4074,6 +4096,7 @@ int trmc_upload_forcing(trmc_plan *pl, int nsteps, const void *qlat, int64_t nq,
     if (pl->nseg > 0)
         HIP_TRY(hipMemcpyAsync(pl->in_qlat.p, qlat, (size_t)pl->nseg * nq * e, hipMemcpyHostToDevice, pl->stream));
     pl->qlat_direct = false;
+    pl->qlat_alt_ready = false; // (a staged forcing, transposed already, is replaced by this one)
     return stage_state(pl, nsteps, nq, q0, boundary_fvd);
 }
 
@@ -4124,6 +4147,7 @@ int trmc_upload_forcing_packed(trmc_plan *pl, int nsteps, int64_t nq, int64_t nf
         HIP_TRY(hipGetLastError());
     }
     pl->qlat_direct = true;
+    pl->qlat_alt_ready = false;
     // (feat_of_pos is pageable host memory: the copy above must have been consumed before it goes out of scope;
     // stage_state ends with a stream synchronisation)
     return stage_state(pl, nsteps, nq, q0, boundary_fvd);
