@@ -22,6 +22,12 @@ rows = [(short(n), s, e, q, st) for n, s, e, q, st in rows]
 # a window starts with its forcing transpose (the windows of a sequence handed on in HBM have no k_init_state); in such a
 # sequence the next-to-last window is the one shown, between its transpose and the last window's
 starts = [i for i, r in enumerate(rows) if r[0] == "k_prep_qlat"] or [i for i, r in enumerate(rows) if r[0] == "k_init_state"]
+# (a sequence of two plans in sequence mode transposes a day's forcing a day EARLY, behind its copy: there the windows are
+# told apart by the tile stream, which alternates between the plans)
+tiles_at = [i for i, r in enumerate(rows) if r[0] == "k_mc_tile"]
+groups = [i for j, i in enumerate(tiles_at) if j == 0 or rows[tiles_at[j - 1]][4] != rows[i][4]]
+if len(groups) >= 3:
+    starts = groups
 if not starts:
     sys.exit("no window found")
 i0 = starts[-1]
@@ -34,7 +40,7 @@ if len(starts) >= 2 and not any(r[0] == "k_init_state" for r in win):
     i0, i1 = starts[-2], starts[-1]
     inter = rows[i0:i1]
     mine = set()
-    for kind in ("k_mc_tile", "k_mc_step", "k_emit", "k_prep_qlat"):
+    for kind in ("k_mc_tile", "k_mc_step", "k_emit") + (() if starts is groups else ("k_prep_qlat",)):
         on = [r[4] for r in inter if r[0] == kind]
         if on:
             mine.add((kind, on[-1]))
