@@ -1,9 +1,12 @@
+#!/usr/bin/env python3
+"""Experiment: how many rows the hot lists of k_mc_tile carry per launch (trmc_plan_hot_rows) on the plan built from the
+topology alone and on the cost-ordered plan, and what a resident CONUS day takes with and without them."""
 import os, sys
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from troute_amd import synthetic
 from troute_amd.distributed import ShardedRouter
-net = synthetic.generate(cache_dir="/tmp/trmc_cache")
+net = synthetic.generate(cache_dir=os.environ.get("TRMC_CACHE", "/tmp/trmc_cache"))
 to, params, qlat = net["to"], net["params"], net["qlat"]
 n = to.shape[0]
 q0 = np.zeros((n, 3), np.float32)
