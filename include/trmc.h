@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 17
+#define TRMC_ABI_VERSION 18
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -173,6 +173,17 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *                  are routed by blocks of their own in the next one, so that they do not set the pace of the wavefront they
  *                  would otherwise sit in (1.5 % of the rows of an unordered CONUS plan are in half of its wavefronts); those
  *                  blocks are the first of the launch.  0 = default (on when the in-block partition is), > 0 = on, < 0 = off.
+ *   cluster_rows   (since ABI 18) > 0: a plan created with TRMC_PLAN_SHORT_TS on the level engine lays the rows BELOW its wide
+ *                  levels out in clusters -- connected pieces of the network of at most so many rows (at most 128 = one workgroup)
+ *                  -- and routes them wide_k steps per launch as well (k_mc_ctile: flows inside a cluster through LDS, a cluster
+ *                  level one tile behind the one that feeds it) instead of one launch per timestep: what a STREAM of windows
+ *                  needs (trmc_stream_*; there wide_min_rows may be small -- more levels in slices cost nothing).  0 (default):
+ *                  no cluster order -- a single window pays for the clusters' skew with some thirty small launches at its end.
+ *                  Such a plan routes with assume_short_ts only.  Single windows whose boundary hydrographs arrive chunk by
+ *                  chunk or whose rows carry a lag (trmc_plan_set_lag) keep the one-step launches.
+ *   cluster_late_lag  cluster order: rows fed by boundary rows (and rows marked 2 in `boundary`) run at least so many tiles
+ *                  behind the headwaters -- the trunk of a cut basin in a multi-GPU stream, whose inflows are exchanged once a
+ *                  day (troute_amd.sequence.RouteStream).
  *   tail_sort      < 0: keep the per-level order below the tiled levels of a hinted short-timestep plan (default: by cost).
  *   stem_min_rows  general-mode dataflow plans: basins whose longest path has at least so many rows are laid out stem-last
  *                  (0 = default 1 024, < 0 = off).
@@ -201,11 +212,50 @@ typedef struct trmc_plan_options {
     int32_t flow_lean;
     int32_t flow_debug;
     int32_t hot_rows;
-    int32_t reserved[7];
+    int32_t cluster_rows;
+    int32_t cluster_late_lag;
+    int32_t reserved[5];
 } trmc_plan_options;
 int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                          const float *params, const uint8_t *boundary, const uint8_t *cost_hint,
                          int precision, int device, int flags, const trmc_plan_options *options, trmc_plan **out);
+/* A STREAM OF WINDOWS on one plan (since ABI 18; csrc/stream.inc): the reference's run-set loop -- compute_nhd_routing_v02 per run
+ * set, every call with that window's qlat_values (mc_reach.pyx:173,:723), new_q0 between them (AbstractNetwork.py:177-191; loop
+ * nwm_routing/__main__.py:195-333) -- as ONE sequence of tile launches whose tile index runs on over the days.  assume_short_ts
+ * only; the plan must be in cluster order (TRMC_PLAN_SHORT_TS on the level engine, cluster_rows >= 0), without reservoirs,
+ * nudging tables or lagged rows.  Every launch routes every row through the next wide_k steps of ITS place in the stream (a row
+ * `lag` tiles behind the headwaters works on an earlier tile, possibly of the day before): nsteps / wide_k launches per day, no
+ * launches that only part of the network has work in, nothing between two days.  Results are the bits of the same days routed
+ * one by one.
+ *   trmc_stream_begin  after trmc_upload_forcing (the state q0 -- or NULL: what the plan's last window left -- and the shape of
+ *                      the forcing: every day has its nq columns).  slots: days the ring holds (0 = as many as the rows' lag needs:
+ *                      2 + ceil((lag_max + 1) / tiles_per_day)); full_output != 0: every day's out[nseg][nsteps][3] is assembled
+ *                      (9.4 GB per slot for CONUS) and may be asked for; output_stride = n > 0: every n-th step of every row's
+ *                      (q, v, d) is (what the reference's writers take, nwm_routing/output.py:209-216) -- otherwise a day's
+ *                      products are its row-set hydrographs and its final state only and nothing else is written.
+ *   trmc_stream_push   the next day: qlat [nseg][nq] on the host (page-locked memory for a copy that runs beside the launches; it
+ *                      must stay unchanged until the day has begun on the device -- e.g. until the push after next returns);
+ *                      boundary_q_dev: flows of the plan's boundary rows for the day [nboundary][nsteps] in DEVICE memory (NULL
+ *                      without boundary rows); where the day's products go (any may be NULL): hyd_host [rows of rowset][nsteps],
+ *                      q0_host [nseg][3], fvd_host [nseg][nsteps / output_stride][3] (or [nseg][nsteps][3] with full_output and no
+ *                      stride) -- page-locked host arrays, filled when the day's LAST row has been routed through it, lag_max
+ *                      launches into the days that follow.
+ *   trmc_stream_flush  queues the launches that end every pushed day (nothing new starts); further days may be pushed afterwards.
+ *   trmc_stream_wait   blocks until the products of `day` (0-based count of pushes) are on the host; TRMC_ESTATE if the day has
+ *                      not been queued to its end yet (push on, or flush).
+ *   trmc_stream_end    flush + wait for the device; the last day's final state stays staged (trmc_upload_forcing with q0 = NULL,
+ *                      or another stream, continues from it).
+ *   trmc_stream_info   facts: slots, tiles per day, the largest lag in tiles, wide levels, cluster levels, days pushed, days
+ *                      queued to their end, tile launches so far (any pointer may be NULL). */
+int trmc_stream_begin(trmc_plan *plan, int nsteps, int qts_subdivisions, int slots, int full_output, int output_stride);
+int trmc_stream_push(trmc_plan *plan, const void *qlat, int64_t nq, const void *boundary_q_dev, int32_t rowset, void *hyd_host,
+                     void *q0_host, void *fvd_host);
+int trmc_stream_flush(trmc_plan *plan);
+int trmc_stream_wait(trmc_plan *plan, int64_t day);
+int trmc_stream_info(const trmc_plan *plan, int32_t *slots, int32_t *tiles_per_day, int32_t *lag_max, int32_t *wide_levels,
+                     int32_t *cluster_levels, int64_t *days_pushed, int64_t *days_complete, int64_t *launches);
+int trmc_stream_end(trmc_plan *plan);
+
 /* Switch the sequence mode of a plan (see trmc_plan_options) between windows. */
 int trmc_plan_set_sequence_mode(trmc_plan *plan, int on);
 /* 1 if the plan computes in TRMC_ARITH_TOLERANCE, else 0. */
@@ -225,6 +275,17 @@ int trmc_topology_levels(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
 int trmc_topology_levels_hinted(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                                 const uint8_t *boundary, const uint8_t *cost_hint, int32_t *level_of_row,
                                 int64_t *plan_pos_of_row, int32_t *nlevels);
+
+/* Host-only (since ABI 18): the CLUSTER ORDER a short-timestep plan of the level engine is laid out in (trmc_plan_options.cluster_rows;
+ * csrc/topology.hpp).  The leading levels of at least wide_min_rows rows (at most wide_max_levels of them) stay level slices; the
+ * rows below them form clusters of at most cluster_rows rows, packed into blocks of one cluster level each.  lag_of_row[nseg]:
+ * tiles a row runs behind level 0 (-1 for boundary rows) -- a row only reads rows of its own block with its own lag, or rows
+ * with a smaller one; block_of_row[nseg]: its cluster block, -1 in the slices.  Outputs may be NULL.
+ * Reference analogue: build_subnetworks (nhd_network.py:691-771). */
+int trmc_topology_clusters(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
+                           const uint8_t *cost_hint, int64_t wide_min_rows, int32_t wide_max_levels, int32_t cluster_rows,
+                           int64_t *plan_pos_of_row, int32_t *lag_of_row, int32_t *block_of_row, int32_t *wide_levels,
+                           int32_t *cluster_levels, int32_t *cluster_blocks);
 
 /* Host-only: the BLOCK ORDER of the dataflow engine (fp32 plans; csrc/topology.hpp) -- routed rows in depth-first
  * post-order, stably sorted by a downstream-monotone cost tier (cost_tiers != 0), cut into blocks of *block_rows positions (one workgroup
@@ -250,6 +311,9 @@ int trmc_topology_blocks_general(int64_t nseg, const int64_t *up_ptr, const int6
 /* Facts about the flattened topology (host side, no device work). */
 int trmc_plan_info(const trmc_plan *plan, int64_t *nseg, int64_t *nseg_routed,
                    int32_t *nlevels, int32_t *precision, int32_t *device);
+/* A plan in cluster order (trmc_plan_options.cluster_rows): lag_of_row[nseg] = tiles every row runs behind the headwaters (-1:
+ * boundary row), the number of levels kept as slices, the number of cluster levels.  Pointers may be NULL. */
+int trmc_plan_lags(const trmc_plan *plan, int32_t *lag_of_row, int32_t *wide_levels, int32_t *cluster_levels);
 /* level_of_row[nseg] (-1 for boundary rows); plan_pos_of_row[nseg] = position in
  * the level-major device order.  Either pointer may be NULL. */
 int trmc_plan_levels(const trmc_plan *plan, int32_t *level_of_row, int64_t *plan_pos_of_row);

@@ -40,7 +40,7 @@ class PlanOptions(C.Structure):
         ("wide_k", C.c_int32), ("mid_min_rows", C.c_int64), ("mid_levels", C.c_int32), ("mid_k", C.c_int32),
         ("tile_perm_group", C.c_int32), ("tail_sort", C.c_int32), ("stem_min_rows", C.c_int32), ("sequence_mode", C.c_int32),
         ("flow_watchdog_ms", C.c_int32), ("flow_overlap", C.c_int32), ("flow_lean", C.c_int32), ("flow_debug", C.c_int32), ("hot_rows", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("cluster_rows", C.c_int32), ("cluster_late_lag", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -51,7 +51,7 @@ ARITH_EXACT, ARITH_TOLERANCE = 0, 1
 OPTION_ENV = {
     "TRMC_WIDE_MIN_ROWS": ("wide_min_rows", "off0"), "TRMC_WIDE_LEVELS": ("wide_levels", "int"), "TRMC_WIDE_K": ("wide_k", "int"),
     "TRMC_MID_MIN_ROWS": ("mid_min_rows", "off0"), "TRMC_MID_LEVELS": ("mid_levels", "int"), "TRMC_MID_K": ("mid_k", "int"),
-    "TRMC_TILE_PERM": ("tile_perm_group", "off0"), "TRMC_HOT_ROWS": ("hot_rows", "off0"), "TRMC_TAIL_SORT": ("tail_sort", "off0"),
+    "TRMC_TILE_PERM": ("tile_perm_group", "off0"), "TRMC_HOT_ROWS": ("hot_rows", "off0"), "TRMC_CLUSTER_ROWS": ("cluster_rows", "int"), "TRMC_TAIL_SORT": ("tail_sort", "off0"),
     "TRMC_STEM_MIN_ROWS": ("stem_min_rows", "off0"), "TRMC_SETUP_ASIDE": ("sequence_mode", "flag"),
     "TRMC_FLOW_WATCHDOG_MS": ("flow_watchdog_ms", "int"), "TRMC_FLOW_OVERLAP": ("flow_overlap", "flag"),
     "TRMC_FLOW_LEAN": ("flow_lean", "lean"), "TRMC_FLOW_DEBUG": ("flow_debug", "flag"),
@@ -99,15 +99,23 @@ SIGNATURES = {
     "trmc_plan_create_ex": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _P(_vp)]),
     "trmc_plan_create_opt": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _P(PlanOptions), _P(_vp)]),
     "trmc_plan_set_sequence_mode": (_int, [_vp, _int]),
+    "trmc_stream_begin": (_int, [_vp, _int, _int, _int, _int, _int]),
+    "trmc_stream_push": (_int, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "trmc_stream_flush": (_int, [_vp]),
+    "trmc_stream_wait": (_int, [_vp, _i64]),
+    "trmc_stream_info": (_int, [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i32), _P(_i32), _P(_i64), _P(_i64), _P(_i64)]),
+    "trmc_stream_end": (_int, [_vp]),
     "trmc_plan_arithmetic": (_int, [_vp, _P(_i32)]),
     "trmc_plan_engine": (_int, [_vp, _P(_i32)]),
     "trmc_plan_destroy": (None, [_vp]),
     "trmc_topology_levels": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
     "trmc_topology_levels_hinted": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _P(_i32)]),
+    "trmc_topology_clusters": (_int, [_i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _P(_i32), _P(_i32), _P(_i32)]),
     "trmc_topology_blocks": (_int, [_i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _P(_i32), _P(_i32)]),
     "trmc_topology_blocks_general": (_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _P(_i32), _P(_i32), _vp, _i32, _P(_i32)]),
     "trmc_plan_info": (_int, [_vp, _P(_i64), _P(_i64), _P(_i32), _P(_i32), _P(_i32)]),
     "trmc_plan_levels": (_int, [_vp, _vp, _vp]),
+    "trmc_plan_lags": (_int, [_vp, _vp, _P(_i32), _P(_i32)]),
     "trmc_upload_forcing": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "trmc_upload_forcing_packed": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trmc_set_boundary_flow_device": (_int, [_vp, _int, _vp]),
@@ -190,9 +198,9 @@ SIGNATURES_DW = {
 
 _LIB = None
 # entry points that never touch the HIP runtime (everything else may initialise it: single_hw_queue_per_priority must know)
-_HOST_ONLY = {"trmc_last_error", "trmc_abi_version", "trmc_topology_levels", "trmc_topology_levels_hinted", "trmc_topology_blocks",
-              "trmc_topology_blocks_general", "trmc_get_stats", "trmc_plan_info", "trmc_plan_levels", "trmc_plan_engine",
-              "trmc_plan_arithmetic", "trdw_last_error", "trdw_last_timing", "trdw_configure", "trmc_comm_info"}
+_HOST_ONLY = {"trmc_last_error", "trmc_abi_version", "trmc_topology_levels", "trmc_topology_levels_hinted", "trmc_topology_blocks", "trmc_topology_clusters",
+              "trmc_topology_blocks_general", "trmc_get_stats", "trmc_plan_info", "trmc_plan_levels", "trmc_plan_lags", "trmc_plan_engine",
+              "trmc_plan_arithmetic", "trmc_stream_info", "trdw_last_error", "trdw_last_timing", "trdw_configure", "trmc_comm_info"}
 
 
 class _Marking:

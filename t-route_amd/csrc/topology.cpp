@@ -13,7 +13,7 @@ namespace trmc {
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &t, std::string &err, const uint8_t *cost_hint, int32_t block_rows,
                    bool cost_tiers, int32_t boundary_floor, int64_t wide_min_rows, int32_t wide_max_levels, int32_t stem_min_rows,
-                   int64_t mid_min_rows, int32_t mid_max_levels)
+                   int64_t mid_min_rows, int32_t mid_max_levels, int32_t cluster_rows, int32_t cluster_late_lag)
 {
     if (nseg < 0 || nseg >= std::numeric_limits<int32_t>::max()) {
         err = "nseg out of range";
@@ -497,6 +497,148 @@ int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
         }
     }
 
+    // the rows below the leading wide levels in clusters (topology.hpp, cluster_rows)
+    if (cluster_rows > 0 && t.nlevels > 0) {
+        int32_t W = 0;
+        if (wide_min_rows > 0)
+            while (W < t.nlevels && W < wide_max_levels && (int64_t)(t.lvl_ptr[W + 1] - t.lvl_ptr[W]) >= wide_min_rows) ++W;
+        t.lagk_of_pos.assign(nseg, 0);
+        if (W < t.nlevels) {
+            const int32_t B = cluster_rows;
+            // cluster level and cluster of every row below the slices, in Kahn order (`queue`: every row after the rows
+            // draining into it)
+            std::vector<int32_t> cl(nseg, -1), root(nseg), size(nseg, 1);
+            for (int64_t r = 0; r < nseg; ++r) root[r] = (int32_t)r;
+            auto find = [&](int32_t x) {
+                while (root[x] != x) {
+                    root[x] = root[root[x]];
+                    x = root[x];
+                }
+                return x;
+            };
+            std::vector<int32_t> tops;
+            int32_t maxcl = 0;
+            for (const int32_t r : queue) {
+                if (t.level_of_row[r] < W) continue;
+                int32_t m = -1;
+                for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) {
+                    const int32_t u = (int32_t)up_idx[k];
+                    if (!is_b(u) && t.level_of_row[u] >= W) m = std::max(m, cl[u]);
+                }
+                // (a row fed by a boundary row, or marked late: at least cluster_late_lag tiles behind level 0)
+                int32_t floor_c = 0;
+                if (cluster_late_lag > W) {
+                    bool late = is_late(r);
+                    for (int64_t k = up_ptr[r]; k < up_ptr[r + 1] && !late; ++k) late = is_b(up_idx[k]);
+                    if (late) floor_c = cluster_late_lag - W;
+                }
+                if (m < floor_c) { // only slices (or boundary rows, or nothing) drain into it -- or rows that run further ahead
+                    cl[r] = floor_c; //   than this one may: a cluster of its own
+                    maxcl = std::max(maxcl, floor_c);
+                    continue;
+                }
+                tops.clear();
+                int64_t tot = 1;
+                for (int64_t k = up_ptr[r]; k < up_ptr[r + 1]; ++k) {
+                    const int32_t u = (int32_t)up_idx[k];
+                    if (is_b(u) || t.level_of_row[u] < W || cl[u] != m) continue;
+                    const int32_t ru = find(u);
+                    if (std::find(tops.begin(), tops.end(), ru) == tops.end()) {
+                        tops.push_back(ru);
+                        tot += size[ru];
+                    }
+                }
+                if (tot <= B) {
+                    cl[r] = m;
+                    const int32_t r0 = tops[0];
+                    for (size_t i = 1; i < tops.size(); ++i) root[tops[i]] = r0;
+                    root[r] = r0;
+                    size[r0] = (int32_t)tot;
+                } else {
+                    cl[r] = m + 1;
+                    maxcl = std::max(maxcl, m + 1);
+                }
+            }
+            const int32_t C = maxcl + 1;
+            // the members of every cluster in Kahn order; clusters by level
+            std::vector<int32_t> cid(nseg, -1);
+            std::vector<std::vector<int32_t>> members;
+            std::vector<int32_t> cl_of, cost_of;
+            for (const int32_t r : queue) {
+                if (t.level_of_row[r] < W) continue;
+                const int32_t rt = find(r);
+                if (cid[rt] < 0) {
+                    cid[rt] = (int32_t)members.size();
+                    members.emplace_back();
+                    cl_of.push_back(cl[r]);
+                    cost_of.push_back(0);
+                }
+                const int32_t c = cid[rt];
+                members[(size_t)c].push_back(r);
+                if (cost_hint) cost_of[(size_t)c] = std::max(cost_of[(size_t)c], (int32_t)cost_hint[r]);
+            }
+            std::vector<std::vector<int32_t>> by_cl((size_t)C);
+            for (int32_t c = 0; c < (int32_t)members.size(); ++c) by_cl[(size_t)cl_of[(size_t)c]].push_back(c);
+            int32_t p = t.lvl_ptr[W];
+            t.cblk_ptr.clear();
+            t.cblk_of_cl.assign((size_t)C + 1, 0);
+            std::vector<std::vector<int32_t>> bins; // clusters of every block of the level being packed
+            std::vector<int32_t> fill;
+            for (int32_t c = 0; c < C; ++c) {
+                std::vector<int32_t> &cs = by_cl[(size_t)c];
+                // by descending cost, then by descending size: the costly clusters open the blocks, the small cheap ones fill
+                // what they leave (a block's threads take its rows by cost class anyway: k_mc_ctile)
+                std::stable_sort(cs.begin(), cs.end(), [&](int32_t a, int32_t b) {
+                    if (cost_of[(size_t)a] != cost_of[(size_t)b]) return cost_of[(size_t)a] > cost_of[(size_t)b];
+                    return members[(size_t)a].size() > members[(size_t)b].size();
+                });
+                bins.clear();
+                fill.clear();
+                // best fit: the fullest block that still takes the cluster (by_free[f]: blocks with f rows free)
+                std::vector<std::vector<int32_t>> by_free((size_t)B + 1);
+                for (const int32_t k : cs) {
+                    const int32_t n = (int32_t)members[(size_t)k].size();
+                    int32_t b = -1;
+                    for (int32_t f = n; f <= B && b < 0; ++f)
+                        if (!by_free[(size_t)f].empty()) {
+                            b = by_free[(size_t)f].back();
+                            by_free[(size_t)f].pop_back();
+                        }
+                    if (b < 0) {
+                        b = (int32_t)bins.size();
+                        bins.emplace_back();
+                        fill.push_back(0);
+                    }
+                    bins[(size_t)b].push_back(k);
+                    fill[(size_t)b] += n;
+                    by_free[(size_t)(B - fill[(size_t)b])].push_back(b);
+                }
+                t.cblk_of_cl[(size_t)c] = (int32_t)t.cblk_ptr.size();
+                for (const auto &bin : bins) {
+                    t.cblk_ptr.push_back(p);
+                    for (const int32_t k : bin)
+                        for (const int32_t r : members[(size_t)k]) {
+                            t.row_of_pos[p] = r;
+                            t.pos_of_row[r] = p;
+                            t.lagk_of_pos[p] = W + c;
+                            ++p;
+                        }
+                }
+            }
+            t.cblk_of_cl[(size_t)C] = (int32_t)t.cblk_ptr.size();
+            t.cblk_ptr.push_back(p);
+            if (p != t.lvl_ptr[t.nlevels]) {
+                err = "internal: the cluster order lost rows";
+                return -2;
+            }
+            t.ncl = C;
+            t.tail_from_level = W; // (the deeper levels are not contiguous slices any more)
+        }
+        for (int32_t l = 0; l < W; ++l)
+            for (int32_t q = t.lvl_ptr[l]; q < t.lvl_ptr[l + 1]; ++q) t.lagk_of_pos[q] = l;
+        t.cl_rows = cluster_rows;
+        t.cl_from_level = W;
+    } else
     // the rows below the leading wide levels: by descending cost across levels (topology.hpp, wide_min_rows)
     if (cost_hint && wide_min_rows > 0 && wide_max_levels > 0) {
         int32_t W = 0;

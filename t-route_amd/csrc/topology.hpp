@@ -44,6 +44,14 @@ struct Topology {
                                          // costliest row it holds (cost hint, else drainage size); costlier = higher
     std::vector<int32_t> early_blocks;   // block order with stem_min_rows > 0: the blocks that hold the long main stems, ascending
                                          // (the general mode starts them FIRST, see build_topology)
+    // CLUSTER ORDER of the rows below the leading wide levels (build_topology with cluster_rows > 0; a short-timestep plan of
+    // the level engine only): see below
+    int32_t cl_rows = 0;                 // 0: none; else the most rows a cluster block holds
+    int32_t cl_from_level = 0;           // W: the levels below it are level slices, the rows of the deeper ones are in clusters
+    int32_t ncl = 0;                     // cluster levels: cluster level c runs W + c tiles behind level 0
+    std::vector<int32_t> cblk_ptr;       // [ncblk + 1] plan positions: cluster block b holds [cblk_ptr[b], cblk_ptr[b + 1])
+    std::vector<int32_t> cblk_of_cl;     // [ncl + 1] first block of every cluster level
+    std::vector<int32_t> lagk_of_pos;    // [nseg] tiles a position runs behind level 0: its level (slices), W + c (clusters), 0 (boundary)
 };
 
 // Returns 0 on success; -1 bad argument, -2 cycle.  `err` receives a message.
@@ -91,9 +99,24 @@ struct Topology {
 // over its basin instead of after it.  Topology::early_blocks lists the blocks that hold such stems; k_mc_flow<false> hands
 // them out first (they wait for their inflows in place; every other block still only needs blocks that were started before
 // it or are among those few).
+// cluster_rows > 0 (level order, a plan that is only ever routed with assume_short_ts): the rows BELOW the leading wide levels
+// (the same rule as above picks those; none of them is wide: every routed row) are laid out in CLUSTERS -- connected pieces of
+// the network of at most cluster_rows rows -- so that the level engine can route them several timesteps per launch as well
+// (k_mc_ctile): the rows of a cluster advance together and hand their flows to each other through LDS, a cluster only reads
+// rows OUTSIDE itself that run at least one tile ahead.  Cluster level of a row: W if nothing below the wide levels drains into
+// it; else m = the highest cluster level among the rows draining into it, if the clusters of that level among them and the
+// row itself fit into one cluster (they are merged); else m + 1 (a new cluster).  A chain of the network therefore climbs one
+// cluster level per cluster_rows rows it collects, not one per row: the 3 538 levels of the synthetic CONUS network become
+// 6 slices + 29 cluster levels of 128 rows.  Clusters of one level are packed into blocks of at most cluster_rows rows (by
+// descending cost hint, so that a block holds clusters of one cost), blocks are ordered by cluster level: a launch takes a
+// contiguous range of them.  cluster_late_lag > 0: a row fed by a boundary row (or marked late) runs at least so many tiles
+// behind level 0 -- the trunk of a cut basin, whose inflows from other GPUs arrive a day or two after they were routed
+// (troute_amd.sequence).  Results do not depend on it.  Reference analogue: build_subnetworks (nhd_network.py:691-771) --
+// there sub-networks of 10 000 segments handed from one order to the next by the host, here of 128 rows pipelined in time.
 int build_topology(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                    const uint8_t *boundary, Topology &topo, std::string &err, const uint8_t *cost_hint = nullptr,
                    int32_t block_rows = 0, bool cost_tiers = true, int32_t boundary_floor = 0, int64_t wide_min_rows = 0,
-                   int32_t wide_max_levels = 0, int32_t stem_min_rows = 0, int64_t mid_min_rows = 0, int32_t mid_max_levels = 0);
+                   int32_t wide_max_levels = 0, int32_t stem_min_rows = 0, int64_t mid_min_rows = 0, int32_t mid_max_levels = 0,
+                   int32_t cluster_rows = 0, int32_t cluster_late_lag = 0);
 
 } // namespace trmc

@@ -473,7 +473,33 @@ template <class T> struct StepArgs {
     // clears the length of the one after; bit 7 of cls_last = "this row is in the list the next launch reads".
     int32_t *hot_list, *hot_cnt;
     int32_t hot_cap, hot_cur, hot_home; // (hot_home: the launch's first so many blocks take the list, the ones behind them positions)
+    // STREAM of windows (trmc_stream_*; tile kernels only): the launch index counts tiles over ALL days -- a position `lag` tiles
+    // behind works on tile (seq_day * seq_tpd + tile) - lag of the stream: day d = that / seq_tpd, in the buffers of slot d %
+    // seq_slots (q_tm, d_tm, qlat_tm, out, dec: slot s begins s * slot_* elements behind the pointer above).  A row that ends a day
+    // also writes its state into time row 0 of the next slot.  seq_slots <= 1: one window, no ring (everything above as it is).
+    int32_t seq_slots, seq_tpd, seq_day, seq_days; // slots; tiles per day; day of the launch's tile index; days pushed so far
+    int32_t seq_day_min;                           // days before this one have been queued to their end (trmc_stream_flush)
+    int64_t slot_tm, slot_qlat, slot_out, slot_dec;
 };
+
+// which tile of which day a position `lag` tiles behind works on in a launch of the stream: false = none (before the first
+// day, or behind the last one pushed)
+template <class T>
+__device__ __forceinline__ bool seq_locate(const StepArgs<T> &a, int32_t tile, int32_t lag, int32_t &behind, int32_t &slot, int32_t &slot_next)
+{
+    behind = tile - lag;
+    slot = slot_next = 0;
+    if (a.seq_slots <= 1) return behind >= 0;
+    int32_t d = a.seq_day;
+    while (behind < 0) {
+        behind += a.seq_tpd;
+        --d;
+    }
+    if (d < a.seq_day_min || d >= a.seq_days) return false;
+    slot = d % a.seq_slots;
+    slot_next = slot + 1 == a.seq_slots ? 0 : slot + 1;
+    return true;
+}
 
 // One launch = one timestep (SHORT) or one wavefront diagonal (!SHORT) over the plan
 // positions [s_begin, s_end); thread w of the launch takes position s_begin + w.
@@ -755,11 +781,23 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         }
         if (s >= s_end) return;
     }
-    const int32_t behind = tile - a.level[s];
+    int32_t behind, slot, slot_next;
+    const bool in_range = seq_locate(a, tile, a.level[s], behind, slot, slot_next);
     const int32_t t_lo = behind * K + 1, t_hi = min(behind * K + K, a.nsteps);
-    if (behind < 0 || t_lo > t_hi) {
+    if (!in_range || t_lo > t_hi) {
         if (from_hot) cold->cls_last[s] &= 0x7f; // (not routed in this launch: back to its block, which does that bookkeeping)
         return;
+    }
+    // Issue priority by cost.  A launch cannot end before its slowest wavefront has made its K dependent steps, and a step of
+    // rows that take three secant iterations or run over bank is some 2 200 instructions against 600-900 for the others: on a
+    // device that the launch does not fill many times over (one rank of a multi-GPU job: five wavefronts per SIMD, all
+    // resident at once) those wavefronts ARE the launch -- 12.5 us per step when they share their SIMD's issue slots equally
+    // with four cheaper ones, measured as 200 us per launch of 16 steps whatever the number of rows.  So the costlier a
+    // wavefront's rows showed themselves in the tile before, the higher its priority (the list's blocks: the highest).
+    if (a.cls_last) {
+        const int32_t cp = from_hot ? 7 : (int32_t)(a.cls_last[s] & 0x7f);
+        if (__any(cp >= 3)) __builtin_amdgcn_s_setprio(3);
+        else if (__any(cp == 2)) __builtin_amdgcn_s_setprio(1);
     }
 
     const uint32_t su = (uint32_t)s;
@@ -788,23 +826,26 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     const int32_t ri = a.res_of_pos ? a.res_of_pos[s] : -1;
     const int32_t gi = a.gage_of_pos ? a.gage_of_pos[s] : -1;
 
-    T q_prev = at(a.q_tm + (size_t)(t_lo - 1) * np, ob);
-    T d_prev = at(a.d_tm + (size_t)(t_lo - 1) * np, ob);
-    T *const out_row = a.out + (size_t)a.row_of_pos[su] * (size_t)a.nsteps * 3;
+    // (a stream of windows: this row's day lives in its slot of the ring)
+    T *const q_tm = a.q_tm + (size_t)slot * (size_t)a.slot_tm;
+    const size_t ql_base = (size_t)slot * (size_t)a.slot_qlat;
+    T q_prev = at(q_tm + (size_t)(t_lo - 1) * np, ob);
+    T d_prev = at(a.d_tm + (size_t)slot * (size_t)a.slot_tm + (size_t)(t_lo - 1) * np, ob);
+    T *const out_row = a.out + (size_t)slot * (size_t)a.slot_out + (size_t)a.row_of_pos[su] * (size_t)a.nsteps * 3;
     // the lateral-inflow column of step t is (t - 1) / qts: found by division once, by a counter from then on
     int32_t ql_col = (t_lo - 1) / a.qts, ql_left = a.qts - (t_lo - 1) % a.qts;
-    T ql = at(a.qlat_tm + (size_t)ql_col * np, ob);
+    T ql = at(a.qlat_tm + ql_base + (size_t)ql_col * np, ob);
     m.coef_ok = coef_guard(p.dt, ql); // (depends on the forcing column only: formed when that changes, not every step)
     const bool count_cost = a.it_sum != nullptr;
     int32_t it_acc = 0, it_last = 0, staged = 0;
     bool over_last = false;
     // flows of the step before (complete: earlier launches); advanced a row per step -- t differs from lane to lane (the
     // level skew), and (size_t)t * np in vector registers is a 64-bit multiplication per step
-    T *q_up = a.q_tm + (size_t)(t_lo - 1) * np;
+    T *q_up = q_tm + (size_t)(t_lo - 1) * np;
     for (int32_t t = t_lo; t <= t_hi; ++t, q_up += np) {
         if (ql_left == 0) {
             ++ql_col;
-            ql = at(cold->qlat_tm + (size_t)ql_col * np, ob);
+            ql = at(cold->qlat_tm + ql_base + (size_t)ql_col * np, ob);
             m.coef_ok = coef_guard(p.dt, ql);
             ql_left = cold->qts;
         }
@@ -860,10 +901,17 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         }
         asm volatile("" : "+v"(ob));
         at(q_up + np, ob) = q_new;
-        if (t == t_hi) at(cold->d_tm + (size_t)t * np, ob) = d_new;
+        if (t == t_hi) {
+            at(cold->d_tm + (size_t)slot * (size_t)cold->slot_tm + (size_t)t * np, ob) = d_new;
+            if (cold->seq_slots > 1 && t == cold->nsteps) { // the day ends: the next one starts from here (its slot's time row 0)
+                at(cold->q_tm + (size_t)slot_next * (size_t)cold->slot_tm, ob) = q_new;
+                at(cold->d_tm + (size_t)slot_next * (size_t)cold->slot_tm, ob) = d_new;
+            }
+        }
         q_prev = q_new;
         d_prev = d_new;
-        {   // stage (q, v, d) of step t; a run ends when kTileStage steps are staged and at the tile's last step
+        if (DEC || a.out) { // stage (q, v, d) of step t; a run ends when kTileStage steps are staged and at the tile's last step
+            // (a.out == nullptr: a stream of windows whose callers take products only -- nothing of the full result is assembled)
             T *so = s_out + (size_t)(staged * 3) * kTileBlock + threadIdx.x;
             so[0] = q_new;
             so[kTileBlock] = v_new;
@@ -872,7 +920,8 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             if (staged == kTileStage || t == t_hi) {
                 T *dst = out_row + (size_t)(t - staged) * 3;
                 const T *si = s_out + threadIdx.x;
-                if (a.out_vec && (staged & 3) == 0) { // (float: 3 * staged values = 3 * staged / 4 pieces of 16 bytes)
+                if (!a.out) {
+                } else if (a.out_vec && (staged & 3) == 0) { // (float: 3 * staged values = 3 * staged / 4 pieces of 16 bytes)
                     for (int j = 0; j < 3 * staged / 4; ++j) {
                         float4 v;
                         v.x = (float)si[(4 * j + 0) * kTileBlock];
@@ -889,11 +938,11 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
                     const int32_t ds = cold->dec_stride;
                     for (int32_t k = t / ds; k >= 1 && k * ds > t - staged; --k) {
                         if (k > cold->dec_keep) continue;
-                        const int32_t slot = k * ds - (t - staged) - 1;
-                        T *dd = cold->dec + ((size_t)cold->row_of_pos[su] * (size_t)cold->dec_keep + (size_t)(k - 1)) * 3;
-                        dd[0] = si[(slot * 3 + 0) * kTileBlock];
-                        dd[1] = si[(slot * 3 + 1) * kTileBlock];
-                        dd[2] = si[(slot * 3 + 2) * kTileBlock];
+                        const int32_t kslot = k * ds - (t - staged) - 1;
+                        T *dd = cold->dec + (size_t)slot * (size_t)cold->slot_dec + ((size_t)cold->row_of_pos[su] * (size_t)cold->dec_keep + (size_t)(k - 1)) * 3;
+                        dd[0] = si[(kslot * 3 + 0) * kTileBlock];
+                        dd[1] = si[(kslot * 3 + 1) * kTileBlock];
+                        dd[2] = si[(kslot * 3 + 2) * kTileBlock];
                     }
                 }
                 staged = 0;
@@ -905,7 +954,7 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         uint8_t c = (uint8_t)(min(it_last, 3) + (over_last ? 4 : 0));
         // (a row that has finished the window starts the next one in its block; and a wavefront that holds sixteen or more of
         // them -- the first blocks of every level of a cost-ordered plan -- keeps them: they pace each other where they are)
-        const bool hot = hot_list && c >= 3 && t_hi < cold->nsteps;
+        const bool hot = hot_list && c >= 3 && (t_hi < cold->nsteps || cold->seq_slots > 1);
         if (hot && (from_hot || __builtin_popcountll(__ballot(hot)) < TRMC_HOT_WAVE_MAX)) {
             const int32_t nxt = (cold->hot_cur + 1) % 3, cap = cold->hot_cap;
             const int32_t i = atomicAdd(&cold->hot_cnt[nxt], 1);
@@ -918,6 +967,8 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     }
     if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535, (int)it_sum[su] + it_acc);
 }
+
+#include "k_mc_ctile.inc"
 
 // plan time: the segment-invariant constants of mc_segment.hpp::make_const, one thread per position,
 // written as six more SoA columns behind the nine parameter columns (same device arithmetic the
@@ -2102,12 +2153,17 @@ struct RouteRun { // the routing window in progress (route_begin_t .. route_end_
     // second tier: the `mid` levels right below the wide ones, mid_k steps per launch under their own skew (k_mc_tile again),
     // queued on the plan's stream between the tail's launches
     int32_t mid = 0, mid_k = 0, mid_next = 0;
+    // cluster tiles (k_mc_ctile): the rows below the wide levels K steps per launch too, cluster level c another tile behind;
+    // `wide` is then the plan's cl_from_level (possibly 0: no slices at all), there is no one-step tail and no transposing pass
+    bool cl = false;
+    int32_t cl_next = 0;          // index of the next cluster tile to queue (they begin at tile `wide`)
     bool tail_active = false;     // the tail launches of this window go to the tail stream
     bool end_queued = false;      // route_end_queue has run for this window
     int32_t dec_stride = 0, dec_keep = 0; // the tiles of this window write the kept steps of their rows into the plan's `dec`
     int32_t dec_lo = 0, dec_hi = 0;       // ... the plan positions [dec_lo, dec_hi) that do
 };
 
+struct StreamRun;
 struct trmc_plan {
     int device = 0;
     int precision = 32;
@@ -2129,6 +2185,7 @@ struct trmc_plan {
     // static, plan order
     DevBuf params; // 9 columns x nseg_pad
     DevBuf up_ptr, up_idx, up2, level, row_of_pos, pos_of_row, it_prev, lag;
+    DevBuf lagk, cblk_ptr;               // cluster order (topology.hpp): tiles every position runs behind level 0; the cluster blocks
     DevBuf it_sum;                       // per-position cost of the window (trmc_plan_collect_cost)
     bool collect_cost = false;
     bool hinted = false;                 // created with a cost hint: rows of a level are grouped by cost
@@ -2186,6 +2243,8 @@ struct trmc_plan {
         int32_t mid_levels = 12, mid_k = 4;
         int32_t tile_perm_group = -1;        // -1: the default (see route_advance_t); 0: off; 1: on
         int32_t hot_rows = -1;               // -1 (default) or 1: with the partition; 0: off
+        int32_t cluster_rows = 0;            // rows per cluster block of a short-timestep plan's deeper rows; 0: no cluster order
+        int32_t cluster_late_lag = 0;        // tiles the rows fed by boundary rows run behind at least (cluster order)
         bool sequence = false;
         bool flow_overlap = false;
         int32_t flow_lean = 0;
@@ -2224,6 +2283,7 @@ struct trmc_plan {
     bool q0_staged = false;              // in_q0 holds the initial state of the window that is staged (an upload's q0, or the last
                                          // window's final state gathered by an upload with q0 = NULL / trmc_stage_forcing): valid
                                          // until a window consumes it, whatever routed_nsteps says in the meantime
+    struct StreamRun *seq = nullptr;     // trmc_stream_*: a stream of windows on a ring of day slots (stream.inc)
     DevBuf hot_list, hot_cnt;            // k_mc_tile's hot rows (StepArgs::hot_list): [3][hot_cap] positions, [3] lengths
     int32_t hot_cap = 0;
     int64_t tile_seq = 0;                // tile launches of the wide tier so far, all windows: which of the three lists is read
@@ -2322,6 +2382,8 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.dec_stride = a.dec_keep = 0;
     a.hot_list = a.hot_cnt = nullptr;
     a.hot_cap = a.hot_cur = a.hot_home = 0;
+    a.seq_slots = a.seq_tpd = a.seq_day = a.seq_days = a.seq_day_min = 0;
+    a.slot_tm = a.slot_qlat = a.slot_out = a.slot_dec = 0;
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
     a.up_idx = (const int32_t *)pl->up_idx.p;
     a.up2 = (const int2 *)pl->up2.p;
@@ -2397,6 +2459,24 @@ inline void launch_tile(hipStream_t st, const StepArgs<T> &a, int32_t p0, int32_
     else hipLaunchKernelGGL((k_mc_tile<T, false, false>), grid, block, 0, st, a, p0, p1, tile, K);
 }
 
+// one launch of k_mc_ctile: the cluster blocks [b0, b1) of the plan at tile index `tile`
+template <class T>
+inline void launch_ctile(hipStream_t st, const StepArgs<T> &a, const int32_t *cblk_ptr, int32_t b0, int32_t b1, int32_t tile, int32_t K,
+                         bool tol)
+{
+    const dim3 grid((unsigned)(b1 - b0)), block(kTileBlock);
+    const bool dec = a.dec != nullptr;
+    if constexpr (sizeof(T) == 4) {
+        if (tol) {
+            if (dec) hipLaunchKernelGGL((k_mc_ctile<T, true, true>), grid, block, 0, st, a, cblk_ptr, b0, tile, K);
+            else hipLaunchKernelGGL((k_mc_ctile<T, true, false>), grid, block, 0, st, a, cblk_ptr, b0, tile, K);
+            return;
+        }
+    }
+    if (dec) hipLaunchKernelGGL((k_mc_ctile<T, false, true>), grid, block, 0, st, a, cblk_ptr, b0, tile, K);
+    else hipLaunchKernelGGL((k_mc_ctile<T, false, false>), grid, block, 0, st, a, cblk_ptr, b0, tile, K);
+}
+
 // A routing window runs in three parts so that a caller can interleave other device work (the multi-GPU
 // hand-off of cut-edge hydrographs, distributed.py) with it, everything asynchronous on the plan's stream:
 //   route_begin_t    forcing transpose, initial state, boundary rows (if already staged)
@@ -2419,7 +2499,9 @@ template <class T> int emit_tiles_through(trmc_plan *pl, int32_t t_complete) // 
         HIP_TRY(hipEventRecord(pl->tile_ev[r.tiles_done], (r.wide > 0 && !r.tail_active) ? pl->wstream : pl->stream));
         HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->tile_ev[r.tiles_done], 0));
         // (rows of the wide levels wrote their results themselves, k_mc_tile: their positions are left out)
-        const int32_t skip_lo = r.wide > 0 ? pl->topo.lvl_ptr[0] : 0, skip_hi = r.wide > 0 ? pl->topo.lvl_ptr[r.wide + r.mid] : 0;
+        // (with cluster tiles every routed row has: only boundary rows are left to this pass)
+        const int32_t skip_lo = (r.wide > 0 || r.cl) ? pl->topo.lvl_ptr[0] : 0;
+        const int32_t skip_hi = r.cl ? pl->topo.lvl_ptr[pl->topo.nlevels] : (r.wide > 0 ? pl->topo.lvl_ptr[r.wide + r.mid] : 0);
         const int32_t shift_from = (skip_lo + 63) / 64 * 64, shift = std::max(0, (skip_hi - shift_from) / 64 * 64);
         const int32_t n_emit = n - shift;
         if (n_emit > 0) {
@@ -2554,7 +2636,7 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         const int64_t min_rows = pl->opt.wide_min_rows;
         int32_t W = 0, M = 0;
         const bool all_in_place = pl->maxlag == 0 && r.boundary_through == nsteps; // (then every level may run ahead)
-        const int32_t level_cap = tp.tail_from_level > 0 ? tp.tail_from_level : tp.nlevels; // (deeper rows are not in level slices)
+        const int32_t level_cap = tp.ncl > 0 ? tp.cl_from_level : (tp.tail_from_level > 0 ? tp.tail_from_level : tp.nlevels); // (deeper rows are not in level slices)
         auto level_ok = [&](int32_t l, int64_t need) {
             return l < level_cap && tp.lvl_ptr[l + 1] - tp.lvl_ptr[l] >= need && (all_in_place || (int64_t)tp.lvl_ptr[l + 1] <= pl->wide_safe_pos);
         };
@@ -2563,18 +2645,27 @@ template <class T> int route_begin_t(trmc_plan *pl, int nsteps, int qts, int sho
         // the second tier: the levels right below, fewer steps per launch (a skew of mid_k steps per level instead of wide_k)
         if (W > 0 && pl->opt.mid_min_rows > 0)
             while (M < pl->opt.mid_levels && level_ok(W + M, pl->opt.mid_min_rows)) ++M;
-        if (W > 0) {
+        // CLUSTER TILES (k_mc_ctile): a plan in cluster order (topology.hpp) routes its deeper rows K steps per launch too --
+        // if, like the wide levels, they find every boundary hydrograph in place and carry no lag of their own.  The slices
+        // are then exactly the plan's (the same rule picked them when the order was made).
+        if (tp.ncl > 0 && all_in_place) {
+            r.cl = true;
+            W = tp.cl_from_level;
+            M = 0;
+        }
+        if (W > 0 || r.cl) {
             r.wide = W;
             r.wide_k = std::max(1, std::min(nsteps, pl->opt.wide_k > 0 ? pl->opt.wide_k : std::max(1, std::min(16, nsteps / 8))));
             r.mid = M;
             r.mid_k = M > 0 ? std::max(1, std::min(r.wide_k, pl->opt.mid_k)) : 0;
+            r.cl_next = W;
             if (!pl->wstream) {
                 // ordinary priority: between the tail's step launches (high) and the result transpose (low); one hardware queue each
                 HIP_TRY(hipStreamCreateWithFlags(&pl->wstream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&pl->ev_tail, hipEventDisableTiming));
             }
             HIP_TRY(hipStreamWaitEvent(pl->wstream, pl->ev[1], 0)); // the tiles start behind the window's set-up
-            const size_t ntile = (size_t)((nsteps + r.wide_k - 1) / r.wide_k + W - 1);
+            const size_t ntile = (size_t)std::max(1, (nsteps + r.wide_k - 1) / r.wide_k + W - 1);
             while (pl->wide_t0.size() < ntile) { // (t0: only the first is used -- a tile starts where the one before it ended)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 HIP_TRY(hipEventCreate(&e0));
@@ -2616,7 +2707,7 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
     hipStream_t st = pl->stream;
     if (pl->nrouted > 0) {
         const int32_t L = tp.nlevels;
-        if (r.short_ts && r.wide > 0) {
+        if (r.short_ts && (r.wide > 0 || r.cl)) {
             // wide levels: K steps per launch, level l trailing level l - 1 by K steps (k_mc_tile), on the TILE stream
             // (ordinary priority); the narrow tail of the level order: one step per launch (k_mc_step) on the plan's own
             // high-priority stream, behind the last wide level (an event per tile).  The tail is what the window waits for
@@ -2627,23 +2718,27 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
             // row at t_end.
             const int32_t K = r.wide_k, W = r.wide, M = r.mid, K2 = r.mid_k;
             const int32_t w0 = tp.lvl_ptr[0], w1 = tp.lvl_ptr[W], m1 = tp.lvl_ptr[W + M], s1 = tp.lvl_ptr[L];
-            const int32_t ntile = (nsteps + K - 1) / K + W - 1;
+            const int32_t nt = (nsteps + K - 1) / K;
+            const int32_t ntile = W > 0 ? nt + W - 1 : 0;
             const int32_t nmid = M > 0 ? (nsteps + K2 - 1) / K2 + M - 1 : 0;
-            const bool tail = s1 > m1;
+            const bool tail = s1 > m1 && !r.cl;
             const bool tol = pl->opt.tol;
             hipStream_t ws = pl->wstream;
-            r.tail_active = tail || M > 0;
+            r.tail_active = tail || M > 0 || r.cl;
             // Every tile of the window is queued at once, at the window's first call: the wide path needs all boundary
             // hydrographs up front (route_begin_t), so a tile depends on nothing but the tile before it.  (Queued one by one
             // as the tail came to need them, the last tiles of a window were late -- the host runs only a little ahead of the
             // device once the runtime's pool of dependency signals is in use -- and the tail, the critical path, waited
             // 1.2 ms for them.)  One event per tile: it ends the tile for the clock (a tile starts where the one before it
             // ended; the first has a start event of its own) and it is what the tail waits for.
-            if (r.wide_next == 0) {
+            // what the tiles of this window are launched with: the in-block partition, the hot rows, the decimated output
+            // (idempotent: the buffers are made and cleared on the first call only)
+            StepArgs<T> at = a;
+            if (r.cl) at.level = (const int32_t *)pl->lagk.p; // (tiles every position runs behind: the level in the slices)
+            {
                 // rows dealt to the threads of every block of a tile by the cost class they showed in the tile before (k_mc_tile's
-                // prologue; trmc_plan_options.tile_perm_group: < 0 off, > 0 on, 0 the default below).
+                // prologue; trmc_plan_options.tile_perm_group: > 0 on, 0 off, < 0 the default below).
                 const bool use_perm = pl->opt.tile_perm_group > 0 || (pl->opt.tile_perm_group < 0 && kTilePartitionDefault(pl->hinted));
-                StepArgs<T> at = a;
                 if (pl->out_stride > 0 && nsteps / pl->out_stride >= 1) {
                     r.dec_stride = pl->out_stride;
                     r.dec_keep = nsteps / pl->out_stride;
@@ -2652,7 +2747,7 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     at.dec_stride = r.dec_stride;
                     at.dec_keep = r.dec_keep;
                     r.dec_lo = w0;
-                    r.dec_hi = m1;
+                    r.dec_hi = r.cl ? s1 : m1;
                 }
                 if (use_perm) {
                     const bool fresh = pl->cls_last.bytes < (size_t)pl->nseg_pad;
@@ -2663,7 +2758,7 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                     // (ms per day, with / without): plan built from the topology alone 17.4 / 19.5; cost-ordered plan on its own
                     // kind of days 16.22 / 16.34 -- once the list's blocks were made the FIRST of the launch: behind the others
                     // (the costliest rows of all started last, every launch ended on them) it was 16.7 / 16.2 and 18.3 / 19.4.
-                    if (pl->opt.hot_rows != 0) {
+                    if (pl->opt.hot_rows != 0 && W > 0) {
                         const int32_t cap = std::max<int32_t>(kTileBlock, ((w1 - w0) / 32 + kTileBlock - 1) / kTileBlock * kTileBlock);
                         if (pl->hot_cap != cap || !pl->hot_list.p) { // (a tier of another size: the lists start empty, the marks are cleared)
                             if (int rc = pl->hot_list.ensure((size_t)3 * cap * sizeof(int32_t))) return rc;
@@ -2679,6 +2774,8 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                         at.hot_home = (cap + kTileBlock - 1) / kTileBlock;
                     }
                 }
+            }
+            if (r.wide_next == 0 && W > 0) {
                 stamp(pl, ws, 0);
                 HIP_TRY(hipEventRecord(pl->wide_t0[0], ws));
                 for (int32_t j = 0; j < ntile; ++j) {
@@ -2692,8 +2789,13 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                 r.wide_next = ntile;
                 r.wide_through = -1; // (from here on: the last tile the tail has been told to wait for)
             }
+            if (r.wide_next == 0 && W == 0) { // (cluster tiles only: no slices, nothing on the tile stream)
+                stamp(pl, st, 2);
+                r.wide_next = -1;
+                r.wide_through = -1;
+            }
             auto wait_tile = [&](int32_t need) -> int { // the plan's stream behind wide tile `need` (once per tile)
-                if (need > r.wide_through) {
+                if (ntile > 0 && need > r.wide_through) {
                     HIP_TRY(hipStreamWaitEvent(st, pl->wide_t1[(size_t)std::min(need, ntile - 1)], 0));
                     r.wide_through = need;
                 }
@@ -2722,10 +2824,34 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                 }
                 return 0;
             };
+            if (r.cl) {
+                // CLUSTER TILES on the plan's own stream: tile j routes cluster level c (W + c tiles behind level 0) through the
+                // steps ((j - W - c) K, (j - W - c + 1) K]; its rows read rows outside their cluster at least one tile ahead of
+                // them -- the last slice is there after wide tile j - 1, every cluster level above after cluster tile j - 1 (this
+                // stream).  Every row has reached step t after tile W + C - 1 + ceil(t / K) - 1.
+                const int32_t C = tp.ncl;
+                const int32_t te = std::min(t_end, nsteps);
+                const int32_t j_end = te <= 0 ? W - 1 : W + C - 1 + (te + K - 1) / K - 1;
+                const int32_t *cblk_ptr = (const int32_t *)pl->cblk_ptr.p;
+                StepArgs<T> ac = at;
+                ac.hot_list = ac.hot_cnt = nullptr;
+                for (; r.cl_next <= j_end; ++r.cl_next) {
+                    const int32_t j = r.cl_next;
+                    const int32_t c_lo = std::max(0, j - W - nt + 1), c_hi = std::min(C - 1, j - W);
+                    if (c_lo > c_hi) continue;
+                    if (j >= 1)
+                        if (int rc = wait_tile(std::min(j - 1, ntile - 1))) return rc;
+                    const int32_t b0 = tp.cblk_of_cl[(size_t)c_lo], b1 = tp.cblk_of_cl[(size_t)c_hi + 1];
+                    if (b1 > b0) {
+                        launch_ctile<T>(st, ac, cblk_ptr, b0, b1, j, K, tol);
+                        ++r.launches;
+                    }
+                }
+            }
             // (with lagged rows -- always in the tail, route_begin_t -- launch t routes the tail's other rows at step t and the
             // lagged ones at step t - maxlag, and the window ends at launch nsteps + maxlag: k_mc_step's LAG form)
             const int32_t lagmax = pl->maxlag;
-            for (int32_t t = t0 + 1; t <= t_end; ++t) {
+            for (int32_t t = t0 + 1; t <= t_end && !r.cl; ++t) {
                 const int32_t tn = std::min(t, nsteps);
                 // the tail's step t reads the rows above it at step t - 1: the last level of the second tier is there after
                 // launch M - 2 + ceil((t - 1) / K2) ...
@@ -2751,7 +2877,7 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                 const int32_t te = std::min(t_end, nsteps);
                 if (M > 0 && te >= 1)
                     if (int rc = mid_through(M - 2 + (te + K2 - 1) / K2)) return rc;
-                const int32_t need_end = te <= 0 ? -1 : std::min((te - 1) / K + W - 1, ntile - 1);
+                const int32_t need_end = (te <= 0 || ntile == 0) ? -1 : std::min((te - 1) / K + W - 1, ntile - 1);
                 if (need_end >= 0)
                     if (int rc = wait_tile(need_end)) return rc;
             }
@@ -2821,21 +2947,22 @@ template <class T> int route_end_t(trmc_plan *pl)
     s.ms_total = (double)ms01 + ms12 + ms23;
     s.wide_levels = r.wide;
     s.wide_k = r.wide_k;
-    s.wide_launches = r.wide_next;
+    s.wide_launches = std::max(0, r.wide_next);
     s.mid_levels = r.mid;
     s.mid_k = r.mid_k;
     s.mid_launches = r.mid_next;
     s.arithmetic = pl->opt.tol ? TRMC_ARITH_TOLERANCE : TRMC_ARITH_EXACT;
-    s.wide_segment_steps = r.wide > 0 ? (int64_t)(tp.lvl_ptr[r.wide + r.mid] - tp.lvl_ptr[0]) * nsteps : 0;
+    s.wide_segment_steps = r.cl ? (int64_t)(tp.lvl_ptr[tp.nlevels] - tp.lvl_ptr[0]) * nsteps
+                                : (r.wide > 0 ? (int64_t)(tp.lvl_ptr[r.wide + r.mid] - tp.lvl_ptr[0]) * nsteps : 0);
     s.ms_wide = 0.0;
     {
-        const size_t timed_n = std::min<size_t>((size_t)r.wide_next, pl->wide_t0.size());
+        const size_t timed_n = std::min<size_t>((size_t)std::max(0, r.wide_next), pl->wide_t0.size());
         for (size_t i = 0; i < timed_n; ++i) { // (a tile's clock starts where the previous tile's stopped)
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, i == 0 ? pl->wide_t0[0] : pl->wide_t1[i - 1], pl->wide_t1[i]));
             s.ms_wide += ms;
         }
-        if (timed_n > 0 && timed_n < (size_t)r.wide_next) s.ms_wide *= (double)r.wide_next / (double)timed_n;
+        if (timed_n > 0 && (int64_t)timed_n < (int64_t)r.wide_next) s.ms_wide *= (double)r.wide_next / (double)timed_n;
     }
     pl->routed_nsteps = nsteps;
     pl->dec_stride_done = r.dec_stride;
@@ -3367,7 +3494,8 @@ template <class T> int chain_from_t(trmc_plan *dst, trmc_plan *src, int nsteps_d
     HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_chain[1], 0));
     if (w0 > b0) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(w0 - b0)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, b0, w0);
     if (m1 > w1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(m1 - w1)), dim3(kBlock), 0, dst->stream, sq, sq, sd, dq, dv, dd, w1, m1);
-    if (s1 > m1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(s1 - m1)), dim3(kBlock), 0, dst->stream, sq, sv, sd, dq, dv, dd, m1, s1);
+    // (rows routed by cluster tiles wrote no velocity row either)
+    if (s1 > m1) hipLaunchKernelGGL((k_chain_state<T>), dim3(blocks_for(s1 - m1)), dim3(kBlock), 0, dst->stream, sq, src->run.cl ? sq : sv, sd, dq, dv, dd, m1, s1);
     HIP_TRY(hipEventRecord(dst->ev_chain[3], dst->stream));
     if (!src->ev_released[1]) HIP_TRY(hipEventCreateWithFlags(&src->ev_released[1], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(src->ev_released[1], dst->stream));
@@ -3447,6 +3575,8 @@ int check_device(int device)
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
+static void stream_release(trmc_plan *pl); // (stream.inc)
+
 const char *trmc_last_error(void) { return g_err.c_str(); }
 int trmc_abi_version(void) { return TRMC_ABI_VERSION; }
 
@@ -3481,6 +3611,33 @@ int trmc_topology_levels_hinted(int64_t nseg, const int64_t *up_ptr, const int64
         if (plan_pos_of_row) plan_pos_of_row[r] = t.pos_of_row[r];
     }
     if (nlevels) *nlevels = t.nlevels;
+    return 0;
+}
+
+int trmc_topology_clusters(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx, const uint8_t *boundary,
+                           const uint8_t *cost_hint, int64_t wide_min_rows, int32_t wide_max_levels, int32_t cluster_rows,
+                           int64_t *plan_pos_of_row, int32_t *lag_of_row, int32_t *block_of_row, int32_t *wide_levels,
+                           int32_t *cluster_levels, int32_t *cluster_blocks)
+{
+    if (cluster_rows <= 0 || cluster_rows > kTileBlock) return fail(TRMC_EINVAL, "cluster_rows must be in [1, 128]");
+    trmc::Topology t;
+    std::string err;
+    const int rc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, t, err, cost_hint, 0, true, kWideMaxLevels, wide_min_rows,
+                                        std::min<int32_t>(wide_max_levels, kWideMaxLevels), 0, 0, 0, cluster_rows);
+    if (rc) return fail(rc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
+    const int32_t nb = t.ncl > 0 ? (int32_t)t.cblk_ptr.size() - 1 : 0;
+    std::vector<int32_t> blk_of_pos((size_t)nseg, -1);
+    for (int32_t b = 0; b < nb; ++b)
+        for (int32_t p = t.cblk_ptr[(size_t)b]; p < t.cblk_ptr[(size_t)b + 1]; ++p) blk_of_pos[(size_t)p] = b;
+    for (int64_t r = 0; r < nseg; ++r) {
+        const int32_t p = t.pos_of_row[r];
+        if (plan_pos_of_row) plan_pos_of_row[r] = p;
+        if (lag_of_row) lag_of_row[r] = t.level_of_row[r] < 0 ? -1 : t.lagk_of_pos[(size_t)p];
+        if (block_of_row) block_of_row[r] = blk_of_pos[(size_t)p];
+    }
+    if (wide_levels) *wide_levels = t.cl_from_level;
+    if (cluster_levels) *cluster_levels = t.ncl;
+    if (cluster_blocks) *cluster_blocks = nb;
     return 0;
 }
 
@@ -3652,6 +3809,11 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         po.mid_k = o.mid_k > 0 ? o.mid_k : 4;
         po.tile_perm_group = o.tile_perm_group < 0 ? 0 : (o.tile_perm_group > 0 ? 1 : -1); // off / on / by the plan (default)
         po.hot_rows = o.hot_rows < 0 ? 0 : (o.hot_rows > 0 ? 1 : -1);
+        // (the cluster order is for plans whose windows follow each other as a stream, trmc_stream_*: a single window pays for the
+        // clusters' skew with some thirty small launches at its end -- CONUS: 20.7 ms alone against 16.8 with one launch per
+        // step -- so a plan only gets it when asked)
+        po.cluster_rows = o.cluster_rows > 0 ? std::min<int32_t>(o.cluster_rows, kTileBlock) : 0;
+        po.cluster_late_lag = std::max(0, o.cluster_late_lag);
         po.sequence = o.sequence_mode != 0;
         po.flow_overlap = o.flow_overlap != 0;
         po.flow_lean = o.flow_lean;
@@ -3673,6 +3835,17 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         mid_min_rows = pl->opt.mid_min_rows;
         mid_max_levels = pl->opt.mid_levels;
     }
+    // ... or, if asked for, laid out in CLUSTERS (topology.hpp, cluster_rows): then they are routed several timesteps per launch
+    // as well (k_mc_ctile) -- what a stream of windows needs (trmc_stream_*); the second tier has no part in that
+    int32_t cluster_rows = 0;
+    if (tiers && !pl->flow && pl->opt.cluster_rows > 0) {
+        cluster_rows = pl->opt.cluster_rows;
+        wide_min_rows = pl->opt.wide_min_rows;
+        wide_max_levels = pl->opt.wide_levels;
+        mid_min_rows = 0;
+        mid_max_levels = 0;
+        pl->opt.mid_min_rows = 0;
+    }
     // (a dataflow plan built for the general mode: basins with a main stem of at least stem_min_rows rows -- default 1 024,
     // < 0 = off -- are laid out stem-last with the side tributaries from the top of the stem down, and their stems' blocks take
     // the first tickets: topology.hpp, stem_min_rows)
@@ -3680,7 +3853,7 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
     if (pl->flow && (flags & TRMC_PLAN_FULL_TS)) stem_min_rows = o.stem_min_rows < 0 ? 0 : (o.stem_min_rows > 0 ? o.stem_min_rows : 1024);
     const int trc = trmc::build_topology(nseg, up_ptr, up_idx, boundary, pl->topo, err, cost_hint, pl->flow ? kFlowBlock : 0, tiers,
                                          (tiers && !pl->flow) ? kWideMaxLevels : 0, wide_min_rows, wide_max_levels, stem_min_rows,
-                                         mid_min_rows, mid_max_levels);
+                                         mid_min_rows, mid_max_levels, cluster_rows, pl->opt.cluster_late_lag);
     if (trc) {
         delete pl;
         return fail(trc == -2 ? TRMC_ECYCLE : TRMC_EINVAL, err);
@@ -3727,6 +3900,12 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
     std::vector<int32_t> level_plan((size_t)pl->nseg_pad, 0);
     for (int64_t p = 0; p < nseg; ++p) level_plan[p] = pl->topo.level_of_row[pl->topo.row_of_pos[p]];
     if ((rc = upload_i32(pl->level, level_plan, 1))) return bail(rc);
+    if (pl->topo.ncl > 0) {
+        std::vector<int32_t> lagk(pl->topo.lagk_of_pos);
+        lagk.resize((size_t)pl->nseg_pad, 0);
+        if ((rc = upload_i32(pl->lagk, lagk, 1))) return bail(rc);
+        if ((rc = upload_i32(pl->cblk_ptr, pl->topo.cblk_ptr, 1))) return bail(rc);
+    }
     if ((rc = upload_i32(pl->up_ptr, pl->topo.up_ptr, 1))) return bail(rc);
     if ((rc = upload_i32(pl->up_idx, pl->topo.up_idx, 1))) return bail(rc);
     {
@@ -3802,6 +3981,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     }
     trmc_plan *const parent = pl->parent;
     (void)hipSetDevice(pl->device);
+    stream_release(pl);
     if (pl->ev_forcing) (void)hipEventDestroy(pl->ev_forcing);
     for (DevBuf &b : pl->rowsets) b.release();
     pl->fetch_hyd.release();
@@ -3814,7 +3994,7 @@ void trmc_plan_destroy(trmc_plan *pl)
     if (pl->ev_fetch_ready) (void)hipEventDestroy(pl->ev_fetch_ready);
     if (pl->ev_fetch_done) (void)hipEventDestroy(pl->ev_fetch_done);
     if (pl->ev_gather) (void)hipEventDestroy(pl->ev_gather);
-    for (DevBuf *b : {&pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
+    for (DevBuf *b : {&pl->lagk, &pl->cblk_ptr, &pl->params, &pl->up_ptr, &pl->up_idx, &pl->up2, &pl->level, &pl->row_of_pos, &pl->pos_of_row, &pl->it_prev, &pl->it_sum, &pl->lag, &pl->d_state, &pl->ticket, &pl->ticket_map, &pl->rank, &pl->dbg, &pl->prio, &pl->cuq_ptr, &pl->cuq_blk, &pl->cuq_head, &pl->cu_index, &pl->cuq_perm, &pl->d_gran, &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos,
                       &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos, &pl->res_par, &pl->res_inflow,
                       &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->qlat_alt, &pl->tm, &pl->out, &pl->scratch, &pl->gathered, &pl->cls_last, &pl->hot_list, &pl->hot_cnt})
         b->release();
@@ -3900,6 +4080,8 @@ int trmc_plan_clone(trmc_plan *src, trmc_plan **out)
     pl->up_idx.borrow(src->up_idx);
     pl->up2.borrow(src->up2);
     pl->level.borrow(src->level);
+    pl->lagk.borrow(src->lagk);
+    pl->cblk_ptr.borrow(src->cblk_ptr);
     pl->row_of_pos.borrow(src->row_of_pos);
     pl->pos_of_row.borrow(src->pos_of_row);
     pl->rank.borrow(src->rank);
@@ -4003,6 +4185,18 @@ int trmc_plan_info(const trmc_plan *pl, int64_t *nseg, int64_t *nseg_routed, int
     if (nlevels) *nlevels = pl->topo.nlevels;
     if (precision) *precision = pl->precision;
     if (device) *device = pl->device;
+    return 0;
+}
+
+int trmc_plan_lags(const trmc_plan *pl, int32_t *lag_of_row, int32_t *wide_levels, int32_t *cluster_levels)
+{
+    if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
+    const trmc::Topology &t = pl->topo;
+    if (t.cl_rows <= 0) return fail(TRMC_EINVAL, "the plan is not in cluster order (trmc_plan_options.cluster_rows)");
+    for (int64_t r = 0; lag_of_row && r < pl->nseg; ++r)
+        lag_of_row[r] = t.level_of_row[r] < 0 ? -1 : t.lagk_of_pos[(size_t)t.pos_of_row[r]];
+    if (wide_levels) *wide_levels = t.cl_from_level;
+    if (cluster_levels) *cluster_levels = t.ncl;
     return 0;
 }
 
@@ -4320,9 +4514,9 @@ static int route_check(trmc_plan *pl, int nsteps, int qts_subdivisions, bool bou
 
 static int lag_check(trmc_plan *pl, int assume_short_ts)
 {
-    if (pl->topo.tail_from_level > 0 && !assume_short_ts)
-        return fail(TRMC_EINVAL, "this plan was created for assume_short_ts (TRMC_PLAN_SHORT_TS with a cost hint: its deeper rows are "
-                                 "ordered by cost, not by level); create a plan for the general mode");
+    if ((pl->topo.tail_from_level > 0 || pl->topo.ncl > 0) && !assume_short_ts)
+        return fail(TRMC_EINVAL, "this plan was created for assume_short_ts (TRMC_PLAN_SHORT_TS on the level engine: its deeper rows are "
+                                 "ordered in clusters or by cost, not by level); create a plan for the general mode");
     if (pl->maxlag > 0 && !assume_short_ts)
         return fail(TRMC_EINVAL, "a plan with lagged rows (trmc_plan_set_lag) routes with assume_short_ts only");
     return 0;
@@ -4977,5 +5171,7 @@ int trmc_selfcheck_fast_arith(int device, int what, int64_t n, uint64_t seed, in
     *mismatches_out = (int64_t)bad;
     return 0;
 }
+
+#include "stream.inc"
 
 } // extern "C"

@@ -53,6 +53,24 @@ def topology_blocks(up_ptr, up_idx, boundary=None, cost_hint=None, cost_tiers=Tr
     return pos, rank, br.value, nb.value
 
 
+def topology_clusters(up_ptr, up_idx, boundary=None, cost_hint=None, wide_min_rows=0, wide_max_levels=16, cluster_rows=128):
+    """Host-only cluster order of a short-timestep plan of the level engine (no GPU; csrc/topology.hpp).  Returns
+    (plan_pos_of_row, lag_of_row, block_of_row, wide_levels, cluster_levels, cluster_blocks)."""
+    up_ptr = np.ascontiguousarray(up_ptr, dtype=np.int64)
+    up_idx = np.ascontiguousarray(up_idx, dtype=np.int64)
+    nseg = up_ptr.shape[0] - 1
+    b = None if boundary is None else np.ascontiguousarray(boundary, dtype=np.uint8)
+    h = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
+    pos = np.empty(nseg, dtype=np.int64)
+    lag = np.empty(nseg, dtype=np.int32)
+    blk = np.empty(nseg, dtype=np.int32)
+    w, c, nb = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.lib().trmc_topology_clusters(nseg, _lib.ptr(up_ptr), _lib.ptr(up_idx), _lib.ptr(b), _lib.ptr(h),
+                                                 int(wide_min_rows), int(wide_max_levels), int(cluster_rows), _lib.ptr(pos),
+                                                 _lib.ptr(lag), _lib.ptr(blk), C.byref(w), C.byref(c), C.byref(nb)))
+    return pos, lag, blk, w.value, c.value, nb.value
+
+
 def topology_blocks_general(up_ptr, up_idx, boundary=None, stem_min_rows=1024):
     """Host-only block order of a dataflow plan built for the general mode (no GPU): long stems last in their basin, their
     side tributaries from the top down.  Returns (plan_pos_of_row, rank_of_row, block_rows, nblocks, early_blocks)."""
@@ -156,6 +174,14 @@ class RoutingPlan:
         pos = np.empty(self.nseg, dtype=np.int64)
         _lib.check(_lib.lib().trmc_plan_levels(self._h, _lib.ptr(lvl), _lib.ptr(pos)))
         return lvl, pos
+
+    def lags(self):
+        """A plan in cluster order: (tiles every row runs behind the headwaters [-1: boundary row], levels kept as slices,
+        cluster levels) -- include/trmc.h, trmc_plan_lags."""
+        lag = np.empty(self.nseg, dtype=np.int32)
+        w, c = C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.lib().trmc_plan_lags(self._h, _lib.ptr(lag), C.byref(w), C.byref(c)))
+        return lag, w.value, c.value
 
     def stats(self):
         s = _lib.Stats()
@@ -302,6 +328,43 @@ class RoutingPlan:
     def route_end(self):
         _lib.check(_lib.lib().trmc_route_end(self._h))
         return self.stats()
+
+    # -- a stream of windows (include/trmc.h, trmc_stream_*) ------------------------------------------------
+    def stream_begin(self, nsteps, qts_subdivisions, slots=0, full_output=False, output_stride=0):
+        """After ``upload_forcing`` (the state, the shape of the forcing): days are then ``stream_push``-ed one after the other."""
+        _lib.check(_lib.lib().trmc_stream_begin(self._h, int(nsteps), int(qts_subdivisions), int(slots), int(bool(full_output)),
+                                                int(output_stride or 0)))
+        self._nsteps = nsteps
+        self._stream_keep = {}
+
+    def stream_push(self, qlat, boundary_q_ptr=None, rowset=None, hyd=None, q0=None, fvd=None):
+        """The next day: ``qlat`` [nseg, nq] (page-locked: ``_lib.result_empty(..., always_pinned=True)``), where its products go
+        (page-locked arrays or None), the device pointer of its boundary rows' flows.  Returns the day's number in the stream."""
+        if qlat.dtype != self.dtype or not qlat.flags.c_contiguous or qlat.ndim != 2 or qlat.shape[0] != self.nseg:
+            raise ValueError(f"qlat must be a C-contiguous {np.dtype(self.dtype).name} array of shape ({self.nseg}, nq)")
+        day = self.stream_info()["days_pushed"]
+        self._stream_keep[day] = (qlat, hyd, q0, fvd)          # (alive while the copies may be in flight)
+        for old in [k for k in self._stream_keep if k < day - 8]:
+            del self._stream_keep[old]
+        _lib.check(_lib.lib().trmc_stream_push(self._h, _lib.ptr(qlat), qlat.shape[1], C.c_void_p(boundary_q_ptr or 0),
+                                               -1 if rowset is None else int(rowset), _lib.ptr(hyd), _lib.ptr(q0), _lib.ptr(fvd)))
+        return day
+
+    def stream_flush(self):
+        _lib.check(_lib.lib().trmc_stream_flush(self._h))
+
+    def stream_wait(self, day):
+        _lib.check(_lib.lib().trmc_stream_wait(self._h, int(day)))
+
+    def stream_info(self):
+        v = [C.c_int32(0) for _ in range(5)] + [C.c_int64(0) for _ in range(3)]
+        _lib.check(_lib.lib().trmc_stream_info(self._h, *[C.byref(x) for x in v]))
+        names = ("slots", "tiles_per_day", "lag_max", "wide_levels", "cluster_levels", "days_pushed", "days_complete", "launches")
+        return {k: x.value for k, x in zip(names, v)}
+
+    def stream_end(self):
+        _lib.check(_lib.lib().trmc_stream_end(self._h))
+        self._stream_keep = {}
 
     def stream(self):
         """hipStream_t of the plan as an integer (what troute_amd.comm's event / stream calls and the collectives take)."""

@@ -8,7 +8,7 @@ import pytest
 
 import helpers as H
 from troute_amd import _lib
-from troute_amd.plan import RoutingPlan, csr_from_lists, segments, topology_levels
+from troute_amd.plan import RoutingPlan, csr_from_lists, segments, topology_clusters, topology_levels
 from troute_amd.routing.fast_reach.mc_reach import _flatten_network, binary_find, column_mapper
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in trmc.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with trmc.h"
-    assert lib.trmc_abi_version() == 17
+    assert lib.trmc_abi_version() == 18
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "trdw.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(trdw_[a-z0-9_]+)\s*\(", hdr))
     for name in declared:
@@ -260,6 +260,73 @@ def test_block_order_is_a_valid_dataflow_order():
         for h in (None, hint):
             for tiers in (True, False):
                 _check_block_order(bp, bi, boundary, h, tiers)
+
+
+def _check_cluster_order(up_ptr, up_idx, boundary, hint, wide_min_rows, cluster_rows):
+    nseg = up_ptr.shape[0] - 1
+    lvl, _, nlevels = topology_levels(up_ptr, up_idx, boundary)
+    pos, lag, blk, W, C, nb = topology_clusters(up_ptr, up_idx, boundary, hint, wide_min_rows=wide_min_rows,
+                                                wide_max_levels=16, cluster_rows=cluster_rows)
+    assert np.array_equal(np.sort(pos), np.arange(nseg))                 # a permutation of the rows
+    routed = lvl >= 0
+    assert np.all(lag[~routed] == -1) and np.all(blk[~routed] == -1)
+    assert np.all(pos[~routed] < (~routed).sum())                        # boundary rows first
+    # the leading slices are the levels themselves, in level order, each with at least wide_min_rows rows
+    width = np.bincount(lvl[routed], minlength=max(nlevels, 1))
+    want_w = 0
+    while want_w < min(nlevels, 16) and wide_min_rows > 0 and width[want_w] >= wide_min_rows:
+        want_w += 1
+    assert W == want_w
+    sl = routed & (lvl < W)
+    assert np.array_equal(lag[sl], lvl[sl]) and np.all(blk[sl] == -1)
+    if W > 0 and sl.any():
+        assert np.all(np.diff(lvl[sl][np.argsort(pos[sl])]) >= 0)
+        assert pos[sl].max() < pos[routed & (lvl >= W)].min(initial=nseg)
+    cl = routed & (lvl >= W)
+    assert np.all(blk[cl] >= 0) and np.all(lag[cl] >= W)
+    if cl.any():
+        assert C == lag[cl].max() - W + 1 and nb == blk[cl].max() + 1
+        # a block: consecutive positions, at most cluster_rows of them, one lag; blocks ordered by lag
+        order = np.argsort(pos[cl])
+        b_sorted, l_sorted = blk[cl][order], lag[cl][order]
+        assert np.all(np.diff(b_sorted) >= 0) and np.all(np.diff(l_sorted) >= 0)
+        assert np.bincount(b_sorted).max() <= cluster_rows
+        first = np.r_[0, np.flatnonzero(np.diff(b_sorted)) + 1]
+        assert np.all(np.maximum.reduceat(l_sorted, first) == np.minimum.reduceat(l_sorted, first))
+    else:
+        assert C == 0 and nb == 0
+    # THE promise: a row reads only rows of its own block (same lag: they advance together) or rows that run ahead of it
+    down = np.repeat(np.arange(nseg), np.diff(up_ptr))
+    keep = routed[up_idx] & routed[down]
+    u, d = up_idx[keep], down[keep]
+    same = (blk[u] == blk[d]) & (blk[d] >= 0)
+    assert np.all(lag[u][same] == lag[d][same])
+    assert np.all(lag[u][~same] < lag[d][~same])
+    return W, C, nb
+
+
+def test_cluster_order_is_a_valid_skewed_order():
+    """trmc_plan_options.cluster_rows (csrc/topology.hpp): the rows below the wide levels in clusters -- what k_mc_ctile relies on"""
+    rng = np.random.default_rng(77)
+    for nseg in (1, 2, 65, 700, 5000, 30000):
+        to = H.random_network(rng, nseg)
+        _, _, ups = H.reaches_from_to(to)
+        up_ptr, up_idx = csr_from_lists(ups)
+        for wide, rows in ((0, 128), (40, 128), (8, 16), (0, 1), (300, 5)):
+            hint = rng.integers(0, 4, nseg).astype(np.uint8) if wide == 40 else None
+            _check_cluster_order(up_ptr, up_idx, None, hint, wide, rows)
+    # with boundary rows (prescribed hydrographs: they constrain nothing) and the LowerColorado network
+    lc = H.LowerColorado()
+    up_ptr, up_idx = lc.csr()
+    b = np.zeros(lc.nseg, np.uint8)
+    b[rng.choice(lc.nseg, 40, replace=False)] = 1
+    _check_cluster_order(up_ptr, up_idx, b, None, 0, 128)
+    W, C, nb = _check_cluster_order(up_ptr, up_idx, None, None, 0, 128)
+    # 649 levels of segments (SURVEY 8a12: longest segment path 649) become a few cluster levels of 128 rows, blocks almost full
+    lvl, _, nlevels = topology_levels(up_ptr, up_idx)
+    assert nlevels == 649 and W == 0 and C <= 24 and nb <= int(np.ceil(lc.nseg / 128 * 1.05))
+    with pytest.raises(ValueError):
+        topology_clusters(up_ptr, up_idx, cluster_rows=129)
 
 
 def test_block_order_groups_rows_by_cost_tier_and_keeps_chains_together():

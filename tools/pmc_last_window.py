@@ -8,7 +8,7 @@ import sys
 
 
 def short(n):
-    for k in ("k_mc_tile", "k_mc_step", "k_emit", "k_init_state", "k_prep_qlat", "k_gather_rows", "k_final_state", "k_mc_flow_lean", "k_mc_flow"):
+    for k in ("k_mc_ctile", "k_mc_tile", "k_mc_step", "k_emit", "k_init_state", "k_prep_qlat", "k_gather_rows", "k_final_state", "k_mc_flow_lean", "k_mc_flow"):
         if k in n:
             return k
     return n[:32]
