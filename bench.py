@@ -188,7 +188,7 @@ def cpu_baseline(net, qlat, nsteps, qts, short_ts, target_s, cpu_threads=0):
     }
 
 
-def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0, plan=None, final_fetched=None):
+def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0, plan=None, final_fetched=None, fvd_fetched=None):
     """Checker, run AFTER the timed region: EVERY segment of the workload -- the dominant basin included -- is routed on the
     CPU by the reference Fortran kernel (canonical Qj_0; oracle/_ref built from the reference's sources, else the pinned
     restatement) through the same sequence of windows the router has been through -- `days`: the forcing of day N-1 (cold
@@ -216,11 +216,14 @@ def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0, pla
         base.update({"bit_identical": same_o, "compared": "the all-gathered outlet hydrographs of every network",
                      "differing_values": int((u32(o_hyd) != u32(want_o)).sum()), "seconds": round(time.perf_counter() - t0, 1)})
         return base
-    plan = plan if plan is not None else router.plan0          # (the plan that routed the last window)
-    fvd = plan.download_fvd().reshape(nseg, nsteps, 3)
-    final = plan.download_final_state()
-    if final_fetched is not None and not np.array_equal(u32(final_fetched), u32(final)):
-        return dict(base, bit_identical=False, error="the asynchronously fetched final state differs from the plan's")
+    if fvd_fetched is not None:                                # (a stream of windows: the last day's products as they arrived)
+        fvd, final = np.asarray(fvd_fetched).reshape(nseg, nsteps, 3), final_fetched
+    else:
+        plan = plan if plan is not None else router.plan0      # (the plan that routed the last window)
+        fvd = plan.download_fvd().reshape(nseg, nsteps, 3)
+        final = plan.download_final_state()
+        if final_fetched is not None and not np.array_equal(u32(final_fetched), u32(final)):
+            return dict(base, bit_identical=False, error="the asynchronously fetched final state differs from the plan's")
     diff_q = 0
     for lo in range(0, nseg, 200000):
         diff_q += int((u32(fvd[lo:lo + 200000, :, 0]) != u32(ref["q"][lo:lo + 200000, 1:])).sum())
@@ -440,15 +443,22 @@ def main():
     qlat_b = synthetic.forcing(nseg, qlat_s.shape[1], synthetic.DEFAULT_SEED + 2, previous=qlat_a)
     q0 = np.zeros((nseg, 3), dtype=np.float32)
 
-    tuned = {"speed": None, "part": None}
+    tuned = {"speed": None, "part": None, "part_last": None}
 
-    def make_router(hint, short_ts, qlat, state, options=None):
+    def make_router(hint, short_ts, qlat, state, options=None, stream=False):
         # with a hint (the measured cost of every row on the tuning day) the partition is packed by cost as well, and by the
         # pace every rank was MEASURED to keep on that day (what a trunk does to its owner is in there; sharding.partition)
         part = (sharding.partition(to, world, row_cost=hint, rank_speed=tuned["speed"], previous=tuned["part"])
                 if (hint is not None and world > 1) else None)
+        if stream:                                     # (the plans a STREAM of windows runs on: troute_amd.sequence.RouteStream)
+            r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint,
+                              partition=tuned["part_last"] if tuned["part_last"] is not None else part, options=options, stream=True)
+            if use_dist:
+                r.enable_device_exchange(comm)
+            return r
         r = ShardedRouter(to, params, rank=rank, world=world, device=local_rank, precision=a.precision, cost_hint=hint,
                           assume_short_ts=short_ts, partition=part, options=options)
+        tuned["part_last"] = r.part if world > 1 else None
         r.upload(a.nsteps, qlat, state)
         if use_dist:
             r.enable_device_exchange(comm)
@@ -625,26 +635,71 @@ def main():
     # (diagnosis only, with --headline-only: TRMC_BENCH_OUTPUT_STRIDE=n times / traces the pipeline with the decimated result
     # among each day's products -- the `hourly_output.in_sequence` leg -- in place of the headline's)
     ostride = (int(os.environ.get("TRMC_BENCH_OUTPUT_STRIDE", "0")) or None) if a.headline_only else None
+    # THE HEADLINE (round 6): the days as ONE STREAM of tile launches (troute_amd.sequence.RouteStream, trmc_stream_*) on a router
+    # whose plans are in cluster order -- every launch carries every row, a day costs nsteps / 16 launches on the tile stream and
+    # as many on the clusters', nothing between two days; on several ranks the cut-edge hydrographs are exchanged once a day.
+    # TRMC_BENCH_PIPELINE=two-plans times round 5's pipeline (DaySequence: a plan and its clone) as the headline instead.
+    from troute_amd.sequence import RouteStream
+    use_stream = os.environ.get("TRMC_BENCH_PIPELINE", "stream") != "two-plans" and a.precision == 32
     dayseq = DaySequence(router, a.nsteps, a.qts, nchunks=a.chunks, output_stride=ostride,
                          timeline=bool(os.environ.get("TRMC_BENCH_DEBUG")))
-    if use_dist:
+    srouter, stream_ring, stream_err = None, None, None
+    if use_stream:
+        try:
+            srouter = make_router(hint, True, None, None, stream=True)
+            with RouteStream(srouter, a.nsteps, a.qts, output_stride=ostride) as rs:
+                # (this rank's rows of every day, page-locked: outside the clock; one GPU: the ring's arrays as they are)
+                stream_ring = rs.prepare_days(ring) if use_dist else ring
+                rs.run(stream_ring, state_n, 2, 0, prepared=True)   # (untimed: the ring of day slots, the page-locked product rings)
+                sseq = rs.run(stream_ring, state_n, a.steps, a.warmup, prepared=True)
+            sinfo = sseq["info"]
+            tpd = sinfo["tiles_per_day"]
+            nrouted = int(srouter._rowsS.shape[0]) if use_dist else nseg
+            push_ms = float(np.mean(sseq["push_ms"])) if sseq["push_ms"] else sseq["el"] / a.steps * 1e3
+            sstats = {"segment_steps": nrouted * a.nsteps, "main_launches": sinfo["launches"] // max(1, sseq["days_routed"]),
+                      "wide_launches": tpd if sinfo["wide_levels"] > 0 else 0, "wide_levels": sinfo["wide_levels"], "wide_k": a.nsteps // tpd,
+                      "cluster_levels": sinfo["cluster_levels"], "lag_max_tiles": sinfo["lag_max"], "slots": sinfo["slots"],
+                      "ms_wide": push_ms, "ms_main": sseq["el"] / a.steps * 1e3}
+            lagS = srouter.stream_plan(getattr(srouter, "_planS_lag", 0)).lags()[0]
+            sstats["wide_segment_steps"] = int((lagS[lagS >= 0] < sinfo["wide_levels"]).sum()) * a.nsteps
+            head = {"el": sseq["el"], "ms_main": sseq["el"] / a.steps * 1e3, "ms_total": sseq["el"] / a.steps * 1e3,
+                    "launches": sstats["main_launches"], "stats": {"phase0": sstats}, "hyd": sseq["hyd"], "steps": a.steps,
+                    "stream": {"warmup_days": sseq["warmup"], **sinfo}}
+            seq = {"day_ms": [round(x, 2) for x in sseq["push_ms"]], "hyd": sseq["hyd"], "el": sseq["el"]}
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            stream_err, use_stream = repr(e), False
+            if use_dist:
+                raise
+    two_plans = None
+    if use_dist and not use_stream:
         local_ring = dayseq.prepare_days(ring)          # (this rank's rows of every day, page-locked: outside the clock)
         seq = dayseq.run(local_ring, state_n, a.steps, a.warmup, prepared=True)
         head = {"el": seq["el"], "ms_main": float(np.mean(seq["ms_main"])), "ms_total": seq["el"] / a.steps * 1e3,
                 "launches": router.last_stats["phase0"]["main_launches"], "stats": router.last_stats, "hyd": seq["hyd"], "steps": a.steps}
-    else:
+    elif not use_dist and not (use_stream and a.headline_only):
+        # round 5's pipeline -- a plan and its clone taking turns (DaySequence) -- beside the stream (`pipeline_two_plans`), or as
+        # the headline itself (TRMC_BENCH_PIPELINE=two-plans)
         # (untimed: the clone's window buffers -- 19 GB of planes and result -- and both plans' copy streams and page-locked
         # result rings are made at their first use)
         # ... and every page-locked array -- the ring of days, the three result sets of either plan -- is used by a copy for the
         # first time (a first use costs milliseconds once: the third timed day took 20-22 ms and the fourth 13 without this)
         dayseq.run(ring, state_n, max(6, len(ring)), 0)
-        seq = dayseq.run(ring, state_n, a.steps, a.warmup)
-        # (ms_main of the sequence: the WALL time per day, every kernel, copy and hand-over of the pipeline in it -- the events
-        # around a single window also span what the neighbouring day's kernels take of the device while they overlap it)
-        head = {"el": seq["el"], "ms_main": seq["el"] / a.steps * 1e3, "ms_total": seq["el"] / a.steps * 1e3,
-                "ms_window_events": float(np.mean(seq["ms_main"])),
-                "launches": router.plan0.stats()["main_launches"], "stats": {"phase0": seq["last_plan"].stats()},
-                "hyd": seq["hyd"], "steps": a.steps}
+        osteps = a.steps if not use_stream else max(2, min(a.steps, 6))
+        oseq = dayseq.run(ring, state_n, osteps, a.warmup)
+        two_plans = {"ms_per_step": oseq["el"] / osteps * 1e3, "steps": osteps, "value": nseg * a.nsteps * osteps / oseq["el"],
+                     "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / (oseq["el"] / osteps) / 1e9 / HBM_PEAK_GBS,
+                     "what": "round 5's headline pipeline on the same days: a plan and its clone taking turns (DaySequence), the narrow levels "
+                             "one launch per timestep"}
+        if not use_stream:
+            seq = oseq
+            # (ms_main of the sequence: the WALL time per day, every kernel, copy and hand-over of the pipeline in it -- the events
+            # around a single window also span what the neighbouring day's kernels take of the device while they overlap it)
+            head = {"el": seq["el"], "ms_main": seq["el"] / a.steps * 1e3, "ms_total": seq["el"] / a.steps * 1e3,
+                    "ms_window_events": float(np.mean(seq["ms_main"])),
+                    "launches": router.plan0.stats()["main_launches"], "stats": {"phase0": seq["last_plan"].stats()},
+                    "hyd": seq["hyd"], "steps": a.steps}
         # how much of this rests on the day-to-day persistence of the forcing: the same pipeline with half, and with none, of
         # the rows keeping their magnitude from one day to the next (the plan stays the one tuned on day N)
         if not a.headline_only and not a.no_persistence_sweep:
@@ -656,7 +711,11 @@ def main():
                     r2.append(ring[i])                # (the page-locked arrays of the headline's ring are reused)
                     ring[i][...] = day
                     prev_day = day
-                s2 = dayseq.run(r2, state_n, 4, 1)
+                if use_stream:                        # (the headline's pipeline: the stream; one GPU: its days are the ring's arrays)
+                    with RouteStream(srouter, a.nsteps, a.qts) as rs:
+                        s2 = rs.run(r2, state_n, 4, 1, prepared=True)
+                else:
+                    s2 = dayseq.run(r2, state_n, 4, 1)
                 persist[str(pv)] = {"ms_per_day": s2["el"] / 4 * 1e3,
                                     "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / (s2["el"] / 4) / 1e9 / HBM_PEAK_GBS}
             persist["what"] = ("the timed pipeline on the same tuned plan with days whose rows keep their forcing magnitude with "
@@ -686,6 +745,8 @@ def main():
             json_out.flush()
         dayseq.close()
         router.close()
+        if srouter is not None:
+            srouter.close()
         if comm is not None:
             comm.close()
         return
@@ -696,9 +757,16 @@ def main():
     if use_dist and not a.no_parity_full and a.precision == 32:
         # the first two days of the timed sequence once more, untimed, from the state after day N: the all-gathered outlet block
         # of day N+2 is what rank 0 hands to the checker (AFTER the last leg the ranks take together)
-        chk = dayseq.run(local_ring[:2], state_n, 2, 0, prepared=True)
-        if rank == 0:
-            dist_outlets = (np.array(router._out_rows, copy=True), np.array(chk["hyd"], copy=True))
+        if use_stream:
+            with RouteStream(srouter, a.nsteps, a.qts) as rs:
+                chk = rs.run(stream_ring[:2], state_n, 2, 0, prepared=True)
+                out_rows_s = rs.outlet_rows
+            if rank == 0:
+                dist_outlets = (np.array(out_rows_s, copy=True), np.array(chk["hyd"], copy=True))
+        else:
+            chk = dayseq.run(local_ring[:2], state_n, 2, 0, prepared=True)
+            if rank == 0:
+                dist_outlets = (np.array(router._out_rows, copy=True), np.array(chk["hyd"], copy=True))
     router.upload(a.nsteps, qlat_b, None if use_dist else state_n)   # (the legs below route day N+1 again and again on the one plan)
     resident = timed(router, True, max(1, min(a.steps, 3)), 1)
     value = rate(head)
@@ -758,6 +826,25 @@ def main():
                 extra["hourly_output"]["in_sequence"] = {"error": repr(e)}
             finally:
                 dayseq.set_output_stride(None)
+            if use_stream:
+                try:      # ... and as a product of the STREAM's days (the tiles write the kept steps aside as they go; nothing else of the result is assembled)
+                    with RouteStream(srouter, a.nsteps, a.qts, output_stride=a.qts) as rs:
+                        rs.run(ring[:4], state_n, 2, 0, prepared=True)
+                        hsteps = max(2, min(a.steps, 6))
+                        hs = rs.run(ring, state_n, hsteps, 1, prepared=True)
+                        rows_o = np.array(rs.outlet_rows, copy=True)
+                    per = hs["el"] / hsteps
+                    extra["hourly_output"]["in_stream"] = {
+                        "value": nseg * a.nsteps / per, "ms_per_step": per * 1e3, "steps": hsteps,
+                        "outlet_rows_equal_the_fetched_hydrographs": bool(np.array_equal(
+                            hs["fvd"][rows_o, :, 0].view(np.uint32), hs["hyd"][:, a.qts - 1::a.qts].view(np.uint32))),
+                        "what": "the headline's stream with every row's (q, v, d) at every qts-th step among each day's products"}
+                    del hs
+                except Exception as e:
+                    extra["hourly_output"]["in_stream"] = {"error": repr(e)}
+            try:
+                pass
+            finally:
                 for pl_ in dayseq.plans:
                     pl_._fetch_ring = None
                 _tl.pinned_pool_clear()
@@ -805,16 +892,31 @@ def main():
             # the timed pipeline once more, untimed, over the first two days of the ring (days N+1 and N+2 from the state
             # after day N: plan and clone, staged forcing, state handed over on the device, asynchronous fetch), and the
             # reference on the CPU through ALL the days from the cold start: N-1, N, N+1, N+2
-            chk = dayseq.run(ring[:2], state_n, 2, 0)
-            parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
-                                 outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
-                                 final_fetched=chk["final"])
-            parity["pipeline"] = ("the timed pass's pipeline (plan + clone, forcing staged from page-locked memory, state handed "
-                                  "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
+            if use_stream:
+                # the timed pass's pipeline -- the stream -- once more, untimed, over days N+1 and N+2 from the state after day N,
+                # this time with every day's full result assembled and day N+2's handed over with its other products
+                with RouteStream(srouter, a.nsteps, a.qts, full_output=True) as rs:
+                    chk = rs.run(ring[:2], state_n, 2, 0, prepared=True)
+                    o_rows = np.array(rs.outlet_rows, copy=True)
+                parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts, outlets=(o_rows, chk["hyd"]),
+                                     threads=a.cpu_threads, final_fetched=chk["final"], fvd_fetched=chk["fvd"])
+                parity["pipeline"] = ("the timed pass's pipeline (ONE stream of tile launches over the days, forcing staged from page-locked "
+                                      "memory, a ring of day slots in HBM, products copied beside the launches that follow) re-run untimed "
+                                      "over days N+1, N+2 with the full result of every day assembled; day N+2's compared")
+                del chk
+            else:
+                chk = dayseq.run(ring[:2], state_n, 2, 0)
+                parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts,
+                                     outlets=(router.my_out0_global, chk["hyd"]), threads=a.cpu_threads, plan=chk["last_plan"],
+                                     final_fetched=chk["final"])
+                parity["pipeline"] = ("the timed pass's pipeline (plan + clone, forcing staged from page-locked memory, state handed "
+                                      "over in HBM, asynchronous fetch) re-run untimed over days N+1, N+2")
         except Exception as e:
             parity = {"error": repr(e)}
     dayseq.close()
     router.close()
+    if srouter is not None:
+        srouter.close()
 
     full = None
     if not a.no_full_ts:
@@ -869,13 +971,17 @@ def main():
             k_ms, k_launches, k_bytes = st0["ms_wide"], wl, wss * bytes_per / wl
             tail = {"kernel": f"k_mc_step<{tname},true>", "launches_per_step": launches - wl,
                     "segment_steps": int(seg0 - wss), "runs": "on the tail stream, beside the wide launches"}
+            if head.get("stream"):
+                tail = {"kernel": f"k_mc_ctile<{tname}>", "launches_per_step": launches - wl, "segment_steps": int(seg0 - wss),
+                        "runs": "the rows below the slices, in clusters, on the plan's own stream beside the slices' launches; K steps per launch too"}
         else:
             kernel = {"levels": f"k_mc_step<{tname},true>", "flow": "k_mc_flow_lean / k_mc_flow<true>"}[engine]
             pat = "k_mc_step" if engine == "levels" else "k_mc_flow"
             k_ms, k_launches, k_bytes = head["ms_main"], launches, seg0 * bytes_per / launches
             tail = None
         k_achieved = k_bytes * k_launches / (k_ms * 1e-3) / 1e9
-        pmc = pmc_counters(pat, k_launches, a) if rank == 0 else {}
+        pmc = pmc_counters(pat, k_launches, a, stream=None if not head.get("stream") else
+                           {"lag_max": head["stream"]["lag_max"], "launches_per_day": launches}) if rank == 0 else {}
         valu = pmc.get("valu")
         dominant = {
             "kernel": kernel, "achieved": k_achieved, "frac": k_achieved / HBM_PEAK_GBS,
@@ -883,6 +989,9 @@ def main():
             "traffic": pmc.get("traffic"), "valu": valu,
             "what": "algorithmic bytes of one launch over its mean duration, HIP events around every launch on its stream",
         }
+        if head.get("stream"):
+            dominant["what"] = ("algorithmic bytes of one launch over its mean duration: HIP events on the tile stream around the nsteps / K "
+                                "launches of each timed day (they follow each other without a gap), / their number")
         if tail is not None:
             # its launches share the device with the tail's: the duration above is that of a kernel that has part of the
             # device; alone (the serialised launches of the counter passes) it is shorter
@@ -897,7 +1006,8 @@ def main():
             # segment-steps over the device time of ALL its kernels (HIP events on the plan's stream around the window) --
             # which no overlap can flatter.  `dominant_kernel` keeps the per-kernel arithmetic beside it.
             roof = {
-                "bound": "hbm", "kernel": f"{kernel} + {tail['kernel']} + k_emit<{tname}>, concurrent streams: one routing window",
+                "bound": "hbm", "kernel": (f"{kernel} + {tail['kernel']}, concurrent streams: one day of the stream" if head.get("stream") else
+                                           f"{kernel} + {tail['kernel']} + k_emit<{tname}>, concurrent streams: one routing window"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc.get("window_traffic"),
                 "launches_per_step": launches, "avg_launch_ms": head["ms_main"], "alg_bytes_per_launch": seg0 * bytes_per,
@@ -932,7 +1042,12 @@ def main():
                 "workload": "synthetic CONUS NHDPlus-shaped network, MC-only, 24 h @ 300 s dt (configs[2])",
                 "segments": int(nseg), "networks": int(len(net["net_sizes"])), "timesteps": a.nsteps,
                 "qts_subdivisions": a.qts, "assume_short_ts": True,
-                "timed_window": ("a sequence of consecutive days with distinct forcing after day N-1 (spin-up from cold) and day N (tuning): forcing "
+                "timed_window": ("consecutive days with distinct forcing after day N-1 (spin-up from cold) and day N (tuning) as ONE stream of "
+                                 "tile launches (troute_amd.sequence.RouteStream): forcing host-to-device, the state carried on in HBM, outlet "
+                                 "hydrographs + final state of every day to the host, all inside the clock; the clock covers `steps` days of "
+                                 "launches between two device synchronisations, the stream full (every launch carries every row)"
+                                 if head.get("stream") else
+                                 "a sequence of consecutive days with distinct forcing after day N-1 (spin-up from cold) and day N (tuning): forcing "
                                  "host-to-device, state handed on in HBM, outlet hydrographs + final state to the host, all inside the clock, "
                                  "on a plan and its clone") if seq is not None else
                                 "day N+1 of three consecutive days of the same basin (N-1 spin-up from cold, N tuning, N+1 timed), warm start from the state day N leaves in HBM",
@@ -951,6 +1066,9 @@ def main():
             "cpu_baseline": cpu,
             "parity_full": parity,
             "forcing_persistence": persist,
+            "stream": head.get("stream"),
+            "stream_error": stream_err,
+            "pipeline_two_plans": two_plans,
             "untuned": untuned,
             "full_ts": full,
             "per_rank": per_rank,
@@ -962,7 +1080,7 @@ def main():
         json_out.flush()
 
 
-def pmc_counters(pattern, launches_per_window, args):
+def pmc_counters(pattern, launches_per_window, args, stream=None):
     """Hardware counters of the dominant kernel, MEASURED IN THIS RUN: three counter-only rocprofv3 passes (--kernel-trace
     only, as MI355X_MICROARCH.md prescribes: FETCH_SIZE; WRITE_SIZE; the SQ instruction / cycle counters) over a child run of
     this script that stops after one headline window (--headline-only), read per dispatch for the LAST window's launches of
@@ -1013,6 +1131,9 @@ def pmc_counters(pattern, launches_per_window, args):
                 disp = con.execute(
                     "select d.id, d.event_id, d.end - d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
                     "on d.kernel_id = s.id where s.kernel_name like ? order by d.start", (f"%{pattern}%",)).fetchall()
+                if stream:      # (a stream of windows ends with `lag_max` launches that only bring the last days to their end: the
+                    #  last FULL day is the launches before those)
+                    disp = disp[:len(disp) - int(stream["lag_max"])]
                 last = disp[-int(launches_per_window):]
                 ev = [x[1] for x in last]
                 q = ",".join("?" * len(ev))
@@ -1028,6 +1149,8 @@ def pmc_counters(pattern, launches_per_window, args):
                     "on d.kernel_id = s.id order by d.start").fetchall()
                 first = max(j for j, x in enumerate(alld) if "k_prep_qlat" in x[1])   # (a window starts with its forcing transpose)
                 wev = [x[0] for x in alld[first:]]
+                if stream:      # (the last day pushed: the tile launches of both kinds that its push queued, nothing of the flush behind them)
+                    wev = [x[0] for x in alld[first:] if "k_mc_tile" in x[1] or "k_mc_ctile" in x[1]][:int(stream["launches_per_day"])]
                 for lo in range(0, len(wev), 500):
                     part = wev[lo:lo + 500]
                     q = ",".join("?" * len(part))

@@ -250,10 +250,26 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
 int trmc_stream_begin(trmc_plan *plan, int nsteps, int qts_subdivisions, int slots, int full_output, int output_stride);
 int trmc_stream_push(trmc_plan *plan, const void *qlat, int64_t nq, const void *boundary_q_dev, int32_t rowset, void *hyd_host,
                      void *q0_host, void *fvd_host);
+/* Multi-GPU streams (the trunk of a cut basin: rows fed by boundary rows, cluster_late_lag tiles behind).  trmc_stream_gather: the
+ * flows of a row set over `day` [rows][nsteps] into DEVICE memory, queued on `stream` (NULL: the plan's) behind the launches
+ * queued so far -- TRMC_ESTATE if the set's rows have not been queued through that day yet.  trmc_stream_boundary: the boundary
+ * rows' flows of `day` (already pushed, with boundary_q_dev = NULL) from a block of hydrographs in DEVICE memory -- boundary row b
+ * takes row index_dev[b] (NULL: row b) of q_dev, rows src_row_stride elements apart -- queued on `stream` (NULL: the copy stream);
+ * the launches of the NEXT push go behind it, so the rows that read boundary rows must run at least that far behind
+ * (trmc_plan_options.cluster_late_lag).  Calls for consecutive days in order. */
+int trmc_stream_gather(trmc_plan *plan, int64_t day, int32_t rowset, void *dst_dev, void *stream);
+int trmc_stream_boundary(trmc_plan *plan, int64_t day, const void *q_dev, int64_t src_row_stride, const int64_t *index_dev, void *stream);
+/* The next ntiles launches without a new day (the rows still under way move on; at most up to the launch that ends the last day
+ * pushed).  trmc_stream_flush = all of them.  A stream advanced this way takes a new day only once it has been flushed. */
+int trmc_stream_advance(trmc_plan *plan, int ntiles);
 int trmc_stream_flush(trmc_plan *plan);
 int trmc_stream_wait(trmc_plan *plan, int64_t day);
 int trmc_stream_info(const trmc_plan *plan, int32_t *slots, int32_t *tiles_per_day, int32_t *lag_max, int32_t *wide_levels,
                      int32_t *cluster_levels, int64_t *days_pushed, int64_t *days_complete, int64_t *launches);
+/* Device time (HIP events, ms) from the first to the last of the nsteps / wide_k launches that pushing `day` queued on the stream
+ * that carries the slices (the dominant kernel, k_mc_tile): / tiles_per_day = the mean duration of one launch beside whatever
+ * else runs.  Waits for those launches.  The day must still be in the ring. */
+int trmc_stream_day_ms(trmc_plan *plan, int64_t day, double *ms_out);
 int trmc_stream_end(trmc_plan *plan);
 
 /* Switch the sequence mode of a plan (see trmc_plan_options) between windows. */

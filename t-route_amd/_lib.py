@@ -101,9 +101,13 @@ SIGNATURES = {
     "trmc_plan_set_sequence_mode": (_int, [_vp, _int]),
     "trmc_stream_begin": (_int, [_vp, _int, _int, _int, _int, _int]),
     "trmc_stream_push": (_int, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "trmc_stream_gather": (_int, [_vp, _i64, _i32, _vp, _vp]),
+    "trmc_stream_boundary": (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "trmc_stream_advance": (_int, [_vp, _int]),
     "trmc_stream_flush": (_int, [_vp]),
     "trmc_stream_wait": (_int, [_vp, _i64]),
     "trmc_stream_info": (_int, [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i32), _P(_i32), _P(_i64), _P(_i64), _P(_i64)]),
+    "trmc_stream_day_ms": (_int, [_vp, _i64, _P(C.c_double)]),
     "trmc_stream_end": (_int, [_vp]),
     "trmc_plan_arithmetic": (_int, [_vp, _P(_i32)]),
     "trmc_plan_engine": (_int, [_vp, _P(_i32)]),
@@ -325,6 +329,7 @@ def _pool():
 
 def _pinned_release(address, nbytes):
     try:
+        _pinned_live.pop(address, None)
         if getattr(_pinned_inside, "depth", 0) > 0:      # a finalizer run by a collection inside the pool code of this thread
             _pinned_pending.append((address, nbytes))
             return
@@ -351,8 +356,22 @@ def result_empty(shape, dtype, always_pinned=False):
             return np.empty(shape, dtype=dtype)
         address = p.value
     buf = (C.c_char * nbytes).from_address(address)
+    _pinned_live[address] = nbytes
     weakref.finalize(buf, _pinned_release, address, nbytes)
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+_pinned_live = {}         # address -> nbytes of the page-locked buffers handed out and still alive
+
+
+def is_pinned(array):
+    """True if the array's memory lies inside a page-locked buffer this module handed out (``result_empty``): an asynchronous
+    copy can then read or write it where it is."""
+    if not isinstance(array, np.ndarray) or array.size == 0:
+        return False
+    lo = array.ctypes.data
+    hi = lo + array.nbytes
+    return array.flags.c_contiguous and any(a <= lo and hi <= a + n for a, n in list(_pinned_live.items()))
 
 
 def pinned_pool_clear():

@@ -2291,6 +2291,7 @@ struct trmc_plan {
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)
     std::vector<int64_t> rowset_n;
     std::vector<int32_t> rowset_lag;
+    std::vector<int32_t> rowset_lagk;   // cluster order: the largest tile lag among the set's rows (trmc_stream_gather)
 };
 
 namespace {
@@ -3576,6 +3577,7 @@ int check_device(int device)
 extern "C" {
 
 static void stream_release(trmc_plan *pl); // (stream.inc)
+static bool stream_active(const trmc_plan *pl);
 
 const char *trmc_last_error(void) { return g_err.c_str(); }
 int trmc_abi_version(void) { return TRMC_ABI_VERSION; }
@@ -4265,6 +4267,7 @@ static int upload_check(trmc_plan *pl, int nsteps, int64_t nq, const void *q0)
 {
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is in progress");
+    if (stream_active(pl)) return fail(TRMC_ESTATE, "a stream of windows is in progress (trmc_stream_end it first)");
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (nq < 1) return fail(TRMC_EINVAL, "qlat needs at least one column");
     if (pl->nseg > 0 && !q0 && pl->routed_nsteps < 0 && !pl->q0_staged)
@@ -4495,6 +4498,7 @@ static int route_check(trmc_plan *pl, int nsteps, int qts_subdivisions, bool bou
     if (!pl) return fail(TRMC_EINVAL, "plan is NULL");
     if (pl->staged_nsteps < 0) return fail(TRMC_ESTATE, "trmc_upload_forcing must precede routing");
     if (pl->run.active) return fail(TRMC_ESTATE, "a routing window is already in progress (trmc_route_end it first)");
+    if (stream_active(pl)) return fail(TRMC_ESTATE, "a stream of windows is in progress (trmc_stream_end it first)");
     if (nsteps < 1) return fail(TRMC_EINVAL, "nsteps must be >= 1");
     if (qts_subdivisions < 1) return fail(TRMC_EINVAL, "qts_subdivisions must be >= 1");
     if (pl->topo.nboundary > 0 && nsteps != pl->staged_nsteps)
@@ -4672,6 +4676,10 @@ int trmc_rowset_create(trmc_plan *pl, const int64_t *rows, int64_t nrows, int32_
     pl->rowsets.push_back(b);
     pl->rowset_n.push_back(nrows);
     pl->rowset_lag.push_back(rs_lag);
+    int32_t lk = 0;
+    if (!pl->topo.lagk_of_pos.empty())
+        for (int64_t i = 0; i < nrows; ++i) lk = std::max(lk, pl->topo.lagk_of_pos[(size_t)pos[i]]);
+    pl->rowset_lagk.push_back(lk);
     *id_out = (int32_t)pl->rowsets.size() - 1;
     return 0;
 }

@@ -43,12 +43,19 @@ class _EngineOf:
 
 class ShardedRouter:
     def __init__(self, to, params, rank=0, world=1, device=0, plan_factory=None, precision=32,
-                 partition=None, cost_hint=None, assume_short_ts=None, engine="auto", options=None):
+                 partition=None, cost_hint=None, assume_short_ts=None, engine="auto", options=None, stream=False):
         """cost_hint: optional uint8 [nseg] (global rows), the ``iteration_hint()`` of a router of the same network
         after a window -- every plan then groups its rows by that cost (RoutingPlan ``cost_hint``; results unchanged,
         the kernels' wavefronts become uniform in cost).  assume_short_ts / engine: passed to every RoutingPlan (the
         timestep mode the router will be used with, if known; "auto" | "levels" | "flow"); options: RoutingPlan's (a dict of
         trmc_plan_options fields, e.g. {"arithmetic": "tolerance"})."""
+        # stream=True: the router's windows follow each other as a STREAM (troute_amd.sequence.RouteStream, trmc_stream_*): its
+        # plans are short-timestep plans of the level engine in cluster order, with as many levels in slices as are worth a
+        # slice (in a stream they cost no launches)
+        self._stream = bool(stream)
+        if stream:
+            options = {"cluster_rows": 128, "wide_min_rows": 1024, **(options or {})}
+            assume_short_ts, engine = True, "levels"
         if plan_factory is None:
             from .plan import RoutingPlan  # the HIP engine; no fallback
             from . import _lib
@@ -57,10 +64,11 @@ class ShardedRouter:
             # changes nothing for other HIP users of the process.
             _lib.single_hw_queue_per_priority("troute_amd.distributed.ShardedRouter")
 
-            def plan_factory(lp, li, par, boundary, prec, dev, short=None, **kw):
+            def plan_factory(lp, li, par, boundary, prec, dev, short=None, extra_options=None, **kw):
                 # short: the merged plan of the short-timestep device path is built for that mode whatever the caller said
+                opt = options if not extra_options else {**(options or {}), **extra_options}
                 return RoutingPlan(lp, li, par, boundary, prec, dev,
-                                   assume_short_ts=assume_short_ts if short is None else short, engine=engine, options=options, **kw)
+                                   assume_short_ts=assume_short_ts if short is None else short, engine=engine, options=opt, **kw)
         from .synthetic import upstream_csr
         self._hint = None if cost_hint is None else np.ascontiguousarray(cost_hint, dtype=np.uint8)
         if self._hint is not None:
@@ -167,6 +175,8 @@ class ShardedRouter:
             return True
         if self.planM is not None:
             take(self.planM, self._rowsM)
+        if getattr(self, "_planS", None) is not None and self._planS is not self.plan0:
+            take(self._planS, self._rowsS)
         take(self.plan0, self.rows0)
         if self.plan1 is not None:
             take(self.plan1, self.rows1)
@@ -313,6 +323,49 @@ class ShardedRouter:
             self.planM.upload_forcing(self.nsteps, self._qlat[self._rowsM], self._q0_of(self._rowsM), None)
             self._planM_upload = self._upload_gen
         return self.planM
+
+    # ---- a STREAM of days on this rank (troute_amd.sequence.RouteStream) ---------------------------------------------------
+    def stream_plan(self, late_lag=0):
+        """The plan a stream of windows runs on (router made with ``stream=True``): plan0 itself where this rank owns no trunk,
+        else plan0's table followed by the trunk table (trunk rows + boundary copies of the cut rows that feed it) in ONE
+        cluster-ordered plan whose trunk rows run at least ``late_lag`` tiles behind the headwaters -- their inflows are
+        exchanged once a day (no lag table, no chunks: every row of a stream has its own tile lag).  Also sets the row sets
+        ``_rsS_cut`` (my cut rows), ``_rsS_out`` (my outlets: sub-basins', then the trunk's)."""
+        if not self._stream:
+            raise ValueError("ShardedRouter(..., stream=True) builds the plans a stream of windows runs on")
+        if getattr(self, "_planS", None) is not None and self._planS_lag == late_lag:
+            return self._planS
+        self._close_stream_plan()
+        mk = self._mk
+        n0 = self.rows0.shape[0]
+        if self.plan1 is None:
+            P = self.plan0
+            self._rowsS = self.rows0
+            out_local = self.my_out0_local
+        else:
+            lp0, li0 = mk["csr0"]
+            lp1, li1 = mk["csr1"]
+            up_ptr = np.concatenate([lp0, lp0[-1] + lp1[1:]])
+            up_idx = np.concatenate([li0, li1 + n0])
+            rows = np.concatenate([self.rows0, self.rows1])
+            boundary = np.concatenate([np.zeros(n0, np.uint8), np.where(self.boundary1, 1, 2).astype(np.uint8)])
+            self._rowsS = rows
+            P = mk["factory"](up_ptr, up_idx, mk["params"][rows], boundary, mk["precision"], mk["device"], rows=rows,
+                              short=True, extra_options={"cluster_late_lag": int(late_lag)})
+            out_local = np.concatenate([self.my_out0_local, n0 + self.my_out1_local]) if self.my_out1_global.size else self.my_out0_local
+        self._planS, self._planS_lag = P, late_lag
+        self._rsS_cut = P.rowset(self.my_cut_local)
+        self._rsS_out = P.rowset(out_local)
+        self._outS_global = np.concatenate([self.my_out0_global, self.my_out1_global])
+        if self._collect:
+            P.collect_cost(True)
+        return P
+
+    def _close_stream_plan(self):
+        P = getattr(self, "_planS", None)
+        if P is not None and P is not self.plan0:
+            P.close()
+        self._planS = None
 
     # ---- a sequence of days on this rank (troute_amd.sequence.DaySequence): the forcing staged by the caller, day by day ----
     def sequence_rows(self):
@@ -537,6 +590,7 @@ class ShardedRouter:
         return self._out_rows, X.DeviceArray(hyd, (self._out_rows.shape[0], nsteps), self.dtype, sc)
 
     def close(self):
+        self._close_stream_plan()
         if self.planM is not None:
             self.planM.close()
         self.plan0.close()

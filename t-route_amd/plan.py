@@ -136,10 +136,12 @@ class RoutingPlan:
                                                    C.byref(h)))
         self._h = h
         self.arithmetic = "tolerance" if opt.arithmetic == _lib.ARITH_TOLERANCE else "exact"
+        self.tile_steps = int(opt.wide_k) if opt.wide_k > 0 else 16          # steps per tile launch (trmc_plan_options.wide_k)
         f = C.c_int32(0)
         _lib.check(_lib.lib().trmc_plan_engine(self._h, C.byref(f)))
         self.engine = "flow" if f.value else "levels"
         self._nsteps = None
+        self._stream_keep = {}
         self.maxlag = 0
 
     # -- lifetime ---------------------------------------------------------------------
@@ -289,13 +291,14 @@ class RoutingPlan:
         order in HBM, its own forcing / state / result / streams -- for a sequence of windows that takes turns on the two
         (``chain_from``, ``stage_forcing``)."""
         other = object.__new__(RoutingPlan)
-        for k in ("nseg", "precision", "dtype", "nboundary", "engine", "maxlag", "arithmetic"):
+        for k in ("nseg", "precision", "dtype", "nboundary", "engine", "maxlag", "arithmetic", "tile_steps"):
             setattr(other, k, getattr(self, k))
         h = C.c_void_p(0)
         other._h = C.c_void_p(0)
         _lib.check(_lib.lib().trmc_plan_clone(self._h, C.byref(h)))
         other._h = h
         other._nsteps = None
+        other._stream_keep = {}
         return other
 
     def set_sequence_mode(self, on=True):
@@ -344,11 +347,49 @@ class RoutingPlan:
             raise ValueError(f"qlat must be a C-contiguous {np.dtype(self.dtype).name} array of shape ({self.nseg}, nq)")
         day = self.stream_info()["days_pushed"]
         self._stream_keep[day] = (qlat, hyd, q0, fvd)          # (alive while the copies may be in flight)
-        for old in [k for k in self._stream_keep if k < day - 8]:
+        for old in [k for k in self._stream_keep if isinstance(k, int) and k < day - 8]:
             del self._stream_keep[old]
         _lib.check(_lib.lib().trmc_stream_push(self._h, _lib.ptr(qlat), qlat.shape[1], C.c_void_p(boundary_q_ptr or 0),
                                                -1 if rowset is None else int(rowset), _lib.ptr(hyd), _lib.ptr(q0), _lib.ptr(fvd)))
         return day
+
+    def stream_gather(self, day, rowset, device_ptr, stream=0):
+        """Flows of a row set over `day` [rows, nsteps] into device memory (trmc_stream_gather)."""
+        _lib.check(_lib.lib().trmc_stream_gather(self._h, int(day), int(rowset), C.c_void_p(device_ptr), C.c_void_p(stream or 0)))
+
+    def stream_boundary(self, day, device_ptr, src_row_stride, index_ptr=None, stream=0):
+        """The boundary rows' flows of `day` from a block of hydrographs in device memory (trmc_stream_boundary)."""
+        _lib.check(_lib.lib().trmc_stream_boundary(self._h, int(day), C.c_void_p(device_ptr), int(src_row_stride),
+                                                   C.c_void_p(index_ptr or 0), C.c_void_p(stream or 0)))
+
+    def stream_gather_host(self, day, rowset):
+        """The same through the host: [rows, nsteps] (a stream whose ranks exchange with host collectives)."""
+        from . import comm as X
+        n = self._rowset_n[rowset]
+        if n == 0:
+            return np.zeros((0, self._nsteps), dtype=self.dtype)
+        dev = self.info()["device"]
+        buf = X.DeviceBuffer(dev, n * self._nsteps * np.dtype(self.dtype).itemsize)
+        self.stream_gather(day, rowset, buf.ptr)
+        return buf.download((n, self._nsteps), self.dtype, stream=self.stream())
+
+    def stream_boundary_host(self, day, flows):
+        """The boundary rows' flows of `day` [nboundary, nsteps] from a host array."""
+        from . import comm as X
+        flows = np.ascontiguousarray(flows, dtype=self.dtype)
+        if flows.shape != (self.nboundary, self._nsteps):
+            raise ValueError("boundary flows must be [nboundary, nsteps]")
+        if self.nboundary == 0:
+            return
+        buf = X.DeviceBuffer.from_array(self.info()["device"], flows)
+        self._stream_keep[("boundary", int(day))] = buf          # (alive until the fill has run)
+        for k in [k for k in self._stream_keep if isinstance(k, tuple) and k[1] < day - 8]:
+            del self._stream_keep[k]
+        self.stream_boundary(day, buf.ptr, self._nsteps)
+
+    def stream_advance(self, ntiles):
+        """Queue the next ``ntiles`` launches of the stream without a new day (the rows still under way move on)."""
+        _lib.check(_lib.lib().trmc_stream_advance(self._h, int(ntiles)))
 
     def stream_flush(self):
         _lib.check(_lib.lib().trmc_stream_flush(self._h))
@@ -361,6 +402,12 @@ class RoutingPlan:
         _lib.check(_lib.lib().trmc_stream_info(self._h, *[C.byref(x) for x in v]))
         names = ("slots", "tiles_per_day", "lag_max", "wide_levels", "cluster_levels", "days_pushed", "days_complete", "launches")
         return {k: x.value for k, x in zip(names, v)}
+
+    def stream_day_ms(self, day):
+        """device ms between the first and the last launch of the day's push on the slices' stream (trmc_stream_day_ms)"""
+        ms = C.c_double(0)
+        _lib.check(_lib.lib().trmc_stream_day_ms(self._h, int(day), C.byref(ms)))
+        return ms.value
 
     def stream_end(self):
         _lib.check(_lib.lib().trmc_stream_end(self._h))

@@ -243,3 +243,303 @@ class DaySequence:
         day_ms = [round((b - a) * 1e3, 2) for a, b in zip(ends[:-1], ends[1:])][max(0, warmup - 1):]
         return {"el": el, "ms_main": ms_main, "hyd": got[0], "final": got[1], "fvd": got[2] if len(got) > 2 else None,
                 "days_routed": total, "last_plan": r._state_plans[0], "day_ms": day_ms}
+
+
+class RouteStream:
+    """The product's run-set loop (the reference: ``for run in run_sets: nwm_route(...) -> compute_nhd_routing_v02(...); new_q0;
+    assemble_forcings(next)``, nwm_routing/__main__.py:195-333) as an iterator over days::
+
+        router = ShardedRouter(to, params, ..., stream=True)
+        with RouteStream(router, nsteps, qts_subdivisions) as rs:
+            for day, hydrographs, final_state in rs.route(forcings, state0):
+                ...
+
+    ``forcings``: any iterable of [nseg, nq] arrays (global rows; page-locked ones -- ``pinned_like`` -- are copied from where
+    they are, others through a page-locked ring); it is consumed as far ahead as the device can take days and may yield late.
+    Every day's products come back in order: the outlet hydrographs [noutlets, nsteps] (rows ``outlet_rows``; on rank 0 of a
+    multi-rank job, or everywhere with ``hydrographs_on_every_rank``), the final state ([nseg, 3]; a rank of a multi-rank job:
+    of its ``rows``), with ``output_stride=n`` also every n-th step of (q, v, d) of those rows.  The arrays belong to a ring:
+    copy what is kept beyond the next few days.
+
+    Underneath is ONE stream of tile launches (include/trmc.h, trmc_stream_*): the tile index runs on over the days, every
+    launch routes every row through the next K steps of its own place in the stream -- a row deep in the network works on an
+    earlier tile than the headwaters, possibly of an earlier day -- so a day costs nsteps / K launches and nothing else, and a
+    day's products are complete ``lag`` launches after its first row finished it.  ``latency="low"`` flushes after every day
+    (each day's products right after its push, at the price of the partly filled launches a single window has).
+
+    Several ranks: every rank streams its sub-basins and small networks; the trunk of the dominant basin rides in its owner's
+    stream a day or two behind, and the cut-edge hydrographs are exchanged ONCE PER DAY (an all-gather on the exchange
+    stream, ``comm``) when every rank's cut rows are through that day -- SURVEY 8e's "upstream piece finishes, sends the
+    tailwater hydrograph", with the order DAG resolved by the trunk's lag instead of by waiting.
+    """
+
+    def __init__(self, router, nsteps, qts_subdivisions, output_stride=None, full_output=False, slots=0, latency="throughput",
+                 hydrographs_on_every_rank=False, comm=None, exchange=None):
+        """comm / exchange (several ranks): the communicator -- default: the one given to ``router.enable_device_exchange`` -- and
+        how the daily cut-edge hydrographs travel: "device" (gather kernel -> all-gather on the exchange stream -> boundary rows,
+        everything in HBM: RCCL over xGMI) or "host" (through ``comm.all_gather_rows_host``: any communicator with that method,
+        ``all_reduce_max_host`` and ``barrier`` -- a transport without device collectives; the days of slack the trunk's lag gives
+        cover the round trip).  Default: "device" when the router has a device exchange, else "host"."""
+        if latency not in ("throughput", "low"):
+            raise ValueError("latency must be 'throughput' or 'low'")
+        self.r = router
+        self.comm = comm if comm is not None else getattr(router, "_comm", None)
+        self.exchange = exchange or ("device" if getattr(router, "_X", None) is not None else "host")
+        if self.exchange not in ("device", "host"):
+            raise ValueError("exchange must be 'device' or 'host'")
+        if router.world > 1 and self.comm is None:
+            raise ValueError("several ranks need a communicator (router.enable_device_exchange(comm), or comm=...)")
+        self.nsteps, self.qts = int(nsteps), int(qts_subdivisions)
+        self.output_stride = int(output_stride) if output_stride else 0
+        self.full_output = bool(full_output)
+        self.slots, self.latency = int(slots), latency
+        self.world, self.rank = router.world, router.rank
+        self._hyd_everywhere = bool(hydrographs_on_every_rank)
+        self.plan = None
+        self.info = None
+        self.last_info = None
+        self._dc = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self.plan is not None and self.info is not None:
+            try:
+                self.plan.stream_end()
+            except Exception:
+                pass
+        self.info = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _setup(self):
+        """the plan, the trunk's lag (every rank must agree on it: the largest lag among ALL ranks' cut rows decides how many
+        days after a day its cut-edge hydrographs can be exchanged), the row sets"""
+        r = self.r
+        K = None
+        if self.world == 1:
+            P = r.stream_plan(0)
+            self._dc = 0
+        else:
+            comm = self.comm
+            late = getattr(r, "_planS_lag", 0) or 3 * 18
+            while True:
+                P = r.stream_plan(late)
+                lag, W, C = P.lags()
+                mine = int(lag[r.my_cut_local].max()) if r.my_cut_local.size else 0
+                pmax = int(comm.all_reduce_max_host(np.array([mine], dtype=np.float64))[0])
+                K = K or self._tile_steps(P)
+                tpd = self.nsteps // K
+                dc = -(-(pmax + 1) // tpd)                  # days after which every rank's cut rows are through a day
+                need = (dc + 1) * tpd                       # ... and the tiles the trunk must run behind for that
+                if need <= late:
+                    break
+                late = need
+            self._dc = dc
+        self.plan = P
+        self.rows = r._rowsS
+        return P
+
+    def _tile_steps(self, P):
+        return int(getattr(P, "tile_steps", 16))
+
+    @property
+    def outlet_rows(self):
+        """global rows of the hydrographs handed out (ascending)"""
+        return self._out_rows
+
+    def prepare_days(self, days):
+        """This rank's rows of every day in page-locked memory (where a rank of a real job reads them from the forcing files to);
+        pass ``prepared=True`` to ``route`` with such arrays.  One GPU: page-locked copies of the arrays."""
+        if self.plan is None:
+            self._setup()
+        rows = self.rows
+        local = rows.shape[0] != self.r.nseg or self.world > 1
+        return [pinned_like(np.ascontiguousarray(d[rows] if local else d, dtype=self.plan.dtype)) for d in days]
+
+    def run(self, days, state0, steps, warmup=0, on_day=None, prepared=False):
+        """Measurement form (bench.py, tools/sim_ranks.py): route ``warmup + steps`` consecutive days -- day w takes
+        ``days[w % len(days)]`` -- and time the ``steps`` days pushed after the warm-up ones: the device is drained (and the ranks
+        meet at a barrier) before the first of them is pushed and after the last of them has been, so the clock covers exactly
+        ``steps`` days of launches, each carrying every row (the stream is full: ``warmup`` is raised to the days the rows' lag
+        spans), the forcing of those days on its way in and the products of as many earlier days on their way out.  What brings
+        the last days to their end afterwards (the flush) is outside the clock, as the work of the warm-up days' last rows is
+        inside it.  Returns {"el": seconds, "days_routed", "warmup", "hyd", "final", "fvd": the last day's products, "info"}."""
+        from . import comm as X
+        if self.plan is None:
+            self._setup()
+        days = list(days) if prepared else self.prepare_days(days)
+        P, multi = self.plan, self.world > 1
+        lag, _, _ = P.lags()
+        tpd = self.nsteps // self._tile_steps(P)
+        fill = -(-int(lag.max(initial=0)) // tpd) + 1 + (self._dc + 1 if multi else 0)
+        if multi:
+            fill = int(self.comm.all_reduce_max_host(np.array([fill], dtype=np.float64))[0])
+        wu = max(int(warmup), fill)
+        total, nd = wu + int(steps), len(days)
+        dev = P.info()["device"]
+        marks = {}
+        comm = self.comm
+
+        def meet():
+            if dev >= 0:
+                X.device_synchronize(dev)
+            if multi:
+                self.comm.barrier()
+
+        def feed():
+            for w in range(total):
+                if w == wu:
+                    meet()
+                    marks["t0"] = time.perf_counter()
+                yield days[w % nd]
+            meet()
+            marks["t1"] = time.perf_counter()
+        last, push_ms = None, []
+        for item in self.route(feed(), state0, prepared=True):
+            if on_day is not None:
+                on_day(*item)
+            if item[0] >= wu and self.info is not None:
+                try:                                        # (device time of the day's own launches on the slices' stream)
+                    push_ms.append(P.stream_day_ms(item[0]))
+                except (RuntimeError, ValueError):
+                    pass
+            last = item
+        el = marks["t1"] - marks["t0"]
+        if multi:
+            el = float(self.comm.all_reduce_max_host(np.array([el], dtype=np.float64))[0])
+        return {"el": el, "days_routed": total, "warmup": wu, "hyd": last[1], "final": last[2], "fvd": last[3] if len(last) > 3 else None,
+                "info": self.last_info, "push_ms": push_ms}
+
+    def route(self, forcings, state0=None, prepared=False):
+        """generator of (day, hydrographs, final_state[, fvd]) -- see the class.  prepared: the arrays hold this rank's rows only
+        (``prepare_days``)."""
+        r, nsteps, qts = self.r, self.nsteps, self.qts
+        P = self.plan if self.plan is not None else self._setup()
+        world, multi = self.world, self.world > 1
+        rows = self.rows
+        local = multi or rows.shape[0] != r.nseg
+        it = iter(forcings)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        nq = first.shape[1]
+        dtype = P.dtype
+        nrows = rows.shape[0]
+
+        def take(q):
+            return q[rows] if (local and not prepared) else q
+        # the state and the shape of the forcing
+        q0 = None if state0 is None else np.ascontiguousarray(state0[rows] if (local and state0.shape[0] == r.nseg) else state0, dtype=dtype)
+        P.upload_forcing(nsteps, np.ascontiguousarray(take(first), dtype=dtype), q0)
+        P.stream_begin(nsteps, qts, slots=self.slots, full_output=self.full_output and not self.output_stride,
+                       output_stride=self.output_stride)
+        self.info = info = P.stream_info()
+        D, tpd, lmax = info["slots"], info["tiles_per_day"], info["lag_max"]
+        want_fvd = bool(self.output_stride or self.full_output)
+        keep = nsteps // self.output_stride if self.output_stride else nsteps
+        nout = r._outS_global.shape[0]
+        hyds = [_lib.result_empty((max(nout, 1), nsteps), dtype, always_pinned=True) for _ in range(D)]
+        fins = [_lib.result_empty((nrows, 3), dtype, always_pinned=True) for _ in range(D)]
+        fvds = [_lib.result_empty((nrows, keep, 3), dtype, always_pinned=True) if want_fvd else None for _ in range(D)]
+        stage = [_lib.result_empty((nrows, nq), dtype, always_pinned=True) for _ in range(3)]
+        # when a day's products are waited for: a day after they were queued (the host then never waits for launches it has
+        # just queued -- the device always holds a day of work); latency="low": right after the day's own push (flushed)
+        low = self.latency == "low"
+        behind = 0 if low else (-(-lmax // tpd) if lmax else 0) + 1
+        if multi:
+            comm = self.comm
+            on_device = self.exchange == "device"
+            ncut = int(r.cut_rows.shape[0])
+            if on_device:
+                X, dev = r._X, r._dev
+                e = np.dtype(dtype).itemsize
+                mc = max(r._max_cut, 1)
+                send = [X.DeviceBuffer(dev, mc * nsteps * e) for _ in range(2)]
+                recv = [X.DeviceBuffer(dev, world * mc * nsteps * e) for _ in range(2)]
+                sc = r._sc
+            lmax_all = int(comm.all_reduce_max_host(np.array([lmax], dtype=np.float64))[0])
+            behind = (-(-lmax_all // tpd) if lmax_all else 0) + 1       # (every rank hands a day over in the same iteration)
+            order = None
+        self._out_rows = np.sort(r._outS_global) if not multi else None
+        sel_own = np.argsort(r._outS_global, kind="stable")
+
+        def exchange(day):
+            """the cut-edge hydrographs of `day` (through on every rank): gathered, all-gathered, into the trunk's boundary rows"""
+            if not multi or ncut == 0 or day < 0:
+                return
+            if not on_device:                           # through the host: any communicator with all_gather_rows_host
+                parts = comm.all_gather_rows_host(P.stream_gather_host(day, r._rsS_cut))
+                if r.plan1 is not None:
+                    cut_q = np.zeros((ncut, nsteps), dtype=dtype)
+                    for k, blk in enumerate(parts):
+                        cut_q[r.cut_owner == k] = blk
+                    P.stream_boundary_host(day, cut_q[r.b_cut_index])
+                return
+            k = day % 2
+            P.stream_gather(day, r._rsS_cut, send[k].ptr, stream=sc)
+            comm.all_gather(send[k].ptr, recv[k].ptr, mc * nsteps * e, sc)
+            if r.plan1 is not None:
+                P.stream_boundary(day, recv[k].ptr, nsteps, index_ptr=r._d_b_index.ptr, stream=sc)
+
+        def deliver(day):
+            nonlocal order
+            P.stream_wait(day)
+            k = day % D
+            hyd = hyds[k][:nout]
+            if multi:
+                parts = comm.all_gather_rows_host(np.ascontiguousarray(hyd))
+                if order is None:
+                    rows_all = np.concatenate(comm.all_gather_rows_host(np.ascontiguousarray(r._outS_global.astype(np.int64)[:, None])))[:, 0]
+                    order = np.argsort(rows_all, kind="stable")
+                    self._out_rows = rows_all[order]
+                hyd = np.concatenate(parts, 0)[order] if (self.rank == 0 or self._hyd_everywhere) else None
+                fin = [fins[k]]
+                fvd = [fvds[k]] if want_fvd else None
+            else:
+                hyd = hyd[sel_own]
+                fin, fvd = fins[k], fvds[k]
+            return (day, hyd, fin, fvd) if want_fvd else (day, hyd, fin)
+
+        d, nxt, pending = 0, first, 0
+        delivered = 0
+        while nxt is not None:
+            q = take(nxt)
+            if not (_lib.is_pinned(q) and q.dtype == dtype and q.flags.c_contiguous):
+                buf = stage[d % 3]
+                buf[...] = q
+                q = buf
+            P.stream_push(q, rowset=r._rsS_out, hyd=hyds[d % D], q0=fins[d % D], fvd=fvds[d % D])
+            if low:
+                if multi:
+                    raise ValueError("latency='low' is a one-GPU option")
+                P.stream_flush()
+            exchange(d - self._dc)
+            while delivered <= d - behind:
+                yield deliver(delivered)
+                delivered += 1
+            d += 1
+            try:
+                nxt = next(it)
+            except StopIteration:
+                nxt = None
+        total = d
+        # the days still under way: no new day starts, the stream advances a day's launches at a time (the exchange of the last
+        # days' cut-edge hydrographs between them), until every day has been queued to its end
+        if multi:
+            if low:
+                raise ValueError("latency='low' is a one-GPU option")
+            for k in range(self._dc):
+                P.stream_advance(tpd)
+                exchange(total + k - self._dc)
+        P.stream_flush()
+        while delivered < total:
+            yield deliver(delivered)
+            delivered += 1
+        self.last_info = P.stream_info()
+        P.stream_end()
+        self.info = None

@@ -106,6 +106,99 @@ def test_world2_gloo_equals_single_process(tmp_path, short):
         assert np.array_equal(o["hyd"].view(np.uint32), hyd1.view(np.uint32))
 
 
+def _stream_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle_plan import OracleStreamPlan
+    from troute_amd.distributed import ShardedRouter
+    from troute_amd.sequence import RouteStream
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class GlooComm:
+        """the three host collectives RouteStream(exchange="host") asks of a communicator, over torch.distributed / gloo"""
+        def all_gather_rows_host(self, arr):
+            arr = np.ascontiguousarray(arr)
+            n = torch.tensor([arr.shape[0]], dtype=torch.int64)
+            ns = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(ns, n)
+            ns = [int(x) for x in ns]
+            buf = torch.zeros((max(max(ns), 1),) + arr.shape[1:], dtype=torch.from_numpy(arr[:0]).dtype)
+            if arr.shape[0]:
+                buf[:arr.shape[0]] = torch.from_numpy(arr)
+            outs = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(outs, buf)
+            return [o[:k].numpy() for o, k in zip(outs, ns)]
+
+        def all_reduce_max_host(self, arr):
+            t = torch.from_numpy(np.array(arr, copy=True))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.numpy()
+
+        def barrier(self):
+            dist.barrier()
+    net = small_conus()
+    nseg = net["to"].shape[0]
+    rng = np.random.default_rng(9)
+    days = [rng.uniform(0, 0.5, (nseg, 2)).astype(np.float32) for _ in range(3)]
+    ndays = 7
+    q0 = np.zeros((nseg, 3), np.float32)
+    router = ShardedRouter(net["to"], net["params"], rank=rank, world=world, plan_factory=OracleStreamPlan, stream=True)
+    got = {}
+    with RouteStream(router, 16, 8, comm=GlooComm()) as rs:
+        assert rs.exchange == "host"
+        for day, hyd, fin in rs.route((days[w % 3] for w in range(ndays)), q0):
+            got[day] = (None if hyd is None else np.array(hyd, copy=True), np.array(fin[0], copy=True))
+        rows_out, srows, dc = np.array(rs.outlet_rows, copy=True), np.array(rs.rows, copy=True), rs._dc
+        lag = router._planS_lag
+    np.savez(os.path.join(tmp, f"stream_{rank}.npz"), rows=rows_out, srows=srows, ndays=len(got), dc=dc, lag=lag,
+             has_trunk=router.plan1 is not None, ncut=router.cut_rows.shape[0],
+             **{f"hyd{w}": (got[w][0] if got[w][0] is not None else np.zeros((0, 16), np.float32)) for w in got},
+             **{f"fin{w}": got[w][1] for w in got})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_stream_of_days_equals_single_process(tmp_path):
+    """troute_amd.sequence.RouteStream on two ranks (gloo, host exchange) with an oracle-backed stand-in for the plan: the
+    protocol -- the trunk's lag agreed by an all-reduce over every rank's cut rows, the cut-edge hydrographs of day e exchanged
+    when every rank's cut rows are through it, the drain after the last day -- against seven days routed one by one on one
+    process.  The stand-in checks the schedule the way the library does and poisons rows whose inflows arrive too late."""
+    import torch.multiprocessing as mp
+    from oracle_plan import OraclePlan
+    from troute_amd.distributed import ShardedRouter
+    net = small_conus()
+    nseg = net["to"].shape[0]
+    rng = np.random.default_rng(9)
+    days = [rng.uniform(0, 0.5, (nseg, 2)).astype(np.float32) for _ in range(3)]
+    ndays = 7
+    single = ShardedRouter(net["to"], net["params"], plan_factory=OraclePlan)
+    state = np.zeros((nseg, 3), np.float32)
+    want_h, want_s = [], []
+    for w in range(ndays):
+        single.upload(16, days[w % 3], state)
+        rows1, hyd = single.route(8, True)
+        f = single.plan0.download_fvd()
+        state = np.stack([f[:, -1, 0], f[:, -1, 0], f[:, -1, 2]], 1)
+        want_h.append(hyd)
+        want_s.append(state)
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [np.load(tmp_path / f"stream_{r}.npz") for r in range(2)]
+    assert int(outs[0]["ncut"]) > 0 and (bool(outs[0]["has_trunk"]) or bool(outs[1]["has_trunk"]))
+    assert int(outs[0]["dc"]) == int(outs[1]["dc"]) >= 1 and int(outs[0]["lag"]) == int(outs[1]["lag"])
+    assert np.array_equal(outs[0]["rows"], rows1)
+    for r, o in enumerate(outs):
+        assert int(o["ndays"]) == ndays
+        srows = o["srows"]
+        for w in range(ndays):
+            if r == 0:                                               # rank 0 holds every day's outlet hydrographs of the whole network
+                assert np.array_equal(o[f"hyd{w}"].view(np.uint32), want_h[w].view(np.uint32)), w
+            assert np.array_equal(o[f"fin{w}"][:, 0].view(np.uint32), want_s[w][srows][:, 0].view(np.uint32)), (r, w)
+
+
 def _shm_worker(rank, world, key, tmp, short):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
