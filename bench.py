@@ -88,6 +88,7 @@ def parse():
     ap.add_argument("--no-retune", action="store_true",
                     help="keep the plain topological plan order (skip the untimed tuning window and plan rebuild)")
     ap.add_argument("--no-diffusive", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the leg through the reference's call surface (compute_nhd_routing_v02 from DataFrames)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the TRMC_ARITH_TOLERANCE leg (a second router of the network)")
     ap.add_argument("--no-parity-full", "--no-parity-sample", dest="no_parity_full", action="store_true",
                     help="skip the post-timing check of every segment against the reference on the CPU")
@@ -238,6 +239,68 @@ def parity_full(net, router, days, q0, nsteps, qts, outlets=None, threads=0, pla
                              "state of every row; the outlet hydrographs of the last timed window",
                  "seconds": round(time.perf_counter() - t0, 1)})
     return base
+
+
+def dropin_leg(net, nsteps, qts, days):
+    """The reference's own call surface at the workload's size: ``compute_nhd_routing_v02`` (compute.py:507-546) fed what
+    ``nwm_route`` feeds it -- connection / reach dictionaries made by the reference-shaped graph producers
+    (nhd_network.organize_independent_networks), DataFrames of parameters, state and lateral inflows -- once per run set
+    (nwm_routing/__main__.py:195-333, :1215): the first call (flattening, plan, tuning), then steady-state calls on the next
+    days' forcing with the state of the call before (new_q0, AbstractNetwork.py:177-191), every qts-th step of the result kept
+    (``output_stride``: what the writers take, output.py:209-216).  Wall time per call, split."""
+    import pandas as pd
+    from troute_amd import nhd_network as nn
+    from troute_amd.routing import compute as RC
+    to = net["to"]
+    nseg = to.shape[0]
+    t0 = time.perf_counter()
+    ids = np.arange(1, nseg + 1, dtype=np.int64)                  # (ascending ids in row order: the caller's table is sorted by id)
+    dn = np.where(to >= 0, ids[np.maximum(to, 0)], 0)
+    conn = {int(s): ([int(t)] if t else []) for s, t in zip(ids.tolist(), dn.tolist())}
+    ind, reaches_bytw, rconn = nn.organize_independent_networks(conn)
+    t_graph = time.perf_counter() - t0
+    cols = ["dx", "bw", "tw", "twcc", "n", "ncc", "cs", "s0"]
+    param_df = pd.DataFrame(net["params"][:, 1:], index=ids, columns=cols)
+    param_df["alt"] = 0.0
+    q0_df = pd.DataFrame(np.zeros((nseg, 3), np.float32), index=ids, columns=["qu0", "qd0", "h0"])
+    e = pd.DataFrame()
+    calls = []
+    device_ms = []
+    for k in range(4):
+        qlat_df = pd.DataFrame(days[k % len(days)], index=ids)
+        prof = None
+        if k == 3 and os.environ.get("TRMC_DROPIN_PROFILE"):      # (diagnosis: where the steady-state call's time goes)
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
+        t0 = time.perf_counter()
+        res, _ = RC.compute_nhd_routing_v02(conn, rconn, {}, reaches_bytw, "V02-structured", "by-network", 10000, 4, None, 300.0, nsteps,
+                                            qts, ind, param_df, q0_df, qlat_df, e, e, e, e, e, e, e, e, e, e, e, {}, True, False, e, {},
+                                            e, False, [{}, {}], output_stride=qts)
+        t1 = time.perf_counter()
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(22)
+        # new_q0 (AbstractNetwork.py:182-190): the last kept step of every row, (q, q, depth), in the table's order
+        fin = np.concatenate([r[1][:, [-3, -3, -1]] for r in res])
+        order = np.concatenate([r[0] for r in res])
+        q0_df = pd.DataFrame(fin, index=order, columns=["qu0", "qd0", "h0"]).reindex(ids)
+        calls.append({"call_s": round(t1 - t0, 4), "new_q0_s": round(time.perf_counter() - t1, 4)})
+        try:
+            from troute_amd.routing.fast_reach import mc_reach as MR
+            plans = list(MR._PLANS._d.values())
+            device_ms.append(round(float(plans[-1]["plan"].stats()["ms_total"]), 2) if plans else None)
+        except Exception:
+            device_ms.append(None)
+    steady = calls[-1]["call_s"]
+    return {"graph_s": round(t_graph, 2), "tailwaters": len(reaches_bytw), "reaches": int(sum(len(v) for v in reaches_bytw.values())),
+            "calls": calls, "device_window_ms_of_each_call": device_ms, "steady_state_call_ms": round(steady * 1e3, 1),
+            "output_stride": qts, "result": f"{len(res)} tuples; flowveldepth [rows, {nsteps // qts} x 3] per tailwater (views of one block)",
+            "what": "compute_nhd_routing_v02(connections, rconn, ..., param_df, q0, qlats, ...) at the workload's size: call 0 flattens the "
+                    "network and builds the plan, call 1 rebuilds it with call 0's costs as the row-order hint, calls 2-3 are the steady "
+                    "state (network, table and plan found by the identity of the caller's objects); each call = table look-up of q0 / "
+                    "qlats + upload + one routing window + the decimated result to the host + the per-tailwater result list"}
 
 
 def _diffusive_inputs(gold, nsteps):
@@ -758,11 +821,12 @@ def main():
         # the first two days of the timed sequence once more, untimed, from the state after day N: the all-gathered outlet block
         # of day N+2 is what rank 0 hands to the checker (AFTER the last leg the ranks take together)
         if use_stream:
-            with RouteStream(srouter, a.nsteps, a.qts) as rs:
-                chk = rs.run(stream_ring[:2], state_n, 2, 0, prepared=True)
+            with RouteStream(srouter, a.nsteps, a.qts) as rs:        # (exactly these two days, from the state after day N)
+                for item in rs.route(stream_ring[:2], state_n, prepared=True):
+                    chk_hyd = None if item[1] is None else np.array(item[1], copy=True)
                 out_rows_s = rs.outlet_rows
             if rank == 0:
-                dist_outlets = (np.array(out_rows_s, copy=True), np.array(chk["hyd"], copy=True))
+                dist_outlets = (np.array(out_rows_s, copy=True), chk_hyd)
         else:
             chk = dayseq.run(local_ring[:2], state_n, 2, 0, prepared=True)
             if rank == 0:
@@ -896,7 +960,8 @@ def main():
                 # the timed pass's pipeline -- the stream -- once more, untimed, over days N+1 and N+2 from the state after day N,
                 # this time with every day's full result assembled and day N+2's handed over with its other products
                 with RouteStream(srouter, a.nsteps, a.qts, full_output=True) as rs:
-                    chk = rs.run(ring[:2], state_n, 2, 0, prepared=True)
+                    for item in rs.route(ring[:2], state_n, prepared=True):       # (exactly these two days; the last item is day N+2)
+                        chk = {"hyd": item[1], "final": item[2], "fvd": item[3]}
                     o_rows = np.array(rs.outlet_rows, copy=True)
                 parity = parity_full(net, router, (qlat_s, qlat_a, ring[0], ring[1]), q0, a.nsteps, a.qts, outlets=(o_rows, chk["hyd"]),
                                      threads=a.cpu_threads, final_fetched=chk["final"], fvd_fetched=chk["fvd"])
@@ -950,6 +1015,15 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             cpu = {"error": repr(e)}
 
+    dropin = None
+    if rank == 0 and world == 1 and not a.no_dropin:
+        try:
+            dropin = dropin_leg(net, a.nsteps, a.qts, [qlat_s, qlat_a, qlat_b])
+            from troute_amd.routing.fast_reach import mc_reach as _MR
+            _MR._PLANS.clear()
+            _MR._FLAT.clear()
+        except Exception as e:
+            dropin = {"error": repr(e)}
     diffusive = None
     if rank == 0 and world == 1 and not a.no_diffusive:
         try:
@@ -1074,6 +1148,7 @@ def main():
             "per_rank": per_rank,
             "outlet_hydrographs": list(hyd.shape),
             "diffusive": diffusive,
+            "dropin": dropin,
         }
         line.update(extra)
         json_out.write(json.dumps(line) + "\n")

@@ -167,8 +167,8 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *                  skew, queued on the plan's stream between the tail's launches; 0 = default (OFF: measured slower on the
  *                  CONUS day at every setting tried), < 0 = never.  mid_levels (0 = 12), mid_k (0 = 4).
  *   tile_perm_group  the threads of every block of a wide tile take the block's rows by the cost class the rows showed in the
- *                  tile before (inside the launch; wavefronts of one class whatever the forcing does): 0 = default (on for a
- *                  plan created with a cost hint), > 0 = on, < 0 = off.
+ *                  tile before (inside the launch; wavefronts of one class whatever the forcing does): 0 = default (ON, with or
+ *                  without a cost hint), > 0 = on, < 0 = off.
  *   hot_rows       the few rows of a wide tile that showed three or more secant iterations (or went over bank) in the tile before
  *                  are routed by blocks of their own in the next one, so that they do not set the pace of the wavefront they
  *                  would otherwise sit in (1.5 % of the rows of an unordered CONUS plan are in half of its wavefronts); those

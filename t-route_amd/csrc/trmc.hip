@@ -74,12 +74,6 @@ namespace {
 // fp32: the bit-reproducible power of det_pow.h (IEEE double + - * / fma only), so the
 // whole fp32 path is bit-comparable with the host oracle; sqrtf and / are the
 // correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
-#ifndef TRMC_EXPERIMENT_DIV   // 0: one shared reciprocal for the four Muskingum coefficients (product).  1: plain divisions
-#define TRMC_EXPERIMENT_DIV 0
-#endif
-#ifndef TRMC_EXPERIMENT_POW   // 0: det_pow.h (product).  1: ocml powf, 2: hardware log/exp -- timing experiments only
-#define TRMC_EXPERIMENT_POW 0
-#endif
 __device__ const uint64_t d_pow_tab[TRMC_POW_TAB_WORDS] = TRMC_POW_TAB_VALUES;
 
 // fp32: the bit-reproducible powf of det_pow.h (tables staged in LDS by the kernel), so the whole
@@ -87,7 +81,6 @@ __device__ const uint64_t d_pow_tab[TRMC_POW_TAB_WORDS] = TRMC_POW_TAB_VALUES;
 // default -fhip-fp32-correctly-rounded-divide-sqrt).
 struct DevMathF {
     const uint64_t *tab; // LDS copy of d_pow_tab
-#if TRMC_EXPERIMENT_POW == 0
     using Log = double;
     __device__ __forceinline__ Log log_of(float x) const { return trmc_det_log2(x, tab); }
     __device__ __forceinline__ float pow_l(Log l, float, float y) const { return trmc_det_powf_from_log(l, y, tab); }
@@ -98,21 +91,6 @@ struct DevMathF {
     {
         return ok ? trmc_det_powf_from_log_inrange(l, y, tab) : trmc_det_powf_from_log(l, y, tab);
     }
-#elif TRMC_EXPERIMENT_POW == 1
-    using Log = float;
-    __device__ __forceinline__ Log log_of(float x) const { return x; }
-    __device__ __forceinline__ float pow_l(Log, float x, float y) const { return ::powf(x, y); }
-    __device__ __forceinline__ float pow(float x, float y) const { return ::powf(x, y); }
-    __device__ __forceinline__ Log log_of_r(float x, bool) const { return x; }
-    __device__ __forceinline__ float pow_l_r(Log, float x, float y, bool) const { return ::powf(x, y); }
-#else
-    using Log = float;
-    __device__ __forceinline__ Log log_of(float x) const { return __builtin_amdgcn_logf(x); }
-    __device__ __forceinline__ float pow_l(Log l, float, float y) const { return __builtin_amdgcn_exp2f(y * l); }
-    __device__ __forceinline__ float pow(float x, float y) const { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
-    __device__ __forceinline__ Log log_of_r(float x, bool) const { return __builtin_amdgcn_logf(x); }
-    __device__ __forceinline__ float pow_l_r(Log l, float, float y, bool) const { return __builtin_amdgcn_exp2f(y * l); }
-#endif
     __device__ __forceinline__ float sqrt(float x) const { return ::sqrtf(x); }
     // wave-wide AND over the active lanes: a scalar, so the branch on it is a uniform one
     __device__ __forceinline__ bool all(bool p) const { return __all(p) != 0; }
@@ -177,11 +155,7 @@ struct DevMathF {
     }
     __device__ __forceinline__ bool fast_ok(float h, float h_in, float h_over) const
     {
-#if TRMC_EXPERIMENT_DIV != 1
         return sane && h_in >= 0x1p-30f && h <= 0x1p17f && (h_over == 0.0f || h_over >= 0x1p-30f);
-#else
-        return false;
-#endif
     }
     __device__ __forceinline__ static float refined_rcp(float b)
     {
@@ -207,11 +181,7 @@ struct DevMathF {
     // the remaining divisions of a secant iteration (weighting factor, K = dx / celerity, secant update): IEEE
     __device__ __forceinline__ float divx(float a, float b) const
     {
-#if TRMC_EXPERIMENT_DIV == 2 // timing experiment only: what would range proofs for these four divisions buy?
-        return quot(a, b, refined_rcp(b));
-#else
         return a / b;
-#endif
     }
     __device__ __forceinline__ static float quot(float a, float b, float y1)
     {
@@ -219,7 +189,6 @@ struct DevMathF {
         const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y1, q0);
         return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y1, q1);
     }
-#if TRMC_EXPERIMENT_DIV != 1
     bool coef_ok;
     __device__ __forceinline__ static float refined_quot(float a, float b, float y1)
     {
@@ -244,17 +213,6 @@ struct DevMathF {
             q4 = n4 / d;
         }
     }
-#else
-    bool coef_ok;
-    __device__ __forceinline__ void div4(float n1, float n2, float n3, float n4, float d, float &q1, float &q2,
-                                         float &q3, float &q4) const
-    {
-        q1 = n1 / d;
-        q2 = n2 / d;
-        q3 = n3 / d;
-        q4 = n4 / d;
-    }
-#endif
 };
 // The same arithmetic for the dataflow kernels, without the in-bank body: there a wavefront steps through time by itself
 // and what counts is the latency of ITS step -- registers and code size -- not the instruction count of a full device
@@ -520,16 +478,8 @@ constexpr int kStepBlock = TRMC_STEP_BLOCK;
 // transpose trails the last step launch: CONUS day 22.3 ms with tiles of 128 steps, 21.7 with 64, 21.5 with 32
 #define TRMC_EMIT_TILE 32
 #endif
-#ifndef TRMC_EXPERIMENT_WAVES
-#define TRMC_EXPERIMENT_WAVES 1
-#endif
-#ifdef TRMC_STEP_VGPRS // experiment: cap the register allocation of the step kernel
-#define TRMC_STEP_ATTR __attribute__((amdgpu_num_vgpr(TRMC_STEP_VGPRS)))
-#else
-#define TRMC_STEP_ATTR
-#endif
 template <class T, bool SHORT, bool LAG = false, bool TOL = false>
-__global__ void __launch_bounds__(kStepBlock, TRMC_EXPERIMENT_WAVES) TRMC_STEP_ATTR
+__global__ void __launch_bounds__(kStepBlock)
 k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const int32_t diag, const int32_t ql_col)
 {   // ql_col: the lateral-inflow column (diag - 1) / qts of a launch whose rows are all at step diag (SHORT, no lag) -- formed
     // by the host: an integer division by a run-time divisor is some 35 instructions per thread
@@ -639,16 +589,8 @@ k_mc_step(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
             }
         }
 
-#ifdef TRMC_EXPERIMENT_MEMONLY // timing experiment: all loads and stores, no arithmetic to speak of
-        trmc::StepResult<T> r;
-        r.qdc = p.dt + p.dx + p.bw + c.z + c.bfd + f.qup + f.quc + f.qdp;
-        r.velc = p.twcc + p.n + p.ncc + f.ql + c.sqrt_s0 + c.sq1pz2;
-        r.depthc = c.s0_n + c.s0_ncc + p.s0 + depthp;
-        r.iters = 0;
-#else
         m.coef_ok = coef_guard(p.dt, f.ql);
         const trmc::StepResult<T> r = trmc::mc_segment_step<T, M>(p, c, f, depthp, m);
-#endif
         T q_new = r.qdc;
         if (a.gage_of_pos) { // reference hook mc_reach.pyx:761-796; arithmetic of simple_da.pyx:47-76
             const int32_t g = a.gage_of_pos[s];
@@ -842,6 +784,9 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
     // flows of the step before (complete: earlier launches); advanced a row per step -- t differs from lane to lane (the
     // level skew), and (size_t)t * np in vector registers is a 64-bit multiplication per step
     T *q_up = q_tm + (size_t)(t_lo - 1) * np;
+    // (asking for the upstream flows of step t + 1 while step t is computed -- they were all written by earlier launches -- was built
+    // and measured in round 6: the CONUS stream 14.3 ms per day against 13.9, the ranks of an 8-way partition 2.76 against 2.70: two
+    // more live registers in a kernel that already spills four cost more than the L2 trip they take off the chain)
     for (int32_t t = t_lo; t <= t_hi; ++t, q_up += np) {
         if (ql_left == 0) {
             ++ql_col;
@@ -1367,27 +1312,15 @@ __device__ __forceinline__ void flow_report(FlowCold a, const unsigned long long
         a->ticket[5] = (int32_t)(v >> 32);
     }
 }
-#ifdef TRMC_FLOW_DEBUG_WAITS // developer build: polls of the granule plane / of the LDS ring, per thread
-__device__ uint32_t g_dbg_polls_plane, g_dbg_polls_ring;
-#define TRMC_DBG_COUNT(var) (++(var))
-static __device__ __forceinline__ uint32_t &dbg_plane() { __shared__ uint32_t c[1024]; return c[threadIdx.x]; }
-static __device__ __forceinline__ uint32_t &dbg_ring() { __shared__ uint32_t c[1024]; return c[threadIdx.x]; }
-#endif
 __device__ __forceinline__ float flow_wait(const unsigned long long *g, uint32_t want, FlowCold a, bool &dead)
 {
     unsigned long long v = gran_load(g);
-#ifdef TRMC_FLOW_EXP_NOWAIT // timing experiment: no dependence between rows (wrong results)
-    return __uint_as_float((uint32_t)v);
-#endif
     if ((uint32_t)(v >> 32) != want) {
         uint32_t polls = 0;
         uint64_t t_start = 0;
         do {
             __builtin_amdgcn_s_sleep(TRMC_FLOW_SLEEP);
             v = gran_load(g);
-#ifdef TRMC_FLOW_DEBUG_WAITS
-            ++dbg_plane();
-#endif
             if (flow_watchdog(polls, t_start, a)) {
                 dead = true;
                 flow_report(a, g, want, v);
@@ -1442,13 +1375,8 @@ __device__ __forceinline__ float flow_edge_get(FlowEdge &e, const unsigned long 
     return __uint_as_float((uint32_t)v);
 }
 
-#ifdef TRMC_FLOW_VGPRS // experiment: cap the register allocation (more wavefronts per SIMD, possibly spills)
-#define TRMC_FLOW_ATTR __attribute__((amdgpu_num_vgpr(TRMC_FLOW_VGPRS)))
-#else
-#define TRMC_FLOW_ATTR
-#endif
 template <bool SHORT, bool TOL = false>
-__global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES) TRMC_FLOW_ATTR
+__global__ void __launch_bounds__(kFlowBlock, TRMC_FLOW_WAVES)
 k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the launches / steps (t0, t1] of the window
 {
     using M = std::conditional_t<TOL, DevMathTolFlow, DevMathFlow>;
@@ -1517,19 +1445,12 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
                 const bool inb = u >= blk_base && u < blk_base + kFlowBlock;
                 // (a skewed row and a row in step never share the ring: their step windows differ)
                 const bool same = !SHORT || !a.lag || a.lag[u] == lag;
-#ifndef TRMC_FLOW_EXP_NOLDS // (timing experiment: every edge through the granule plane)
                 if (inb && same) e.l = u - blk_base;
-#endif
             }
             e.ahead = e.l < 0;
         };
-#ifdef TRMC_FLOW_EXP_NOUP
-        init(e0, -1);
-        init(e1, -1);
-#else
         init(e0, up.x);
         init(e1, up.y >= 0 ? (up.y & 0x3fffffff) : -1);
-#endif
     }
     const int32_t ri = a.res_of_pos ? a.res_of_pos[su] : -1;
     const int32_t gi = a.gage_of_pos ? a.gage_of_pos[su] : -1;
@@ -1669,9 +1590,6 @@ k_mc_flow(const FlowArgs a, const int32_t t0, const int32_t t1) // routes the la
         q_prev = q_new;
         d_prev = d_new;
         // stage (q, v, d) of step t; a run ends at every 8th step of the window and at the last step of the launch
-#ifdef TRMC_FLOW_EXP_NOOUT // timing experiment: results are not written
-        if (q_new + v_new + d_new == 12345.678f)
-#endif
         {
             const int32_t slot = (t - 1) & (kFlowStage - 1);
             float *so = s_out + (size_t)(slot * 3) * kFlowBlock + threadIdx.x;
@@ -1732,18 +1650,12 @@ __device__ __forceinline__ float lean_edge_get(int32_t u, int32_t l, uint32_t &f
     if (!(flags & (ahead_bit | never_bit))) {
         const unsigned long long *slot = ring + (size_t)(ws & (kLeanRing - 1)) * kFlowBlock + l;
         unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef TRMC_FLOW_EXP_NOWAIT
-        return __uint_as_float((uint32_t)v);
-#endif
         if ((int32_t)((uint32_t)(v >> 32) - want) < 0) { // not produced yet: the producer is a wave of this block
             uint32_t polls = 0;
             uint64_t t_start = 0;
             do {
                 __builtin_amdgcn_s_sleep(TRMC_LEAN_RING_SLEEP);
                 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef TRMC_FLOW_DEBUG_WAITS
-                ++dbg_ring();
-#endif
                 if (flow_watchdog(polls, t_start, a)) dead = true;
             } while ((int32_t)((uint32_t)(v >> 32) - want) < 0 && !dead);
         }
@@ -1822,13 +1734,8 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
     const int32_t tix = grp * 64 + (int32_t)(threadIdx.x & 63u); // the row of the block this thread routes
     const int32_t blk_base = a.first + s_blk * kFlowBlock;
     if (cold->dbg && tix == 0) cold->dbg[2 * s_blk] = ((unsigned long long)hw_cu_key() << 48) | (wall_clock64() & 0xffffffffffffull);
-#ifdef TRMC_FLOW_DEBUG_WAITS
-    dbg_plane() = 0;
-    dbg_ring() = 0;
-#else
     if (cold->dbg && (threadIdx.x & 63u) == 0) // which SIMD every row group ran on
         cold->dbg[2 * (size_t)(cold->nblocks_dbg + 1) + 4 * (size_t)s_blk + grp] = 1ull + my_simd + ((unsigned long long)(threadIdx.x >> 6) << 8);
-#endif
     if (a.prio) { // the costlier a wavefront, the higher its issue priority (topology.cpp)
         const int pr = __builtin_amdgcn_readfirstlane((int)a.prio[(s_blk * kFlowBlock + tix) >> 6]);
         if (pr == 1) __builtin_amdgcn_s_setprio(1);
@@ -1872,9 +1779,6 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
         if (u1 >= 0 && !ring_ok(u1)) flags |= 8u;
         if (a.res_of_pos && a.res_of_pos[su] >= 0) flags |= 32u;
         if (a.gage_of_pos && a.gage_of_pos[su] >= 0) flags |= 64u;
-#ifdef TRMC_FLOW_EXP_NOUP
-        u0 = u1 = -1;
-#endif
     }
     const size_t np = (size_t)a.nseg_pad;
     const uint32_t out_idx = (uint32_t)a.row_of_pos[su] * (uint32_t)a.nsteps * 3u; // (the host checks nseg * nsteps * 3 < 2**32)
@@ -1994,25 +1898,14 @@ k_mc_flow_lean(const FlowArgs a, const int32_t t0, const int32_t t1)
         if (t == t_hi) // hand the depth over to the next launch of the window
             __hip_atomic_store(cold->d_gran + su, ((unsigned long long)(tag_p + 1u) << 32) | (unsigned long long)__float_as_uint(d_new),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifndef TRMC_FLOW_EXP_NOOUT
         {
             float *o = a.out + (size_t)(out_idx + (uint32_t)(t - 1) * 3u);
             o[0] = q_new;
             o[1] = v_new;
             o[2] = d_new;
         }
-#endif
     }
     if (cold->dbg) atomicMax(cold->dbg + 2 * s_blk + 1, (unsigned long long)wall_clock64());
-#ifdef TRMC_FLOW_DEBUG_WAITS
-    if (cold->dbg) { // [2 * (nblocks + 1) ...]: per block {max plane polls of a thread, max ring polls, iteration sum of the block}
-        unsigned long long *x = cold->dbg + 2 * (size_t)(cold->nblocks_dbg + 1) + 4 * (size_t)s_blk;
-        atomicMax(x + 0, (unsigned long long)dbg_plane());
-        atomicMax(x + 1, (unsigned long long)dbg_ring());
-        atomicAdd(x + 2, (unsigned long long)(its & 0x00ffffffu));
-        atomicMax(x + 3, (unsigned long long)(its & 0x00ffffffu));
-    }
-#endif
     cold->d_state[su] = d_prev;
     if (t_hi == cold->nsteps) cold->it_prev[su] = (uint8_t)(its >> 24);
     if (uint16_t *const it_sum = cold->it_sum) it_sum[su] = (uint16_t)min(65535u, (uint32_t)it_sum[su] + (its & 0x00ffffffu));
@@ -3349,31 +3242,6 @@ int flow_route_end(trmc_plan *pl)
             std::fprintf(stderr, "   %6d  %9.3f %9.3f %9.3f\n", b, (d[2 * b] - t_min) * 1e-5, (d[2 * b + 1] - t_min) * 1e-5,
                          (d[2 * b + 1] - d[2 * b]) * 1e-5);
         }
-#ifdef TRMC_FLOW_DEBUG_WAITS
-        {
-            std::vector<unsigned long long> w((size_t)nb * 4);
-            HIP_TRY(hipMemcpy(w.data(), (unsigned long long *)pl->dbg.p + 2 * (size_t)(nb + 1), w.size() * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "   by twentieth of the block order: mean end ms, mean max-plane-polls, mean max-ring-polls, mean its/row, max its, mean prio\n");
-            std::vector<int8_t> prio((size_t)nb * (kFlowBlock / 64), 0);
-            for (size_t q = 0; q < prio.size() && q < pl->topo.prio_of_wave.size(); ++q) prio[q] = (int8_t)pl->topo.prio_of_wave[q];
-            for (int k = 0; k < 20; ++k) {
-                const int32_t b0 = (int32_t)((int64_t)nb * k / 20), b1 = (int32_t)((int64_t)nb * (k + 1) / 20);
-                double e = 0, p0 = 0, p1 = 0, it = 0, mx = 0, pr = 0;
-                for (int32_t b = b0; b < b1; ++b) {
-                    e += (d[2 * b + 1] - t_min) * 1e-5;
-                    p0 += (double)w[4 * b];
-                    p1 += (double)w[4 * b + 1];
-                    it += (double)w[4 * b + 2] / kFlowBlock;
-                    mx += (double)w[4 * b + 3];
-                    for (int q = 0; q < kFlowBlock / 64; ++q) pr += prio[(size_t)b * (kFlowBlock / 64) + q] / (double)(kFlowBlock / 64);
-                }
-                const double n = b1 - b0 > 0 ? b1 - b0 : 1;
-                std::fprintf(stderr, "   %2d  end %7.3f  plane %8.0f  ring %8.0f  its %7.1f  max %7.1f  prio %4.2f\n", k, e / n, p0 / n, p1 / n, it / n,
-                             mx / n, pr / n);
-            }
-        }
-#endif
         // how many blocks are running at a few instants
         for (int k = 1; k <= 10; ++k) {
             const unsigned long long tt = t_min + (t_max - t_min) * k / 11;
@@ -3972,7 +3840,7 @@ void trmc_plan_destroy(trmc_plan *pl)
             (void)hipSetDevice(pl->device);
             for (DevBuf &b : pl->rowsets) b.release();
             pl->rowsets.clear();
-            for (DevBuf *b : {&pl->fetch_hyd, &pl->fetch_q0, &pl->fetch_fvd, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
+            for (DevBuf *b : {&pl->dec, &pl->fetch_hyd, &pl->fetch_q0, &pl->fetch_fvd, &pl->it_prev, &pl->it_sum, &pl->d_state, &pl->ticket, &pl->dbg, &pl->cuq_head, &pl->d_gran,
                               &pl->raw_of_pos, &pl->da_raw, &pl->gage_of_pos, &pl->da_mode, &pl->da_a, &pl->da_w, &pl->da_nudge, &pl->res_of_pos,
                               &pl->res_par, &pl->res_inflow, &pl->in_qlat, &pl->in_q0, &pl->in_bfvd, &pl->qlat_tm, &pl->qlat_alt, &pl->tm, &pl->out, &pl->scratch,
                               &pl->gathered, &pl->cls_last, &pl->hot_list, &pl->hot_cnt})

@@ -383,17 +383,28 @@ class ShardedRouter:
         K = max(1, -(-self.nsteps // max(1, int(nchunks))))
         return K, -(-self.nsteps // K), (2 * K if self.plan1 is not None else 0)
 
-    def begin_sequence(self, nsteps, local_qlat, state0, qts_subdivisions, nchunks=None):
-        """Day 0 of a sequence: this rank's rows of the forcing (``sequence_rows()`` order) and the state -- global
-        [nseg, 3], or None to continue from what the rank's last window left in HBM -- staged synchronously."""
+    def begin_sequence(self, nsteps, local_qlat, state0, qts_subdivisions=None, nchunks=None, local=None):
+        """Day 0 of a sequence: this rank's rows of the forcing (``sequence_rows()`` order) and the state -- None to continue
+        from what the rank's last window left in HBM, else [nseg, 3] of every row (``local=False``) or this rank's rows in
+        ``sequence_rows()`` order (``local=True``) -- staged synchronously.  ``local=None`` tells the two apart by the row count
+        and refuses the one case in which that is ambiguous (a rank whose table, boundary copies included, has exactly nseg
+        rows).  (``qts_subdivisions`` is not needed here; kept for the callers that pass it.)"""
         self.nsteps = nsteps
         P = self._merged_plan(self._chunking(nchunks)[2], upload=False)
         rows = self.sequence_rows()
+        if state0 is not None and local is None:
+            if rows.shape[0] == self.nseg and self.world > 1:
+                raise ValueError("state0 has as many rows as the network AND as this rank's table: say local=True / False")
+            local = state0.shape[0] == rows.shape[0] and rows.shape[0] != self.nseg
         if state0 is None:
             q0 = None
-        elif state0.shape[0] == rows.shape[0] and rows.shape[0] != self.nseg:   # (already this rank's rows, in that order)
+        elif local:                                     # (already this rank's rows, in that order)
+            if state0.shape[0] != rows.shape[0]:
+                raise ValueError("local state0 must have one row per row of sequence_rows()")
             q0 = np.ascontiguousarray(state0)
         else:
+            if state0.shape[0] != self.nseg:
+                raise ValueError("global state0 must have one row per row of the network")
             q0 = np.ascontiguousarray(state0[rows])
         P.upload_forcing(nsteps, local_qlat, q0, None)
         self._plan0_staged = self.plan1 is None

@@ -314,7 +314,11 @@ class RoutingPlan:
             raise ValueError(f"qlat must be a C-contiguous {np.dtype(self.dtype).name} array of shape ({self.nseg}, nq)")
         self._staged_qlat = qlat                      # (kept alive while the copy may be in flight)
         _lib.check(_lib.lib().trmc_stage_forcing(self._h, int(nsteps), _lib.ptr(qlat), qlat.shape[1]))
-        self._nsteps = nsteps
+        # (the STAGED window's length: the window in progress, whose products a fetch queued right after this call sizes its
+        # arrays for, keeps its own until route_begin starts the staged one)
+        self._staged_nsteps = nsteps
+        if getattr(self, "_nsteps", None) is None:
+            self._nsteps = nsteps
 
     def chain_from(self, source):
         """This plan's NEXT window starts from the state `source`'s window (queued to its end) leaves, handed over on the
@@ -324,6 +328,7 @@ class RoutingPlan:
     def route_begin(self, nsteps, qts_subdivisions, assume_short_ts):
         _lib.check(_lib.lib().trmc_route_begin(self._h, nsteps, qts_subdivisions, int(bool(assume_short_ts))))
         self._nsteps = nsteps
+        self._staged_nsteps = None
 
     def route_advance(self, t_end):
         _lib.check(_lib.lib().trmc_route_advance(self._h, int(t_end)))

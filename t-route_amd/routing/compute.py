@@ -154,6 +154,126 @@ def compute_nhd_routing_v02(
                 "Lakes) is outside the Muskingum-Cunge path this package replaces")
     offnetwork_upstreams = sorted(int(k) for k in flowveldepth_interorder) if flowveldepth_interorder else []
 
+    # ---- what depends on the NETWORK only is made once per set of caller objects (nwm_route hands the same dictionaries and
+    # the same parameter table to every run set, nwm_routing/__main__.py:1215-1257; at CONUS size the walks below are seconds)
+    import os
+    ckey = None
+    if os.environ.get("TRMC_CALL_CACHE", "1") != "0":
+        ckey = (id(reaches_bytw), id(independent_networks), id(param_df), id(waterbodies_df), id(waterbody_types_df), float(dt),
+                len(reaches_bytw), len(independent_networks), tuple(param_df.shape), tuple(offnetwork_upstreams),
+                param_df.iloc[:: max(1, len(param_df) // 257)].values.astype("float64").sum(axis=0).tobytes() if len(param_df) else b"")
+    net = _NETWORKS.get(ckey) if ckey is not None else None
+    if net is None:
+        net = _network_of_call(reaches_bytw, independent_networks, param_df, dt, waterbodies_df, waterbody_types_df, offnetwork_upstreams)
+        if ckey is not None:
+            net["refs"] = (reaches_bytw, independent_networks, param_df, waterbodies_df, waterbody_types_df)   # (ids stay taken)
+            _NETWORKS[ckey] = net
+            while len(_NETWORKS) > 2:
+                _NETWORKS.pop(next(iter(_NETWORKS)))
+    tws, reaches_wTypes, reach_owner, upstream_connections = net["tws"], net["reaches_wTypes"], net["reach_owner"], net["upstream_connections"]
+    lake_segs, waterbodies_sub, types_sub, table_index, table_cols, table_values = (
+        net["lake_segs"], net["waterbodies_sub"], net["types_sub"], net["index"], net["columns"], net["values"])
+    ids = net["ids"]
+    nseg = ids.shape[0]
+
+    def rows_of(df):
+        """a caller's frame in the table's row order, float32 -- without a copy when it is in that order already"""
+        if df.index is table_index or (len(df.index) == nseg and df.index.dtype == table_index.dtype
+                                       and np.array_equal(df.index.values, ids)):
+            v = df.values
+            if v.dtype != np.float32:
+                v = v.astype("float32")
+            # (a NaN anywhere makes the sum NaN: one pass without a temporary the size of the table; infinities cannot cancel
+            # each other out of it unless both signs are there, and then the sum is NaN as well)
+            return v if not np.isnan(v.sum(dtype=np.float64)) else np.nan_to_num(v, nan=0.0)
+        return df.reindex(table_index).fillna(0.0).values.astype("float32")
+    q0_v, qlat_v = rows_of(q0), rows_of(qlats)
+
+    upstream_results = {}
+    for u in offnetwork_upstreams:                                       # compute.py:1649-1655
+        upstream_results[u] = {"results": np.asarray(flowveldepth_interorder[u]["results"]),
+                               "position_index": int(table_index.get_loc(u))}
+
+    e_f2, e_f1, e_i1 = np.zeros((0, 0), "float32"), np.zeros(0, "float32"), np.zeros(0, "int32")
+    # streamflow nudging tables of the whole call (reference: per tailwater, compute.py:1468-1469)
+    import pandas as pd
+    if _is_empty(usgs_df) and _is_empty(lastobs_df):
+        usgs_sub, lastobs_sub, da_byseg, da_byreach, da_bygage = pd.DataFrame(), pd.DataFrame(), [], [], np.zeros(0, dtype=np.intp)
+    else:
+        usgs_sub, lastobs_sub, da_byseg = _prep_da_dataframes(
+            pd.DataFrame() if usgs_df is None else usgs_df, pd.DataFrame() if lastobs_df is None else lastobs_df, table_index)
+        da_byreach, da_bygage = _prep_da_positions_byreach([reach for reach, _ in reaches_wTypes], lastobs_sub.index)
+    ngage = len(da_byseg)
+    if ngage:
+        usgs_v = usgs_sub.values.astype("float32")
+        null = pd.Series(index=lastobs_sub.index, name="Null", dtype="float32")
+        lastobs_v = lastobs_sub.get("lastobs_discharge", null).values.astype("float32")     # compute.py:1533-1535
+        lastobs_t = lastobs_sub.get("time_since_lastobs", null).values.astype("float32")
+        gage_args = (usgs_v, np.array(da_byseg, dtype="int32"), np.array(da_byreach, dtype="int32"),
+                     np.array(da_bygage, dtype="int32"), lastobs_v, lastobs_t)
+    else:
+        gage_args = (e_f2, e_i1, e_i1, e_i1, e_f1, e_f1)
+    r = compute_network_structured(
+        nts, dt, qts_subdivisions, reaches_wTypes, upstream_connections, ids, table_cols,
+        table_values, q0_v, qlat_v, lake_segs, waterbodies_sub, data_assimilation_parameters,
+        types_sub, bool(waterbody_type_specified),
+        t0.strftime('%Y-%m-%d_%H:%M:%S') if hasattr(t0, "strftime") else str(t0),
+        *gage_args, da_parameter_dict.get("da_decay_coefficient", 0) if da_parameter_dict else 0,
+        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
+        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
+        e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
+        e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
+        upstream_results, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device,
+        output_stride=output_stride)
+    rids = r[0].astype("int64")                  # (the rows of upstream_results are masked out, mc_reach.pyx:451,:812)
+    fvd, upstream = r[1], r[6]
+    gage_ids, lastobs_times, lastobs_values = r[3]
+    nudge = r[8]
+    if ngage:                                                            # gage rows in the (masked) result order
+        gseg = ids[np.asarray(da_byseg, dtype=np.int64)]
+        nres = rids.shape[0]
+        gage_row = np.minimum(np.searchsorted(rids, gseg), max(nres - 1, 0))
+        # a gage whose segment is an off-network upstream row (flowveldepth_interorder: masked out of the result,
+        # mc_reach.pyx:451,:812) belongs to no tailwater of this call
+        gage_row = np.where(rids[gage_row] == gseg, gage_row, -1) if nres else np.full(ngage, -1, dtype=np.int64)
+    else:
+        gage_row = np.zeros(0, dtype=np.int64)
+
+    # ---- back to the reference's per-tailwater result list: ONE gather into tailwater order (the rows of a network are then a
+    # slice -- a view -- of it; 14 713 boolean masks over 2.7 million rows were most of a minute at CONUS size) -------------
+    owner, order, bounds = net["owner"], net["order"], net["bounds"]
+    if rids.shape[0] != nseg:                    # (off-network rows masked out of the result: their positions drop out)
+        keep = np.ones(nseg, dtype=bool)
+        keep[[int(v["position_index"]) for v in upstream_results.values()]] = False
+        owner = owner[keep]
+        order = np.argsort(owner, kind="stable")
+        bounds = np.searchsorted(owner[order], np.arange(len(tws) + 1))
+    ids_o, fvd_o = rids[order].astype(np.intp), fvd[order]
+    # (the upstream-inflow series are zero except on waterbody rows, mc_reach.pyx:487,:710: without waterbodies any order of an
+    # all-zero block is the block itself -- 3.1 GB for a CONUS day that need not be permuted)
+    up_o = upstream[order] if len(lake_segs) else upstream
+    e5, e3, e4 = (e_i1, e_f1, e_f1, e_f1, e_f1), (e_i1, e_f1, e_i1), (e_i1, e_f1, e_i1, e_i1)
+    no_gage = (np.asarray([], dtype=np.int64), np.full(0, np.nan, "float32"), np.full(0, np.nan, "float32"))
+    no_nudge = np.zeros((0, nts + 1), dtype="float32")
+    gage_owner = owner[np.maximum(gage_row, 0)] if ngage else None
+    results = []
+    for k in range(len(tws)):
+        lo, hi = int(bounds[k]), int(bounds[k + 1])
+        if ngage:
+            gk = np.flatnonzero((gage_row >= 0) & (gage_owner == k))                          # this network's gages
+            gt = (np.asarray(gage_ids)[gk], np.asarray(lastobs_times)[gk], np.asarray(lastobs_values)[gk])
+        results.append((ids_o[lo:hi], fvd_o[lo:hi], 0, gt if ngage else no_gage, e5, e5, up_o[lo:hi], e3,
+                        nudge[gk] if ngage else no_nudge, e4))
+    return results, subnetwork_list
+
+
+_NETWORKS = {}
+
+
+def _network_of_call(reaches_bytw, independent_networks, param_df, dt, waterbodies_df, waterbody_types_df, offnetwork_upstreams):
+    """Everything compute_nhd_routing_v02 derives from the network alone: the reach list with its types, the merged upstream
+    dictionary, the parameter table of the call (compute.py:548-549, :1399-1467: one table for every network of the call instead
+    of one per tailwater), which tailwater owns every row, and the order that groups the rows by tailwater."""
     # compute.py:548-549
     param_df = param_df.copy()
     param_df["dt"] = dt
@@ -168,7 +288,8 @@ def compute_nhd_routing_v02(
     for k, tw in enumerate(tws):
         upstream_connections.update(independent_networks[tw])
         for reach in reaches_bytw[tw]:
-            is_wb = any(s not in param_ids for s in reach)          # _build_reach_type_list, compute.py:40-46
+            # _build_reach_type_list, compute.py:40-46 (a reach of more than one node never holds a waterbody node)
+            is_wb = (reach[0] not in param_ids) if len(reach) == 1 else any(s not in param_ids for s in reach)
             reaches_wTypes.append((list(reach), 1 if is_wb else 0))
             reach_owner.append(k)
             (lake_ids if is_wb else seg_ids).extend(reach)
@@ -203,82 +324,20 @@ def compute_nhd_routing_v02(
             types_sub = waterbody_types_df.loc[lake_segs, ["reservoir_type"]].values.astype("int32")
     seg_all = sorted(set(seg_ids) | set(off_segs))
     table = param_df.loc[seg_all, cols].reindex(seg_all + lake_segs).sort_index()                   # :1447-1465
-    ids = table.index.values.astype("int64")
+    ids = np.ascontiguousarray(table.index.values.astype("int64"))
     nseg = ids.shape[0]
-    q0_v = q0.reindex(table.index).fillna(0.0).values.astype("float32")
-    qlat_v = qlats.reindex(table.index).fillna(0.0).values.astype("float32")
-
-    upstream_results = {}
-    for u in offnetwork_upstreams:                                       # compute.py:1649-1655
-        upstream_results[u] = {"results": np.asarray(flowveldepth_interorder[u]["results"]),
-                               "position_index": int(table.index.get_loc(u))}
-
-    e_f2, e_f1, e_i1 = np.zeros((0, 0), "float32"), np.zeros(0, "float32"), np.zeros(0, "int32")
-    # streamflow nudging tables of the whole call (reference: per tailwater, compute.py:1468-1469)
-    import pandas as pd
-    usgs_sub, lastobs_sub, da_byseg = _prep_da_dataframes(
-        pd.DataFrame() if usgs_df is None else usgs_df, pd.DataFrame() if lastobs_df is None else lastobs_df, table.index)
-    da_byreach, da_bygage = _prep_da_positions_byreach([reach for reach, _ in reaches_wTypes], lastobs_sub.index)
-    ngage = len(da_byseg)
-    if ngage:
-        usgs_v = usgs_sub.values.astype("float32")
-        null = pd.Series(index=lastobs_sub.index, name="Null", dtype="float32")
-        lastobs_v = lastobs_sub.get("lastobs_discharge", null).values.astype("float32")     # compute.py:1533-1535
-        lastobs_t = lastobs_sub.get("time_since_lastobs", null).values.astype("float32")
-        gage_args = (usgs_v, np.array(da_byseg, dtype="int32"), np.array(da_byreach, dtype="int32"),
-                     np.array(da_bygage, dtype="int32"), lastobs_v, lastobs_t)
-    else:
-        gage_args = (e_f2, e_i1, e_i1, e_i1, e_f1, e_f1)
-    r = compute_network_structured(
-        nts, dt, qts_subdivisions, reaches_wTypes, upstream_connections, ids, table.columns.values,
-        table.values.astype("float32"), q0_v, qlat_v, lake_segs, waterbodies_sub, data_assimilation_parameters,
-        types_sub, bool(waterbody_type_specified),
-        t0.strftime('%Y-%m-%d_%H:%M:%S') if hasattr(t0, "strftime") else str(t0),
-        *gage_args, da_parameter_dict.get("da_decay_coefficient", 0) if da_parameter_dict else 0,
-        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
-        e_f2, e_i1, e_f1, e_f1, e_f1, e_f1, e_f1,
-        e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
-        e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
-        upstream_results, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device,
-        output_stride=output_stride)
-    ids = r[0].astype("int64")                   # (the rows of upstream_results are masked out, mc_reach.pyx:451,:812)
-    nseg = ids.shape[0]
-    fvd, upstream = r[1], r[6]
-    gage_ids, lastobs_times, lastobs_values = r[3]
-    nudge = r[8]
-    if ngage:                                                            # gage rows in the (masked) result order
-        gseg = table.index.values[np.asarray(da_byseg, dtype=np.int64)]
-        gage_row = np.minimum(np.searchsorted(ids, gseg), max(nseg - 1, 0))
-        # a gage whose segment is an off-network upstream row (flowveldepth_interorder: masked out of the result,
-        # mc_reach.pyx:451,:812) belongs to no tailwater of this call
-        gage_row = np.where(ids[gage_row] == gseg, gage_row, -1) if nseg else np.full(ngage, -1, dtype=np.int64)
-    else:
-        gage_row = np.zeros(0, dtype=np.int64)
-
-    # ---- back to the reference's per-tailwater result list ---------------------------------------------
+    # which tailwater owns every row of the table (-1: a row in no reach of the call), and the order that groups them
     owner = np.full(nseg, -1, dtype=np.int64)
-    flat = np.fromiter((s for reach, _ in reaches_wTypes for s in reach), dtype=np.int64)
-    own = np.repeat(np.asarray(reach_owner, dtype=np.int64), [len(reach) for reach, _ in reaches_wTypes])
-    owner[np.searchsorted(ids, flat)] = own
-    results = []
-    for k in range(len(tws)):
-        sel = np.flatnonzero(owner == k)
-        gk = (np.flatnonzero((gage_row >= 0) & (owner[np.maximum(gage_row, 0)] == k)) if ngage
-              else np.zeros(0, dtype=np.int64))                                                # this network's gages
-        results.append((
-            ids[sel].astype(np.intp),
-            fvd[sel],
-            0,
-            (np.asarray(gage_ids)[gk], np.asarray(lastobs_times)[gk], np.asarray(lastobs_values)[gk]) if ngage else
-            (np.asarray([], dtype=np.int64), np.full(0, np.nan, "float32"), np.full(0, np.nan, "float32")),
-            (e_i1, e_f1, e_f1, e_f1, e_f1),
-            (e_i1, e_f1, e_f1, e_f1, e_f1),
-            upstream[sel],
-            (e_i1, e_f1, e_i1),
-            nudge[gk] if ngage else np.zeros((0, nts + 1), dtype="float32"),
-            (e_i1, e_f1, e_i1, e_i1),
-        ))
-    return results, subnetwork_list
+    lens = np.fromiter((len(reach) for reach, _ in reaches_wTypes), dtype=np.int64, count=len(reaches_wTypes))
+    flat = np.fromiter((s for reach, _ in reaches_wTypes for s in reach), dtype=np.int64, count=int(lens.sum()))
+    owner[np.searchsorted(ids, flat)] = np.repeat(np.asarray(reach_owner, dtype=np.int64), lens)
+    order = np.argsort(owner, kind="stable")
+    bounds = np.searchsorted(owner[order], np.arange(len(tws) + 1))
+    return {"tws": tws, "reaches_wTypes": reaches_wTypes, "reach_owner": reach_owner, "upstream_connections": upstream_connections,
+            "lake_segs": lake_segs, "waterbodies_sub": waterbodies_sub, "types_sub": types_sub, "index": table.index,
+            "columns": table.columns.values, "values": np.ascontiguousarray(table.values.astype("float32")), "ids": ids,
+            "owner": owner, "order": order, "bounds": bounds}
+
 
 
 def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt, nts, q0, qlats, qts_subdivisions, usgs_df,
@@ -309,6 +368,11 @@ def compute_diffusive_routing(results, diffusive_network_data, cpu_pool, t0, dt,
         dn = diffusive_network_data[tw]
         trib_segs, trib_flow = None, None
         for r in results:                                                    # compute.py:1766-1781
+            if r[1].shape[1] != 3 * nts:
+                # (a result decimated with output_stride holds every n-th step only: its columns are not the nts junction
+                # inflows the solver takes)
+                raise ValueError(f"the Muskingum-Cunge results hold {r[1].shape[1] // 3} steps per row, not nts = {nts}: route the "
+                                 "windows that feed the diffusive pass without output_stride")
             x = np.isin(r[0], dn["tributary_segments"])
             if x.sum() > 0:
                 trib_segs = r[0][x] if trib_segs is None else np.append(trib_segs, r[0][x])

@@ -118,7 +118,10 @@ class _PlanCache:
         h.update(repr((precision, device, short_ts, res_rows, engine)).encode())
         return h.digest()
 
-    def lease(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine="auto"):
+    def lease(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine="auto", token=None):
+        """token: a hashable that stands for (up_ptr, up_idx, params) -- the caller vouches that the same token means the same
+        arrays (compute_network_structured: the flattened network of one set of caller objects, _FlatCache) -- and spares the
+        hash of their 120 MB per call"""
         import contextlib
         import os
         keep = int(os.environ.get("TRMC_PLAN_CACHE", "2"))
@@ -138,7 +141,11 @@ class _PlanCache:
         @contextlib.contextmanager
         def cached():
             with self._lock:
-                key = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine)
+                if token is not None:
+                    bkey = None if boundary is None else np.packbits(np.asarray(boundary, dtype=bool)).tobytes()
+                    key = ("token", token, bkey, precision, device, short_ts, res_rows, engine)
+                else:
+                    key = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine)
                 e = self._d.pop(key, None)
                 tune = short_ts and precision == 32
                 retune = tune and os.environ.get("TRMC_RETUNE", "1") != "0"
@@ -186,6 +193,55 @@ class _PlanCache:
 
 
 _PLANS = _PlanCache()
+
+
+class _FlatCache:
+    """The flattened network of the objects a caller keeps handing in.  ``nwm_route`` calls the kernel callable once per run
+    set with the SAME reach list, upstream dictionary and id table (nwm_routing/__main__.py:1215-1257); at CONUS size the walk
+    over 2.1 million reach lists, the look-up of 2.7 million ids and the hash of the result for the plan cache are seconds
+    around a window of milliseconds.  So the last few results are kept by the IDENTITY of those objects (with their lengths and
+    end points as a guard against an object that was refilled in place) -- the objects themselves are kept alive by the entry,
+    so an id cannot be reused while it is in here.  ``TRMC_FLAT_CACHE=0`` switches it off."""
+
+    def __init__(self, keep=3):
+        import collections
+        self._d, self._keep = collections.OrderedDict(), keep
+
+    @staticmethod
+    def _guard(reaches_wTypes, upstream_connections, data_idx):
+        n = len(reaches_wTypes)
+        ends = (tuple(reaches_wTypes[0][0]), reaches_wTypes[0][1], tuple(reaches_wTypes[-1][0]), reaches_wTypes[-1][1]) if n else ()
+        return (n, len(upstream_connections), data_idx.shape[0], ends,
+                int(data_idx[0]) if data_idx.size else 0, int(data_idx[-1]) if data_idx.size else 0)
+
+    def get(self, reaches_wTypes, upstream_connections, data_idx):
+        import os
+        if os.environ.get("TRMC_FLAT_CACHE", "1") == "0" or not isinstance(reaches_wTypes, list):
+            return None, None
+        key = (id(reaches_wTypes), id(upstream_connections), id(data_idx))
+        e = self._d.get(key)
+        if e is not None and e["guard"] == self._guard(reaches_wTypes, upstream_connections, data_idx):
+            self._d.move_to_end(key)
+            return key, e
+        return key, None
+
+    def put(self, key, reaches_wTypes, upstream_connections, data_idx, **content):
+        if key is None:
+            return None
+        e = dict(content, guard=self._guard(reaches_wTypes, upstream_connections, data_idx),
+                 refs=(reaches_wTypes, upstream_connections, data_idx), serial=_FlatCache._serial)
+        _FlatCache._serial += 1
+        self._d[key] = e
+        while len(self._d) > self._keep:
+            self._d.popitem(last=False)
+        return e
+
+    def clear(self):
+        self._d.clear()
+
+
+_FlatCache._serial = 0
+_FLAT = _FlatCache()
 
 
 def column_mapper(src_cols):
@@ -327,6 +383,10 @@ def compute_network_structured(
     stride = 1 if output_stride is None else int(output_stride)
     if stride < 1:
         raise ValueError("output_stride must be a positive number of timesteps")
+    if int(nsteps) % stride != 0:
+        # (with a remainder the last kept step is not the window's last one: new_q0 -- AbstractNetwork.py:182-190 takes the last
+        # column -- would restart the next window from an earlier step without a word)
+        raise ValueError(f"output_stride ({stride}) must divide nsteps ({nsteps}): the last kept step has to be the window's last")
     data_idx = np.ascontiguousarray(data_idx, dtype=np.int64)
     data_values = np.asarray(data_values)
     qlat_values = np.asarray(qlat_values)
@@ -348,12 +408,30 @@ def compute_network_structured(
     usgs_positions = np.asarray(usgs_positions, dtype=np.int64)
     gages_size = usgs_positions.shape[0]
 
-    params = np.ascontiguousarray(np.asarray(data_values, dtype=np.float32)[:, column_mapper(list(data_cols))])
-    up_ptr, up_idx, in_reach = _flatten_network(reaches_wTypes, upstream_connections, data_idx)
+    fkey, fe = _FLAT.get(reaches_wTypes, upstream_connections, data_idx)
+    if fe is None:
+        up_ptr, up_idx, in_reach = _flatten_network(reaches_wTypes, upstream_connections, data_idx)
+        fe = _FLAT.put(fkey, reaches_wTypes, upstream_connections, data_idx, up_ptr=up_ptr, up_idx=up_idx, in_reach=in_reach,
+                       any_res=any(rt == 1 for _, rt in reaches_wTypes), params_of=None, params=None)
+        any_res = fe["any_res"] if fe is not None else any(rt == 1 for _, rt in reaches_wTypes)
+    else:
+        up_ptr, up_idx, in_reach, any_res = fe["up_ptr"], fe["up_idx"], fe["in_reach"], fe["any_res"]
+    # (the parameter table in kernel column order: kept with the flattened network while the caller hands in the same array)
+    plan_token = None
+    sample = None
+    if fe is not None:      # (a table refilled in place is another table: a strided sample of its rows guards the identity)
+        sample = np.asarray(data_values[::max(1, nseg // 257)], dtype=np.float64).sum(axis=0).tobytes() if nseg else b""
+    if fe is not None and fe["params_of"] is data_values and fe.get("params_sample") == sample:
+        params = fe["params"]
+        plan_token = ("flat", fe["serial"], id(data_values), sample)
+    else:
+        params = np.ascontiguousarray(np.asarray(data_values, dtype=np.float32)[:, column_mapper(list(data_cols))])
+        if fe is not None:
+            fe["params_of"], fe["params"], fe["params_sample"] = data_values, params, sample
 
     # ---- level-pool reservoirs (mc_reach.pyx:283-356): one-node reaches of type 1 ----------------------
     res_rows, res_par, res_q0 = [], [], []
-    if any(rt == 1 for _, rt in reaches_wTypes):
+    if any_res:
         wb = np.asarray(wbody_cols, dtype=np.float64)
         rtypes = np.asarray(reservoir_types)
         for reach, rt in reaches_wTypes:
@@ -457,7 +535,7 @@ def compute_network_structured(
     # (gages inside a reach in the general mode need the level engine: it carries the un-nudged flow beside the nudged one)
     engine = "levels" if nudging is not None and nudging[5] is not None else "auto"
     with _PLANS.lease(up_ptr, up_idx, params, boundary if brow.size else None, precision, device,
-                      bool(assume_short_ts), tuple(res_rows), engine) as plan:
+                      bool(assume_short_ts), tuple(res_rows), engine, token=plan_token) as plan:
         if res_rows:
             plan.set_reservoirs(res_rows, np.asarray(res_par, dtype=dtype), dt)
         plan.upload_forcing(nsteps, qlat_values, q0, boundary_fvd)
