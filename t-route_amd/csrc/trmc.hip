@@ -431,6 +431,7 @@ template <class T> struct StepArgs {
     // clears the length of the one after; bit 7 of cls_last = "this row is in the list the next launch reads".
     int32_t *hot_list, *hot_cnt;
     int32_t hot_cap, hot_cur, hot_home; // (hot_home: the launch's first so many blocks take the list, the ones behind them positions)
+    int32_t hot_wave_rows;              // rows of the list per wavefront of those blocks (trmc_plan_options.hot_wave_rows)
     // STREAM of windows (trmc_stream_*; tile kernels only): the launch index counts tiles over ALL days -- a position `lag` tiles
     // behind works on tile (seq_day * seq_tpd + tile) - lag of the stream: day d = that / seq_tpd, in the buffers of slot d %
     // seq_slots (q_tm, d_tm, qlat_tm, out, dec: slot s begins s * slot_* elements behind the pointer above).  A row that ends a day
@@ -649,7 +650,7 @@ constexpr int kTileStage = 8;
 #define TRMC_TILE_BLOCK 128
 #endif
 constexpr int kTileBlock = TRMC_TILE_BLOCK;
-constexpr int32_t kWideMaxLevels = 16; // at most this many leading levels are routed by k_mc_tile's first tier (wide_levels is capped by it)
+constexpr int32_t kWideMaxLevels = 64; // at most this many leading levels are routed by k_mc_tile (wide_levels, default 16, is capped by it)
 // in-block partition of a tile's rows by cost class: on.  Measured on the CONUS sequence (ms per day, on / off): plan built from
 // the topology alone 19.3 / 20.4, tuned plan on days whose forcing is drawn anew 19.8 / 20.8, tuned plan on its own kind of days
 // 16.7 / 16.6, tolerance arithmetic 12.55 / 12.54 -- what a stale or missing cost hint loses, the partition wins back in part
@@ -691,11 +692,16 @@ k_mc_tile(const StepArgs<T> a, const int32_t s_begin, const int32_t s_end, const
         // the mark: no row is left marked without being listed.  A row that a list thread has routed AND found cooled down
         // before a late block of the same launch looks at its byte is routed a second time by that block: the same steps from
         // the same inputs (a tile reads nothing it writes), so the same values are stored twice -- work, not a difference.
-        const int32_t cur = cold->hot_cur, cap = cold->hot_cap;
-        const int32_t i = (int32_t)blockIdx.x * kTileBlock + (int32_t)threadIdx.x;
+        // A wavefront of these blocks takes hot_wave_rows entries (its other lanes leave): a wavefront's step costs what its
+        // costliest row's does, and where the launch does not fill the device many times over (a rank of a multi-GPU job) the
+        // K dependent steps of its slowest wavefront ARE the launch -- sixteen rows per wavefront have a row of five or six
+        // iterations among them a quarter as often as sixty-four.
+        const int32_t cur = cold->hot_cur, cap = cold->hot_cap, H = cold->hot_wave_rows;
+        const int32_t lane = (int32_t)(threadIdx.x & 63u), wave = (int32_t)blockIdx.x * (kTileBlock / 64) + (int32_t)(threadIdx.x >> 6);
+        const int32_t i = wave * H + lane;
         const int32_t nlist = min(cold->hot_cnt[cur], cap);
-        if (i >= nlist) return;
-        if (threadIdx.x == 0) atomicAdd(&cold->hot_cnt[3], min(nlist - i, kTileBlock)); // (trmc_plan_hot_rows: a running total)
+        if (lane >= H || i >= nlist) return;
+        if (lane == 0) atomicAdd(&cold->hot_cnt[3], min(nlist - i, H)); // (trmc_plan_hot_rows: a running total)
         s = hot_list[(size_t)cur * (size_t)cap + (size_t)i];
         from_hot = true;
         if (s < s_begin || s >= s_end) { // (listed by a window whose tiled levels reached further: back to where it is routed now)
@@ -2138,6 +2144,8 @@ struct trmc_plan {
         int32_t hot_rows = -1;               // -1 (default) or 1: with the partition; 0: off
         int32_t cluster_rows = 0;            // rows per cluster block of a short-timestep plan's deeper rows; 0: no cluster order
         int32_t cluster_late_lag = 0;        // tiles the rows fed by boundary rows run behind at least (cluster order)
+        int32_t stream_split = 0;            // a stream's slices from this level on ride on the clusters' stream (0: all on the tile stream)
+        int32_t hot_wave_rows = 0;           // rows of the hot list per wavefront (0: by the plan's size)
         bool sequence = false;
         bool flow_overlap = false;
         int32_t flow_lean = 0;
@@ -2276,6 +2284,7 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
     a.dec_stride = a.dec_keep = 0;
     a.hot_list = a.hot_cnt = nullptr;
     a.hot_cap = a.hot_cur = a.hot_home = 0;
+    a.hot_wave_rows = 64;
     a.seq_slots = a.seq_tpd = a.seq_day = a.seq_days = a.seq_day_min = 0;
     a.slot_tm = a.slot_qlat = a.slot_out = a.slot_dec = 0;
     a.up_ptr = (const int32_t *)pl->up_ptr.p;
@@ -2314,6 +2323,8 @@ template <class T> StepArgs<T> step_args(trmc_plan *pl, int nsteps, int qts)
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+// rows of the hot list per wavefront of the blocks that route it (trmc_plan_options.hot_wave_rows)
+inline int32_t hot_wave_rows_of(const trmc_plan *pl) { return pl->opt.hot_wave_rows > 0 ? pl->opt.hot_wave_rows : (pl->nrouted >= 1000000 ? 64 : 16); }
 
 template <class T, bool SHORT, bool TOL>
 inline void launch_step_m(hipStream_t st, const StepArgs<T> &a, int32_t s0, int32_t s1, int32_t d)
@@ -2665,7 +2676,8 @@ template <class T> int route_advance_t(trmc_plan *pl, int t_end)
                         at.hot_list = (int32_t *)pl->hot_list.p;
                         at.hot_cnt = (int32_t *)pl->hot_cnt.p;
                         at.hot_cap = cap;
-                        at.hot_home = (cap + kTileBlock - 1) / kTileBlock;
+                        at.hot_wave_rows = hot_wave_rows_of(pl);
+                        at.hot_home = (cap + at.hot_wave_rows * (kTileBlock / 64) - 1) / (at.hot_wave_rows * (kTileBlock / 64));
                     }
                 }
             }
@@ -3684,6 +3696,8 @@ int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_
         // step -- so a plan only gets it when asked)
         po.cluster_rows = o.cluster_rows > 0 ? std::min<int32_t>(o.cluster_rows, kTileBlock) : 0;
         po.cluster_late_lag = std::max(0, o.cluster_late_lag);
+        po.stream_split = std::max(0, o.stream_split);
+        po.hot_wave_rows = std::max(0, std::min(64, o.hot_wave_rows));
         po.sequence = o.sequence_mode != 0;
         po.flow_overlap = o.flow_overlap != 0;
         po.flow_lean = o.flow_lean;

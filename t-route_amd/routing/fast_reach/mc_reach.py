@@ -428,6 +428,7 @@ def compute_network_structured(
         params = np.ascontiguousarray(np.asarray(data_values, dtype=np.float32)[:, column_mapper(list(data_cols))])
         if fe is not None:
             fe["params_of"], fe["params"], fe["params_sample"] = data_values, params, sample
+            plan_token = ("flat", fe["serial"], id(data_values), sample)     # (the same token the next call with these objects finds)
 
     # ---- level-pool reservoirs (mc_reach.pyx:283-356): one-node reaches of type 1 ----------------------
     res_rows, res_par, res_q0 = [], [], []

@@ -18,6 +18,8 @@ ap.add_argument("--nseg", type=int, default=S.CONUS_NSEG)
 ap.add_argument("--days", type=int, default=8)
 ap.add_argument("--wide-min-rows", type=int, default=0)
 ap.add_argument("--wide-k", type=int, default=0)
+ap.add_argument("--wide-levels", type=int, default=0)
+ap.add_argument("--split", type=int, default=0)
 ap.add_argument("--hint", action="store_true")
 ap.add_argument("--stride", type=int, default=0)
 ap.add_argument("--full", action="store_true")
@@ -41,7 +43,7 @@ for q in days:
 q0 = np.zeros((n, 3), np.float32)
 rng = np.random.default_rng(5)
 sample = np.sort(rng.choice(n, min(n, 3000), replace=False))
-opts = {"wide_min_rows": a.wide_min_rows, "wide_k": a.wide_k, "cluster_rows": 128}
+opts = {"wide_min_rows": a.wide_min_rows, "wide_k": a.wide_k, "cluster_rows": 128, "wide_levels": a.wide_levels, "stream_split": a.split}
 hint = None
 if a.hint:
     with RoutingPlan(up_ptr, up_idx, net["params"], assume_short_ts=True, engine="levels", options=opts) as p:
