@@ -184,11 +184,9 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *   cluster_late_lag  cluster order: rows fed by boundary rows (and rows marked 2 in `boundary`) run at least so many tiles
  *                  behind the headwaters -- the trunk of a cut basin in a multi-GPU stream, whose inflows are exchanged once a
  *                  day (troute_amd.sequence.RouteStream).
- *   hot_wave_rows  rows of the hot list per WAVEFRONT of the blocks that route it (1..64; 0 = default: 64 for a plan of a million
- *                  routed rows or more, 16 below).  A launch cannot end before its slowest wavefront has made its wide_k dependent
- *                  steps, and a wavefront's step costs what its costliest row's does: on a device that one launch does not fill
- *                  many times over (a rank of a multi-GPU job) fewer hot rows per wavefront shorten that chain, at the price of
- *                  more wavefronts.
+ *   hot_wave_rows  rows of the hot list per WAVEFRONT of the blocks that route it (1..64; 0 = default 64).  An experiment's knob:
+ *                  fewer rows per wavefront were meant to shorten the slowest wavefront's chain of wide_k dependent steps on a
+ *                  device one launch does not fill (a rank of a multi-GPU job); measured slower at 32, 16 and 8.
  *   stream_split   s > 0: in a stream of windows the slices from level s on are launched on the clusters' stream instead of the
  *                  tile stream (an experiment: 3 % faster on CONUS on one GPU, twice as slow on a rank of eight; default 0).
  *   tail_sort      < 0: keep the per-level order below the tiled levels of a hinted short-timestep plan (default: by cost).

@@ -54,7 +54,7 @@ class ShardedRouter:
         # slice (in a stream they cost no launches)
         self._stream = bool(stream)
         if stream:
-            options = {"cluster_rows": 128, "wide_min_rows": 1024, **(options or {})}
+            options = {"cluster_rows": 128, "wide_min_rows": 1024, "wide_levels": 32, **(options or {})}
             assume_short_ts, engine = True, "levels"
         if plan_factory is None:
             from .plan import RoutingPlan  # the HIP engine; no fallback

@@ -119,9 +119,9 @@ class _PlanCache:
         return h.digest()
 
     def lease(self, up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine="auto", token=None):
-        """token: a hashable that stands for (up_ptr, up_idx, params) -- the caller vouches that the same token means the same
-        arrays (compute_network_structured: the flattened network of one set of caller objects, _FlatCache) -- and spares the
-        hash of their 120 MB per call"""
+        """token: None, or a dict the caller keeps with the arrays (compute_network_structured: the entry of its _FlatCache for
+        one set of caller objects -- the same entry means the same up_ptr, up_idx, params): the content key is computed once,
+        kept in it, and found again on the next call instead of hashing 120 MB of tables per call"""
         import contextlib
         import os
         keep = int(os.environ.get("TRMC_PLAN_CACHE", "2"))
@@ -143,7 +143,10 @@ class _PlanCache:
             with self._lock:
                 if token is not None:
                     bkey = None if boundary is None else np.packbits(np.asarray(boundary, dtype=bool)).tobytes()
-                    key = ("token", token, bkey, precision, device, short_ts, res_rows, engine)
+                    small = (bkey, precision, device, short_ts, res_rows, engine)
+                    key = token.get(small)
+                    if key is None:
+                        key = token[small] = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine)
                 else:
                     key = self._key(up_ptr, up_idx, params, boundary, precision, device, short_ts, res_rows, engine)
                 e = self._d.pop(key, None)
@@ -423,12 +426,12 @@ def compute_network_structured(
         sample = np.asarray(data_values[::max(1, nseg // 257)], dtype=np.float64).sum(axis=0).tobytes() if nseg else b""
     if fe is not None and fe["params_of"] is data_values and fe.get("params_sample") == sample:
         params = fe["params"]
-        plan_token = ("flat", fe["serial"], id(data_values), sample)
+        plan_token = fe["plan_keys"]
     else:
         params = np.ascontiguousarray(np.asarray(data_values, dtype=np.float32)[:, column_mapper(list(data_cols))])
         if fe is not None:
             fe["params_of"], fe["params"], fe["params_sample"] = data_values, params, sample
-            plan_token = ("flat", fe["serial"], id(data_values), sample)     # (the same token the next call with these objects finds)
+            plan_token = fe["plan_keys"] = {}     # (content keys of the plans of these tables: filled by the plan cache, found again next call)
 
     # ---- level-pool reservoirs (mc_reach.pyx:283-356): one-node reaches of type 1 ----------------------
     res_rows, res_par, res_q0 = [], [], []

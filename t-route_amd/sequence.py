@@ -325,7 +325,7 @@ class RouteStream:
             self._dc = 0
         else:
             comm = self.comm
-            late = getattr(r, "_planS_lag", 0) or 3 * 18
+            late = getattr(r, "_planS_lag", 0) or 4 * 18      # (a first guess: the loop below raises it if the cut rows run further behind)
             while True:
                 P = r.stream_plan(late)
                 lag, W, C = P.lags()
@@ -436,7 +436,15 @@ class RouteStream:
         # the state and the shape of the forcing
         q0 = None if state0 is None else np.ascontiguousarray(state0[rows] if (local and state0.shape[0] == r.nseg) else state0, dtype=dtype)
         P.upload_forcing(nsteps, np.ascontiguousarray(take(first), dtype=dtype), q0)
-        P.stream_begin(nsteps, qts, slots=self.slots, full_output=self.full_output and not self.output_stride,
+        slots = self.slots
+        if multi:
+            # every rank hands a day over in the same iteration -- when the rank whose rows run furthest behind (the trunk's owner)
+            # has it: a rank's ring must hold its days that long
+            lmax_mine = int(P.lags()[0].max(initial=0))
+            lmax_all = int(self.comm.all_reduce_max_host(np.array([lmax_mine], dtype=np.float64))[0])
+            tpd0 = nsteps // self._tile_steps(P)
+            slots = max(slots, (-(-lmax_all // tpd0) if lmax_all else 0) + 3)
+        P.stream_begin(nsteps, qts, slots=slots, full_output=self.full_output and not self.output_stride,
                        output_stride=self.output_stride)
         self.info = info = P.stream_info()
         D, tpd, lmax = info["slots"], info["tiles_per_day"], info["lag_max"]
@@ -462,7 +470,6 @@ class RouteStream:
                 send = [X.DeviceBuffer(dev, mc * nsteps * e) for _ in range(2)]
                 recv = [X.DeviceBuffer(dev, world * mc * nsteps * e) for _ in range(2)]
                 sc = r._sc
-            lmax_all = int(comm.all_reduce_max_host(np.array([lmax], dtype=np.float64))[0])
             behind = (-(-lmax_all // tpd) if lmax_all else 0) + 1       # (every rank hands a day over in the same iteration)
             order = None
         self._out_rows = np.sort(r._outS_global) if not multi else None

@@ -59,7 +59,8 @@ def test_lowercolorado_through_compute_nhd_routing_v02(short):
 def test_output_stride_is_the_full_result_sliced(short, engine, monkeypatch):
     """``output_stride`` (keyword-only extension of the drop-in): every n-th timestep, decimated on the device -- what the
     reference's writers keep of a window (nwm_routing/output.py:209-216, nhd_io.py:2379-2382) -- equals slicing the full
-    ``flowveldepth`` bit for bit, whatever n; the final state (``new_q0``) is the same when n divides nts."""
+    ``flowveldepth`` bit for bit for every n that divides nts -- then the last kept step is the window's last and ``new_q0`` is
+    the same; an n that does not divide nts is refused (the next window would silently restart from an earlier step)."""
     monkeypatch.setenv("TRMC_ENGINE", engine)
     monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "32")
     lc = H.LowerColorado()
@@ -68,7 +69,7 @@ def test_output_stride_is_the_full_result_sliced(short, engine, monkeypatch):
     nts = 96
     full, _, _ = call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short)
     want = full[0][1].reshape(lc.nseg, nts, 3)
-    for n in (12, 7, 96, 100):
+    for n in (12, 8, 96, 1):
         got, _, _ = call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short, output_stride=n)
         fvd = got[0][1]
         assert fvd.shape == (lc.nseg, (nts // n) * 3) and fvd.dtype == np.float32
@@ -78,6 +79,9 @@ def test_output_stride_is_the_full_result_sliced(short, engine, monkeypatch):
     assert np.array_equal(new_q0(got).values, new_q0(full).values)
     with pytest.raises(ValueError, match="output_stride"):
         call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short, output_stride=0)
+    for n in (7, 100):
+        with pytest.raises(ValueError, match="must divide nsteps"):
+            call(conn, param_df, q0_df, qlat_df, nts, lc.qts, short, output_stride=n)
 
 
 def test_many_networks_one_plan_results_per_tailwater():

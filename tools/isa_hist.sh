@@ -13,7 +13,7 @@ import re
 import subprocess
 import sys
 
-want = ("k_mc_tile", "k_mc_step", "k_mc_flow_lean", "k_mc_flow", "k_emit")
+want = ("k_mc_ctile", "k_mc_tile", "k_mc_step", "k_mc_flow_lean", "k_mc_flow", "k_emit")
 lines = open(sys.argv[1]).read().splitlines()
 
 

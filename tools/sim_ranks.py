@@ -380,7 +380,7 @@ def stream_mode(a, net, to, params, qlat, q0, part, hint, nsteps, qts, dev, X, s
           mine = cut_rows[owner[piece][cut_rows] == k] if cut_rows.size else cut_rows
           if mine.size:
               _, lag, _, _, _, _ = topology_clusters(lp, li, cost_hint=None if hint is None else hint[rows0],
-                                                     wide_min_rows=opts.get("wide_min_rows", 1024), wide_max_levels=16, cluster_rows=128)
+                                                     wide_min_rows=opts.get("wide_min_rows", 1024), wide_max_levels=32, cluster_rows=128)
               pmax = max(pmax, int(lag[g2l[mine]].max()))
       for rank in ([int(k) for k in a.ranks.split(',')] if a.ranks else range(a.world)):
           r = ShardedRouter(to, params, rank=rank, world=a.world, device=0, partition=part, cost_hint=hint, stream=True, options=opts)
