@@ -325,19 +325,14 @@ class RouteStream:
             self._dc = 0
         else:
             comm = self.comm
-            late = getattr(r, "_planS_lag", 0) or 4 * 18      # (a first guess: the loop below raises it if the cut rows run further behind)
-            while True:
-                P = r.stream_plan(late)
-                lag, W, C = P.lags()
-                mine = int(lag[r.my_cut_local].max()) if r.my_cut_local.size else 0
-                pmax = int(comm.all_reduce_max_host(np.array([mine], dtype=np.float64))[0])
-                K = K or self._tile_steps(P)
-                tpd = self.nsteps // K
-                dc = -(-(pmax + 1) // tpd)                  # days after which every rank's cut rows are through a day
-                need = (dc + 1) * tpd                       # ... and the tiles the trunk must run behind for that
-                if need <= late:
-                    break
-                late = need
+            # (the cut rows are rows of plan0 -- the sub-basins -- whose order does not depend on the trunk: their lag is known
+            # before the merged plan is built, so that plan is built once, with the lag the trunk needs)
+            lag0, _, _ = r.plan0.lags()
+            mine = int(lag0[r.my_cut_local].max()) if r.my_cut_local.size else 0
+            pmax = int(comm.all_reduce_max_host(np.array([mine], dtype=np.float64))[0])
+            tpd = self.nsteps // self._tile_steps(r.plan0)
+            dc = -(-(pmax + 1) // tpd)                      # days after which every rank's cut rows are through a day
+            P = r.stream_plan((dc + 1) * tpd)               # ... and the tiles the trunk must run behind for that
             self._dc = dc
         self.plan = P
         self.rows = r._rowsS
