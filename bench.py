@@ -991,6 +991,22 @@ def main():
         full = {"value": rate(f), "unit": "segment-timesteps/s", "ms_per_step": f["el"] / fsteps * 1e3,
                 "launches": f["launches"], "ms_main": f["ms_main"], "roofline_frac": frac(f),
                 "engine": getattr(rf.plan0, "engine", "levels"), "window": "day N+1 forcing, cold start"}
+        if world == 1:
+            try:      # the general mode's sequence form: D days as ONE window of D x nsteps steps (the same values: a window's end
+                # state is the next one's start, AbstractNetwork.py:177-191) -- the ramp over the network's levels is paid once
+                D = 4
+                nq1 = a.nsteps // a.qts
+                qD = np.ascontiguousarray(np.concatenate([ring[k % len(ring)][:, :nq1] for k in range(D)], axis=1))
+                pD = rf.plan0
+                pD.upload_forcing(a.nsteps * D, qD, q0)
+                stD = pD.route_device(a.nsteps * D, a.qts, False)
+                full["days_as_one_window"] = {"days": D, "ms_per_day": stD["ms_main"] / D, "roofline_frac":
+                                              nseg * a.nsteps * 64 / (stD["ms_main"] / D * 1e-3) / 8e12,
+                                              "what": f"{D} days' forcing side by side, one window of {a.nsteps * D} steps on the same plan "
+                                                      "(device time of the window / days)"}
+                del qD
+            except Exception as e:
+                full["days_as_one_window"] = {"error": repr(e)}
         rf.close()
 
     transport = None

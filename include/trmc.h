@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TRMC_ABI_VERSION 18
+#define TRMC_ABI_VERSION 19
 
 typedef enum trmc_status {
     TRMC_OK = 0,
@@ -488,6 +488,11 @@ int trmc_download_fvd(trmc_plan *plan, void *fvd_out);
  * falls on a multiple of dt * qts_subdivisions; stride = qts_subdivisions for hourly output of 5-minute steps).  A twelfth
  * of the bytes crosses the host link: a CONUS day 0.78 GB instead of 9.4.  Bit-identical to slicing the full array. */
 int trmc_download_fvd_strided(trmc_plan *plan, int stride, void *fvd_out);
+/* The same for the rows of a registered set (trmc_rowset_create), in the set's order: fvd_out[rows of the set][nsteps / stride][3]
+ * (stride = 1: every step).  compute_nhd_routing_v02 hands its result back as one block per tailwater (compute.py:1738, the
+ * per-network loop :1399-1738): with the set = the table's rows grouped by tailwater, each of those is a slice of fvd_out and
+ * the host never permutes the block. */
+int trmc_download_fvd_rowset(trmc_plan *plan, int stride, int32_t rowset, void *fvd_out);
 /* Page-locked host memory for result arrays: a D2H copy into it runs at the speed of the link instead of through the
  * driver's staging buffers (the 9.4 GB flowveldepth array of a CONUS day: 0.2 s instead of 0.8 s).  The Python host side
  * keeps a small pool of these behind download_fvd(); a C caller may use them for any *_out argument.  Plain memory to the

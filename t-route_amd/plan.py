@@ -452,12 +452,18 @@ class RoutingPlan:
         _lib.check(_lib.lib().trmc_plan_set_lag(self._h, _lib.ptr(lag)))
         self.maxlag = 0 if lag is None else int(lag.max(initial=0))
 
-    def download_fvd(self, stride=1):
+    def download_fvd(self, stride=1, rowset=None):
         """fvd [nseg, nsteps // stride, 3]: every `stride`-th step (the steps stride, 2 stride, ... counted from 1), decimated
-        on the device (trmc_download_fvd_strided); stride = 1: the whole result."""
+        on the device (trmc_download_fvd_strided); stride = 1: the whole result.  rowset (``rowset(rows)``): the rows of that
+        set only, in its order (trmc_download_fvd_rowset)."""
         stride = int(stride)
         if stride < 1:
             raise ValueError("stride must be >= 1")
+        if rowset is not None:
+            out = _lib.result_empty((self._rowset_n[rowset], self._nsteps // stride, 3), self.dtype)
+            if out.size:
+                _lib.check(_lib.lib().trmc_download_fvd_rowset(self._h, stride, int(rowset), _lib.ptr(out)))
+            return out
         out = _lib.result_empty((self.nseg, self._nsteps // stride, 3), self.dtype)
         if out.size:
             _lib.check(_lib.lib().trmc_download_fvd_strided(self._h, stride, _lib.ptr(out)))

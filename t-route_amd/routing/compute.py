@@ -183,9 +183,9 @@ def compute_nhd_routing_v02(
             v = df.values
             if v.dtype != np.float32:
                 v = v.astype("float32")
-            # (a NaN anywhere makes the sum NaN: one pass without a temporary the size of the table; infinities cannot cancel
-            # each other out of it unless both signs are there, and then the sum is NaN as well)
-            return v if not np.isnan(v.sum(dtype=np.float64)) else np.nan_to_num(v, nan=0.0)
+            # (a NaN anywhere makes the minimum NaN -- np.min propagates it: one vectorised pass without a temporary the size of
+            # the table)
+            return v if not (v.size and np.isnan(v.min())) else np.nan_to_num(v, nan=0.0)
         return df.reindex(table_index).fillna(0.0).values.astype("float32")
     q0_v, qlat_v = rows_of(q0), rows_of(qlats)
 
@@ -213,6 +213,9 @@ def compute_nhd_routing_v02(
                      np.array(da_bygage, dtype="int32"), lastobs_v, lastobs_t)
     else:
         gage_args = (e_f2, e_i1, e_i1, e_i1, e_f1, e_f1)
+    # the result in the order that groups the table's rows by tailwater (a network's block is then a slice of it), permuted on the
+    # device as it is decimated -- when every row of the table belongs to a tailwater of the call and is in the result
+    grouped = not upstream_results and not ngage and net["order"].shape[0] == nseg and bool(net["bounds"][0] == 0)
     r = compute_network_structured(
         nts, dt, qts_subdivisions, reaches_wTypes, upstream_connections, ids, table_cols,
         table_values, q0_v, qlat_v, lake_segs, waterbodies_sub, data_assimilation_parameters,
@@ -224,7 +227,7 @@ def compute_nhd_routing_v02(
         e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
         e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
         upstream_results, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device,
-        output_stride=output_stride)
+        output_stride=output_stride, result_order=net["order"] if grouped else None)
     rids = r[0].astype("int64")                  # (the rows of upstream_results are masked out, mc_reach.pyx:451,:812)
     fvd, upstream = r[1], r[6]
     gage_ids, lastobs_times, lastobs_values = r[3]
@@ -248,10 +251,13 @@ def compute_nhd_routing_v02(
         owner = owner[keep]
         order = np.argsort(owner, kind="stable")
         bounds = np.searchsorted(owner[order], np.arange(len(tws) + 1))
-    ids_o, fvd_o = rids[order].astype(np.intp), fvd[order]
-    # (the upstream-inflow series are zero except on waterbody rows, mc_reach.pyx:487,:710: without waterbodies any order of an
-    # all-zero block is the block itself -- 3.1 GB for a CONUS day that need not be permuted)
-    up_o = upstream[order] if len(lake_segs) else upstream
+    if grouped:                                  # (compute_network_structured has handed its rows back in that order)
+        ids_o, fvd_o, up_o = rids.astype(np.intp), fvd, upstream
+    else:
+        ids_o, fvd_o = rids[order].astype(np.intp), fvd[order]
+        # (the upstream-inflow series are zero except on waterbody rows, mc_reach.pyx:487,:710: without waterbodies any order of
+        # an all-zero block is the block itself -- 3.1 GB for a CONUS day that need not be permuted)
+        up_o = upstream[order] if len(lake_segs) else upstream
     e5, e3, e4 = (e_i1, e_f1, e_f1, e_f1, e_f1), (e_i1, e_f1, e_i1), (e_i1, e_f1, e_i1, e_i1)
     no_gage = (np.asarray([], dtype=np.int64), np.full(0, np.nan, "float32"), np.full(0, np.nan, "float32"))
     no_nudge = np.zeros((0, nts + 1), dtype="float32")

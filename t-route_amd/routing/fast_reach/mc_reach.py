@@ -370,6 +370,7 @@ def compute_network_structured(
     device=0,
     return_stats=False,
     output_stride=None,
+    result_order=None,
 ):
     """Route one (sub)network for ``nsteps`` timesteps on the GPU.
 
@@ -381,7 +382,12 @@ def compute_network_structured(
     every n-th step only -- ``flowveldepth[:, 3 * (n (k + 1) - 1) : ...]``, the steps
     the reference's writers keep when n = qts_subdivisions, nwm_routing/output.py:209-216,
     :232-240 -- decimated on the device, so that a twelfth of the bytes crosses the host
-    link; bit-identical to slicing the full result; the other elements are unchanged).
+    link; bit-identical to slicing the full result; the other elements are unchanged),
+    ``result_order`` (None: rows in the order of ``data_idx``, the reference's; a
+    permutation of ``range(len(data_idx))``: elements [0], [1] and [6] come back in that
+    row order, permuted on the device -- compute_nhd_routing_v02 asks for its rows grouped
+    by tailwater, so that every network's block is a slice; without off-network
+    ``upstream_results`` rows only).
     """
     stride = 1 if output_stride is None else int(output_stride)
     if stride < 1:
@@ -548,7 +554,24 @@ def compute_network_structured(
             if nudging[5] is not None:
                 plan.set_nudging_successors(nudging[5])
         plan.route_device(nsteps, qts_subdivisions, assume_short_ts)
-        fvd = plan.download_fvd(stride)
+        oset = None
+        if result_order is not None:
+            if not fill_index_mask.all():
+                raise ValueError("result_order: not with off-network upstream_results rows (they are masked out of the result)")
+            result_order = np.ascontiguousarray(result_order, dtype=np.int64)
+            if result_order.shape != (nseg,):
+                raise ValueError(f"result_order must be a permutation of the {nseg} rows")
+            sets = plan.__dict__.setdefault("_order_sets", {})      # (the set lives with the plan: one per caller's order array)
+            okey = (result_order.ctypes.data, nseg)
+            hit = sets.get(okey)
+            if hit is None or hit[0] is not result_order:
+                if len(sets) >= 2:
+                    sets.clear()
+                if nseg and not np.array_equal(np.sort(result_order), np.arange(nseg)):
+                    raise ValueError(f"result_order must be a permutation of the {nseg} rows")
+                hit = sets[okey] = (result_order, plan.rowset(result_order))
+            oset = hit[1]
+        fvd = plan.download_fvd(stride, rowset=oset)
         if nudging is not None:
             nudge[nudging[4], 1:] = plan.download_nudge()
         res_inflow = plan.download_reservoir_inflow() if res_rows else None
@@ -561,13 +584,15 @@ def compute_network_structured(
     upstream = np.zeros((nseg, nsteps), dtype="float32")  # np.empty in the reference (:487), reservoir rows filled (:710)
     if res_rows:
         upstream[res_rows] = res_inflow
+        if result_order is not None:
+            upstream = upstream[result_order]
     if not fill_index_mask.all():
         upstream = upstream[fill_index_mask]
     t_end = nsteps * dt
     f32 = lambda a: np.asarray(a, dtype="float32")  # noqa: E731
     i32 = lambda a: np.asarray(a, dtype="int32")  # noqa: E731
     result = (
-        np.asarray(data_idx, dtype=np.intp)[fill_index_mask],
+        np.asarray(data_idx, dtype=np.intp)[fill_index_mask] if result_order is None else np.asarray(data_idx, dtype=np.intp)[result_order],
         flowveldepth,
         0,
         (

@@ -370,7 +370,7 @@ class RouteStream:
         P, multi = self.plan, self.world > 1
         lag, _, _ = P.lags()
         tpd = self.nsteps // self._tile_steps(P)
-        fill = -(-int(lag.max(initial=0)) // tpd) + 1 + (self._dc + 1 if multi else 0)
+        fill = -(-int(lag.max(initial=0)) // tpd) + 1 + (self._dc + 1 if multi else 0) + (1 if (self.output_stride or self.full_output) else 0)
         if multi:
             fill = int(self.comm.all_reduce_max_host(np.array([fill], dtype=np.float64))[0])
         wu = max(int(warmup), fill)
@@ -432,18 +432,23 @@ class RouteStream:
         q0 = None if state0 is None else np.ascontiguousarray(state0[rows] if (local and state0.shape[0] == r.nseg) else state0, dtype=dtype)
         P.upload_forcing(nsteps, np.ascontiguousarray(take(first), dtype=dtype), q0)
         slots = self.slots
+        want_fvd = bool(self.output_stride or self.full_output)
+        lmax_mine = int(P.lags()[0].max(initial=0))
+        tpd0 = nsteps // self._tile_steps(P)
+        if want_fvd and not multi:
+            # a day's (q, v, d) block takes most of a day to cross PCIe (0.79 GB of a CONUS day with hourly output: 14.5 ms):
+            # it is handed over a day later than the other products would be, so that the host never waits for a copy while the
+            # device runs out of queued days -- and the ring holds a slot more for it
+            slots = max(slots, 3 + -(-(lmax_mine + 1) // tpd0))
         if multi:
             # every rank hands a day over in the same iteration -- when the rank whose rows run furthest behind (the trunk's owner)
             # has it: a rank's ring must hold its days that long
-            lmax_mine = int(P.lags()[0].max(initial=0))
             lmax_all = int(self.comm.all_reduce_max_host(np.array([lmax_mine], dtype=np.float64))[0])
-            tpd0 = nsteps // self._tile_steps(P)
-            slots = max(slots, (-(-lmax_all // tpd0) if lmax_all else 0) + 3)
+            slots = max(slots, (-(-lmax_all // tpd0) if lmax_all else 0) + 3 + (1 if want_fvd else 0))
         P.stream_begin(nsteps, qts, slots=slots, full_output=self.full_output and not self.output_stride,
                        output_stride=self.output_stride)
         self.info = info = P.stream_info()
         D, tpd, lmax = info["slots"], info["tiles_per_day"], info["lag_max"]
-        want_fvd = bool(self.output_stride or self.full_output)
         keep = nsteps // self.output_stride if self.output_stride else nsteps
         nout = r._outS_global.shape[0]
         hyds = [_lib.result_empty((max(nout, 1), nsteps), dtype, always_pinned=True) for _ in range(D)]
@@ -453,7 +458,7 @@ class RouteStream:
         # when a day's products are waited for: a day after they were queued (the host then never waits for launches it has
         # just queued -- the device always holds a day of work); latency="low": right after the day's own push (flushed)
         low = self.latency == "low"
-        behind = 0 if low else (-(-lmax // tpd) if lmax else 0) + 1
+        behind = 0 if low else (-(-lmax // tpd) if lmax else 0) + 1 + (1 if want_fvd else 0)
         if multi:
             comm = self.comm
             on_device = self.exchange == "device"
@@ -465,7 +470,7 @@ class RouteStream:
                 send = [X.DeviceBuffer(dev, mc * nsteps * e) for _ in range(2)]
                 recv = [X.DeviceBuffer(dev, world * mc * nsteps * e) for _ in range(2)]
                 sc = r._sc
-            behind = (-(-lmax_all // tpd) if lmax_all else 0) + 1       # (every rank hands a day over in the same iteration)
+            behind = (-(-lmax_all // tpd) if lmax_all else 0) + 1 + (1 if want_fvd else 0)   # (every rank hands a day over in the same iteration)
             order = None
         self._out_rows = np.sort(r._outS_global) if not multi else None
         sel_own = np.argsort(r._outS_global, kind="stable")

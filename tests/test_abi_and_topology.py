@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in trmc.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with trmc.h"
-    assert lib.trmc_abi_version() == 18
+    assert lib.trmc_abi_version() == 19
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "trdw.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(trdw_[a-z0-9_]+)\s*\(", hdr))
     for name in declared:

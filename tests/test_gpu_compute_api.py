@@ -264,3 +264,26 @@ def test_kernel_callable_reuses_and_tunes_its_plan_without_changing_results(monk
     assert e["stage"] == 2 and e["policy"] is None
     M._PLANS.clear()
     assert not M._PLANS._d
+
+
+@pytest.mark.parametrize("short", [True, False])
+def test_result_order_is_the_result_permuted(short):
+    """``result_order`` (keyword-only extension of compute_network_structured; trmc_download_fvd_rowset): ids, flowveldepth and
+    the upstream series in a row order of the caller's choice, permuted on the device as the result is decimated -- equal to
+    indexing the reference-ordered result, for the full result and a decimated one; anything but a permutation is refused."""
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+    lc = H.LowerColorado()
+    nts = 48
+    args = mc_only_args(nts, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, lc.q0, lc.qlat, None, short)
+    full = compute_network_structured(*args)
+    perm = np.random.default_rng(5).permutation(lc.nseg)
+    for n in (1, 12):
+        got = compute_network_structured(*args, output_stride=n, result_order=perm)
+        assert np.array_equal(got[0], full[0][perm])
+        want = full[1].reshape(lc.nseg, nts, 3)[perm][:, n - 1::n, :]
+        assert np.array_equal(got[1].reshape(lc.nseg, nts // n, 3).view(np.uint32), want.view(np.uint32)), n
+        assert got[6].shape == full[6].shape
+    with pytest.raises(ValueError, match="permutation"):
+        compute_network_structured(*args, result_order=np.zeros(lc.nseg, dtype=np.int64))
+    with pytest.raises(ValueError, match="permutation"):
+        compute_network_structured(*args, result_order=perm[:-1])

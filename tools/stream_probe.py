@@ -25,6 +25,7 @@ ap.add_argument("--stride", type=int, default=0)
 ap.add_argument("--full", action="store_true")
 ap.add_argument("--no-check", action="store_true")
 ap.add_argument("--slots", type=int, default=0)
+ap.add_argument("--later", type=int, default=0, help="hand a day over this many days later than its last row allows (and hold as many more slots)")
 a = ap.parse_args()
 _lib.single_hw_queue_per_priority("stream_probe")
 nnet = S.CONUS_NNET if a.nseg == S.CONUS_NSEG else max(1, a.nseg // 185)
@@ -69,7 +70,7 @@ with RoutingPlan(up_ptr, up_idx, net["params"], assume_short_ts=True, engine="le
         print(f"one by one: {(time.perf_counter() - t0) / a.days * 1e3:.2f} ms per day (host loop, downloads included); window ms_main {st['ms_main']:.2f}", flush=True)
     # the stream
     p.upload_forcing(nsteps, days[0], q0)
-    p.stream_begin(nsteps, qts, slots=a.slots, full_output=a.full and not a.stride, output_stride=a.stride)
+    p.stream_begin(nsteps, qts, slots=a.slots + a.later if a.slots else (a.later and 2 + -(-(int(p.lags()[0].max(initial=0)) + 1) // (nsteps // p.tile_steps)) + a.later), full_output=a.full and not a.stride, output_stride=a.stride)
     info = p.stream_info()
     print("stream:", info, flush=True)
     D = info["slots"]
@@ -78,7 +79,7 @@ with RoutingPlan(up_ptr, up_idx, net["params"], assume_short_ts=True, engine="le
     keep = nsteps // a.stride if a.stride else nsteps
     fvds = [_lib.result_empty((n, keep, 3), np.float32, always_pinned=True) for _ in range(D)] if (a.stride or a.full) else [None] * D
     got = []
-    behind = (info["lag_max"] + info["tiles_per_day"]) // info["tiles_per_day"]
+    behind = (info["lag_max"] + info["tiles_per_day"]) // info["tiles_per_day"] + a.later
     ok = True
     marks = []
 
