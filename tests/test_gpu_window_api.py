@@ -384,7 +384,8 @@ def test_windows_that_decimate_as_they_go_hand_over_the_same_block(monkeypatch, 
 def test_hot_rows_are_routed_by_blocks_of_their_own_and_change_nothing(monkeypatch, hinted):
     """trmc_plan_options.hot_rows: rows that end a tile in three or more secant iterations (or over bank) are taken out of their
     blocks for the next tile.  A forcing that floods part of the network makes sure there are some -- more than the list holds
-    (the rest stay where they are) -- over several windows, and the result must be the one without the option, bit for bit."""
+    (the rest stay where they are) -- over several windows, and the result must be the one without the option, bit for bit; so
+    must the cost every row collected (trmc_plan_collect_cost): a row routed twice in a launch would have counted twice."""
     monkeypatch.setenv("TRMC_ENGINE", "levels")
     monkeypatch.setenv("TRMC_WIDE_MIN_ROWS", "64")
     monkeypatch.setenv("TRMC_WIDE_K", "4")
@@ -399,17 +400,21 @@ def test_hot_rows_are_routed_by_blocks_of_their_own_and_change_nothing(monkeypat
         hint = (rng.integers(0, 4, to.shape[0]).astype(np.uint8) if hinted else None)
         with RoutingPlan(up_ptr, up_idx, p, assume_short_ts=True, cost_hint=hint) as plan:
             res = []
+            plan.collect_cost(True)
             plan.upload_forcing(nsteps, qlat, q0)
             for k in range(3):
                 plan.route_device(nsteps, qts, True)
                 res.append(plan.download_fvd())
+                res.append(plan.download_cost()[0])
                 plan.upload_forcing(nsteps, qlat * np.float32(1.0 + 0.5 * (k + 1)), None)
             assert plan.stats()["wide_levels"] > 0
             n = plan.hot_rows()
             assert (n > 200) == bool(hot), n
             out[hot] = res
+    # (... and every row is routed ONCE per tile, by its block or by the list's: the cost sums -- one addition per routing of a
+    # row -- are the same numbers either way)
     for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(a.view(np.uint32 if a.dtype == np.float32 else a.dtype), b.view(np.uint32 if b.dtype == np.float32 else b.dtype))
 
 
 def test_device_clock_stamps_of_consecutive_windows(monkeypatch):
