@@ -103,6 +103,35 @@ def test_a_stream_of_days_on_one_gpu_equals_the_days_routed_one_by_one(variant):
     r.close()
 
 
+def test_a_second_stream_with_more_slots_on_the_same_plan():
+    """The bench's order of things: a products-only stream, then -- on the same plan -- a stream that also hands every row's
+    decimated (q, v, d) block over and therefore holds a slot more (the block leaves a day later, RouteStream): the per-slot
+    buffers of the second are sized for ITS ring (the hydrograph slots once were not: a write past the allocation)."""
+    net = synthetic.generate(nseg=20000, nnet=60, seed=12, nq=3)
+    nseg = net["to"].shape[0]
+    nsteps, qts, ndays = 48, 16, 9
+    q0 = np.random.default_rng(2).uniform(0, 1, (nseg, 3)).astype(np.float32)
+    days = days_of(net, 3, seed=8)
+    seq_days = [days[w % 3] for w in range(ndays)]
+    rows, want_h, want_s, want_f = reference_days(net, seq_days, q0, nsteps, qts, 12, False)
+    r = ShardedRouter(net["to"], net["params"], stream=True, options={"wide_min_rows": 64, "wide_k": 8})
+    slots = []
+    for stride in (None, 12, None):
+        got = {}
+        with RouteStream(r, nsteps, qts, output_stride=stride) as rs:
+            for item in rs.route(iter(seq_days), q0):
+                got[item[0]] = tuple(None if x is None else np.array(x, copy=True) for x in item[1:])
+            slots.append(rs.last_info["slots"])
+        assert sorted(got) == list(range(ndays))
+        for w in range(ndays):
+            assert np.array_equal(bits(got[w][0]), bits(want_h[w])), (stride, w)
+            assert np.array_equal(bits(got[w][1]), bits(want_s[w])), (stride, w)
+            if stride:
+                assert np.array_equal(bits(got[w][2]), bits(want_f[w])), w
+    assert slots[1] == slots[0] + 1 and slots[2] == slots[0], slots
+    r.close()
+
+
 def test_stream_api_errors_and_bookkeeping():
     net = synthetic.generate(nseg=3000, nnet=9, seed=5, nq=3)
     nseg = net["to"].shape[0]
