@@ -903,9 +903,49 @@ def main():
                         "outlet_rows_equal_the_fetched_hydrographs": bool(np.array_equal(
                             hs["fvd"][rows_o, :, 0].view(np.uint32), hs["hyd"][:, a.qts - 1::a.qts].view(np.uint32))),
                         "what": "the headline's stream with every row's (q, v, d) at every qts-th step among each day's products"}
+                    fvd_ref, hyd_ref, fin_ref = np.array(hs["fvd"], copy=True), np.array(hs["hyd"], copy=True), np.array(hs["final"], copy=True)
                     del hs
+                    # ... and with trmc_plan_options.velocity_on_demand: a step's velocity formed only where it is handed on (the kept
+                    # steps here; nowhere when the products are hydrographs and states) -- the same days on a plan made with the option
+                    vr = make_router(hint, True, None, None, options={"velocity_on_demand": 1}, stream=True)
+                    try:
+                        with RouteStream(vr, a.nsteps, a.qts, output_stride=a.qts) as rs:
+                            rs.run(ring[:4], state_n, 2, 0, prepared=True)
+                            hv = rs.run(ring, state_n, hsteps, 1, prepared=True)
+                        same_h = bool(np.array_equal(hv["fvd"].view(np.uint32), fvd_ref.view(np.uint32)) and
+                                      np.array_equal(hv["hyd"].view(np.uint32), hyd_ref.view(np.uint32)) and
+                                      np.array_equal(hv["final"].view(np.uint32), fin_ref.view(np.uint32)))
+                        per_h = hv["el"] / hsteps
+                        del hv, fvd_ref
+                        psteps = max(2, min(a.steps, 12))
+                        with RouteStream(srouter, a.nsteps, a.qts) as rs:
+                            p0 = rs.run(ring, state_n, psteps, 1, prepared=True)
+                        hyd0, fin0, per0 = np.array(p0["hyd"], copy=True), np.array(p0["final"], copy=True), p0["el"] / psteps
+                        del p0
+                        with RouteStream(vr, a.nsteps, a.qts) as rs:
+                            rs.run(ring[:4], state_n, 2, 0, prepared=True)
+                            p1 = rs.run(ring, state_n, psteps, 1, prepared=True)
+                        per1 = p1["el"] / psteps
+                        extra["velocity_on_demand"] = {
+                            "products_only": {"ms_per_step": per1 * 1e3, "value": nseg * a.nsteps / per1, "steps": psteps,
+                                              "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / per1 / 1e9 / HBM_PEAK_GBS,
+                                              "same_run_with_every_velocity_ms": per0 * 1e3,
+                                              "hydrographs_and_final_state_bit_identical": bool(
+                                                  np.array_equal(p1["hyd"].view(np.uint32), hyd0.view(np.uint32)) and
+                                                  np.array_equal(p1["final"].view(np.uint32), fin0.view(np.uint32)))},
+                            "hourly_output": {"ms_per_step": per_h * 1e3, "steps": hsteps,
+                                              "block_hydrographs_final_state_bit_identical_to_in_stream": same_h},
+                            "what": "NOT the headline: the stream on a plan made with trmc_plan_options.velocity_on_demand -- the velocity "
+                                    "of a step (it feeds nothing: f90:163-169 forms it from the final depth) is computed only where it "
+                                    "is handed on"}
+                        del p1
+                    finally:
+                        vr.close()
                 except Exception as e:
-                    extra["hourly_output"]["in_stream"] = {"error": repr(e)}
+                    import traceback
+                    traceback.print_exc()
+                    extra["hourly_output"].setdefault("in_stream", {"error": repr(e)})
+                    extra["velocity_on_demand"] = {"error": repr(e)}
             try:
                 pass
             finally:

@@ -189,6 +189,11 @@ int trmc_plan_create_ex(int64_t nseg, const int64_t *up_ptr, const int64_t *up_i
  *                  device one launch does not fill (a rank of a multi-GPU job); measured slower at 32, 16 and 8.
  *   stream_split   s > 0: in a stream of windows the slices from level s on are launched on the clusters' stream instead of the
  *                  tile stream (an experiment: 3 % faster on CONUS on one GPU, twice as slow on a rank of eight; default 0).
+ *   velocity_on_demand  != 0: in a stream of windows begun without full_output, a step's velocity is formed only where it is
+ *                  handed on -- at the kept steps of output_stride, or nowhere when the products are hydrographs and final
+ *                  states.  The velocity feeds nothing (MCsingleSegStime_f2py_NOLOOP.f90:163-169 computes it from the final
+ *                  depth; the next step takes velp and does not read it), so every product keeps its bits; a tenth of a step's
+ *                  instructions are not issued (CONUS: 12.3 instead of 13.5 ms per day).  Default 0: every step forms it.
  *   tail_sort      < 0: keep the per-level order below the tiled levels of a hinted short-timestep plan (default: by cost).
  *   stem_min_rows  general-mode dataflow plans: basins whose longest path has at least so many rows are laid out stem-last
  *                  (0 = default 1 024, < 0 = off).
@@ -221,7 +226,8 @@ typedef struct trmc_plan_options {
     int32_t cluster_late_lag;
     int32_t stream_split;
     int32_t hot_wave_rows;
-    int32_t reserved[3];
+    int32_t velocity_on_demand;
+    int32_t reserved[2];
 } trmc_plan_options;
 int trmc_plan_create_opt(int64_t nseg, const int64_t *up_ptr, const int64_t *up_idx,
                          const float *params, const uint8_t *boundary, const uint8_t *cost_hint,

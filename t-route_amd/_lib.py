@@ -40,7 +40,7 @@ class PlanOptions(C.Structure):
         ("wide_k", C.c_int32), ("mid_min_rows", C.c_int64), ("mid_levels", C.c_int32), ("mid_k", C.c_int32),
         ("tile_perm_group", C.c_int32), ("tail_sort", C.c_int32), ("stem_min_rows", C.c_int32), ("sequence_mode", C.c_int32),
         ("flow_watchdog_ms", C.c_int32), ("flow_overlap", C.c_int32), ("flow_lean", C.c_int32), ("flow_debug", C.c_int32), ("hot_rows", C.c_int32),
-        ("cluster_rows", C.c_int32), ("cluster_late_lag", C.c_int32), ("stream_split", C.c_int32), ("hot_wave_rows", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("cluster_rows", C.c_int32), ("cluster_late_lag", C.c_int32), ("stream_split", C.c_int32), ("hot_wave_rows", C.c_int32), ("velocity_on_demand", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -51,7 +51,7 @@ ARITH_EXACT, ARITH_TOLERANCE = 0, 1
 OPTION_ENV = {
     "TRMC_WIDE_MIN_ROWS": ("wide_min_rows", "off0"), "TRMC_WIDE_LEVELS": ("wide_levels", "int"), "TRMC_WIDE_K": ("wide_k", "int"),
     "TRMC_MID_MIN_ROWS": ("mid_min_rows", "off0"), "TRMC_MID_LEVELS": ("mid_levels", "int"), "TRMC_MID_K": ("mid_k", "int"),
-    "TRMC_TILE_PERM": ("tile_perm_group", "off0"), "TRMC_HOT_ROWS": ("hot_rows", "off0"), "TRMC_CLUSTER_ROWS": ("cluster_rows", "int"), "TRMC_STREAM_SPLIT": ("stream_split", "int"), "TRMC_HOT_WAVE_ROWS": ("hot_wave_rows", "int"), "TRMC_TAIL_SORT": ("tail_sort", "off0"),
+    "TRMC_TILE_PERM": ("tile_perm_group", "off0"), "TRMC_HOT_ROWS": ("hot_rows", "off0"), "TRMC_CLUSTER_ROWS": ("cluster_rows", "int"), "TRMC_STREAM_SPLIT": ("stream_split", "int"), "TRMC_HOT_WAVE_ROWS": ("hot_wave_rows", "int"), "TRMC_VELOCITY_ON_DEMAND": ("velocity_on_demand", "int"), "TRMC_TAIL_SORT": ("tail_sort", "off0"),
     "TRMC_STEM_MIN_ROWS": ("stem_min_rows", "off0"), "TRMC_SETUP_ASIDE": ("sequence_mode", "flag"),
     "TRMC_FLOW_WATCHDOG_MS": ("flow_watchdog_ms", "int"), "TRMC_FLOW_OVERLAP": ("flow_overlap", "flag"),
     "TRMC_FLOW_LEAN": ("flow_lean", "lean"), "TRMC_FLOW_DEBUG": ("flow_debug", "flag"),

@@ -488,9 +488,11 @@ MC_HD T step_velocity(const ChannelParams<T> &p, const ChannelConst<T> &c, T h, 
 }
 
 // One segment, one timestep (f90:8-186), with the segment-invariant constants supplied.
+// want_velocity = false: velc is left 0 -- for callers that hand nobody this step's velocity (it feeds nothing: the next step
+// starts from the flow and the depth, f90:8-186 takes velp and does not read it).
 template <class T, class M>
 MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelConst<T> &c, const Inflow<T> &f,
-                                    T depthp, const M &m)
+                                    T depthp, const M &m, bool want_velocity = true)
 {
     StepResult<T> out;
     if (!step_has_flow(f)) {
@@ -504,7 +506,7 @@ MC_HD StepResult<T> mc_segment_step(const ChannelParams<T> &p, const ChannelCons
     none.have = false;
     const StepSolve<T> s = step_solve<T, M>(p, c, f, depthp, none, m);
     out.qdc = s.qdc;
-    out.velc = step_velocity<T, M>(p, c, s.h, m);
+    out.velc = want_velocity ? step_velocity<T, M>(p, c, s.h, m) : T(0);
     out.depthc = s.h;
     out.h = s.h;
     out.X = s.X;

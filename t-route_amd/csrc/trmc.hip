@@ -222,6 +222,7 @@ struct trmc_plan {
         int32_t cluster_late_lag = 0;        // tiles the rows fed by boundary rows run behind at least (cluster order)
         int32_t stream_split = 0;            // a stream's slices from this level on ride on the clusters' stream (0: all on the tile stream)
         int32_t hot_wave_rows = 0;           // rows of the hot list per wavefront (0: by the plan's size)
+        bool velocity_on_demand = false;     // a stream without full_output forms a step's velocity only where it is handed on
         bool sequence = false;
         bool flow_overlap = false;
         int32_t flow_lean = 0;

@@ -48,7 +48,8 @@ def reference_days(net, days, q0, nsteps, qts, stride=None, full=False):
     return rows, hyds, states, fvds
 
 
-@pytest.mark.parametrize("variant", ["slices+clusters", "clusters-only", "stride", "low-latency", "k4-small-clusters"])
+@pytest.mark.parametrize("variant", ["slices+clusters", "clusters-only", "stride", "low-latency", "k4-small-clusters",
+                                     "velocity-on-demand", "velocity-on-demand+stride", "velocity-on-demand+full"])
 def test_a_stream_of_days_on_one_gpu_equals_the_days_routed_one_by_one(variant):
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
@@ -56,14 +57,18 @@ def test_a_stream_of_days_on_one_gpu_equals_the_days_routed_one_by_one(variant):
     q0 = np.random.default_rng(1).uniform(0, 1, (nseg, 3)).astype(np.float32)
     days = days_of(net, 4)
     seq_days = [days[w % 4] for w in range(ndays)]
-    stride = 12 if variant == "stride" else None
-    full = variant in ("slices+clusters", "k4-small-clusters")
+    stride = 12 if variant in ("stride", "velocity-on-demand+stride") else None
+    full = variant in ("slices+clusters", "k4-small-clusters", "velocity-on-demand+full")
     rows, want_h, want_s, want_f = reference_days(net, seq_days, q0, nsteps, qts, stride, full)
     opts = {"wide_min_rows": 64, "wide_k": 8}
     if variant == "clusters-only":
         opts = {"wide_min_rows": -1, "wide_k": 16}
     if variant == "k4-small-clusters":
         opts = {"wide_min_rows": 500, "wide_k": 4, "cluster_rows": 24}
+    if variant.startswith("velocity-on-demand"):
+        # (trmc_plan_options.velocity_on_demand: a step's velocity is formed where it is handed on only -- the kept steps of the
+        # stride, every step of a full result, nowhere for hydrographs and states; every product keeps its bits)
+        opts = dict(opts, velocity_on_demand=1)
     r = ShardedRouter(net["to"], net["params"], stream=True, options=opts)
     lag, W, C = r.plan0.lags()
     assert C > 0 and (W > 0) == (variant != "clusters-only") and lag.max() == W + C - 1

@@ -25,6 +25,7 @@ ap.add_argument("--stride", type=int, default=0)
 ap.add_argument("--full", action="store_true")
 ap.add_argument("--no-check", action="store_true")
 ap.add_argument("--slots", type=int, default=0)
+ap.add_argument("--velocity-on-demand", type=int, default=0)
 ap.add_argument("--later", type=int, default=0, help="hand a day over this many days later than its last row allows (and hold as many more slots)")
 a = ap.parse_args()
 _lib.single_hw_queue_per_priority("stream_probe")
@@ -44,7 +45,7 @@ for q in days:
 q0 = np.zeros((n, 3), np.float32)
 rng = np.random.default_rng(5)
 sample = np.sort(rng.choice(n, min(n, 3000), replace=False))
-opts = {"wide_min_rows": a.wide_min_rows, "wide_k": a.wide_k, "cluster_rows": 128, "wide_levels": a.wide_levels, "stream_split": a.split}
+opts = {"wide_min_rows": a.wide_min_rows, "wide_k": a.wide_k, "cluster_rows": 128, "wide_levels": a.wide_levels, "stream_split": a.split, "velocity_on_demand": a.velocity_on_demand}
 hint = None
 if a.hint:
     with RoutingPlan(up_ptr, up_idx, net["params"], assume_short_ts=True, engine="levels", options=opts) as p:
