@@ -17,7 +17,8 @@ import json
 d=json.loads(open('gpurun_out/r06z/bench.json').read().strip().splitlines()[-1])
 print({k:d[k] for k in ('value','ms_per_step')}, 'roof', d['roofline']['frac'], 'dom', d['roofline'].get('dominant_kernel',{}).get('frac'), 'two plans', (d.get('pipeline_two_plans') or {}).get('ms_per_step'),
       'tol', (d.get('value_tolerance') or {}).get('ms_per_step'), 'hourly', {k: (v.get('ms_per_step') if isinstance(v, dict) else v) for k, v in (d.get('hourly_output') or {}).items() if k in ('ms_per_step','in_sequence','in_stream')},
-      'parity', (d.get('parity_full') or {}).get('bit_identical'), 'untuned', d['untuned']['ms_per_step'], 'persist', d['forcing_persistence'], 'dropin', (d.get('dropin') or {}).get('steady_state_call_ms'))
+      'parity', (d.get('parity_full') or {}).get('bit_identical'), 'untuned', d['untuned']['ms_per_step'], 'persist', d['forcing_persistence'], 'dropin', (d.get('dropin') or {}).get('steady_state_call_ms'),
+      'full_ts', {k: d['full_ts'].get(k) for k in ('ms_per_step', 'days_as_one_window')}, 'velocity_on_demand', d.get('velocity_on_demand'), 'valu', d['roofline'].get('valu_instructions_per_window'))
 PY
 lean="--headline-only --no-traffic --no-parity-full"
 timeout 900 rocprofv3 --kernel-trace -d $out/trace -o trace -- python bench.py --steps 6 --warmup 1 $lean > $out/trace.log 2>&1
