@@ -239,17 +239,19 @@ def test_stream_lowercolorado_bit_identical_to_reference_golden():
     assert np.array_equal(bits(out[g["probes"]]), bits(g["shortts_f32_probes"][:, 1:, :]))
 
 
-def test_a_stream_on_two_ranks_equals_the_days_routed_one_by_one():
+@pytest.mark.parametrize("stride", [None, 8])
+def test_a_stream_on_two_ranks_equals_the_days_routed_one_by_one(stride):
     """Two ranks (threads) on one device over the shared-memory transport: every rank streams its sub-basins, the trunk rides in
     its owner's stream behind them, the cut-edge hydrographs are all-gathered once a day; rank 0 gets every day's outlet
-    hydrographs of the WHOLE network, every rank the final state of its rows."""
+    hydrographs of the WHOLE network, every rank the final state of its rows -- and, with an output stride, every n-th step of its
+    rows' (q, v, d) a day later (the ring then holds a slot more on every rank)."""
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
     nsteps, qts, ndays = 32, 16, 7
     q0 = np.random.default_rng(2).uniform(0, 1, (nseg, 3)).astype(np.float32)
     days = days_of(net, 3, seed=5)
     seq_days = [days[w % 3] for w in range(ndays)]
-    rows1, want_h, want_s, _ = reference_days(net, seq_days, q0, nsteps, qts)
+    rows1, want_h, want_s, want_f = reference_days(net, seq_days, q0, nsteps, qts, stride)
     world = 2
     _serial[0] += 1
     key = f"stream{os.getpid()}_{_serial[0]}"
@@ -261,9 +263,11 @@ def test_a_stream_on_two_ranks_equals_the_days_routed_one_by_one():
             r = ShardedRouter(net["to"], net["params"], rank=rank, world=world, device=0, stream=True, options={"wide_min_rows": 64, "wide_k": 8})
             r.enable_device_exchange(comm)
             got = {}
-            with RouteStream(r, nsteps, qts) as rs:
-                for day, hyd, fin in rs.route(seq_days, q0):
-                    got[day] = (None if hyd is None else np.array(hyd, copy=True), np.array(fin[0], copy=True))
+            with RouteStream(r, nsteps, qts, output_stride=stride) as rs:
+                for item in rs.route(seq_days, q0):
+                    day, hyd, fin = item[:3]
+                    got[day] = (None if hyd is None else np.array(hyd, copy=True), np.array(fin[0], copy=True),
+                                np.array(item[3][0], copy=True) if stride else None)
                 out_rows = np.array(rs.outlet_rows, copy=True)
                 srows = np.array(rs.rows, copy=True)
             routed = np.ones(srows.shape[0], bool)          # (not the boundary copies of the cut rows: flow only)
@@ -293,3 +297,7 @@ def test_a_stream_on_two_ranks_equals_the_days_routed_one_by_one():
             assert state.shape == (srows.shape[0], 3)
             assert np.array_equal(bits(state[routed][:, [0, 2]]), bits(want_s[w][srows[routed]][:, [0, 2]])), (rank, w)
             assert np.array_equal(bits(state[:, 0]), bits(want_s[w][srows][:, 0])), (rank, w)
+            if stride:
+                blk = got[w][2]
+                assert blk.shape == (srows.shape[0], nsteps // stride, 3)
+                assert np.array_equal(bits(blk[routed]), bits(want_f[w][srows[routed]])), (rank, w)

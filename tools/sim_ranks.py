@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--cycles", type=int, default=3, help="--stream: the D days are routed so many times over in one stream (a longer steady state)")
     ap.add_argument("--wide-k", type=int, default=0)
     ap.add_argument("--wide-min-rows", type=int, default=0)
+    ap.add_argument("--cluster-rows", type=int, default=0)
+    ap.add_argument("--wide-levels", type=int, default=0)
+    ap.add_argument("--velocity-on-demand", type=int, default=0)
     a = ap.parse_args()
     from troute_amd import comm as X
     from troute_amd import sharding, synthetic
@@ -316,7 +319,8 @@ def stream_mode(a, net, to, params, qlat, q0, part, hint, nsteps, qts, dev, X, s
         ref_hyd.append(single.outlet_hydrographs())
     ref_rows = single.my_out0_global
     single.close()
-    opts = {k: v for k, v in (("wide_k", a.wide_k), ("wide_min_rows", a.wide_min_rows)) if v}
+    opts = {k: v for k, v in (("wide_k", a.wide_k), ("wide_min_rows", a.wide_min_rows), ("cluster_rows", a.cluster_rows),
+                              ("wide_levels", a.wide_levels), ("velocity_on_demand", a.velocity_on_demand)) if v}
     ring = [pinned_like(d) for d in days]
 
     def timed(router, comm_days=None):
