@@ -662,6 +662,23 @@ def main():
             router.upload(a.nsteps, qlat_b, state_n)
         except Exception as e:
             untuned["in_sequence"] = {"error": repr(e)}
+        try:      # ... and the headline's protocol of round 6 -- ONE stream of tile launches over the days -- on a plan in cluster
+            # order built from the topology alone (no cost hint: neither the rows' order nor the clusters' packing knows a cost)
+            from troute_amd.sequence import RouteStream as _RS
+            ur = make_router(None, True, None, None, stream=True)
+            try:
+                with _RS(ur, a.nsteps, a.qts) as us:
+                    us.run(ring[:4], state_n, 2, 0, prepared=True)
+                    ssteps = max(2, min(a.steps, 12))
+                    s2 = us.run(ring, state_n, ssteps, 1, prepared=True)
+                untuned["in_stream"] = {"ms_per_step": s2["el"] / ssteps * 1e3, "steps": ssteps,
+                                        "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / (s2["el"] / ssteps) / 1e9 / HBM_PEAK_GBS,
+                                        "what": "the headline's stream of days on a plan built from the topology alone (no tuning window)"}
+                del s2
+            finally:
+                ur.close()
+        except Exception as e:
+            untuned["in_stream"] = {"error": repr(e)}
 
     # ---- 2. the plan rebuilt with day N's costs as its hint (same results: tests/test_gpu_parity.py), spun up again ----
     if not a.no_retune:
