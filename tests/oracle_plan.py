@@ -101,7 +101,8 @@ class OracleStreamPlan(OraclePlan):
         tpd = nsteps // self.tile_steps
         lmax = int(self._lag.max(initial=0))
         self._s = {"nsteps": nsteps, "qts": qts, "tpd": tpd, "lmax": lmax, "slots": max(slots, 2 + -(-(lmax + 1) // tpd)), "days": [],
-                   "g": -1, "state0": np.asarray(self.q0, np.float32), "clean": 0, "launches": 0}
+                   "g": -1, "state0": np.asarray(self.q0, np.float32), "clean": 0, "launches": 0,
+                   "stride": int(output_stride or 0), "full": bool(full_output)}
 
     def stream_info(self):
         s = self._s
@@ -112,7 +113,9 @@ class OracleStreamPlan(OraclePlan):
     def stream_push(self, qlat, boundary_q_ptr=None, rowset=None, hyd=None, q0=None, fvd=None):
         s = self._s
         assert s["g"] <= len(s["days"]) * s["tpd"] - 1 or self.stream_info()["days_complete"] == len(s["days"]), "advanced, not flushed"
-        s["days"].append({"qlat": np.array(qlat, np.float32), "bq": None, "rowset": rowset, "hyd": hyd, "q0": q0, "fvd": None})
+        assert fvd is None or s["stride"] or s["full"], "no (q, v, d) block in a stream begun without full_output / output_stride"
+        s["days"].append({"qlat": np.array(qlat, np.float32), "bq": None, "rowset": rowset, "hyd": hyd, "q0": q0, "fvd": None,
+                          "fvd_out": fvd})
         s["g"] = len(s["days"]) * s["tpd"] - 1
         s["launches"] += s["tpd"]
         return len(s["days"]) - 1
@@ -177,6 +180,9 @@ class OracleStreamPlan(OraclePlan):
             rec["hyd"][:rows.shape[0]] = rec["fvd"][rows, 1:, 0]
         if rec["q0"] is not None:
             rec["q0"][...] = rec["final"]
+        if rec["fvd_out"] is not None:                      # every stride-th step (or every step) of every row's (q, v, d)
+            n = s["stride"] or 1
+            rec["fvd_out"][...] = rec["fvd"][:, 1:, :][:, n - 1::n, :]
 
     def stream_day_ms(self, day):
         return 0.0

@@ -106,7 +106,7 @@ def test_world2_gloo_equals_single_process(tmp_path, short):
         assert np.array_equal(o["hyd"].view(np.uint32), hyd1.view(np.uint32))
 
 
-def _stream_worker(rank, world, port, tmp):
+def _stream_worker(rank, world, port, tmp, stride=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -147,21 +147,35 @@ def _stream_worker(rank, world, port, tmp):
     q0 = np.zeros((nseg, 3), np.float32)
     router = ShardedRouter(net["to"], net["params"], rank=rank, world=world, plan_factory=OracleStreamPlan, stream=True)
     got = {}
-    with RouteStream(router, 16, 8, comm=GlooComm()) as rs:
+    order, pushed = [], [0]
+
+    def feed():
+        for w in range(ndays):
+            pushed[0] = w + 1
+            yield days[w % 3]
+    with RouteStream(router, 16, 8, comm=GlooComm(), output_stride=stride) as rs:
         assert rs.exchange == "host"
-        for day, hyd, fin in rs.route((days[w % 3] for w in range(ndays)), q0):
-            got[day] = (None if hyd is None else np.array(hyd, copy=True), np.array(fin[0], copy=True))
+        for item in rs.route(feed(), q0):
+            day, hyd, fin = item[:3]
+            order.append((day, pushed[0]))
+            got[day] = (None if hyd is None else np.array(hyd, copy=True), np.array(fin[0], copy=True),
+                        np.array(item[3][0], copy=True) if stride else np.zeros((0, 0, 3), np.float32))
         rows_out, srows, dc = np.array(rs.outlet_rows, copy=True), np.array(rs.rows, copy=True), rs._dc
         lag = router._planS_lag
+        slots = rs.last_info["slots"]
     np.savez(os.path.join(tmp, f"stream_{rank}.npz"), rows=rows_out, srows=srows, ndays=len(got), dc=dc, lag=lag,
-             has_trunk=router.plan1 is not None, ncut=router.cut_rows.shape[0],
+             has_trunk=router.plan1 is not None, ncut=router.cut_rows.shape[0], slots=slots, order=np.array(order),
+             boundary=(np.concatenate([np.zeros(router.rows0.shape[0], bool), router.boundary1]) if router.plan1 is not None
+                       else np.zeros(srows.shape[0], bool)),
+             **{f"blk{w}": got[w][2] for w in got},
              **{f"hyd{w}": (got[w][0] if got[w][0] is not None else np.zeros((0, 16), np.float32)) for w in got},
              **{f"fin{w}": got[w][1] for w in got})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world2_gloo_stream_of_days_equals_single_process(tmp_path):
+@pytest.mark.parametrize("stride", [None, 8])
+def test_world2_gloo_stream_of_days_equals_single_process(tmp_path, stride):
     """troute_amd.sequence.RouteStream on two ranks (gloo, host exchange) with an oracle-backed stand-in for the plan: the
     protocol -- the trunk's lag agreed by an all-reduce over every rank's cut rows, the cut-edge hydrographs of day e exchanged
     when every rank's cut rows are through it, the drain after the last day -- against seven days routed one by one on one
@@ -176,7 +190,7 @@ def test_world2_gloo_stream_of_days_equals_single_process(tmp_path):
     ndays = 7
     single = ShardedRouter(net["to"], net["params"], plan_factory=OraclePlan)
     state = np.zeros((nseg, 3), np.float32)
-    want_h, want_s = [], []
+    want_h, want_s, want_f = [], [], []
     for w in range(ndays):
         single.upload(16, days[w % 3], state)
         rows1, hyd = single.route(8, True)
@@ -184,8 +198,9 @@ def test_world2_gloo_stream_of_days_equals_single_process(tmp_path):
         state = np.stack([f[:, -1, 0], f[:, -1, 0], f[:, -1, 2]], 1)
         want_h.append(hyd)
         want_s.append(state)
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_stream_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+        want_f.append(f)
+    port = 31500 + (os.getpid() % 2000) + (7 if stride else 0)
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path), stride), nprocs=2, join=True)
     outs = [np.load(tmp_path / f"stream_{r}.npz") for r in range(2)]
     assert int(outs[0]["ncut"]) > 0 and (bool(outs[0]["has_trunk"]) or bool(outs[1]["has_trunk"]))
     assert int(outs[0]["dc"]) == int(outs[1]["dc"]) >= 1 and int(outs[0]["lag"]) == int(outs[1]["lag"])
@@ -197,6 +212,52 @@ def test_world2_gloo_stream_of_days_equals_single_process(tmp_path):
             if r == 0:                                               # rank 0 holds every day's outlet hydrographs of the whole network
                 assert np.array_equal(o[f"hyd{w}"].view(np.uint32), want_h[w].view(np.uint32)), w
             assert np.array_equal(o[f"fin{w}"][:, 0].view(np.uint32), want_s[w][srows][:, 0].view(np.uint32)), (r, w)
+            if stride:       # every stride-th step of every ROUTED row of the rank (the boundary copies of cut rows carry flows only)
+                routed = ~o["boundary"]
+                assert np.array_equal(o[f"blk{w}"][routed].view(np.uint32), want_f[w][srows[routed]][:, stride - 1::stride, :].view(np.uint32)), (r, w)
+    # a stream that hands blocks over holds a slot more and delivers a day later, the same on every rank
+    assert int(outs[0]["slots"]) == int(outs[1]["slots"])
+    first = {int(o["order"][0][1]) for o in outs}
+    assert len(first) == 1
+
+
+def test_stream_with_blocks_delivers_a_day_later_and_holds_a_slot_more():
+    """RouteStream on one process (oracle-backed stand-in for the plan): with an output stride every row's kept steps are among
+    each day's products -- a block that takes most of a day to reach the host -- so such a stream hands a day over one day later
+    than a products-only one and its ring holds one slot more; the products are the same days' either way."""
+    from oracle_plan import OracleStreamPlan
+    from troute_amd.distributed import ShardedRouter
+    from troute_amd.sequence import RouteStream
+    net = small_conus()
+    nseg = net["to"].shape[0]
+    rng = np.random.default_rng(4)
+    days = [rng.uniform(0, 0.5, (nseg, 8)).astype(np.float32) for _ in range(9)]
+    q0 = np.zeros((nseg, 3), np.float32)
+    seen = {}
+    for stride in (None, 4):
+        router = ShardedRouter(net["to"], net["params"], plan_factory=OracleStreamPlan, stream=True)
+        pushed, order, got = [0], [], {}
+
+        def feed():
+            for d in days:
+                pushed[0] += 1
+                yield d
+        with RouteStream(router, 64, 8, output_stride=stride) as rs:
+            for item in rs.route(feed(), q0):
+                order.append((item[0], pushed[0]))
+                got[item[0]] = [np.array(x, copy=True) for x in item[1:]]
+            slots = rs.last_info["slots"]
+        router.close()
+        assert [d for d, _ in order] == list(range(len(days)))
+        seen[stride] = (slots, order[0][1], got)
+    assert seen[4][0] == seen[None][0] + 1                  # a slot more
+    assert seen[4][1] == seen[None][1] + 1                  # ... and the first day handed over one push later
+    for d in range(len(days)):
+        assert np.array_equal(seen[4][2][d][0].view(np.uint32), seen[None][2][d][0].view(np.uint32))      # hydrographs
+        assert np.array_equal(seen[4][2][d][1].view(np.uint32), seen[None][2][d][1].view(np.uint32))      # final states
+        blk = seen[4][2][d][2]
+        assert blk.shape == (nseg, 16, 3)
+        assert np.array_equal(blk[:, -1, [0, 2]].view(np.uint32), seen[None][2][d][1][:, [0, 2]].view(np.uint32))
 
 
 def _shm_worker(rank, world, key, tmp, short):
