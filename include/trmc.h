@@ -499,6 +499,10 @@ int trmc_download_fvd_strided(trmc_plan *plan, int stride, void *fvd_out);
  * per-network loop :1399-1738): with the set = the table's rows grouped by tailwater, each of those is a slice of fvd_out and
  * the host never permutes the block. */
 int trmc_download_fvd_rowset(trmc_plan *plan, int stride, int32_t rowset, void *fvd_out);
+/* on != 0: trmc_upload_forcing turns every NaN of qlat and q0 into 0 on the device, behind the copy.  The reference's reindexed
+ * tables hold NaN on waterbody rows (compute.py:1466-1467), which the Muskingum-Cunge rows never read; the drop-in used to screen
+ * the caller's frames for them on the host -- 20 ms of a CONUS call.  Default off: values go to the kernels as they are. */
+int trmc_plan_set_nan_is_zero(trmc_plan *plan, int on);
 /* Page-locked host memory for result arrays: a D2H copy into it runs at the speed of the link instead of through the
  * driver's staging buffers (the 9.4 GB flowveldepth array of a CONUS day: 0.2 s instead of 0.8 s).  The Python host side
  * keeps a small pool of these behind download_fvd(); a C caller may use them for any *_out argument.  Plain memory to the

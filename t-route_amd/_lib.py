@@ -141,6 +141,7 @@ SIGNATURES = {
     "trmc_download_fvd": (_int, [_vp, _vp]),
     "trmc_download_fvd_strided": (_int, [_vp, _int, _vp]),
     "trmc_download_fvd_rowset": (_int, [_vp, _int, C.c_int32, _vp]),
+    "trmc_plan_set_nan_is_zero": (_int, [_vp, _int]),
     "trmc_host_alloc": (_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "trmc_host_free": (_int, [_vp]),
     "trmc_download_final_state": (_int, [_vp, _vp]),

@@ -264,6 +264,7 @@ struct trmc_plan {
     struct StreamRun *seq = nullptr;     // trmc_stream_*: a stream of windows on a ring of day slots (stream.inc)
     DevBuf hot_list, hot_cnt;            // k_mc_tile's hot rows (StepArgs::hot_list): [3][hot_cap] positions, [3] lengths
     int32_t hot_cap = 0;
+    bool nan_is_zero = false;            // uploads of forcing and state: NaN -> 0 on the device (trmc_plan_set_nan_is_zero)
     int64_t tile_seq = 0;                // tile launches of the wide tier so far, all windows: which of the three lists is read
     DevBuf cls_last;                     // the cost class every wide row showed at the end of its last tile (k_mc_tile's in-block partition)
     std::vector<DevBuf> rowsets;        // positions of registered row sets (trmc_rowset_create)

@@ -469,6 +469,10 @@ class RoutingPlan:
             _lib.check(_lib.lib().trmc_download_fvd_strided(self._h, stride, _lib.ptr(out)))
         return out
 
+    def set_nan_is_zero(self, on=True):
+        """uploads of forcing and state: NaN -> 0 on the device (trmc_plan_set_nan_is_zero)"""
+        _lib.check(_lib.lib().trmc_plan_set_nan_is_zero(self._h, int(bool(on))))
+
     def download_final_state(self):
         out = _lib.result_empty((self.nseg, 3), self.dtype)
         _lib.check(_lib.lib().trmc_download_final_state(self._h, _lib.ptr(out)))

@@ -183,9 +183,8 @@ def compute_nhd_routing_v02(
             v = df.values
             if v.dtype != np.float32:
                 v = v.astype("float32")
-            # (a NaN anywhere makes the minimum NaN -- np.min propagates it: one vectorised pass without a temporary the size of
-            # the table)
-            return v if not (v.size and np.isnan(v.min())) else np.nan_to_num(v, nan=0.0)
+            # (NaN -- the rows a reindexed frame does not hold -- become 0 on the device behind the upload: nan_is_zero below)
+            return v
         return df.reindex(table_index).fillna(0.0).values.astype("float32")
     q0_v, qlat_v = rows_of(q0), rows_of(qlats)
 
@@ -227,7 +226,7 @@ def compute_nhd_routing_v02(
         e_f2, e_i1, e_i1, [], e_i1, e_i1, e_f1, e_i1, e_i1,
         e_i1, e_i1, e_f1, e_i1, e_f1, e_i1, e_i1, e_f2,
         upstream_results, assume_short_ts, return_courant, from_files=from_files, precision=precision, device=device,
-        output_stride=output_stride, result_order=net["order"] if grouped else None)
+        output_stride=output_stride, result_order=net["order"] if grouped else None, nan_is_zero=True)
     rids = r[0].astype("int64")                  # (the rows of upstream_results are masked out, mc_reach.pyx:451,:812)
     fvd, upstream = r[1], r[6]
     gage_ids, lastobs_times, lastobs_values = r[3]

@@ -371,6 +371,7 @@ def compute_network_structured(
     return_stats=False,
     output_stride=None,
     result_order=None,
+    nan_is_zero=False,
 ):
     """Route one (sub)network for ``nsteps`` timesteps on the GPU.
 
@@ -387,7 +388,10 @@ def compute_network_structured(
     permutation of ``range(len(data_idx))``: elements [0], [1] and [6] come back in that
     row order, permuted on the device -- compute_nhd_routing_v02 asks for its rows grouped
     by tailwater, so that every network's block is a slice; without off-network
-    ``upstream_results`` rows only).
+    ``upstream_results`` rows only), ``nan_is_zero`` (True: NaN in ``qlat_values`` and
+    ``initial_conditions`` -- the waterbody rows of the reference's reindexed tables,
+    compute.py:1466-1467, which no Muskingum-Cunge row reads -- become 0 on the device
+    behind the upload instead of in a pass over the arrays on the host).
     """
     stride = 1 if output_stride is None else int(output_stride)
     if stride < 1:
@@ -548,6 +552,7 @@ def compute_network_structured(
                       bool(assume_short_ts), tuple(res_rows), engine, token=plan_token) as plan:
         if res_rows:
             plan.set_reservoirs(res_rows, np.asarray(res_par, dtype=dtype), dt)
+        plan.set_nan_is_zero(bool(nan_is_zero))
         plan.upload_forcing(nsteps, qlat_values, q0, boundary_fvd)
         if nudging is not None:
             plan.set_nudging(nsteps, nudging[0], nudging[1], nudging[2], nudging[3])

@@ -287,3 +287,27 @@ def test_result_order_is_the_result_permuted(short):
         compute_network_structured(*args, result_order=np.zeros(lc.nseg, dtype=np.int64))
     with pytest.raises(ValueError, match="permutation"):
         compute_network_structured(*args, result_order=perm[:-1])
+
+
+def test_nan_is_zero_scrubs_the_upload_on_the_device():
+    """``nan_is_zero`` (keyword-only extension; trmc_plan_set_nan_is_zero): NaN in the forcing and the initial conditions -- what a
+    reindexed frame holds on rows the caller's table lacks (compute.py:1466-1467) -- counts as 0, replaced on the device behind the
+    upload: the same result as zeros put there on the host; without the option the values reach the kernels as they are."""
+    from troute_amd.routing.fast_reach.mc_reach import compute_network_structured, mc_only_args
+    lc = H.LowerColorado()
+    nts = 24
+    rng = np.random.default_rng(3)
+    hit = rng.choice(lc.nseg, 40, replace=False)
+    ql_nan, q0_nan = lc.qlat.copy(), lc.q0.copy()
+    ql_nan[hit[:25]] = np.nan
+    q0_nan[hit[20:]] = np.nan
+    ql_zero, q0_zero = np.nan_to_num(ql_nan, nan=0.0), np.nan_to_num(q0_nan, nan=0.0)
+    a_nan = mc_only_args(nts, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, q0_nan, ql_nan, None, True)
+    a_zero = mc_only_args(nts, lc.dt, lc.qts, lc.reaches, lc.rconn, lc.ids, lc.data_cols, lc.data_values, q0_zero, ql_zero, None, True)
+    want = compute_network_structured(*a_zero)[1]
+    got = compute_network_structured(*a_nan, nan_is_zero=True)[1]
+    assert np.isfinite(got).all() and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    raw = compute_network_structured(*a_nan)[1]            # (the plan is the same cached one: the policy is set per call)
+    assert np.isnan(raw).any()
+    again = compute_network_structured(*a_zero, nan_is_zero=True)[1]
+    assert np.array_equal(again.view(np.uint32), want.view(np.uint32))
