@@ -1003,8 +1003,23 @@ def main():
                                  "reciprocal-multiply division): not bit-comparable; stated tolerance and its test: include/trmc.h, "
                                  "tests/test_gpu_tolerance.py, profiles/r05_tolerance_report.json"}
             rt.close()
+            if use_stream:      # ... and as the headline's STREAM of days (with and without the velocities nobody is handed)
+                for key, opt in (("in_stream", {"arithmetic": "tolerance"}),
+                                 ("in_stream_velocity_on_demand", {"arithmetic": "tolerance", "velocity_on_demand": 1})):
+                    rt = make_router(hint, True, None, None, options=opt, stream=True)
+                    try:
+                        with RouteStream(rt, a.nsteps, a.qts) as ts:
+                            ts.run(ring[:4], state_n, 2, 0, prepared=True)
+                            tsteps = max(2, min(a.steps, 12))
+                            s4 = ts.run(ring, state_n, tsteps, 1, prepared=True)
+                        per = s4["el"] / tsteps
+                        tolerance[key] = {"ms_per_step": per * 1e3, "steps": tsteps, "value": nseg * a.nsteps / per,
+                                          "roofline_frac": nseg * a.nsteps * ALG_BYTES_PER_SEGSTEP / per / 1e9 / HBM_PEAK_GBS}
+                        del s4
+                    finally:
+                        rt.close()
         except Exception as e:
-            tolerance = {"error": repr(e)}
+            tolerance = {"error": repr(e)} if tolerance is None else dict(tolerance, stream_error=repr(e))
     extra["value_tolerance"] = tolerance
     # ---- the checker, LAST of the legs on this router (it runs OpenMP in this process and pins large host arrays: the copy
     # legs above are timed before it) ------------------------------------------------------------------------------------

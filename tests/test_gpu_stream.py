@@ -31,9 +31,9 @@ def days_of(net, n, seed=3):
     return [rng.uniform(0, 0.6, net["qlat"].shape).astype(np.float32) for _ in range(n)]
 
 
-def reference_days(net, days, q0, nsteps, qts, stride=None, full=False):
+def reference_days(net, days, q0, nsteps, qts, stride=None, full=False, options=None):
     """every day on ONE plain router (no cluster order), the state through the host"""
-    r = ShardedRouter(net["to"], net["params"], assume_short_ts=True)
+    r = ShardedRouter(net["to"], net["params"], assume_short_ts=True, options=options)
     hyds, states, fvds, state = [], [], [], q0
     for d in days:
         r.upload(nsteps, d, state)
@@ -49,7 +49,8 @@ def reference_days(net, days, q0, nsteps, qts, stride=None, full=False):
 
 
 @pytest.mark.parametrize("variant", ["slices+clusters", "clusters-only", "stride", "low-latency", "k4-small-clusters",
-                                     "velocity-on-demand", "velocity-on-demand+stride", "velocity-on-demand+full"])
+                                     "velocity-on-demand", "velocity-on-demand+stride", "velocity-on-demand+full",
+                                     "tolerance", "tolerance+velocity-on-demand+stride"])
 def test_a_stream_of_days_on_one_gpu_equals_the_days_routed_one_by_one(variant):
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
@@ -57,15 +58,20 @@ def test_a_stream_of_days_on_one_gpu_equals_the_days_routed_one_by_one(variant):
     q0 = np.random.default_rng(1).uniform(0, 1, (nseg, 3)).astype(np.float32)
     days = days_of(net, 4)
     seq_days = [days[w % 4] for w in range(ndays)]
-    stride = 12 if variant in ("stride", "velocity-on-demand+stride") else None
+    stride = 12 if variant in ("stride", "velocity-on-demand+stride", "tolerance+velocity-on-demand+stride") else None
     full = variant in ("slices+clusters", "k4-small-clusters", "velocity-on-demand+full")
-    rows, want_h, want_s, want_f = reference_days(net, seq_days, q0, nsteps, qts, stride, full)
+    # (TRMC_ARITH_TOLERANCE: another arithmetic, the same for every kernel of a plan -- the stream's tiles against the one-step
+    # launches of a plain plan in that arithmetic, bit for bit as well)
+    tol = {"arithmetic": "tolerance"} if variant.startswith("tolerance") else None
+    rows, want_h, want_s, want_f = reference_days(net, seq_days, q0, nsteps, qts, stride, full, options=tol)
     opts = {"wide_min_rows": 64, "wide_k": 8}
     if variant == "clusters-only":
         opts = {"wide_min_rows": -1, "wide_k": 16}
     if variant == "k4-small-clusters":
         opts = {"wide_min_rows": 500, "wide_k": 4, "cluster_rows": 24}
-    if variant.startswith("velocity-on-demand"):
+    if tol:
+        opts = dict(opts, **tol)
+    if "velocity-on-demand" in variant:
         # (trmc_plan_options.velocity_on_demand: a step's velocity is formed where it is handed on only -- the kept steps of the
         # stride, every step of a full result, nowhere for hydrographs and states; every product keeps its bits)
         opts = dict(opts, velocity_on_demand=1)
@@ -98,7 +104,7 @@ def test_a_stream_of_days_on_one_gpu_equals_the_days_routed_one_by_one(variant):
     rows2, hyd2 = None, None
     r.upload(nsteps, seq_days[0], None)
     rows2, hyd2 = r.route(qts, True)
-    ref = ShardedRouter(net["to"], net["params"], assume_short_ts=True)
+    ref = ShardedRouter(net["to"], net["params"], assume_short_ts=True, options=tol)
     ref.upload(nsteps, seq_days[0], want_s[-1])
     _, hyd3 = ref.route(qts, True)
     ref.close()
