@@ -50,7 +50,7 @@ def reference_days(net, days, q0, nsteps, qts, stride=None, full=False, options=
 
 @pytest.mark.parametrize("variant", ["slices+clusters", "clusters-only", "stride", "low-latency", "k4-small-clusters",
                                      "velocity-on-demand", "velocity-on-demand+stride", "velocity-on-demand+full",
-                                     "tolerance", "tolerance+velocity-on-demand+stride"])
+                                     "tolerance", "tolerance+velocity-on-demand", "tolerance+velocity-on-demand+stride"])
 def test_a_stream_of_days_on_one_gpu_equals_the_days_routed_one_by_one(variant):
     net = synthetic.generate(nseg=20000, nnet=60, seed=11, nq=3)
     nseg = net["to"].shape[0]
