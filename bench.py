@@ -15,36 +15,45 @@ troute_amd/synthetic.py) for one forcing window ("day") of 288 x 300 s timesteps
 reference's configured assume_short_ts=True (test/LowerColorado_TX/test_AnA.yaml:32),
 fp32 (the reference's arithmetic type).
 
-What is timed (one GPU): a SEQUENCE of consecutive days with DISTINCT forcing -- day N-1 spins the network up from a cold
-start, the plan is tuned on day N (both untimed), the clock covers days N+1, N+2, ... (a ring of up to ten distinct days,
-each derived from the one before like the reference's own forcing files one day apart).  Inside the clock, per day: the
-forcing travels from page-locked host memory to the device (trmc_stage_forcing, on the copy stream, two days ahead), the
-state is handed from day to day in HBM (trmc_plan_chain_from, between a plan and its clone: one copy of the topology and
-parameter columns, two sets of window buffers), the window is routed, and its products -- outlet hydrographs and final
-state, SURVEY 8d's throughput mode -- are copied to page-locked host arrays.  Topology and parameters are resident.
-The pipeline is the package's (troute_amd.sequence.DaySequence), and N > 1 is timed by the SAME protocol: every rank
-stages its rows of each day's forcing from page-locked memory, carries its state on in HBM, exchanges the cut-edge
-hydrographs chunk by chunk and fetches its final state (rank 0: the gathered outlet block too) beside the next day.
+What is timed: a SEQUENCE of consecutive days with DISTINCT forcing -- day N-1 spins the network up from a cold start, the
+plan is tuned on day N (both untimed), the clock covers days N+1, N+2, ... (a ring of up to ten distinct days, each derived
+from the one before like the reference's own forcing files one day apart) routed as ONE STREAM of tile launches
+(troute_amd.sequence.RouteStream, include/trmc.h trmc_stream_*: the tile index runs on over the days on a ring of day slots in
+HBM; every launch carries every row; a day is nsteps / 16 launches of k_mc_tile and as many of k_mc_ctile).  Inside the clock,
+per day: the forcing travels from page-locked host memory to the device on a stream of its own, the state stays in HBM, and the
+day's products -- outlet hydrographs and final state, SURVEY 8d's throughput mode -- are copied to page-locked host arrays beside
+the launches of the days that follow.  Topology and parameters are resident.  N > 1 is timed by the SAME protocol: every rank
+streams its sub-basins (the cut basin's trunk rides in its owner's stream some days behind), the cut-edge hydrographs are
+exchanged once per day, rank 0 gathers the outlet block.  TRMC_BENCH_PIPELINE=two-plans times round 5's pipeline
+(troute_amd.sequence.DaySequence: a plan and its clone taking turns) as the headline instead.
 
 Prints ONE JSON line: BASELINE.json's metric (segment-timesteps/s) plus
-  roofline          dominant kernel against the 8 TB/s HBM roofline, timed with HIP events on the plan's own stream
-                    inside this run
+  roofline          the day (all launches of one day of the stream) and, under dominant_kernel, k_mc_tile by itself against the
+                    8 TB/s HBM roofline: HIP events on the tile stream around every timed day's launches; traffic and valu: counter
+                    passes of this very command (rocprofv3 --pmc) over the last window
   cpu_baseline      the reference Fortran kernel (oracle/_ref, amdflang -O2) over every segment, decomposed like the
                     reference's by-subnetwork-jit method, C + OpenMP, bounded sample of the timesteps
-  untuned           the plan built from the topology alone, day N, cold start
-  value             the sequence above: INCLUDES every day's forcing host-to-device and the copy of what a throughput-mode caller
-                    consumes -- outlet hydrographs + final state -- to the host;  value_resident: day N+1 routed
-                    again and again on the one plan, forcing resident, everything left in HBM (earlier rounds' protocol)
-  value_tolerance   the same sequence on a plan created with TRMC_ARITH_TOLERANCE (hardware log2 / exp2 / reciprocal: NOT
-                    bit-comparable; its stated tolerance is tested in tests/test_gpu_tolerance.py) -- beside the headline, never it
-  forcing_persistence   the same pipeline with days whose rows keep their magnitude with probability 0.5 / 0.0
-  parity_full       EVERY segment against the reference Fortran on the CPU (the pipeline re-run over days N+1, N+2)
+  value             the stream above: INCLUDES every day's forcing host-to-device and the copy of what a throughput-mode caller
+                    consumes -- outlet hydrographs + final state -- to the host;  stream: the stream's shape (slots,
+                    lag, launches);  pipeline_two_plans: round 5's pipeline on the same days;  value_resident: day N+1 routed again
+                    and again on the one plan, forcing resident, everything left in HBM (earlier rounds' protocol)
+  untuned           the plan built from the topology alone: a window, round 5's pipeline (in_sequence), the stream (in_stream)
+  velocity_on_demand   NOT the headline: the stream on a plan made with trmc_plan_options.velocity_on_demand (a step's velocity
+                    formed only where it is handed on), products only and with hourly blocks, every product compared bit for bit
+  value_tolerance   the same days on a plan created with TRMC_ARITH_TOLERANCE (hardware log2 / exp2 / reciprocal: NOT
+                    bit-comparable; its stated tolerance is tested in tests/test_gpu_tolerance.py) -- beside the headline, never
+                    it: round 5's pipeline, the stream (in_stream), the stream with velocities on demand
+  forcing_persistence   the stream with days whose rows keep their magnitude with probability 0.5 / 0.0
+  parity_full       EVERY segment against the reference Fortran on the CPU (the stream re-run over days N+1, N+2, full result)
   parity_mode       the whole flowveldepth array copied to the host inside the timed region
-  hourly_output     every qts-th step of it (what the reference's writers keep), decimated on the device, copied inside the timed region;
-                    in_sequence: the same product fetched beside the next day in the pipeline
+  hourly_output     every qts-th step of it (what the reference's writers keep), decimated on the device, copied inside the timed
+                    region; in_sequence / in_stream: the same block as one more product of each day of either pipeline
+  dropin            compute_nhd_routing_v02 from dictionaries and DataFrames at the workload's size: first call, steady state
   tuned_window_warm / cold_start / independent_forcing_cold   the tuned plan on the very window it was tuned on, on a
                     cold start, on an unrelated day
-  full_ts           the same workload without the short-timestep assumption (dataflow engine)
+  full_ts           the same workload without the short-timestep assumption (dataflow engine); days_as_one_window: four days
+                    routed as one window of 4 x nsteps steps (the general mode's sequence form)
+  diffusive         the hybrid configuration's mainstem solver: one domain, a batch of 64, the reference Fortran beside them
   per_rank          (N > 1) every rank's device time
 """
 import argparse
